@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- mel-frames/s of the batched Tacotron forward (BASELINE.json metric) on N MI355X.
+
+A "step" = one pass of the hot path (taco_forward_infer, replayed from its hipGraph plan) over one
+synthetic batch: ids -> encoder CBHG -> attention decoder (max_iters steps) -> post-net CBHG ->
+linear spectrogram, inputs/outputs resident in HBM.  Workload at N=1 is BASELINE.json configs[1]
+(C2: B=32, T_in=128, T_mel=512).  N>1: one process per GPU, per-GPU batch fixed (weak scaling),
+no data-path collective; barrier + synchronize on both sides, MAX over ranks.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md 'Measurement' for every field)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+
+WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speakers, model_type)
+    "C1": (1, 64, 5, 200, 1, "single"),
+    "C2": (32, 128, 4, 128, 1, "single"),
+    "C3": (32, 128, 4, 128, 4, "deepvoice"),
+    "C5": (8, 512, 4, 1000, 1, "single"),
+}
+
+
+def algorithmic_bytes(spec, hp, B, T_in, n):
+    """SURVEY 8(d) streaming model (fp32): feed-forward weights once, decoder weights and attention
+    keys/values once per decoder step, activations in/out once."""
+    import numpy as np
+    cnt = lambda pred: sum(int(np.prod(s)) if len(s) else 1 for k, s in spec if pred(k))
+    W_dec = cnt(lambda k: k.startswith("decoder/") or k.startswith("attention/query") or k.startswith("attention/attention_"))
+    W_post = cnt(lambda k: k.startswith("post_cbhg/") or k.startswith("linear/"))
+    W_enc = cnt(lambda k: True) - W_dec - W_post
+    A, D = hp.attention_size, 2 * hp.enc_rnn_size
+    M, F, r = hp.num_mels, hp.num_freq, hp.reduction_factor
+    LD = hp.dec_layer_num * hp.dec_rnn_size
+    per_step = W_dec + B * T_in * (A + D) + B * (2 * (M + D + hp.attention_state_size + LD) + M * r + 3 * T_in)
+    total = W_enc + W_post + n * per_step + B * T_in * (1 + D + A) + B * n * r * (M + F)
+    return 4 * total, 4 * per_step
+
+
+def algorithmic_flops(hp, B, T_in, n):
+    """2*MAC of every contraction of the forward (180.3 GFLOP at C2)."""
+    r, M = hp.reduction_factor, hp.num_mels
+    def cbhg(rows, din, K, C, projs, pw, rnn, depth):
+        mac = sum(k * din * C for k in range(1, K + 1))
+        d = K * C
+        for p in projs:
+            mac += pw * d * p
+            d = p
+        if d != rnn:
+            mac += d * rnn
+        mac += depth * 2 * rnn * rnn + 2 * (2 * rnn) * 3 * rnn   # highway; BiGRU both directions
+        return rows * mac
+    enc_rows, post_rows = B * T_in, B * n * r
+    d = hp.embedding_size
+    pre = 0
+    for s in hp.enc_prenet_sizes:
+        pre += d * s
+        d = s
+    D, A, As, Hd = 2 * hp.enc_rnn_size, hp.attention_size, hp.attention_state_size, hp.dec_rnn_size
+    enc = enc_rows * (pre + D * A) + cbhg(enc_rows, d, hp.enc_bank_size, hp.enc_bank_channel_size, hp.enc_proj_sizes,
+                                            hp.enc_proj_width, hp.enc_rnn_size, hp.enc_highway_depth)
+    dd = M + D
+    dp = 0
+    for s in hp.dec_prenet_sizes:
+        dp += dd * s
+        dd = s
+    step = dp + (dd + As) * 3 * As + As * A + T_in * (A + D) + (As + D) * Hd + hp.dec_layer_num * (2 * Hd) * 3 * Hd + Hd * M * r
+    post = cbhg(post_rows, M, hp.post_bank_size, hp.post_bank_channel_size, hp.post_proj_sizes, hp.post_proj_width,
+                hp.post_rnn_size, hp.post_highway_depth) + post_rows * 2 * hp.post_rnn_size * hp.num_freq
+    return 2 * (enc + B * n * step + post)
+
+
+def cpu_baseline(name, seed):
+    """The oracle (float32, NumPy/OpenBLAS) timed on this host: a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import taco_oracle as O
+    B, T_in, r, n, ns, mt = WORKLOADS[name]
+    ohp = O.OracleHParams(max_iters=n, reduction_factor=r, model_type=mt)
+    w = O.init_weights(ohp, ns, seed)
+    ids, L = O.synthetic_inputs(B, T_in, seed)
+    spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    reps, t_total = 0, 0.0
+    while reps < 3 and t_total < 12.0:
+        t0 = time.perf_counter()
+        O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, dtype=np.float32, honor_stop=False)
+        t_total += time.perf_counter() - t0
+        reps += 1
+    frames = B * n * r * reps
+    return {"value": frames / t_total, "unit": "mel-frames/s", "cores": int(cores), "kind": "port",
+            "sample": "%d full %s forward(s) (B=%d,T_in=%d,T_mel=%d) of oracle/taco_oracle.py in float32, %.1f s"
+                      % (reps, name, B, T_in, n * r, t_total)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="enqueue kernels directly instead of replaying the hipGraph plan")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import taco_amd
+    from taco_amd import dist as D
+    from taco_amd.tacotron import _ptr, _stream
+
+    rank, local_rank, world = D.env_rank()
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist = D.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+        dist = None
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    B, T_in, r, n, ns, mt = WORKLOADS[args.workload]
+    hp = taco_amd.hparams.copy(max_iters=n, reduction_factor=r, model_type=mt)
+    model = taco_amd.create_model(hp)
+    seed = 1234 + sorted(WORKLOADS).index(args.workload)
+    model.load_weights(taco_amd.weights.random_weights(hp, ns, seed=seed))   # random-init weights of the architecture
+    model.initialize(None, None, ns, None, device=str(dev))
+    rs = np.random.RandomState(seed + 100 * rank)
+    ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)
+    ids[:, T_in - 1] = 1                                                       # fixed-length batches
+    lengths = taco_amd.input_lengths_from_tokens(ids)
+    plan = model.plan_for(B, T_in, n)
+    plan.inputs.copy_(torch.from_numpy(ids))
+    plan.lengths.copy_(torch.from_numpy(lengths))
+    if ns > 1:
+        plan.speaker_id.copy_(torch.from_numpy((np.arange(B) % ns).astype(np.int32)))
+
+    def step():
+        if args.eager:
+            spk = plan.speaker_id if ns > 1 else None
+            taco_amd._lib.check(model._lib.taco_forward_infer(
+                model._handle, _stream(), _ptr(plan.inputs), _ptr(plan.lengths), _ptr(spk), B, T_in, n, _ptr(None),
+                _ptr(plan.mel), _ptr(plan.linear), _ptr(plan.align), _ptr(plan.stop), _ptr(plan.ws), plan.ws_bytes))
+        else:
+            plan.launch()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                       # same stream the plan is launched on (torch's current stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    wall = D.max_over_ranks(wall, device=dev if dist is not None else "cpu")
+    dev_ms = D.max_over_ranks(dev_ms, device=dev if dist is not None else "cpu")
+    finite = bool(torch.isfinite(plan.mel).all().item() and torch.isfinite(plan.linear).all().item())
+
+    if rank == 0:
+        frames = world * B * n * r * args.steps
+        spec = taco_amd.weights.weight_spec(hp, ns)
+        abytes, per_step = algorithmic_bytes(spec, hp, B, T_in, n)
+        flops = algorithmic_flops(hp, B, T_in, n)
+        fwd_s = dev_ms / 1e3 / args.steps      # avg duration of one forward ("launch" of the plan), HIP events
+        out = {
+            "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
+                                   % (args.workload, B, T_in, n * r, r, mt),
+                       "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
+                       "launch": "eager" if args.eager else "hipGraph plan (%d nodes)" % plan.num_nodes},
+            "roofline": {"bound": "hbm", "achieved": abytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "whole forward (one hipGraph launch); algorithmic bytes %.3f GB per forward, "
+                                   "%.2f MB per decoder step" % (abytes / 1e9, per_step / 1e6),
+                         "forward_ms": fwd_s * 1e3,
+                         "mfma_f32": {"achieved": flops / fwd_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                      "frac": flops / fwd_s / 1e12 / MFMA_F32_PEAK_TF, "gflop_per_forward": flops / 1e9}},
+            "outputs_finite": finite,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, seed)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,153 @@
+/* taco_abi.h -- C ABI of libtaco_hip.so, the MI355X (gfx950) Tacotron hot path.
+ *
+ * The reference (GSByeon/multi-speaker-tacotron-tensorflow) has no FFI/plugin interface: its hot
+ * path is the TF1 graph built by Tacotron.initialize() (models/tacotron.py:21-271) and executed by
+ * sess.run from Synthesizer.synthesize (synthesizer.py:166-167) and train() (train.py:217-219).
+ * This header is the boundary a maintainer would bind instead of sess.run (see INTEGRATION.md for
+ * the ctypes stub).  Each entry point cites the reference lines it replaces.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; fp32 row-major [batch, time, channels];
+ * all `d_*` pointers are DEVICE pointers owned by the caller; the library owns only the weight
+ * pack inside taco_model.  Every call is asynchronous on `hip_stream` (a hipStream_t passed as
+ * void*), performs no allocation and no host<->device synchronisation, and is hipGraph-capturable.
+ * Return value 0 = OK; negative = error class below, text in taco_last_error().
+ */
+#ifndef TACO_ABI_H
+#define TACO_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TACO_ABI_VERSION 1
+
+#define TACO_OK 0
+#define TACO_ERR_ARG (-1)         /* null pointer, bad size, unknown name */
+#define TACO_ERR_SHAPE (-2)       /* weight/activation shape mismatch (tacotron.py:192-194) */
+#define TACO_ERR_UNSUPPORTED (-3) /* unknown model_type / attention_type (tacotron.py:88,152) */
+#define TACO_ERR_HIP (-4)         /* HIP runtime error */
+#define TACO_ERR_STATE (-5)       /* model not finalized / missing weights / workspace too small */
+
+typedef struct taco_model taco_model; /* opaque: hparams + device weight pack */
+typedef struct taco_plan taco_plan;   /* opaque: an instantiated hipGraph of one forward */
+
+/* Mirrors the model keys of hparams.py:33-69 and max_iters (hparams.py:141). */
+typedef struct {
+  int32_t num_symbols;             /* len(symbols), text/symbols.py:13 (80) */
+  int32_t num_mels, num_freq;      /* hparams.py:16-17 */
+  int32_t num_speakers;            /* train.py:301 / synthesizer.py:28 */
+  int32_t model_type;              /* 0 single, 1 simple, 2 deepvoice      tacotron.py:51-94 */
+  int32_t speaker_embedding_size;  /* hparams.py:35 */
+  int32_t embedding_size;          /* hparams.py:37 */
+  int32_t enc_prenet_n, enc_prenet[4];                                     /* hparams.py:40 */
+  int32_t enc_bank_size, enc_bank_channels, enc_maxpool, enc_highway_depth, enc_rnn_size;
+  int32_t enc_proj_n, enc_proj[4], enc_proj_width;                         /* hparams.py:41-47 */
+  int32_t attention_type;          /* 0 bah, 1 bah_norm, 2 bah_mon         tacotron.py:132-146 */
+  int32_t attention_size, attention_state_size;                            /* hparams.py:51-52 */
+  int32_t dec_layer_num, dec_rnn_size;                                     /* hparams.py:55-56 */
+  int32_t dec_prenet_n, dec_prenet[4];                                     /* hparams.py:59 */
+  int32_t post_bank_size, post_bank_channels, post_maxpool, post_highway_depth, post_rnn_size;
+  int32_t post_proj_n, post_proj[4], post_proj_width;                      /* hparams.py:60-66 */
+  int32_t reduction_factor;        /* hparams.py:68 */
+  int32_t max_iters;               /* hparams.py:141 */
+} taco_hparams;
+
+int taco_abi_version(void);
+const char* taco_last_error(void); /* thread-local; valid until the next call on this thread */
+
+/* ---- model life cycle: replaces create_model + tf.train.Saver.restore (models/__init__.py:6-7,
+ *      synthesizer.py:46-67).  Weight names are the canonical names listed in DESIGN.md
+ *      (one per TF variable of SURVEY App. B); tensors are HOST fp32 arrays in TF layout
+ *      (dense kernel [in,out]; conv1d kernel [k,in,out]; GRU gates [in+n,2n] r|u, candidate [in+n,n]). */
+int taco_model_create(const taco_hparams* hp, int device, taco_model** out);
+int taco_model_set_weight(taco_model* m, const char* name, const float* host, const int64_t* shape, int ndim);
+int taco_model_num_weights(const taco_model* m);                 /* how many tensors the hparams require */
+int taco_model_weight_name(const taco_model* m, int i, char* buf, int buflen, int64_t* shape4, int* ndim);
+int taco_model_finalize(taco_model* m); /* repack: MFMA fragment layouts, BN -> scale/shift, GRU [x;h] split */
+void taco_model_destroy(taco_model* m);
+
+/* ---- whole forward: replaces sess.run([linear_outputs, alignments]) at synthesizer.py:166-167
+ *      over the graph of models/tacotron.py:29-239 (inference, is_training False). */
+size_t taco_workspace_bytes(const taco_model* m, int B, int T_in, int n_steps);
+
+int taco_forward_infer(taco_model* m, void* hip_stream,
+                       const int32_t* d_inputs,          /* [B,T_in] ids, PAD=0 EOS=1   tacotron.py:38 */
+                       const int32_t* d_input_lengths,   /* [B]                          synthesizer.py:120 */
+                       const int32_t* d_speaker_id,      /* [B] or NULL (zeros)          synthesizer.py:43-44 */
+                       int B, int T_in, int n_steps,     /* n_steps = max_iters          tacotron.py:210 */
+                       const float* d_manual_alignments, /* NULL, or [B,n_steps,T_in]    rnn_wrappers.py:313-317 */
+                       float* d_mel,                     /* [B,n_steps*r,num_mels]       tacotron.py:213-214 */
+                       float* d_linear,                  /* [B,n_steps*r,num_freq]       tacotron.py:235 */
+                       float* d_alignments,              /* [B,T_in,n_steps]             tacotron.py:238-239 */
+                       int32_t* d_stop_step,             /* [1]: decoder steps the reference's stop rule
+                                                            (helpers.py:29 + dynamic_decode) would have run;
+                                                            == n_steps unless every row emitted an all-zero step */
+                       void* d_workspace, size_t workspace_bytes);
+
+/* The same forward captured once into a hipGraph (all pointers baked in) and replayed. */
+int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_input_lengths,
+                     const int32_t* d_speaker_id, int B, int T_in, int n_steps,
+                     const float* d_manual_alignments, float* d_mel, float* d_linear,
+                     float* d_alignments, int32_t* d_stop_step, void* d_workspace, size_t workspace_bytes,
+                     taco_plan** out);
+int taco_plan_launch(taco_plan* p, void* hip_stream);
+int taco_plan_num_nodes(const taco_plan* p);
+void taco_plan_destroy(taco_plan* p);
+
+/* ---- stage-level entry points (parity tests, profiling) ---- */
+/* embedding -> prenet -> encoder CBHG (tacotron.py:34-112).  d_encoder_out [B,T_in,2*enc_rnn_size]. */
+int taco_encoder_forward(taco_model* m, void* hip_stream, const int32_t* d_inputs,
+                         const int32_t* d_input_lengths, const int32_t* d_speaker_id, int B, int T_in,
+                         float* d_encoder_out, void* d_workspace, size_t workspace_bytes);
+/* attention memory + decoder loop (tacotron.py:120-214; rnn_wrappers.py:218-341,367-415; helpers.py).
+ * d_teacher_frames NULL, or [B,n_steps,num_mels]: frame fed at step t>=1 is teacher[:,t-1]
+ * (TacoTrainingHelper rule, helpers.py:44,66).  d_dbg_states NULL, or
+ * [n_steps,B,attention_state_size + 2*enc_rnn_size + dec_layer_num*dec_rnn_size]: (h_att, ctx, h_1..h_L) after each step. */
+int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder_out,
+                         const int32_t* d_speaker_id, int B, int T_in, int n_steps,
+                         const float* d_manual_alignments, const float* d_teacher_frames,
+                         float* d_mel, float* d_alignments, int32_t* d_stop_step, float* d_dbg_states,
+                         void* d_workspace, size_t workspace_bytes);
+/* post-net CBHG + linear head (tacotron.py:219-235).  d_mel [B,T_mel,num_mels] -> d_linear [B,T_mel,num_freq];
+ * d_post_out optional [B,T_mel,2*post_rnn_size]. */
+int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, int B, int T_mel,
+                         float* d_linear, float* d_post_out, void* d_workspace, size_t workspace_bytes);
+size_t taco_stage_workspace_bytes(const taco_model* m, int B, int T);
+
+/* ---- op-level entry points, addressed by layer name inside the model ---- */
+/* modules.py:123-131 conv1d -> act -> batch_norm (inference).  act: 0 none, 1 relu.
+ * maxpool_width > 1 applies max_pooling1d(width, stride 1, 'same') (modules.py:47-51) to x first. */
+int taco_conv1d_bn_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int B, int T,
+                       int act, int maxpool_width, float* d_out);
+/* tf.layers.dense on [rows, in] (A.1).  act: 0 none, 1 relu, 2 sigmoid, 3 tanh. */
+int taco_dense_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int rows, int act,
+                   float* d_out);
+/* modules.py:105-120 on [rows, D]. */
+int taco_highway_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int rows,
+                     float* d_out);
+/* modules.py:82-96 BiGRU; scope "encoder_cbhg" or "post_cbhg".  d_lengths / d_init_state ([B,2H]) nullable. */
+int taco_bigru_f32(taco_model* m, void* hip_stream, const char* scope, const float* d_x,
+                   const int32_t* d_lengths, const float* d_init_state, int B, int T, float* d_out,
+                   void* d_workspace, size_t workspace_bytes);
+/* one attention evaluation (rnn_wrappers.py:304-341 + TF-sem score/normaliser):
+ * query = d_cell_output . W_q; alignments from keys/prev; context = alignments . values. */
+int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell_output, const float* d_keys,
+                            const float* d_values, const float* d_prev_alignments, int B, int T_in,
+                            float* d_alignments, float* d_context, void* d_workspace, size_t workspace_bytes);
+
+/* one tf.contrib.rnn.GRUCell step (A.6) of a decoder GRU by name ("decoder/attention_gru",
+ * "decoder/gru_1", ...; tacotron.py:127-130,171-172).  d_h [R,H] is updated in place; d_out_res
+ * (nullable) = h' + x (ResidualWrapper).  Workspace: 3*R*H floats. */
+int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
+                      float* d_out_res, void* d_workspace, size_t workspace_bytes);
+
+/* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
+int taco_debug_force_gemm_config(taco_model* m, int cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TACO_ABI_H */

@@ -1,0 +1,1129 @@
+// taco_lib.hip -- host side of libtaco_hip.so: weight pack, stage orchestration, hipGraph plans and
+// the C ABI of include/taco_abi.h.  Replaces the TF1 graph built by Tacotron.initialize()
+// (models/tacotron.py:21-271 of the reference) and its sess.run execution (synthesizer.py:166-167).
+// No CPU compute path exists here: every stage is a gfx950 kernel from taco_kernels.h.
+#include "taco_kernels.h"
+#include "../../include/taco_abi.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(TACO_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define TRY(expr)            \
+  do {                       \
+    int rc_ = (expr);        \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int rup(int a, int b) { return cdiv(a, b) * b; }
+static inline size_t rup_sz(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// ------------------------------------------------------------------------------------------------
+// model
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+  bool set = false;
+};
+
+struct ConvL {  // a k_gemm layer (conv1d+BN, dense, highway, hoisted GRU input projection)
+  int kw = 1, cin = 0, cin_pad = 0, N = 0;
+  size_t wp = 0, wp2 = 0, bias = 0, bias2 = 0, bns = 0, bnb = 0;  // arena offsets (+1; 0 = absent)
+  int var_index = -1;                                              // index into the device GemmVar array
+};
+struct SkW {  // a k_skinny weight
+  int K = 0, Kq = 0, N = 0;
+  size_t wp = 0, bias = 0;
+};
+struct GruDec { SkW gates, cx, ch; int I = 0, H = 0; };
+struct Cbhg {
+  int in_dim = 0, K = 0, C = 0, maxpool = 1, depth = 0, rnn = 0, pw = 3;
+  int nproj = 0, proj_dim[4] = {0, 0, 0, 0};   // known from hparams alone (workspace sizing before finalize)
+  std::vector<ConvL> bank;  // ordered widest first (longest workgroups are dispatched first)
+  int bank_var0 = -1;
+  std::vector<ConvL> proj;
+  bool has_dense = false;
+  ConvL dense;
+  std::vector<ConvL> hw;
+  ConvL xproj;              // N = 2 directions x (2H gates | H candidate), biases folded in
+  SkW gh[2], ch[2];
+};
+
+struct taco_model {
+  taco_hparams hp;
+  int device = 0;
+  bool finalized = false;
+  std::vector<std::pair<std::string, std::vector<int64_t>>> spec;  // required tensors
+  std::map<std::string, HostTensor> raw;
+  // packed
+  std::vector<float> harena;
+  float* darena = nullptr;
+  std::vector<GemmVar> hvars;
+  GemmVar* dvars = nullptr;
+  std::map<std::string, ConvL> convs;
+  std::map<std::string, SkW> skinny;
+  std::map<std::string, GruDec> grus;
+  std::vector<ConvL> enc_prenet;
+  Cbhg enc, post;
+  ConvL memory_layer, linear;
+  std::vector<SkW> dec_prenet;
+  GruDec att_gru;
+  std::vector<GruDec> dec_gru;
+  SkW query, concat_proj, frame_proj;
+  size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0;
+  std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
+  std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
+  int force_cfg = -1;
+};
+
+static size_t arena_put(taco_model* m, const float* src, size_t n) {
+  size_t off = rup_sz(m->harena.size(), 16);
+  m->harena.resize(off + rup_sz(std::max<size_t>(n, 1), 16), 0.f);
+  if (src) memcpy(&m->harena[off], src, n * sizeof(float));
+  return off + 1;
+}
+static inline const float* AP(const taco_model* m, size_t off1) { return off1 ? m->darena + (off1 - 1) : nullptr; }
+
+// ---- required tensor list (tests/test_host.py checks it against the CPU checker) ----
+static void spec_add(taco_model* m, const std::string& n, std::vector<int64_t> s) { m->spec.push_back({n, s}); }
+static void spec_dense(taco_model* m, const std::string& n, int i, int o, bool bias = true) {
+  spec_add(m, n + "/kernel", {i, o});
+  if (bias) spec_add(m, n + "/bias", {o});
+}
+static void spec_conv(taco_model* m, const std::string& n, int k, int i, int o) {
+  spec_add(m, n + "/kernel", {k, i, o});
+  spec_add(m, n + "/bias", {o});
+  for (const char* p : {"gamma", "beta", "moving_mean", "moving_variance"}) spec_add(m, n + "/" + p, {o});
+}
+static void spec_gru(taco_model* m, const std::string& n, int i, int h) {
+  spec_add(m, n + "/gates/kernel", {i + h, 2 * h});
+  spec_add(m, n + "/gates/bias", {2 * h});
+  spec_add(m, n + "/candidate/kernel", {i + h, h});
+  spec_add(m, n + "/candidate/bias", {h});
+}
+static void spec_cbhg(taco_model* m, const std::string& sc, int in_dim, int K, int C, int depth, int rnn,
+                      const int* projs, int nproj, int pw) {
+  for (int k = 1; k <= K; ++k) spec_conv(m, sc + "/conv_bank/conv1d_" + std::to_string(k), k, in_dim, C);
+  int d = K * C;
+  for (int i = 0; i < nproj; ++i) {
+    spec_conv(m, sc + "/proj_" + std::to_string(i + 1), pw, d, projs[i]);
+    d = projs[i];
+  }
+  if (d != rnn) spec_dense(m, sc + "/dense", d, rnn);
+  for (int i = 0; i < depth; ++i) {
+    spec_dense(m, sc + "/highway_" + std::to_string(i + 1) + "/H", rnn, rnn);
+    spec_dense(m, sc + "/highway_" + std::to_string(i + 1) + "/T", rnn, rnn);
+  }
+  spec_gru(m, sc + "/bigru/fw", rnn, rnn);
+  spec_gru(m, sc + "/bigru/bw", rnn, rnn);
+}
+static const char* kSpkNames[3] = {"before_highway", "encoder_rnn_init", "attention_rnn_init"};
+
+static int build_spec(taco_model* m) {
+  const taco_hparams& hp = m->hp;
+  m->spec.clear();
+  spec_add(m, "embedding", {hp.num_symbols, hp.embedding_size});
+  const bool multi = hp.num_speakers > 1;
+  const int spk = hp.speaker_embedding_size;
+  if (multi) {
+    if (spk != 1) spec_add(m, "speaker_embedding", {hp.num_speakers, spk});
+    if (hp.model_type == 2) {
+      std::vector<std::pair<std::string, int>> dims = {{kSpkNames[0], hp.enc_prenet[hp.enc_prenet_n - 1]},
+                                                       {kSpkNames[1], hp.enc_rnn_size * 2},
+                                                       {kSpkNames[2], hp.attention_state_size}};
+      for (int i = 0; i < hp.dec_layer_num; ++i) dims.push_back({"decoder_rnn_init_" + std::to_string(i + 1), hp.dec_rnn_size});
+      for (auto& d : dims) {
+        if (spk == 1) spec_add(m, "spk/" + d.first + "/table", {hp.num_speakers, d.second});
+        else spec_dense(m, "spk/" + d.first, spk, d.second);
+      }
+    }
+  }
+  int d = hp.embedding_size;
+  for (int i = 0; i < hp.enc_prenet_n; ++i) {
+    spec_dense(m, "prenet/dense_" + std::to_string(i + 1), d, hp.enc_prenet[i]);
+    d = hp.enc_prenet[i];
+  }
+  spec_cbhg(m, "encoder_cbhg", d, hp.enc_bank_size, hp.enc_bank_channels, hp.enc_highway_depth, hp.enc_rnn_size,
+            hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width);
+  const int enc_out = 2 * hp.enc_rnn_size, A = hp.attention_size;
+  spec_dense(m, "attention/memory_layer", enc_out, A, false);
+  spec_dense(m, "attention/query_layer", hp.attention_state_size, A, false);
+  spec_add(m, "attention/attention_v", {A});
+  if (hp.attention_type == 2) spec_add(m, "attention/attention_score_bias", {});
+  if (hp.attention_type == 1) {
+    spec_add(m, "attention/attention_g", {});
+    spec_add(m, "attention/attention_b", {A});
+  }
+  d = hp.num_mels + enc_out;
+  for (int i = 0; i < hp.dec_prenet_n; ++i) {
+    spec_dense(m, "decoder/prenet/dense_" + std::to_string(i + 1), d, hp.dec_prenet[i]);
+    d = hp.dec_prenet[i];
+  }
+  spec_gru(m, "decoder/attention_gru", d, hp.attention_state_size);
+  spec_dense(m, "decoder/concat_projection", hp.attention_state_size + enc_out, hp.dec_rnn_size);
+  for (int i = 0; i < hp.dec_layer_num; ++i) spec_gru(m, "decoder/gru_" + std::to_string(i + 1), hp.dec_rnn_size, hp.dec_rnn_size);
+  spec_dense(m, "decoder/frame_projection", hp.dec_rnn_size, hp.num_mels * hp.reduction_factor);
+  spec_cbhg(m, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_highway_depth,
+            hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width);
+  spec_dense(m, "linear", 2 * hp.post_rnn_size, hp.num_freq);
+  return 0;
+}
+
+// ---- packing ----
+// W32 pack of a [kw, cin, N] kernel (dense: kw = 1): see taco_kernels.h.
+static size_t pack_w32(taco_model* m, const float* W, int kw, int cin, int N, int* cin_pad_out, int* Kq_out, int* NT_out) {
+  const int cin_pad = rup(cin, 8), Kq = kw * cin_pad / 4, NT = cdiv(N, 32);
+  std::vector<float> p((size_t)NT * Kq * 32 * 4, 0.f);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int kq = 0; kq < Kq; ++kq)
+      for (int j = 0; j < 32; ++j)
+        for (int e = 0; e < 4; ++e) {
+          const int k = 4 * kq + e, tap = k / cin_pad, c = k % cin_pad, n = 32 * nt + j;
+          if (c < cin && n < N) p[(((size_t)nt * Kq + kq) * 32 + j) * 4 + e] = W[((size_t)tap * cin + c) * N + n];
+        }
+  *cin_pad_out = cin_pad; *Kq_out = Kq; *NT_out = NT;
+  return arena_put(m, p.data(), p.size());
+}
+// W16 pack of rows [r0, r0+K) and columns [c0, c0+N) of a row-major [*, ldw] matrix.
+static SkW pack_w16(taco_model* m, const float* W, int ldw, int r0, int K, int c0, int N, const float* bias) {
+  SkW s;
+  s.K = K; s.N = N;
+  const int Kpad = rup(K, 16), NT = cdiv(N, 16);
+  s.Kq = Kpad / 4;
+  std::vector<float> p((size_t)NT * s.Kq * 16 * 4, 0.f);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int kq = 0; kq < s.Kq; ++kq)
+      for (int j = 0; j < 16; ++j)
+        for (int e = 0; e < 4; ++e) {
+          const int k = 4 * kq + e, n = 16 * nt + j;
+          if (k < K && n < N) p[(((size_t)nt * s.Kq + kq) * 16 + j) * 4 + e] = W[(size_t)(r0 + k) * ldw + c0 + n];
+        }
+  s.wp = arena_put(m, p.data(), p.size());
+  if (bias) s.bias = arena_put(m, bias + c0, N);
+  return s;
+}
+
+static const HostTensor& T_(taco_model* m, const std::string& n) { return m->raw[n]; }
+
+static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has_bias = true) {
+  const HostTensor& k = T_(m, name + "/kernel");
+  ConvL L;
+  if (k.shape.size() == 3) { L.kw = (int)k.shape[0]; L.cin = (int)k.shape[1]; L.N = (int)k.shape[2]; }
+  else { L.kw = 1; L.cin = (int)k.shape[0]; L.N = (int)k.shape[1]; }
+  int Kq, NT;
+  L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
+  if (has_bias) L.bias = arena_put(m, T_(m, name + "/bias").data.data(), L.N);
+  if (bn) {  // BatchNorm inference folded to y*scale + shift (A.2; epsilon 1e-3 = tf.layers default)
+    const auto& g = T_(m, name + "/gamma").data; const auto& b = T_(m, name + "/beta").data;
+    const auto& mu = T_(m, name + "/moving_mean").data; const auto& var = T_(m, name + "/moving_variance").data;
+    std::vector<float> sc(L.N), sh(L.N);
+    for (int i = 0; i < L.N; ++i) {
+      const double s = (double)g[i] / std::sqrt((double)var[i] + 1e-3);
+      sc[i] = (float)s; sh[i] = (float)((double)b[i] - (double)mu[i] * s);
+    }
+    L.bns = arena_put(m, sc.data(), L.N); L.bnb = arena_put(m, sh.data(), L.N);
+  }
+  return L;
+}
+
+static GruDec make_grudec(taco_model* m, const std::string& name, int I, int H) {
+  GruDec g; g.I = I; g.H = H;
+  const auto& gk = T_(m, name + "/gates/kernel").data; const auto& gb = T_(m, name + "/gates/bias").data;
+  const auto& ck = T_(m, name + "/candidate/kernel").data; const auto& cb = T_(m, name + "/candidate/bias").data;
+  g.gates = pack_w16(m, gk.data(), 2 * H, 0, I + H, 0, 2 * H, gb.data());
+  g.cx = pack_w16(m, ck.data(), H, 0, I, 0, H, nullptr);      // x rows of candidate/kernel
+  g.ch = pack_w16(m, ck.data(), H, I, H, 0, H, cb.data());    // h rows of candidate/kernel (+ candidate bias)
+  return g;
+}
+
+static void cbhg_dims(Cbhg& c, int in_dim, int K, int C, int maxpool, int depth, int rnn, const int* projs, int nproj, int pw) {
+  c.in_dim = in_dim; c.K = K; c.C = C; c.maxpool = maxpool; c.depth = depth; c.rnn = rnn; c.pw = pw;
+  c.nproj = nproj;
+  for (int i = 0; i < nproj; ++i) c.proj_dim[i] = projs[i];
+}
+
+static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim, int K, int C, int maxpool,
+                      int depth, int rnn, const int* projs, int nproj, int pw) {
+  cbhg_dims(c, in_dim, K, C, maxpool, depth, rnn, projs, nproj, pw);
+  for (int k = K; k >= 1; --k) {
+    const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
+    ConvL L = make_conv(m, n, true);
+    c.bank.push_back(L);
+    m->convs[n] = L;
+  }
+  for (int i = 0; i < nproj; ++i) {
+    const std::string n = sc + "/proj_" + std::to_string(i + 1);
+    c.proj.push_back(make_conv(m, n, true));
+    m->convs[n] = c.proj.back();
+  }
+  const int last = projs[nproj - 1];
+  c.has_dense = last != rnn;
+  if (c.has_dense) { c.dense = make_conv(m, sc + "/dense", false); m->convs[sc + "/dense"] = c.dense; }
+  for (int i = 0; i < depth; ++i) {
+    const std::string n = sc + "/highway_" + std::to_string(i + 1);
+    ConvL L = make_conv(m, n + "/H", false);
+    ConvL Tt = make_conv(m, n + "/T", false);
+    L.wp2 = Tt.wp; L.bias2 = Tt.bias;
+    c.hw.push_back(L);
+    m->convs[n] = L;
+  }
+  // BiGRU: hoisted input projection [rnn, 2*(2H+H)] = [fw gates(r|u) | fw cand | bw gates | bw cand]
+  const int H = rnn, I = rnn;
+  std::vector<float> Wx((size_t)I * 6 * H), bx(6 * H);
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+    const auto& gk = T_(m, n + "/gates/kernel").data; const auto& gb = T_(m, n + "/gates/bias").data;
+    const auto& ck = T_(m, n + "/candidate/kernel").data; const auto& cb = T_(m, n + "/candidate/bias").data;
+    for (int i = 0; i < I; ++i) {
+      for (int j = 0; j < 2 * H; ++j) Wx[(size_t)i * 6 * H + dir * 3 * H + j] = gk[(size_t)i * 2 * H + j];
+      for (int j = 0; j < H; ++j) Wx[(size_t)i * 6 * H + dir * 3 * H + 2 * H + j] = ck[(size_t)i * H + j];
+    }
+    for (int j = 0; j < 2 * H; ++j) bx[dir * 3 * H + j] = gb[j];
+    for (int j = 0; j < H; ++j) bx[dir * 3 * H + 2 * H + j] = cb[j];
+    c.gh[dir] = pack_w16(m, gk.data(), 2 * H, I, H, 0, 2 * H, nullptr);
+    c.ch[dir] = pack_w16(m, ck.data(), H, I, H, 0, H, nullptr);
+  }
+  ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
+  int Kq, NT;
+  X.wp = pack_w32(m, Wx.data(), 1, I, 6 * H, &X.cin_pad, &Kq, &NT);
+  X.bias = arena_put(m, bx.data(), 6 * H);
+  c.xproj = X;
+}
+
+static int add_var(taco_model* m, ConvL& L, int coff) {
+  GemmVar v;
+  memset(&v, 0, sizeof v);
+  // pointers are resolved after the arena upload (see finalize): store offsets for now
+  v.wp = (const float*)L.wp; v.wp2 = (const float*)L.wp2; v.bias = (const float*)L.bias; v.bias2 = (const float*)L.bias2;
+  v.bn_scale = (const float*)L.bns; v.bn_shift = (const float*)L.bnb;
+  v.kw = L.kw; v.padl = (L.kw - 1) / 2; v.Kq = L.kw * L.cin_pad / 4; v.NT = cdiv(L.N, 32); v.N = L.N; v.coff = coff;
+  L.var_index = (int)m->hvars.size();
+  m->hvars.push_back(v);
+  return L.var_index;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+struct GemmCall {
+  const float* x = nullptr; const int* gather = nullptr; int ldx = 0;
+  int M = 0, T = 0, mpw = 1, act = ACT_NONE;
+  const float* res = nullptr; int ldres = 0;
+  const float* rowvec = nullptr; int ldrv = 0;
+  float* out = nullptr; int ldo = 0;
+};
+
+template <int WM, int WN, int TM, int TN, int KS, bool DUAL>
+static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = 64 * WM * WN * KS;
+  size_t lds = (size_t)(BM + kw_max - 1) * TACO_LDSW * sizeof(float);
+  if (KS > 1) lds = std::max(lds, (size_t)(KS - 1) * WM * WN * TM * TN * 1024 * (DUAL ? 2 : 1) * sizeof(float));
+  dim3 grid(cdiv(a.M, BM), cdiv(Nmax, BN), nvar);
+  hipLaunchKernelGGL((k_gemm<WM, WN, TM, TN, KS, DUAL>), grid, dim3(NTHR), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// cfg: 0 = 128x64 tile (4 waves), 1 = 64x64 (4 waves), 2 = 32x64 split-K 4 (8 waves), 3 = 128x128 (4 waves)
+static int pick_cfg(const taco_model* m, int M, int N, int nvar) {
+  if (m->force_cfg >= 0) return m->force_cfg;
+  const long b0 = (long)cdiv(M, 128) * cdiv(N, 64) * nvar;
+  if (b0 >= 512) return 0;
+  const long b1 = (long)cdiv(M, 64) * cdiv(N, 64) * nvar;
+  if (b1 >= 256) return 1;
+  return 2;
+}
+
+static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, int nvar, bool dual, const GemmCall& c) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  const ConvL& L0 = layers[0];
+  a.x = c.x; a.gather = c.gather; a.vars = m->dvars + L0.var_index; a.res = c.res; a.rowvec = c.rowvec; a.out = c.out;
+  a.ldx = c.ldx; a.M = c.M; a.T = c.T > 0 ? c.T : c.M; a.Cin = L0.cin; a.cin_pad = L0.cin_pad; a.mpw = c.mpw;
+  a.act = c.act; a.ldres = c.ldres; a.ldrv = c.ldrv; a.ldo = c.ldo;
+  a.vec_ok = (c.ldx % 4 == 0) && (L0.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.x) & 15) == 0);
+  int kw_max = 1, Nmax = 0;
+  for (int i = 0; i < nvar; ++i) {
+    kw_max = std::max(kw_max, layers[i].kw); Nmax = std::max(Nmax, layers[i].N);
+    if (layers[i].var_index != L0.var_index + i) return fail(TACO_ERR_STATE, "bank variants not contiguous");
+  }
+  const int cfg = pick_cfg(m, c.M, Nmax, nvar);
+  if (dual) {
+    switch (cfg) {
+      case 0: case 3: return launch_gemm_cfg<2, 2, 2, 1, 1, true>(st, a, nvar, kw_max, Nmax);
+      case 1: return launch_gemm_cfg<2, 2, 1, 1, 1, true>(st, a, nvar, kw_max, Nmax);
+      default: return launch_gemm_cfg<1, 2, 1, 1, 4, true>(st, a, nvar, kw_max, Nmax);
+    }
+  }
+  switch (cfg) {
+    case 0: return launch_gemm_cfg<2, 2, 2, 1, 1, false>(st, a, nvar, kw_max, Nmax);
+    case 1: return launch_gemm_cfg<2, 2, 1, 1, 1, false>(st, a, nvar, kw_max, Nmax);
+    case 3: return launch_gemm_cfg<2, 2, 2, 2, 1, false>(st, a, nvar, kw_max, Nmax);
+    default: return launch_gemm_cfg<1, 2, 1, 1, 4, false>(st, a, nvar, kw_max, Nmax);
+  }
+}
+
+// ---- skinny jobs ----
+static SkJob sk_base(const taco_model* m, const SkW& w, const float* x0, int ldx0, int K0, const float* x1, int ldx1) {
+  SkJob j;
+  memset(&j, 0, sizeof j);
+  j.x0 = x0; j.ldx0 = ldx0; j.K0 = K0; j.x1 = x1; j.ldx1 = ldx1;
+  j.K = w.K; j.Kq = w.Kq; j.N = w.N; j.wp = AP(m, w.wp); j.bias = AP(m, w.bias);
+  return j;
+}
+static SkJob sk_linear(const taco_model* m, const SkW& w, const float* x0, int ldx0, int K0, const float* x1, int ldx1,
+                       int act, float* out, int ldo) {
+  SkJob j = sk_base(m, w, x0, ldx0, K0, x1, ldx1);
+  j.epi = EPI_LINEAR; j.act = act; j.o0 = out; j.ldo0 = ldo;
+  return j;
+}
+static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs) {
+  if (R > 64) return fail(TACO_ERR_UNSUPPORTED, "batch %d > 64 rows per device is not supported: shard the batch", R);
+  SkArgs a;
+  memset(&a, 0, sizeof a);
+  a.R = R; a.njobs = njobs;
+  int tiles = 0;
+  for (int i = 0; i < njobs; ++i) { jobs[i].tile0 = tiles; tiles += cdiv(jobs[i].N, 16); a.j[i] = jobs[i]; }
+  const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
+  if (RT == 1) hipLaunchKernelGGL(k_skinny<1>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else if (RT == 2) hipLaunchKernelGGL(k_skinny<2>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else hipLaunchKernelGGL(k_skinny<4>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// One GRUCell step for a decoder GRU (A.6), two launches: gates (+ x-part of candidate) then candidate.
+//   x [R, I] (ldx), h [R, H] updated in place; out_res (optional) = h' + x (ResidualWrapper, tacotron.py:172)
+static int run_gru_cell(const taco_model* m, hipStream_t st, const GruDec& g, int R, const float* x, int ldx,
+                        float* h, float* rh, float* u, float* xc, float* out_res) {
+  SkJob ja[2];
+  ja[0] = sk_base(m, g.gates, x, ldx, g.I, h, g.H);
+  ja[0].epi = EPI_GRU_GATES; ja[0].H = g.H; ja[0].e0 = h; ja[0].lde0 = g.H; ja[0].o0 = rh; ja[0].ldo0 = g.H; ja[0].o1 = u; ja[0].ldo1 = g.H;
+  ja[1] = sk_linear(m, g.cx, x, ldx, g.I, nullptr, 0, ACT_NONE, xc, g.H);
+  TRY(run_skinny(st, R, ja, 2));
+  SkJob jb = sk_base(m, g.ch, rh, g.H, g.H, nullptr, 0);
+  jb.epi = EPI_GRU_CAND; jb.H = g.H; jb.e0 = h; jb.lde0 = g.H; jb.e1 = xc; jb.lde1 = g.H; jb.e2 = u; jb.lde2 = g.H;
+  jb.o0 = h; jb.ldo0 = g.H;
+  if (out_res) { jb.e3 = x; jb.lde3 = ldx; jb.o1 = out_res; jb.ldo1 = g.H; }
+  TRY(run_skinny(st, R, &jb, 1));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace carving
+// ------------------------------------------------------------------------------------------------
+struct Carver {
+  char* base; size_t off = 0, cap;
+  Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+  float* f(size_t n) { return (float*)raw(n * sizeof(float)); }
+  int* i(size_t n) { return (int*)raw(n * sizeof(int)); }
+  void* raw(size_t bytes) {
+    void* p = base ? base + off : nullptr;
+    off += rup_sz(bytes, 256);
+    return p;
+  }
+  bool ok() const { return !base || off <= cap; }
+};
+
+struct CbhgWs { float *bank, *p[4], *hi0, *hi1, *xproj, *h, *rh, *u; };
+static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
+  const size_t M = (size_t)B * T;
+  w.bank = cv.f(M * c.K * c.C);
+  for (int i = 0; i < c.nproj; ++i) w.p[i] = cv.f(M * c.proj_dim[i]);
+  w.hi0 = cv.f(M * c.rnn); w.hi1 = cv.f(M * c.rnn);
+  w.xproj = cv.f(M * 6 * c.rnn);
+  w.h = cv.f((size_t)2 * B * c.rnn); w.rh = cv.f((size_t)2 * B * c.rnn); w.u = cv.f((size_t)2 * B * c.rnn);
+}
+
+// BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
+// directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
+// directions side by side in each launch.  x [B*T, rnn], out [B*T, 2*rnn].
+static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
+                      const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
+  const int H = c.rnn, M = B * T;
+  { GemmCall xp; xp.x = x; xp.ldx = c.rnn; xp.M = M; xp.out = w.xproj; xp.ldo = 6 * H;
+    TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
+  for (int dir = 0; dir < 2; ++dir)
+    hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * H, 256)), dim3(256), 0, st, init_state ? init_state + dir * H : nullptr,
+                       2 * H, w.h + (size_t)dir * B * H, H, B, H);
+  HIPCHK(hipGetLastError());
+  for (int s = 0; s < T; ++s) {
+    SkJob ja[2], jb[2];
+    for (int dir = 0; dir < 2; ++dir) {
+      float* h = w.h + (size_t)dir * B * H; float* rh = w.rh + (size_t)dir * B * H; float* u = w.u + (size_t)dir * B * H;
+      ja[dir] = sk_base(m, c.gh[dir], h, H, H, nullptr, 0);
+      ja[dir].epi = EPI_GRU_GATES; ja[dir].H = H; ja[dir].e0 = h; ja[dir].lde0 = H;
+      ja[dir].e1 = w.xproj + dir * 3 * H; ja[dir].lde1 = 6 * H;
+      ja[dir].o0 = rh; ja[dir].ldo0 = H; ja[dir].o1 = u; ja[dir].ldo1 = H;
+      ja[dir].lengths = lengths; ja[dir].step = s; ja[dir].T = T; ja[dir].dir = dir;
+      jb[dir] = sk_base(m, c.ch[dir], rh, H, H, nullptr, 0);
+      jb[dir].epi = EPI_GRU_CAND; jb[dir].H = H; jb[dir].e0 = h; jb[dir].lde0 = H;
+      jb[dir].e1 = w.xproj + dir * 3 * H + 2 * H; jb[dir].lde1 = 6 * H; jb[dir].e2 = u; jb[dir].lde2 = H;
+      jb[dir].o0 = h; jb[dir].ldo0 = H; jb[dir].o2 = out; jb[dir].ldo2 = 2 * H; jb[dir].seq_coff = dir * H;
+      jb[dir].lengths = lengths; jb[dir].step = s; jb[dir].T = T; jb[dir].dir = dir;
+    }
+    TRY(run_skinny(st, B, ja, 2));
+    TRY(run_skinny(st, B, jb, 2));
+  }
+  return 0;
+}
+
+// modules.py:27-96.  x [B*T, in_dim] (or embedding rows via gather==null only), out [B*T, 2*rnn].
+static int cbhg_forward(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
+                        const int* lengths, const float* before_highway, const float* init_state, float* out,
+                        const CbhgWs& w) {
+  const int M = B * T;
+  GemmCall g;
+  // conv bank: all K widths in one launch, written channel-concatenated (modules.py:35-44)
+  g.x = x; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank; g.ldo = c.K * c.C;
+  TRY(run_gemm(m, st, c.bank.data(), c.K, false, g));
+  // maxpool (fused into the staging of proj_1) + projections (modules.py:47-59)
+  const float* cur = w.bank; int curd = c.K * c.C;
+  for (size_t i = 0; i < c.proj.size(); ++i) {
+    GemmCall p;
+    p.x = cur; p.ldx = curd; p.M = M; p.T = T; p.mpw = (i == 0) ? c.maxpool : 1;
+    p.act = (i + 1 == c.proj.size()) ? ACT_NONE : ACT_RELU;
+    p.out = w.p[i]; p.ldo = c.proj[i].N;
+    if (i + 1 == c.proj.size()) {  // residual (modules.py:62-69)
+      p.res = x; p.ldres = c.in_dim;
+      p.rowvec = before_highway; p.ldrv = c.in_dim;
+    }
+    TRY(run_gemm(m, st, &c.proj[i], 1, false, p));
+    cur = w.p[i]; curd = c.proj[i].N;
+  }
+  if (c.has_dense) {  // modules.py:72-73
+    GemmCall d; d.x = cur; d.ldx = curd; d.M = M; d.out = w.hi0; d.ldo = c.rnn;
+    TRY(run_gemm(m, st, &c.dense, 1, false, d));
+    cur = w.hi0;
+  }
+  float* bufs[2] = {w.hi0, w.hi1};
+  int sel = (cur == w.hi0) ? 1 : 0;
+  for (int i = 0; i < c.depth; ++i) {  // modules.py:76-77
+    GemmCall h; h.x = cur; h.ldx = c.rnn; h.M = M; h.out = bufs[sel]; h.ldo = c.rnn;
+    TRY(run_gemm(m, st, &c.hw[i], 1, true, h));
+    cur = h.out; sel ^= 1;
+  }
+  return bigru_scan(m, st, c, cur, B, T, lengths, init_state, out, w);
+}
+
+// ---- speaker conditioning (tacotron.py:41-94) ----
+struct SpkWs { float *emb, *vec[8]; };
+static void carve_spk(Carver& cv, const taco_model* m, int B, SpkWs& w) {
+  const taco_hparams& hp = m->hp;
+  w.emb = cv.f((size_t)B * std::max(hp.speaker_embedding_size, 1));
+  const int dims[3] = {hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_rnn_size * 2, hp.attention_state_size};
+  for (int i = 0; i < 3 + hp.dec_layer_num; ++i) w.vec[i] = cv.f((size_t)B * (i < 3 ? dims[i] : hp.dec_rnn_size));
+}
+static bool is_deepvoice(const taco_model* m) { return m->hp.num_speakers > 1 && m->hp.model_type == 2; }
+// computes vec[0..2+L) = before_highway, encoder_rnn_init, attention_rnn_init, decoder_rnn_init_i
+static int spk_forward(const taco_model* m, hipStream_t st, const int* speaker_id, int B, const SpkWs& w) {
+  const taco_hparams& hp = m->hp;
+  const int nv = 3 + hp.dec_layer_num;
+  const int dims[3] = {hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_rnn_size * 2, hp.attention_state_size};
+  if (hp.speaker_embedding_size == 1) {
+    for (int i = 0; i < nv; ++i) {
+      const int D = i < 3 ? dims[i] : hp.dec_rnn_size;
+      hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(B * D, 256)), dim3(256), 0, st, AP(m, m->spk_table[i]), speaker_id, B, D, w.vec[i]);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  const int S = hp.speaker_embedding_size;
+  hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(B * S, 256)), dim3(256), 0, st, AP(m, m->spk_emb), speaker_id, B, S, w.emb);
+  HIPCHK(hipGetLastError());
+  for (int i0 = 0; i0 < nv; i0 += SK_MAXJOBS) {
+    SkJob js[SK_MAXJOBS];
+    const int nj = std::min(SK_MAXJOBS, nv - i0);
+    for (int i = 0; i < nj; ++i) {
+      const int D = (i0 + i) < 3 ? dims[i0 + i] : hp.dec_rnn_size;
+      js[i] = sk_linear(m, m->spk_dense[i0 + i], w.emb, S, S, nullptr, 0, ACT_SOFTSIGN, w.vec[i0 + i], D);
+    }
+    TRY(run_skinny(st, B, js, nj));
+  }
+  return 0;
+}
+
+// ---- encoder (tacotron.py:34-112) ----
+struct EncWs { float* pre[4]; CbhgWs cb; SpkWs spk; };
+static void carve_enc(Carver& cv, const taco_model* m, int B, int T, EncWs& w) {
+  for (int i = 0; i < m->hp.enc_prenet_n; ++i) w.pre[i] = cv.f((size_t)B * T * m->hp.enc_prenet[i]);
+  carve_cbhg(cv, m->enc, B, T, w.cb);
+  carve_spk(cv, m, B, w.spk);
+}
+static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, const int* lengths, const int* speaker_id,
+                           int B, int T, float* enc_out, const EncWs& w, bool spk_done) {
+  const taco_hparams& hp = m->hp;
+  const int M = B * T;
+  if (is_deepvoice(m) && !spk_done) TRY(spk_forward(m, st, speaker_id, B, w.spk));
+  const float* cur = AP(m, m->emb); int curd = hp.embedding_size;
+  for (int i = 0; i < hp.enc_prenet_n; ++i) {  // embedding_lookup fused as a row gather (tacotron.py:38-39)
+    GemmCall g; g.x = cur; g.ldx = curd; g.gather = (i == 0) ? ids : nullptr; g.M = M; g.act = ACT_RELU;
+    g.out = w.pre[i]; g.ldo = hp.enc_prenet[i];
+    TRY(run_gemm(m, st, &m->enc_prenet[i], 1, false, g));
+    cur = w.pre[i]; curd = hp.enc_prenet[i];
+  }
+  return cbhg_forward(m, st, m->enc, cur, B, T, lengths, is_deepvoice(m) ? w.spk.vec[0] : nullptr,
+                      is_deepvoice(m) ? w.spk.vec[1] : nullptr, enc_out, w.cb);
+}
+
+// ---- decoder (tacotron.py:120-214) ----
+struct DecWs {
+  float *keys, *zero, *ctx, *pz[4], *h_att, *rh, *u, *xc, *q, *align, *o[5], *hd[4], *Y;
+  int* nz;
+  SpkWs spk;
+};
+static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, DecWs& w) {
+  const taco_hparams& hp = m->hp;
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size;
+  const int Hmax = std::max(As, Hd);
+  w.keys = cv.f((size_t)B * T_in * hp.attention_size);
+  w.zero = cv.f((size_t)B * hp.num_mels);
+  w.ctx = cv.f((size_t)B * D);
+  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f((size_t)B * hp.dec_prenet[i]);
+  w.h_att = cv.f((size_t)B * As); w.rh = cv.f((size_t)B * Hmax); w.u = cv.f((size_t)B * Hmax); w.xc = cv.f((size_t)B * Hmax);
+  w.q = cv.f((size_t)B * hp.attention_size);
+  w.align = cv.f((size_t)B * T_in);
+  for (int i = 0; i <= hp.dec_layer_num; ++i) w.o[i] = cv.f((size_t)B * Hd);
+  for (int i = 0; i < hp.dec_layer_num; ++i) w.hd[i] = cv.f((size_t)B * Hd);
+  w.Y = nullptr;
+  w.nz = cv.i((size_t)n * B);
+  carve_spk(cv, m, B, w.spk);
+}
+static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B,
+                           int T_in, int n, const float* manual, const float* teacher, float* mel, float* align_out,
+                           int* stop_step, float* dbg, const DecWs& w, bool spk_ready, const SpkWs* spk_in) {
+  const taco_hparams& hp = m->hp;
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
+  const int Mm = hp.num_mels, rM = hp.num_mels * hp.reduction_factor, L = hp.dec_layer_num;
+  if (T_in > ATT_MAXT) return fail(TACO_ERR_UNSUPPORTED, "T_in %d > %d", T_in, ATT_MAXT);
+  if ((A % 4) || (D % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention_size and 2*enc_rnn_size must be multiples of 4");
+  const SpkWs* spk = spk_in ? spk_in : &w.spk;
+  if (is_deepvoice(m) && !spk_ready) TRY(spk_forward(m, st, speaker_id, B, *spk));
+  // attention memory: keys = values . W_mem, no bias, no length mask (A.8)
+  { GemmCall g; g.x = enc_out; g.ldx = D; g.M = B * T_in; g.out = w.keys; g.ldo = A;
+    TRY(run_gemm(m, st, &m->memory_layer, 1, false, g)); }
+  // initial state (rnn_wrappers.py:186-216; tacotron.py:183-197)
+  auto fill = [&](const float* src, int lds, float* dst, int C) {
+    hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * C, 256)), dim3(256), 0, st, src, lds, dst, C, B, C);
+  };
+  const bool dv = is_deepvoice(m);
+  fill(nullptr, 0, w.zero, Mm);
+  fill(nullptr, 0, w.ctx, D);
+  fill(dv ? spk->vec[2] : nullptr, As, w.h_att, As);
+  for (int i = 0; i < L; ++i) fill(dv ? spk->vec[3 + i] : nullptr, Hd, w.hd[i], Hd);
+  hipLaunchKernelGGL(k_init_align, dim3(cdiv(B * T_in, 256)), dim3(256), 0, st, w.align, B, T_in, hp.attention_type == 2 ? 1 : 0);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
+  const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
+  const int dbgw = As + D + L * Hd;
+  for (int t = 0; t < n; ++t) {
+    // frame fed to the prenet: zeros at t=0 (helpers.py:70-72), else last of the r frames (helpers.py:31)
+    const float* frame; int ldf;
+    if (t == 0) { frame = w.zero; ldf = Mm; }
+    else if (teacher) { frame = teacher + (size_t)(t - 1) * Mm; ldf = n * Mm; }
+    else { frame = mel + (size_t)(t - 1) * rM + (rM - Mm); ldf = ldY; }
+    // DecoderPrenetWrapper (rnn_wrappers.py:249,367-378): prenet(concat(frame, previous context))
+    const float* cur = nullptr; int curd = 0;
+    for (int i = 0; i < hp.dec_prenet_n; ++i) {
+      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, w.ctx, D, ACT_RELU, w.pz[0], hp.dec_prenet[0])
+                         : sk_linear(m, m->dec_prenet[i], cur, curd, curd, nullptr, 0, ACT_RELU, w.pz[i], hp.dec_prenet[i]);
+      TRY(run_skinny(st, B, &j, 1));
+      cur = w.pz[i]; curd = hp.dec_prenet[i];
+    }
+    // attention GRUCell (tacotron.py:127-130)
+    TRY(run_gru_cell(m, st, m->att_gru, B, cur, curd, w.h_att, w.rh, w.u, w.xc, nullptr));
+    // query + score + normaliser + context (rnn_wrappers.py:304-341)
+    { SkJob j = sk_linear(m, m->query, w.h_att, As, As, nullptr, 0, ACT_NONE, w.q, A);
+      TRY(run_skinny(st, B, &j, 1)); }
+    { AttnArgs a; memset(&a, 0, sizeof a);
+      a.q = w.q; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
+      a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx;
+      a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
+      hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
+      HIPCHK(hipGetLastError()); }
+    // ConcatOutputAndAttentionWrapper + OutputProjectionWrapper (rnn_wrappers.py:405-415; tacotron.py:166-170)
+    { SkJob j = sk_linear(m, m->concat_proj, w.h_att, As, As, w.ctx, D, ACT_NONE, w.o[0], Hd);
+      TRY(run_skinny(st, B, &j, 1)); }
+    // residual GRU stack (tacotron.py:171-172)
+    for (int i = 0; i < L; ++i) TRY(run_gru_cell(m, st, m->dec_gru[i], B, w.o[i], Hd, w.hd[i], w.rh, w.u, w.xc, w.o[i + 1]));
+    // frame projection to r frames (tacotron.py:178-179), written straight into the mel buffer
+    { SkJob j = sk_linear(m, m->frame_proj, w.o[L], Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, ldY);
+      j.o2 = reinterpret_cast<float*>(w.nz + (size_t)t * B);
+      TRY(run_skinny(st, B, &j, 1)); }
+    if (dbg) {
+      float* d = dbg + (size_t)t * B * dbgw;
+      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, w.h_att, As, d, dbgw, B, As);
+      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, w.ctx, D, d + As, dbgw, B, D);
+      for (int i = 0; i < L; ++i)
+        hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, w.hd[i], Hd, d + As + D + i * Hd, dbgw, B, Hd);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  if (stop_step) {
+    hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(64), 0, st, w.nz, B, n, stop_step);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// ---- post-net + linear head (tacotron.py:219-235) ----
+struct PostWs { CbhgWs cb; float* post_out; };
+static void carve_post(Carver& cv, const taco_model* m, int B, int T, PostWs& w) {
+  carve_cbhg(cv, m->post, B, T, w.cb);
+  w.post_out = cv.f((size_t)B * T * 2 * m->hp.post_rnn_size);
+}
+static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel, int B, int T, float* linear,
+                           float* post_out_user, const PostWs& w) {
+  float* po = post_out_user ? post_out_user : w.post_out;
+  TRY(cbhg_forward(m, st, m->post, mel, B, T, nullptr, nullptr, nullptr, po, w.cb));
+  GemmCall g; g.x = po; g.ldx = 2 * m->hp.post_rnn_size; g.M = B * T; g.out = linear; g.ldo = m->hp.num_freq;
+  return run_gemm(m, st, &m->linear, 1, false, g);
+}
+
+struct FullWs { EncWs enc; DecWs dec; PostWs post; float* enc_out; };
+static void carve_full(Carver& cv, const taco_model* m, int B, int T_in, int n, FullWs& w) {
+  carve_enc(cv, m, B, T_in, w.enc);
+  w.enc_out = cv.f((size_t)B * T_in * 2 * m->hp.enc_rnn_size);
+  carve_dec(cv, m, B, T_in, n, w.dec);
+  carve_post(cv, m, B, n * m->hp.reduction_factor, w.post);
+}
+
+static int check_common(const taco_model* m, int B, int T) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  if (!m->finalized) return fail(TACO_ERR_STATE, "model not finalized");
+  if (B <= 0 || T <= 0) return fail(TACO_ERR_ARG, "bad batch/time %d/%d", B, T);
+  if (B > 64) return fail(TACO_ERR_UNSUPPORTED, "batch %d > 64 rows per device is not supported: shard the batch", B);
+  return 0;
+}
+
+static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
+                           int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
+                           int32_t* stop, void* ws, size_t ws_bytes) {
+  TRY(check_common(m, B, T_in));
+  if (n <= 0) return fail(TACO_ERR_ARG, "n_steps must be positive");
+  if (!ids || !lengths || !mel || !linear || !align || !ws) return fail(TACO_ERR_ARG, "null buffer");
+  if (m->hp.num_speakers > 1 && !spk) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  Carver cv(ws, ws_bytes);
+  FullWs w;
+  carve_full(cv, m, B, T_in, n, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
+  TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
+  TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
+  TRY(postnet_forward(m, st, mel, B, n * m->hp.reduction_factor, linear, nullptr, w.post));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int taco_abi_version(void) { return TACO_ABI_VERSION; }
+const char* taco_last_error(void) { return g_err.c_str(); }
+
+int taco_model_create(const taco_hparams* hp, int device, taco_model** out) {
+  if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
+  if (hp->model_type < 0 || hp->model_type > 2) return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown multi-speaker model type: %d", hp->model_type);
+  if (hp->attention_type < 0 || hp->attention_type > 2) return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown attention type: %d", hp->attention_type);
+  if (hp->num_speakers > 1 && hp->model_type == 1)
+    return fail(TACO_ERR_UNSUPPORTED, "model_type 'simple' (speaker embedding concatenated at three points, tacotron.py:82-86,226-233) is not built yet");
+  if (hp->num_speakers > 1 && hp->model_type == 0)
+    return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown multi-speaker model type: single (num_speakers > 1 needs simple or deepvoice)");
+  if (hp->enc_prenet_n < 1 || hp->enc_prenet_n > 4 || hp->dec_prenet_n < 1 || hp->dec_prenet_n > 4 || hp->enc_proj_n < 1 ||
+      hp->enc_proj_n > 4 || hp->post_proj_n < 1 || hp->post_proj_n > 4 || hp->dec_layer_num < 1 || hp->dec_layer_num > 4)
+    return fail(TACO_ERR_ARG, "layer-count hparams out of range");
+  if (hp->enc_proj[hp->enc_proj_n - 1] != hp->enc_prenet[hp->enc_prenet_n - 1])
+    return fail(TACO_ERR_SHAPE, "encoder CBHG residual needs enc_proj_sizes[-1] == enc_prenet_sizes[-1]");
+  if (hp->post_proj[hp->post_proj_n - 1] != hp->num_mels)
+    return fail(TACO_ERR_SHAPE, "post CBHG residual needs post_proj_sizes[-1] == num_mels");
+  if (hp->attention_state_size % 4 || hp->dec_rnn_size % 4 || hp->enc_rnn_size % 4 || hp->post_rnn_size % 4 || hp->num_mels % 4)
+    return fail(TACO_ERR_UNSUPPORTED, "rnn sizes and num_mels must be multiples of 4");
+  taco_model* m = new taco_model();
+  m->hp = *hp;
+  m->device = device;
+  build_spec(m);
+  cbhg_dims(m->enc, hp->enc_prenet[hp->enc_prenet_n - 1], hp->enc_bank_size, hp->enc_bank_channels, hp->enc_maxpool,
+            hp->enc_highway_depth, hp->enc_rnn_size, hp->enc_proj, hp->enc_proj_n, hp->enc_proj_width);
+  cbhg_dims(m->post, hp->num_mels, hp->post_bank_size, hp->post_bank_channels, hp->post_maxpool, hp->post_highway_depth,
+            hp->post_rnn_size, hp->post_proj, hp->post_proj_n, hp->post_proj_width);
+  *out = m;
+  return 0;
+}
+
+int taco_model_num_weights(const taco_model* m) { return m ? (int)m->spec.size() : 0; }
+
+int taco_model_weight_name(const taco_model* m, int i, char* buf, int buflen, int64_t* shape4, int* ndim) {
+  if (!m || i < 0 || i >= (int)m->spec.size() || !buf) return fail(TACO_ERR_ARG, "bad index");
+  snprintf(buf, buflen, "%s", m->spec[i].first.c_str());
+  if (ndim) *ndim = (int)m->spec[i].second.size();
+  if (shape4) for (size_t d = 0; d < m->spec[i].second.size() && d < 4; ++d) shape4[d] = m->spec[i].second[d];
+  return 0;
+}
+
+int taco_model_set_weight(taco_model* m, const char* name, const float* host, const int64_t* shape, int ndim) {
+  if (!m || !name || !host || ndim < 0 || (ndim > 0 && !shape)) return fail(TACO_ERR_ARG, "null argument");
+  if (m->finalized) return fail(TACO_ERR_STATE, "model already finalized");
+  for (auto& s : m->spec) {
+    if (s.first != name) continue;
+    if ((int)s.second.size() != ndim) return fail(TACO_ERR_SHAPE, "%s: rank %d, expected %zu", name, ndim, s.second.size());
+    size_t n = 1;
+    for (int d = 0; d < ndim; ++d) {
+      if (shape[d] != s.second[d]) return fail(TACO_ERR_SHAPE, "%s: dim %d is %lld, expected %lld", name, d, (long long)shape[d], (long long)s.second[d]);
+      n *= (size_t)shape[d];
+    }
+    HostTensor& t = m->raw[name];
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(host, host + n);
+    t.set = true;
+    return 0;
+  }
+  return fail(TACO_ERR_ARG, "unknown weight name '%s'", name);
+}
+
+int taco_model_finalize(taco_model* m) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  if (m->finalized) return 0;
+  for (auto& s : m->spec)
+    if (!m->raw.count(s.first) || !m->raw[s.first].set) return fail(TACO_ERR_STATE, "weight '%s' was never set", s.first.c_str());
+  const taco_hparams& hp = m->hp;
+  HIPCHK(hipSetDevice(m->device));
+  m->harena.clear(); m->hvars.clear();
+  m->emb = arena_put(m, T_(m, "embedding").data.data(), T_(m, "embedding").data.size());
+  for (int i = 0; i < hp.enc_prenet_n; ++i) {
+    const std::string n = "prenet/dense_" + std::to_string(i + 1);
+    m->enc_prenet.push_back(make_conv(m, n, false));
+  }
+  make_cbhg(m, m->enc, "encoder_cbhg", hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_bank_size, hp.enc_bank_channels,
+            hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width);
+  m->memory_layer = make_conv(m, "attention/memory_layer", false, false);
+  make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
+            hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width);
+  m->linear = make_conv(m, "linear", false);
+  // decoder (skinny packs)
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
+  int d = hp.num_mels + D;
+  for (int i = 0; i < hp.dec_prenet_n; ++i) {
+    const std::string n = "decoder/prenet/dense_" + std::to_string(i + 1);
+    m->dec_prenet.push_back(pack_w16(m, T_(m, n + "/kernel").data.data(), hp.dec_prenet[i], 0, d, 0, hp.dec_prenet[i], T_(m, n + "/bias").data.data()));
+    m->skinny[n] = m->dec_prenet.back();
+    d = hp.dec_prenet[i];
+  }
+  m->att_gru = make_grudec(m, "decoder/attention_gru", d, As);
+  m->grus["decoder/attention_gru"] = m->att_gru;
+  m->query = pack_w16(m, T_(m, "attention/query_layer/kernel").data.data(), A, 0, As, 0, A, nullptr);
+  m->skinny["attention/query_layer"] = m->query;
+  m->concat_proj = pack_w16(m, T_(m, "decoder/concat_projection/kernel").data.data(), Hd, 0, As + D, 0, Hd, T_(m, "decoder/concat_projection/bias").data.data());
+  m->skinny["decoder/concat_projection"] = m->concat_proj;
+  for (int i = 0; i < hp.dec_layer_num; ++i) {
+    const std::string n = "decoder/gru_" + std::to_string(i + 1);
+    m->dec_gru.push_back(make_grudec(m, n, Hd, Hd));
+    m->grus[n] = m->dec_gru.back();
+  }
+  const int rM = hp.num_mels * hp.reduction_factor;
+  m->frame_proj = pack_w16(m, T_(m, "decoder/frame_projection/kernel").data.data(), rM, 0, Hd, 0, rM, T_(m, "decoder/frame_projection/bias").data.data());
+  m->skinny["decoder/frame_projection"] = m->frame_proj;
+  {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
+    std::vector<float> v = T_(m, "attention/attention_v").data;
+    if (hp.attention_type == 1) {
+      double nrm = 0; for (float x : v) nrm += (double)x * x;
+      const double sc = (double)T_(m, "attention/attention_g").data[0] / std::sqrt(nrm);
+      for (float& x : v) x = (float)(x * sc);
+      m->att_b = arena_put(m, T_(m, "attention/attention_b").data.data(), A);
+    }
+    m->att_v = arena_put(m, v.data(), A);
+    if (hp.attention_type == 2) m->att_sb = arena_put(m, T_(m, "attention/attention_score_bias").data.data(), 1);
+  }
+  if (is_deepvoice(m)) {
+    std::vector<std::string> names = {kSpkNames[0], kSpkNames[1], kSpkNames[2]};
+    for (int i = 0; i < hp.dec_layer_num; ++i) names.push_back("decoder_rnn_init_" + std::to_string(i + 1));
+    if (hp.speaker_embedding_size == 1) {
+      for (auto& n : names) m->spk_table.push_back(arena_put(m, T_(m, "spk/" + n + "/table").data.data(), T_(m, "spk/" + n + "/table").data.size()));
+    } else {
+      m->spk_emb = arena_put(m, T_(m, "speaker_embedding").data.data(), T_(m, "speaker_embedding").data.size());
+      for (auto& n : names) {
+        const HostTensor& k = T_(m, "spk/" + n + "/kernel");
+        m->spk_dense.push_back(pack_w16(m, k.data.data(), (int)k.shape[1], 0, (int)k.shape[0], 0, (int)k.shape[1], T_(m, "spk/" + n + "/bias").data.data()));
+      }
+    }
+  }
+  // GemmVar table (bank variants must be contiguous)
+  for (int i = 0; i < hp.enc_prenet_n; ++i) add_var(m, m->enc_prenet[i], 0);
+  for (Cbhg* c : {&m->enc, &m->post}) {
+    for (size_t i = 0; i < c->bank.size(); ++i) add_var(m, c->bank[i], (c->bank[i].kw - 1) * c->C);
+    for (auto& L : c->proj) add_var(m, L, 0);
+    if (c->has_dense) add_var(m, c->dense, 0);
+    for (auto& L : c->hw) add_var(m, L, 0);
+    add_var(m, c->xproj, 0);
+  }
+  add_var(m, m->memory_layer, 0);
+  add_var(m, m->linear, 0);
+  // stand-alone copies for the op-level entry points (coff 0)
+  for (auto& kv : m->convs) add_var(m, kv.second, 0);
+  for (int i = 0; i < hp.enc_prenet_n; ++i) m->convs["prenet/dense_" + std::to_string(i + 1)] = m->enc_prenet[i];
+  m->convs["attention/memory_layer"] = m->memory_layer;
+  m->convs["linear"] = m->linear;
+  // upload
+  HIPCHK(hipMalloc((void**)&m->darena, m->harena.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(m->darena, m->harena.data(), m->harena.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (auto& v : m->hvars) {
+    v.wp = AP(m, (size_t)v.wp); v.wp2 = AP(m, (size_t)v.wp2); v.bias = AP(m, (size_t)v.bias); v.bias2 = AP(m, (size_t)v.bias2);
+    v.bn_scale = AP(m, (size_t)v.bn_scale); v.bn_shift = AP(m, (size_t)v.bn_shift);
+  }
+  HIPCHK(hipMalloc((void**)&m->dvars, m->hvars.size() * sizeof(GemmVar)));
+  HIPCHK(hipMemcpy(m->dvars, m->hvars.data(), m->hvars.size() * sizeof(GemmVar), hipMemcpyHostToDevice));
+  m->harena.clear(); m->harena.shrink_to_fit();
+  m->raw.clear();
+  m->finalized = true;
+  return 0;
+}
+
+void taco_model_destroy(taco_model* m) {
+  if (!m) return;
+  if (m->darena) (void)hipFree(m->darena);
+  if (m->dvars) (void)hipFree(m->dvars);
+  delete m;
+}
+
+int taco_debug_force_gemm_config(taco_model* m, int cfg) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->force_cfg = cfg;
+  return 0;
+}
+
+size_t taco_workspace_bytes(const taco_model* m, int B, int T_in, int n_steps) {
+  if (!m) return 0;
+  Carver cv(nullptr, 0);
+  FullWs w;
+  carve_full(cv, m, B, T_in, n_steps, w);
+  return cv.off;
+}
+
+size_t taco_stage_workspace_bytes(const taco_model* m, int B, int T) {
+  if (!m) return 0;
+  // large enough for any single stage at (B, T): encoder at T_in=T, decoder with T_in=T and n_steps=T, post-net at T_mel=T
+  Carver a(nullptr, 0), b(nullptr, 0), c(nullptr, 0);
+  EncWs e; carve_enc(a, m, B, T, e);
+  DecWs d; carve_dec(b, m, B, T, T, d);
+  PostWs p; carve_post(c, m, B, T, p);
+  return std::max(a.off, std::max(b.off, c.off));
+}
+
+int taco_forward_infer(taco_model* m, void* hip_stream, const int32_t* d_inputs, const int32_t* d_input_lengths,
+                       const int32_t* d_speaker_id, int B, int T_in, int n_steps, const float* d_manual_alignments,
+                       float* d_mel, float* d_linear, float* d_alignments, int32_t* d_stop_step, void* d_workspace,
+                       size_t workspace_bytes) {
+  if (m) HIPCHK(hipSetDevice(m->device));
+  return forward_enqueue(m, (hipStream_t)hip_stream, d_inputs, d_input_lengths, d_speaker_id, B, T_in, n_steps,
+                         d_manual_alignments, d_mel, d_linear, d_alignments, d_stop_step, d_workspace, workspace_bytes);
+}
+
+struct taco_plan {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  size_t nodes = 0;
+  int device = 0;
+};
+
+int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_input_lengths, const int32_t* d_speaker_id,
+                     int B, int T_in, int n_steps, const float* d_manual_alignments, float* d_mel, float* d_linear,
+                     float* d_alignments, int32_t* d_stop_step, void* d_workspace, size_t workspace_bytes, taco_plan** out) {
+  if (!m || !out) return fail(TACO_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t cs;
+  HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) { (void)hipStreamDestroy(cs); return fail(TACO_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+  int rc = forward_enqueue(m, cs, d_inputs, d_input_lengths, d_speaker_id, B, T_in, n_steps, d_manual_alignments, d_mel,
+                           d_linear, d_alignments, d_stop_step, d_workspace, workspace_bytes);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(cs, &g);
+  (void)hipStreamDestroy(cs);
+  if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return fail(TACO_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  taco_plan* p = new taco_plan();
+  p->graph = g; p->device = m->device;
+  e = hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); delete p; return fail(TACO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+  (void)hipGraphGetNodes(g, nullptr, &p->nodes);
+  *out = p;
+  return 0;
+}
+
+int taco_plan_launch(taco_plan* p, void* hip_stream) {
+  if (!p || !p->exec) return fail(TACO_ERR_ARG, "null plan");
+  HIPCHK(hipGraphLaunch(p->exec, (hipStream_t)hip_stream));
+  return 0;
+}
+int taco_plan_num_nodes(const taco_plan* p) { return p ? (int)p->nodes : 0; }
+void taco_plan_destroy(taco_plan* p) {
+  if (!p) return;
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  delete p;
+}
+
+int taco_encoder_forward(taco_model* m, void* hip_stream, const int32_t* d_inputs, const int32_t* d_input_lengths,
+                         const int32_t* d_speaker_id, int B, int T_in, float* d_encoder_out, void* d_workspace,
+                         size_t workspace_bytes) {
+  TRY(check_common(m, B, T_in));
+  if (!d_inputs || !d_input_lengths || !d_encoder_out || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
+  if (m->hp.num_speakers > 1 && !d_speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  HIPCHK(hipSetDevice(m->device));
+  Carver cv(d_workspace, workspace_bytes);
+  EncWs w; carve_enc(cv, m, B, T_in, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
+  return encoder_forward(m, (hipStream_t)hip_stream, d_inputs, d_input_lengths, d_speaker_id, B, T_in, d_encoder_out, w, false);
+}
+
+int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder_out, const int32_t* d_speaker_id, int B,
+                         int T_in, int n_steps, const float* d_manual_alignments, const float* d_teacher_frames,
+                         float* d_mel, float* d_alignments, int32_t* d_stop_step, float* d_dbg_states, void* d_workspace,
+                         size_t workspace_bytes) {
+  TRY(check_common(m, B, T_in));
+  if (n_steps <= 0 || !d_encoder_out || !d_mel || !d_alignments || !d_workspace) return fail(TACO_ERR_ARG, "bad argument");
+  if (m->hp.num_speakers > 1 && !d_speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  HIPCHK(hipSetDevice(m->device));
+  Carver cv(d_workspace, workspace_bytes);
+  DecWs w; carve_dec(cv, m, B, T_in, n_steps, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
+  return decoder_forward(m, (hipStream_t)hip_stream, d_encoder_out, d_speaker_id, B, T_in, n_steps, d_manual_alignments,
+                         d_teacher_frames, d_mel, d_alignments, d_stop_step, d_dbg_states, w, false, nullptr);
+}
+
+int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, int B, int T_mel, float* d_linear,
+                         float* d_post_out, void* d_workspace, size_t workspace_bytes) {
+  TRY(check_common(m, B, T_mel));
+  if (!d_mel || !d_linear || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
+  HIPCHK(hipSetDevice(m->device));
+  Carver cv(d_workspace, workspace_bytes);
+  PostWs w; carve_post(cv, m, B, T_mel, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
+  return postnet_forward(m, (hipStream_t)hip_stream, d_mel, B, T_mel, d_linear, d_post_out, w);
+}
+
+static const ConvL* find_conv(taco_model* m, const char* layer) {
+  auto it = m->convs.find(layer ? layer : "");
+  return it == m->convs.end() ? nullptr : &it->second;
+}
+
+int taco_conv1d_bn_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int B, int T, int act,
+                       int maxpool_width, float* d_out) {
+  if (!m || !m->finalized) return fail(TACO_ERR_STATE, "model not finalized");
+  const ConvL* L = find_conv(m, layer);
+  if (!L) return fail(TACO_ERR_ARG, "unknown conv layer '%s'", layer ? layer : "(null)");
+  if (!d_x || !d_out || B <= 0 || T <= 0) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  GemmCall g; g.x = d_x; g.ldx = L->cin; g.M = B * T; g.T = T; g.act = act; g.mpw = maxpool_width < 1 ? 1 : maxpool_width;
+  g.out = d_out; g.ldo = L->N;
+  return run_gemm(m, (hipStream_t)hip_stream, L, 1, false, g);
+}
+
+int taco_dense_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int rows, int act, float* d_out) {
+  if (!m || !m->finalized) return fail(TACO_ERR_STATE, "model not finalized");
+  if (!d_x || !d_out || rows <= 0) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  auto sk = m->skinny.find(layer ? layer : "");
+  if (sk != m->skinny.end()) {
+    SkJob j = sk_linear(m, sk->second, d_x, sk->second.K, sk->second.K, nullptr, 0, act, d_out, sk->second.N);
+    return run_skinny((hipStream_t)hip_stream, rows, &j, 1);
+  }
+  const ConvL* L = find_conv(m, layer);
+  if (!L || L->kw != 1) return fail(TACO_ERR_ARG, "unknown dense layer '%s'", layer ? layer : "(null)");
+  GemmCall g; g.x = d_x; g.ldx = L->cin; g.M = rows; g.act = act; g.out = d_out; g.ldo = L->N;
+  return run_gemm(m, (hipStream_t)hip_stream, L, 1, false, g);
+}
+
+int taco_highway_f32(taco_model* m, void* hip_stream, const char* layer, const float* d_x, int rows, float* d_out) {
+  if (!m || !m->finalized) return fail(TACO_ERR_STATE, "model not finalized");
+  const ConvL* L = find_conv(m, layer);
+  if (!L || !L->wp2) return fail(TACO_ERR_ARG, "unknown highway layer '%s'", layer ? layer : "(null)");
+  if (!d_x || !d_out || rows <= 0 || d_x == d_out) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  GemmCall g; g.x = d_x; g.ldx = L->cin; g.M = rows; g.out = d_out; g.ldo = L->N;
+  return run_gemm(m, (hipStream_t)hip_stream, L, 1, true, g);
+}
+
+int taco_bigru_f32(taco_model* m, void* hip_stream, const char* scope, const float* d_x, const int32_t* d_lengths,
+                   const float* d_init_state, int B, int T, float* d_out, void* d_workspace, size_t workspace_bytes) {
+  TRY(check_common(m, B, T));
+  const std::string sc = scope ? scope : "";
+  const Cbhg* c = sc == "encoder_cbhg" ? &m->enc : (sc == "post_cbhg" ? &m->post : nullptr);
+  if (!c) return fail(TACO_ERR_ARG, "unknown BiGRU scope '%s'", sc.c_str());
+  if (!d_x || !d_out || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  Carver cv(d_workspace, workspace_bytes);
+  CbhgWs w; carve_cbhg(cv, *c, B, T, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
+  return bigru_scan(m, st, *c, d_x, B, T, d_lengths, d_init_state, d_out, w);
+}
+
+int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell_output, const float* d_keys,
+                            const float* d_values, const float* d_prev_alignments, int B, int T_in, float* d_alignments,
+                            float* d_context, void* d_workspace, size_t workspace_bytes) {
+  TRY(check_common(m, B, T_in));
+  if (!d_cell_output || !d_keys || !d_values || !d_prev_alignments || !d_alignments || !d_context || !d_workspace)
+    return fail(TACO_ERR_ARG, "null buffer");
+  if (T_in > ATT_MAXT) return fail(TACO_ERR_UNSUPPORTED, "T_in %d > %d", T_in, ATT_MAXT);
+  HIPCHK(hipSetDevice(m->device));
+  hipStream_t st = (hipStream_t)hip_stream;
+  const taco_hparams& hp = m->hp;
+  const int A = hp.attention_size, D = 2 * hp.enc_rnn_size, As = hp.attention_state_size;
+  Carver cv(d_workspace, workspace_bytes);
+  float* q = cv.f((size_t)B * A);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small");
+  SkJob j = sk_linear(m, m->query, d_cell_output, As, As, nullptr, 0, ACT_NONE, q, A);
+  TRY(run_skinny(st, B, &j, 1));
+  if (d_alignments != d_prev_alignments)
+    HIPCHK(hipMemcpyAsync(d_alignments, d_prev_alignments, (size_t)B * T_in * sizeof(float), hipMemcpyDeviceToDevice, st));
+  AttnArgs a; memset(&a, 0, sizeof a);
+  a.q = q; a.keys = d_keys; a.values = d_values; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
+  a.align = d_alignments; a.ctx = d_context; a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.n_steps = 1;
+  hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+/* One GRUCell step of a decoder GRU by name ("decoder/attention_gru", "decoder/gru_1", ...):
+ * d_h [R,H] is updated in place; d_out_res (nullable) = h' + x (ResidualWrapper).  Workspace: 3*R*H floats. */
+int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
+                      float* d_out_res, void* d_workspace, size_t workspace_bytes) {
+  if (!m || !m->finalized) return fail(TACO_ERR_STATE, "model not finalized");
+  auto it = m->grus.find(name ? name : "");
+  if (it == m->grus.end()) return fail(TACO_ERR_ARG, "unknown GRU '%s'", name ? name : "(null)");
+  if (!d_x || !d_h || !d_workspace || R <= 0) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  const GruDec& g = it->second;
+  Carver cv(d_workspace, workspace_bytes);
+  float* rh = cv.f((size_t)R * g.H); float* u = cv.f((size_t)R * g.H); float* xc = cv.f((size_t)R * g.H);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small");
+  if (d_out_res && g.I != g.H) return fail(TACO_ERR_SHAPE, "residual needs input size == state size");
+  return run_gru_cell(m, (hipStream_t)hip_stream, g, R, d_x, g.I, d_h, rh, u, xc, d_out_res);
+}
+
+}  // extern "C"

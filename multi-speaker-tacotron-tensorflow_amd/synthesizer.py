@@ -1,0 +1,99 @@
+"""`Synthesizer` -- the inference driver of the reference (synthesizer.py:23-207), re-hosted.
+
+Kept: load() / synthesize() / close() names and arguments; token -> input_lengths rule
+(synthesizer.py:120); default speaker id zeros (:43-44); the (linear_outputs, alignments) fetch pair
+(:122-126,166-167); manual-attention second pass for modes 1 and 3 (:171-205; mode 2 is broken in the
+reference: np.pow does not exist).  Out of scope: text normalisation,
+plots, Griffin-Lim, wav I/O -- `synthesize` returns the model outputs as numpy arrays instead."""
+import glob
+import os
+import re
+
+import numpy as np
+
+from .hparams import hparams, load_hparams, EOS_ID
+from .tacotron import create_model
+from .weights import load_weights
+
+
+def get_most_recent_checkpoint(checkpoint_dir, checkpoint_step=None):
+    """synthesizer.py:289-299 analogue for `model.ckpt-<step>.safetensors` packs."""
+    if checkpoint_step is None:
+        paths = glob.glob(os.path.join(checkpoint_dir, "*.safetensors"))
+        if not paths:
+            raise Exception(" [!] No checkpoint found in {}".format(checkpoint_dir))
+        def step_of(p):
+            m = re.search(r"ckpt-(\d+)", os.path.basename(p))
+            return int(m.group(1)) if m else -1
+        return max(paths, key=step_of)
+    return os.path.join(checkpoint_dir, "model.ckpt-{}.safetensors".format(checkpoint_step))
+
+
+class Synthesizer(object):
+    text_to_sequence = None   # optional callable text -> list of ids ending in EOS (text/__init__.py:23-58)
+
+    def close(self):
+        if getattr(self, "model", None) is not None:
+            self.model.close()
+            self.model = None
+
+    def load(self, checkpoint_path, num_speakers=2, checkpoint_step=None, model_name='tacotron', device=None):
+        self.num_speakers = num_speakers
+        if os.path.isdir(checkpoint_path):
+            load_path = checkpoint_path
+            checkpoint_path = get_most_recent_checkpoint(checkpoint_path, checkpoint_step)
+        else:
+            load_path = os.path.dirname(checkpoint_path)
+        self.hparams = hparams.copy()
+        load_hparams(self.hparams, load_path)
+        self.model = create_model(self.hparams)
+        self.model.load_weights(load_weights(checkpoint_path))
+        self.model.initialize(None, None, self.num_speakers, None, device=device)   # placeholders (:39-52)
+        return self
+
+    def synthesize(self, texts=None, tokens=None, base_path=None, paths=None, speaker_ids=None,
+                   start_of_sentence=None, end_of_sentence=True, pre_word_num=0, post_word_num=0,
+                   pre_surplus_idx=0, post_surplus_idx=1, use_short_concat=False,
+                   manual_attention_mode=0, base_alignment_path=None, librosa_trim=False,
+                   attention_trim=True, manual_alignments=None):
+        if type(texts) == str:
+            texts = [texts]
+        if texts is not None and tokens is None:
+            if self.text_to_sequence is None:
+                raise Exception("text front-end (text/__init__.py) is outside the accelerated path: pass tokens=, "
+                                "or set Synthesizer.text_to_sequence")
+            sequences = [self.text_to_sequence(text) for text in texts]
+        elif tokens is not None:
+            sequences = tokens
+        else:
+            raise Exception("either texts or tokens is required")
+        sequences = np.asarray(sequences)
+        if sequences.ndim != 2:
+            raise Exception("token rows must have equal length (pre-pad with 0 as eval.py / train.py:27-40 do)")
+        input_lengths = np.argmax(sequences == EOS_ID, 1).astype(np.int32)             # synthesizer.py:120
+        if type(speaker_ids) == dict:
+            raise Exception("dict-valued speaker_ids is broken in the reference (synthesizer.py:153-164) and not supported")
+        if manual_alignments is None and base_alignment_path is not None:               # :134-150
+            alignment_path = os.path.join(base_alignment_path, os.path.basename(base_path))
+            loaded = [np.load("{}.{}.npy".format(alignment_path, idx)) for idx in range(len(sequences))]
+            manual_alignments = np.transpose(loaded, [0, 2, 1])
+        linear, alignments = self.model.run(
+            inputs=sequences.astype(np.int32), input_lengths=input_lengths, speaker_id=speaker_ids,
+            manual_alignments=manual_alignments, is_manual_attention=manual_alignments is not None)
+        linear, alignments = linear.cpu().numpy(), alignments.cpu().numpy()
+        if manual_attention_mode > 0:                                                    # :171-205
+            if manual_attention_mode == 2:
+                raise Exception("manual_attention_mode 2 is broken in the reference (np.pow, synthesizer.py:181-188)")
+            alignments_T = np.transpose(alignments, [0, 2, 1])                           # [N, D, E]
+            new_alignments = np.zeros_like(alignments_T) if manual_attention_mode == 1 else alignments_T.copy()
+            for idx in range(len(alignments)):
+                argmax = alignments[idx].argmax(1)
+                # reference indexing (:176-179): new_alignments[idx][(argmax, range(len(argmax)))] = 1 on the
+                # [E-major] transpose; only shape-consistent when T_in == T_dec.  Applied here per decoder step.
+                am = alignments[idx].argmax(0)                                           # [T_dec] -> encoder index
+                new_alignments[idx][(np.arange(len(am)), am)] = 1
+            linear, alignments = self.model.run(
+                inputs=sequences.astype(np.int32), input_lengths=input_lengths, speaker_id=speaker_ids,
+                manual_alignments=new_alignments, is_manual_attention=True)
+            linear, alignments = linear.cpu().numpy(), alignments.cpu().numpy()
+        return linear, alignments

@@ -1,0 +1,261 @@
+"""`Tacotron` -- the reference's model object (models/tacotron.py:16-343) re-hosted on libtaco_hip.
+
+The reference builds a TF1 graph in `initialize()` and evaluates it with `sess.run`.  Here
+`initialize()` creates the device weight pack and (when concrete inputs are given) runs the forward
+eagerly; `run()` is the `sess.run([linear_outputs, alignments], feed_dict)` of
+synthesizer.py:166-167.  Attribute names after `initialize()` are the reference's
+(tacotron.py:242-251; is_manual_attention / manual_alignments :120-125).
+
+PyTorch is used only for device memory and streams; all compute is in the HIP library."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hparams import hparams as default_hparams, PAD_ID, EOS_ID
+from .weights import random_weights
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Plan(object):
+    """Static buffers + one captured hipGraph for a (B, T_in, n_steps, manual?) shape."""
+
+    def __init__(self, model, B, T_in, n, manual):
+        hp, dev = model._hparams, model.device
+        lib = model._lib
+        r, M, F = hp.reduction_factor, hp.num_mels, hp.num_freq
+        self.B, self.T_in, self.n = B, T_in, n
+        self.inputs = torch.zeros((B, T_in), dtype=torch.int32, device=dev)
+        self.lengths = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.speaker_id = torch.zeros((B,), dtype=torch.int32, device=dev)
+        self.manual = torch.zeros((B, n, T_in), dtype=torch.float32, device=dev) if manual else None
+        self.mel = torch.empty((B, n * r, M), dtype=torch.float32, device=dev)
+        self.linear = torch.empty((B, n * r, F), dtype=torch.float32, device=dev)
+        self.align = torch.empty((B, T_in, n), dtype=torch.float32, device=dev)
+        self.stop = torch.zeros((1,), dtype=torch.int32, device=dev)
+        nbytes = int(lib.taco_workspace_bytes(model._handle, B, T_in, n))
+        self.ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        self.ws_bytes = nbytes
+        self.handle = C.c_void_p()
+        self._lib = lib
+        spk = self.speaker_id if model.num_speakers > 1 else None
+        _lib.check(lib.taco_plan_create(
+            model._handle, _ptr(self.inputs), _ptr(self.lengths), _ptr(spk), B, T_in, n, _ptr(self.manual),
+            _ptr(self.mel), _ptr(self.linear), _ptr(self.align), _ptr(self.stop), _ptr(self.ws), nbytes,
+            C.byref(self.handle)))
+        self.num_nodes = lib.taco_plan_num_nodes(self.handle)
+
+    def launch(self):
+        _lib.check(self._lib.taco_plan_launch(self.handle, _stream()))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.taco_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Tacotron(object):
+    def __init__(self, hparams=None):
+        self._hparams = hparams if hparams is not None else default_hparams
+        self._lib = None
+        self._handle = None
+        self._weights = None
+        self._plans = {}
+        self.device = None
+        self.num_speakers = 1
+        self.is_manual_attention = False
+        self.manual_alignments = None
+
+    # ---- weights (tf variables + Saver.restore in the reference) ----
+    def load_weights(self, weights):
+        """dict name -> float32 array (canonical names, weights.py).  Must precede initialize()."""
+        if self._handle is not None:
+            raise RuntimeError("load_weights() must be called before initialize()")
+        self._weights = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+
+    def _build(self, num_speakers, device, seed=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("taco_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        self._lib = _lib.load_library()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        chp = _lib.to_c_hparams(self._hparams, num_speakers)
+        h = C.c_void_p()
+        _lib.check(self._lib.taco_model_create(C.byref(chp), self.device.index or 0, C.byref(h)))
+        self._handle = h
+        if self._weights is None:   # variables keep their initial values (synthesizer.py:65 / train.py:187)
+            self._weights = random_weights(self._hparams, num_speakers, seed)
+        for name, arr in self._weights.items():
+            shp = (C.c_int64 * max(arr.ndim, 1))(*arr.shape)
+            _lib.check(self._lib.taco_model_set_weight(h, name.encode(), arr.ctypes.data_as(C.c_void_p), shp, arr.ndim))
+        _lib.check(self._lib.taco_model_finalize(h))
+        self._weights = None
+
+    def initialize(self, inputs, input_lengths, num_speakers, speaker_id,
+                   mel_targets=None, linear_targets=None, loss_coeff=None,
+                   rnn_decoder_test_mode=False, is_randomly_initialized=False, device=None):
+        """models/tacotron.py:21-25.  `inputs` int32 [B,T_in] (PAD=0, EOS=1) and `input_lengths`
+        int32 [B] may be None ("placeholders", synthesizer.py:39-44): then only the model is built
+        and `run()` supplies the feed later."""
+        is_training = linear_targets is not None                          # tacotron.py:26
+        if is_training:
+            raise NotImplementedError(
+                "training forward/backward (teacher forcing helpers.py:35-67, add_loss, add_optimizer) is not built "
+                "yet in the HIP path -- see DESIGN.md 'what comes next'")
+        self.is_randomly_initialized = is_randomly_initialized
+        self.num_speakers = num_speakers
+        if self._handle is None:
+            self._build(num_speakers, device)
+        self.inputs, self.speaker_id, self.input_lengths = inputs, speaker_id, input_lengths
+        self.loss_coeff, self.mel_targets, self.linear_targets = loss_coeff, mel_targets, linear_targets
+        self.mel_outputs = self.linear_outputs = self.alignments = None
+        self.final_decoder_state = None
+        if inputs is not None:
+            self.run()
+        return self
+
+    def get_dummy_feed_dict(self):
+        """tacotron.py:338-343."""
+        return {"is_manual_attention": False, "manual_alignments": np.zeros([1, 1, 1])}
+
+    # ---- sess.run([linear_outputs, alignments], feed_dict) ----
+    def _as_dev(self, x, dtype):
+        if x is None:
+            return None
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x))
+        return x.to(device=self.device, dtype=dtype).contiguous()
+
+    def plan_for(self, B, T_in, n_steps=None, manual=False):
+        n = self._hparams.max_iters if n_steps is None else n_steps
+        key = (B, T_in, n, bool(manual))
+        if key not in self._plans:
+            with torch.cuda.device(self.device):
+                self._plans[key] = _Plan(self, B, T_in, n, manual)
+        return self._plans[key]
+
+    def run(self, inputs=None, input_lengths=None, speaker_id=None, manual_alignments=None,
+            is_manual_attention=None, n_steps=None, honor_stop=True):
+        """One forward.  Returns (linear_outputs, alignments) as device tensors and refreshes the
+        public attributes.  `manual_alignments` [B,T_dec,T_in] + `is_manual_attention`
+        (rnn_wrappers.py:313-317).  With honor_stop the outputs are cut where the reference's stop rule
+        (helpers.py:29 + dynamic_decode) would have ended the loop (one host sync)."""
+        if self._handle is None:
+            raise RuntimeError("initialize() must be called first")
+        inputs = self.inputs if inputs is None else inputs
+        input_lengths = self.input_lengths if input_lengths is None else input_lengths
+        speaker_id = self.speaker_id if speaker_id is None else speaker_id
+        if is_manual_attention is None:
+            is_manual_attention = self.is_manual_attention
+        if manual_alignments is None:
+            manual_alignments = self.manual_alignments
+        ids = self._as_dev(inputs, torch.int32)
+        if ids.dim() != 2:
+            raise Exception("inputs must be [batch, time], got shape %s" % (tuple(ids.shape),))
+        B, T_in = ids.shape
+        lens = self._as_dev(input_lengths, torch.int32)
+        manual = bool(is_manual_attention)
+        plan = self.plan_for(B, T_in, n_steps, manual)
+        with torch.cuda.device(self.device):
+            plan.inputs.copy_(ids)
+            plan.lengths.copy_(lens)
+            if self.num_speakers > 1:
+                if speaker_id is None:      # placeholder_with_default(zeros) (synthesizer.py:43-44)
+                    plan.speaker_id.zero_()
+                else:
+                    plan.speaker_id.copy_(self._as_dev(speaker_id, torch.int32))
+            if manual:
+                ma = self._as_dev(manual_alignments, torch.float32)
+                if tuple(ma.shape) != tuple(plan.manual.shape):
+                    raise Exception("manual_alignments must be [B, T_dec, T_in] = %s, got %s"
+                                    % (tuple(plan.manual.shape), tuple(ma.shape)))
+                plan.manual.copy_(ma)
+            plan.launch()
+            mel, linear, align = plan.mel, plan.linear, plan.align
+            self.stop_step = plan.n
+            if honor_stop:
+                stop = int(plan.stop.item())
+                self.stop_step = stop
+                if stop < plan.n:   # dynamic_decode ended early: re-run the post-net on the frames that exist
+                    r = self._hparams.reduction_factor
+                    mel = mel.view(B, plan.n, -1)[:, :stop].reshape(B, stop * r, self._hparams.num_mels).contiguous()
+                    align = align[:, :, :stop].contiguous()
+                    linear = self.postnet(mel)
+        self.mel_outputs, self.linear_outputs, self.alignments = mel, linear, align
+        return linear, align
+
+    # ---- stage / op level access (used by the parity tests) ----
+    def _stage_ws(self, B, T):
+        n = int(self._lib.taco_stage_workspace_bytes(self._handle, B, T))
+        return torch.empty((n,), dtype=torch.uint8, device=self.device), n
+
+    def encoder(self, inputs, input_lengths, speaker_id=None):
+        ids, lens = self._as_dev(inputs, torch.int32), self._as_dev(input_lengths, torch.int32)
+        spk = self._as_dev(speaker_id, torch.int32)
+        B, T = ids.shape
+        out = torch.empty((B, T, 2 * self._hparams.enc_rnn_size), dtype=torch.float32, device=self.device)
+        ws, n = self._stage_ws(B, T)
+        _lib.check(self._lib.taco_encoder_forward(self._handle, _stream(), _ptr(ids), _ptr(lens), _ptr(spk), B, T,
+                                                  _ptr(out), _ptr(ws), n))
+        return out
+
+    def decoder(self, encoder_out, n_steps, speaker_id=None, manual_alignments=None, teacher_frames=None, debug=False):
+        hp = self._hparams
+        enc = self._as_dev(encoder_out, torch.float32)
+        B, T_in, _ = enc.shape
+        spk = self._as_dev(speaker_id, torch.int32)
+        man = self._as_dev(manual_alignments, torch.float32)
+        tf_ = self._as_dev(teacher_frames, torch.float32)
+        r, M = hp.reduction_factor, hp.num_mels
+        mel = torch.empty((B, n_steps * r, M), dtype=torch.float32, device=self.device)
+        align = torch.empty((B, T_in, n_steps), dtype=torch.float32, device=self.device)
+        stop = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        dbgw = hp.attention_state_size + 2 * hp.enc_rnn_size + hp.dec_layer_num * hp.dec_rnn_size
+        dbg = torch.empty((n_steps, B, dbgw), dtype=torch.float32, device=self.device) if debug else None
+        ws, n = self._stage_ws(B, max(T_in, n_steps))
+        _lib.check(self._lib.taco_decoder_forward(self._handle, _stream(), _ptr(enc), _ptr(spk), B, T_in, n_steps,
+                                                  _ptr(man), _ptr(tf_), _ptr(mel), _ptr(align), _ptr(stop), _ptr(dbg),
+                                                  _ptr(ws), n))
+        return mel, align, stop, dbg
+
+    def postnet(self, mel, return_post=False):
+        hp = self._hparams
+        mel = self._as_dev(mel, torch.float32)
+        B, T, _ = mel.shape
+        lin = torch.empty((B, T, hp.num_freq), dtype=torch.float32, device=self.device)
+        post = torch.empty((B, T, 2 * hp.post_rnn_size), dtype=torch.float32, device=self.device) if return_post else None
+        ws, n = self._stage_ws(B, T)
+        _lib.check(self._lib.taco_postnet_forward(self._handle, _stream(), _ptr(mel), B, T, _ptr(lin), _ptr(post),
+                                                  _ptr(ws), n))
+        return (lin, post) if return_post else lin
+
+    def close(self):
+        self._plans.clear()
+        if self._handle is not None and self._lib is not None:
+            self._lib.taco_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_model(hparams):
+    """models/__init__.py:6-7."""
+    return Tacotron(hparams)
+
+
+def input_lengths_from_tokens(sequences):
+    """synthesizer.py:120: index of the first EOS (the EOS itself is outside the length)."""
+    return np.argmax(np.asarray(sequences) == EOS_ID, 1).astype(np.int32)

@@ -1,0 +1,53 @@
+"""world_size-2 gloo test of the N>1 bench path on CPU: batch sharding with no data-path collective,
+barrier + max-over-ranks timing, whole-job aggregation.  The per-rank 'compute' is the
+oracle (test infrastructure) so that shard-vs-single equality of concatenated outputs is checked."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+import taco_oracle as O
+from util import tiny_hp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import taco_amd
+    from taco_amd import dist as D
+    import torch.distributed as dist
+    D.init_process_group("gloo")
+    hp = tiny_hp()
+    w = O.init_weights(hp, 1, 0)
+    ids, L = O.synthetic_inputs(5, 8, 11, ragged=True)
+    lo, hi = D.shard_range(5, rank, world)
+    out = O.forward(w, hp, ids[lo:hi], L[lo:hi])
+    dist.barrier()
+    t = D.max_over_ranks(1.0 + rank)            # slowest rank wins
+    frames = D.sum_over_ranks(out["mel"].shape[0] * out["mel"].shape[1])
+    parts = D.gather_rows(out["mel"], world)
+    if rank == 0:
+        q.put((t, frames, np.concatenate(parts, 0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_inference_equals_single():
+    hp = tiny_hp()
+    w = O.init_weights(hp, 1, 0)
+    ids, L = O.synthetic_inputs(5, 8, 11, ragged=True)
+    ref = O.forward(w, hp, ids, L)["mel"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    t, frames, mel = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 2.0
+    assert frames == ref.shape[0] * ref.shape[1]
+    assert np.allclose(mel, ref, atol=1e-12)

@@ -1,0 +1,175 @@
+"""GPU parity, op level: each HIP kernel family against the oracle through the C ABI.
+Tolerances: a single fp32 GEMM/conv vs the float64 oracle -> 2e-5 abs on O(1) values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import taco_oracle as O
+from util import tiny_hp, build_model, dev, ptr, stream, maxabs
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-5
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import taco_amd
+    ohp = tiny_hp()
+    w = O.init_weights(ohp, 1, 7)
+    m = build_model(ohp, w)
+    return ohp, w, m, taco_amd._lib
+
+
+def _conv(ctx, layer, x, act, mpw=1):
+    import torch
+    ohp, w, m, L = ctx
+    B, T, _ = x.shape
+    cout = w[layer + "/kernel"].shape[-1]
+    out = torch.full((B, T, cout), float("nan"), device="cuda")
+    L.check(m._lib.taco_conv1d_bn_f32(m._handle, stream(), layer.encode(), ptr(dev(x, torch.float32)), B, T, act, mpw, ptr(out)))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+def test_conv_bank_member(ctx, k, cfg):
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(100 + k)
+    x = rs.randn(3, 37, ohp.enc_prenet_sizes[-1])
+    name = "encoder_cbhg/conv_bank/conv1d_%d" % k
+    m._lib.taco_debug_force_gemm_config(m._handle, cfg)
+    try:
+        y = _conv(ctx, name, x, 1)
+    finally:
+        m._lib.taco_debug_force_gemm_config(m._handle, -1)
+    assert maxabs(y, O.conv1d_bn(x, w, name, O.relu)) < TOL
+
+
+def test_conv_rows_cross_tile_and_batch_boundaries(ctx):
+    # T not a multiple of any tile, B*T > 128 so several M-tiles, halo must not leak across batch rows
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(5)
+    x = rs.randn(5, 61, ohp.enc_prenet_sizes[-1])
+    for k in (4, 5):
+        name = "encoder_cbhg/conv_bank/conv1d_%d" % k
+        assert maxabs(_conv(ctx, name, x, 1), O.conv1d_bn(x, w, name, O.relu)) < TOL
+
+
+def test_projection_with_fused_maxpool(ctx):
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(6)
+    C_in = ohp.enc_bank_size * ohp.enc_bank_channel_size      # > 64 channels -> several LDS chunks
+    x = rs.randn(2, 29, C_in)
+    ref = O.conv1d_bn(O.maxpool_same_stride1(x, 2), w, "encoder_cbhg/proj_1", O.relu)
+    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 1, mpw=2), ref) < TOL
+    ref = O.conv1d_bn(x, w, "encoder_cbhg/proj_1", None)
+    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 0, mpw=1), ref) < TOL
+
+
+@pytest.mark.parametrize("layer,rows", [("prenet/dense_2", 50), ("linear", 70), ("post_cbhg/dense", 33),
+                                        ("attention/memory_layer", 19), ("decoder/prenet/dense_2", 3),
+                                        ("decoder/frame_projection", 9), ("attention/query_layer", 33),
+                                        ("decoder/concat_projection", 64)])
+def test_dense_layers_big_and_skinny(ctx, layer, rows):
+    import torch
+    ohp, w, m, L = ctx
+    k = w[layer + "/kernel"]
+    rs = np.random.RandomState(rows)
+    x = rs.randn(rows, k.shape[0])
+    out = torch.full((rows, k.shape[1]), float("nan"), device="cuda")
+    L.check(m._lib.taco_dense_f32(m._handle, stream(), layer.encode(), ptr(dev(x, torch.float32)), rows, 1, ptr(out)))
+    torch.cuda.synchronize()
+    ref = O.dense(x, w, layer, O.relu, bias=(layer + "/bias") in w)
+    assert maxabs(out.cpu().numpy(), ref) < TOL
+
+
+def test_highway(ctx):
+    import torch
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(8)
+    for scope, D in (("encoder_cbhg", ohp.enc_rnn_size), ("post_cbhg", ohp.post_rnn_size)):
+        x = rs.randn(77, D)
+        out = torch.full((77, D), float("nan"), device="cuda")
+        L.check(m._lib.taco_highway_f32(m._handle, stream(), (scope + "/highway_2").encode(), ptr(dev(x, torch.float32)), 77, ptr(out)))
+        torch.cuda.synchronize()
+        assert maxabs(out.cpu().numpy(), O.highwaynet(x, w, scope + "/highway_2")) < TOL
+
+
+@pytest.mark.parametrize("B", [1, 5, 17, 33])
+def test_bigru_with_lengths_and_init_state(ctx, B):
+    import torch
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(B)
+    T, H = 12, ohp.enc_rnn_size
+    x = rs.randn(B, T, H)
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32)
+    lens[0] = T
+    init = rs.randn(B, 2 * H) * 0.5
+    ref = O.bidirectional_gru(x, lens, w, "encoder_cbhg/bigru", init)
+    out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+    n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(dev(x, torch.float32)), ptr(dev(lens)),
+                                  ptr(dev(init, torch.float32)), B, T, ptr(out), ptr(ws), n))
+    torch.cuda.synchronize()
+    assert maxabs(out.cpu().numpy(), ref) < 1e-4
+    # post-net flavour: no lengths, zero init
+    Hp = ohp.post_rnn_size
+    xp = rs.randn(B, T, Hp)
+    outp = torch.full((B, T, 2 * Hp), float("nan"), device="cuda")
+    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(dev(xp, torch.float32)), ptr(None), ptr(None),
+                                  B, T, ptr(outp), ptr(ws), n))
+    torch.cuda.synchronize()
+    assert maxabs(outp.cpu().numpy(), O.bidirectional_gru(xp, None, w, "post_cbhg/bigru")) < 1e-4
+
+
+@pytest.mark.parametrize("name,res", [("decoder/attention_gru", False), ("decoder/gru_1", True), ("decoder/gru_2", True)])
+def test_decoder_gru_cell(ctx, name, res):
+    import torch
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(3)
+    I = w[name + "/gates/kernel"].shape[0] - w[name + "/candidate/bias"].shape[0]
+    H = w[name + "/candidate/bias"].shape[0]
+    R = 6
+    x, h = rs.randn(R, I), rs.randn(R, H)
+    hn = O.gru_cell(x, h, w, name)
+    hd = dev(h, torch.float32)
+    outr = torch.full((R, H), float("nan"), device="cuda") if res else None
+    ws = torch.empty((1 << 16,), dtype=torch.uint8, device="cuda")
+    L.check(m._lib.taco_gru_cell_f32(m._handle, stream(), name.encode(), ptr(dev(x, torch.float32)), ptr(hd), R,
+                                     ptr(outr), ptr(ws), 1 << 16))
+    torch.cuda.synchronize()
+    assert maxabs(hd.cpu().numpy(), hn) < TOL
+    if res:
+        assert maxabs(outr.cpu().numpy(), hn + x) < TOL
+
+
+@pytest.mark.parametrize("atype", ["bah", "bah_norm", "bah_mon"])
+@pytest.mark.parametrize("T_in", [1, 7, 64, 150])
+def test_attention_step(atype, T_in):
+    import torch
+    import taco_amd
+    ohp = tiny_hp(attention_type=atype)
+    w = O.init_weights(ohp, 1, 9)
+    if atype == "bah_mon":
+        w["attention/attention_score_bias"] = np.float32(-0.7).reshape(())
+    m = build_model(ohp, w)
+    rs = np.random.RandomState(T_in)
+    B, A, D = 4, ohp.attention_size, 2 * ohp.enc_rnn_size
+    cell = rs.randn(B, ohp.attention_state_size)
+    keys, values = rs.randn(B, T_in, A), rs.randn(B, T_in, D)
+    prev = rs.dirichlet(np.ones(T_in), B)
+    q = O.dense(cell, w, "attention/query_layer", bias=False)
+    a_ref = O.attention_alignments(q, keys, prev, w, atype)
+    c_ref = np.einsum("bj,bjd->bd", a_ref, values)
+    al = torch.full((B, T_in), float("nan"), device="cuda")
+    cx = torch.full((B, D), float("nan"), device="cuda")
+    ws = torch.empty((1 << 16,), dtype=torch.uint8, device="cuda")
+    taco_amd._lib.check(m._lib.taco_attention_step_f32(
+        m._handle, stream(), ptr(dev(cell, torch.float32)), ptr(dev(keys, torch.float32)), ptr(dev(values, torch.float32)),
+        ptr(dev(prev, torch.float32)), B, T_in, ptr(al), ptr(cx), ptr(ws), 1 << 16))
+    torch.cuda.synchronize()
+    assert maxabs(al.cpu().numpy(), a_ref) < 2e-6
+    assert maxabs(cx.cpu().numpy(), c_ref) < 2e-5

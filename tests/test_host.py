@@ -1,0 +1,143 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the tensor
+list agrees with the oracle, hparams/IO helpers, error behaviour that needs no GPU."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import taco_oracle as O
+import taco_amd
+from taco_amd import _lib
+from util import tiny_hp, to_product_hp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_header_symbol():
+    lib = _lib.load_library()
+    assert lib.taco_abi_version() == 1
+    header = open(os.path.join(ROOT, "include", "taco_abi.h")).read()
+    declared = set(re.findall(r"\b(taco_[a-z0-9_]+)\s*\(", header))
+    declared -= {"taco_model", "taco_plan", "taco_hparams"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), "header declares %s but libtaco_hip.so does not export it" % name
+        assert name in _lib.PROTOTYPES, "%s has no ctypes prototype" % name
+
+
+def test_c_struct_layout_matches_header_order():
+    header = open(os.path.join(ROOT, "include", "taco_abi.h")).read()
+    body = header[header.index("typedef struct {"):header.index("} taco_hparams;")]
+    names = [n.split("[")[0] for n in re.findall(r"\b([a-z_]+(?:\[4\])?)\s*[,;]", re.sub(r"/\*.*?\*/", "", body, flags=re.S))]
+    assert names == [f[0] for f in _lib.TacoHParams._fields_]
+
+
+@pytest.mark.parametrize("ns,mt", [(1, "single"), (4, "deepvoice")])
+def test_weight_spec_equals_oracle(ns, mt):
+    for ohp in (O.OracleHParams(model_type=mt), tiny_hp(model_type=mt), tiny_hp(model_type=mt, attention_type="bah_norm")):
+        spec = dict(taco_amd.weights.weight_spec(to_product_hp(ohp), ns))
+        assert spec == O.weight_shapes(ohp, ns)
+
+
+def test_speaker_embedding_size_one_uses_tables():
+    ohp = tiny_hp(model_type="deepvoice", speaker_embedding_size=1)
+    spec = dict(taco_amd.weights.weight_spec(to_product_hp(ohp), 3))
+    assert spec == O.weight_shapes(ohp, 3) and "spk/before_highway/table" in spec and "speaker_embedding" not in spec
+
+
+def test_unknown_types_raise_like_the_reference():
+    hp = taco_amd.hparams.copy(model_type="bogus")
+    with pytest.raises(Exception, match=r"Unkown multi-speaker model type"):
+        taco_amd.weights.weight_spec(hp, 2)
+    hp = taco_amd.hparams.copy(attention_type="luong")       # LuongAttention is never imported: tacotron.py:138-150
+    with pytest.raises(Exception, match=r"Unkown attention type"):
+        taco_amd.weights.weight_spec(hp, 1)
+
+
+def test_simple_model_type_fails_loudly():
+    hp = taco_amd.hparams.copy(model_type="simple")
+    with pytest.raises(_lib.TacoError, match="not built yet"):
+        taco_amd.weights.weight_spec(hp, 2)
+
+
+def test_set_weight_shape_errors():
+    lib = _lib.load_library()
+    chp = _lib.to_c_hparams(taco_amd.hparams, 1)
+    h = C.c_void_p()
+    _lib.check(lib.taco_model_create(C.byref(chp), 0, C.byref(h)))
+    bad = np.zeros((3, 3), np.float32)
+    shp = (C.c_int64 * 2)(3, 3)
+    assert lib.taco_model_set_weight(h, b"embedding", bad.ctypes.data_as(C.c_void_p), shp, 2) == _lib.TACO_ERR_SHAPE
+    assert b"embedding" in lib.taco_last_error()
+    assert lib.taco_model_set_weight(h, b"nope", bad.ctypes.data_as(C.c_void_p), shp, 2) == _lib.TACO_ERR_ARG
+    assert lib.taco_model_finalize(h) == _lib.TACO_ERR_STATE       # weights missing
+    lib.taco_model_destroy(h)
+
+
+def test_workspace_bytes_is_monotone_and_positive():
+    lib = _lib.load_library()
+    chp = _lib.to_c_hparams(taco_amd.hparams, 1)
+    h = C.c_void_p()
+    _lib.check(lib.taco_model_create(C.byref(chp), 0, C.byref(h)))
+    a = lib.taco_workspace_bytes(h, 8, 64, 50)
+    b = lib.taco_workspace_bytes(h, 32, 128, 128)
+    assert 0 < a < b
+    # C2: bank [16384,2048] + xproj [16384,1536] fp32 dominate -> a few hundred MB
+    assert 2e8 < b < 1e9
+    lib.taco_model_destroy(h)
+
+
+def test_random_weights_follow_reference_initialisers():
+    w = taco_amd.weights.random_weights(taco_amd.hparams, 1, seed=0)
+    assert np.all(w["encoder_cbhg/bigru/fw/gates/bias"] == 1.0)
+    assert np.all(w["encoder_cbhg/highway_1/T/bias"] == -1.0)
+    assert np.all(w["prenet/dense_1/bias"] == 0.0)
+    assert np.abs(w["embedding"]).max() <= 1.0 + 1e-6                       # truncated at 2 sigma, sigma 0.5
+    lim = np.sqrt(6.0 / (256 + 256))
+    assert np.abs(w["prenet/dense_1/kernel"]).max() <= lim + 1e-7
+    assert w["attention/attention_score_bias"].shape == ()
+
+
+def test_weights_roundtrip_safetensors(tmp_path):
+    ohp = tiny_hp()
+    w = O.init_weights(ohp, 1, 0)
+    p = str(tmp_path / "model.ckpt-7.safetensors")
+    taco_amd.weights.save_weights(p, w)
+    w2 = taco_amd.weights.load_weights(p)
+    assert set(w) == set(w2)
+    for k in w:
+        assert w[k].shape == w2[k].shape and np.array_equal(w[k], w2[k])
+
+
+def test_hparams_json_roundtrip(tmp_path):
+    hp = taco_amd.hparams.copy(reduction_factor=5, attention_type="bah")
+    taco_amd.save_hparams(str(tmp_path), hp)
+    hp2 = taco_amd.load_hparams(taco_amd.hparams.copy(), str(tmp_path))
+    assert hp2.reduction_factor == 5 and hp2.attention_type == "bah"
+    assert json.load(open(tmp_path / "params.json"))["enc_bank_size"] == 16
+
+
+def test_input_lengths_rule():
+    toks = np.array([[5, 6, 1, 0, 0], [7, 8, 9, 10, 1], [3, 3, 3, 3, 3]])
+    assert taco_amd.input_lengths_from_tokens(toks).tolist() == [2, 4, 0]     # synthesizer.py:120 (no EOS -> 0)
+
+
+def test_shard_range_partitions_the_batch():
+    from taco_amd.dist import shard_range
+    for n, w in [(256, 8), (32, 3), (5, 8), (1, 1)]:
+        parts = [shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in parts) - min(b - a for a, b in parts) <= 1
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert "taco_oracle" not in src and "oracle/" not in src, f
