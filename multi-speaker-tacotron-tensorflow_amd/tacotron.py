@@ -81,7 +81,7 @@ class Tacotron(object):
         """dict name -> float32 array (canonical names, weights.py).  Must precede initialize()."""
         if self._handle is not None:
             raise RuntimeError("load_weights() must be called before initialize()")
-        self._weights = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+        self._weights = {k: np.array(v, dtype=np.float32, order='C') for k, v in weights.items()}   # keeps rank 0
 
     def _build(self, num_speakers, device, seed=0):
         if not torch.cuda.is_available():

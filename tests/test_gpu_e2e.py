@@ -183,7 +183,8 @@ def test_graph_replay_equals_eager_and_is_repeatable():
     stop = torch.zeros((1,), dtype=torch.int32, device="cuda")
     nb = int(m._lib.taco_workspace_bytes(m._handle, B, T_in, n))
     ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
-    taco_amd._lib.check(m._lib.taco_forward_infer(m._handle, stream(), ptr(dev(ids)), ptr(dev(L)), ptr(None), B, T_in, n,
+    idd, Ld = dev(ids), dev(L)
+    taco_amd._lib.check(m._lib.taco_forward_infer(m._handle, stream(), ptr(idd), ptr(Ld), ptr(None), B, T_in, n,
                                                   ptr(None), ptr(mel), ptr(lin), ptr(al), ptr(stop), ptr(ws), nb))
     torch.cuda.synchronize()
     assert np.array_equal(mel.cpu().numpy(), mel_g) and np.array_equal(lin.cpu().numpy(), lin_g)
@@ -199,7 +200,8 @@ def test_workspace_too_small_is_an_error_not_a_crash():
     ids, L = O.synthetic_inputs(2, 6, 40)
     ws = torch.empty((1024,), dtype=torch.uint8, device="cuda")
     out = torch.empty((1 << 16,), device="cuda")
-    rc = m._lib.taco_forward_infer(m._handle, stream(), ptr(dev(ids)), ptr(dev(L)), ptr(None), 2, 6, 3, ptr(None),
+    idd, Ld = dev(ids), dev(L)
+    rc = m._lib.taco_forward_infer(m._handle, stream(), ptr(idd), ptr(Ld), ptr(None), 2, 6, 3, ptr(None),
                                    ptr(out), ptr(out), ptr(out), ptr(None), ptr(ws), 1024)
     assert rc == taco_amd._lib.TACO_ERR_STATE and b"workspace too small" in m._lib.taco_last_error()
 

@@ -27,7 +27,8 @@ def _conv(ctx, layer, x, act, mpw=1):
     B, T, _ = x.shape
     cout = w[layer + "/kernel"].shape[-1]
     out = torch.full((B, T, cout), float("nan"), device="cuda")
-    L.check(m._lib.taco_conv1d_bn_f32(m._handle, stream(), layer.encode(), ptr(dev(x, torch.float32)), B, T, act, mpw, ptr(out)))
+    xd = dev(x, torch.float32)      # keep a reference: the allocator may reuse a freed temporary
+    L.check(m._lib.taco_conv1d_bn_f32(m._handle, stream(), layer.encode(), ptr(xd), B, T, act, mpw, ptr(out)))
     torch.cuda.synchronize()
     return out.cpu().numpy()
 
@@ -79,7 +80,8 @@ def test_dense_layers_big_and_skinny(ctx, layer, rows):
     rs = np.random.RandomState(rows)
     x = rs.randn(rows, k.shape[0])
     out = torch.full((rows, k.shape[1]), float("nan"), device="cuda")
-    L.check(m._lib.taco_dense_f32(m._handle, stream(), layer.encode(), ptr(dev(x, torch.float32)), rows, 1, ptr(out)))
+    xd = dev(x, torch.float32)
+    L.check(m._lib.taco_dense_f32(m._handle, stream(), layer.encode(), ptr(xd), rows, 1, ptr(out)))
     torch.cuda.synchronize()
     ref = O.dense(x, w, layer, O.relu, bias=(layer + "/bias") in w)
     assert maxabs(out.cpu().numpy(), ref) < TOL
@@ -92,7 +94,8 @@ def test_highway(ctx):
     for scope, D in (("encoder_cbhg", ohp.enc_rnn_size), ("post_cbhg", ohp.post_rnn_size)):
         x = rs.randn(77, D)
         out = torch.full((77, D), float("nan"), device="cuda")
-        L.check(m._lib.taco_highway_f32(m._handle, stream(), (scope + "/highway_2").encode(), ptr(dev(x, torch.float32)), 77, ptr(out)))
+        xd = dev(x, torch.float32)
+        L.check(m._lib.taco_highway_f32(m._handle, stream(), (scope + "/highway_2").encode(), ptr(xd), 77, ptr(out)))
         torch.cuda.synchronize()
         assert maxabs(out.cpu().numpy(), O.highwaynet(x, w, scope + "/highway_2")) < TOL
 
@@ -111,16 +114,16 @@ def test_bigru_with_lengths_and_init_state(ctx, B):
     out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
-    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(dev(x, torch.float32)), ptr(dev(lens)),
-                                  ptr(dev(init, torch.float32)), B, T, ptr(out), ptr(ws), n))
+    xd, ld, idv = dev(x, torch.float32), dev(lens), dev(init, torch.float32)
+    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(xd), ptr(ld), ptr(idv), B, T, ptr(out), ptr(ws), n))
     torch.cuda.synchronize()
     assert maxabs(out.cpu().numpy(), ref) < 1e-4
     # post-net flavour: no lengths, zero init
     Hp = ohp.post_rnn_size
     xp = rs.randn(B, T, Hp)
     outp = torch.full((B, T, 2 * Hp), float("nan"), device="cuda")
-    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(dev(xp, torch.float32)), ptr(None), ptr(None),
-                                  B, T, ptr(outp), ptr(ws), n))
+    xpd = dev(xp, torch.float32)
+    L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(xpd), ptr(None), ptr(None), B, T, ptr(outp), ptr(ws), n))
     torch.cuda.synchronize()
     assert maxabs(outp.cpu().numpy(), O.bidirectional_gru(xp, None, w, "post_cbhg/bigru")) < 1e-4
 
@@ -138,8 +141,8 @@ def test_decoder_gru_cell(ctx, name, res):
     hd = dev(h, torch.float32)
     outr = torch.full((R, H), float("nan"), device="cuda") if res else None
     ws = torch.empty((1 << 16,), dtype=torch.uint8, device="cuda")
-    L.check(m._lib.taco_gru_cell_f32(m._handle, stream(), name.encode(), ptr(dev(x, torch.float32)), ptr(hd), R,
-                                     ptr(outr), ptr(ws), 1 << 16))
+    xd = dev(x, torch.float32)
+    L.check(m._lib.taco_gru_cell_f32(m._handle, stream(), name.encode(), ptr(xd), ptr(hd), R, ptr(outr), ptr(ws), 1 << 16))
     torch.cuda.synchronize()
     assert maxabs(hd.cpu().numpy(), hn) < TOL
     if res:
@@ -167,9 +170,9 @@ def test_attention_step(atype, T_in):
     al = torch.full((B, T_in), float("nan"), device="cuda")
     cx = torch.full((B, D), float("nan"), device="cuda")
     ws = torch.empty((1 << 16,), dtype=torch.uint8, device="cuda")
+    cd, kd, vd, pd = (dev(t, torch.float32) for t in (cell, keys, values, prev))
     taco_amd._lib.check(m._lib.taco_attention_step_f32(
-        m._handle, stream(), ptr(dev(cell, torch.float32)), ptr(dev(keys, torch.float32)), ptr(dev(values, torch.float32)),
-        ptr(dev(prev, torch.float32)), B, T_in, ptr(al), ptr(cx), ptr(ws), 1 << 16))
+        m._handle, stream(), ptr(cd), ptr(kd), ptr(vd), ptr(pd), B, T_in, ptr(al), ptr(cx), ptr(ws), 1 << 16))
     torch.cuda.synchronize()
     assert maxabs(al.cpu().numpy(), a_ref) < 2e-6
     assert maxabs(cx.cpu().numpy(), c_ref) < 2e-5
