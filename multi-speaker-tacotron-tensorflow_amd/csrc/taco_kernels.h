@@ -25,6 +25,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define TACO_KC 64            // channels staged per LDS chunk
 #define TACO_LDSW (TACO_KC + 4) // LDS row stride in floats: (68/4)=17 odd -> ds_read_b128 conflict-free
 
+// Kernel-argument structs are read with scalar loads.  Left alone, hipcc sinks each field's s_load to
+// its first use inside a branch and waits for it there: dozens of serialized scalar-memory round trips
+// per launch (measured: ~5 us of a 7 us launch).  PIN forces a value to be materialised in an SGPR at
+// the top of the kernel, so all fields arrive in one batch of s_load_dwordx8/x16.
+#define PIN(x) asm volatile("" : "+s"(x))
+
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_SOFTSIGN = 4 };
 
 __device__ __forceinline__ float taco_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -64,16 +70,19 @@ struct GemmVar {
 struct GemmArgs {
   const float* x;         // input rows [M, ldx] (or embedding table when gather != null)
   const int* gather;      // optional [M] row indices into x
-  const GemmVar* vars;    // device array, one per blockIdx.z
   const float* res;       // optional residual [M, ldres]
   const float* rowvec;    // optional per-batch-row vector [M/T, ldrv] (deepvoice before_highway)
+  const int* rev_len;     // with rev_col0 >= 0: columns >= rev_col0 of row (b,t) are stored at row (b, L_b-1-t) for t < L_b
+                          // (tf.reverse_sequence, A.7); null lengths = T
   float* out;             // [M, ldo]
-  int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok;
+  int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0;
+  GemmVar v[16];          // one per blockIdx.z (conv-bank widths); by value so the fields arrive by scalar loads
 };
 
 // One float4 of the (optionally max-pooled, optionally gathered) input at flat row m, channel c.
 // max_pooling1d(pool=w, stride 1, 'same') pads (w-1)/2 left and never lets padding win (A.3).
-__device__ __forceinline__ float4 taco_stage_load(const GemmArgs& a, int m, int c) {
+template <typename ArgsT>
+__device__ __forceinline__ float4 taco_stage_load(const ArgsT& a, int m, int c) {
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (m < 0 || m >= a.M || c >= a.Cin) return z;
   if (a.mpw <= 1) {
@@ -113,11 +122,20 @@ __device__ __forceinline__ float4 taco_stage_load(const GemmArgs& a, int m, int 
 // Workgroup = WM x WN x KS waves; each wave owns TM x TN MFMA tiles of 32x32; KS waves split the
 // (tap, k8-group) iteration space of every staged chunk and are reduced through LDS at the end.
 template <int WM, int WN, int TM, int TN, int KS, bool DUAL>
-__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in) {
   constexpr int NTHR = 64 * WM * WN * KS;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const GemmVar v = a.vars[blockIdx.z];
+  struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
+           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0; } a =
+      {a_in.x, a_in.gather, a_in.res, a_in.rowvec, a_in.rev_len, a_in.out, a_in.ldx, a_in.M, a_in.T, a_in.Cin, a_in.cin_pad,
+       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0};
+  PIN(a.rev_len); PIN(a.rev_col0);
+  PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out);
+  PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.cin_pad); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
+  GemmVar v = a_in.v[blockIdx.z];
+  PIN(v.wp); PIN(v.wp2); PIN(v.bias); PIN(v.bias2); PIN(v.bn_scale); PIN(v.bn_shift);
+  PIN(v.kw); PIN(v.padl); PIN(v.Kq); PIN(v.NT); PIN(v.N); PIN(v.coff);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
@@ -257,7 +275,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a) {
           if (a.res) val += a.res[(size_t)row * a.ldres + col];        // modules.py:62-69
           if (a.rowvec) val += a.rowvec[(size_t)(row / a.T) * a.ldrv + col];
         }
-        a.out[(size_t)row * a.ldo + v.coff + col] = val;
+        int orow = row;
+        if (a.rev_col0 >= 0 && col >= a.rev_col0) {
+          const int bb = row / a.T, tt = row - bb * a.T;
+          const int L = a.rev_len ? a.rev_len[bb] : a.T;
+          if (tt < L) orow = bb * a.T + (L - 1 - tt);
+        }
+        a.out[(size_t)orow * a.ldo + v.coff + col] = val;
       }
     }
 }
@@ -278,14 +302,15 @@ struct SkJob {
   const float* x0; const float* x1; const int* gather0;
   const float* wp; const float* bias;
   const float* e0;   // GATES/CAND: h state [R, lde0]
-  const float* e1;   // GATES: precomputed x-part of gates or null; CAND: x-part of candidate or null
+  const float* e1;   // GATES: precomputed x-part of the gates (BiGRU hoist) or null; CAND: x-part of candidate
   const float* e2;   // CAND: u [R, lde2]
   const float* e3;   // CAND: residual input (ResidualWrapper, tacotron.py:172) or null
   float* o0;         // LINEAR: out; GATES: r*h; CAND: new state h (may alias e0)
   float* o1;         // GATES: u; CAND: h' + residual (or null)
-  float* o2;         // CAND: sequence output [R, T, ldo2] (BiGRU) or null ; LINEAR: per-row nonzero flag (int*) or null
+  float* o2;         // GATES: x-part of the candidate (columns >= 2H) or null; CAND: sequence output [R,T,ldo2]
+                     // (BiGRU) or null; LINEAR: per-row non-zero flag (int*) or null
   const int* lengths;  // BiGRU sequence_length or null
-  int ldx0, ldx1, K0, K, Kq, N, H, epi, act;
+  int ldx0, ldx1, K0, K, Kq, N, H, act;
   int lde0, lde1, lde2, lde3, ldo0, ldo1, ldo2;
   int step, T, dir, seq_coff;   // BiGRU scan position: dir 0 forward, 1 backward (reverse_sequence)
   int tile0;                    // first workgroup of this job
@@ -294,13 +319,14 @@ struct SkJob {
 struct SkArgs { int R; int njobs; SkJob j[SK_MAXJOBS]; };
 
 #define SK_NW 8
+#define SK_CH 4   // k16 groups per wave whose loads are issued together before any MFMA
 
-__device__ __forceinline__ float4 taco_sk_load(const SkJob& jb, int r, int k) {
-  // X[r][k..k+3] of the concatenation [x0 (K0 cols) | x1 (K-K0 cols)]
-  const float* p; int rem;
-  if (k < jb.K0) { p = jb.x0 + (size_t)(jb.gather0 ? jb.gather0[r] : r) * jb.ldx0 + k; rem = jb.K0 - k; }
-  else { p = jb.x1 + (size_t)r * jb.ldx1 + (k - jb.K0); rem = jb.K - k; }
-  if (rem >= 4 && ((reinterpret_cast<uintptr_t>(p) & 15) == 0)) return *reinterpret_cast<const float4*>(p);
+// X[r][k..k+3] of the concatenation [x0 (K0 cols) | x1 (K-K0 cols)]; p0/p1 = row base pointers.
+template <bool VEC>
+__device__ __forceinline__ float4 taco_sk_load(const SkJob& jb, const float* p0, const float* p1, int k) {
+  const float* p = (k < jb.K0) ? p0 + k : p1 + (k - jb.K0);
+  if (VEC) return *reinterpret_cast<const float4*>(p);
+  const int rem = (k < jb.K0) ? jb.K0 - k : jb.K - k;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rem > 0) v.x = p[0];
   if (rem > 1) v.y = p[1];
@@ -309,42 +335,103 @@ __device__ __forceinline__ float4 taco_sk_load(const SkJob& jb, int r, int k) {
   return v;
 }
 
-template <int RT>
+// Latency structure (this kernel is a chain of round trips, not bandwidth): the job descriptor arrives
+// in one batch of scalar loads (PIN); every epilogue operand (bias, h, u, x-part, residual, length) is
+// requested first; then all weight/activation fragments of up to SK_CH k16-groups per wave are
+// requested before the first MFMA -- one memory round trip covers everything; then MFMA, LDS reduction
+// over the 8 K-slices, epilogue on the prefetched operands.  EPI and VEC are compile-time so the
+// prologue is branch-free.  The BiGRU x-part is stored time-reversed for the backward direction by the
+// hoisted GEMM, so its address does not depend on `lengths` (only the final store position does).
+template <int RT, int EPI, bool VEC>
 __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   __shared__ float red[SK_NW * RT * 256];
+  constexpr int NE = (RT * 256 + 64 * SK_NW - 1) / (64 * SK_NW);   // outputs per thread
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int ji = 0;
 #pragma unroll
   for (int q = 1; q < SK_MAXJOBS; ++q)
     if (q < a.njobs && (int)blockIdx.x >= a.j[q].tile0) ji = q;
-  const SkJob& jb = a.j[ji];
+  SkJob jb = a.j[ji];
+  PIN(jb.x0); PIN(jb.x1); PIN(jb.gather0); PIN(jb.wp); PIN(jb.bias); PIN(jb.e0); PIN(jb.e1); PIN(jb.e2); PIN(jb.e3);
+  PIN(jb.o0); PIN(jb.o1); PIN(jb.o2); PIN(jb.lengths);
+  PIN(jb.ldx0); PIN(jb.ldx1); PIN(jb.K0); PIN(jb.K); PIN(jb.Kq); PIN(jb.N); PIN(jb.H); PIN(jb.act);
+  PIN(jb.lde0); PIN(jb.lde1); PIN(jb.lde2); PIN(jb.lde3); PIN(jb.ldo0); PIN(jb.ldo1); PIN(jb.ldo2);
+  PIN(jb.step); PIN(jb.T); PIN(jb.dir); PIN(jb.seq_coff); PIN(jb.tile0);
   const int nt = blockIdx.x - jb.tile0;
   const int l15 = lane & 15, lq = lane >> 4;
-  const int R = a.R;
+  int R = a.R;
+  PIN(R);
 
+  // ---- (1) epilogue operands ----
+  float pb[NE], pe0[NE], pe1[NE], pe2[NE], pe3[NE];
+  int pL[NE]; bool pvalid[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int idx = tid + e * 64 * SK_NW;
+    const int rt = idx >> 8, w = idx & 255, reg = w >> 6, ln = w & 63;
+    const int r = rt * 16 + (ln >> 4) * 4 + reg;       // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    const int n = nt * 16 + (ln & 15);
+    const bool valid = (idx < RT * 256) && r < R && n < jb.N;
+    pvalid[e] = valid;
+    const int rr = valid ? r : 0, nn = valid ? n : 0;    // clamped so every load below is unconditional
+    pb[e] = jb.bias ? jb.bias[nn] : 0.f;
+    pe0[e] = pe1[e] = pe2[e] = pe3[e] = 0.f; pL[e] = jb.T;
+    if (EPI != EPI_LINEAR) {
+      if (jb.lengths) pL[e] = jb.lengths[rr];
+      const size_t xrow = (jb.T > 0) ? ((size_t)rr * jb.T + jb.step) : (size_t)rr;
+      if (EPI == EPI_GRU_GATES) {
+        if (jb.e1) pe1[e] = jb.e1[xrow * jb.lde1 + nn];
+        pe0[e] = jb.e0[(size_t)rr * jb.lde0 + (nn < jb.H ? nn : 0)];
+      } else {
+        pe1[e] = jb.e1[xrow * jb.lde1 + nn];
+        pe0[e] = jb.e0[(size_t)rr * jb.lde0 + nn];
+        pe2[e] = jb.e2[(size_t)rr * jb.lde2 + nn];
+        if (jb.e3) pe3[e] = jb.e3[(size_t)rr * jb.lde3 + nn];
+      }
+    }
+  }
+
+  // ---- (2) fragments, (3) MFMA ----
   f32x4 acc[RT];
+  const float* xp0[RT]; const float* xp1[RT]; bool rok[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+  for (int rt = 0; rt < RT; ++rt) {
+    acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = rt * 16 + l15;
+    rok[rt] = r < R;
+    const int rr = rok[rt] ? r : 0;
+    xp0[rt] = jb.x0 + (size_t)(jb.gather0 ? jb.gather0[rr] : rr) * jb.ldx0;
+    xp1[rt] = jb.x1 ? jb.x1 + (size_t)rr * jb.ldx1 : jb.x0;
+  }
   const int ngroups = jb.Kq >> 2;
-  for (int g = wave; g < ngroups; g += SK_NW) {
-    const int kq = 4 * g + lq;
-    const int k = 4 * kq;
-    const float4 b = *reinterpret_cast<const float4*>(jb.wp + ((size_t)(nt * jb.Kq + kq) * 16 + l15) * 4);
-    float4 x[RT];
+  const float* wbase = jb.wp + ((size_t)nt * jb.Kq * 16 + l15) * 4;
+  for (int g0 = wave; g0 < ngroups; g0 += SK_NW * SK_CH) {
+    float4 b[SK_CH], x[SK_CH][RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const int r = rt * 16 + l15;
-      x[rt] = (r < R && k < jb.K) ? taco_sk_load(jb, r, k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < SK_CH; ++u) {
+      const int g = g0 + u * SK_NW;
+      const bool gok = g < ngroups;
+      const int kq = 4 * (gok ? g : g0) + lq;
+      const int k = 4 * kq;
+      const float4 bl = *reinterpret_cast<const float4*>(wbase + (size_t)kq * 64);
+      b[u] = gok ? bl : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kc = (k < jb.K) ? k : 0;                 // clamped: rows beyond K multiply zero weights
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 xl = taco_sk_load<VEC>(jb, xp0[rt], xp1[rt], kc);
+        x[u][rt] = (rok[rt] && k < jb.K) ? xl : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].x, b.x, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].y, b.y, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].z, b.z, acc[rt], 0, 0, 0);
-      acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[rt].w, b.w, acc[rt], 0, 0, 0);
-    }
+    for (int u = 0; u < SK_CH; ++u)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][rt].x, b[u].x, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][rt].y, b[u].y, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][rt].z, b[u].z, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u][rt].w, b[u].w, acc[rt], 0, 0, 0);
+      }
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -352,43 +439,36 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
     for (int r = 0; r < 4; ++r) red[(wave * RT + rt) * 256 + r * 64 + lane] = acc[rt][r];
   __syncthreads();
 
-  // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg.
-  for (int idx = tid; idx < RT * 256; idx += 64 * SK_NW) {
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    if (!pvalid[e]) continue;
+    const int idx = tid + e * 64 * SK_NW;
     const int rt = idx >> 8, w = idx & 255, reg = w >> 6, ln = w & 63;
-    float s = 0.f;
+    float s = pb[e];
 #pragma unroll
     for (int wv = 0; wv < SK_NW; ++wv) s += red[(wv * RT + rt) * 256 + w];
     const int r = rt * 16 + (ln >> 4) * 4 + reg;
     const int n = nt * 16 + (ln & 15);
-    if (r >= R || n >= jb.N) continue;
-    if (jb.bias) s += jb.bias[n];
-    if (jb.epi == EPI_LINEAR) {
+    if (EPI == EPI_LINEAR) {
       const float y = taco_act(s, jb.act);
       jb.o0[(size_t)r * jb.ldo0 + n] = y;
       if (jb.o2 && y != 0.f) reinterpret_cast<int*>(jb.o2)[r] = 1;   // stop rule helpers.py:29
-      continue;
-    }
-    // BiGRU time mapping (A.7): row active iff step < L; forward t = step, backward t = L-1-step.
-    int t = jb.step; bool active = true;
-    if (jb.T > 0) {
-      const int L = jb.lengths ? jb.lengths[r] : jb.T;
-      active = jb.step < L;
-      t = (jb.dir && active) ? (L - 1 - jb.step) : jb.step;
-    }
-    const size_t xrow = (jb.T > 0) ? ((size_t)r * jb.T + t) : (size_t)r;
-    if (jb.epi == EPI_GRU_GATES) {
-      if (jb.e1) s += jb.e1[xrow * jb.lde1 + n];
-      const float sg = taco_sigmoid(s);
-      if (n < jb.H) jb.o0[(size_t)r * jb.ldo0 + n] = sg * jb.e0[(size_t)r * jb.lde0 + n];
-      else jb.o1[(size_t)r * jb.ldo1 + (n - jb.H)] = sg;
+    } else if (EPI == EPI_GRU_GATES) {
+      if (n < 2 * jb.H) {
+        const float sg = taco_sigmoid(s + pe1[e]);
+        if (n < jb.H) jb.o0[(size_t)r * jb.ldo0 + n] = sg * pe0[e];       // r * h
+        else jb.o1[(size_t)r * jb.ldo1 + (n - jb.H)] = sg;                // u
+      } else {
+        jb.o2[(size_t)r * jb.ldo2 + (n - 2 * jb.H)] = s;                  // x . Wc_x (bias added with the h part)
+      }
     } else {  // EPI_GRU_CAND
-      if (jb.e1) s += jb.e1[xrow * jb.lde1 + n];
-      const float c = tanhf(s);
-      const float h = jb.e0[(size_t)r * jb.lde0 + n];
-      const float u = jb.e2[(size_t)r * jb.lde2 + n];
-      const float hn = u * h + (1.f - u) * c;
+      // BiGRU time mapping (A.7): row active iff step < L; forward t = step, backward t = L-1-step.
+      const bool active = (jb.T <= 0) || jb.step < pL[e];
+      const int t = (jb.dir && active) ? (pL[e] - 1 - jb.step) : jb.step;
+      const float c = tanhf(s + pe1[e]);
+      const float hn = pe2[e] * pe0[e] + (1.f - pe2[e]) * c;            // u*h + (1-u)*c
       if (active) jb.o0[(size_t)r * jb.ldo0 + n] = hn;
-      if (jb.o1) jb.o1[(size_t)r * jb.ldo1 + n] = hn + (jb.e3 ? jb.e3[(size_t)r * jb.lde3 + n] : 0.f);
+      if (jb.o1) jb.o1[(size_t)r * jb.ldo1 + n] = hn + pe3[e];
       if (jb.o2) jb.o2[((size_t)r * jb.T + t) * jb.ldo2 + jb.seq_coff + n] = active ? hn : 0.f;
     }
   }
@@ -413,6 +493,8 @@ struct AttnArgs {
 
 #define ATT_NW 8
 #define ATT_MAXT 2048
+#define ATT_JU 4     // score iterations (of 32 encoder positions each) whose key loads are issued together
+#define ATT_VU 16    // value rows per wave whose loads are issued together (before the normaliser)
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -433,8 +515,19 @@ __device__ __forceinline__ float wave_scan(float x, int lane) {
   }
   return x;
 }
+// tanh(x) = 1 - 2/(1 + e^{2x}) on v_exp_f32 / v_rcp_f32 (each ~1 ulp): abs error < 4e-7, exact limits +-1.
+__device__ __forceinline__ float taco_tanh_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);   // e^{2x}
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
 
-__global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a) {
+// One workgroup (8 waves) per batch row.  Everything a step needs from HBM/L2 -- the row's keys
+// [T_in, A] and values [T_in, D] -- is requested up front in two bursts (scores burst; values burst
+// before the serial normaliser), so a step costs ~one memory round trip plus the tanh/exp math.
+__global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) {
+  AttnArgs a = a_in;
+  PIN(a.q); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
+  PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps);
   __shared__ float sc[ATT_MAXT];     // scores -> alignments
   __shared__ float tmp[ATT_MAXT];
   __shared__ float tmp2[ATT_MAXT];
@@ -443,29 +536,67 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T_in;
   float* al = a.align + (size_t)b * T;
+  const float* vrow = a.values + (size_t)b * T * a.D;
+
+  // values burst for the first 256 output channels: wave w owns positions j = w + 8*i
+  float4 vpre[ATT_VU];
+  {
+    const int d = lane * 4;
+#pragma unroll
+    for (int i = 0; i < ATT_VU; ++i) {
+      const int j = wave + ATT_NW * i;
+      vpre[i] = (j < T && d < a.D) ? *reinterpret_cast<const float4*>(vrow + (size_t)j * a.D + d)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
 
   if (a.manual) {
     for (int j = tid; j < T; j += 64 * ATT_NW) sc[j] = a.manual[((size_t)b * a.n_steps + a.step) * T + j];
     __syncthreads();
   } else {
     // scores: e[j] = sum_a v[a] * tanh(keys[b,j,a] + q[b,a] (+ b[a]))   (_bahdanau_score, A.9)
+    // 16 lanes per encoder position; lane covers channels c = (lane&15)*4 + 64*m.
+    const int l16 = lane & 15, grp = lane >> 4;
     const float* qb = a.q + (size_t)b * a.A;
-    for (int j = wave; j < T; j += ATT_NW) {
-      const float* kr = a.keys + ((size_t)b * T + j) * a.A;
-      float part = 0.f;
-      for (int c = lane * 4; c < a.A; c += 256) {
-        const float4 k4 = *reinterpret_cast<const float4*>(kr + c);
-        const float4 q4 = *reinterpret_cast<const float4*>(qb + c);
-        const float4 v4 = *reinterpret_cast<const float4*>(a.v + c);
-        float4 s4 = make_float4(k4.x + q4.x, k4.y + q4.y, k4.z + q4.z, k4.w + q4.w);
-        if (a.battn) {
-          const float4 b4 = *reinterpret_cast<const float4*>(a.battn + c);
-          s4.x += b4.x; s4.y += b4.y; s4.z += b4.z; s4.w += b4.w;
+    const float* krow = a.keys + (size_t)b * T * a.A;
+    for (int j0 = 0; j0 < T; j0 += 32 * ATT_JU) {
+      float part[ATT_JU];
+#pragma unroll
+      for (int u = 0; u < ATT_JU; ++u) part[u] = 0.f;
+      for (int c0 = 0; c0 < a.A; c0 += 256) {
+        float4 q4[4], v4[4], k4[ATT_JU][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = c0 + l16 * 4 + 64 * m;
+          const bool ok = c < a.A;
+          q4[m] = ok ? *reinterpret_cast<const float4*>(qb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v4[m] = ok ? *reinterpret_cast<const float4*>(a.v + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok && a.battn) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.battn + c);
+            q4[m].x += b4.x; q4[m].y += b4.y; q4[m].z += b4.z; q4[m].w += b4.w;
+          }
+#pragma unroll
+          for (int u = 0; u < ATT_JU; ++u) {
+            const int j = j0 + 32 * u + wave * 4 + grp;
+            k4[u][m] = (ok && j < T) ? *reinterpret_cast<const float4*>(krow + (size_t)j * a.A + c)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
-        part += v4.x * tanhf(s4.x) + v4.y * tanhf(s4.y) + v4.z * tanhf(s4.z) + v4.w * tanhf(s4.w);
+#pragma unroll
+        for (int u = 0; u < ATT_JU; ++u)
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            part[u] += v4[m].x * taco_tanh_fast(k4[u][m].x + q4[m].x) + v4[m].y * taco_tanh_fast(k4[u][m].y + q4[m].y) +
+                       v4[m].z * taco_tanh_fast(k4[u][m].z + q4[m].z) + v4[m].w * taco_tanh_fast(k4[u][m].w + q4[m].w);
+          }
       }
-      part = wave_sum(part);
-      if (lane == 0) sc[j] = part;
+#pragma unroll
+      for (int u = 0; u < ATT_JU; ++u) {
+        float p = part[u];
+        p += __shfl_xor(p, 8, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 1, 64);
+        const int j = j0 + 32 * u + wave * 4 + grp;
+        if (l16 == 0 && j < T) sc[j] = p;
+      }
     }
     __syncthreads();
     if (wave == 0) {
@@ -517,9 +648,18 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a) {
     const int d = d0 + lane * 4;
     float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (d < a.D) {
-      for (int j = wave; j < T; j += ATT_NW) {
+      int i = 0;
+      if (d0 == 0) {   // the prefetched burst
+#pragma unroll
+        for (; i < ATT_VU; ++i) {
+          const int j = wave + ATT_NW * i;
+          const float w = (j < T) ? sc[j] : 0.f;
+          c4.x += w * vpre[i].x; c4.y += w * vpre[i].y; c4.z += w * vpre[i].z; c4.w += w * vpre[i].w;
+        }
+      }
+      for (int j = wave + ATT_NW * i; j < T; j += ATT_NW) {
         const float w = sc[j];
-        const float4 v4 = *reinterpret_cast<const float4*>(a.values + ((size_t)b * T + j) * a.D + d);
+        const float4 v4 = *reinterpret_cast<const float4*>(vrow + (size_t)j * a.D + d);
         c4.x += w * v4.x; c4.y += w * v4.y; c4.z += w * v4.z; c4.w += w * v4.w;
       }
     }

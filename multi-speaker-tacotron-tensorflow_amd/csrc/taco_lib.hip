@@ -60,7 +60,7 @@ struct SkW {  // a k_skinny weight
   int K = 0, Kq = 0, N = 0;
   size_t wp = 0, bias = 0;
 };
-struct GruDec { SkW gates, cx, ch; int I = 0, H = 0; };
+struct GruDec { SkW gx, ch; int I = 0, H = 0; };   // gx: [I+H, 3H] = [gates (r|u) | x-rows of candidate]; ch: h-rows of candidate
 struct Cbhg {
   int in_dim = 0, K = 0, C = 0, maxpool = 1, depth = 0, rnn = 0, pw = 3;
   int nproj = 0, proj_dim[4] = {0, 0, 0, 0};   // known from hparams alone (workspace sizing before finalize)
@@ -84,7 +84,6 @@ struct taco_model {
   std::vector<float> harena;
   float* darena = nullptr;
   std::vector<GemmVar> hvars;
-  GemmVar* dvars = nullptr;
   std::map<std::string, ConvL> convs;
   std::map<std::string, SkW> skinny;
   std::map<std::string, GruDec> grus;
@@ -255,8 +254,15 @@ static GruDec make_grudec(taco_model* m, const std::string& name, int I, int H) 
   GruDec g; g.I = I; g.H = H;
   const auto& gk = T_(m, name + "/gates/kernel").data; const auto& gb = T_(m, name + "/gates/bias").data;
   const auto& ck = T_(m, name + "/candidate/kernel").data; const auto& cb = T_(m, name + "/candidate/bias").data;
-  g.gates = pack_w16(m, gk.data(), 2 * H, 0, I + H, 0, 2 * H, gb.data());
-  g.cx = pack_w16(m, ck.data(), H, 0, I, 0, H, nullptr);      // x rows of candidate/kernel
+  // one [I+H, 3H] matrix: columns [0,2H) = gates/kernel, columns [2H,3H) = candidate/kernel rows of x
+  // (rows of h zero: the candidate's h part needs r first and runs in the second launch)
+  std::vector<float> W((size_t)(I + H) * 3 * H, 0.f), b(3 * H, 0.f);
+  for (int i = 0; i < I + H; ++i) {
+    for (int j = 0; j < 2 * H; ++j) W[(size_t)i * 3 * H + j] = gk[(size_t)i * 2 * H + j];
+    if (i < I) for (int j = 0; j < H; ++j) W[(size_t)i * 3 * H + 2 * H + j] = ck[(size_t)i * H + j];
+  }
+  for (int j = 0; j < 2 * H; ++j) b[j] = gb[j];
+  g.gx = pack_w16(m, W.data(), 3 * H, 0, I + H, 0, 3 * H, b.data());
   g.ch = pack_w16(m, ck.data(), H, I, H, 0, H, cb.data());    // h rows of candidate/kernel (+ candidate bias)
   return g;
 }
@@ -335,6 +341,7 @@ struct GemmCall {
   int M = 0, T = 0, mpw = 1, act = ACT_NONE;
   const float* res = nullptr; int ldres = 0;
   const float* rowvec = nullptr; int ldrv = 0;
+  const int* rev_len = nullptr; int rev_col0 = -1;
   float* out = nullptr; int ldo = 0;
 };
 
@@ -363,15 +370,17 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
   GemmArgs a;
   memset(&a, 0, sizeof a);
   const ConvL& L0 = layers[0];
-  a.x = c.x; a.gather = c.gather; a.vars = m->dvars + L0.var_index; a.res = c.res; a.rowvec = c.rowvec; a.out = c.out;
+  a.x = c.x; a.gather = c.gather; a.res = c.res; a.rowvec = c.rowvec; a.out = c.out;
   a.ldx = c.ldx; a.M = c.M; a.T = c.T > 0 ? c.T : c.M; a.Cin = L0.cin; a.cin_pad = L0.cin_pad; a.mpw = c.mpw;
-  a.act = c.act; a.ldres = c.ldres; a.ldrv = c.ldrv; a.ldo = c.ldo;
+  a.act = c.act; a.ldres = c.ldres; a.ldrv = c.ldrv; a.ldo = c.ldo; a.rev_len = c.rev_len; a.rev_col0 = c.rev_col0;
   a.vec_ok = (c.ldx % 4 == 0) && (L0.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.x) & 15) == 0);
   int kw_max = 1, Nmax = 0;
   for (int i = 0; i < nvar; ++i) {
     kw_max = std::max(kw_max, layers[i].kw); Nmax = std::max(Nmax, layers[i].N);
-    if (layers[i].var_index != L0.var_index + i) return fail(TACO_ERR_STATE, "bank variants not contiguous");
+    if (layers[i].var_index < 0) return fail(TACO_ERR_STATE, "layer has no GemmVar");
+    a.v[i] = m->hvars[layers[i].var_index];
   }
+  if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
   const int cfg = pick_cfg(m, c.M, Nmax, nvar);
   if (dual) {
     switch (cfg) {
@@ -399,20 +408,39 @@ static SkJob sk_base(const taco_model* m, const SkW& w, const float* x0, int ldx
 static SkJob sk_linear(const taco_model* m, const SkW& w, const float* x0, int ldx0, int K0, const float* x1, int ldx1,
                        int act, float* out, int ldo) {
   SkJob j = sk_base(m, w, x0, ldx0, K0, x1, ldx1);
-  j.epi = EPI_LINEAR; j.act = act; j.o0 = out; j.ldo0 = ldo;
+  j.act = act; j.o0 = out; j.ldo0 = ldo;
   return j;
 }
-static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs) {
+template <int RT, int EPI>
+static void launch_skinny(hipStream_t st, int tiles, bool vec, const SkArgs& a) {
+  if (vec) hipLaunchKernelGGL((k_skinny<RT, EPI, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else hipLaunchKernelGGL((k_skinny<RT, EPI, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+}
+template <int EPI>
+static void launch_skinny_rt(hipStream_t st, int RT, int tiles, bool vec, const SkArgs& a) {
+  if (RT == 1) launch_skinny<1, EPI>(st, tiles, vec, a);
+  else if (RT == 2) launch_skinny<2, EPI>(st, tiles, vec, a);
+  else launch_skinny<4, EPI>(st, tiles, vec, a);
+}
+// all jobs of one launch share the epilogue type
+static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs, int epi = EPI_LINEAR) {
   if (R > 64) return fail(TACO_ERR_UNSUPPORTED, "batch %d > 64 rows per device is not supported: shard the batch", R);
   SkArgs a;
   memset(&a, 0, sizeof a);
   a.R = R; a.njobs = njobs;
   int tiles = 0;
-  for (int i = 0; i < njobs; ++i) { jobs[i].tile0 = tiles; tiles += cdiv(jobs[i].N, 16); a.j[i] = jobs[i]; }
+  bool vec = true;
+  // float4 activation loads are legal when every row segment is 16-byte aligned and a multiple of 4 long
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  for (int i = 0; i < njobs; ++i) {
+    const SkJob& j = jobs[i];
+    vec = vec && (j.K0 % 4 == 0) && (j.K % 4 == 0) && (j.ldx0 % 4 == 0) && al16(j.x0) && (!j.x1 || ((j.ldx1 % 4 == 0) && al16(j.x1)));
+    jobs[i].tile0 = tiles; tiles += cdiv(jobs[i].N, 16); a.j[i] = jobs[i];
+  }
   const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
-  if (RT == 1) hipLaunchKernelGGL(k_skinny<1>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else if (RT == 2) hipLaunchKernelGGL(k_skinny<2>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else hipLaunchKernelGGL(k_skinny<4>, dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  if (epi == EPI_LINEAR) launch_skinny_rt<EPI_LINEAR>(st, RT, tiles, vec, a);
+  else if (epi == EPI_GRU_GATES) launch_skinny_rt<EPI_GRU_GATES>(st, RT, tiles, vec, a);
+  else launch_skinny_rt<EPI_GRU_CAND>(st, RT, tiles, vec, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -421,16 +449,14 @@ static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs) {
 //   x [R, I] (ldx), h [R, H] updated in place; out_res (optional) = h' + x (ResidualWrapper, tacotron.py:172)
 static int run_gru_cell(const taco_model* m, hipStream_t st, const GruDec& g, int R, const float* x, int ldx,
                         float* h, float* rh, float* u, float* xc, float* out_res) {
-  SkJob ja[2];
-  ja[0] = sk_base(m, g.gates, x, ldx, g.I, h, g.H);
-  ja[0].epi = EPI_GRU_GATES; ja[0].H = g.H; ja[0].e0 = h; ja[0].lde0 = g.H; ja[0].o0 = rh; ja[0].ldo0 = g.H; ja[0].o1 = u; ja[0].ldo1 = g.H;
-  ja[1] = sk_linear(m, g.cx, x, ldx, g.I, nullptr, 0, ACT_NONE, xc, g.H);
-  TRY(run_skinny(st, R, ja, 2));
+  SkJob ja = sk_base(m, g.gx, x, ldx, g.I, h, g.H);
+  ja.H = g.H; ja.e0 = h; ja.lde0 = g.H; ja.o0 = rh; ja.ldo0 = g.H; ja.o1 = u; ja.ldo1 = g.H; ja.o2 = xc; ja.ldo2 = g.H;
+  TRY(run_skinny(st, R, &ja, 1, EPI_GRU_GATES));
   SkJob jb = sk_base(m, g.ch, rh, g.H, g.H, nullptr, 0);
-  jb.epi = EPI_GRU_CAND; jb.H = g.H; jb.e0 = h; jb.lde0 = g.H; jb.e1 = xc; jb.lde1 = g.H; jb.e2 = u; jb.lde2 = g.H;
+  jb.H = g.H; jb.e0 = h; jb.lde0 = g.H; jb.e1 = xc; jb.lde1 = g.H; jb.e2 = u; jb.lde2 = g.H;
   jb.o0 = h; jb.ldo0 = g.H;
   if (out_res) { jb.e3 = x; jb.lde3 = ldx; jb.o1 = out_res; jb.ldo1 = g.H; }
-  TRY(run_skinny(st, R, &jb, 1));
+  TRY(run_skinny(st, R, &jb, 1, EPI_GRU_CAND));
   return 0;
 }
 
@@ -466,7 +492,9 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn, M = B * T;
-  { GemmCall xp; xp.x = x; xp.ldx = c.rnn; xp.M = M; xp.out = w.xproj; xp.ldo = 6 * H;
+  // backward-direction columns are stored time-reversed per row (reverse_sequence), so scan step s reads row s
+  { GemmCall xp; xp.x = x; xp.ldx = c.rnn; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H;
+    xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
   for (int dir = 0; dir < 2; ++dir)
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * H, 256)), dim3(256), 0, st, init_state ? init_state + dir * H : nullptr,
@@ -477,18 +505,18 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const 
     for (int dir = 0; dir < 2; ++dir) {
       float* h = w.h + (size_t)dir * B * H; float* rh = w.rh + (size_t)dir * B * H; float* u = w.u + (size_t)dir * B * H;
       ja[dir] = sk_base(m, c.gh[dir], h, H, H, nullptr, 0);
-      ja[dir].epi = EPI_GRU_GATES; ja[dir].H = H; ja[dir].e0 = h; ja[dir].lde0 = H;
+      ja[dir].H = H; ja[dir].e0 = h; ja[dir].lde0 = H;
       ja[dir].e1 = w.xproj + dir * 3 * H; ja[dir].lde1 = 6 * H;
       ja[dir].o0 = rh; ja[dir].ldo0 = H; ja[dir].o1 = u; ja[dir].ldo1 = H;
-      ja[dir].lengths = lengths; ja[dir].step = s; ja[dir].T = T; ja[dir].dir = dir;
+      ja[dir].step = s; ja[dir].T = T; ja[dir].dir = dir;
       jb[dir] = sk_base(m, c.ch[dir], rh, H, H, nullptr, 0);
-      jb[dir].epi = EPI_GRU_CAND; jb[dir].H = H; jb[dir].e0 = h; jb[dir].lde0 = H;
+      jb[dir].H = H; jb[dir].e0 = h; jb[dir].lde0 = H;
       jb[dir].e1 = w.xproj + dir * 3 * H + 2 * H; jb[dir].lde1 = 6 * H; jb[dir].e2 = u; jb[dir].lde2 = H;
       jb[dir].o0 = h; jb[dir].ldo0 = H; jb[dir].o2 = out; jb[dir].ldo2 = 2 * H; jb[dir].seq_coff = dir * H;
       jb[dir].lengths = lengths; jb[dir].step = s; jb[dir].T = T; jb[dir].dir = dir;
     }
-    TRY(run_skinny(st, B, ja, 2));
-    TRY(run_skinny(st, B, jb, 2));
+    TRY(run_skinny(st, B, ja, 2, EPI_GRU_GATES));
+    TRY(run_skinny(st, B, jb, 2, EPI_GRU_CAND));
   }
   return 0;
 }
@@ -894,8 +922,6 @@ int taco_model_finalize(taco_model* m) {
     v.wp = AP(m, (size_t)v.wp); v.wp2 = AP(m, (size_t)v.wp2); v.bias = AP(m, (size_t)v.bias); v.bias2 = AP(m, (size_t)v.bias2);
     v.bn_scale = AP(m, (size_t)v.bn_scale); v.bn_shift = AP(m, (size_t)v.bn_shift);
   }
-  HIPCHK(hipMalloc((void**)&m->dvars, m->hvars.size() * sizeof(GemmVar)));
-  HIPCHK(hipMemcpy(m->dvars, m->hvars.data(), m->hvars.size() * sizeof(GemmVar), hipMemcpyHostToDevice));
   m->harena.clear(); m->harena.shrink_to_fit();
   m->raw.clear();
   m->finalized = true;
@@ -905,7 +931,6 @@ int taco_model_finalize(taco_model* m) {
 void taco_model_destroy(taco_model* m) {
   if (!m) return;
   if (m->darena) (void)hipFree(m->darena);
-  if (m->dvars) (void)hipFree(m->dvars);
   delete m;
 }
 
