@@ -144,6 +144,13 @@ int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell
 int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
                       float* d_out_res, void* d_workspace, size_t workspace_bytes);
 
+/* Persistent (multi-workgroup, in-kernel synchronised) kernels bound every spin; if one ever expires it sets a
+ * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;
+ * non-zero means the outputs of the affected forward are invalid. */
+int taco_model_device_errors(taco_model* m, int* out);
+/* test hook: 0 = per-step launches for the sequential loops, 1 (default) = persistent row-parallel kernels when they fit */
+int taco_debug_set_persistent(taco_model* m, int on);
+
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
 int taco_debug_force_gemm_config(taco_model* m, int cfg);
 

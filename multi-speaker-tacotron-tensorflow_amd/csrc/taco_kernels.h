@@ -475,6 +475,142 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// row-parallel persistent kernels: streaming mat-vec primitive
+// ------------------------------------------------------------------------------------------------
+// The two sequential loops (BiGRU scans, decoder) are chains of small dependent mat-vecs.  Measured on
+// MI355X (profiles/r01_ubench_*.txt): a dependent kernel launch costs >= 4.5 us once it has to fetch
+// weights, an in-launch all-gather among 8 workgroups ~2.4 us + an LDS-resident slice's MFMA time, while
+// ONE workgroup streams an L2-resident matrix at ~150 GB/s with the FMAs hidden.  Batch rows are
+// independent, so a workgroup that owns R rows and streams every weight matrix from L2 each step needs NO
+// cross-workgroup synchronisation: only __syncthreads.  Weights stay in TF layout [K, N] row-major:
+// thread = 4 consecutive columns x one K-slice, loads are 16 bytes and coalesce over the row.
+#define RP_NT 1024   // threads per workgroup (16 waves: enough 16-byte loads in flight to reach ~150 GB/s)
+
+// partial[(ks*R + r)*N + n] = sum over K-slice ks of x[r][k] * W[k][n].  x in LDS ([R][ldx]); W global.
+// Returns KS (number of K-slices) for the reducer.  No barrier inside.
+template <int R>
+__device__ __forceinline__ int rp_matvec(const float* __restrict__ W, int K, int N, const float* x, int ldx,
+                                         float* part, int tid) {
+  const int NC = N >> 2;
+  int KS = RP_NT / NC; if (KS > K) KS = K; if (KS < 1) KS = 1;
+  const int kper = (K + KS - 1) / KS;
+  const int cg = tid % NC, ks = tid / NC;               // host guarantees N <= 4*RP_NT
+  if (ks < KS) {
+    const int k0 = ks * kper, k1 = min(K, k0 + kper);
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* wp = reinterpret_cast<const float4*>(W) + cg;
+#pragma unroll 8
+    for (int k = k0; k < k1; ++k) {
+      const float4 w = wp[(size_t)k * NC];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float xv = x[r * ldx + k];
+        acc[r].x = fmaf(xv, w.x, acc[r].x); acc[r].y = fmaf(xv, w.y, acc[r].y);
+        acc[r].z = fmaf(xv, w.z, acc[r].z); acc[r].w = fmaf(xv, w.w, acc[r].w);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<float4*>(part + ((size_t)ks * R + r) * N + 4 * cg) = acc[r];
+  }
+  return KS;
+}
+__device__ __forceinline__ float rp_reduce(const float* part, int KS, int RN, int o) {
+  float s = 0.f;
+  for (int ks = 0; ks < KS; ++ks) s += part[(size_t)ks * RN + o];
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bigru_rows : the whole BiGRU scan (K8) as ONE launch, row-parallel
+// ------------------------------------------------------------------------------------------------
+// grid = 2 directions x ceil(B/R) workgroups; workgroup = R batch rows of one direction for all T steps.
+// Per step: gates = h.Wg_h + xg (hoisted GEMM) -> r,u ; c = tanh((r(.)h).Wc_h + xc) ; h' = u*h + (1-u)*c  (A.6)
+// with TF's sequence_length masking / reverse_sequence time mapping (A.7).  The hoisted projection stores the
+// backward direction time-reversed, so step s reads row s for both directions.
+struct BigruRArgs {
+  const float* xproj;   // [B*T, 6H]
+  const float* wg0; const float* wg1;   // h-rows of gates/kernel      [H, 2H] row-major, per direction
+  const float* wc0; const float* wc1;   // h-rows of candidate/kernel  [H, H]
+  const float* h0;      // [B, 2H] initial states (fw | bw) or null
+  const int* lengths;   // [B] or null
+  float* out;           // [B*T, 2H]
+  int B, T, H;
+};
+
+template <int R>
+__global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BigruRArgs a = a_in;
+  PIN(a.xproj); PIN(a.wg0); PIN(a.wg1); PIN(a.wc0); PIN(a.wc1); PIN(a.h0); PIN(a.lengths); PIN(a.out);
+  PIN(a.B); PIN(a.T); PIN(a.H);
+  const int tid = threadIdx.x;
+  const int ngrp = (a.B + R - 1) / R;
+  const int d = blockIdx.x / ngrp, r0 = (blockIdx.x % ngrp) * R;
+  const int B = a.B, T = a.T, H = a.H;
+  const float* Wg = d ? a.wg1 : a.wg0;
+  const float* Wc = d ? a.wc1 : a.wc0;
+  float* hs = smem;                   // [R][H]
+  float* rhs = hs + R * H;            // [R][H]
+  float* us = rhs + R * H;            // [R][H]
+  float* part = us + R * H;           // [KS][R][N] <= RP_NT*R*4 floats
+  for (int i = tid; i < R * H; i += RP_NT) {
+    const int r = i / H, c = i % H, b = r0 + r;
+    hs[i] = (a.h0 && b < B) ? a.h0[(size_t)b * 2 * H + d * H + c] : 0.f;
+  }
+  __syncthreads();
+  constexpr int NE1 = 2, NE2 = 1;     // epilogue outputs per thread (host guarantees R*2H <= 2*RP_NT)
+  for (int s = 0; s < T; ++s) {
+    // x-parts of this thread's outputs: requested now, consumed after the weight stream
+    float xg[NE1], xc[NE2]; int Lr = T;
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) {
+      const int o = tid + e * RP_NT; xg[e] = 0.f;
+      if (o < R * 2 * H) { const int r = o / (2 * H), n = o % (2 * H), b = r0 + r;
+        if (b < B) xg[e] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + n]; }
+    }
+    {
+      const int o = tid; xc[0] = 0.f;
+      if (o < R * H) { const int r = o / H, n = o % H, b = r0 + r;
+        if (b < B) { xc[0] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + 2 * H + n]; if (a.lengths) Lr = a.lengths[b]; } }
+    }
+    // ---- gates ----
+    int KS = rp_matvec<R>(Wg, H, 2 * H, hs, H, part, tid);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) {
+      const int o = tid + e * RP_NT;
+      if (o < R * 2 * H) {
+        const int r = o / (2 * H), n = o % (2 * H);
+        const float sg = taco_sigmoid(rp_reduce(part, KS, R * 2 * H, o) + xg[e]);
+        if (n < H) rhs[r * H + n] = sg * hs[r * H + n];
+        else us[r * H + (n - H)] = sg;
+      }
+    }
+    __syncthreads();
+    // ---- candidate + state update ----
+    KS = rp_matvec<R>(Wc, H, H, rhs, H, part, tid);
+    __syncthreads();
+    {
+      const int o = tid;
+      if (o < R * H) {
+        const int r = o / H, n = o % H, b = r0 + r;
+        const float c = tanhf(rp_reduce(part, KS, R * H, o) + xc[0]);
+        const float h = hs[o], u = us[o];
+        const float hn = u * h + (1.f - u) * c;
+        // BiGRU time mapping (A.7): row active iff s < L; forward t = s, backward t = L-1-s
+        const bool active = s < Lr;
+        const int t = (d && active) ? (Lr - 1 - s) : s;
+        if (active) hs[o] = hn;
+        if (b < B) a.out[((size_t)b * T + t) * 2 * H + d * H + n] = active ? hn : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_attention : one workgroup per batch row
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {

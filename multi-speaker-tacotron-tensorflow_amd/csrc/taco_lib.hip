@@ -72,6 +72,7 @@ struct Cbhg {
   std::vector<ConvL> hw;
   ConvL xproj;              // N = 2 directions x (2H gates | H candidate), biases folded in
   SkW gh[2], ch[2];
+  size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
 };
 
 struct taco_model {
@@ -98,6 +99,8 @@ struct taco_model {
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
   std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
   int force_cfg = -1;
+  unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
+  int persist = 1;             // use the persistent BiGRU kernel when it fits
 };
 
 static size_t arena_put(taco_model* m, const float* src, size_t n) {
@@ -313,6 +316,8 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
     for (int j = 0; j < H; ++j) bx[dir * 3 * H + 2 * H + j] = cb[j];
     c.gh[dir] = pack_w16(m, gk.data(), 2 * H, I, H, 0, 2 * H, nullptr);
     c.ch[dir] = pack_w16(m, ck.data(), H, I, H, 0, H, nullptr);
+    c.raw_gh[dir] = arena_put(m, gk.data() + (size_t)I * 2 * H, (size_t)H * 2 * H);
+    c.raw_ch[dir] = arena_put(m, ck.data() + (size_t)I * H, (size_t)H * H);
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
@@ -486,6 +491,18 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
   w.h = cv.f((size_t)2 * B * c.rnn); w.rh = cv.f((size_t)2 * B * c.rnn); w.u = cv.f((size_t)2 * B * c.rnn);
 }
 
+// Row-parallel persistent BiGRU: R rows per workgroup.  Returns false when it does not fit.
+static bool bigru_rows_cfg(int B, int H, int* R_out, size_t* lds_out) {
+  if (H % 4) return false;
+  for (int R : {4, 2, 1}) {
+    if (R > 1 && B < R) continue;
+    if ((size_t)R * 2 * H > 2 * RP_NT) continue;          // <= 2 gate outputs per thread
+    const size_t fl = (size_t)3 * R * H + (size_t)RP_NT * R * 4 + 64;
+    if (fl * sizeof(float) <= 160 * 1024) { *R_out = R; *lds_out = fl * sizeof(float); return true; }
+  }
+  return false;
+}
+
 // BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
 // directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
 // directions side by side in each launch.  x [B*T, rnn], out [B*T, 2*rnn].
@@ -496,6 +513,20 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const 
   { GemmCall xp; xp.x = x; xp.ldx = c.rnn; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H;
     xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
+  {  // row-parallel persistent kernel: the whole scan in one launch, weights streamed from L2 every step
+    int R = 0; size_t lds = 0;
+    if (m->persist && bigru_rows_cfg(B, H, &R, &lds)) {
+      BigruRArgs a; memset(&a, 0, sizeof a);
+      a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
+      a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T; a.H = H;
+      const dim3 grid(2 * cdiv(B, R));
+      if (R == 4) hipLaunchKernelGGL(k_bigru_rows<4>, grid, dim3(RP_NT), lds, st, a);
+      else if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, grid, dim3(RP_NT), lds, st, a);
+      else hipLaunchKernelGGL(k_bigru_rows<1>, grid, dim3(RP_NT), lds, st, a);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
+  }
   for (int dir = 0; dir < 2; ++dir)
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * H, 256)), dim3(256), 0, st, init_state ? init_state + dir * H : nullptr,
                        2 * H, w.h + (size_t)dir * B * H, H, B, H);
@@ -922,6 +953,12 @@ int taco_model_finalize(taco_model* m) {
     v.wp = AP(m, (size_t)v.wp); v.wp2 = AP(m, (size_t)v.wp2); v.bias = AP(m, (size_t)v.bias); v.bias2 = AP(m, (size_t)v.bias2);
     v.bn_scale = AP(m, (size_t)v.bn_scale); v.bn_shift = AP(m, (size_t)v.bn_shift);
   }
+  // persistent kernels carve up to the full 160 KiB of LDS
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipMalloc((void**)&m->d_err, 256));
+  HIPCHK(hipMemset(m->d_err, 0, 256));
   m->harena.clear(); m->harena.shrink_to_fit();
   m->raw.clear();
   m->finalized = true;
@@ -931,7 +968,24 @@ int taco_model_finalize(taco_model* m) {
 void taco_model_destroy(taco_model* m) {
   if (!m) return;
   if (m->darena) (void)hipFree(m->darena);
+  if (m->d_err) (void)hipFree(m->d_err);
   delete m;
+}
+
+int taco_model_device_errors(taco_model* m, int* out) {
+  if (!m || !m->finalized || !out) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  unsigned v = 0;
+  HIPCHK(hipMemcpy(&v, m->d_err, sizeof v, hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemset(m->d_err, 0, 256));
+  *out = (int)v;
+  return 0;
+}
+
+int taco_debug_set_persistent(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->persist = on;
+  return 0;
 }
 
 int taco_debug_force_gemm_config(taco_model* m, int cfg) {

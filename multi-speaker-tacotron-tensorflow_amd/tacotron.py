@@ -184,6 +184,7 @@ class Tacotron(object):
             self.stop_step = plan.n
             if honor_stop:
                 stop = int(plan.stop.item())
+                self.check_device_errors()
                 self.stop_step = stop
                 if stop < plan.n:   # dynamic_decode ended early: re-run the post-net on the frames that exist
                     r = self._hparams.reduction_factor
@@ -237,6 +238,13 @@ class Tacotron(object):
         _lib.check(self._lib.taco_postnet_forward(self._handle, _stream(), _ptr(mel), B, T, _ptr(lin), _ptr(post),
                                                   _ptr(ws), n))
         return (lin, post) if return_post else lin
+
+    def check_device_errors(self):
+        """Synchronises and raises if a persistent kernel's bounded spin expired (outputs invalid)."""
+        v = C.c_int(0)
+        _lib.check(self._lib.taco_model_device_errors(self._handle, C.byref(v)))
+        if v.value:
+            raise _lib.TacoError(_lib.TACO_ERR_HIP, "a persistent kernel timed out waiting for a peer workgroup; outputs are invalid")
 
     def close(self):
         self._plans.clear()

@@ -100,10 +100,14 @@ def test_highway(ctx):
         assert maxabs(out.cpu().numpy(), O.highwaynet(x, w, scope + "/highway_2")) < TOL
 
 
-@pytest.mark.parametrize("B", [1, 5, 17, 33])
-def test_bigru_with_lengths_and_init_state(ctx, B):
+@pytest.mark.parametrize("persist", [1, 0])
+@pytest.mark.parametrize("B", [1, 5, 17, 32, 33])
+def test_bigru_with_lengths_and_init_state(ctx, B, persist):
+    """persist=1: one persistent row-parallel launch (weights streamed from L2 every step);
+    persist=0: two launches per time step."""
     import torch
     ohp, w, m, L = ctx
+    m._lib.taco_debug_set_persistent(m._handle, persist)
     rs = np.random.RandomState(B)
     T, H = 12, ohp.enc_rnn_size
     x = rs.randn(B, T, H)
@@ -126,6 +130,46 @@ def test_bigru_with_lengths_and_init_state(ctx, B):
     L.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(xpd), ptr(None), ptr(None), B, T, ptr(outp), ptr(ws), n))
     torch.cuda.synchronize()
     assert maxabs(outp.cpu().numpy(), O.bidirectional_gru(xp, None, w, "post_cbhg/bigru")) < 1e-4
+    m._lib.taco_debug_set_persistent(m._handle, 1)
+    m.check_device_errors()
+
+
+def test_bigru_persistent_full_width_repeatable():
+    """Full-width post-net BiGRU (H=256, 4 rows per workgroup), T=64, run three times: results must
+    match the oracle and be bit-identical run to run."""
+    import torch
+    import taco_amd
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 11)
+    m = build_model(ohp, w)
+    rs = np.random.RandomState(12)
+    B, T, H = 32, 64, ohp.post_rnn_size
+    x = rs.randn(B, T, H) * 0.5
+    ref = O.bidirectional_gru(x, None, w, "post_cbhg/bigru")
+    xd = dev(x, torch.float32)
+    n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(3):
+        out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+        taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(xd), ptr(None), ptr(None), B, T,
+                                                  ptr(out), ptr(ws), n))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    m.check_device_errors()
+    assert maxabs(outs[0], ref) < 1e-4
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    # encoder flavour with ragged lengths
+    He = ohp.enc_rnn_size
+    xe = rs.randn(B, T, He) * 0.5
+    lens = rs.randint(1, T + 1, size=B).astype(np.int32)
+    xed, ld = dev(xe, torch.float32), dev(lens)
+    oute = torch.full((B, T, 2 * He), float("nan"), device="cuda")
+    taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(xed), ptr(ld), ptr(None), B, T,
+                                              ptr(oute), ptr(ws), n))
+    torch.cuda.synchronize()
+    m.check_device_errors()
+    assert maxabs(oute.cpu().numpy(), O.bidirectional_gru(xe, lens, w, "encoder_cbhg/bigru")) < 1e-4
 
 
 @pytest.mark.parametrize("name,res", [("decoder/attention_gru", False), ("decoder/gru_1", True), ("decoder/gru_2", True)])
