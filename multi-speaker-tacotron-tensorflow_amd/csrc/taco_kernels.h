@@ -342,17 +342,21 @@ __device__ __forceinline__ float4 taco_sk_load(const SkJob& jb, const float* p0,
 // over the 8 K-slices, epilogue on the prefetched operands.  EPI and VEC are compile-time so the
 // prologue is branch-free.  The BiGRU x-part is stored time-reversed for the backward direction by the
 // hoisted GEMM, so its address does not depend on `lengths` (only the final store position does).
-template <int RT, int EPI, bool VEC>
+template <int RT, int EPI, bool VEC, bool MULTI>
 __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   __shared__ float red[SK_NW * RT * 256];
   constexpr int NE = (RT * 256 + 64 * SK_NW - 1) / (64 * SK_NW);   // outputs per thread
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // single-job launches (every decoder stage) read the descriptor at static kernarg offsets: ONE scalar
+  // round trip instead of two (job select, then the selected descriptor)
   int ji = 0;
+  if (MULTI) {
 #pragma unroll
-  for (int q = 1; q < SK_MAXJOBS; ++q)
-    if (q < a.njobs && (int)blockIdx.x >= a.j[q].tile0) ji = q;
-  SkJob jb = a.j[ji];
+    for (int q = 1; q < SK_MAXJOBS; ++q)
+      if (q < a.njobs && (int)blockIdx.x >= a.j[q].tile0) ji = q;
+  }
+  SkJob jb = MULTI ? a.j[ji] : a.j[0];
   PIN(jb.x0); PIN(jb.x1); PIN(jb.gather0); PIN(jb.wp); PIN(jb.bias); PIN(jb.e0); PIN(jb.e1); PIN(jb.e2); PIN(jb.e3);
   PIN(jb.o0); PIN(jb.o1); PIN(jb.o2); PIN(jb.lengths);
   PIN(jb.ldx0); PIN(jb.ldx1); PIN(jb.K0); PIN(jb.K); PIN(jb.Kq); PIN(jb.N); PIN(jb.H); PIN(jb.act);
@@ -484,17 +488,19 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
 // independent, so a workgroup that owns R rows and streams every weight matrix from L2 each step needs NO
 // cross-workgroup synchronisation: only __syncthreads.  Weights stay in TF layout [K, N] row-major:
 // thread = 4 consecutive columns x one K-slice, loads are 16 bytes and coalesce over the row.
-#define RP_NT 1024   // threads per workgroup (16 waves: enough 16-byte loads in flight to reach ~150 GB/s)
+#define RP_NT 1024   // threads per workgroup: 16 waves x 8 sixteen-byte loads in flight = 128 KB outstanding (~150 GB/s)
 
 // partial[(ks*R + r)*N + n] = sum over K-slice ks of x[r][k] * W[k][n].  x in LDS ([R][ldx]); W global.
-// Returns KS (number of K-slices) for the reducer.  No barrier inside.
+// Returns KS (number of K-slices) for the reducer.  No barrier inside.  (Variants that prefetch the next
+// stage's first rows across the barrier were measured: the 128-VGPR budget of a 1024-thread workgroup
+// spills and the scan gets ~1.5x slower; 512-thread workgroups keep too few loads in flight.)
 template <int R>
 __device__ __forceinline__ int rp_matvec(const float* __restrict__ W, int K, int N, const float* x, int ldx,
                                          float* part, int tid) {
-  const int NC = N >> 2;
+  const int NC = N >> 2;                                  // host guarantees N % 4 == 0 and N <= 4*RP_NT
   int KS = RP_NT / NC; if (KS > K) KS = K; if (KS < 1) KS = 1;
   const int kper = (K + KS - 1) / KS;
-  const int cg = tid % NC, ks = tid / NC;               // host guarantees N <= 4*RP_NT
+  const int cg = tid % NC, ks = tid / NC;
   if (ks < KS) {
     const int k0 = ks * kper, k1 = min(K, k0 + kper);
     float4 acc[R];
@@ -563,17 +569,20 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
   constexpr int NE1 = 2, NE2 = 1;     // epilogue outputs per thread (host guarantees R*2H <= 2*RP_NT)
   for (int s = 0; s < T; ++s) {
     // x-parts of this thread's outputs: requested now, consumed after the weight stream
-    float xg[NE1], xc[NE2]; int Lr = T;
+    float xg[NE1], xc[NE2]; int Lr[NE2];
+#pragma unroll
+    for (int e = 0; e < NE2; ++e) Lr[e] = T;
 #pragma unroll
     for (int e = 0; e < NE1; ++e) {
       const int o = tid + e * RP_NT; xg[e] = 0.f;
       if (o < R * 2 * H) { const int r = o / (2 * H), n = o % (2 * H), b = r0 + r;
         if (b < B) xg[e] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + n]; }
     }
-    {
-      const int o = tid; xc[0] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE2; ++e) {
+      const int o = tid + e * RP_NT; xc[e] = 0.f;
       if (o < R * H) { const int r = o / H, n = o % H, b = r0 + r;
-        if (b < B) { xc[0] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + 2 * H + n]; if (a.lengths) Lr = a.lengths[b]; } }
+        if (b < B) { xc[e] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + 2 * H + n]; if (a.lengths) Lr[e] = a.lengths[b]; } }
     }
     // ---- gates ----
     int KS = rp_matvec<R>(Wg, H, 2 * H, hs, H, part, tid);
@@ -592,16 +601,17 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
     // ---- candidate + state update ----
     KS = rp_matvec<R>(Wc, H, H, rhs, H, part, tid);
     __syncthreads();
-    {
-      const int o = tid;
+#pragma unroll
+    for (int e = 0; e < NE2; ++e) {
+      const int o = tid + e * RP_NT;
       if (o < R * H) {
         const int r = o / H, n = o % H, b = r0 + r;
-        const float c = tanhf(rp_reduce(part, KS, R * H, o) + xc[0]);
+        const float c = tanhf(rp_reduce(part, KS, R * H, o) + xc[e]);
         const float h = hs[o], u = us[o];
         const float hn = u * h + (1.f - u) * c;
         // BiGRU time mapping (A.7): row active iff s < L; forward t = s, backward t = L-1-s
-        const bool active = s < Lr;
-        const int t = (d && active) ? (Lr - 1 - s) : s;
+        const bool active = s < Lr[e];
+        const int t = (d && active) ? (Lr[e] - 1 - s) : s;
         if (active) hs[o] = hn;
         if (b < B) a.out[((size_t)b * T + t) * 2 * H + d * H + n] = active ? hn : 0.f;
       }
@@ -614,7 +624,9 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
 // k_attention : one workgroup per batch row
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {
-  const float* q;        // [B, A] processed query (h_att . W_q)
+  const float* q;        // [B, A] processed query (h_att . W_q), or null when hq/wq are given
+  const float* hq;       // [B, As] attention-GRU output: the query mat-vec is done here (saves a launch)
+  const float* wq;       // [As, A] query_layer/kernel, TF layout
   const float* keys;     // [B, T_in, A]
   const float* values;   // [B, T_in, D]
   const float* v;        // [A] attention_v (bah_norm: g*v/|v| folded at finalize)
@@ -624,7 +636,7 @@ struct AttnArgs {
   float* align;          // [B, T_in] state: previous alignments in, new alignments out
   float* hist;           // [B, T_in, n_steps] or null (tacotron.py:238-239 layout)
   float* ctx;            // [B, D]
-  int T_in, A, D, type, step, n_steps;
+  int T_in, A, D, type, step, n_steps, As;
 };
 
 #define ATT_NW 8
@@ -662,7 +674,7 @@ __device__ __forceinline__ float taco_tanh_fast(float x) {
 // before the serial normaliser), so a step costs ~one memory round trip plus the tanh/exp math.
 __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) {
   AttnArgs a = a_in;
-  PIN(a.q); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
+  PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
   PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps);
   __shared__ float sc[ATT_MAXT];     // scores -> alignments
   __shared__ float tmp[ATT_MAXT];
@@ -693,7 +705,33 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
     // scores: e[j] = sum_a v[a] * tanh(keys[b,j,a] + q[b,a] (+ b[a]))   (_bahdanau_score, A.9)
     // 16 lanes per encoder position; lane covers channels c = (lane&15)*4 + 64*m.
     const int l16 = lane & 15, grp = lane >> 4;
-    const float* qb = a.q + (size_t)b * a.A;
+    const float* qb = a.q ? a.q + (size_t)b * a.A : cred;
+    if (!a.q) {
+      // q[b,:] = h_att[b,:] . W_q : 4 columns per thread, K split over thread groups, reduced through LDS
+      const int NC = a.A >> 2;
+      int KS = (64 * ATT_NW) / NC; if (KS > a.As) KS = a.As; if (KS < 1) KS = 1;
+      const int kper = (a.As + KS - 1) / KS, cg = tid % NC, ks = tid / NC;
+      float* qpart = tmp;                                     // [KS][A] <= ATT_MAXT floats (host checks)
+      if (ks < KS) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* hb = a.hq + (size_t)b * a.As;
+        const float4* wp = reinterpret_cast<const float4*>(a.wq) + cg;
+        const int k1 = min(a.As, (ks + 1) * kper);
+#pragma unroll 8
+        for (int k = ks * kper; k < k1; ++k) {
+          const float4 w = wp[(size_t)k * NC]; const float xv = hb[k];
+          acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(qpart + (size_t)ks * a.A + 4 * cg) = acc;
+      }
+      __syncthreads();
+      for (int n = tid; n < a.A; n += 64 * ATT_NW) {
+        float sum = 0.f;
+        for (int k2 = 0; k2 < KS; ++k2) sum += qpart[(size_t)k2 * a.A + n];
+        cred[n] = sum;                                        // cred is free until the context phase
+      }
+      __syncthreads();
+    }
     const float* krow = a.keys + (size_t)b * T * a.A;
     for (int j0 = 0; j0 < T; j0 += 32 * ATT_JU) {
       float part[ATT_JU];

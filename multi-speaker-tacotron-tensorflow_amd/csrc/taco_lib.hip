@@ -95,7 +95,7 @@ struct taco_model {
   GruDec att_gru;
   std::vector<GruDec> dec_gru;
   SkW query, concat_proj, frame_proj;
-  size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0;
+  size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0, raw_wq = 0;
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
   std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
   int force_cfg = -1;
@@ -418,8 +418,11 @@ static SkJob sk_linear(const taco_model* m, const SkW& w, const float* x0, int l
 }
 template <int RT, int EPI>
 static void launch_skinny(hipStream_t st, int tiles, bool vec, const SkArgs& a) {
-  if (vec) hipLaunchKernelGGL((k_skinny<RT, EPI, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else hipLaunchKernelGGL((k_skinny<RT, EPI, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  const bool multi = a.njobs > 1;
+  if (vec && !multi) hipLaunchKernelGGL((k_skinny<RT, EPI, true, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else if (vec) hipLaunchKernelGGL((k_skinny<RT, EPI, true, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else if (!multi) hipLaunchKernelGGL((k_skinny<RT, EPI, false, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
+  else hipLaunchKernelGGL((k_skinny<RT, EPI, false, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
 }
 template <int EPI>
 static void launch_skinny_rt(hipStream_t st, int RT, int tiles, bool vec, const SkArgs& a) {
@@ -494,7 +497,7 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
 // Row-parallel persistent BiGRU: R rows per workgroup.  Returns false when it does not fit.
 static bool bigru_rows_cfg(int B, int H, int* R_out, size_t* lds_out) {
   if (H % 4) return false;
-  for (int R : {4, 2, 1}) {
+  for (int R : {2, 1}) {                                   // R = 4 spills at the 128-VGPR budget of a 1024-thread workgroup
     if (R > 1 && B < R) continue;
     if ((size_t)R * 2 * H > 2 * RP_NT) continue;          // <= 2 gate outputs per thread
     const size_t fl = (size_t)3 * R * H + (size_t)RP_NT * R * 4 + 64;
@@ -520,8 +523,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const 
       a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
       a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T; a.H = H;
       const dim3 grid(2 * cdiv(B, R));
-      if (R == 4) hipLaunchKernelGGL(k_bigru_rows<4>, grid, dim3(RP_NT), lds, st, a);
-      else if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, grid, dim3(RP_NT), lds, st, a);
+      if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, grid, dim3(RP_NT), lds, st, a);
       else hipLaunchKernelGGL(k_bigru_rows<1>, grid, dim3(RP_NT), lds, st, a);
       HIPCHK(hipGetLastError());
       return 0;
@@ -717,10 +719,12 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     // attention GRUCell (tacotron.py:127-130)
     TRY(run_gru_cell(m, st, m->att_gru, B, cur, curd, w.h_att, w.rh, w.u, w.xc, nullptr));
     // query + score + normaliser + context (rnn_wrappers.py:304-341)
-    { SkJob j = sk_linear(m, m->query, w.h_att, As, As, nullptr, 0, ACT_NONE, w.q, A);
+    // the query mat-vec runs inside the attention kernel (one launch less) when its partials fit the kernel's LDS
+    const bool fuse_q = (A % 4 == 0) && ((size_t)std::min(std::max((64 * ATT_NW) / (A / 4), 1), As) * A <= ATT_MAXT) && A <= ATT_NW * 256;
+    if (!fuse_q) { SkJob j = sk_linear(m, m->query, w.h_att, As, As, nullptr, 0, ACT_NONE, w.q, A);
       TRY(run_skinny(st, B, &j, 1)); }
     { AttnArgs a; memset(&a, 0, sizeof a);
-      a.q = w.q; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
+      a.q = fuse_q ? nullptr : w.q; a.hq = w.h_att; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
       a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
       hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
@@ -896,6 +900,7 @@ int taco_model_finalize(taco_model* m) {
   m->grus["decoder/attention_gru"] = m->att_gru;
   m->query = pack_w16(m, T_(m, "attention/query_layer/kernel").data.data(), A, 0, As, 0, A, nullptr);
   m->skinny["attention/query_layer"] = m->query;
+  m->raw_wq = arena_put(m, T_(m, "attention/query_layer/kernel").data.data(), (size_t)As * A);
   m->concat_proj = pack_w16(m, T_(m, "decoder/concat_projection/kernel").data.data(), Hd, 0, As + D, 0, Hd, T_(m, "decoder/concat_projection/bias").data.data());
   m->skinny["decoder/concat_projection"] = m->concat_proj;
   for (int i = 0; i < hp.dec_layer_num; ++i) {
@@ -956,7 +961,6 @@ int taco_model_finalize(taco_model* m) {
   // persistent kernels carve up to the full 160 KiB of LDS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipMalloc((void**)&m->d_err, 256));
   HIPCHK(hipMemset(m->d_err, 0, 256));
   m->harena.clear(); m->harena.shrink_to_fit();
