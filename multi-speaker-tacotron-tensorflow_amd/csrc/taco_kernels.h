@@ -161,14 +161,31 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
         for (int r = 0; r < 16; ++r) acc2[tm][tn][r] = 0.f;
     }
 
+  // Staging is software-pipelined: the global loads of chunk c+1 are issued into registers right after
+  // chunk c landed in LDS, so their latency overlaps chunk c's MFMAs (one LDS buffer, two barriers/chunk).
+  constexpr int NPRE = ((BM + 15) * (TACO_KC / 4) + NTHR - 1) / NTHR;
+  float4 pre[NPRE];
+  const int nstage = rows * (TACO_KC / 4);
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int idx = tid + u * NTHR;
+    if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), 4 * (idx % (TACO_KC / 4)));
+  }
   for (int c0 = 0; c0 < a.cin_pad; c0 += TACO_KC) {
     __syncthreads();
-    for (int idx = tid; idx < rows * (TACO_KC / 4); idx += NTHR) {
-      const int s = idx / (TACO_KC / 4), c4 = idx % (TACO_KC / 4);
-      const float4 val = taco_stage_load(a, m0 - v.padl + s, c0 + 4 * c4);
-      *reinterpret_cast<float4*>(&smem[s * TACO_LDSW + 4 * c4]) = val;
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < nstage) *reinterpret_cast<float4*>(&smem[(idx / (TACO_KC / 4)) * TACO_LDSW + 4 * (idx % (TACO_KC / 4))]) = pre[u];
     }
     __syncthreads();
+    if (c0 + TACO_KC < a.cin_pad) {
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int idx = tid + u * NTHR;
+        if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), c0 + TACO_KC + 4 * (idx % (TACO_KC / 4)));
+      }
+    }
     const int ng = min(TACO_KC, a.cin_pad - c0) >> 3;
     int it = 0;
     for (int j = 0; j < v.kw; ++j) {
@@ -366,6 +383,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   const int l15 = lane & 15, lq = lane >> 4;
   int R = a.R;
   PIN(R);
+  const int row0 = blockIdx.y * (RT * 16);          // grid.y splits the batch rows into groups of RT*16
 
   // ---- (1) epilogue operands ----
   float pb[NE], pe0[NE], pe1[NE], pe2[NE], pe3[NE];
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   for (int e = 0; e < NE; ++e) {
     const int idx = tid + e * 64 * SK_NW;
     const int rt = idx >> 8, w = idx & 255, reg = w >> 6, ln = w & 63;
-    const int r = rt * 16 + (ln >> 4) * 4 + reg;       // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+    const int r = row0 + rt * 16 + (ln >> 4) * 4 + reg;   // C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
     const int n = nt * 16 + (ln & 15);
     const bool valid = (idx < RT * 256) && r < R && n < jb.N;
     pvalid[e] = valid;
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int r = rt * 16 + l15;
+    const int r = row0 + rt * 16 + l15;
     rok[rt] = r < R;
     const int rr = rok[rt] ? r : 0;
     xp0[rt] = jb.x0 + (size_t)(jb.gather0 ? jb.gather0[rr] : rr) * jb.ldx0;
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
     float s = pb[e];
 #pragma unroll
     for (int wv = 0; wv < SK_NW; ++wv) s += red[(wv * RT + rt) * 256 + w];
-    const int r = rt * 16 + (ln >> 4) * 4 + reg;
+    const int r = row0 + rt * 16 + (ln >> 4) * 4 + reg;
     const int n = nt * 16 + (ln & 15);
     if (EPI == EPI_LINEAR) {
       const float y = taco_act(s, jb.act);

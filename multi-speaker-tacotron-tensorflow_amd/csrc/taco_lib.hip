@@ -364,10 +364,10 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
 // cfg: 0 = 128x64 tile (4 waves), 1 = 64x64 (4 waves), 2 = 32x64 split-K 4 (8 waves), 3 = 128x128 (4 waves)
 static int pick_cfg(const taco_model* m, int M, int N, int nvar) {
   if (m->force_cfg >= 0) return m->force_cfg;
-  const long b0 = (long)cdiv(M, 128) * cdiv(N, 64) * nvar;
-  if (b0 >= 512) return 0;
+  // measured (tools/time_gemm_layers.py): the 64x64 tile (32 VGPRs, 8 waves/SIMD) beats 128x64 and 128x128 on
+  // every large layer -- the kernel is bound by latency hiding, not operand reuse; small-M layers need split-K
   const long b1 = (long)cdiv(M, 64) * cdiv(N, 64) * nvar;
-  if (b1 >= 256) return 1;
+  if (b1 >= 512) return 1;
   return 2;
 }
 
@@ -416,19 +416,16 @@ static SkJob sk_linear(const taco_model* m, const SkW& w, const float* x0, int l
   j.act = act; j.o0 = out; j.ldo0 = ldo;
   return j;
 }
-template <int RT, int EPI>
-static void launch_skinny(hipStream_t st, int tiles, bool vec, const SkArgs& a) {
-  const bool multi = a.njobs > 1;
-  if (vec && !multi) hipLaunchKernelGGL((k_skinny<RT, EPI, true, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else if (vec) hipLaunchKernelGGL((k_skinny<RT, EPI, true, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else if (!multi) hipLaunchKernelGGL((k_skinny<RT, EPI, false, false>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-  else hipLaunchKernelGGL((k_skinny<RT, EPI, false, true>), dim3(tiles), dim3(64 * SK_NW), 0, st, a);
-}
+// fp32 MFMA sustains only 256 FLOP/clk per CU, so the MFMA chain of a stage is kept short by giving every
+// 16-row tile of the batch its own workgroup (grid.y) instead of looping row tiles inside one.
 template <int EPI>
-static void launch_skinny_rt(hipStream_t st, int RT, int tiles, bool vec, const SkArgs& a) {
-  if (RT == 1) launch_skinny<1, EPI>(st, tiles, vec, a);
-  else if (RT == 2) launch_skinny<2, EPI>(st, tiles, vec, a);
-  else launch_skinny<4, EPI>(st, tiles, vec, a);
+static void launch_skinny_rt(hipStream_t st, int rowgroups, int tiles, bool vec, const SkArgs& a) {
+  const bool multi = a.njobs > 1;
+  const dim3 grid(tiles, rowgroups), blk(64 * SK_NW);
+  if (vec && !multi) hipLaunchKernelGGL((k_skinny<1, EPI, true, false>), grid, blk, 0, st, a);
+  else if (vec) hipLaunchKernelGGL((k_skinny<1, EPI, true, true>), grid, blk, 0, st, a);
+  else if (!multi) hipLaunchKernelGGL((k_skinny<1, EPI, false, false>), grid, blk, 0, st, a);
+  else hipLaunchKernelGGL((k_skinny<1, EPI, false, true>), grid, blk, 0, st, a);
 }
 // all jobs of one launch share the epilogue type
 static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs, int epi = EPI_LINEAR) {
@@ -445,10 +442,10 @@ static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs, int epi = E
     vec = vec && (j.K0 % 4 == 0) && (j.K % 4 == 0) && (j.ldx0 % 4 == 0) && al16(j.x0) && (!j.x1 || ((j.ldx1 % 4 == 0) && al16(j.x1)));
     jobs[i].tile0 = tiles; tiles += cdiv(jobs[i].N, 16); a.j[i] = jobs[i];
   }
-  const int RT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
-  if (epi == EPI_LINEAR) launch_skinny_rt<EPI_LINEAR>(st, RT, tiles, vec, a);
-  else if (epi == EPI_GRU_GATES) launch_skinny_rt<EPI_GRU_GATES>(st, RT, tiles, vec, a);
-  else launch_skinny_rt<EPI_GRU_CAND>(st, RT, tiles, vec, a);
+  const int RG = cdiv(R, 16);
+  if (epi == EPI_LINEAR) launch_skinny_rt<EPI_LINEAR>(st, RG, tiles, vec, a);
+  else if (epi == EPI_GRU_GATES) launch_skinny_rt<EPI_GRU_GATES>(st, RG, tiles, vec, a);
+  else launch_skinny_rt<EPI_GRU_CAND>(st, RG, tiles, vec, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
