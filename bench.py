@@ -201,6 +201,17 @@ def main():
                                       "frac": flops / fwd_s / 1e12 / MFMA_F32_PEAK_TF, "gflop_per_forward": flops / 1e9}},
             "outputs_finite": finite,
         }
+        # HBM-side traffic per forward from the committed PMC passes (profiles/*pmc_hbm_traffic.json), same workload only
+        try:
+            import glob
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
+            if pm:
+                rec = json.load(open(pm[-1]))
+                if rec.get("workload") == args.workload:
+                    out["roofline"]["traffic"] = rec["traffic_bytes_per_forward"]
+                    out["roofline"]["traffic_source"] = os.path.basename(pm[-1])
+        except Exception:
+            pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, seed)
         print(json.dumps(out))

@@ -657,10 +657,10 @@ struct AttnArgs {
   int T_in, A, D, type, step, n_steps, As;
 };
 
-#define ATT_NW 8
+#define ATT_NW 16    // waves per workgroup (1024 threads: more key/value loads and tanh evaluations in flight)
 #define ATT_MAXT 2048
-#define ATT_JU 4     // score iterations (of 32 encoder positions each) whose key loads are issued together
-#define ATT_VU 16    // value rows per wave whose loads are issued together (before the normaliser)
+#define ATT_JU 2     // score iterations (of 4*ATT_NW encoder positions each) whose key loads are issued together
+#define ATT_VU 8     // value rows per wave whose loads are issued together (before the normaliser)
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
       __syncthreads();
     }
     const float* krow = a.keys + (size_t)b * T * a.A;
-    for (int j0 = 0; j0 < T; j0 += 32 * ATT_JU) {
+    for (int j0 = 0; j0 < T; j0 += 4 * ATT_NW * ATT_JU) {
       float part[ATT_JU];
 #pragma unroll
       for (int u = 0; u < ATT_JU; ++u) part[u] = 0.f;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
           }
 #pragma unroll
           for (int u = 0; u < ATT_JU; ++u) {
-            const int j = j0 + 32 * u + wave * 4 + grp;
+            const int j = j0 + 4 * ATT_NW * u + wave * 4 + grp;
             k4[u][m] = (ok && j < T) ? *reinterpret_cast<const float4*>(krow + (size_t)j * a.A + c)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
           }
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
       for (int u = 0; u < ATT_JU; ++u) {
         float p = part[u];
         p += __shfl_xor(p, 8, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 1, 64);
-        const int j = j0 + 32 * u + wave * 4 + grp;
+        const int j = j0 + 4 * ATT_NW * u + wave * 4 + grp;
         if (l16 == 0 && j < T) sc[j] = p;
       }
     }

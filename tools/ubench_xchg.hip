@@ -69,7 +69,7 @@ int main() {
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 2000;
-  for (int P : {8, 16}) for (int slice : {1024, 4096}) for (int mode = 0; mode < 4; ++mode) {
+  for (int P : {2, 4, 8}) for (int slice : {256, 1024}) for (int mode = 0; mode < 4; ++mode) {
     CK(hipMemsetAsync(flags, 0, 4096, s)); CK(hipMemsetAsync(err, 0, 256, s));
     size_t lds = (size_t)P * slice * 4;
     auto launch = [&](int it) {
