@@ -690,18 +690,14 @@ __device__ __forceinline__ float taco_tanh_fast(float x) {
 // One workgroup (8 waves) per batch row.  Everything a step needs from HBM/L2 -- the row's keys
 // [T_in, A] and values [T_in, D] -- is requested up front in two bursts (scores burst; values burst
 // before the serial normaliser), so a step costs ~one memory round trip plus the tanh/exp math.
-__global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) {
-  AttnArgs a = a_in;
-  PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
-  PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps);
-  __shared__ float sc[ATT_MAXT];     // scores -> alignments
-  __shared__ float tmp[ATT_MAXT];
-  __shared__ float tmp2[ATT_MAXT];
-  __shared__ __attribute__((aligned(16))) float cred[ATT_NW * 256];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// The attention of ONE batch row b by one 16-wave workgroup.  LDS scratch: sc/tmp/tmp2 [T_in], cred [ATT_NW*256].
+// hq_row: the row's attention-GRU output (global or LDS) when the query mat-vec is done here; al: the row's
+// alignment state [T_in] (in: previous, out: new; global or LDS); ctx_out: [D] (global or LDS).
+__device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, float* tmp, float* tmp2, float* cred,
+                                         const float* hq_row, float* al, float* ctx_out) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T_in;
-  float* al = a.align + (size_t)b * T;
   const float* vrow = a.values + (size_t)b * T * a.D;
 
   // values burst for the first 256 output channels: wave w owns positions j = w + 8*i
@@ -727,12 +723,12 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
     if (!a.q) {
       // q[b,:] = h_att[b,:] . W_q : 4 columns per thread, K split over thread groups, reduced through LDS
       const int NC = a.A >> 2;
-      int KS = (64 * ATT_NW) / NC; if (KS > a.As) KS = a.As; if (KS < 1) KS = 1;
+      int KS = (64 * ATT_NW) / NC; if (KS > a.As) KS = a.As; if (KS * a.A > ATT_MAXT) KS = ATT_MAXT / a.A; if (KS < 1) KS = 1;
       const int kper = (a.As + KS - 1) / KS, cg = tid % NC, ks = tid / NC;
-      float* qpart = tmp;                                     // [KS][A] <= ATT_MAXT floats (host checks)
+      float* qpart = tmp;                                     // [KS][A] <= ATT_MAXT floats (tmp holds >= ATT_MAXT)
       if (ks < KS) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* hb = a.hq + (size_t)b * a.As;
+        const float* hb = hq_row;
         const float4* wp = reinterpret_cast<const float4*>(a.wq) + cg;
         const int k1 = min(a.As, (ks + 1) * kper);
 #pragma unroll 8
@@ -862,9 +858,22 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < ATT_NW; ++w) s += cred[w * 256 + tid];
-      a.ctx[(size_t)b * a.D + d0 + tid] = s;
+      ctx_out[d0 + tid] = s;
     }
   }
+}
+
+__global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) {
+  AttnArgs a = a_in;
+  PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
+  PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps);
+  __shared__ float sc[ATT_MAXT];     // scores -> alignments
+  __shared__ float tmp[ATT_MAXT];
+  __shared__ float tmp2[ATT_MAXT];
+  __shared__ __attribute__((aligned(16))) float cred[ATT_NW * 256];
+  const int b = blockIdx.x;
+  att_core(a, b, sc, tmp, tmp2, cred, a.hq ? a.hq + (size_t)b * a.As : nullptr, a.align + (size_t)b * a.T_in,
+           a.ctx + (size_t)b * a.D);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -717,7 +717,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     TRY(run_gru_cell(m, st, m->att_gru, B, cur, curd, w.h_att, w.rh, w.u, w.xc, nullptr));
     // query + score + normaliser + context (rnn_wrappers.py:304-341)
     // the query mat-vec runs inside the attention kernel (one launch less) when its partials fit the kernel's LDS
-    const bool fuse_q = (A % 4 == 0) && ((size_t)std::min(std::max((64 * ATT_NW) / (A / 4), 1), As) * A <= ATT_MAXT) && A <= ATT_NW * 256;
+    const bool fuse_q = (A % 4 == 0) && A <= ATT_MAXT && A / 4 <= 64 * ATT_NW;
     if (!fuse_q) { SkJob j = sk_linear(m, m->query, w.h_att, As, As, nullptr, 0, ACT_NONE, w.q, A);
       TRY(run_skinny(st, B, &j, 1)); }
     { AttnArgs a; memset(&a, 0, sizeof a);

@@ -188,7 +188,7 @@ def test_graph_replay_equals_eager_and_is_repeatable():
                                                   ptr(None), ptr(mel), ptr(lin), ptr(al), ptr(stop), ptr(ws), nb))
     torch.cuda.synchronize()
     assert np.array_equal(mel.cpu().numpy(), mel_g) and np.array_equal(lin.cpu().numpy(), lin_g)
-    assert m.plan_for(B, T_in).num_nodes > 50
+    assert m.plan_for(B, T_in).num_nodes > 10
 
 
 def test_workspace_too_small_is_an_error_not_a_crash():
