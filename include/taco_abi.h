@@ -112,8 +112,8 @@ int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder
                          float* d_mel, float* d_alignments, int32_t* d_stop_step, float* d_dbg_states,
                          void* d_workspace, size_t workspace_bytes);
 /* post-net CBHG + linear head (tacotron.py:219-235).  d_mel [B,T_mel,num_mels] -> d_linear [B,T_mel,num_freq];
- * d_post_out optional [B,T_mel,2*post_rnn_size]. */
-int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, int B, int T_mel,
+ * d_post_out optional [B,T_mel,2*post_rnn_size]; d_speaker_id is read only by model_type 'simple' (:226-233). */
+int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, const int32_t* d_speaker_id, int B, int T_mel,
                          float* d_linear, float* d_post_out, void* d_workspace, size_t workspace_bytes);
 size_t taco_stage_workspace_bytes(const taco_model* m, int B, int T);
 

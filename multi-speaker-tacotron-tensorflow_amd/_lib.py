@@ -100,7 +100,7 @@ PROTOTYPES = {
     "taco_plan_destroy": (None, [_P]),
     "taco_encoder_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _S]),
     "taco_decoder_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _S]),
-    "taco_postnet_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _S]),
+    "taco_postnet_forward": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P, _S]),
     "taco_conv1d_bn_f32": (_I, [_P, _P, C.c_char_p, _P, _I, _I, _I, _I, _P]),
     "taco_dense_f32": (_I, [_P, _P, C.c_char_p, _P, _I, _I, _P]),
     "taco_highway_f32": (_I, [_P, _P, C.c_char_p, _P, _I, _P]),

@@ -654,7 +654,7 @@ struct AttnArgs {
   float* align;          // [B, T_in] state: previous alignments in, new alignments out
   float* hist;           // [B, T_in, n_steps] or null (tacotron.py:238-239 layout)
   float* ctx;            // [B, D]
-  int T_in, A, D, type, step, n_steps, As;
+  int T_in, A, D, type, step, n_steps, As, ldctx;   // ldctx: row stride of ctx (D, or D + speaker columns)
 };
 
 #define ATT_NW 16    // waves per workgroup (1024 threads: more key/value loads and tanh evaluations in flight)
@@ -866,14 +866,14 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
 __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) {
   AttnArgs a = a_in;
   PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
-  PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps);
+  PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps); PIN(a.ldctx);
   __shared__ float sc[ATT_MAXT];     // scores -> alignments
   __shared__ float tmp[ATT_MAXT];
   __shared__ float tmp2[ATT_MAXT];
   __shared__ __attribute__((aligned(16))) float cred[ATT_NW * 256];
   const int b = blockIdx.x;
   att_core(a, b, sc, tmp, tmp2, cred, a.hq ? a.hq + (size_t)b * a.As : nullptr, a.align + (size_t)b * a.T_in,
-           a.ctx + (size_t)b * a.D);
+           a.ctx + (size_t)b * a.ldctx);
 }
 
 // ------------------------------------------------------------------------------------------------

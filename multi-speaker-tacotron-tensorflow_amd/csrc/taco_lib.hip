@@ -94,7 +94,7 @@ struct taco_model {
   std::vector<SkW> dec_prenet;
   GruDec att_gru;
   std::vector<GruDec> dec_gru;
-  SkW query, concat_proj, frame_proj;
+  SkW query, concat_proj, frame_proj, lin_spk;   // lin_spk: speaker rows of the linear head ('simple')
   size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0, raw_wq = 0;
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
   std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
@@ -186,13 +186,14 @@ static int build_spec(taco_model* m) {
     spec_dense(m, "decoder/prenet/dense_" + std::to_string(i + 1), d, hp.dec_prenet[i]);
     d = hp.dec_prenet[i];
   }
-  spec_gru(m, "decoder/attention_gru", d, hp.attention_state_size);
-  spec_dense(m, "decoder/concat_projection", hp.attention_state_size + enc_out, hp.dec_rnn_size);
+  const int sspk = (multi && hp.model_type == 1) ? spk : 0;   // 'simple': speaker embedding concatenated (tacotron.py:82-86)
+  spec_gru(m, "decoder/attention_gru", d + sspk, hp.attention_state_size);                       // rnn_wrappers.py:372-376
+  spec_dense(m, "decoder/concat_projection", hp.attention_state_size + enc_out + sspk, hp.dec_rnn_size);   // :405-413
   for (int i = 0; i < hp.dec_layer_num; ++i) spec_gru(m, "decoder/gru_" + std::to_string(i + 1), hp.dec_rnn_size, hp.dec_rnn_size);
   spec_dense(m, "decoder/frame_projection", hp.dec_rnn_size, hp.num_mels * hp.reduction_factor);
   spec_cbhg(m, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_highway_depth,
             hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width);
-  spec_dense(m, "linear", 2 * hp.post_rnn_size, hp.num_freq);
+  spec_dense(m, "linear", 2 * hp.post_rnn_size + sspk, hp.num_freq);   // tacotron.py:226-235 (embedding in front)
   return 0;
 }
 
@@ -598,6 +599,8 @@ static void carve_spk(Carver& cv, const taco_model* m, int B, SpkWs& w) {
   for (int i = 0; i < 3 + hp.dec_layer_num; ++i) w.vec[i] = cv.f((size_t)B * (i < 3 ? dims[i] : hp.dec_rnn_size));
 }
 static bool is_deepvoice(const taco_model* m) { return m->hp.num_speakers > 1 && m->hp.model_type == 2; }
+static bool is_simple(const taco_model* m) { return m->hp.num_speakers > 1 && m->hp.model_type == 1; }
+static int simple_S(const taco_model* m) { return is_simple(m) ? m->hp.speaker_embedding_size : 0; }
 // computes vec[0..2+L) = before_highway, encoder_rnn_init, attention_rnn_init, decoder_rnn_init_i
 static int spk_forward(const taco_model* m, hipStream_t st, const int* speaker_id, int B, const SpkWs& w) {
   const taco_hparams& hp = m->hp;
@@ -661,8 +664,9 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
   const int Hmax = std::max(As, Hd);
   w.keys = cv.f((size_t)B * T_in * hp.attention_size);
   w.zero = cv.f((size_t)B * hp.num_mels);
-  w.ctx = cv.f((size_t)B * D);
-  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f((size_t)B * hp.dec_prenet[i]);
+  const int S = simple_S(m);     // 'simple': the speaker embedding rides in the last S columns of ctx and of the prenet output
+  w.ctx = cv.f((size_t)B * (D + S));
+  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f((size_t)B * (hp.dec_prenet[i] + S));
   w.h_att = cv.f((size_t)B * As); w.rh = cv.f((size_t)B * Hmax); w.u = cv.f((size_t)B * Hmax); w.xc = cv.f((size_t)B * Hmax);
   w.q = cv.f((size_t)B * hp.attention_size);
   w.align = cv.f((size_t)B * T_in);
@@ -682,6 +686,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   if ((A % 4) || (D % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention_size and 2*enc_rnn_size must be multiples of 4");
   const SpkWs* spk = spk_in ? spk_in : &w.spk;
   if (is_deepvoice(m) && !spk_ready) TRY(spk_forward(m, st, speaker_id, B, *spk));
+  if (is_simple(m) && !speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
   // attention memory: keys = values . W_mem, no bias, no length mask (A.8)
   { GemmCall g; g.x = enc_out; g.ldx = D; g.M = B * T_in; g.out = w.keys; g.ldo = A;
     TRY(run_gemm(m, st, &m->memory_layer, 1, false, g)); }
@@ -690,8 +695,14 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * C, 256)), dim3(256), 0, st, src, lds, dst, C, B, C);
   };
   const bool dv = is_deepvoice(m);
+  const int S = simple_S(m), ldc = D + S, np = hp.dec_prenet_n, Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
   fill(nullptr, 0, w.zero, Mm);
-  fill(nullptr, 0, w.ctx, D);
+  hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const float*)nullptr, 0, w.ctx, ldc, B, D);
+  if (S) {  // speaker_embed = embedding_lookup(table, speaker_id) (tacotron.py:44-49), parked behind ctx and behind the prenet output
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(B * S, 256)), dim3(256), 0, st, AP(m, m->spk_emb), speaker_id, B, S, spk->emb);
+    hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * S, 256)), dim3(256), 0, st, spk->emb, S, w.ctx + D, ldc, B, S);
+    hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * S, 256)), dim3(256), 0, st, spk->emb, S, w.pz[np - 1] + Ilast, ldz, B, S);
+  }
   fill(dv ? spk->vec[2] : nullptr, As, w.h_att, As);
   for (int i = 0; i < L; ++i) fill(dv ? spk->vec[3 + i] : nullptr, Hd, w.hd[i], Hd);
   hipLaunchKernelGGL(k_init_align, dim3(cdiv(B * T_in, 256)), dim3(256), 0, st, w.align, B, T_in, hp.attention_type == 2 ? 1 : 0);
@@ -708,13 +719,14 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     // DecoderPrenetWrapper (rnn_wrappers.py:249,367-378): prenet(concat(frame, previous context))
     const float* cur = nullptr; int curd = 0;
     for (int i = 0; i < hp.dec_prenet_n; ++i) {
-      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, w.ctx, D, ACT_RELU, w.pz[0], hp.dec_prenet[0])
-                         : sk_linear(m, m->dec_prenet[i], cur, curd, curd, nullptr, 0, ACT_RELU, w.pz[i], hp.dec_prenet[i]);
+      const int ldo = (i == np - 1) ? ldz : hp.dec_prenet[i];
+      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, w.ctx, ldc, ACT_RELU, w.pz[0], ldo)
+                         : sk_linear(m, m->dec_prenet[i], cur, curd, curd, nullptr, 0, ACT_RELU, w.pz[i], ldo);
       TRY(run_skinny(st, B, &j, 1));
       cur = w.pz[i]; curd = hp.dec_prenet[i];
     }
-    // attention GRUCell (tacotron.py:127-130)
-    TRY(run_gru_cell(m, st, m->att_gru, B, cur, curd, w.h_att, w.rh, w.u, w.xc, nullptr));
+    // attention GRUCell (tacotron.py:127-130); 'simple': input = concat(prenet_out, speaker_embed) (rnn_wrappers.py:372-376)
+    TRY(run_gru_cell(m, st, m->att_gru, B, cur, ldz, w.h_att, w.rh, w.u, w.xc, nullptr));
     // query + score + normaliser + context (rnn_wrappers.py:304-341)
     // the query mat-vec runs inside the attention kernel (one launch less) when its partials fit the kernel's LDS
     const bool fuse_q = (A % 4 == 0) && A <= ATT_MAXT && A / 4 <= 64 * ATT_NW;
@@ -722,12 +734,12 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
       TRY(run_skinny(st, B, &j, 1)); }
     { AttnArgs a; memset(&a, 0, sizeof a);
       a.q = fuse_q ? nullptr : w.q; a.hq = w.h_att; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
-      a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx;
+      a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx; a.ldctx = ldc;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
       hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
       HIPCHK(hipGetLastError()); }
     // ConcatOutputAndAttentionWrapper + OutputProjectionWrapper (rnn_wrappers.py:405-415; tacotron.py:166-170)
-    { SkJob j = sk_linear(m, m->concat_proj, w.h_att, As, As, w.ctx, D, ACT_NONE, w.o[0], Hd);
+    { SkJob j = sk_linear(m, m->concat_proj, w.h_att, As, As, w.ctx, ldc, ACT_NONE, w.o[0], Hd);   // 'simple': + speaker_embed (rnn_wrappers.py:408-413)
       TRY(run_skinny(st, B, &j, 1)); }
     // residual GRU stack (tacotron.py:171-172)
     for (int i = 0; i < L; ++i) TRY(run_gru_cell(m, st, m->dec_gru[i], B, w.o[i], Hd, w.hd[i], w.rh, w.u, w.xc, w.o[i + 1]));
@@ -738,7 +750,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     if (dbg) {
       float* d = dbg + (size_t)t * B * dbgw;
       hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, w.h_att, As, d, dbgw, B, As);
-      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, w.ctx, D, d + As, dbgw, B, D);
+      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, w.ctx, ldc, d + As, dbgw, B, D);
       for (int i = 0; i < L; ++i)
         hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, w.hd[i], Hd, d + As + D + i * Hd, dbgw, B, Hd);
       HIPCHK(hipGetLastError());
@@ -752,16 +764,28 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
 }
 
 // ---- post-net + linear head (tacotron.py:219-235) ----
-struct PostWs { CbhgWs cb; float* post_out; };
+struct PostWs { CbhgWs cb; float* post_out; float* spk_emb; float* rowvec; };
 static void carve_post(Carver& cv, const taco_model* m, int B, int T, PostWs& w) {
   carve_cbhg(cv, m->post, B, T, w.cb);
   w.post_out = cv.f((size_t)B * T * 2 * m->hp.post_rnn_size);
+  w.spk_emb = cv.f((size_t)B * std::max(simple_S(m), 1));
+  w.rowvec = cv.f((size_t)B * m->hp.num_freq);
 }
-static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel, int B, int T, float* linear,
-                           float* post_out_user, const PostWs& w) {
+static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel, const int* speaker_id, int B, int T,
+                           float* linear, float* post_out_user, const PostWs& w) {
   float* po = post_out_user ? post_out_user : w.post_out;
   TRY(cbhg_forward(m, st, m->post, mel, B, T, nullptr, nullptr, nullptr, po, w.cb));
   GemmCall g; g.x = po; g.ldx = 2 * m->hp.post_rnn_size; g.M = B * T; g.out = linear; g.ldo = m->hp.num_freq;
+  if (is_simple(m)) {
+    // linear(concat(tiled speaker_embed, post)) (tacotron.py:226-235) = post . W[S:] + (speaker_embed . W[:S]) per batch row
+    if (!speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+    const int S = simple_S(m), F = m->hp.num_freq;
+    hipLaunchKernelGGL(k_gather_rows, dim3(cdiv(B * S, 256)), dim3(256), 0, st, AP(m, m->spk_emb), speaker_id, B, S, w.spk_emb);
+    HIPCHK(hipGetLastError());
+    SkJob j = sk_linear(m, m->lin_spk, w.spk_emb, S, S, nullptr, 0, ACT_NONE, w.rowvec, F);
+    TRY(run_skinny(st, B, &j, 1));
+    g.T = T; g.rowvec = w.rowvec; g.ldrv = F;
+  }
   return run_gemm(m, st, &m->linear, 1, false, g);
 }
 
@@ -794,7 +818,7 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
   TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
   TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
-  TRY(postnet_forward(m, st, mel, B, n * m->hp.reduction_factor, linear, nullptr, w.post));
+  TRY(postnet_forward(m, st, mel, spk, B, n * m->hp.reduction_factor, linear, nullptr, w.post));
   return 0;
 }
 
@@ -810,8 +834,10 @@ int taco_model_create(const taco_hparams* hp, int device, taco_model** out) {
   if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
   if (hp->model_type < 0 || hp->model_type > 2) return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown multi-speaker model type: %d", hp->model_type);
   if (hp->attention_type < 0 || hp->attention_type > 2) return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown attention type: %d", hp->attention_type);
-  if (hp->num_speakers > 1 && hp->model_type == 1)
-    return fail(TACO_ERR_UNSUPPORTED, "model_type 'simple' (speaker embedding concatenated at three points, tacotron.py:82-86,226-233) is not built yet");
+  if (hp->num_speakers > 1 && hp->model_type == 1 && hp->speaker_embedding_size == 1)
+    return fail(TACO_ERR_UNSUPPORTED, "model_type 'simple' with speaker_embedding_size 1 leaves speaker_embed undefined in the reference (tacotron.py:44-49,82-86)");
+  if (hp->num_speakers > 1 && hp->model_type == 1 && hp->speaker_embedding_size % 4)
+    return fail(TACO_ERR_UNSUPPORTED, "model_type 'simple' needs speaker_embedding_size to be a multiple of 4");
   if (hp->num_speakers > 1 && hp->model_type == 0)
     return fail(TACO_ERR_UNSUPPORTED, " [!] Unkown multi-speaker model type: single (num_speakers > 1 needs simple or deepvoice)");
   if (hp->enc_prenet_n < 1 || hp->enc_prenet_n > 4 || hp->dec_prenet_n < 1 || hp->dec_prenet_n > 4 || hp->enc_proj_n < 1 ||
@@ -883,6 +909,18 @@ int taco_model_finalize(taco_model* m) {
   m->memory_layer = make_conv(m, "attention/memory_layer", false, false);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
             hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width);
+  if (hp.num_speakers > 1 && hp.model_type == 1) {
+    // linear head input = concat(speaker_embed, post_outputs) (tacotron.py:226-235): rows [0,S) of the kernel
+    // multiply the per-utterance embedding -> a per-batch-row vector; rows [S,..) stay a GEMM over the frames
+    const int S = hp.speaker_embedding_size, F = hp.num_freq;
+    HostTensor& k = m->raw["linear/kernel"];
+    m->lin_spk = pack_w16(m, k.data.data(), F, 0, S, 0, F, nullptr);
+    HostTensor rest; rest.shape = {k.shape[0] - S, (int64_t)F};
+    rest.data.assign(k.data.begin() + (size_t)S * F, k.data.end());
+    rest.set = true;
+    m->raw["linear/kernel"] = rest;
+    m->spk_emb = arena_put(m, T_(m, "speaker_embedding").data.data(), T_(m, "speaker_embedding").data.size());
+  }
   m->linear = make_conv(m, "linear", false);
   // decoder (skinny packs)
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
@@ -893,12 +931,12 @@ int taco_model_finalize(taco_model* m) {
     m->skinny[n] = m->dec_prenet.back();
     d = hp.dec_prenet[i];
   }
-  m->att_gru = make_grudec(m, "decoder/attention_gru", d, As);
+  m->att_gru = make_grudec(m, "decoder/attention_gru", d + simple_S(m), As);   // simple: input = concat(prenet_out, speaker_embed)
   m->grus["decoder/attention_gru"] = m->att_gru;
   m->query = pack_w16(m, T_(m, "attention/query_layer/kernel").data.data(), A, 0, As, 0, A, nullptr);
   m->skinny["attention/query_layer"] = m->query;
   m->raw_wq = arena_put(m, T_(m, "attention/query_layer/kernel").data.data(), (size_t)As * A);
-  m->concat_proj = pack_w16(m, T_(m, "decoder/concat_projection/kernel").data.data(), Hd, 0, As + D, 0, Hd, T_(m, "decoder/concat_projection/bias").data.data());
+  m->concat_proj = pack_w16(m, T_(m, "decoder/concat_projection/kernel").data.data(), Hd, 0, As + D + simple_S(m), 0, Hd, T_(m, "decoder/concat_projection/bias").data.data());
   m->skinny["decoder/concat_projection"] = m->concat_proj;
   for (int i = 0; i < hp.dec_layer_num; ++i) {
     const std::string n = "decoder/gru_" + std::to_string(i + 1);
@@ -1095,15 +1133,15 @@ int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder
                          d_teacher_frames, d_mel, d_alignments, d_stop_step, d_dbg_states, w, false, nullptr);
 }
 
-int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, int B, int T_mel, float* d_linear,
-                         float* d_post_out, void* d_workspace, size_t workspace_bytes) {
+int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, const int32_t* d_speaker_id, int B, int T_mel,
+                         float* d_linear, float* d_post_out, void* d_workspace, size_t workspace_bytes) {
   TRY(check_common(m, B, T_mel));
   if (!d_mel || !d_linear || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
   HIPCHK(hipSetDevice(m->device));
   Carver cv(d_workspace, workspace_bytes);
   PostWs w; carve_post(cv, m, B, T_mel, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
-  return postnet_forward(m, (hipStream_t)hip_stream, d_mel, B, T_mel, d_linear, d_post_out, w);
+  return postnet_forward(m, (hipStream_t)hip_stream, d_mel, d_speaker_id, B, T_mel, d_linear, d_post_out, w);
 }
 
 static const ConvL* find_conv(taco_model* m, const char* layer) {
@@ -1183,7 +1221,7 @@ int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell
     HIPCHK(hipMemcpyAsync(d_alignments, d_prev_alignments, (size_t)B * T_in * sizeof(float), hipMemcpyDeviceToDevice, st));
   AttnArgs a; memset(&a, 0, sizeof a);
   a.q = q; a.keys = d_keys; a.values = d_values; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
-  a.align = d_alignments; a.ctx = d_context; a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.n_steps = 1;
+  a.align = d_alignments; a.ctx = d_context; a.ldctx = D; a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.n_steps = 1;
   hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
   HIPCHK(hipGetLastError());
   return 0;

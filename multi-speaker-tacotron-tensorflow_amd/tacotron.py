@@ -190,7 +190,7 @@ class Tacotron(object):
                     r = self._hparams.reduction_factor
                     mel = mel.view(B, plan.n, -1)[:, :stop].reshape(B, stop * r, self._hparams.num_mels).contiguous()
                     align = align[:, :, :stop].contiguous()
-                    linear = self.postnet(mel)
+                    linear = self.postnet(mel, speaker_id=plan.speaker_id if self.num_speakers > 1 else None)
         self.mel_outputs, self.linear_outputs, self.alignments = mel, linear, align
         return linear, align
 
@@ -228,14 +228,15 @@ class Tacotron(object):
                                                   _ptr(ws), n))
         return mel, align, stop, dbg
 
-    def postnet(self, mel, return_post=False):
+    def postnet(self, mel, return_post=False, speaker_id=None):
         hp = self._hparams
         mel = self._as_dev(mel, torch.float32)
+        spk = self._as_dev(speaker_id, torch.int32)
         B, T, _ = mel.shape
         lin = torch.empty((B, T, hp.num_freq), dtype=torch.float32, device=self.device)
         post = torch.empty((B, T, 2 * hp.post_rnn_size), dtype=torch.float32, device=self.device) if return_post else None
         ws, n = self._stage_ws(B, T)
-        _lib.check(self._lib.taco_postnet_forward(self._handle, _stream(), _ptr(mel), B, T, _ptr(lin), _ptr(post),
+        _lib.check(self._lib.taco_postnet_forward(self._handle, _stream(), _ptr(mel), _ptr(spk), B, T, _ptr(lin), _ptr(post),
                                                   _ptr(ws), n))
         return (lin, post) if return_post else lin
 

@@ -108,6 +108,31 @@ def test_speaker_embedding_size_one_tables():
     _check(_run(m, ids, L, spk), O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=3), tol=2e-4)
 
 
+@pytest.mark.parametrize("atype", ["bah_mon", "bah"])
+def test_simple_multispeaker_model(atype):
+    """model_type 'simple': speaker embedding concatenated at the attention-GRU input, the concat projection
+    and (in front) the linear head (rnn_wrappers.py:372-376,405-413; tacotron.py:226-235)."""
+    ohp = tiny_hp(model_type="simple", attention_type=atype)
+    w = O.init_weights(ohp, 3, 41)
+    ids, L = O.synthetic_inputs(4, 9, 42, ragged=True)
+    spk = np.array([2, 0, 1, 2], np.int32)
+    m = build_model(ohp, w, num_speakers=3)
+    _check(_run(m, ids, L, spk), O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=3), tol=2e-4)
+    # a different speaker changes the output
+    mel_a = _run(m, ids, L, spk)[0]
+    mel_b = _run(m, ids, L, np.array([0, 0, 1, 2], np.int32))[0]
+    assert np.abs(mel_a[0] - mel_b[0]).max() > 1e-4 and np.array_equal(mel_a[1:], mel_b[1:])
+
+
+def test_simple_full_width():
+    ohp = O.OracleHParams(max_iters=8, model_type="simple")
+    w = O.init_weights(ohp, 4, 43)
+    ids, L = O.synthetic_inputs(5, 40, 44, ragged=True)
+    spk = np.array([3, 1, 0, 2, 3], np.int32)
+    m = build_model(ohp, w, num_speakers=4)
+    _check(_run(m, ids, L, spk), O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=4), tol=1e-3)
+
+
 def test_batch_permutation_and_row_independence():
     ohp = tiny_hp()
     w = O.init_weights(ohp, 1, 25)

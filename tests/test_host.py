@@ -35,7 +35,7 @@ def test_c_struct_layout_matches_header_order():
     assert names == [f[0] for f in _lib.TacoHParams._fields_]
 
 
-@pytest.mark.parametrize("ns,mt", [(1, "single"), (4, "deepvoice")])
+@pytest.mark.parametrize("ns,mt", [(1, "single"), (4, "deepvoice"), (3, "simple")])
 def test_weight_spec_equals_oracle(ns, mt):
     for ohp in (O.OracleHParams(model_type=mt), tiny_hp(model_type=mt), tiny_hp(model_type=mt, attention_type="bah_norm")):
         spec = dict(taco_amd.weights.weight_spec(to_product_hp(ohp), ns))
@@ -57,9 +57,10 @@ def test_unknown_types_raise_like_the_reference():
         taco_amd.weights.weight_spec(hp, 1)
 
 
-def test_simple_model_type_fails_loudly():
-    hp = taco_amd.hparams.copy(model_type="simple")
-    with pytest.raises(_lib.TacoError, match="not built yet"):
+def test_simple_model_type_with_embedding_size_one_is_refused():
+    # the reference leaves speaker_embed undefined in that combination (tacotron.py:44-49,82-86)
+    hp = taco_amd.hparams.copy(model_type="simple", speaker_embedding_size=1)
+    with pytest.raises(_lib.TacoError, match="speaker_embed undefined"):
         taco_amd.weights.weight_spec(hp, 2)
 
 
