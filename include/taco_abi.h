@@ -144,6 +144,21 @@ int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell
 int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
                       float* d_out_res, void* d_workspace, size_t workspace_bytes);
 
+/* ---- training-side entry points that need no backward pass (the backward itself is not built yet) ---- */
+/* add_loss (tacotron.py:274-302).  d_mel_* [B,T,num_mels], d_lin_* [B,T,num_freq], d_loss_coeff [B] (nullable = 1).
+ * d_losses[4] = loss, mel_loss, linear_loss, loss_without_coeff.  Workspace >= 64 KiB. */
+int taco_loss_f32(void* hip_stream, const float* d_mel_out, const float* d_mel_tgt, const float* d_lin_out,
+                  const float* d_lin_tgt, const float* d_loss_coeff, int B, int T, int num_mels, int num_freq,
+                  int prioritize_loss, int sample_rate, float* d_losses, void* d_workspace, size_t workspace_bytes);
+/* learning-rate schedule of add_optimizer (tacotron.py:313-325); global_step = completed updates. */
+float taco_learning_rate(long long global_step, float initial_learning_rate, int decay_learning_rate_mode,
+                         int is_randomly_initialized);
+/* clip_by_global_norm + tf.train.AdamOptimizer update (tacotron.py:327-336, TF form of Adam) on flat fp32 buffers.
+ * Workspace >= 8 KiB.  d_gnorm_out nullable. */
+int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, float* d_m, float* d_v, size_t n,
+                       long long global_step, float learning_rate, float beta1, float beta2, float epsilon, float clip_norm,
+                       float* d_gnorm_out, void* d_workspace, size_t workspace_bytes);
+
 /* Persistent (multi-workgroup, in-kernel synchronised) kernels bound every spin; if one ever expires it sets a
  * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;
  * non-zero means the outputs of the affected forward are invalid. */

@@ -3,6 +3,7 @@
 // (models/tacotron.py:21-271 of the reference) and its sess.run execution (synthesizer.py:166-167).
 // No CPU compute path exists here: every stage is a gfx950 kernel from taco_kernels.h.
 #include "taco_kernels.h"
+#include "taco_train_kernels.h"
 #include "../../include/taco_abi.h"
 
 #include <algorithm>
@@ -1242,6 +1243,62 @@ int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const f
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small");
   if (d_out_res && g.I != g.H) return fail(TACO_ERR_SHAPE, "residual needs input size == state size");
   return run_gru_cell(m, (hipStream_t)hip_stream, g, R, d_x, g.I, d_h, rh, u, xc, d_out_res);
+}
+
+/* add_loss (tacotron.py:274-302) on device tensors.  d_losses[4] = loss, mel_loss, linear_loss, loss_without_coeff.
+ * Workspace: 2 * 1024 * 4 doubles. */
+int taco_loss_f32(void* hip_stream, const float* d_mel_out, const float* d_mel_tgt, const float* d_lin_out,
+                  const float* d_lin_tgt, const float* d_loss_coeff, int B, int T, int num_mels, int num_freq,
+                  int prioritize_loss, int sample_rate, float* d_losses, void* d_workspace, size_t workspace_bytes) {
+  if (!d_mel_out || !d_mel_tgt || !d_lin_out || !d_lin_tgt || !d_losses || !d_workspace || B <= 0 || T <= 0)
+    return fail(TACO_ERR_ARG, "bad argument");
+  if (workspace_bytes < (size_t)2 * TR_MAXBLK * 4 * sizeof(double)) return fail(TACO_ERR_STATE, "workspace too small");
+  hipStream_t st = (hipStream_t)hip_stream;
+  double* pm = (double*)d_workspace; double* pl = pm + (size_t)TR_MAXBLK * 4;
+  const int rows = B * T;
+  int lo = 0, hi = 0;
+  if (prioritize_loss) {   // tacotron.py:283-285
+    hi = (int)(5000 / (sample_rate * 0.5) * num_freq);
+    lo = (int)(165 / (sample_rate * 0.5) * num_freq);
+  }
+  const int nbm = std::min(TR_MAXBLK, cdiv(rows * num_mels, TR_NT * 8)), nbl = std::min(TR_MAXBLK, cdiv(rows * num_freq, TR_NT * 8));
+  hipLaunchKernelGGL(k_l1_partial, dim3(nbm), dim3(TR_NT), 0, st, d_mel_out, d_mel_tgt, d_loss_coeff, rows, T, num_mels, 0, 0, pm);
+  hipLaunchKernelGGL(k_l1_partial, dim3(nbl), dim3(TR_NT), 0, st, d_lin_out, d_lin_tgt, d_loss_coeff, rows, T, num_freq, lo, hi, pl);
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, st, pm, nbm, pl, nbl, (double)rows * num_mels, (double)rows * num_freq,
+                     (double)rows * std::max(hi - lo, 1), prioritize_loss, d_losses);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+/* learning rate of tacotron.py:313-325 for `global_step` (0-based count of completed updates). */
+float taco_learning_rate(long long global_step, float initial_learning_rate, int decay_learning_rate_mode, int is_randomly_initialized) {
+  const double step = (double)(global_step + 1);
+  if (decay_learning_rate_mode == 0) {
+    const double w = is_randomly_initialized ? 4000.0 : 40000.0;
+    return (float)(initial_learning_rate * std::sqrt(w) * std::min(step * std::pow(w, -1.5), std::pow(step, -0.5)));
+  }
+  return (float)(initial_learning_rate * std::pow(0.95, step / 3000.0));
+}
+
+/* add_optimizer's update (tacotron.py:327-336) on flat buffers of n floats: clip_by_global_norm(clip_norm), then
+ * tf.train.AdamOptimizer(lr, beta1, beta2) in TF form.  `global_step` = completed updates so far (Adam's t = +1).
+ * d_gnorm_out (nullable) receives the global gradient norm.  Workspace: 1024 doubles. */
+int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, float* d_m, float* d_v, size_t n,
+                       long long global_step, float learning_rate, float beta1, float beta2, float epsilon, float clip_norm,
+                       float* d_gnorm_out, void* d_workspace, size_t workspace_bytes) {
+  if (!d_params || !d_grads || !d_m || !d_v || !d_workspace || n == 0) return fail(TACO_ERR_ARG, "bad argument");
+  if (workspace_bytes < (size_t)TR_MAXBLK * sizeof(double)) return fail(TACO_ERR_STATE, "workspace too small");
+  if ((reinterpret_cast<uintptr_t>(d_grads) & 15) != 0) return fail(TACO_ERR_ARG, "gradient buffer must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)hip_stream;
+  double* part = (double*)d_workspace;
+  const int nblk = (int)std::min<size_t>(TR_MAXBLK, (n + TR_NT * 16 - 1) / (TR_NT * 16));
+  const double t = (double)(global_step + 1);
+  const float lr_t = (float)((double)learning_rate * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(nblk), dim3(TR_NT), 0, st, d_grads, n, part);
+  hipLaunchKernelGGL(k_adam, dim3(std::max(nblk, 1) * 2), dim3(TR_NT), 0, st, d_params, d_grads, d_m, d_v, n, part, nblk, lr_t, beta1,
+                     beta2, epsilon, clip_norm, d_gnorm_out);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

@@ -1,0 +1,77 @@
+"""Training-side operators that exist so far (the backward pass K22 is NOT built yet):
+
+* `l1_losses`      -- Tacotron.add_loss (models/tacotron.py:274-302) on device tensors (HIP reduction kernels)
+* `FlatAdam`       -- Tacotron.add_optimizer's update (tacotron.py:305-336): LR schedule, clip_by_global_norm(1.0),
+                      tf.train.AdamOptimizer in TF form, fused over ONE flat fp32 parameter buffer
+* `allreduce_gradients` -- the single collective of the data-parallel train step: one all-reduce
+                      (sum) of the flat gradient bucket over RCCL (xGMI), then division by the world size because
+                      the loss is a mean over the global batch.
+
+PyTorch provides device memory, the stream and torch.distributed; the arithmetic is in libtaco_hip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def l1_losses(mel_outputs, mel_targets, linear_outputs, linear_targets, loss_coeff=None, prioritize_loss=False,
+              sample_rate=24000):
+    """Returns a device tensor [4] = (loss, mel_loss, linear_loss, loss_without_coeff)."""
+    lib = _lib.load_library()
+    B, T, M = mel_outputs.shape
+    F = linear_outputs.shape[-1]
+    assert mel_targets.shape == mel_outputs.shape and linear_targets.shape == linear_outputs.shape
+    out = torch.empty(4, dtype=torch.float32, device=mel_outputs.device)
+    ws = torch.empty(1 << 16, dtype=torch.uint8, device=mel_outputs.device)
+    tens = [t.contiguous().float() for t in (mel_outputs, mel_targets, linear_outputs, linear_targets)]
+    coeff = loss_coeff.contiguous().float() if loss_coeff is not None else None
+    _lib.check(lib.taco_loss_f32(_st(), _p(tens[0]), _p(tens[1]), _p(tens[2]), _p(tens[3]), _p(coeff), B, T, M, F,
+                                 int(bool(prioritize_loss)), int(sample_rate), _p(out), _p(ws), ws.numel()))
+    return out
+
+
+class FlatAdam(object):
+    """One flat fp32 buffer for all parameters (37.3 MB at the default hparams), Adam slots beside it."""
+
+    def __init__(self, flat_params, initial_learning_rate=0.002, beta1=0.9, beta2=0.999, epsilon=1e-8,
+                 decay_learning_rate_mode=0, is_randomly_initialized=True, clip_norm=1.0):
+        assert flat_params.dtype == torch.float32 and flat_params.is_contiguous() and flat_params.dim() == 1
+        self.params = flat_params
+        self.m = torch.zeros_like(flat_params)
+        self.v = torch.zeros_like(flat_params)
+        self.global_step = 0
+        self.hyper = (initial_learning_rate, beta1, beta2, epsilon, decay_learning_rate_mode, is_randomly_initialized, clip_norm)
+        self._ws = torch.empty(1 << 14, dtype=torch.uint8, device=flat_params.device)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=flat_params.device)
+        self._lib = _lib.load_library()
+
+    @property
+    def learning_rate(self):
+        lr0, _, _, _, mode, rnd, _ = self.hyper
+        return float(self._lib.taco_learning_rate(self.global_step, lr0, mode, int(rnd)))
+
+    def step(self, flat_grads):
+        lr0, b1, b2, eps, mode, rnd, clip = self.hyper
+        assert flat_grads.shape == self.params.shape and flat_grads.dtype == torch.float32
+        _lib.check(self._lib.taco_adam_step_f32(_st(), _p(self.params), _p(flat_grads.contiguous()), _p(self.m), _p(self.v),
+                                                self.params.numel(), self.global_step, self.learning_rate, b1, b2, eps, clip,
+                                                _p(self.gnorm), _p(self._ws), self._ws.numel()))
+        self.global_step += 1
+
+
+def allreduce_gradients(flat_grads):
+    """In place: sum over ranks (RCCL all-reduce of ONE bucket), divided by the world size."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        flat_grads.div_(dist.get_world_size())
+    return flat_grads

@@ -595,3 +595,47 @@ def algorithmic_bytes(hp: OracleHParams, B, T_in, n, num_speakers=1):
     per_step = W_dec + B * T_in * (A + D) + B * (2 * (M + D + hp.attention_state_size + LD) + M * r + 3 * T_in)
     total = W_enc + W_post + n * per_step + B * T_in * (1 + D + A) + B * n * r * (M + F)
     return 4 * total, 4 * per_step
+
+
+# ----------------------------------------------------------------------------------------
+# training-side pieces that do not need a backward pass (tacotron.py:274-336)
+# ----------------------------------------------------------------------------------------
+
+def add_loss(mel_out, mel_tgt, lin_out, lin_tgt, loss_coeff, prioritize_loss=False, sample_rate=24000):
+    """tacotron.py:274-302.  Returns dict(loss, mel_loss, linear_loss, loss_without_coeff)."""
+    mel_l = np.abs(mel_tgt - mel_out)
+    l1 = np.abs(lin_tgt - lin_out)
+    c = np.asarray(loss_coeff, dtype=mel_l.dtype)[:, None, None]
+    F = lin_out.shape[-1]
+    if prioritize_loss:
+        up = int(5000 / (sample_rate * 0.5) * F)
+        lo = int(165 / (sample_rate * 0.5) * F)
+        pr = l1[:, :, lo:up]
+        loss = np.mean(mel_l * c) + 0.5 * np.mean(l1 * c) + 0.5 * np.mean(pr * c)
+        lin_loss = 0.5 * (np.mean(l1) + np.mean(pr))
+    else:
+        loss = np.mean(mel_l * c) + np.mean(l1 * c)
+        lin_loss = np.mean(l1)
+    mel_loss = np.mean(mel_l)
+    return dict(loss=loss, mel_loss=mel_loss, linear_loss=lin_loss, loss_without_coeff=mel_loss + lin_loss)
+
+
+def learning_rate(global_step, initial_learning_rate=0.002, decay_learning_rate_mode=0, is_randomly_initialized=True):
+    """tacotron.py:313-325 (step = global_step + 1)."""
+    step = float(global_step + 1)
+    if decay_learning_rate_mode == 0:
+        w = 4000.0 if is_randomly_initialized else 40000.0
+        return initial_learning_rate * w ** 0.5 * min(step * w ** -1.5, step ** -0.5)
+    return initial_learning_rate * 0.95 ** (step / 3000.0)       # TF-sem exponential_decay(1., step, 3000, 0.95)
+
+
+def adam_clip_step(params, grads, m, v, t, lr, beta1=0.9, beta2=0.999, eps=1e-8, clip_norm=1.0):
+    """tacotron.py:327-336: clip_by_global_norm(1.0) then tf.train.AdamOptimizer (A.14; epsilon outside
+    the bias-corrected form).  t = number of this update (1-based).  Flat float arrays; returns
+    (params, m, v, global_norm)."""
+    gn = np.sqrt(np.sum(np.square(grads.astype(np.float64))))
+    g = grads * (clip_norm / max(gn, clip_norm))               # TF-sem clip_by_global_norm
+    lr_t = lr * np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    m = beta1 * m + (1 - beta1) * g
+    v = beta2 * v + (1 - beta2) * g * g
+    return params - lr_t * m / (np.sqrt(v) + eps), m, v, gn

@@ -51,3 +51,33 @@ def test_two_rank_sharded_inference_equals_single():
     assert t == 2.0
     assert frames == ref.shape[0] * ref.shape[1]
     assert np.allclose(mel, ref, atol=1e-12)
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch
+    import torch.distributed as dist
+    from taco_amd import dist as D
+    from taco_amd.train_ops import allreduce_gradients
+    D.init_process_group("gloo")
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)       # per-shard gradient of a per-shard mean loss
+    allreduce_gradients(g)
+    if rank == 0:
+        q.put(g.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_is_the_mean_of_the_shards():
+    """X1: one all-reduce of the flat bucket, divided by world size = gradient of the global-batch mean."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(g, np.arange(1000) * 1.5)

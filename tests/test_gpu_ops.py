@@ -220,3 +220,42 @@ def test_attention_step(atype, T_in):
     torch.cuda.synchronize()
     assert maxabs(al.cpu().numpy(), a_ref) < 2e-6
     assert maxabs(cx.cpu().numpy(), c_ref) < 2e-5
+
+
+@pytest.mark.parametrize("prioritize", [False, True])
+def test_add_loss_kernel(prioritize):
+    """tacotron.py:274-302 incl. the prioritize_loss band (165 Hz .. 5 kHz of num_freq bins)."""
+    import torch
+    import taco_amd
+    rs = np.random.RandomState(5)
+    B, T, M, F = 3, 37, 80, 1025
+    mo, mt = rs.rand(B, T, M), rs.rand(B, T, M)
+    lo, lt = rs.rand(B, T, F), rs.rand(B, T, F)
+    coeff = np.array([1.0, 0.5, 2.0])
+    ref = O.add_loss(mo, mt, lo, lt, coeff, prioritize_loss=prioritize, sample_rate=24000)
+    out = taco_amd.train_ops.l1_losses(dev(mo, torch.float32), dev(mt, torch.float32), dev(lo, torch.float32), dev(lt, torch.float32),
+                                       dev(coeff, torch.float32), prioritize_loss=prioritize, sample_rate=24000).cpu().numpy()
+    want = [ref["loss"], ref["mel_loss"], ref["linear_loss"], ref["loss_without_coeff"]]
+    assert np.allclose(out, want, rtol=2e-6, atol=1e-7), (out, want)
+
+
+@pytest.mark.parametrize("mode,rnd", [(0, True), (0, False), (1, True)])
+def test_flat_adam_clip_lr_schedule(mode, rnd):
+    """tacotron.py:305-336: LR schedule, clip_by_global_norm(1.0), TF-form Adam over a flat buffer; 5 updates."""
+    import torch
+    import taco_amd
+    rs = np.random.RandomState(6)
+    n = 100003
+    p0 = rs.randn(n).astype(np.float32)
+    opt = taco_amd.train_ops.FlatAdam(dev(p0.copy()), decay_learning_rate_mode=mode, is_randomly_initialized=rnd)
+    p, m, v = p0.astype(np.float64), np.zeros(n), np.zeros(n)
+    for t in range(1, 6):
+        g = (rs.randn(n) * (3.0 if t % 2 else 0.001)).astype(np.float32)          # norm above and below the clip
+        lr = O.learning_rate(t - 1, 0.002, mode, rnd)
+        assert abs(opt.learning_rate - lr) < 1e-9 + 1e-6 * lr
+        p, m, v, gn = O.adam_clip_step(p, g.astype(np.float64), m, v, t, lr)
+        opt.step(dev(g))
+        torch.cuda.synchronize()
+        assert abs(float(opt.gnorm.item()) - gn) < 1e-4 * gn
+    assert np.abs(opt.params.cpu().numpy() - p).max() < 2e-6
+    assert np.abs(opt.m.cpu().numpy() - m).max() < 1e-6 and np.abs(opt.v.cpu().numpy() - v).max() < 1e-6
