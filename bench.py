@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=None, help="debug: 0 = no decoder/post-net overlap, N>1 = chunk of N decoder steps")
     ap.add_argument("--eager", action="store_true", help="enqueue kernels directly instead of replaying the hipGraph plan")
     args = ap.parse_args()
 
@@ -137,6 +138,8 @@ def main():
     seed = 1234 + sorted(WORKLOADS).index(args.workload)
     model.load_weights(taco_amd.weights.random_weights(hp, ns, seed=seed))   # random-init weights of the architecture
     model.initialize(None, None, ns, None, device=str(dev))
+    if args.overlap is not None:
+        model._lib.taco_debug_set_overlap(model._handle, args.overlap)
     rs = np.random.RandomState(seed + 100 * rank)
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)
     ids[:, T_in - 1] = 1                                                       # fixed-length batches

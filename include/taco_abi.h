@@ -166,6 +166,11 @@ int taco_model_device_errors(taco_model* m, int* out);
 /* test hook: 0 = per-step launches for the sequential loops, 1 (default) = persistent row-parallel kernels when they fit */
 int taco_debug_set_persistent(taco_model* m, int on);
 
+/* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream
+ * (fork/join by events, a parallel branch in the hipGraph) in chunks of max(on,16) decoder steps; 0 (default) =
+ * strictly sequential, which measures faster on MI355X (profiles/README.md) */
+int taco_debug_set_overlap(taco_model* m, int on);
+
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
 int taco_debug_force_gemm_config(taco_model* m, int cfg);
 

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "taco_adam_step_f32": (_I, [_P, _P, _P, _P, _P, _S, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
+    "taco_debug_set_overlap": (_I, [_P, _I]),
     "taco_model_device_errors": (_I, [_P, C.POINTER(_I)]),
 }
 

@@ -76,6 +76,7 @@ struct GemmArgs {
                           // (tf.reverse_sequence, A.7); null lengths = T
   float* out;             // [M, ldo]
   int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0;
+  int t_begin, t_len, tiles_per_b;   // time-window mode (t_len > 0): rows (b, t_begin + i), i < t_len, for every batch row b
   GemmVar v[16];          // one per blockIdx.z (conv-bank widths); by value so the fields arrive by scalar loads
 };
 
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
-           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0; } a =
+           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b; } a =
       {a_in.x, a_in.gather, a_in.res, a_in.rowvec, a_in.rev_len, a_in.out, a_in.ldx, a_in.M, a_in.T, a_in.Cin, a_in.cin_pad,
-       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0};
+       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b};
+  PIN(a.t_begin); PIN(a.t_len); PIN(a.tiles_per_b);
   PIN(a.rev_len); PIN(a.rev_col0);
   PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out);
   PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.cin_pad); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
@@ -139,7 +141,16 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // flat mode: M-tiles over rows m = b*T + t; window mode: tiles over [t_begin, t_begin + t_len) of every batch row
+  // (the post-net's feed-forward stages run chunk by chunk behind the decoder; halo rows outside the window are
+  //  read like any other row -- they were produced by earlier chunks)
+  int m0 = blockIdx.x * BM, row_limit = a.M;
+  if (a.t_len > 0) {
+    const int bb = blockIdx.x / a.tiles_per_b, tile = blockIdx.x - bb * a.tiles_per_b;
+    m0 = bb * a.T + a.t_begin + tile * BM;
+    row_limit = bb * a.T + a.t_begin + a.t_len;
+  }
+  const int n0 = blockIdx.y * BN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int rows = BM + v.kw - 1;
 
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= a.M) continue;
+        if (row >= row_limit) continue;
         float val;
         if constexpr (DUAL) {  // highway (modules.py:105-120): H*T + x*(1-T)
           const float H = fmaxf(acc[tm][tn][r] + bia, 0.f);

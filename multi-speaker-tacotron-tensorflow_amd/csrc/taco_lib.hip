@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -102,6 +103,10 @@ struct taco_model {
   int force_cfg = -1;
   unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
   int persist = 1;             // use the persistent BiGRU kernel when it fits
+  int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
+                               // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
+  hipStream_t side = nullptr;  // that second stream
+  std::vector<hipEvent_t> events;
 };
 
 static size_t arena_put(taco_model* m, const float* src, size_t n) {
@@ -349,6 +354,7 @@ struct GemmCall {
   const float* res = nullptr; int ldres = 0;
   const float* rowvec = nullptr; int ldrv = 0;
   const int* rev_len = nullptr; int rev_col0 = -1;
+  int t_begin = 0, t_len = 0;      // time window [t_begin, t_begin + t_len) of every batch row (t_len 0 = all rows)
   float* out = nullptr; int ldo = 0;
 };
 
@@ -357,8 +363,11 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NTHR = 64 * WM * WN * KS;
   size_t lds = (size_t)(BM + kw_max - 1) * TACO_LDSW * sizeof(float);
   if (KS > 1) lds = std::max(lds, (size_t)(KS - 1) * WM * WN * TM * TN * 1024 * (DUAL ? 2 : 1) * sizeof(float));
-  dim3 grid(cdiv(a.M, BM), cdiv(Nmax, BN), nvar);
-  hipLaunchKernelGGL((k_gemm<WM, WN, TM, TN, KS, DUAL>), grid, dim3(NTHR), lds, st, a);
+  GemmArgs aa = a;
+  int gx = cdiv(a.M, BM);
+  if (a.t_len > 0) { aa.tiles_per_b = cdiv(a.t_len, BM); gx = (a.M / a.T) * aa.tiles_per_b; }
+  dim3 grid(gx, cdiv(Nmax, BN), nvar);
+  hipLaunchKernelGGL((k_gemm<WM, WN, TM, TN, KS, DUAL>), grid, dim3(NTHR), lds, st, aa);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -380,6 +389,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
   a.x = c.x; a.gather = c.gather; a.res = c.res; a.rowvec = c.rowvec; a.out = c.out;
   a.ldx = c.ldx; a.M = c.M; a.T = c.T > 0 ? c.T : c.M; a.Cin = L0.cin; a.cin_pad = L0.cin_pad; a.mpw = c.mpw;
   a.act = c.act; a.ldres = c.ldres; a.ldrv = c.ldrv; a.ldo = c.ldo; a.rev_len = c.rev_len; a.rev_col0 = c.rev_col0;
+  a.t_begin = c.t_begin; a.t_len = c.t_len;
   a.vec_ok = (c.ldx % 4 == 0) && (L0.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.x) & 15) == 0);
   int kw_max = 1, Nmax = 0;
   for (int i = 0; i < nvar; ++i) {
@@ -388,7 +398,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     a.v[i] = m->hvars[layers[i].var_index];
   }
   if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
-  const int cfg = pick_cfg(m, c.M, Nmax, nvar);
+  const int cfg = pick_cfg(m, c.t_len > 0 ? (c.M / a.T) * c.t_len : c.M, Nmax, nvar);
   if (dual) {
     switch (cfg) {
       case 0: case 3: return launch_gemm_cfg<2, 2, 2, 1, 1, true>(st, a, nvar, kw_max, Nmax);
@@ -508,13 +518,9 @@ static bool bigru_rows_cfg(int B, int H, int* R_out, size_t* lds_out) {
 // BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
 // directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
 // directions side by side in each launch.  x [B*T, rnn], out [B*T, 2*rnn].
-static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
+static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
-  const int H = c.rnn, M = B * T;
-  // backward-direction columns are stored time-reversed per row (reverse_sequence), so scan step s reads row s
-  { GemmCall xp; xp.x = x; xp.ldx = c.rnn; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H;
-    xp.rev_len = lengths; xp.rev_col0 = 3 * H;
-    TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
+  const int H = c.rnn;
   {  // row-parallel persistent kernel: the whole scan in one launch, weights streamed from L2 every step
     int R = 0; size_t lds = 0;
     if (m->persist && bigru_rows_cfg(B, H, &R, &lds)) {
@@ -553,42 +559,77 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, const 
   return 0;
 }
 
-// modules.py:27-96.  x [B*T, in_dim] (or embedding rows via gather==null only), out [B*T, 2*rnn].
-static int cbhg_forward(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
-                        const int* lengths, const float* before_highway, const float* init_state, float* out,
-                        const CbhgWs& w) {
+// Feed-forward part of a CBHG (modules.py:27-77) with per-stage watermarks, so it can run chunk by chunk
+// behind a producer of its input frames (the decoder): every stage is advanced as far as the frames
+// available to it allow (a conv needs its right halo; the last chunk gets TF's zero padding).
+struct FfProg { int w_bank = 0, w_p[4] = {0, 0, 0, 0}, w_pt = 0; };
+static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
+                           const int* lengths, const float* before_highway, const CbhgWs& w, FfProg& pg, int avail,
+                           const float** ff_out) {
   const int M = B * T;
-  GemmCall g;
+  auto right = [](int k) { return k - 1 - (k - 1) / 2; };
+  auto advance = [&](int win, int reach) { return win >= T ? T : std::max(0, win - reach); };
   // conv bank: all K widths in one launch, written channel-concatenated (modules.py:35-44)
-  g.x = x; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank; g.ldo = c.K * c.C;
-  TRY(run_gemm(m, st, c.bank.data(), c.K, false, g));
+  { const int nw = advance(avail, right(c.K));
+    if (nw > pg.w_bank) {
+      GemmCall g; g.x = x; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank; g.ldo = c.K * c.C;
+      g.t_begin = pg.w_bank; g.t_len = nw - pg.w_bank;
+      TRY(run_gemm(m, st, c.bank.data(), c.K, false, g));
+      pg.w_bank = nw;
+    } }
   // maxpool (fused into the staging of proj_1) + projections (modules.py:47-59)
   const float* cur = w.bank; int curd = c.K * c.C;
   for (size_t i = 0; i < c.proj.size(); ++i) {
-    GemmCall p;
-    p.x = cur; p.ldx = curd; p.M = M; p.T = T; p.mpw = (i == 0) ? c.maxpool : 1;
-    p.act = (i + 1 == c.proj.size()) ? ACT_NONE : ACT_RELU;
-    p.out = w.p[i]; p.ldo = c.proj[i].N;
-    if (i + 1 == c.proj.size()) {  // residual (modules.py:62-69)
-      p.res = x; p.ldres = c.in_dim;
-      p.rowvec = before_highway; p.ldrv = c.in_dim;
+    const int win = (i == 0) ? pg.w_bank : pg.w_p[i - 1];
+    const int nw = advance(win, right(c.pw) + ((i == 0) ? right(c.maxpool) : 0));
+    if (nw > pg.w_p[i]) {
+      GemmCall p;
+      p.x = cur; p.ldx = curd; p.M = M; p.T = T; p.mpw = (i == 0) ? c.maxpool : 1;
+      p.act = (i + 1 == c.proj.size()) ? ACT_NONE : ACT_RELU;
+      p.out = w.p[i]; p.ldo = c.proj[i].N;
+      p.t_begin = pg.w_p[i]; p.t_len = nw - pg.w_p[i];
+      if (i + 1 == c.proj.size()) {  // residual (modules.py:62-69)
+        p.res = x; p.ldres = c.in_dim;
+        p.rowvec = before_highway; p.ldrv = c.in_dim;
+      }
+      TRY(run_gemm(m, st, &c.proj[i], 1, false, p));
+      pg.w_p[i] = nw;
     }
-    TRY(run_gemm(m, st, &c.proj[i], 1, false, p));
     cur = w.p[i]; curd = c.proj[i].N;
   }
-  if (c.has_dense) {  // modules.py:72-73
-    GemmCall d; d.x = cur; d.ldx = curd; d.M = M; d.out = w.hi0; d.ldo = c.rnn;
-    TRY(run_gemm(m, st, &c.dense, 1, false, d));
+  // point-wise chain: optional dense (modules.py:72-73), highway x depth (:76-77), hoisted BiGRU input projection
+  const int wlast = pg.w_p[c.proj.size() - 1];
+  const int t0 = pg.w_pt, tl = wlast - pg.w_pt;
+  if (c.has_dense) {
+    if (tl > 0) { GemmCall d; d.x = cur; d.ldx = curd; d.M = M; d.T = T; d.out = w.hi0; d.ldo = c.rnn; d.t_begin = t0; d.t_len = tl;
+      TRY(run_gemm(m, st, &c.dense, 1, false, d)); }
     cur = w.hi0;
   }
   float* bufs[2] = {w.hi0, w.hi1};
   int sel = (cur == w.hi0) ? 1 : 0;
-  for (int i = 0; i < c.depth; ++i) {  // modules.py:76-77
-    GemmCall h; h.x = cur; h.ldx = c.rnn; h.M = M; h.out = bufs[sel]; h.ldo = c.rnn;
-    TRY(run_gemm(m, st, &c.hw[i], 1, true, h));
-    cur = h.out; sel ^= 1;
+  for (int i = 0; i < c.depth; ++i) {
+    if (tl > 0) { GemmCall h; h.x = cur; h.ldx = c.rnn; h.M = M; h.T = T; h.out = bufs[sel]; h.ldo = c.rnn; h.t_begin = t0; h.t_len = tl;
+      TRY(run_gemm(m, st, &c.hw[i], 1, true, h)); }
+    cur = bufs[sel]; sel ^= 1;
   }
-  return bigru_scan(m, st, c, cur, B, T, lengths, init_state, out, w);
+  if (tl > 0) {  // backward-direction columns are stored time-reversed per row (reverse_sequence), so scan step s reads row s
+    const int H = c.rnn;
+    GemmCall xp; xp.x = cur; xp.ldx = c.rnn; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H;
+    xp.rev_len = lengths; xp.rev_col0 = 3 * H; xp.t_begin = t0; xp.t_len = tl;
+    TRY(run_gemm(m, st, &c.xproj, 1, false, xp));
+    pg.w_pt = wlast;
+  }
+  if (ff_out) *ff_out = cur;
+  return 0;
+}
+
+// modules.py:27-96.  x [B*T, in_dim], out [B*T, 2*rnn].
+static int cbhg_forward(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T,
+                        const int* lengths, const float* before_highway, const float* init_state, float* out,
+                        const CbhgWs& w) {
+  FfProg pg;
+  TRY(cbhg_ff_advance(m, st, c, x, B, T, lengths, before_highway, w, pg, T, nullptr));
+  return bigru_scan(m, st, c, B, T, lengths, init_state, out, w);
 }
 
 // ---- speaker conditioning (tacotron.py:41-94) ----
@@ -679,7 +720,8 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
 }
 static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B,
                            int T_in, int n, const float* manual, const float* teacher, float* mel, float* align_out,
-                           int* stop_step, float* dbg, const DecWs& w, bool spk_ready, const SpkWs* spk_in) {
+                           int* stop_step, float* dbg, const DecWs& w, bool spk_ready, const SpkWs* spk_in,
+                           const std::function<int(int)>* after_step = nullptr) {
   const taco_hparams& hp = m->hp;
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
   const int Mm = hp.num_mels, rM = hp.num_mels * hp.reduction_factor, L = hp.dec_layer_num;
@@ -748,6 +790,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     { SkJob j = sk_linear(m, m->frame_proj, w.o[L], Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, ldY);
       j.o2 = reinterpret_cast<float*>(w.nz + (size_t)t * B);
       TRY(run_skinny(st, B, &j, 1)); }
+    if (after_step) TRY((*after_step)(t));
     if (dbg) {
       float* d = dbg + (size_t)t * B * dbgw;
       hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, w.h_att, As, d, dbgw, B, As);
@@ -772,10 +815,10 @@ static void carve_post(Carver& cv, const taco_model* m, int B, int T, PostWs& w)
   w.spk_emb = cv.f((size_t)B * std::max(simple_S(m), 1));
   w.rowvec = cv.f((size_t)B * m->hp.num_freq);
 }
-static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel, const int* speaker_id, int B, int T,
-                           float* linear, float* post_out_user, const PostWs& w) {
+static int postnet_tail(const taco_model* m, hipStream_t st, const int* speaker_id, int B, int T, float* linear,
+                        float* post_out_user, const PostWs& w) {
   float* po = post_out_user ? post_out_user : w.post_out;
-  TRY(cbhg_forward(m, st, m->post, mel, B, T, nullptr, nullptr, nullptr, po, w.cb));
+  TRY(bigru_scan(m, st, m->post, B, T, nullptr, nullptr, po, w.cb));
   GemmCall g; g.x = po; g.ldx = 2 * m->hp.post_rnn_size; g.M = B * T; g.out = linear; g.ldo = m->hp.num_freq;
   if (is_simple(m)) {
     // linear(concat(tiled speaker_embed, post)) (tacotron.py:226-235) = post . W[S:] + (speaker_embed . W[:S]) per batch row
@@ -788,6 +831,12 @@ static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel
     g.T = T; g.rowvec = w.rowvec; g.ldrv = F;
   }
   return run_gemm(m, st, &m->linear, 1, false, g);
+}
+static int postnet_forward(const taco_model* m, hipStream_t st, const float* mel, const int* speaker_id, int B, int T,
+                           float* linear, float* post_out_user, const PostWs& w) {
+  FfProg pg;
+  TRY(cbhg_ff_advance(m, st, m->post, mel, B, T, nullptr, nullptr, w.cb, pg, T, nullptr));
+  return postnet_tail(m, st, speaker_id, B, T, linear, post_out_user, w);
 }
 
 struct FullWs { EncWs enc; DecWs dec; PostWs post; float* enc_out; };
@@ -818,9 +867,33 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   carve_full(cv, m, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
   TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
-  TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
-  TRY(postnet_forward(m, st, mel, spk, B, n * m->hp.reduction_factor, linear, nullptr, w.post));
-  return 0;
+  const int r = m->hp.reduction_factor, T_mel = n * r;
+  const int CH = m->overlap > 16 ? m->overlap : 16;   // decoder steps per post-net chunk
+  if (!m->overlap || (size_t)(n / CH + 4) > m->events.size()) {
+    TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
+    return postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post);
+  }
+  // The decoder loop is a chain of tiny dependent launches that occupies < 1/5 of the CUs; the post-net's
+  // feed-forward stages (conv bank, projections, highways, hoisted GRU projection: ~1.3 ms of fp32 MFMA work @C2)
+  // need only frames that already exist plus a conv halo.  They run on a second stream, one chunk of CH steps
+  // behind the decoder (fork/join by events; captured into the hipGraph as a parallel branch).
+  hipStream_t s2 = m->side;
+  size_t ev = 0;
+  HIPCHK(hipEventRecord(m->events[ev], st));
+  HIPCHK(hipStreamWaitEvent(s2, m->events[ev], 0));
+  ++ev;
+  FfProg pg;
+  const std::function<int(int)> hook = [&](int t) -> int {
+    if ((t + 1) % CH != 0 && t != n - 1) return 0;
+    HIPCHK(hipEventRecord(m->events[ev], st));
+    HIPCHK(hipStreamWaitEvent(s2, m->events[ev], 0));
+    ++ev;
+    return cbhg_ff_advance(m, s2, m->post, mel, B, T_mel, nullptr, nullptr, w.post.cb, pg, (t + 1) * r, nullptr);
+  };
+  TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk, &hook));
+  HIPCHK(hipEventRecord(m->events[ev], s2));
+  HIPCHK(hipStreamWaitEvent(st, m->events[ev], 0));
+  return postnet_tail(m, st, spk, B, T_mel, linear, nullptr, w.post);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,6 +1070,9 @@ int taco_model_finalize(taco_model* m) {
   // persistent kernels carve up to the full 160 KiB of LDS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+  m->events.resize(192);
+  for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipMalloc((void**)&m->d_err, 256));
   HIPCHK(hipMemset(m->d_err, 0, 256));
   m->harena.clear(); m->harena.shrink_to_fit();
@@ -1009,6 +1085,8 @@ void taco_model_destroy(taco_model* m) {
   if (!m) return;
   if (m->darena) (void)hipFree(m->darena);
   if (m->d_err) (void)hipFree(m->d_err);
+  for (auto& e : m->events) (void)hipEventDestroy(e);
+  if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
 }
 
@@ -1019,6 +1097,12 @@ int taco_model_device_errors(taco_model* m, int* out) {
   HIPCHK(hipMemcpy(&v, m->d_err, sizeof v, hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemset(m->d_err, 0, 256));
   *out = (int)v;
+  return 0;
+}
+
+int taco_debug_set_overlap(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->overlap = on;
   return 0;
 }
 
@@ -1199,7 +1283,11 @@ int taco_bigru_f32(taco_model* m, void* hip_stream, const char* scope, const flo
   Carver cv(d_workspace, workspace_bytes);
   CbhgWs w; carve_cbhg(cv, *c, B, T, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes", cv.off);
-  return bigru_scan(m, st, *c, d_x, B, T, d_lengths, d_init_state, d_out, w);
+  { const int H = c->rnn;   // hoisted input projection (backward columns stored time-reversed), then the scan
+    GemmCall xp; xp.x = d_x; xp.ldx = H; xp.M = B * T; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H;
+    xp.rev_len = d_lengths; xp.rev_col0 = 3 * H;
+    TRY(run_gemm(m, st, &c->xproj, 1, false, xp)); }
+  return bigru_scan(m, st, *c, B, T, d_lengths, d_init_state, d_out, w);
 }
 
 int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell_output, const float* d_keys,

@@ -216,6 +216,23 @@ def test_graph_replay_equals_eager_and_is_repeatable():
     assert m.plan_for(B, T_in).num_nodes > 10
 
 
+def test_overlapped_postnet_equals_sequential():
+    """taco_forward_infer runs the post-net feed-forward stages chunk by chunk behind the decoder on a second
+    stream (time-window GEMMs with conv halos); the result must be bit-identical to the sequential order."""
+    ohp = tiny_hp(max_iters=53, reduction_factor=3)          # 4 chunks of 16 steps, ragged last chunk
+    w = O.init_weights(ohp, 1, 61)
+    ids, L = O.synthetic_inputs(5, 11, 62, ragged=True)
+    m = build_model(ohp, w)
+    m._lib.taco_debug_set_overlap(m._handle, 0)
+    seq = _run(m, ids, L)
+    m._plans.clear()
+    m._lib.taco_debug_set_overlap(m._handle, 1)
+    ovl = _run(m, ids, L)
+    for a, b in zip(seq, ovl):
+        assert np.array_equal(a, b)
+    _check(ovl, O.forward(w, ohp, ids, L), tol=5e-4)
+
+
 def test_workspace_too_small_is_an_error_not_a_crash():
     import torch
     import taco_amd
