@@ -166,6 +166,10 @@ int taco_model_device_errors(taco_model* m, int* out);
 /* test hook: 0 = per-step launches for the sequential loops, 1 (default) = persistent row-parallel kernels when they fit */
 int taco_debug_set_persistent(taco_model* m, int on);
 
+/* test hook: on = 1 (default) runs the post-net feed-forward GEMMs on the bf16 matrix cores with 3-term split
+ * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128 */
+int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
+
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream
  * (fork/join by events, a parallel branch in the hipGraph) in chunks of max(on,16) decoder steps; 0 (default) =
  * strictly sequential, which measures faster on MI355X (profiles/README.md) */

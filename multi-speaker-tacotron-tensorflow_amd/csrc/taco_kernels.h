@@ -65,6 +65,9 @@ struct GemmVar {
   int NT;                 // 32-column tiles in the pack
   int N;                  // real output channels
   int coff;               // column offset in the output row (conv-bank concat)
+  // split-bf16 packs (k_gemm_bf3): hi/lo bf16 halves of the same weights, fragment-native for 32x32x16 MFMA
+  const unsigned short* bh; const unsigned short* bl; const unsigned short* bh2; const unsigned short* bl2;
+  int K16, cin_pad16;     // k16 groups per n-tile = kw*cin_pad16/16
 };
 
 struct GemmArgs {
@@ -301,6 +304,205 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
           val = taco_act(acc[tm][tn][r] + bia, a.act);   // conv/dense + bias -> activation
           val = val * sc + sh;                            // -> BatchNorm (modules.py:131)
           if (a.res) val += a.res[(size_t)row * a.ldres + col];        // modules.py:62-69
+          if (a.rowvec) val += a.rowvec[(size_t)(row / a.T) * a.ldrv + col];
+        }
+        int orow = row;
+        if (a.rev_col0 >= 0 && col >= a.rev_col0) {
+          const int bb = row / a.T, tt = row - bb * a.T;
+          const int L = a.rev_len ? a.rev_len[bb] : a.T;
+          if (tt < L) orow = bb * a.T + (L - 1 - tt);
+        }
+        a.out[(size_t)orow * a.ldo + v.coff + col] = val;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_gemm_bf3 : the same implicit GEMM on the bf16 matrix cores with fp32-grade accuracy
+// ------------------------------------------------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32-input MFMA.  Every fp32 operand x is split
+// into hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits together) and each k16 group issues three
+// MFMAs: hi*hi + hi*lo + lo*hi (the dropped lo*lo term is ~2^-16 relative), all accumulated in fp32.
+// Weights are split once at finalize; activations are split when the tile is staged in LDS (two bf16
+// tiles, same bytes as one fp32 tile).  Measured error vs the float64 oracle ~1e-5 on O(1) outputs --
+// used for the post-net stages (121 of 180 GFLOP @C2), whose results feed no long recurrence.
+// Pack layout: b?[(((nt*K16 + k16)*2 + h)*32 + j)*8 + e] = W[16*k16 + 8*h + e][32*nt + j]; A fragment of lane
+// (i = l&31, h = l>>5) = X[i][16*g + 8*h + e], e < 8 -- A and B use the same (h, e) -> k pairing.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define BF3_LDSW (TACO_KC + 8)    // bf16 elements per LDS row: 144 bytes = 9 x 16 B (odd) -> conflict-free ds_read_b128
+
+__device__ __forceinline__ unsigned short taco_bf16_rne(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void taco_split_bf16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = taco_bf16_rne(x);
+  lo = taco_bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+}
+
+template <int WM, int WN, int TM, int TN, bool DUAL>
+__global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) {
+  constexpr int NTHR = 64 * WM * WN;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
+           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b; } a =
+      {a_in.x, a_in.gather, a_in.res, a_in.rowvec, a_in.rev_len, a_in.out, a_in.ldx, a_in.M, a_in.T, a_in.Cin, a_in.cin_pad,
+       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b};
+  PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out); PIN(a.rev_len);
+  PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
+  PIN(a.rev_col0); PIN(a.t_begin); PIN(a.t_len); PIN(a.tiles_per_b);
+  GemmVar v = a_in.v[blockIdx.z];
+  PIN(v.bias); PIN(v.bias2); PIN(v.bn_scale); PIN(v.bn_shift); PIN(v.bh); PIN(v.bl); PIN(v.bh2); PIN(v.bl2);
+  PIN(v.kw); PIN(v.padl); PIN(v.NT); PIN(v.N); PIN(v.coff); PIN(v.K16); PIN(v.cin_pad16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int m0 = blockIdx.x * BM, row_limit = a.M;
+  if (a.t_len > 0) {
+    const int bb = blockIdx.x / a.tiles_per_b, tile = blockIdx.x - bb * a.tiles_per_b;
+    m0 = bb * a.T + a.t_begin + tile * BM;
+    row_limit = bb * a.T + a.t_begin + a.t_len;
+  }
+  const int n0 = blockIdx.y * BN;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int rows = BM + v.kw - 1;
+  unsigned short* thi = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* tlo = thi + (size_t)(BM + 15) * BF3_LDSW;
+
+  int tloc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) tloc[tm] = (m0 + (wm * TM + tm) * 32 + l31) % a.T;
+  int ntile[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ntile[tn] = (n0 >> 5) + wn * TN + tn;
+
+  f32x16 acc[TM][TN];
+  f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+      if constexpr (DUAL)
+        for (int r = 0; r < 16; ++r) acc2[tm][tn][r] = 0.f;
+    }
+
+  constexpr int NPRE = ((BM + 15) * (TACO_KC / 4) + NTHR - 1) / NTHR;
+  float4 pre[NPRE];
+  const int nstage = rows * (TACO_KC / 4);
+#pragma unroll
+  for (int u = 0; u < NPRE; ++u) {
+    const int idx = tid + u * NTHR;
+    if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), 4 * (idx % (TACO_KC / 4)));
+  }
+  for (int c0 = 0; c0 < v.cin_pad16; c0 += TACO_KC) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < nstage) {
+        ushort4 h4, l4;
+        taco_split_bf16(pre[u].x, h4.x, l4.x); taco_split_bf16(pre[u].y, h4.y, l4.y);
+        taco_split_bf16(pre[u].z, h4.z, l4.z); taco_split_bf16(pre[u].w, h4.w, l4.w);
+        const int off = (idx / (TACO_KC / 4)) * BF3_LDSW + 4 * (idx % (TACO_KC / 4));
+        *reinterpret_cast<ushort4*>(thi + off) = h4;
+        *reinterpret_cast<ushort4*>(tlo + off) = l4;
+      }
+    }
+    __syncthreads();
+    if (c0 + TACO_KC < v.cin_pad16) {
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) {
+        const int idx = tid + u * NTHR;
+        if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), c0 + TACO_KC + 4 * (idx % (TACO_KC / 4)));
+      }
+    }
+    // B fragments are register double-buffered: the loads of iteration it+1 are issued before the MFMAs of
+    // iteration it (L2 latency ~700 cycles vs ~400 cycles of MFMA per iteration at 2-3 waves/SIMD)
+    const int ng = min(TACO_KC, v.cin_pad16 - c0) >> 4;
+    const int nit = v.kw * ng;
+    auto load_b = [&](int it, uint4 (&uh)[TN], uint4 (&ul)[TN], uint4 (&uh2)[DUAL ? TN : 1], uint4 (&ul2)[DUAL ? TN : 1]) {
+      const int j = it / ng, g = it - j * ng;
+      const int k16 = ((j * v.cin_pad16 + c0) >> 4) + g;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uh[tn] = z; ul[tn] = z;
+        if constexpr (DUAL) { uh2[tn] = z; ul2[tn] = z; }
+        if (ntile[tn] < v.NT) {
+          const size_t off = ((((size_t)ntile[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
+          uh[tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[tn] = *reinterpret_cast<const uint4*>(v.bl + off);
+          if constexpr (DUAL) { uh2[tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
+        }
+      }
+    };
+    uint4 cbh[TN], cbl[TN], cbh2[DUAL ? TN : 1], cbl2[DUAL ? TN : 1];
+    uint4 nbh[TN], nbl[TN], nbh2[DUAL ? TN : 1], nbl2[DUAL ? TN : 1];
+    load_b(0, cbh, cbl, cbh2, cbl2);
+    for (int it = 0; it < nit; ++it) {
+      if (it + 1 < nit) load_b(it + 1, nbh, nbl, nbh2, nbl2);
+      const int j = it / ng, g = it - j * ng;
+      bf16x8 ah[TM], al[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int srow = (wm * TM + tm) * 32 + l31 + j;
+        const int off = srow * BF3_LDSW + 16 * g + 8 * lh;
+        uint4 xh = *reinterpret_cast<const uint4*>(thi + off), xl = *reinterpret_cast<const uint4*>(tlo + off);
+        const int tt = tloc[tm] + j - v.padl;   // SAME zero padding + batch-row boundary (A.2)
+        if (!((tt >= 0) && (tt < a.T))) { xh = make_uint4(0u, 0u, 0u, 0u); xl = xh; }
+        ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
+      }
+      // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, cbh[tn]), bl = __builtin_bit_cast(bf16x8, cbl[tn]);
+            const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
+            const bf16x8 bb = (term == 1) ? bl : bh;
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
+            if constexpr (DUAL) {
+              const bf16x8 bh2 = __builtin_bit_cast(bf16x8, cbh2[tn]), bl2 = __builtin_bit_cast(bf16x8, cbl2[tn]);
+              acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
+            }
+          }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        cbh[tn] = nbh[tn]; cbl[tn] = nbl[tn];
+        if constexpr (DUAL) { cbh2[tn] = nbh2[tn]; cbl2[tn] = nbl2[tn]; }
+      }
+    }
+  }
+
+  // epilogue: identical to k_gemm (C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + (wn * TN + tn) * 32 + l31;
+      if (col >= v.N) continue;
+      const float bia = v.bias ? v.bias[col] : 0.f;
+      float bia2 = 0.f;
+      if constexpr (DUAL) bia2 = v.bias2 ? v.bias2[col] : 0.f;
+      const float sc = v.bn_scale ? v.bn_scale[col] : 1.f;
+      const float sh = v.bn_shift ? v.bn_shift[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= row_limit) continue;
+        float val;
+        if constexpr (DUAL) {
+          const float H = fmaxf(acc[tm][tn][r] + bia, 0.f);
+          const float Tg = taco_sigmoid(acc2[tm][tn][r] + bia2);
+          const float xin = a.x[(size_t)row * a.ldx + col];
+          val = H * Tg + xin * (1.f - Tg);
+        } else {
+          val = taco_act(acc[tm][tn][r] + bia, a.act);
+          val = val * sc + sh;
+          if (a.res) val += a.res[(size_t)row * a.ldres + col];
           if (a.rowvec) val += a.rowvec[(size_t)(row / a.T) * a.ldrv + col];
         }
         int orow = row;

@@ -56,6 +56,8 @@ struct HostTensor {
 struct ConvL {  // a k_gemm layer (conv1d+BN, dense, highway, hoisted GRU input projection)
   int kw = 1, cin = 0, cin_pad = 0, N = 0;
   size_t wp = 0, wp2 = 0, bias = 0, bias2 = 0, bns = 0, bnb = 0;  // arena offsets (+1; 0 = absent)
+  size_t bh = 0, bl = 0, bh2 = 0, bl2 = 0;                          // split-bf16 packs (k_gemm_bf3), 0 = not built
+  int K16 = 0, cin_pad16 = 0;
   int var_index = -1;                                              // index into the device GemmVar array
 };
 struct SkW {  // a k_skinny weight
@@ -103,6 +105,8 @@ struct taco_model {
   int force_cfg = -1;
   unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
   int persist = 1;             // use the persistent BiGRU kernel when it fits
+  int bf3 = 1;                 // post-net feed-forward GEMMs on the bf16 matrix cores with 3-term split operands
+  int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   hipStream_t side = nullptr;  // that second stream
@@ -218,6 +222,36 @@ static size_t pack_w32(taco_model* m, const float* W, int kw, int cin, int N, in
   *cin_pad_out = cin_pad; *Kq_out = Kq; *NT_out = NT;
   return arena_put(m, p.data(), p.size());
 }
+// split-bf16 pack of a [kw, cin, N] kernel for k_gemm_bf3: hi = bf16(w), lo = bf16(w - hi), layout in taco_kernels.h
+static unsigned short bf16_rne_host(float x) {
+  unsigned u; memcpy(&u, &x, 4);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size_t* hi_out, size_t* lo_out, int* K16_out, int* cp16_out) {
+  const int cp16 = rup(cin, 16), K16 = kw * cp16 / 16, NT = cdiv(N, 32);
+  std::vector<unsigned short> hi((size_t)NT * K16 * 2 * 32 * 8, 0), lo(hi.size(), 0);
+  for (int nt = 0; nt < NT; ++nt)
+    for (int k16 = 0; k16 < K16; ++k16)
+      for (int h = 0; h < 2; ++h)
+        for (int j = 0; j < 32; ++j)
+          for (int e = 0; e < 8; ++e) {
+            const int k = 16 * k16 + 8 * h + e, tap = k / cp16, c = k % cp16, n = 32 * nt + j;
+            if (c < cin && n < N) {
+              const float w = W[((size_t)tap * cin + c) * N + n];
+              const unsigned short hb = bf16_rne_host(w);
+              unsigned hu = (unsigned)hb << 16; float hf; memcpy(&hf, &hu, 4);
+              const size_t o = ((((size_t)nt * K16 + k16) * 2 + h) * 32 + j) * 8 + e;
+              hi[o] = hb; lo[o] = bf16_rne_host(w - hf);
+            }
+          }
+  auto put = [&](const std::vector<unsigned short>& v) {
+    std::vector<float> f((v.size() + 1) / 2, 0.f);
+    memcpy(f.data(), v.data(), v.size() * sizeof(unsigned short));
+    return arena_put(m, f.data(), f.size());
+  };
+  *hi_out = put(hi); *lo_out = put(lo); *K16_out = K16; *cp16_out = cp16;
+}
+
 // W16 pack of rows [r0, r0+K) and columns [c0, c0+N) of a row-major [*, ldw] matrix.
 static SkW pack_w16(taco_model* m, const float* W, int ldw, int r0, int K, int c0, int N, const float* bias) {
   SkW s;
@@ -239,13 +273,14 @@ static SkW pack_w16(taco_model* m, const float* W, int ldw, int r0, int K, int c
 
 static const HostTensor& T_(taco_model* m, const std::string& n) { return m->raw[n]; }
 
-static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has_bias = true) {
+static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has_bias = true, bool bf3 = false) {
   const HostTensor& k = T_(m, name + "/kernel");
   ConvL L;
   if (k.shape.size() == 3) { L.kw = (int)k.shape[0]; L.cin = (int)k.shape[1]; L.N = (int)k.shape[2]; }
   else { L.kw = 1; L.cin = (int)k.shape[0]; L.N = (int)k.shape[1]; }
   int Kq, NT;
   L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
+  if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16);
   if (has_bias) L.bias = arena_put(m, T_(m, name + "/bias").data.data(), L.N);
   if (bn) {  // BatchNorm inference folded to y*scale + shift (A.2; epsilon 1e-3 = tf.layers default)
     const auto& g = T_(m, name + "/gamma").data; const auto& b = T_(m, name + "/beta").data;
@@ -284,27 +319,27 @@ static void cbhg_dims(Cbhg& c, int in_dim, int K, int C, int maxpool, int depth,
 }
 
 static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim, int K, int C, int maxpool,
-                      int depth, int rnn, const int* projs, int nproj, int pw) {
+                      int depth, int rnn, const int* projs, int nproj, int pw, bool bf3 = false) {
   cbhg_dims(c, in_dim, K, C, maxpool, depth, rnn, projs, nproj, pw);
   for (int k = K; k >= 1; --k) {
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
-    ConvL L = make_conv(m, n, true);
+    ConvL L = make_conv(m, n, true, true, bf3);
     c.bank.push_back(L);
     m->convs[n] = L;
   }
   for (int i = 0; i < nproj; ++i) {
     const std::string n = sc + "/proj_" + std::to_string(i + 1);
-    c.proj.push_back(make_conv(m, n, true));
+    c.proj.push_back(make_conv(m, n, true, true, bf3));
     m->convs[n] = c.proj.back();
   }
   const int last = projs[nproj - 1];
   c.has_dense = last != rnn;
-  if (c.has_dense) { c.dense = make_conv(m, sc + "/dense", false); m->convs[sc + "/dense"] = c.dense; }
+  if (c.has_dense) { c.dense = make_conv(m, sc + "/dense", false, true, bf3); m->convs[sc + "/dense"] = c.dense; }
   for (int i = 0; i < depth; ++i) {
     const std::string n = sc + "/highway_" + std::to_string(i + 1);
-    ConvL L = make_conv(m, n + "/H", false);
-    ConvL Tt = make_conv(m, n + "/T", false);
-    L.wp2 = Tt.wp; L.bias2 = Tt.bias;
+    ConvL L = make_conv(m, n + "/H", false, true, bf3);
+    ConvL Tt = make_conv(m, n + "/T", false, true, bf3);
+    L.wp2 = Tt.wp; L.bias2 = Tt.bias; L.bh2 = Tt.bh; L.bl2 = Tt.bl;
     c.hw.push_back(L);
     m->convs[n] = L;
   }
@@ -329,6 +364,7 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
   X.wp = pack_w32(m, Wx.data(), 1, I, 6 * H, &X.cin_pad, &Kq, &NT);
+  if (bf3) pack_bf3(m, Wx.data(), 1, I, 6 * H, &X.bh, &X.bl, &X.K16, &X.cin_pad16);
   X.bias = arena_put(m, bx.data(), 6 * H);
   c.xproj = X;
 }
@@ -339,6 +375,8 @@ static int add_var(taco_model* m, ConvL& L, int coff) {
   // pointers are resolved after the arena upload (see finalize): store offsets for now
   v.wp = (const float*)L.wp; v.wp2 = (const float*)L.wp2; v.bias = (const float*)L.bias; v.bias2 = (const float*)L.bias2;
   v.bn_scale = (const float*)L.bns; v.bn_shift = (const float*)L.bnb;
+  v.bh = (const unsigned short*)L.bh; v.bl = (const unsigned short*)L.bl; v.bh2 = (const unsigned short*)L.bh2; v.bl2 = (const unsigned short*)L.bl2;
+  v.K16 = L.K16; v.cin_pad16 = L.cin_pad16;
   v.kw = L.kw; v.padl = (L.kw - 1) / 2; v.Kq = L.kw * L.cin_pad / 4; v.NT = cdiv(L.N, 32); v.N = L.N; v.coff = coff;
   L.var_index = (int)m->hvars.size();
   m->hvars.push_back(v);
@@ -372,6 +410,20 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   return 0;
 }
 
+template <int WM, int WN, int TM, int TN, bool DUAL>
+static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds = (size_t)2 * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
+  GemmArgs aa = a;
+  int gx = cdiv(a.M, BM);
+  if (a.t_len > 0) { aa.tiles_per_b = cdiv(a.t_len, BM); gx = (a.M / a.T) * aa.tiles_per_b; }
+  (void)kw_max;
+  dim3 grid(gx, cdiv(Nmax, BN), nvar);
+  hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL>), grid, dim3(64 * WM * WN), lds, st, aa);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // cfg: 0 = 128x64 tile (4 waves), 1 = 64x64 (4 waves), 2 = 32x64 split-K 4 (8 waves), 3 = 128x128 (4 waves)
 static int pick_cfg(const taco_model* m, int M, int N, int nvar) {
   if (m->force_cfg >= 0) return m->force_cfg;
@@ -398,6 +450,18 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     a.v[i] = m->hvars[layers[i].var_index];
   }
   if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
+  if (m->bf3 && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (post-net layers): 128-row tiles
+    // tiles (rows x cols): 1 = 128x64, 2 = 128x128, 3 = 64x256 (one staged 64-row tile feeds 8 MFMA column tiles)
+    // measured (tools/time_gemm_layers.py): 64x256 wins when K or N is large (proj_1, linear, GRU projection), 128x64 otherwise
+    const int Ktot = L0.kw * L0.cin;
+    const int tn = m->bf3_tn ? m->bf3_tn : ((Ktot >= 1024 || Nmax > 512) ? 3 : 1);
+    if (dual) {
+      if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, true>(st, a, nvar, kw_max, Nmax);
+      return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, true>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, true>(st, a, nvar, kw_max, Nmax);
+    }
+    if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, false>(st, a, nvar, kw_max, Nmax);
+    return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, false>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, false>(st, a, nvar, kw_max, Nmax);
+  }
   const int cfg = pick_cfg(m, c.t_len > 0 ? (c.M / a.T) * c.t_len : c.M, Nmax, nvar);
   if (dual) {
     switch (cfg) {
@@ -982,7 +1046,7 @@ int taco_model_finalize(taco_model* m) {
             hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width);
   m->memory_layer = make_conv(m, "attention/memory_layer", false, false);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
-            hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width);
+            hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width, true);
   if (hp.num_speakers > 1 && hp.model_type == 1) {
     // linear head input = concat(speaker_embed, post_outputs) (tacotron.py:226-235): rows [0,S) of the kernel
     // multiply the per-utterance embedding -> a per-batch-row vector; rows [S,..) stay a GEMM over the frames
@@ -995,7 +1059,7 @@ int taco_model_finalize(taco_model* m) {
     m->raw["linear/kernel"] = rest;
     m->spk_emb = arena_put(m, T_(m, "speaker_embedding").data.data(), T_(m, "speaker_embedding").data.size());
   }
-  m->linear = make_conv(m, "linear", false);
+  m->linear = make_conv(m, "linear", false, true, true);
   // decoder (skinny packs)
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
   int d = hp.num_mels + D;
@@ -1066,6 +1130,8 @@ int taco_model_finalize(taco_model* m) {
   for (auto& v : m->hvars) {
     v.wp = AP(m, (size_t)v.wp); v.wp2 = AP(m, (size_t)v.wp2); v.bias = AP(m, (size_t)v.bias); v.bias2 = AP(m, (size_t)v.bias2);
     v.bn_scale = AP(m, (size_t)v.bn_scale); v.bn_shift = AP(m, (size_t)v.bn_shift);
+    v.bh = (const unsigned short*)AP(m, (size_t)v.bh); v.bl = (const unsigned short*)AP(m, (size_t)v.bl);
+    v.bh2 = (const unsigned short*)AP(m, (size_t)v.bh2); v.bl2 = (const unsigned short*)AP(m, (size_t)v.bl2);
   }
   // persistent kernels carve up to the full 160 KiB of LDS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1097,6 +1163,12 @@ int taco_model_device_errors(taco_model* m, int* out) {
   HIPCHK(hipMemcpy(&v, m->d_err, sizeof v, hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemset(m->d_err, 0, 256));
   *out = (int)v;
+  return 0;
+}
+
+int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->bf3 = on; m->bf3_tn = tile_n;
   return 0;
 }
 

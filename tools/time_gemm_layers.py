@@ -16,6 +16,7 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 cases = [  # (kind, layer, B, T, Cin, Cout, kw, mpw, act)
     ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 2, 1),
+    ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 1, 1),
     ("conv", "post_cbhg/conv_bank/conv1d_8", 32, 512, 80, 256, 8, 1, 1),
     ("conv", "encoder_cbhg/proj_1", 32, 128, 2048, 128, 3, 2, 1),
     ("conv", "encoder_cbhg/conv_bank/conv1d_16", 32, 128, 128, 128, 16, 1, 1),
@@ -26,7 +27,8 @@ for kind, layer, B, T, Cin, Cout, kw, mpw, act in cases:
     x = torch.randn(B, T, Cin, device="cuda"); out = torch.empty(B, T, Cout, device="cuda")
     gf = 2.0 * B * T * Cin * Cout * kw * (2 if kind == "hw" else 1) / 1e9
     row = []
-    for cfg in (0, 1, 2, 3):
+    for cfg in (1, 2):
+        L.taco_debug_set_bf3(m._handle, 0, 0)
         L.taco_debug_force_gemm_config(m._handle, cfg)
         if kind == "conv":
             fn = lambda: taco_amd._lib.check(L.taco_conv1d_bn_f32(m._handle, st(), layer.encode(), C.c_void_p(x.data_ptr()), B, T, act, mpw, C.c_void_p(out.data_ptr())))
@@ -37,4 +39,10 @@ for kind, layer, B, T, Cin, Cout, kw, mpw, act in cases:
         us = timeit(fn)
         row.append("cfg%d %7.1f us %5.1f TF" % (cfg, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else gf / (us * 1e-6) / 1e3))
     L.taco_debug_force_gemm_config(m._handle, -1)
+    if layer.startswith(("post_cbhg", "linear")):
+        for tn in (1, 2, 3):
+            L.taco_debug_set_bf3(m._handle, 1, tn)
+            us = timeit(fn)
+            row.append("bf3t%d %7.1f us %5.1f TFeq" % (tn, us, gf / (us * 1e-6) / 1e3))
+        L.taco_debug_set_bf3(m._handle, 1, 0)
     print("%-36s %6.1f GFLOP | " % (layer, gf) + " | ".join(row))
