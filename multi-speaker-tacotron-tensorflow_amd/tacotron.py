@@ -8,6 +8,7 @@ synthesizer.py:166-167.  Attribute names after `initialize()` are the reference'
 
 PyTorch is used only for device memory and streams; all compute is in the HIP library."""
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -62,6 +63,136 @@ class _Plan(object):
                 self._lib.taco_plan_destroy(self.handle)
         except Exception:
             pass
+
+
+def _concurrent_streams(device, want, max_candidates=24):
+    """`want` HIP streams that run concurrently with each other.
+
+    HIP binds every stream to one of the GPU's hardware queues (4 by default, GPU_MAX_HW_QUEUES) and two streams
+    on the same queue serialise.  The binding is static but not round-robin (tools/probe_lane_queues.py: eight
+    consecutive streams landed as {0,3,7} {1,2,6} {4} {5}), and HIP has no call to query or set it -- so probe
+    it: a short spin kernel on two streams takes 1x its duration if they are on different queues, 2x if they
+    share one.  Greedy selection over up to `max_candidates` streams; if fewer than `want` distinct queues
+    exist the remaining lanes share queues (still correct, just not concurrent)."""
+    if want == 1:
+        return [torch.cuda.Stream(device=device)]
+    cyc = 400_000                                   # ~0.17 ms
+
+    def spin(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cyc)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+
+    cands = []
+    for _ in range(max_candidates):
+        st = torch.cuda.Stream(device=device)
+        if all(st.cuda_stream != c.cuda_stream for c in cands):
+            cands.append(st)
+    spin(cands[:1])
+    alone = min(spin(cands[:1]) for _ in range(3))
+    chosen = [cands[0]]
+    for st in cands[1:]:
+        if len(chosen) == want:
+            break
+        if all(min(spin([st, c]), spin([st, c])) < 1.5 * alone for c in chosen):
+            chosen.append(st)
+    rest = [c for c in cands if all(c is not x for x in chosen)]
+    while len(chosen) < want:                       # fewer hardware queues than lanes
+        chosen.append(rest.pop(0) if rest else torch.cuda.Stream(device=device))
+    return chosen
+
+
+class PlanPool(object):
+    """`lanes` independent forwards of one shape in flight, each with its own hipGraph plan, buffers and
+    HIP stream.
+
+    The decoder loop and the BiGRU scans are chains of small dependent kernels that occupy a few dozen of
+    the 256 CUs; a second, third and fourth forward running beside them use CUs that would otherwise idle.
+    Measured on MI355X at C2 (tools/time_multistream.py): 12.5 ms/forward with one lane, 7.0 with two,
+    4.4 with four (the default number of hardware queues); more lanes than hardware queues is slower.
+    The model object is read-only during a forward, so lanes share it.
+
+    The reference serves one `sess.run` at a time (synthesizer.py:166-167); this is the same call with
+    several requests outstanding.  submit() enqueues and returns immediately; result() waits for that lane."""
+
+    def __init__(self, model, B, T_in, n_steps=None, lanes=4):
+        if model._handle is None:
+            raise RuntimeError("initialize() must be called first")
+        if lanes < 1:
+            raise ValueError("lanes must be >= 1")
+        n = model._hparams.max_iters if n_steps is None else n_steps
+        self.model, self.B, self.T_in, self.n, self.lanes = model, B, T_in, n, lanes
+        self.streams, self.plans, self.done, self.pending = [], [], [], []
+        with torch.cuda.device(model.device):
+            self.streams = _concurrent_streams(model.device, lanes)
+            for st in self.streams:
+                with torch.cuda.stream(st):
+                    self.plans.append(_Plan(model, B, T_in, n, False))
+                    self.plans[-1].launch()      # first replay uploads the graph: keep that out of the serving path
+                self.done.append(torch.cuda.Event())
+                self.pending.append(False)
+            torch.cuda.synchronize()
+        self._next = 0
+
+    def next_lane(self):
+        lane = self._next
+        self._next = (self._next + 1) % self.lanes
+        return lane
+
+    def launch(self, lane):
+        """Replay lane's plan on its stream over whatever its input buffers hold."""
+        with torch.cuda.stream(self.streams[lane]):
+            self.plans[lane].launch()
+            self.done[lane].record()
+        self.pending[lane] = True
+
+    def submit(self, inputs, input_lengths, speaker_id=None, lane=None):
+        """Enqueue one forward; returns the lane to pass to result().  Inputs may be host or device arrays."""
+        lane = self.next_lane() if lane is None else lane
+        if self.pending[lane]:
+            raise RuntimeError("lane %d still holds an uncollected result; call result(%d) first" % (lane, lane))
+        m, plan = self.model, self.plans[lane]
+        ids = m._as_dev(inputs, torch.int32)
+        lens = m._as_dev(input_lengths, torch.int32)
+        if tuple(ids.shape) != (self.B, self.T_in):
+            raise Exception("inputs must be [%d, %d], got shape %s" % (self.B, self.T_in, tuple(ids.shape)))
+        cur = torch.cuda.current_stream(m.device)
+        with torch.cuda.stream(self.streams[lane]):
+            self.streams[lane].wait_stream(cur)      # ids/lens may have been produced on the caller's stream
+            plan.inputs.copy_(ids, non_blocking=True)
+            plan.lengths.copy_(lens, non_blocking=True)
+            if m.num_speakers > 1:
+                if speaker_id is None:
+                    plan.speaker_id.zero_()
+                else:
+                    plan.speaker_id.copy_(m._as_dev(speaker_id, torch.int32), non_blocking=True)
+        self.launch(lane)
+        return lane
+
+    def result(self, lane, copy=True):
+        """Waits for lane's forward.  Returns dict(linear, mel, alignments, stop_step); with copy=False the
+        tensors are the lane's own buffers and are overwritten by the lane's next forward."""
+        if not self.pending[lane]:
+            raise RuntimeError("lane %d has no forward in flight" % lane)
+        self.done[lane].synchronize()
+        self.pending[lane] = False
+        p = self.plans[lane]
+        f = (lambda t: t.clone()) if copy else (lambda t: t)
+        with torch.cuda.device(self.model.device):
+            return {"linear": f(p.linear), "mel": f(p.mel), "alignments": f(p.align), "stop_step": int(p.stop.item())}
+
+    def wait_all(self):
+        for lane in range(self.lanes):
+            if self.pending[lane]:
+                self.done[lane].synchronize()
+
+    def close(self):
+        self.wait_all()
+        self.plans = []
 
 
 class Tacotron(object):
@@ -142,6 +273,10 @@ class Tacotron(object):
             with torch.cuda.device(self.device):
                 self._plans[key] = _Plan(self, B, T_in, n, manual)
         return self._plans[key]
+
+    def plan_pool(self, B, T_in, n_steps=None, lanes=4):
+        """`lanes` forwards of this shape in flight at once (PlanPool)."""
+        return PlanPool(self, B, T_in, n_steps, lanes)
 
     def run(self, inputs=None, input_lengths=None, speaker_id=None, manual_alignments=None,
             is_manual_attention=None, n_steps=None, honor_stop=True):

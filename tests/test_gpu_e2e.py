@@ -312,3 +312,38 @@ def test_long_form_C5_shapes_and_roundtrip_properties():
     assert al.min() >= 0 and al.sum(1).max() <= 1 + 1e-4
     mel2, lin2, al2 = _run(m, ids[3:5], L[3:5])
     assert maxabs(mel2, mel[3:5]) < 1e-4 and maxabs(al2, al[3:5]) < 1e-5
+
+
+@pytest.mark.parametrize("mt,ns", [("single", 1), ("deepvoice", 3)])
+def test_plan_pool_lanes_are_independent_and_exact(mt, ns):
+    """Four forwards in flight on four streams (PlanPool), each over DIFFERENT inputs, twice around the lanes:
+    every result must be bit-identical to the same request served alone, and within tolerance of the checker."""
+    ohp = tiny_hp(model_type=mt, speaker_embedding_size=4) if ns > 1 else tiny_hp()
+    w = O.init_weights(ohp, ns, 91)
+    m = build_model(ohp, w, num_speakers=ns)
+    B, T_in = 4, 12
+    reqs = []
+    for i in range(8):
+        ids, L = O.synthetic_inputs(B, T_in, 300 + i, ragged=(i % 2 == 1))
+        spk = ((np.arange(B) + i) % ns).astype(np.int32) if ns > 1 else None
+        reqs.append((ids, L, spk))
+    alone = [_run(m, ids, L, spk, honor_stop=False) for ids, L, spk in reqs]
+    pool = m.plan_pool(B, T_in, lanes=4)
+    got = [None] * len(reqs)
+    for base in (0, 4):
+        lanes = [pool.submit(*reqs[base + k]) for k in range(4)]
+        assert sorted(lanes) == [0, 1, 2, 3]
+        with pytest.raises(RuntimeError):
+            pool.submit(*reqs[0], lane=lanes[0])            # result not collected yet
+        for k in reversed(range(4)):                        # collect out of order
+            r = pool.result(lanes[k])
+            got[base + k] = (r["mel"].cpu().numpy(), r["linear"].cpu().numpy(), r["alignments"].cpu().numpy())
+    with pytest.raises(RuntimeError):
+        pool.result(0)
+    for i, (ids, L, spk) in enumerate(reqs):
+        for a, b in zip(alone[i], got[i]):
+            assert np.array_equal(a, b), "request %d differs between pool and serial" % i
+    ref = O.forward(w, ohp, reqs[5][0], reqs[5][1], speaker_id=reqs[5][2], num_speakers=ns, honor_stop=False)
+    _check(got[5], ref)
+    m.check_device_errors()
+    pool.close()
