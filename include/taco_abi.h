@@ -159,6 +159,35 @@ int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, 
                        long long global_step, float learning_rate, float beta1, float beta2, float epsilon, float clip_norm,
                        float* d_gnorm_out, void* d_workspace, size_t workspace_bytes);
 
+/* ---- training path (config C4): teacher-forced forward with batch-statistics BatchNorm
+ * (tacotron.py:26,199-202; modules.py:131; helpers.py:35-67), add_loss and its full backward pass (tf.gradients of
+ * tacotron.py:274-336).  All parameters live in ONE flat fp32 device buffer owned by the caller (layout: the tensors of
+ * taco_model_weight_name() in order, TF layout, no padding) and all gradients in a second buffer of the same layout --
+ * the single all-reduce bucket of the data-parallel step.  A taco_train owns only index maps and weight packs that it
+ * regenerates from the flat parameters (taco_train_refresh) after every optimizer step.
+ * modules.py:24 calls tf.layers.dropout without training=True, so the reference applies no prenet dropout even when
+ * training; neither does this path.  Supported: num_speakers == 1, attention bah / bah_mon. ---- */
+typedef struct taco_train taco_train;
+int taco_train_create(const taco_hparams* hp, int device, taco_train** out);
+void taco_train_destroy(taco_train* t);
+/* the model handle whose taco_model_num_weights / taco_model_weight_name give the flat parameter order and shapes */
+taco_model* taco_train_model(taco_train* t);
+size_t taco_train_num_params(const taco_train* t);
+int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset);
+/* regenerate every weight pack from the flat parameter buffer (call after loading parameters and after every update) */
+int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params);
+size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_out);
+/* One training forward (+ backward when d_grads != NULL).  d_params is in/out: the BatchNorm moving averages are updated
+ * in place (UPDATE_OPS dependency, tacotron.py:334).  d_mel_targets [B,T_out,num_mels], d_linear_targets [B,T_out,num_freq],
+ * T_out a multiple of r, T_out/r <= max_iters (helpers.py:44-48).  d_losses[4] = loss, mel_loss, linear_loss,
+ * loss_without_coeff (nullable).  d_mel_out / d_linear_out / d_alignments ([B,T_in,T_out/r]) nullable.
+ * d_grads (flat, overwritten) = d loss / d parameter; moving statistics get zero. */
+int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
+                                const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
+                                const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate,
+                                float* d_losses, float* d_mel_out, float* d_linear_out, float* d_alignments, void* d_workspace,
+                                size_t workspace_bytes);
+
 /* Persistent (multi-workgroup, in-kernel synchronised) kernels bound every spin; if one ever expires it sets a
  * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;
  * non-zero means the outputs of the affected forward are invalid. */

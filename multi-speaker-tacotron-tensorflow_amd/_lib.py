@@ -110,6 +110,14 @@ PROTOTYPES = {
     "taco_loss_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
     "taco_learning_rate": (C.c_float, [C.c_longlong, C.c_float, _I, _I]),
     "taco_adam_step_f32": (_I, [_P, _P, _P, _P, _P, _S, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _S]),
+    "taco_train_create": (_I, [C.POINTER(TacoHParams), _I, C.POINTER(_P)]),
+    "taco_train_destroy": (None, [_P]),
+    "taco_train_model": (_P, [_P]),
+    "taco_train_num_params": (_S, [_P]),
+    "taco_train_param_offset": (_I, [_P, C.c_char_p, C.POINTER(_S)]),
+    "taco_train_refresh": (_I, [_P, _P, _P]),
+    "taco_train_workspace_bytes": (_S, [_P, _I, _I, _I]),
+    "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),

@@ -1,0 +1,465 @@
+// taco_backward_kernels.h -- training path: training-mode forward pieces and the backward pass.
+// tf.gradients of the graph of tacotron.py:29-239 under is_training (batch-statistics BatchNorm, teacher forcing),
+// written out by hand.  Every weight gradient is accumulated into ONE flat fp32 buffer (the RCCL bucket of the
+// data-parallel step) with fp32 atomics; the caller zeroes it before a backward pass.
+// Needs taco_kernels.h (PIN, rp_matvec, wave_sum/wave_scan, taco_sigmoid, ATT_MAXT) included first.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// ---- weight packs regenerated from the flat parameter buffer after every optimizer step ----
+// map[i] = 1 + flat index of the parameter that pack element i copies (the host packers run once over
+// index-valued tensors); anything else = zero padding / unused.
+__global__ __launch_bounds__(256) void k_pack_gather(const float* __restrict__ map, const float* __restrict__ P,
+                                                    float* __restrict__ arena, size_t n, unsigned NP) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = map[i];
+    float o = 0.f;
+    if (v >= 1.f && v <= (float)NP) { const unsigned iv = (unsigned)v; if ((float)iv == v) o = P[iv - 1]; }
+    arena[i] = o;
+  }
+}
+
+// ---- per-column reductions over the rows of a [M, C] matrix (bias gradients, BatchNorm statistics) ----
+// mode 0: out1[c] += sum_m a                         mode 1: out2[c] += sum_m (a - mu[c])^2
+// mode 2: out1[c] += sum_m b ; out2[c] += sum_m b * (a - mu[c]) * rstd[c]     (BN backward: b = dy, a = BN input)
+struct ColArgs { const float* a; const float* b; const float* mu; const float* rstd; float* out1; float* out2;
+                 int lda, ldb, M, C, mode, rpb; };
+__global__ __launch_bounds__(256) void k_colsum(const ColArgs g) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int m0 = blockIdx.y * g.rpb, m1 = min(g.M, m0 + g.rpb);
+  float a1 = 0.f, a2 = 0.f;
+  if (c < g.C) {
+    const float mu = g.mu ? g.mu[c] : 0.f, rs = g.rstd ? g.rstd[c] : 1.f;
+    for (int m = m0 + rl; m < m1; m += 4) {
+      const float av = g.a[(size_t)m * g.lda + c];
+      if (g.mode == 0) a1 += av;
+      else if (g.mode == 1) { const float d = av - mu; a2 += d * d; }
+      else { const float bv = g.b[(size_t)m * g.ldb + c]; a1 += bv; a2 += bv * (av - mu) * rs; }
+    }
+  }
+  s1[rl][cl] = a1; s2[rl][cl] = a2;
+  __syncthreads();
+  if (rl == 0 && c < g.C) {
+    const float t1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
+    const float t2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+    if (g.mode != 1 && g.out1) atomicAdd(g.out1 + c, t1);
+    if (g.mode != 0 && g.out2) atomicAdd(g.out2 + c, t2);
+  }
+}
+
+// BatchNorm (training): mu = S1/M; second pass gives S2 = sum (a-mu)^2; rstd = 1/sqrt(S2/M + eps) (biased variance);
+// moving <- moving*momentum + batch*(1-momentum), written straight into the flat parameter buffer (UPDATE_OPS, tacotron.py:334)
+__global__ void k_bn_mean(const float* S1, float* mu, int C, float invM) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) mu[c] = S1[c] * invM;
+}
+__global__ void k_bn_finalize(const float* mu, const float* S2, float* rstd, float* mov_mean, float* mov_var, int C,
+                              float invM, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float var = S2[c] * invM;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (mov_mean) mov_mean[c] = mov_mean[c] * momentum + mu[c] * (1.f - momentum);
+  if (mov_var) mov_var[c] = mov_var[c] * momentum + var * (1.f - momentum);
+}
+__global__ void k_bn_apply(const float* a, int lda, const float* mu, const float* rstd, const float* gamma, const float* beta,
+                           float* y, int ldy, int M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  y[(size_t)m * ldy + c] = (a[(size_t)m * lda + c] - mu[c]) * rstd[c] * gamma[c] + beta[c];
+}
+// dz = [a > 0 if relu] * gamma*rstd * (dy - mean(dy) - ahat*mean(dy*ahat));  sdy = sum dy (= d beta), sdyxh = sum dy*ahat (= d gamma)
+__global__ void k_bn_bwd(const float* a, int lda, const float* dy, int ldy, const float* mu, const float* rstd, const float* gamma,
+                         const float* sdy, const float* sdyxh, int relu, float* dz, int ldz, int M, int C, float invM) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  const float av = a[(size_t)m * lda + c];
+  const float ah = (av - mu[c]) * rstd[c];
+  const float da = gamma[c] * rstd[c] * (dy[(size_t)m * ldy + c] - sdy[c] * invM - ah * sdyxh[c] * invM);
+  dz[(size_t)m * ldz + c] = (relu && !(av > 0.f)) ? 0.f : da;
+}
+
+// ---- weight gradient: dw[tap][k][n] += sum_m x[m + tap - padl][k] * dy[m][n]  (fp32 MFMA 32x32x2, k-dimension = rows) ----
+// Rows m = b*T + t never reach across batch rows (SAME zero padding, A.2); T <= 0: no time structure.  With `gather`
+// row m of x is x[gather[m]] (embedding lookup fused into the first encoder prenet layer).  Workgroup = 4 waves =
+// 64 (k) x 64 (n) tile over `rpb` rows; partial sums leave through fp32 atomics.
+struct WgArgs { const float* x; const int* gather; const float* dy; float* dw; int ldx, ldy, lddw, M, T, K, N, kw, padl, rpb; };
+typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k0 = blockIdx.x * 64 + (wave >> 1) * 32, n0 = blockIdx.y * 64 + (wave & 1) * 32;
+  const int nsplit = (g.M + g.rpb - 1) / g.rpb;
+  const int tap = blockIdx.z / nsplit, sp = blockIdx.z - tap * nsplit;
+  const int shift = tap - g.padl;
+  const int m0 = sp * g.rpb, m1 = min(g.M, m0 + g.rpb);
+  if (k0 >= g.K || n0 >= g.N) return;
+  const int i = lane & 31, kk = lane >> 5;
+  const bool kok = (k0 + i) < g.K, nok = (n0 + i) < g.N;
+  wg_f32x16 acc;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  int t = (g.T > 0) ? (m0 + kk) % g.T : 0;
+  for (int m = m0 + kk; m < m1; m += 2) {
+    float av = 0.f, bv = 0.f;
+    bool rok = true;
+    if (g.T > 0) { const int ts = t + shift; rok = (ts >= 0) && (ts < g.T); t += 2; while (t >= g.T) t -= g.T; }
+    if (kok && rok) {
+      const size_t xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift);
+      av = g.x[xr * g.ldx + k0 + i];
+    }
+    if (nok) bv = g.dy[(size_t)m * g.ldy + n0 + i];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+  }
+  float* dw = g.dw + (size_t)tap * g.K * g.lddw;
+  if (nok) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr = k0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      if (kr < g.K) atomicAdd(dw + (size_t)kr * g.lddw + n0 + i, acc[r]);
+    }
+  }
+}
+
+// ---- small element-wise pieces ----
+// max_pooling1d(width w, stride 1, 'same') forward (materialised for the tape) and backward (gradient to the first maximum)
+__global__ void k_maxpool_fwd(const float* x, float* y, int M, int T, int C, int w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C), t = m % T, pl = (w - 1) >> 1;
+  float best = -INFINITY;
+  for (int j = 0; j < w; ++j) { const int tt = t - pl + j; if (tt >= 0 && tt < T) best = fmaxf(best, x[(size_t)(m - pl + j) * C + c]); }
+  y[i] = best;
+}
+__global__ void k_maxpool_bwd(const float* x, const float* dp, float* dx, int M, int T, int C, int w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C), t = m % T, pl = (w - 1) >> 1;
+  float acc = 0.f;
+  for (int tp = t - (w - 1 - pl); tp <= t + pl; ++tp) {      // output positions whose window contains t
+    if (tp < 0 || tp >= T) continue;
+    int arg = -1; float best = -INFINITY;
+    for (int j = 0; j < w; ++j) {
+      const int tt = tp - pl + j;
+      if (tt < 0 || tt >= T) continue;
+      const float v = x[(size_t)(m + tt - t) * C + c];
+      if (v > best) { best = v; arg = tt; }
+    }
+    if (arg == t) acc += dp[(size_t)(m + tp - t) * C + c];
+  }
+  dx[i] = acc;
+}
+// highway y = H*T + x*(1-T): dcat = [dH_pre | dT_pre] (input of the transposed GEMM), dxd = direct path dy*(1-T)
+__global__ void k_highway_bwd(const float* dy, const float* x, const float* H, const float* Tg, float* dcat, float* dxd, int M, int D) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * D) return;
+  const int m = (int)(i / D), c = (int)(i % D);
+  const float g = dy[i], h = H[i], tg = Tg[i];
+  dcat[(size_t)m * 2 * D + c] = (h > 0.f) ? g * tg : 0.f;
+  dcat[(size_t)m * 2 * D + D + c] = g * (h - x[i]) * tg * (1.f - tg);
+  dxd[i] = g * (1.f - tg);
+}
+__global__ void k_relu_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int ldz, int M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  dz[(size_t)m * ldz + c] = (y[(size_t)m * ldy + c] > 0.f) ? dy[(size_t)m * lddy + c] : 0.f;
+}
+__global__ void k_add2d(float* dst, int ldd, const float* src, int lds, int M, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  dst[(size_t)m * ldd + c] += src[(size_t)m * lds + c];
+}
+// d/d out of mean(|tgt - out| * coeff) (+ the priority-band terms of tacotron.py:283-296): g = sign(out - tgt) * coeff[b] * scale(c)
+__global__ void k_l1_grad(const float* out, const float* tgt, const float* coeff, int rows, int T, int C, float scale, int c_lo,
+                          int c_hi, float scale_band, float* g) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * C) return;
+  const int row = (int)(i / C), c = (int)(i % C);
+  const float d = out[i] - tgt[i];
+  const float sg = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+  const float w = coeff ? coeff[row / T] : 1.f;
+  g[i] = sg * w * (scale + ((c >= c_lo && c < c_hi) ? scale_band : 0.f));
+}
+__global__ void k_embed_bwd(const float* dx, const int* ids, float* dE, int M, int E) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * E) return;
+  const int m = (int)(i / E), c = (int)(i % E);
+  atomicAdd(dE + (size_t)ids[m] * E + c, dx[i]);
+}
+__global__ void k_sum_all(const float* x, int n, float* out) {   // out[0] += sum x  (attention score bias gradient)
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  sm[threadIdx.x] = s; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(out, sm[0]);
+}
+
+// ---- GRUCell backward (A.6), split around the two transposed mat-vecs ----
+//   h' = u*h + (1-u)*c ; c = tanh([x, r*h].Wc + bc) ; [r,u] = sigmoid([x,h].Wg + bg)
+// a: dht = dout (+ carry); dcp = dht*(1-u)*(1-c^2); dgp[H..2H) = dht*(h-c)*u*(1-u)
+__global__ void k_gru_bwd_a(const float* dout, int lddo, const float* carry, const float* u, int ldu, const float* c, int ldc,
+                            const float* hprev, int ldh, float* dht, float* dcp, int lddcp, float* dgp, int lddgp, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, n = i % H;
+  const float g = dout[(size_t)b * lddo + n] + (carry ? carry[i] : 0.f);
+  const float uu = u[(size_t)b * ldu + n], cc = c[(size_t)b * ldc + n];
+  const float hp = hprev ? hprev[(size_t)b * ldh + n] : 0.f;
+  dht[i] = g;
+  dcp[(size_t)b * lddcp + n] = g * (1.f - uu) * (1.f - cc * cc);
+  dgp[(size_t)b * lddgp + H + n] = g * (hp - cc) * uu * (1.f - uu);
+}
+// b: tmp1 = dcp . Wc^T  ([B, I+H]); d(r*h) = tmp1[I..): dgp[0..H) = d(rh)*h*r*(1-r); dhp = dht*u + d(rh)*r
+__global__ void k_gru_bwd_b(const float* tmp1, int ld1, int I, const float* hprev, int ldh, const float* r, int ldr, const float* u,
+                            int ldu, const float* dht, float* dgp, int lddgp, float* dhp, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, n = i % H;
+  const float drh = tmp1[(size_t)b * ld1 + I + n];
+  const float hp = hprev ? hprev[(size_t)b * ldh + n] : 0.f;
+  const float rr = r[(size_t)b * ldr + n];
+  dgp[(size_t)b * lddgp + n] = drh * hp * rr * (1.f - rr);
+  dhp[i] = dht[i] * u[(size_t)b * ldu + n] + drh * rr;
+}
+// c: tmp2 = dgp . Wg^T ([B, I+H]): dx = tmp1[0..I) + tmp2[0..I) (+ dres); carry = dhp + tmp2[I..)
+__global__ void k_gru_bwd_c(const float* tmp1, const float* tmp2, int ld, int I, const float* dres, int lddres, const float* dhp,
+                            float* dx, int lddx, float* carry, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = I + H;
+  if (i >= B * W) return;
+  const int b = i / W, n = i % W;
+  const float s = tmp1[(size_t)b * ld + n] + tmp2[(size_t)b * ld + n];
+  if (n < I) dx[(size_t)b * lddx + n] = s + (dres ? dres[(size_t)b * lddres + n] : 0.f);
+  else carry[(size_t)b * H + (n - I)] = dhp[(size_t)b * H + (n - I)] + tmp2[(size_t)b * ld + n];
+}
+
+// ---- BiGRU backward scan: the mirror of k_bigru_rows (row-parallel, transposed h-weights streamed from L2) ----
+struct BigruBArgs {
+  const float* dout;    // [B*T, 2H] gradient of the BiGRU output
+  const float* out;     // [B*T, 2H] forward output (= state sequence)
+  const float* gsave;   // [B*T, 6H] (r | u | c) per direction, true time
+  const float* wgT0; const float* wgT1;   // (h-rows of gates/kernel)^T     [2H, H]
+  const float* wcT0; const float* wcT1;   // (h-rows of candidate/kernel)^T [H, H]
+  const int* lengths;
+  float* dg;            // [B*T, 6H] out: (d r_pre | d u_pre | d c_pre) per direction at the true time index (host pre-zeroes)
+  float* rh;            // [B*T, 2H] out: r * h_prev (input rows of the candidate kernel's h part, for its weight gradient; host pre-zeroes)
+  int B, T, H;
+};
+template <int R>
+__global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BigruBArgs a = a_in;
+  PIN(a.dout); PIN(a.out); PIN(a.gsave); PIN(a.wgT0); PIN(a.wgT1); PIN(a.wcT0); PIN(a.wcT1); PIN(a.lengths); PIN(a.dg); PIN(a.rh);
+  PIN(a.B); PIN(a.T); PIN(a.H);
+  const int tid = threadIdx.x;
+  const int ngrp = (a.B + R - 1) / R;
+  const int d = blockIdx.x / ngrp, r0 = (blockIdx.x % ngrp) * R;
+  const int B = a.B, T = a.T, H = a.H;
+  const float* WgT = d ? a.wgT1 : a.wgT0;
+  const float* WcT = d ? a.wcT1 : a.wcT0;
+  float* dh = smem;                 // [R][H] carried gradient of the state
+  float* v1 = dh + R * H;           // [R][H]  d c_pre
+  float* v2 = v1 + R * H;           // [R][2H] d r_pre | d u_pre
+  float* part = v2 + R * 2 * H;     // [KS][R][N]
+  const int o = tid;                // one (row, unit) per thread; host guarantees R*H <= RP_NT
+  const bool mine = o < R * H;
+  const int rr_ = mine ? o / H : 0, n = mine ? o % H : 0, b = r0 + rr_;
+  const bool brow = mine && b < B;
+  const int L = brow ? (a.lengths ? a.lengths[b] : T) : 0;
+  int Lmax = 0;
+  for (int r = 0; r < R; ++r) { const int bb = r0 + r; if (bb < B) Lmax = max(Lmax, a.lengths ? a.lengths[bb] : T); }
+  if (mine) dh[o] = 0.f;
+  __syncthreads();
+  for (int s = Lmax - 1; s >= 0; --s) {
+    const bool active = brow && s < L;
+    const int t = d ? (L - 1 - s) : s, tp = d ? t + 1 : t - 1;
+    float keep = 0.f, hp = 0.f, rg = 0.f, dgu = 0.f, dcp = 0.f;
+    if (mine) {
+      keep = dh[o];
+      float x1 = 0.f;
+      if (active) {
+        const size_t row = (size_t)b * T + t;
+        const float g = keep + a.dout[row * 2 * H + d * H + n];
+        rg = a.gsave[row * 6 * H + d * 3 * H + n];
+        const float ug = a.gsave[row * 6 * H + d * 3 * H + H + n];
+        const float cg = a.gsave[row * 6 * H + d * 3 * H + 2 * H + n];
+        hp = (s > 0) ? a.out[((size_t)b * T + tp) * 2 * H + d * H + n] : 0.f;
+        dcp = g * (1.f - ug) * (1.f - cg * cg);
+        dgu = g * (hp - cg) * ug * (1.f - ug);
+        keep = g * ug;
+        x1 = dcp;
+        a.rh[row * 2 * H + d * H + n] = rg * hp;
+      }
+      v1[o] = x1;
+      v2[rr_ * 2 * H + H + n] = active ? dgu : 0.f;
+    }
+    __syncthreads();
+    int KS = rp_matvec<R>(WcT, H, H, v1, H, part, tid);
+    __syncthreads();
+    float dgr = 0.f;
+    if (mine) {
+      const float drh = rp_reduce(part, KS, R * H, o);
+      if (active) { dgr = drh * hp * rg * (1.f - rg); keep += drh * rg; }
+      v2[rr_ * 2 * H + n] = dgr;
+    }
+    __syncthreads();
+    KS = rp_matvec<R>(WgT, 2 * H, H, v2, 2 * H, part, tid);
+    __syncthreads();
+    if (mine) {
+      const float dhg = rp_reduce(part, KS, R * H, o);
+      dh[o] = active ? keep + dhg : keep;
+      if (active) {
+        float* q = a.dg + ((size_t)b * T + t) * 6 * H + d * 3 * H;
+        q[n] = dgr; q[H + n] = dgu; q[2 * H + n] = dcp;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---- attention backward, one workgroup per batch row (mirror of k_attention; recomputes the forward quantities) ----
+struct AttnBArgs {
+  const float* hq; const float* wq; const float* wqT;      // h_att(t) [B, ldhq]; query kernel [As, A] and its transpose [A, As]
+  const float* keys; const float* values; const float* v; const float* score_bias;
+  const float* alpha; const float* alpha_prev;             // tape rows [B, ldal]
+  const float* dctx;                                       // [B, lddctx] total gradient of context(t)
+  float* dalpha;        // [B, T_in] in: gradient of alpha(t) arriving from step t+1; out: gradient of alpha(t-1)
+  float* dkeys; float* dvalues;                            // accumulators [B, T_in, A] / [B, T_in, D]
+  float* dv_acc; float* dsb_acc;                           // per-row accumulators [B, A], [B]
+  float* dq; float* dhq;                                   // out [B, lddq]; in/out [B, lddhq]: += dq . Wq^T
+  int ldhq, ldal, lddctx, lddq, lddhq, T_in, A, D, As, type;
+};
+#define ATB_NT 512
+__global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) {
+  AttnBArgs a = a_in;
+  __shared__ float q[1024], dqv[1024], dcx[1024];     // A, D, As <= 1024 (host checks)
+  __shared__ float p[ATT_MAXT], cp[ATT_MAXT], ss[ATT_MAXT], da[ATT_MAXT], de[ATT_MAXT], w1[ATT_MAXT];
+  __shared__ float red[ATB_NT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = ATB_NT / 64;
+  const int b = blockIdx.x, T = a.T_in, A = a.A, D = a.D, As = a.As;
+  const float* hq = a.hq + (size_t)b * a.ldhq;
+  const float* krow = a.keys + (size_t)b * T * A;
+  const float* vrow = a.values + (size_t)b * T * D;
+  const float* al = a.alpha + (size_t)b * a.ldal;
+  const float* alp = a.alpha_prev + (size_t)b * a.ldal;
+  // q = hq . Wq ; dctx row
+  for (int n2 = tid; n2 < A; n2 += ATB_NT) {
+    float s = 0.f;
+    for (int k = 0; k < As; ++k) s = fmaf(hq[k], a.wq[(size_t)k * A + n2], s);
+    q[n2] = s;
+  }
+  for (int d2 = tid; d2 < D; d2 += ATB_NT) dcx[d2] = a.dctx[(size_t)b * a.lddctx + d2];
+  __syncthreads();
+  // scores e_j (kept in de[] for now) ; d alpha_j = carry + dctx . V_j ; dV_j += alpha_j * dctx
+  for (int j = wave; j < T; j += NWV) {
+    float se = 0.f, sd = 0.f;
+    for (int c = lane; c < A; c += 64) se += a.v[c] * tanhf(krow[(size_t)j * A + c] + q[c]);
+    const float aj = al[j];
+    for (int c = lane; c < D; c += 64) {
+      sd += dcx[c] * vrow[(size_t)j * D + c];
+      a.dvalues[((size_t)b * T + j) * D + c] += aj * dcx[c];
+    }
+    se = wave_sum(se); sd = wave_sum(sd);
+    if (lane == 0) { de[j] = se; da[j] = a.dalpha[(size_t)b * T + j] + sd; }
+  }
+  __syncthreads();
+  // normaliser backward (single wave, chunked scans like the forward)
+  if (wave == 0) {
+    const int C = (T + 63) >> 6, j0 = lane * C, j1 = min(j0 + C, T);
+    if (a.type == 2) {
+      const float sb = a.score_bias ? a.score_bias[0] : 0.f;
+      // forward recompute: p, cp (exclusive cumprod through logs), s = cumsum(prev / clip(cp))
+      float run = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const float pj = taco_sigmoid(de[j] + sb);
+        p[j] = pj; cp[j] = run;
+        run += logf(fminf(fmaxf(1.f - pj, 1.17549435e-38f), 1.f));
+      }
+      const float off = wave_scan(run, lane) - run;
+      float run2 = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const float c1 = expf(cp[j] + off);
+        cp[j] = c1;
+        run2 += alp[j] / fminf(fmaxf(c1, 1e-10f), 1.f);
+        ss[j] = run2;
+      }
+      const float off2 = wave_scan(run2, lane) - run2;
+      for (int j = j0; j < j1; ++j) ss[j] += off2;
+      // backward: ds_j = da*p*cp ; rc = reverse inclusive cumsum(ds)
+      float tot = 0.f;
+      for (int j = j0; j < j1; ++j) tot += da[j] * p[j] * cp[j];
+      const float incl = wave_scan(tot, lane);
+      const float all = __shfl(incl, 63, 64);
+      float suffix = all - incl;                    // sum over later lanes' chunks
+      float dLsum = 0.f;                            // chunk total of dL (for the second reverse scan)
+      for (int j = j1 - 1; j >= j0; --j) {
+        suffix += da[j] * p[j] * cp[j];             // rc_j
+        const float cj = fminf(fmaxf(cp[j], 1e-10f), 1.f);
+        w1[j] = suffix / cj;                        // d alpha_prev_j
+        float dcp = da[j] * p[j] * ss[j];
+        if (cp[j] >= 1e-10f && cp[j] <= 1.f) dcp += -suffix * alp[j] / (cj * cj);
+        const float dL = dcp * cp[j];
+        ss[j] = da[j] * cp[j] * ss[j];              // dp_j (direct term); ss no longer needed as s
+        cp[j] = dL;                                 // reuse: cp now holds dL
+        dLsum += dL;
+      }
+      const float incl2 = wave_scan(dLsum, lane);
+      const float all2 = __shfl(incl2, 63, 64);
+      float suf2 = all2 - incl2;                    // sum of dL over later chunks
+      float dsb = 0.f;
+      for (int j = j1 - 1; j >= j0; --j) {
+        const float dlg = suf2;                     // reverse EXCLUSIVE cumsum: sum_{k>j} dL_k
+        suf2 += cp[j];
+        const float xj = 1.f - p[j];
+        float dp = ss[j];
+        if (xj >= 1.17549435e-38f && xj <= 1.f) dp -= dlg / xj;
+        const float dej = dp * p[j] * (1.f - p[j]);
+        de[j] = dej; dsb += dej;
+      }
+      dsb = wave_sum(dsb);
+      if (lane == 0 && a.dsb_acc) a.dsb_acc[b] += dsb;
+      for (int j = j0; j < j1; ++j) a.dalpha[(size_t)b * T + j] = w1[j];
+    } else {
+      // softmax: de_j = alpha_j * (da_j - sum_k alpha_k da_k); no dependence on the previous alignments
+      float dot = 0.f;
+      for (int j = j0; j < j1; ++j) dot += al[j] * da[j];
+      dot = wave_sum(dot);
+      for (int j = j0; j < j1; ++j) { de[j] = al[j] * (da[j] - dot); a.dalpha[(size_t)b * T + j] = 0.f; }
+    }
+  }
+  __syncthreads();
+  // score backward: g = de_j * v_a * (1 - th^2): dq_a = sum_j g ; dkeys[j,a] += g ; dv_a += sum_j de_j * th
+  {
+    const int NG = ATB_NT / 256;                     // j-groups (256 channels per pass)
+    for (int c0 = 0; c0 < A; c0 += 256) {
+      const int c = c0 + (tid & 255), grp = tid >> 8;
+      float sq = 0.f, sv = 0.f;
+      if (c < A) {
+        const float qc = q[c], vc = a.v[c];
+        for (int j = grp; j < T; j += NG) {
+          const float th = tanhf(krow[(size_t)j * A + c] + qc);
+          const float g = de[j] * vc * (1.f - th * th);
+          sq += g; sv += de[j] * th;
+          a.dkeys[((size_t)b * T + j) * A + c] += g;
+        }
+      }
+      red[tid] = sq; __syncthreads();
+      if (tid < 256 && c < A) { float s = 0.f; for (int g2 = 0; g2 < NG; ++g2) s += red[g2 * 256 + tid]; dqv[c] = s; a.dq[(size_t)b * a.lddq + c] = s; }
+      __syncthreads();
+      red[tid] = sv; __syncthreads();
+      if (tid < 256 && c < A) { float s = 0.f; for (int g2 = 0; g2 < NG; ++g2) s += red[g2 * 256 + tid]; a.dv_acc[(size_t)b * A + c] += s; }
+      __syncthreads();
+    }
+  }
+  // dhq += dq . Wq^T
+  for (int k = tid; k < As; k += ATB_NT) {
+    float s = 0.f;
+    for (int c = 0; c < A; ++c) s = fmaf(dqv[c], a.wqT[(size_t)c * As + k], s);
+    a.dhq[(size_t)b * a.lddhq + k] += s;
+  }
+}

@@ -80,6 +80,7 @@ struct GemmArgs {
   float* out;             // [M, ldo]
   int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0;
   int t_begin, t_len, tiles_per_b;   // time-window mode (t_len > 0): rows (b, t_begin + i), i < t_len, for every batch row b
+  float* aux0; float* aux1;          // training tape (k_gemm DUAL only, nullable): highway H = relu(.) and T = sigmoid(.), [M, ldo]
   GemmVar v[16];          // one per blockIdx.z (conv-bank widths); by value so the fields arrive by scalar loads
 };
 
@@ -131,11 +132,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
-           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b; } a =
+           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b;
+           float* aux0; float* aux1; } a =
       {a_in.x, a_in.gather, a_in.res, a_in.rowvec, a_in.rev_len, a_in.out, a_in.ldx, a_in.M, a_in.T, a_in.Cin, a_in.cin_pad,
-       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b};
+       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b,
+       a_in.aux0, a_in.aux1};
   PIN(a.t_begin); PIN(a.t_len); PIN(a.tiles_per_b);
-  PIN(a.rev_len); PIN(a.rev_col0);
+  PIN(a.rev_len); PIN(a.rev_col0); PIN(a.aux0); PIN(a.aux1);
   PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out);
   PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.cin_pad); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
   GemmVar v = a_in.v[blockIdx.z];
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
           const float Tg = taco_sigmoid(acc2[tm][tn][r] + bia2);
           const float xin = a.x[(size_t)row * a.ldx + col];
           val = H * Tg + xin * (1.f - Tg);
+          if (a.aux0) { a.aux0[(size_t)row * a.ldo + col] = H; a.aux1[(size_t)row * a.ldo + col] = Tg; }
         } else {
           val = taco_act(acc[tm][tn][r] + bia, a.act);   // conv/dense + bias -> activation
           val = val * sc + sh;                            // -> BatchNorm (modules.py:131)
@@ -540,6 +544,7 @@ struct SkJob {
   float* o2;         // GATES: x-part of the candidate (columns >= 2H) or null; CAND: sequence output [R,T,ldo2]
                      // (BiGRU) or null; LINEAR: per-row non-zero flag (int*) or null
   const int* lengths;  // BiGRU sequence_length or null
+  float* o3; int ldo3; // training tape (nullable): GATES: r; CAND: c (the tanh candidate)
   int ldx0, ldx1, K0, K, Kq, N, H, act;
   int lde0, lde1, lde2, lde3, ldo0, ldo1, ldo2;
   int step, T, dir, seq_coff;   // BiGRU scan position: dir 0 forward, 1 backward (reverse_sequence)
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   }
   SkJob jb = MULTI ? a.j[ji] : a.j[0];
   PIN(jb.x0); PIN(jb.x1); PIN(jb.gather0); PIN(jb.wp); PIN(jb.bias); PIN(jb.e0); PIN(jb.e1); PIN(jb.e2); PIN(jb.e3);
-  PIN(jb.o0); PIN(jb.o1); PIN(jb.o2); PIN(jb.lengths);
+  PIN(jb.o0); PIN(jb.o1); PIN(jb.o2); PIN(jb.lengths); PIN(jb.o3); PIN(jb.ldo3);
   PIN(jb.ldx0); PIN(jb.ldx1); PIN(jb.K0); PIN(jb.K); PIN(jb.Kq); PIN(jb.N); PIN(jb.H); PIN(jb.act);
   PIN(jb.lde0); PIN(jb.lde1); PIN(jb.lde2); PIN(jb.lde3); PIN(jb.ldo0); PIN(jb.ldo1); PIN(jb.ldo2);
   PIN(jb.step); PIN(jb.T); PIN(jb.dir); PIN(jb.seq_coff); PIN(jb.tile0);
@@ -691,7 +696,8 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
     } else if (EPI == EPI_GRU_GATES) {
       if (n < 2 * jb.H) {
         const float sg = taco_sigmoid(s + pe1[e]);
-        if (n < jb.H) jb.o0[(size_t)r * jb.ldo0 + n] = sg * pe0[e];       // r * h
+        if (n < jb.H) { jb.o0[(size_t)r * jb.ldo0 + n] = sg * pe0[e];     // r * h
+          if (jb.o3) jb.o3[(size_t)r * jb.ldo3 + n] = sg; }
         else jb.o1[(size_t)r * jb.ldo1 + (n - jb.H)] = sg;                // u
       } else {
         jb.o2[(size_t)r * jb.ldo2 + (n - 2 * jb.H)] = s;                  // x . Wc_x (bias added with the h part)
@@ -703,6 +709,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
       const float c = tanhf(s + pe1[e]);
       const float hn = pe2[e] * pe0[e] + (1.f - pe2[e]) * c;            // u*h + (1-u)*c
       if (active) jb.o0[(size_t)r * jb.ldo0 + n] = hn;
+      if (jb.o3) jb.o3[(size_t)r * jb.ldo3 + n] = c;
       if (jb.o1) jb.o1[(size_t)r * jb.ldo1 + n] = hn + pe3[e];
       if (jb.o2) jb.o2[((size_t)r * jb.T + t) * jb.ldo2 + jb.seq_coff + n] = active ? hn : 0.f;
     }
@@ -773,6 +780,7 @@ struct BigruRArgs {
   const float* h0;      // [B, 2H] initial states (fw | bw) or null
   const int* lengths;   // [B] or null
   float* out;           // [B*T, 2H]
+  float* gsave;         // training tape (nullable) [B*T, 6H]: (r | u | c) per direction at the TRUE time index of the step
   int B, T, H;
 };
 
@@ -780,7 +788,7 @@ template <int R>
 __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BigruRArgs a = a_in;
-  PIN(a.xproj); PIN(a.wg0); PIN(a.wg1); PIN(a.wc0); PIN(a.wc1); PIN(a.h0); PIN(a.lengths); PIN(a.out);
+  PIN(a.xproj); PIN(a.wg0); PIN(a.wg1); PIN(a.wc0); PIN(a.wc1); PIN(a.h0); PIN(a.lengths); PIN(a.out); PIN(a.gsave);
   PIN(a.B); PIN(a.T); PIN(a.H);
   const int tid = threadIdx.x;
   const int ngrp = (a.B + R - 1) / R;
@@ -798,6 +806,12 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
   }
   __syncthreads();
   constexpr int NE1 = 2, NE2 = 1;     // epilogue outputs per thread (host guarantees R*2H <= 2*RP_NT)
+  int Lg[NE1];                        // sequence length of the row of each gate output (tape only)
+#pragma unroll
+  for (int e = 0; e < NE1; ++e) {
+    const int o = tid + e * RP_NT, b = r0 + o / (2 * H);
+    Lg[e] = (a.gsave && a.lengths && o < R * 2 * H && b < B) ? a.lengths[b] : T;
+  }
   for (int s = 0; s < T; ++s) {
     // x-parts of this thread's outputs: requested now, consumed after the weight stream
     float xg[NE1], xc[NE2]; int Lr[NE2];
@@ -826,6 +840,10 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
         const float sg = taco_sigmoid(rp_reduce(part, KS, R * 2 * H, o) + xg[e]);
         if (n < H) rhs[r * H + n] = sg * hs[r * H + n];
         else us[r * H + (n - H)] = sg;
+        if (a.gsave && s < Lg[e] && r0 + r < B) {
+          const int t = d ? (Lg[e] - 1 - s) : s;
+          a.gsave[((size_t)(r0 + r) * T + t) * 6 * H + d * 3 * H + n] = sg;
+        }
       }
     }
     __syncthreads();
@@ -845,6 +863,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
         const int t = (d && active) ? (Lr[e] - 1 - s) : s;
         if (active) hs[o] = hn;
         if (b < B) a.out[((size_t)b * T + t) * 2 * H + d * H + n] = active ? hn : 0.f;
+        if (a.gsave && active && b < B) a.gsave[((size_t)b * T + t) * 6 * H + d * 3 * H + 2 * H + n] = c;
       }
     }
     __syncthreads();
@@ -868,6 +887,8 @@ struct AttnArgs {
   float* hist;           // [B, T_in, n_steps] or null (tacotron.py:238-239 layout)
   float* ctx;            // [B, D]
   int T_in, A, D, type, step, n_steps, As, ldctx;   // ldctx: row stride of ctx (D, or D + speaker columns)
+  const float* align_prev;  // training tape: previous alignments read from here (align is then write-only); null = align
+  int ldalign, ldhq;        // row strides of align/align_prev and hq (0 = T_in / As)
 };
 
 #define ATT_NW 16    // waves per workgroup (1024 threads: more key/value loads and tanh evaluations in flight)
@@ -907,7 +928,8 @@ __device__ __forceinline__ float taco_tanh_fast(float x) {
 // hq_row: the row's attention-GRU output (global or LDS) when the query mat-vec is done here; al: the row's
 // alignment state [T_in] (in: previous, out: new; global or LDS); ctx_out: [D] (global or LDS).
 __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, float* tmp, float* tmp2, float* cred,
-                                         const float* hq_row, float* al, float* ctx_out) {
+                                         const float* hq_row, float* al, float* ctx_out, const float* al_prev = nullptr) {
+  if (!al_prev) al_prev = al;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int T = a.T_in;
@@ -1021,7 +1043,7 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
         for (int j = j0; j < j1; ++j) {
           const float cp = expf(tmp[j] + off);
           tmp[j] = cp;
-          run2 += al[j] / fminf(fmaxf(cp, 1e-10f), 1.f);
+          run2 += al_prev[j] / fminf(fmaxf(cp, 1e-10f), 1.f);
           tmp2[j] = run2;    // inclusive within the lane's chunk
         }
         const float off2 = wave_scan(run2, lane) - run2;
@@ -1080,13 +1102,15 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
   AttnArgs a = a_in;
   PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
   PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps); PIN(a.ldctx);
+  PIN(a.align_prev); PIN(a.ldalign); PIN(a.ldhq);
   __shared__ float sc[ATT_MAXT];     // scores -> alignments
   __shared__ float tmp[ATT_MAXT];
   __shared__ float tmp2[ATT_MAXT];
   __shared__ __attribute__((aligned(16))) float cred[ATT_NW * 256];
   const int b = blockIdx.x;
-  att_core(a, b, sc, tmp, tmp2, cred, a.hq ? a.hq + (size_t)b * a.As : nullptr, a.align + (size_t)b * a.T_in,
-           a.ctx + (size_t)b * a.ldctx);
+  const int lda = a.ldalign ? a.ldalign : a.T_in, ldh = a.ldhq ? a.ldhq : a.As;
+  att_core(a, b, sc, tmp, tmp2, cred, a.hq ? a.hq + (size_t)b * ldh : nullptr, a.align + (size_t)b * lda,
+           a.ctx + (size_t)b * a.ldctx, a.align_prev ? a.align_prev + (size_t)b * lda : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@
 // No CPU compute path exists here: every stage is a gfx950 kernel from taco_kernels.h.
 #include "taco_kernels.h"
 #include "taco_train_kernels.h"
+#include "taco_backward_kernels.h"
 #include "../../include/taco_abi.h"
 
 #include <algorithm>
@@ -88,6 +89,7 @@ struct taco_model {
   // packed
   std::vector<float> harena;
   float* darena = nullptr;
+  size_t arena_n = 0;
   std::vector<GemmVar> hvars;
   std::map<std::string, ConvL> convs;
   std::map<std::string, SkW> skinny;
@@ -111,7 +113,9 @@ struct taco_model {
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   hipStream_t side = nullptr;  // that second stream
   std::vector<hipEvent_t> events;
+  struct TrainPacks* tp = nullptr;   // set on the shadow model of a taco_train: finalize also builds the backward packs
 };
+static int build_train_packs(taco_model* m);   // taco_train.h
 
 static size_t arena_put(taco_model* m, const float* src, size_t n) {
   size_t off = rup_sz(m->harena.size(), 16);
@@ -394,6 +398,7 @@ struct GemmCall {
   const int* rev_len = nullptr; int rev_col0 = -1;
   int t_begin = 0, t_len = 0;      // time window [t_begin, t_begin + t_len) of every batch row (t_len 0 = all rows)
   float* out = nullptr; int ldo = 0;
+  float* aux0 = nullptr; float* aux1 = nullptr;   // highway H / T saved for the backward pass (training tape)
 };
 
 template <int WM, int WN, int TM, int TN, int KS, bool DUAL>
@@ -441,7 +446,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
   a.x = c.x; a.gather = c.gather; a.res = c.res; a.rowvec = c.rowvec; a.out = c.out;
   a.ldx = c.ldx; a.M = c.M; a.T = c.T > 0 ? c.T : c.M; a.Cin = L0.cin; a.cin_pad = L0.cin_pad; a.mpw = c.mpw;
   a.act = c.act; a.ldres = c.ldres; a.ldrv = c.ldrv; a.ldo = c.ldo; a.rev_len = c.rev_len; a.rev_col0 = c.rev_col0;
-  a.t_begin = c.t_begin; a.t_len = c.t_len;
+  a.t_begin = c.t_begin; a.t_len = c.t_len; a.aux0 = c.aux0; a.aux1 = c.aux1;
   a.vec_ok = (c.ldx % 4 == 0) && (L0.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(c.x) & 15) == 0);
   int kw_max = 1, Nmax = 0;
   for (int i = 0; i < nvar; ++i) {
@@ -963,6 +968,8 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+#include "taco_train.h"
+
 extern "C" {
 
 int taco_abi_version(void) { return TACO_ABI_VERSION; }
@@ -1124,6 +1131,7 @@ int taco_model_finalize(taco_model* m) {
   for (int i = 0; i < hp.enc_prenet_n; ++i) m->convs["prenet/dense_" + std::to_string(i + 1)] = m->enc_prenet[i];
   m->convs["attention/memory_layer"] = m->memory_layer;
   m->convs["linear"] = m->linear;
+  if (m->tp) TRY(build_train_packs(m));
   // upload
   HIPCHK(hipMalloc((void**)&m->darena, m->harena.size() * sizeof(float)));
   HIPCHK(hipMemcpy(m->darena, m->harena.data(), m->harena.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1141,6 +1149,7 @@ int taco_model_finalize(taco_model* m) {
   for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIPCHK(hipMalloc((void**)&m->d_err, 256));
   HIPCHK(hipMemset(m->d_err, 0, 256));
+  m->arena_n = m->harena.size();
   m->harena.clear(); m->harena.shrink_to_fit();
   m->raw.clear();
   m->finalized = true;
@@ -1460,5 +1469,7 @@ int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, 
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+#include "taco_train_api.h"
 
 }  // extern "C"

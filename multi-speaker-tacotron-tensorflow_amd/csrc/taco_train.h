@@ -1,0 +1,686 @@
+// taco_train.h -- host side of the training path (included at the end of taco_lib.hip):
+//   * taco_train: a "shadow" taco_model whose weight packs are regenerated on the device from ONE flat fp32
+//     parameter buffer (index maps built by running the normal packers over index-valued tensors), plus the
+//     transposed packs the backward pass needs;
+//   * training-mode forward (tacotron.py:26 is_training graph: batch-statistics BatchNorm with moving-average
+//     updates, TacoTrainingHelper teacher forcing helpers.py:35-67) that records a tape in the caller's workspace;
+//   * the backward pass (tf.gradients of tacotron.py:274-336's loss), gradients accumulated into one flat buffer
+//     laid out like the parameters (the single RCCL all-reduce bucket of the data-parallel step).
+// modules.py:24 calls tf.layers.dropout without training=True, so the prenet dropout is the identity in the
+// reference even when training; nothing is dropped here either.
+// Supported for training: num_speakers == 1, attention bah / bah_mon.
+#pragma once
+
+struct CbhgT {
+  std::vector<ConvL> bank_f, bank_d;   // training-forward (no folded BN) and data-gradient layers, order of Cbhg.bank
+  std::vector<ConvL> proj_f, proj_d;
+  ConvL dense_d;
+  std::vector<ConvL> hw_d;             // [2D -> D]: rows = [W_H^T ; W_T^T]
+  ConvL xproj_d;                       // [6H -> I]
+  size_t ghT[2] = {0, 0}, chT[2] = {0, 0};   // transposed h-rows of the GRU kernels (raw, arena offsets)
+};
+struct GruT { SkW gT, cT; int I = 0, H = 0; };   // gates/kernel^T (K = 2H, N = I+H), candidate/kernel^T (K = H, N = I+H)
+struct TrainPacks {
+  std::vector<ConvL> encpre_d;
+  CbhgT enc, post;
+  ConvL mem_d, lin_d;
+  std::vector<SkW> decpre_T;
+  GruT att, dec[4];
+  SkW concat_T, frame_T;
+  size_t wqT = 0;
+};
+
+struct taco_train {
+  taco_model* sm = nullptr;            // shadow model (arena = gather of the flat parameters)
+  TrainPacks tp;
+  std::map<std::string, size_t> poff;  // flat offset of every spec tensor
+  size_t NP = 0, arena_n = 0;
+  float* d_map = nullptr;              // index map of the arena
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward packs (run inside taco_model_finalize of the shadow model, before the arena upload)
+// ---------------------------------------------------------------------------------------------------------------
+static ConvL make_conv_T(taco_model* m, const float* W, int kw, int cin, int N) {
+  // data gradient of y[t] = sum_j W[j] x[t + j - padl] is the SAME-padded correlation of dy with
+  // WT[j'][n][c] = W[kw-1-j'][c][n] and left padding kw-1-padl
+  std::vector<float> WT((size_t)kw * N * cin);
+  for (int j = 0; j < kw; ++j)
+    for (int c = 0; c < cin; ++c)
+      for (int n = 0; n < N; ++n) WT[((size_t)(kw - 1 - j) * N + n) * cin + c] = W[((size_t)j * cin + c) * N + n];
+  ConvL L; L.kw = kw; L.cin = N; L.N = cin;
+  int Kq, NT;
+  L.wp = pack_w32(m, WT.data(), kw, N, cin, &L.cin_pad, &Kq, &NT);
+  add_var(m, L, 0);
+  m->hvars[L.var_index].padl = kw - 1 - (kw - 1) / 2;
+  return L;
+}
+static ConvL make_conv_T_named(taco_model* m, const std::string& name) {
+  const HostTensor& k = T_(m, name + "/kernel");
+  if (k.shape.size() == 3) return make_conv_T(m, k.data.data(), (int)k.shape[0], (int)k.shape[1], (int)k.shape[2]);
+  return make_conv_T(m, k.data.data(), 1, (int)k.shape[0], (int)k.shape[1]);
+}
+static std::vector<float> transpose2d(const float* W, int rows, int cols, int r0 = 0, int nr = -1) {
+  if (nr < 0) nr = rows - r0;
+  std::vector<float> Tt((size_t)cols * nr);
+  for (int r = 0; r < nr; ++r)
+    for (int c = 0; c < cols; ++c) Tt[(size_t)c * nr + r] = W[(size_t)(r0 + r) * cols + c];
+  return Tt;
+}
+static SkW pack_w16_T(taco_model* m, const float* W, int rows, int cols) {   // pack of W^T: K = cols, N = rows
+  std::vector<float> Tt = transpose2d(W, rows, cols);
+  return pack_w16(m, Tt.data(), rows, 0, cols, 0, rows, nullptr);
+}
+static ConvL conv_noBN(taco_model* m, const ConvL& L, int coff) {
+  ConvL F = L; F.bns = F.bnb = 0; F.bh = F.bl = F.bh2 = F.bl2 = 0; F.var_index = -1;
+  add_var(m, F, coff);
+  return F;
+}
+static void build_cbhg_T(taco_model* m, const Cbhg& c, const std::string& sc, CbhgT& t) {
+  for (size_t i = 0; i < c.bank.size(); ++i) {
+    const int k = c.bank[i].kw;
+    t.bank_f.push_back(conv_noBN(m, c.bank[i], (k - 1) * c.C));
+    t.bank_d.push_back(make_conv_T_named(m, sc + "/conv_bank/conv1d_" + std::to_string(k)));
+  }
+  for (size_t i = 0; i < c.proj.size(); ++i) {
+    t.proj_f.push_back(conv_noBN(m, c.proj[i], 0));
+    t.proj_d.push_back(make_conv_T_named(m, sc + "/proj_" + std::to_string(i + 1)));
+  }
+  if (c.has_dense) t.dense_d = make_conv_T_named(m, sc + "/dense");
+  const int D = c.rnn;
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string n = sc + "/highway_" + std::to_string(i + 1);
+    const auto& WH = T_(m, n + "/H/kernel").data; const auto& WT = T_(m, n + "/T/kernel").data;
+    std::vector<float> cat((size_t)2 * D * D);          // [2D, D] = [W_H^T ; W_T^T]
+    for (int r = 0; r < D; ++r)
+      for (int q = 0; q < D; ++q) { cat[(size_t)q * D + r] = WH[(size_t)r * D + q]; cat[(size_t)(D + q) * D + r] = WT[(size_t)r * D + q]; }
+    ConvL L; L.kw = 1; L.cin = 2 * D; L.N = D;
+    int Kq, NT;
+    L.wp = pack_w32(m, cat.data(), 1, 2 * D, D, &L.cin_pad, &Kq, &NT);
+    add_var(m, L, 0);
+    t.hw_d.push_back(L);
+  }
+  const int H = c.rnn, I = c.rnn;
+  std::vector<float> WxT((size_t)6 * H * I);              // [6H, I]: transposed hoisted input projection
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+    const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
+    for (int i = 0; i < I; ++i) {
+      for (int j = 0; j < 2 * H; ++j) WxT[(size_t)(dir * 3 * H + j) * I + i] = gk[(size_t)i * 2 * H + j];
+      for (int j = 0; j < H; ++j) WxT[(size_t)(dir * 3 * H + 2 * H + j) * I + i] = ck[(size_t)i * H + j];
+    }
+    std::vector<float> gT = transpose2d(gk.data(), I + H, 2 * H, I, H);   // [2H, H]
+    std::vector<float> cT = transpose2d(ck.data(), I + H, H, I, H);       // [H, H]
+    t.ghT[dir] = arena_put(m, gT.data(), gT.size());
+    t.chT[dir] = arena_put(m, cT.data(), cT.size());
+  }
+  ConvL X; X.kw = 1; X.cin = 6 * H; X.N = I;
+  int Kq, NT;
+  X.wp = pack_w32(m, WxT.data(), 1, 6 * H, I, &X.cin_pad, &Kq, &NT);
+  add_var(m, X, 0);
+  t.xproj_d = X;
+}
+static GruT make_gru_T(taco_model* m, const std::string& name, int I, int H) {
+  GruT g; g.I = I; g.H = H;
+  g.gT = pack_w16_T(m, T_(m, name + "/gates/kernel").data.data(), I + H, 2 * H);
+  g.cT = pack_w16_T(m, T_(m, name + "/candidate/kernel").data.data(), I + H, H);
+  return g;
+}
+static int build_train_packs(taco_model* m) {
+  TrainPacks& tp = *m->tp;
+  const taco_hparams& hp = m->hp;
+  if (hp.num_speakers > 1) return fail(TACO_ERR_UNSUPPORTED, "training supports single-speaker models only");
+  if (hp.attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
+  for (int i = 0; i < hp.enc_prenet_n; ++i) tp.encpre_d.push_back(make_conv_T_named(m, "prenet/dense_" + std::to_string(i + 1)));
+  build_cbhg_T(m, m->enc, "encoder_cbhg", tp.enc);
+  build_cbhg_T(m, m->post, "post_cbhg", tp.post);
+  tp.mem_d = make_conv_T_named(m, "attention/memory_layer");
+  tp.lin_d = make_conv_T_named(m, "linear");
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
+  int d = hp.num_mels + D;
+  for (int i = 0; i < hp.dec_prenet_n; ++i) {
+    tp.decpre_T.push_back(pack_w16_T(m, T_(m, "decoder/prenet/dense_" + std::to_string(i + 1) + "/kernel").data.data(), d, hp.dec_prenet[i]));
+    d = hp.dec_prenet[i];
+  }
+  tp.att = make_gru_T(m, "decoder/attention_gru", d, As);
+  for (int i = 0; i < hp.dec_layer_num; ++i) tp.dec[i] = make_gru_T(m, "decoder/gru_" + std::to_string(i + 1), Hd, Hd);
+  tp.concat_T = pack_w16_T(m, T_(m, "decoder/concat_projection/kernel").data.data(), As + D, Hd);
+  tp.frame_T = pack_w16_T(m, T_(m, "decoder/frame_projection/kernel").data.data(), Hd, hp.num_mels * hp.reduction_factor);
+  { std::vector<float> wqT = transpose2d(T_(m, "attention/query_layer/kernel").data.data(), As, A);
+    tp.wqT = arena_put(m, wqT.data(), wqT.size()); }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launch helpers
+// ---------------------------------------------------------------------------------------------------------------
+#define EWGRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
+static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, int ldb, const float* mu, const float* rstd,
+                      float* out1, float* out2, int M, int C, int mode) {
+  ColArgs g; g.a = a; g.b = b; g.mu = mu; g.rstd = rstd; g.out1 = out1; g.out2 = out2; g.lda = lda; g.ldb = ldb; g.M = M; g.C = C;
+  g.mode = mode; g.rpb = 256;
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), cdiv(M, g.rpb)), dim3(256), 0, st, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
+                     int M, int T, int K, int N, int kw = 1, int padl = 0) {
+  WgArgs g; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
+  g.kw = kw; g.padl = padl; g.rpb = 512;
+  hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * cdiv(M, g.rpb)), dim3(256), 0, st, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// y = x . W^T style data gradient through k_gemm: out = conv_T(dy) (+ res)
+static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const float* dy, int lddy, int M, int T, float* out, int ldo,
+                     const float* res = nullptr, int ldres = 0) {
+  GemmCall g; g.x = dy; g.ldx = lddy; g.M = M; g.T = T; g.out = out; g.ldo = ldo; g.res = res; g.ldres = ldres;
+  return run_gemm(m, st, &Ld, 1, false, g);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tape layout
+// ---------------------------------------------------------------------------------------------------------------
+struct CbhgTape {
+  float *bank_a, *bank_y, *pool, *bank_mu, *bank_rs;
+  float *pa[4], *py[4], *pmu[4], *prs[4];
+  float *res, *hx[10], *hH[8], *hT[8];
+  float *xproj, *out, *gsave;
+  float *dg, *rh, *d0, *d1, *dcat, *dbig0, *dbig1, *stat;
+};
+static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w) {
+  const size_t M = (size_t)B * T, KC = (size_t)c.K * c.C;
+  w.bank_a = cv.f(M * KC); w.bank_y = cv.f(M * KC); w.pool = cv.f(M * KC); w.bank_mu = cv.f(KC); w.bank_rs = cv.f(KC);
+  size_t wide = std::max<size_t>(c.in_dim, c.rnn);
+  for (int i = 0; i < c.nproj; ++i) {
+    w.pa[i] = cv.f(M * c.proj_dim[i]); w.py[i] = cv.f(M * c.proj_dim[i]); w.pmu[i] = cv.f(c.proj_dim[i]); w.prs[i] = cv.f(c.proj_dim[i]);
+    wide = std::max<size_t>(wide, c.proj_dim[i]);
+  }
+  w.res = cv.f(M * c.in_dim);
+  for (int i = 0; i <= c.depth; ++i) w.hx[i] = cv.f(M * c.rnn);
+  for (int i = 0; i < c.depth; ++i) { w.hH[i] = cv.f(M * c.rnn); w.hT[i] = cv.f(M * c.rnn); }
+  w.xproj = cv.f(M * 6 * c.rnn); w.out = cv.f(M * 2 * c.rnn); w.gsave = cv.f(M * 6 * c.rnn);
+  w.dg = cv.f(M * 6 * c.rnn); w.rh = cv.f(M * 2 * c.rnn);
+  w.d0 = cv.f(M * wide); w.d1 = cv.f(M * wide); w.dcat = cv.f(M * 2 * c.rnn);
+  w.dbig0 = cv.f(M * KC); w.dbig1 = cv.f(M * KC); w.stat = cv.f(2 * std::max<size_t>(KC, wide));
+}
+struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (b*n + t)*W
+  float *keys, *zero, *ctx, *pz[4], *hA, *rA, *uA, *cA, *rhA, *xcA, *alpha, *alpha0;
+  float *o[5], *h[4], *r[4], *u[4], *c[4], *rh[4], *xc[4];
+  int* nz;
+  // backward
+  float *dkeys, *dvalues, *dv_acc, *dsb_acc, *dalpha, *dctx, *dctx_t, *dhA, *dh[4], *dht, *dhp, *tmp1, *tmp2, *do_[5];
+  float *g_dgp[4], *g_dcp[4], *g_dgpA, *g_dcpA, *g_do0, *g_dq, *g_dz[4], *dpz, *dIn;
+};
+static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int n, DecTape& w) {
+  const taco_hparams& hp = m->hp;
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size, L = hp.dec_layer_num;
+  const size_t R = (size_t)B * n;
+  w.keys = cv.f((size_t)B * T_in * A); w.zero = cv.f((size_t)B * std::max(std::max(hp.num_mels, As), std::max(Hd, D)));
+  w.ctx = cv.f(R * D);
+  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f(R * hp.dec_prenet[i]);
+  w.hA = cv.f(R * As); w.rA = cv.f(R * As); w.uA = cv.f(R * As); w.cA = cv.f(R * As); w.rhA = cv.f(R * As); w.xcA = cv.f(R * As);
+  w.alpha = cv.f((size_t)B * (n + 1) * T_in); w.alpha0 = cv.f((size_t)B * T_in);   // slot 0 = initial alignments, slot t+1 = step t
+  for (int i = 0; i <= L; ++i) w.o[i] = cv.f(R * Hd);
+  for (int i = 0; i < L; ++i) { w.h[i] = cv.f(R * Hd); w.r[i] = cv.f(R * Hd); w.u[i] = cv.f(R * Hd); w.c[i] = cv.f(R * Hd); w.rh[i] = cv.f(R * Hd); w.xc[i] = cv.f(R * Hd); }
+  w.nz = cv.i((size_t)n * B);
+  w.dkeys = cv.f((size_t)B * T_in * A); w.dvalues = cv.f((size_t)B * T_in * D); w.dv_acc = cv.f((size_t)B * A); w.dsb_acc = cv.f(B);
+  w.dalpha = cv.f((size_t)B * T_in); w.dctx = cv.f((size_t)B * D); w.dctx_t = cv.f((size_t)B * D); w.dhA = cv.f((size_t)B * As);
+  for (int i = 0; i < L; ++i) w.dh[i] = cv.f((size_t)B * Hd);
+  const int Wmax = std::max(std::max(As, Hd), D);
+  w.dht = cv.f((size_t)B * Wmax); w.dhp = cv.f((size_t)B * Wmax);
+  const int W2 = std::max(std::max(2 * Hd, As + D), std::max(hp.dec_prenet[hp.dec_prenet_n - 1] + As, hp.num_mels + D)) + Wmax;
+  w.tmp1 = cv.f((size_t)B * W2); w.tmp2 = cv.f((size_t)B * W2);
+  for (int i = 0; i <= L; ++i) w.do_[i] = cv.f((size_t)B * Hd);
+  for (int i = 0; i < L; ++i) { w.g_dgp[i] = cv.f(R * 2 * Hd); w.g_dcp[i] = cv.f(R * Hd); }
+  w.g_dgpA = cv.f(R * 2 * As); w.g_dcpA = cv.f(R * As); w.g_do0 = cv.f(R * Hd); w.g_dq = cv.f(R * A);
+  for (int i = 0; i < hp.dec_prenet_n; ++i) w.g_dz[i] = cv.f(R * hp.dec_prenet[i]);
+  w.dpz = cv.f((size_t)B * W2); w.dIn = cv.f((size_t)B * W2);
+}
+struct TrainWs {
+  float* pre[4]; float* dpre[4];
+  CbhgTape enc, post;
+  DecTape dec;
+  float *teach, *mel, *linear, *dmel, *dlin, *denc, *dpost, *dmel_post, *demb, *losspart;
+};
+static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n, TrainWs& w) {
+  const taco_model* m = t->sm;
+  const taco_hparams& hp = m->hp;
+  const size_t Me = (size_t)B * T_in, Mp = (size_t)B * n * hp.reduction_factor;
+  for (int i = 0; i < hp.enc_prenet_n; ++i) { w.pre[i] = cv.f(Me * hp.enc_prenet[i]); w.dpre[i] = cv.f(Me * std::max(hp.enc_prenet[i], hp.embedding_size)); }
+  carve_cbhg_tape(cv, m->enc, B, T_in, w.enc);
+  carve_cbhg_tape(cv, m->post, B, n * hp.reduction_factor, w.post);
+  carve_dec_tape(cv, m, B, T_in, n, w.dec);
+  w.teach = cv.f((size_t)B * n * hp.num_mels);
+  w.mel = cv.f(Mp * hp.num_mels); w.linear = cv.f(Mp * hp.num_freq);
+  w.dmel = cv.f(Mp * hp.num_mels); w.dlin = cv.f(Mp * hp.num_freq);
+  w.denc = cv.f(Me * 2 * hp.enc_rnn_size);
+  w.dpost = cv.f(Mp * 2 * hp.post_rnn_size); w.dmel_post = cv.f(Mp * hp.num_mels); w.demb = cv.f(Me * hp.embedding_size);
+  w.losspart = (float*)cv.raw((size_t)TR_MAXBLK * 8 * sizeof(double));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// CBHG: training forward with tape, and backward
+// ---------------------------------------------------------------------------------------------------------------
+struct TrainCtx {
+  const taco_train* t; hipStream_t st; float* P; float* G;    // flat parameters (moving statistics are updated in place) and gradients
+  float* p(const std::string& n) const { return P + t->poff.at(n); }
+  float* g(const std::string& n) const { return G + t->poff.at(n); }
+};
+// batch statistics of a [M, C] activation -> mu, rstd (and the moving averages of layer `name` in the parameter buffer)
+static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, float* mu, float* rstd, float* scratch,
+                    const std::string* names, const int* cols, int nnames) {
+  hipStream_t st = x.st;
+  HIPCHK(hipMemsetAsync(scratch, 0, (size_t)2 * C * sizeof(float), st));
+  TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0));
+  hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, 1.0f / M);
+  TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1));
+  int c0 = 0;
+  for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix
+    hipLaunchKernelGGL(k_bn_finalize, EWGRID(cols[i]), 0, st, mu + c0, scratch + C + c0, rstd + c0, x.p(names[i] + "/moving_mean"),
+                       x.p(names[i] + "/moving_variance"), cols[i], 1.0f / M, 1e-3f, 0.99f);
+    c0 += cols[i];
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, const std::string& sc, const float* in, int B, int T,
+                              const int* lengths, const CbhgTape& w) {
+  const taco_model* m = x.t->sm; hipStream_t st = x.st;
+  const int M = B * T, KC = c.K * c.C;
+  { GemmCall g; g.x = in; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank_a; g.ldo = KC;
+    TRY(run_gemm(m, st, ct.bank_f.data(), c.K, false, g)); }
+  { std::vector<std::string> names; std::vector<int> cols;
+    // column block k-1 of the concatenation belongs to conv1d_k (modules.py:35-44)
+    for (int k = 1; k <= c.K; ++k) { names.push_back(sc + "/conv_bank/conv1d_" + std::to_string(k)); cols.push_back(c.C); }
+    TRY(bn_stats(x, w.bank_a, KC, M, KC, w.bank_mu, w.bank_rs, w.stat, names.data(), cols.data(), c.K));
+    for (int k = 1; k <= c.K; ++k) {
+      const int c0 = (k - 1) * c.C;
+      hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * c.C), 0, st, w.bank_a + c0, KC, w.bank_mu + c0, w.bank_rs + c0,
+                         x.p(names[k - 1] + "/gamma"), x.p(names[k - 1] + "/beta"), w.bank_y + c0, KC, M, c.C);
+    } }
+  hipLaunchKernelGGL(k_maxpool_fwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.pool, M, T, KC, c.maxpool);
+  HIPCHK(hipGetLastError());
+  const float* cur = w.pool; int curd = KC;
+  for (int i = 0; i < c.nproj; ++i) {
+    const std::string n = sc + "/proj_" + std::to_string(i + 1);
+    const int N = c.proj_dim[i];
+    GemmCall p; p.x = cur; p.ldx = curd; p.M = M; p.T = T; p.act = (i + 1 == c.nproj) ? ACT_NONE : ACT_RELU; p.out = w.pa[i]; p.ldo = N;
+    TRY(run_gemm(m, st, &ct.proj_f[i], 1, false, p));
+    TRY(bn_stats(x, w.pa[i], N, M, N, w.pmu[i], w.prs[i], w.stat, &n, &N, 1));
+    hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * N), 0, st, w.pa[i], N, w.pmu[i], w.prs[i], x.p(n + "/gamma"), x.p(n + "/beta"), w.py[i], N, M, N);
+    cur = w.py[i]; curd = N;
+  }
+  // residual (modules.py:62-69)
+  hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.in_dim), 0, st, cur, c.in_dim, w.res, c.in_dim, M, c.in_dim);
+  hipLaunchKernelGGL(k_add2d, EWGRID((size_t)M * c.in_dim), 0, st, w.res, c.in_dim, in, c.in_dim, M, c.in_dim);
+  HIPCHK(hipGetLastError());
+  if (c.has_dense) { GemmCall d; d.x = w.res; d.ldx = c.in_dim; d.M = M; d.out = w.hx[0]; d.ldo = c.rnn; TRY(run_gemm(m, st, &c.dense, 1, false, d)); }
+  else hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.rnn), 0, st, w.res, c.rnn, w.hx[0], c.rnn, M, c.rnn);
+  for (int i = 0; i < c.depth; ++i) {
+    GemmCall h; h.x = w.hx[i]; h.ldx = c.rnn; h.M = M; h.out = w.hx[i + 1]; h.ldo = c.rnn; h.aux0 = w.hH[i]; h.aux1 = w.hT[i];
+    TRY(run_gemm(m, st, &c.hw[i], 1, true, h));
+  }
+  const int H = c.rnn;
+  { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
+    TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
+  int R = 0; size_t lds = 0;
+  if (!bigru_rows_cfg(B, H, &R, &lds)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the row-parallel BiGRU kernel", H);
+  HIPCHK(hipMemsetAsync(w.gsave, 0, (size_t)M * 6 * H * sizeof(float), st));
+  BigruRArgs a; memset(&a, 0, sizeof a);
+  a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
+  a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H;
+  if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  else hipLaunchKernelGGL(k_bigru_rows<1>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// one conv1d+act+BN(train) layer backward: dy (grad of BN output) -> weight/bias/gamma/beta grads and dz (pre-activation grad).
+static int conv_bn_backward(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
+                            const float* rstd, bool relu, float* dz, int lddz, int M, int C) {
+  hipStream_t st = x.st;
+  TRY(run_colsum(st, a, lda, dy, lddy, mu, rstd, x.g(name + "/beta"), x.g(name + "/gamma"), M, C, 2));
+  hipLaunchKernelGGL(k_bn_bwd, EWGRID((size_t)M * C), 0, st, a, lda, dy, lddy, mu, rstd, x.p(name + "/gamma"), x.g(name + "/beta"),
+                     x.g(name + "/gamma"), relu ? 1 : 0, dz, lddz, M, C, 1.0f / M);
+  TRY(run_colsum(st, dz, lddz, nullptr, 0, nullptr, nullptr, x.g(name + "/bias"), nullptr, M, C, 0));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+// dout [M, 2*rnn] -> din [M, in_dim]
+static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, const std::string& sc, const float* in, const int* in_gather,
+                         int B, int T, const int* lengths, const float* dout, float* din, const CbhgTape& w) {
+  (void)in_gather;
+  const taco_model* m = x.t->sm; hipStream_t st = x.st;
+  const int M = B * T, KC = c.K * c.C, H = c.rnn, I = c.rnn;
+  // ---- BiGRU ----
+  HIPCHK(hipMemsetAsync(w.dg, 0, (size_t)M * 6 * H * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.rh, 0, (size_t)M * 2 * H * sizeof(float), st));
+  {
+    int R = (B >= 2 && 2 * H <= RP_NT) ? 2 : 1;
+    if ((size_t)R * H > RP_NT || (H % 4)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the BiGRU backward kernel", H);
+    const size_t lds = ((size_t)4 * R * H + (size_t)RP_NT * R * 4 + 64) * sizeof(float);
+    BigruBArgs a; memset(&a, 0, sizeof a);
+    a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.wgT0 = AP(m, ct.ghT[0]); a.wgT1 = AP(m, ct.ghT[1]); a.wcT0 = AP(m, ct.chT[0]); a.wcT1 = AP(m, ct.chT[1]);
+    a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.B = B; a.T = T; a.H = H;
+    if (R == 2) hipLaunchKernelGGL(k_bigru_rows_bwd<2>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+    else hipLaunchKernelGGL(k_bigru_rows_bwd<1>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+    HIPCHK(hipGetLastError());
+  }
+  const float* hlast = w.hx[c.depth];
+  for (int dir = 0; dir < 2; ++dir) {
+    const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+    const float* dgg = w.dg + dir * 3 * H;          // gates columns (r|u), candidate at +2H
+    float* Gg = x.g(n + "/gates/kernel"); float* Gc = x.g(n + "/candidate/kernel");
+    TRY(run_wgrad(st, hlast, nullptr, I, dgg, 6 * H, Gg, 2 * H, M, T, I, 2 * H));                                   // x rows of gates
+    TRY(run_wgrad(st, hlast, nullptr, I, dgg + 2 * H, 6 * H, Gc, H, M, T, I, H));                                    // x rows of candidate
+    // h rows: state before the step = output one step earlier in the direction's own time (zero at the sequence start / past the length)
+    TRY(run_wgrad(st, w.out + dir * H, nullptr, 2 * H, dgg, 6 * H, Gg + (size_t)I * 2 * H, 2 * H, M, T, H, 2 * H, 1, dir ? -1 : 1));
+    TRY(run_wgrad(st, w.rh + dir * H, nullptr, 2 * H, dgg + 2 * H, 6 * H, Gc + (size_t)I * H, H, M, T, H, H));
+    TRY(run_colsum(st, dgg, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/gates/bias"), nullptr, M, 2 * H, 0));
+    TRY(run_colsum(st, dgg + 2 * H, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/candidate/bias"), nullptr, M, H, 0));
+  }
+  float* dcur = w.d0; float* dalt = w.d1;
+  TRY(run_dgrad(m, st, ct.xproj_d, w.dg, 6 * H, M, T, dcur, I));
+  // ---- highways ----
+  for (int i = c.depth - 1; i >= 0; --i) {
+    const std::string n = sc + "/highway_" + std::to_string(i + 1);
+    hipLaunchKernelGGL(k_highway_bwd, EWGRID((size_t)M * H), 0, st, dcur, w.hx[i], w.hH[i], w.hT[i], w.dcat, dalt, M, H);
+    HIPCHK(hipGetLastError());
+    TRY(run_wgrad(st, w.hx[i], nullptr, H, w.dcat, 2 * H, x.g(n + "/H/kernel"), H, M, 0, H, H));
+    TRY(run_wgrad(st, w.hx[i], nullptr, H, w.dcat + H, 2 * H, x.g(n + "/T/kernel"), H, M, 0, H, H));
+    TRY(run_colsum(st, w.dcat, 2 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/H/bias"), nullptr, M, H, 0));
+    TRY(run_colsum(st, w.dcat + H, 2 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/T/bias"), nullptr, M, H, 0));
+    TRY(run_dgrad(m, st, ct.hw_d[i], w.dcat, 2 * H, M, 0, dalt, H, dalt, H));   // += direct path
+    std::swap(dcur, dalt);
+  }
+  // ---- dense (post-net) ----
+  if (c.has_dense) {
+    TRY(run_wgrad(st, w.res, nullptr, c.in_dim, dcur, H, x.g(sc + "/dense/kernel"), H, M, 0, c.in_dim, H));
+    TRY(run_colsum(st, dcur, H, nullptr, 0, nullptr, nullptr, x.g(sc + "/dense/bias"), nullptr, M, H, 0));
+    TRY(run_dgrad(m, st, ct.dense_d, dcur, H, M, 0, dalt, c.in_dim));
+    std::swap(dcur, dalt);
+  }
+  // dcur = gradient of (proj_last + x): keep a copy for the residual path
+  float* dres = din;
+  hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.in_dim), 0, st, dcur, c.in_dim, dres, c.in_dim, M, c.in_dim);
+  HIPCHK(hipGetLastError());
+  // ---- projections (last first) ----
+  for (int i = c.nproj - 1; i >= 0; --i) {
+    const std::string n = sc + "/proj_" + std::to_string(i + 1);
+    const int N = c.proj_dim[i];
+    const float* xin = (i == 0) ? w.pool : w.py[i - 1]; const int xd = (i == 0) ? KC : c.proj_dim[i - 1];
+    TRY(conv_bn_backward(x, n, w.pa[i], N, dcur, N, w.pmu[i], w.prs[i], i + 1 != c.nproj, dalt, N, M, N));
+    TRY(run_wgrad(st, xin, nullptr, xd, dalt, N, x.g(n + "/kernel"), N, M, T, xd, N, c.pw, (c.pw - 1) / 2));
+    float* dnext = (i == 0) ? w.dbig0 : dcur;
+    TRY(run_dgrad(m, st, ct.proj_d[i], dalt, N, M, T, dnext, xd));
+    if (i > 0) { /* dnext == dcur already holds the gradient of py[i-1] */ }
+  }
+  // ---- maxpool + conv bank ----
+  hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
+  HIPCHK(hipGetLastError());
+  for (size_t bi = 0; bi < c.bank.size(); ++bi) {
+    const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
+    const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
+    TRY(conv_bn_backward(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C));
+    TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
+    TRY(run_dgrad(m, st, ct.bank_d[bi], w.dbig0 + c0, KC, M, T, din, c.in_dim, din, c.in_dim));   // accumulates onto the residual path
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// decoder: teacher-forced training forward with tape (TacoTrainingHelper, helpers.py:35-67), and BPTT
+// ---------------------------------------------------------------------------------------------------------------
+static int gru_cell_train(const taco_model* m, hipStream_t st, const GruDec& g, int B, const float* xin, int ldx, const float* hprev, int ldh,
+                          float* hnew, float* rh, float* u, float* xc, float* r, float* c, int ld, float* out_res) {
+  SkJob ja = sk_base(m, g.gx, xin, ldx, g.I, hprev, ldh);
+  ja.H = g.H; ja.e0 = hprev; ja.lde0 = ldh; ja.o0 = rh; ja.ldo0 = ld; ja.o1 = u; ja.ldo1 = ld; ja.o2 = xc; ja.ldo2 = ld; ja.o3 = r; ja.ldo3 = ld;
+  TRY(run_skinny(st, B, &ja, 1, EPI_GRU_GATES));
+  SkJob jb = sk_base(m, g.ch, rh, ld, g.H, nullptr, 0);
+  jb.H = g.H; jb.e0 = hprev; jb.lde0 = ldh; jb.e1 = xc; jb.lde1 = ld; jb.e2 = u; jb.lde2 = ld; jb.o0 = hnew; jb.ldo0 = ld; jb.o3 = c; jb.ldo3 = ld;
+  if (out_res) { jb.e3 = xin; jb.lde3 = ldx; jb.o1 = out_res; jb.ldo1 = ld; }
+  TRY(run_skinny(st, B, &jb, 1, EPI_GRU_CAND));
+  return 0;
+}
+static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, float* mel,
+                                 float* align_hist, const DecTape& w) {
+  const taco_model* m = x.t->sm; hipStream_t st = x.st;
+  const taco_hparams& hp = m->hp;
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
+  const int Mm = hp.num_mels, rM = Mm * hp.reduction_factor, L = hp.dec_layer_num, np = hp.dec_prenet_n;
+  if (T_in > ATT_MAXT) return fail(TACO_ERR_UNSUPPORTED, "T_in %d > %d", T_in, ATT_MAXT);
+  if (!((A % 4 == 0) && A <= ATT_MAXT && A / 4 <= 64 * ATT_NW) || (D % 4) || A > 1024 || D > 1024 || As > 1024)
+    return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the training kernels");
+  { GemmCall g; g.x = enc_out; g.ldx = D; g.M = B * T_in; g.out = w.keys; g.ldo = A; TRY(run_gemm(m, st, &m->memory_layer, 1, false, g)); }
+  const int Wz = std::max(std::max(Mm, As), std::max(Hd, D));
+  hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * Wz), 0, st, (const float*)nullptr, 0, w.zero, Wz, B, Wz);
+  hipLaunchKernelGGL(k_init_align, EWGRID((size_t)B * T_in), 0, st, w.alpha0, B, T_in, hp.attention_type == 2 ? 1 : 0);
+  const int ldal = (n + 1) * T_in;
+  hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * T_in), 0, st, w.alpha0, T_in, w.alpha, ldal, B, T_in);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
+  const int Pl = hp.dec_prenet[np - 1];
+  for (int t = 0; t < n; ++t) {
+    const float* frame = (t == 0) ? w.zero : teach + (size_t)(t - 1) * Mm; const int ldf = (t == 0) ? Mm : n * Mm;   // helpers.py:44,66,70-72
+    const float* cprev = (t == 0) ? w.zero : w.ctx + (size_t)(t - 1) * D; const int ldcp = (t == 0) ? D : n * D;
+    for (int i = 0; i < np; ++i) {
+      const int P = hp.dec_prenet[i];
+      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, cprev, ldcp, ACT_RELU, w.pz[0] + (size_t)t * P, n * P)
+                         : sk_linear(m, m->dec_prenet[i], w.pz[i - 1] + (size_t)t * hp.dec_prenet[i - 1], n * hp.dec_prenet[i - 1],
+                                     hp.dec_prenet[i - 1], nullptr, 0, ACT_RELU, w.pz[i] + (size_t)t * P, n * P);
+      TRY(run_skinny(st, B, &j, 1));
+    }
+    const float* hAp = (t == 0) ? w.zero : w.hA + (size_t)(t - 1) * As; const int ldhA = (t == 0) ? As : n * As;
+    const size_t oa = (size_t)t * As;
+    TRY(gru_cell_train(m, st, m->att_gru, B, w.pz[np - 1] + (size_t)t * Pl, n * Pl, hAp, ldhA, w.hA + oa, w.rhA + oa, w.uA + oa, w.xcA + oa,
+                       w.rA + oa, w.cA + oa, n * As, nullptr));
+    { AttnArgs a; memset(&a, 0, sizeof a);
+      a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v);
+      a.score_bias = AP(m, m->att_sb); a.align = w.alpha + (size_t)(t + 1) * T_in; a.align_prev = w.alpha + (size_t)t * T_in; a.ldalign = ldal;
+      a.hist = align_hist; a.ctx = w.ctx + (size_t)t * D; a.ldctx = n * D;
+      a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
+      hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
+      HIPCHK(hipGetLastError()); }
+    { SkJob j = sk_linear(m, m->concat_proj, w.hA + oa, n * As, As, w.ctx + (size_t)t * D, n * D, ACT_NONE, w.o[0] + (size_t)t * Hd, n * Hd);
+      TRY(run_skinny(st, B, &j, 1)); }
+    const size_t oh = (size_t)t * Hd;
+    for (int i = 0; i < L; ++i) {
+      const float* hp_ = (t == 0) ? w.zero : w.h[i] + (size_t)(t - 1) * Hd; const int ldhp = (t == 0) ? Hd : n * Hd;
+      TRY(gru_cell_train(m, st, m->dec_gru[i], B, w.o[i] + oh, n * Hd, hp_, ldhp, w.h[i] + oh, w.rh[i] + oh, w.u[i] + oh, w.xc[i] + oh,
+                         w.r[i] + oh, w.c[i] + oh, n * Hd, w.o[i + 1] + oh));
+    }
+    { SkJob j = sk_linear(m, m->frame_proj, w.o[L] + oh, n * Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, n * rM);
+      j.o2 = reinterpret_cast<float*>(w.nz + (size_t)t * B);
+      TRY(run_skinny(st, B, &j, 1)); }
+  }
+  return 0;
+}
+
+static SkJob sk_T(const taco_model* m, const SkW& wT, const float* dy, int lddy, float* out, int ldo) {
+  return sk_linear(m, wT, dy, lddy, wT.K, nullptr, 0, ACT_NONE, out, ldo);
+}
+// one GRUCell backward: dout [B,H] (+carry) -> dx [B,I] (+dres), new carry; tape slices at step t
+static int gru_cell_backward(const TrainCtx& x, const GruT& gt, int B, const float* dout, int lddo, float* carry, bool add_carry,
+                             const float* u, const float* c, const float* r, const float* hprev, int ld, float* g_dcp, float* g_dgp,
+                             const float* dres, int lddres, float* dx, int lddx, const DecTape& w) {
+  const taco_model* m = x.t->sm; hipStream_t st = x.st;
+  const int H = gt.H, I = gt.I, W = I + H;
+  hipLaunchKernelGGL(k_gru_bwd_a, EWGRID((size_t)B * H), 0, st, dout, lddo, add_carry ? carry : (const float*)nullptr, u, ld, c, ld, hprev, ld,
+                     w.dht, g_dcp, ld, g_dgp, 2 * ld, B, H);
+  { SkJob j = sk_T(m, gt.cT, g_dcp, ld, w.tmp1, W); TRY(run_skinny(st, B, &j, 1)); }
+  hipLaunchKernelGGL(k_gru_bwd_b, EWGRID((size_t)B * H), 0, st, w.tmp1, W, I, hprev, ld, r, ld, u, ld, w.dht, g_dgp, 2 * ld, w.dhp, B, H);
+  { SkJob j = sk_T(m, gt.gT, g_dgp, 2 * ld, w.tmp2, W); TRY(run_skinny(st, B, &j, 1)); }
+  hipLaunchKernelGGL(k_gru_bwd_c, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int gru_weight_grads(const TrainCtx& x, const std::string& name, int I, int H, const float* xin, int ldx, const float* hseq,
+                            const float* rh, const float* g_dgp, const float* g_dcp, int R, int n) {
+  hipStream_t st = x.st;
+  float* Gg = x.g(name + "/gates/kernel"); float* Gc = x.g(name + "/candidate/kernel");
+  TRY(run_wgrad(st, xin, nullptr, ldx, g_dgp, 2 * H, Gg, 2 * H, R, 0, I, 2 * H));
+  TRY(run_wgrad(st, hseq, nullptr, H, g_dgp, 2 * H, Gg + (size_t)I * 2 * H, 2 * H, R, n, H, 2 * H, 1, 1));   // previous state = one step earlier
+  TRY(run_wgrad(st, xin, nullptr, ldx, g_dcp, H, Gc, H, R, 0, I, H));
+  TRY(run_wgrad(st, rh, nullptr, H, g_dcp, H, Gc + (size_t)I * H, H, R, 0, H, H));
+  TRY(run_colsum(st, g_dgp, 2 * H, nullptr, 0, nullptr, nullptr, x.g(name + "/gates/bias"), nullptr, R, 2 * H, 0));
+  TRY(run_colsum(st, g_dcp, H, nullptr, 0, nullptr, nullptr, x.g(name + "/candidate/bias"), nullptr, R, H, 0));
+  return 0;
+}
+static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, const float* dmel,
+                            float* denc, const DecTape& w) {
+  const taco_model* m = x.t->sm; hipStream_t st = x.st;
+  const TrainPacks& tp = x.t->tp;
+  const taco_hparams& hp = m->hp;
+  const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
+  const int Mm = hp.num_mels, rM = Mm * hp.reduction_factor, L = hp.dec_layer_num, np = hp.dec_prenet_n, Pl = hp.dec_prenet[np - 1];
+  const int ldal = (n + 1) * T_in, R = B * n;
+  HIPCHK(hipMemsetAsync(w.dkeys, 0, (size_t)B * T_in * A * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dvalues, 0, (size_t)B * T_in * D * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dv_acc, 0, (size_t)B * A * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dsb_acc, 0, (size_t)B * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dalpha, 0, (size_t)B * T_in * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dctx, 0, (size_t)B * D * sizeof(float), st));
+  HIPCHK(hipMemsetAsync(w.dhA, 0, (size_t)B * As * sizeof(float), st));
+  for (int i = 0; i < L; ++i) HIPCHK(hipMemsetAsync(w.dh[i], 0, (size_t)B * Hd * sizeof(float), st));
+  for (int t = n - 1; t >= 0; --t) {
+    const size_t oh = (size_t)t * Hd, oa = (size_t)t * As;
+    { SkJob j = sk_T(m, tp.frame_T, dmel + (size_t)t * rM, n * rM, w.do_[L], Hd); TRY(run_skinny(st, B, &j, 1)); }
+    for (int i = L - 1; i >= 0; --i) {
+      const float* hprev = (t == 0) ? nullptr : w.h[i] + (size_t)(t - 1) * Hd;
+      float* dx = (i == 0) ? w.g_do0 + oh : w.do_[i]; const int lddx = (i == 0) ? n * Hd : Hd;
+      TRY(gru_cell_backward(x, tp.dec[i], B, w.do_[i + 1], Hd, w.dh[i], true, w.u[i] + oh, w.c[i] + oh, w.r[i] + oh, hprev, n * Hd,
+                            w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w));
+    }
+    // concat projection: [h_att | ctx] <- d o0
+    { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.tmp1, As + D); TRY(run_skinny(st, B, &j, 1)); }
+    hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, w.tmp1, As + D, B, As);
+    hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * D), 0, st, w.dctx, D, w.tmp1 + As, As + D, B, D);
+    { AttnBArgs a; memset(&a, 0, sizeof a);
+      a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.wqT = AP(m, tp.wqT); a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v);
+      a.score_bias = AP(m, m->att_sb); a.alpha = w.alpha + (size_t)(t + 1) * T_in; a.alpha_prev = w.alpha + (size_t)t * T_in; a.ldal = ldal;
+      a.dctx = w.dctx; a.lddctx = D; a.dalpha = w.dalpha; a.dkeys = w.dkeys; a.dvalues = w.dvalues; a.dv_acc = w.dv_acc; a.dsb_acc = w.dsb_acc;
+      a.dq = w.g_dq + (size_t)t * A; a.lddq = n * A; a.dhq = w.dhA; a.lddhq = As; a.T_in = T_in; a.A = A; a.D = D; a.As = As; a.type = hp.attention_type;
+      hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(ATB_NT), 0, st, a);
+      HIPCHK(hipGetLastError()); }
+    { const float* hprev = (t == 0) ? nullptr : w.hA + (size_t)(t - 1) * As;
+      TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
+                            w.g_dgpA + 2 * oa, nullptr, 0, w.dpz, Pl, w)); }
+    for (int i = np - 1; i >= 0; --i) {
+      const int P = hp.dec_prenet[i];
+      float* gz = w.g_dz[i] + (size_t)t * P;
+      hipLaunchKernelGGL(k_relu_bwd, EWGRID((size_t)B * P), 0, st, w.dpz, P, w.pz[i] + (size_t)t * P, n * P, gz, n * P, B, P);
+      if (i > 0) { SkJob j = sk_T(m, tp.decpre_T[i], gz, n * P, w.dpz, hp.dec_prenet[i - 1]); TRY(run_skinny(st, B, &j, 1)); }
+      else {
+        SkJob j = sk_T(m, tp.decpre_T[0], gz, n * P, w.dIn, Mm + D); TRY(run_skinny(st, B, &j, 1));
+        hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * D), 0, st, w.dIn + Mm, Mm + D, w.dctx, D, B, D);   // gradient of context(t-1)
+      }
+    }
+    HIPCHK(hipGetLastError());
+  }
+  // ---- weight gradients, hoisted over all steps: rows (b, t) of the [B, n, .] tapes ----
+  TRY(run_wgrad(st, w.o[L], nullptr, Hd, dmel, rM, x.g("decoder/frame_projection/kernel"), rM, R, 0, Hd, rM));
+  TRY(run_colsum(st, dmel, rM, nullptr, 0, nullptr, nullptr, x.g("decoder/frame_projection/bias"), nullptr, R, rM, 0));
+  for (int i = 0; i < L; ++i)
+    TRY(gru_weight_grads(x, "decoder/gru_" + std::to_string(i + 1), Hd, Hd, w.o[i], Hd, w.h[i], w.rh[i], w.g_dgp[i], w.g_dcp[i], R, n));
+  { float* Gk = x.g("decoder/concat_projection/kernel");
+    TRY(run_wgrad(st, w.hA, nullptr, As, w.g_do0, Hd, Gk, Hd, R, 0, As, Hd));
+    TRY(run_wgrad(st, w.ctx, nullptr, D, w.g_do0, Hd, Gk + (size_t)As * Hd, Hd, R, 0, D, Hd));
+    TRY(run_colsum(st, w.g_do0, Hd, nullptr, 0, nullptr, nullptr, x.g("decoder/concat_projection/bias"), nullptr, R, Hd, 0)); }
+  TRY(run_wgrad(st, w.hA, nullptr, As, w.g_dq, A, x.g("attention/query_layer/kernel"), A, R, 0, As, A));
+  TRY(gru_weight_grads(x, "decoder/attention_gru", Pl, As, w.pz[np - 1], Pl, w.hA, w.rhA, w.g_dgpA, w.g_dcpA, R, n));
+  for (int i = np - 1; i >= 0; --i) {
+    const int P = hp.dec_prenet[i];
+    const std::string nm = "decoder/prenet/dense_" + std::to_string(i + 1);
+    float* Gk = x.g(nm + "/kernel");
+    if (i > 0) TRY(run_wgrad(st, w.pz[i - 1], nullptr, hp.dec_prenet[i - 1], w.g_dz[i], P, Gk, P, R, 0, hp.dec_prenet[i - 1], P));
+    else {   // input = concat(previous teacher frame, previous context): both one step earlier, zero at t = 0
+      TRY(run_wgrad(st, teach, nullptr, Mm, w.g_dz[0], P, Gk, P, R, n, Mm, P, 1, 1));
+      TRY(run_wgrad(st, w.ctx, nullptr, D, w.g_dz[0], P, Gk + (size_t)Mm * P, P, R, n, D, P, 1, 1));
+    }
+    TRY(run_colsum(st, w.g_dz[i], P, nullptr, 0, nullptr, nullptr, x.g(nm + "/bias"), nullptr, R, P, 0));
+  }
+  TRY(run_colsum(st, w.dv_acc, A, nullptr, 0, nullptr, nullptr, x.g("attention/attention_v"), nullptr, B, A, 0));
+  if (hp.attention_type == 2) { hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, st, w.dsb_acc, B, x.g("attention/attention_score_bias")); HIPCHK(hipGetLastError()); }
+  TRY(run_wgrad(st, enc_out, nullptr, D, w.dkeys, A, x.g("attention/memory_layer/kernel"), A, B * T_in, 0, D, A));
+  TRY(run_dgrad(m, st, tp.mem_d, w.dkeys, A, B * T_in, 0, denc, D, w.dvalues, D));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// whole step: forward (tape) + loss + backward
+// ---------------------------------------------------------------------------------------------------------------
+static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float* G, const int* ids, const int* lengths, const float* mel_tgt,
+                                  const float* lin_tgt, const float* loss_coeff, int B, int T_in, int T_out, int prioritize_loss,
+                                  int sample_rate, float* d_losses, float* mel_out, float* lin_out, float* align_out, void* ws, size_t ws_bytes,
+                                  bool do_backward) {
+  taco_model* m = t->sm;
+  const taco_hparams& hp = m->hp;
+  const int r = hp.reduction_factor, Mm = hp.num_mels, F = hp.num_freq;
+  if (T_out % r) return fail(TACO_ERR_SHAPE, "T_out %d is not a multiple of the reduction factor %d", T_out, r);
+  const int n = T_out / r;
+  if (n > hp.max_iters) return fail(TACO_ERR_SHAPE, "T_out/r = %d exceeds max_iters %d", n, hp.max_iters);
+  TRY(check_common(m, B, T_in));
+  Carver cv(ws, ws_bytes);
+  TrainWs w; carve_train(cv, t, B, T_in, n, w);
+  if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
+  TrainCtx x{t, st, P, G};
+  const int Me = B * T_in, Mp = B * T_out;
+  // ---- forward ----
+  const float* cur = x.p("embedding"); int curd = hp.embedding_size;
+  for (int i = 0; i < hp.enc_prenet_n; ++i) {
+    GemmCall g; g.x = cur; g.ldx = curd; g.gather = (i == 0) ? ids : nullptr; g.M = Me; g.act = ACT_RELU; g.out = w.pre[i]; g.ldo = hp.enc_prenet[i];
+    TRY(run_gemm(m, st, &m->enc_prenet[i], 1, false, g));
+    cur = w.pre[i]; curd = hp.enc_prenet[i];
+  }
+  TRY(cbhg_forward_train(x, m->enc, t->tp.enc, "encoder_cbhg", cur, B, T_in, lengths, w.enc));
+  const float* enc_out = w.enc.out;
+  // teacher inputs: every r-th target frame (helpers.py:44): teach[b, t] = mel_targets[b, t*r + r-1]
+  hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * n * Mm), 0, st, mel_tgt + (size_t)(r - 1) * Mm, r * Mm, w.teach, Mm, B * n, Mm);
+  HIPCHK(hipGetLastError());
+  float* mel = mel_out ? mel_out : w.mel; float* lin = lin_out ? lin_out : w.linear;
+  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec));
+  TRY(cbhg_forward_train(x, m->post, t->tp.post, "post_cbhg", mel, B, T_out, nullptr, w.post));
+  { GemmCall g; g.x = w.post.out; g.ldx = 2 * hp.post_rnn_size; g.M = Mp; g.out = lin; g.ldo = F; TRY(run_gemm(m, st, &m->linear, 1, false, g)); }
+  // ---- loss (tacotron.py:274-302) ----
+  if (d_losses) TRY(taco_loss_f32((void*)st, mel, mel_tgt, lin, lin_tgt, loss_coeff, B, T_out, Mm, F, prioritize_loss, sample_rate, d_losses,
+                                  w.losspart, (size_t)TR_MAXBLK * 8 * sizeof(double)));
+  if (!do_backward) return 0;
+  // ---- backward ----
+  HIPCHK(hipMemsetAsync(G, 0, t->NP * sizeof(float), st));
+  int c_lo = 0, c_hi = 0; float s_lin = 1.0f / ((float)Mp * F), s_band = 0.f;
+  if (prioritize_loss) {
+    c_hi = (int)(5000.0 / (sample_rate * 0.5) * F); c_lo = (int)(165.0 / (sample_rate * 0.5) * F);
+    s_lin = 0.5f / ((float)Mp * F); s_band = 0.5f / ((float)Mp * (c_hi - c_lo));
+  }
+  hipLaunchKernelGGL(k_l1_grad, EWGRID((size_t)Mp * Mm), 0, st, mel, mel_tgt, loss_coeff, Mp, T_out, Mm, 1.0f / ((float)Mp * Mm), 0, 0, 0.f, w.dmel);
+  hipLaunchKernelGGL(k_l1_grad, EWGRID((size_t)Mp * F), 0, st, lin, lin_tgt, loss_coeff, Mp, T_out, F, s_lin, c_lo, c_hi, s_band, w.dlin);
+  HIPCHK(hipGetLastError());
+  const int Hp2 = 2 * hp.post_rnn_size;
+  TRY(run_wgrad(st, w.post.out, nullptr, Hp2, w.dlin, F, x.g("linear/kernel"), F, Mp, 0, Hp2, F));
+  TRY(run_colsum(st, w.dlin, F, nullptr, 0, nullptr, nullptr, x.g("linear/bias"), nullptr, Mp, F, 0));
+  float* dpost = w.dpost; float* dmel_post = w.dmel_post;
+  TRY(run_dgrad(m, st, t->tp.lin_d, w.dlin, F, Mp, 0, dpost, Hp2));
+  TRY(cbhg_backward(x, m->post, t->tp.post, "post_cbhg", mel, nullptr, B, T_out, nullptr, dpost, dmel_post, w.post));
+  hipLaunchKernelGGL(k_add2d, EWGRID((size_t)Mp * Mm), 0, st, w.dmel, Mm, dmel_post, Mm, Mp, Mm);
+  HIPCHK(hipGetLastError());
+  TRY(decoder_backward(x, enc_out, B, T_in, n, w.teach, w.dmel, w.denc, w.dec));
+  float* dpre = w.dpre[hp.enc_prenet_n - 1];
+  TRY(cbhg_backward(x, m->enc, t->tp.enc, "encoder_cbhg", cur, nullptr, B, T_in, lengths, w.denc, dpre, w.enc));
+  for (int i = hp.enc_prenet_n - 1; i >= 0; --i) {
+    const int N = hp.enc_prenet[i];
+    const std::string nm = "prenet/dense_" + std::to_string(i + 1);
+    hipLaunchKernelGGL(k_relu_bwd, EWGRID((size_t)Me * N), 0, st, dpre, N, w.pre[i], N, dpre, N, Me, N);
+    HIPCHK(hipGetLastError());
+    if (i > 0) TRY(run_wgrad(st, w.pre[i - 1], nullptr, hp.enc_prenet[i - 1], dpre, N, x.g(nm + "/kernel"), N, Me, 0, hp.enc_prenet[i - 1], N));
+    else TRY(run_wgrad(st, x.p("embedding"), ids, hp.embedding_size, dpre, N, x.g(nm + "/kernel"), N, Me, 0, hp.embedding_size, N));
+    TRY(run_colsum(st, dpre, N, nullptr, 0, nullptr, nullptr, x.g(nm + "/bias"), nullptr, Me, N, 0));
+    float* dnext = (i > 0) ? w.dpre[i - 1] : w.demb;
+    const int nd = (i > 0) ? hp.enc_prenet[i - 1] : hp.embedding_size;
+    TRY(run_dgrad(m, st, t->tp.encpre_d[i], dpre, N, Me, 0, dnext, nd));
+    dpre = dnext;
+  }
+  hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)Me * hp.embedding_size), 0, st, dpre, ids, x.g("embedding"), Me, hp.embedding_size);
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,82 @@
+// taco_train_api.h -- C ABI of the training path (declared in include/taco_abi.h); included inside extern "C".
+
+int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
+  if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
+  if (hp->num_speakers > 1) return fail(TACO_ERR_UNSUPPORTED, "training supports single-speaker models only");
+  if (hp->attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
+  taco_train* t = new taco_train();
+  int rc = taco_model_create(hp, device, &t->sm);
+  if (rc != 0) { delete t; return rc; }
+  taco_model* sm = t->sm;
+  size_t off = 0;
+  for (auto& s : sm->spec) {          // flat layout = spec order, TF tensor layout, no padding
+    size_t cnt = 1;
+    for (int64_t d : s.second) cnt *= (size_t)d;
+    t->poff[s.first] = off;
+    HostTensor ht; ht.shape = s.second; ht.data.resize(cnt); ht.set = true;
+    for (size_t k = 0; k < cnt; ++k) ht.data[k] = (float)(off + k + 1);     // index-valued "weights": the packs become index maps
+    sm->raw[s.first] = ht;
+    off += cnt;
+  }
+  t->NP = off;
+  if (off >= (1u << 24)) { taco_model_destroy(sm); delete t; return fail(TACO_ERR_UNSUPPORTED, "more than 2^24 parameters"); }
+  sm->tp = &t->tp;
+  sm->bf3 = 0;                        // training keeps every GEMM on the exact-fp32 matrix-core path
+  rc = taco_model_finalize(sm);
+  if (rc != 0) { taco_model_destroy(sm); delete t; return rc; }
+  t->arena_n = sm->arena_n;
+  if (hipMalloc((void**)&t->d_map, t->arena_n * sizeof(float)) != hipSuccess ||
+      hipMemcpy(t->d_map, sm->darena, t->arena_n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
+    taco_model_destroy(sm); delete t; return fail(TACO_ERR_HIP, "index map allocation failed");
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  *out = t;
+  return 0;
+}
+
+void taco_train_destroy(taco_train* t) {
+  if (!t) return;
+  if (t->d_map) (void)hipFree(t->d_map);
+  if (t->sm) taco_model_destroy(t->sm);
+  delete t;
+}
+
+taco_model* taco_train_model(taco_train* t) { return t ? t->sm : nullptr; }
+size_t taco_train_num_params(const taco_train* t) { return t ? t->NP : 0; }
+
+int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset) {
+  if (!t || !name || !offset) return fail(TACO_ERR_ARG, "null argument");
+  auto it = t->poff.find(name);
+  if (it == t->poff.end()) return fail(TACO_ERR_ARG, "unknown parameter '%s'", name);
+  *offset = it->second;
+  return 0;
+}
+
+int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params) {
+  if (!t || !d_params) return fail(TACO_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->sm->device));
+  hipLaunchKernelGGL(k_pack_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, t->d_map, d_params, t->sm->darena, t->arena_n, (unsigned)t->NP);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_out) {
+  if (!t || B <= 0 || T_in <= 0 || T_out <= 0) return 0;
+  const int r = t->sm->hp.reduction_factor;
+  Carver cv(nullptr, 0);
+  TrainWs w; carve_train(cv, t, B, T_in, (T_out + r - 1) / r, w);
+  return cv.off;
+}
+
+int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
+                                const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
+                                const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate, float* d_losses,
+                                float* d_mel_out, float* d_linear_out, float* d_alignments, void* d_workspace, size_t workspace_bytes) {
+  if (!t || !d_params || !d_inputs || !d_input_lengths || !d_mel_targets || !d_linear_targets || !d_workspace)
+    return fail(TACO_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->sm->device));
+  return train_forward_backward(t, (hipStream_t)hip_stream, d_params, d_grads, d_inputs, d_input_lengths, d_mel_targets, d_linear_targets,
+                                d_loss_coeff, B, T_in, T_out, prioritize_loss, sample_rate, d_losses, d_mel_out, d_linear_out, d_alignments,
+                                d_workspace, workspace_bytes, d_grads != nullptr);
+}

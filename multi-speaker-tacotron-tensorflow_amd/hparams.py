@@ -50,6 +50,13 @@ basic_params = {
     'min_tokens': 50,
     'min_iters': 30,
     'max_iters': 200,
+    # training (hparams.py:28,123-133)
+    'sample_rate': 24000,
+    'adam_beta1': 0.9,
+    'adam_beta2': 0.999,
+    'initial_learning_rate': 0.002,
+    'decay_learning_rate_mode': 0,
+    'prioritize_loss': False,
 }
 
 MODEL_TYPES = {'single': 0, 'simple': 1, 'deepvoice': 2}

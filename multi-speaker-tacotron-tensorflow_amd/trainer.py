@@ -1,0 +1,145 @@
+"""`Trainer` -- the training half of the reference's model object: `initialize(..., mel_targets, linear_targets)`
++ `add_loss()` + `add_optimizer(global_step)` (models/tacotron.py:21-336) and the step of train.py:215-219
+(`sess.run([global_step, loss_without_coeff, optimize])`), on libtaco_hip's training path.
+
+All parameters live in ONE flat fp32 device tensor (`params`, layout = taco_model_weight_name order) and all
+gradients in a second one (`grads`) -- the single RCCL all-reduce bucket of the data-parallel step.
+Per step: taco_train_forward_backward (teacher-forced forward with batch-statistics BatchNorm, L1 losses, full
+backward) -> all-reduce of `grads` / world size -> clip_by_global_norm + Adam (taco_adam_step_f32) ->
+taco_train_refresh (weight packs regenerated from the flat parameters).  PyTorch is device memory, streams and
+torch.distributed only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .train_ops import FlatAdam, allreduce_gradients
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Trainer(object):
+    def __init__(self, hparams, weights, device="cuda:0", is_randomly_initialized=True):
+        """`weights`: dict canonical name -> array (weights.random_weights / load_weights)."""
+        self.hp = hparams
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.TacoError(_lib.TACO_ERR_ARG, "the training path runs on a GPU (got device %s); there is no CPU fallback" % device)
+        self._lib = _lib.load_library()
+        chp = _lib.to_c_hparams(hparams, 1)
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.taco_train_create(C.byref(chp), idx, C.byref(self._h)))
+        mh = C.c_void_p(self._lib.taco_train_model(self._h))
+        self.spec, self.offsets = [], {}
+        buf = C.create_string_buffer(256)
+        shp = (C.c_int64 * 4)()
+        nd = C.c_int()
+        off = C.c_size_t()
+        for i in range(self._lib.taco_model_num_weights(mh)):
+            _lib.check(self._lib.taco_model_weight_name(mh, i, buf, 256, shp, C.byref(nd)))
+            name, shape = buf.value.decode(), tuple(int(shp[d]) for d in range(nd.value))
+            _lib.check(self._lib.taco_train_param_offset(self._h, name.encode(), C.byref(off)))
+            self.spec.append((name, shape))
+            self.offsets[name] = (int(off.value), int(np.prod(shape)) if shape else 1)
+        self.num_params = int(self._lib.taco_train_num_params(self._h))
+        self.params = torch.zeros(self.num_params, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.set_weights(weights)
+        g = lambda k, d: getattr(hparams, k, d)
+        self.adam = FlatAdam(self.params, g("initial_learning_rate", 0.002), g("adam_beta1", 0.9), g("adam_beta2", 0.999), 1e-8,
+                             g("decay_learning_rate_mode", 0), is_randomly_initialized, 1.0)
+        self._ws = None
+        self.mel_outputs = self.linear_outputs = self.alignments = None
+
+    # ---- parameters ----
+    def set_weights(self, weights):
+        host = np.zeros(self.num_params, np.float32)
+        for name, shape in self.spec:
+            if name not in weights:
+                raise _lib.TacoError(_lib.TACO_ERR_STATE, "weight '%s' missing" % name)
+            v = np.asarray(weights[name], np.float32)
+            if tuple(v.shape) != shape:
+                raise _lib.TacoError(_lib.TACO_ERR_SHAPE, "weight '%s' has shape %s, expected %s" % (name, v.shape, shape))
+            o, c = self.offsets[name]
+            host[o:o + c] = v.reshape(-1)
+        self.params.copy_(torch.from_numpy(host))
+        self.refresh()
+
+    def get_weights(self):
+        host = self.params.detach().cpu().numpy()
+        return {name: host[o:o + c].reshape(shape).copy() for (name, shape) in self.spec for (o, c) in [self.offsets[name]]}
+
+    def grad_dict(self):
+        host = self.grads.detach().cpu().numpy()
+        return {name: host[o:o + c].reshape(shape).copy() for (name, shape) in self.spec for (o, c) in [self.offsets[name]]}
+
+    def refresh(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.taco_train_refresh(self._h, _st(), _p(self.params)))
+
+    # ---- one forward (+ backward) ----
+    def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False):
+        """Fills self.grads (when backward) and returns the device tensor [4] = loss, mel_loss, linear_loss, loss_without_coeff."""
+        dev = self.device
+        ids = torch.as_tensor(np.asarray(inputs) if not torch.is_tensor(inputs) else inputs).to(dev, torch.int32).contiguous()
+        lens = torch.as_tensor(np.asarray(input_lengths) if not torch.is_tensor(input_lengths) else input_lengths).to(dev, torch.int32).contiguous()
+        mt = torch.as_tensor(np.asarray(mel_targets) if not torch.is_tensor(mel_targets) else mel_targets).to(dev, torch.float32).contiguous()
+        lt = torch.as_tensor(np.asarray(linear_targets) if not torch.is_tensor(linear_targets) else linear_targets).to(dev, torch.float32).contiguous()
+        co = None if loss_coeff is None else torch.as_tensor(np.asarray(loss_coeff) if not torch.is_tensor(loss_coeff) else loss_coeff).to(dev, torch.float32).contiguous()
+        B, T_in = ids.shape
+        T_out = mt.shape[1]
+        hp = self.hp
+        if mt.shape != (B, T_out, hp.num_mels) or lt.shape != (B, T_out, hp.num_freq):
+            raise Exception("targets must be [B, T_out, num_mels] / [B, T_out, num_freq], got %s / %s" % (tuple(mt.shape), tuple(lt.shape)))
+        nb = int(self._lib.taco_train_workspace_bytes(self._h, B, T_in, T_out))
+        if self._ws is None or self._ws.numel() < nb:
+            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        mel = lin = ali = None
+        if keep_outputs:
+            mel = torch.empty((B, T_out, hp.num_mels), dtype=torch.float32, device=dev)
+            lin = torch.empty((B, T_out, hp.num_freq), dtype=torch.float32, device=dev)
+            ali = torch.empty((B, T_in, T_out // hp.reduction_factor), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(self._lib.taco_train_forward_backward(
+                self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(mt), _p(lt), _p(co),
+                B, T_in, T_out, int(bool(getattr(hp, "prioritize_loss", False))), int(getattr(hp, "sample_rate", 24000)), _p(self.losses),
+                _p(mel), _p(lin), _p(ali), _p(self._ws), self._ws.numel()))
+        self.mel_outputs, self.linear_outputs, self.alignments = mel, lin, ali
+        return self.losses
+
+    def train_step(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None):
+        """train.py:217-219: one fwd+bwd+update; returns (global_step, loss_without_coeff) like the reference's fetch."""
+        self.forward_backward(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, backward=True)
+        allreduce_gradients(self.grads)          # no-op on one process; RCCL all-reduce of the flat bucket otherwise
+        self.adam.step(self.grads)
+        self.refresh()
+        return self.adam.global_step, self.losses[3]
+
+    @property
+    def global_step(self):
+        return self.adam.global_step
+
+    @property
+    def learning_rate(self):
+        return self.adam.learning_rate
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.taco_train_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -285,11 +285,32 @@ def batch_norm_infer(y, w, name):
     return g * (y - m) / np.sqrt(v + BN_EPS) + b
 
 
-def conv1d_bn(x, w, name, act):
+BN_MOMENTUM = 0.99
+
+
+def batch_norm_train(y, w, name, updates):
+    """TF-sem batch_normalization(training=True) on [B,T,C] (modules.py:131 with is_training): normalise with
+    the batch mean and BIASED batch variance over (B,T) -- padded frames included, nothing is masked -- and
+    record the moving-average update moving <- moving*0.99 + batch*0.01 that tacotron.py:334 makes the
+    optimizer depend on (UPDATE_OPS).  Assumption (unpinned): the non-fused 3-D path, whose
+    moving variance also takes the biased batch variance."""
+    g = w[name + "/gamma"].astype(y.dtype)
+    b = w[name + "/beta"].astype(y.dtype)
+    mu = y.mean(axis=(0, 1))
+    var = ((y - mu) ** 2).mean(axis=(0, 1))
+    if updates is not None:
+        updates[name + "/moving_mean"] = w[name + "/moving_mean"].astype(y.dtype) * BN_MOMENTUM + mu * (1 - BN_MOMENTUM)
+        updates[name + "/moving_variance"] = w[name + "/moving_variance"].astype(y.dtype) * BN_MOMENTUM + var * (1 - BN_MOMENTUM)
+    return g * (y - mu) / np.sqrt(var + BN_EPS) + b
+
+
+def conv1d_bn(x, w, name, act, bn_updates=None, training=False):
     """modules.py:123-131: conv1d -> activation -> batch_normalization (BN *after* the activation)."""
     y = conv1d_same(x, w[name + "/kernel"], w[name + "/bias"])
     if act is not None:
         y = act(y)
+    if training:
+        return batch_norm_train(y, w, name, bn_updates)
     return batch_norm_infer(y, w, name)
 
 
@@ -375,15 +396,15 @@ def bidirectional_gru(x, lengths, w, scope, init_state=None):
 
 
 def cbhg(x, lengths, w, scope, K, maxpool_width, depth, projs, before_highway=None, rnn_init=None,
-         taps=None):
+         taps=None, training=False, bn_updates=None):
     """modules.py:27-96."""
-    bank = np.concatenate([conv1d_bn(x, w, "%s/conv_bank/conv1d_%d" % (scope, k), relu)
+    bank = np.concatenate([conv1d_bn(x, w, "%s/conv_bank/conv1d_%d" % (scope, k), relu, bn_updates, training)
                            for k in range(1, K + 1)], axis=-1)             # :35-44
     mp = maxpool_same_stride1(bank, maxpool_width)                         # :47-51
     p = mp
     for i in range(len(projs)):
         act = None if i == len(projs) - 1 else relu                        # :55
-        p = conv1d_bn(p, w, "%s/proj_%d" % (scope, i + 1), act)
+        p = conv1d_bn(p, w, "%s/proj_%d" % (scope, i + 1), act, bn_updates, training)
     hi = p + x                                                             # :62-69
     if before_highway is not None:
         hi = hi + before_highway[:, None, :]
@@ -453,13 +474,20 @@ def initial_alignments(B, T_in, attention_type, dtype):
 def forward(w: Dict[str, np.ndarray], hp: OracleHParams, inputs, input_lengths, speaker_id=None,
             num_speakers: int = 1, n_steps: Optional[int] = None, manual_alignments=None,
             dtype=np.float64, taps: Optional[dict] = None, honor_stop: bool = True,
-            teacher_frames=None):
+            teacher_frames=None, training: bool = False, bn_updates: Optional[dict] = None):
     """Returns dict(mel [B,n*r,M], linear [B,n*r,F], alignments [B,T_in,n], stop_step).
 
     `n_steps` = max_iters (tacotron.py:210).  `manual_alignments` [B,T_dec,T_in] switches on the
     manual override of rnn_wrappers.py:313-317.  `teacher_frames` [B,n,M] (optional) replaces the
     fed-back frame at step t>=1 with teacher_frames[:,t-1] -- the TacoTrainingHelper input rule
-    (helpers.py:44,66) -- used only for per-step ("teacher-forced state") kernel parity."""
+    (helpers.py:44,66).
+
+    `training=True` is the is_training graph of tacotron.py:26: batch-normalisation with batch statistics
+    (moving-average updates returned in `bn_updates`), nothing else changes -- modules.py:24 calls
+    tf.layers.dropout WITHOUT training=True, and tf.layers.dropout defaults to training=False, so the prenet
+    dropout is the identity in the reference even while training (drop_rate is computed and unused).  A
+    training caller passes teacher_frames = mel_targets[:, r-1::r] and n_steps = T_out / r (helpers.py:44-48)
+    and honor_stop=False (TacoTrainingHelper finishes on step count only, :62)."""
     inputs = np.asarray(inputs)
     B, T_in = inputs.shape
     r, M = hp.reduction_factor, hp.num_mels
@@ -491,7 +519,8 @@ def forward(w: Dict[str, np.ndarray], hp: OracleHParams, inputs, input_lengths, 
 
     pre = prenet(x, w, "prenet", hp.enc_prenet_sizes)                      # tacotron.py:101-103
     enc = cbhg(pre, lengths, w, "encoder_cbhg", hp.enc_bank_size, hp.enc_maxpool_width,
-               hp.enc_highway_depth, hp.enc_proj_sizes, before_highway, enc_init, taps)  # :105-112
+               hp.enc_highway_depth, hp.enc_proj_sizes, before_highway, enc_init, taps,
+               training=training, bn_updates=bn_updates)                   # :105-112
     if hp.attention_type not in ("bah", "bah_norm", "bah_mon"):
         raise Exception(" [!] Unkown attention type: {}".format(hp.attention_type))     # :152
     values = enc                                                           # no memory_sequence_length (A.8)
@@ -540,7 +569,8 @@ def forward(w: Dict[str, np.ndarray], hp: OracleHParams, inputs, input_lengths, 
     n_eff = stop_step
     mel = Y[:, :n_eff].reshape(B, n_eff * r, M)                            # tacotron.py:213-214
     post = cbhg(mel, None, w, "post_cbhg", hp.post_bank_size, hp.post_maxpool_width,
-                hp.post_highway_depth, hp.post_proj_sizes, taps=taps)      # :219-224
+                hp.post_highway_depth, hp.post_proj_sizes, taps=taps,
+                training=training, bn_updates=bn_updates)                  # :219-224
     if spk_embed is not None:                                              # :226-233 ('simple')
         tiled = np.broadcast_to(spk_embed[:, None, :], (B, post.shape[1], spk_embed.shape[1]))
         post = np.concatenate([tiled, post], axis=-1)

@@ -14,7 +14,8 @@ DT = torch.float64
 
 
 def _t(w, name):
-    return torch.as_tensor(w[name], dtype=DT)
+    v = w[name]
+    return v if torch.is_tensor(v) else torch.as_tensor(v, dtype=DT)
 
 
 def dense(x, w, name, bias=True):
@@ -22,8 +23,8 @@ def dense(x, w, name, bias=True):
     return y + _t(w, name + "/bias") if bias else y
 
 
-def conv_bn(x, w, name, act):
-    """x [B,T,C] -> conv1d SAME (modules.py:123-131) -> act -> BN(inference)."""
+def conv_bn(x, w, name, act, training=False):
+    """x [B,T,C] -> conv1d SAME (modules.py:123-131) -> act -> BN (moving statistics, or batch statistics when training)."""
     k = _t(w, name + "/kernel")                       # [k, in, out]
     kw = k.shape[0]
     pl = (kw - 1) // 2
@@ -31,8 +32,11 @@ def conv_bn(x, w, name, act):
     y = F.conv1d(xc, k.permute(2, 1, 0), _t(w, name + "/bias"))
     if act:
         y = F.relu(y)
-    y = F.batch_norm(y, _t(w, name + "/moving_mean"), _t(w, name + "/moving_variance"), _t(w, name + "/gamma"),
-                     _t(w, name + "/beta"), training=False, eps=1e-3)
+    if training:      # batch mean / biased variance over (B,T); running statistics are not touched here
+        y = F.batch_norm(y, None, None, _t(w, name + "/gamma"), _t(w, name + "/beta"), training=True, eps=1e-3)
+    else:
+        y = F.batch_norm(y, _t(w, name + "/moving_mean"), _t(w, name + "/moving_variance"), _t(w, name + "/gamma"),
+                         _t(w, name + "/beta"), training=False, eps=1e-3)
     return y.permute(0, 2, 1)
 
 
@@ -50,23 +54,27 @@ def bigru(x, lengths, w, scope, init=None):
     B, T, _ = x.shape
     n = w[scope + "/fw/candidate/bias"].shape[0]
     L = torch.full((B,), T, dtype=torch.long) if lengths is None else torch.as_tensor(lengths, dtype=torch.long)
-    out = torch.zeros(B, T, 2 * n, dtype=DT)
+    dirs = []
     for d, nm in enumerate(("fw", "bw")):
+        rows = []
         for b in range(B):                             # row by row: no masking logic at all
             h = torch.zeros(1, n, dtype=DT) if init is None else init[b:b + 1, d * n:(d + 1) * n].clone()
             order = range(int(L[b])) if d == 0 else range(int(L[b]) - 1, -1, -1)
+            seq = [torch.zeros(n, dtype=DT)] * T       # positions past the length stay zero
             for t in order:
                 h = gru_step(x[b:b + 1, t], h, w, scope + "/" + nm)
-                out[b, t, d * n:(d + 1) * n] = h[0]
-    return out
+                seq[t] = h[0]
+            rows.append(torch.stack(seq, 0))
+        dirs.append(torch.stack(rows, 0))
+    return torch.cat(dirs, -1)
 
 
-def cbhg(x, lengths, w, scope, K, depth, nproj, before=None, init=None):
-    bank = torch.cat([conv_bn(x, w, "%s/conv_bank/conv1d_%d" % (scope, k), True) for k in range(1, K + 1)], -1)
+def cbhg(x, lengths, w, scope, K, depth, nproj, before=None, init=None, training=False):
+    bank = torch.cat([conv_bn(x, w, "%s/conv_bank/conv1d_%d" % (scope, k), True, training) for k in range(1, K + 1)], -1)
     mp = F.max_pool1d(F.pad(bank.permute(0, 2, 1), (0, 1), value=float("-inf")), 2, 1).permute(0, 2, 1)
     p = mp
     for i in range(nproj):
-        p = conv_bn(p, w, "%s/proj_%d" % (scope, i + 1), i < nproj - 1)
+        p = conv_bn(p, w, "%s/proj_%d" % (scope, i + 1), i < nproj - 1, training)
     h = p + x
     if before is not None:
         h = h + before[:, None, :]
@@ -80,14 +88,24 @@ def cbhg(x, lengths, w, scope, K, depth, nproj, before=None, init=None):
 
 
 def monotonic_sequential(p, prev):
-    q = torch.zeros_like(p)
-    q[:, 0] = prev[:, 0]
+    qs = [prev[:, 0]]
     for j in range(1, p.shape[1]):
-        q[:, j] = (1 - p[:, j - 1]) * q[:, j - 1] + prev[:, j]
-    return p * q
+        qs.append((1 - p[:, j - 1]) * qs[-1] + prev[:, j])
+    return p * torch.stack(qs, 1)
 
 
-def forward(w, hp, ids, lengths, speaker_id=None, num_speakers=1, n_steps=None, manual=None):
+def monotonic_closed_form(p, prev):
+    """tf.contrib.seq2seq.monotonic_attention(mode='parallel') op for op -- what tf.gradients differentiates:
+    p * safe_cumprod(1-p, exclusive) * cumsum(prev / clip(safe_cumprod, 1e-10, 1)).  The clips stop gradients
+    where they are active, which the sequential recurrence above would not reproduce."""
+    tiny = torch.finfo(p.dtype).tiny
+    lg = torch.log(torch.clamp(1 - p, tiny, 1.0))
+    cp = torch.exp(torch.cumsum(lg, 1) - lg)                 # exclusive cumsum
+    return p * cp * torch.cumsum(prev / torch.clamp(cp, 1e-10, 1.0), 1)
+
+
+def forward(w, hp, ids, lengths, speaker_id=None, num_speakers=1, n_steps=None, manual=None, training=False,
+            teacher_frames=None, as_numpy=True):
     ids = torch.as_tensor(ids, dtype=torch.long)
     B, T_in = ids.shape
     r, M = hp.reduction_factor, hp.num_mels
@@ -107,7 +125,8 @@ def forward(w, hp, ids, lengths, speaker_id=None, num_speakers=1, n_steps=None, 
             spk = None
     for i in range(len(hp.enc_prenet_sizes)):
         x = F.relu(dense(x, w, "prenet/dense_%d" % (i + 1)))
-    enc = cbhg(x, lengths, w, "encoder_cbhg", hp.enc_bank_size, hp.enc_highway_depth, len(hp.enc_proj_sizes), before, enc_init)
+    enc = cbhg(x, lengths, w, "encoder_cbhg", hp.enc_bank_size, hp.enc_highway_depth, len(hp.enc_proj_sizes), before, enc_init,
+               training)
     keys = dense(enc, w, "attention/memory_layer", bias=False)
     v = _t(w, "attention/attention_v")
     h_att = torch.zeros(B, hp.attention_state_size, dtype=DT) if att_init is None else att_init.clone()
@@ -132,7 +151,8 @@ def forward(w, hp, ids, lengths, speaker_id=None, num_speakers=1, n_steps=None, 
         else:
             e = (v * torch.tanh(keys + qv[:, None])).sum(-1)
         if hp.attention_type == "bah_mon":
-            alpha = monotonic_sequential(torch.sigmoid(e + _t(w, "attention/attention_score_bias")), alpha)
+            mono = monotonic_closed_form if training else monotonic_sequential
+            alpha = mono(torch.sigmoid(e + _t(w, "attention/attention_score_bias")), alpha)
         else:
             alpha = F.softmax(e, dim=1)
         if manual is not None:
@@ -146,9 +166,51 @@ def forward(w, hp, ids, lengths, speaker_id=None, num_speakers=1, n_steps=None, 
         y = dense(o, w, "decoder/frame_projection")
         ys.append(y)
         frame = y[:, -M:]
+        if teacher_frames is not None:
+            frame = torch.as_tensor(teacher_frames, dtype=DT)[:, t]
     mel = torch.stack(ys, 1).reshape(B, n * r, M)
-    post = cbhg(mel, None, w, "post_cbhg", hp.post_bank_size, hp.post_highway_depth, len(hp.post_proj_sizes))
+    post = cbhg(mel, None, w, "post_cbhg", hp.post_bank_size, hp.post_highway_depth, len(hp.post_proj_sizes),
+                training=training)
     if spk is not None:
         post = torch.cat([spk[:, None].expand(B, post.shape[1], spk.shape[1]), post], -1)
     linear = dense(post, w, "linear")
-    return dict(mel=mel.numpy(), linear=linear.numpy(), alignments=torch.stack(als, 2).numpy())
+    if not as_numpy:
+        return dict(mel=mel, linear=linear, alignments=torch.stack(als, 2))
+    return dict(mel=mel.detach().numpy(), linear=linear.detach().numpy(), alignments=torch.stack(als, 2).detach().numpy())
+
+
+def add_loss(mel_out, mel_tgt, lin_out, lin_tgt, coeff, prioritize_loss=False, sample_rate=24000):
+    """tacotron.py:274-302 on torch tensors; returns the scalar `loss` the optimizer minimises."""
+    ml = (mel_tgt - mel_out).abs()
+    l1 = (lin_tgt - lin_out).abs()
+    c = coeff[:, None, None]
+    if prioritize_loss:
+        Fq = lin_out.shape[-1]
+        up, lo = int(5000 / (sample_rate * 0.5) * Fq), int(165 / (sample_rate * 0.5) * Fq)
+        return (ml * c).mean() + 0.5 * (l1 * c).mean() + 0.5 * (l1[:, :, lo:up] * c).mean()
+    return (ml * c).mean() + (l1 * c).mean()
+
+
+def train_grads(w, hp, ids, lengths, mel_targets, linear_targets, loss_coeff=None, speaker_id=None, num_speakers=1,
+                prioritize_loss=False, sample_rate=24000):
+    """The training graph of tacotron.py:26,199-202,274-302 + tf.gradients: teacher-forced forward with batch-stat
+    BN, L1 losses, reverse-mode autograd.  Returns (loss, dict name -> d loss / d weight as float64 arrays,
+    forward outputs).  Moving statistics get no gradient (they are not trainable variables)."""
+    r = hp.reduction_factor
+    mt = torch.as_tensor(mel_targets, dtype=DT)
+    lt = torch.as_tensor(linear_targets, dtype=DT)
+    B, T_out, _ = mt.shape
+    assert T_out % r == 0
+    co = torch.ones(B, dtype=DT) if loss_coeff is None else torch.as_tensor(loss_coeff, dtype=DT)
+    wt = {}
+    for k, v in w.items():
+        t = torch.tensor(v, dtype=DT)
+        if not k.endswith(("/moving_mean", "/moving_variance")):
+            t.requires_grad_(True)
+        wt[k] = t
+    out = forward(wt, hp, ids, lengths, speaker_id, num_speakers, n_steps=T_out // r, training=True,
+                  teacher_frames=mt[:, r - 1::r], as_numpy=False)
+    loss = add_loss(out["mel"], mt, out["linear"], lt, co, prioritize_loss, sample_rate)
+    loss.backward()
+    grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in wt.items() if t.requires_grad}
+    return float(loss), grads, {k: v.detach().numpy() for k, v in out.items()}
