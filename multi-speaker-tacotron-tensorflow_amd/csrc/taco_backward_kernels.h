@@ -334,6 +334,16 @@ struct AttnBArgs {
   float* dq; float* dhq;                                   // out [B, lddq]; in/out [B, lddhq]: += dq . Wq^T
   int ldhq, ldal, lddctx, lddq, lddhq, T_in, A, D, As, type;
 };
+// inclusive wave64 SUFFIX sum (lane l gets sum over lanes >= l); never formed as total - prefix, which cancels
+// catastrophically when the tail is many orders of magnitude below the head (it is: the tail carries cumprod(1-p))
+__device__ __forceinline__ float wave_rscan(float x, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float y = __shfl_down(x, o, 64);
+    if (lane + o < 64) x += y;
+  }
+  return x;
+}
 #define ATB_NT 512
 __global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) {
   AttnBArgs a = a_in;
@@ -393,9 +403,7 @@ __global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) 
       // backward: ds_j = da*p*cp ; rc = reverse inclusive cumsum(ds)
       float tot = 0.f;
       for (int j = j0; j < j1; ++j) tot += da[j] * p[j] * cp[j];
-      const float incl = wave_scan(tot, lane);
-      const float all = __shfl(incl, 63, 64);
-      float suffix = all - incl;                    // sum over later lanes' chunks
+      float suffix = wave_rscan(tot, lane) - tot;   // sum over later lanes' chunks
       float dLsum = 0.f;                            // chunk total of dL (for the second reverse scan)
       for (int j = j1 - 1; j >= j0; --j) {
         suffix += da[j] * p[j] * cp[j];             // rc_j
@@ -408,9 +416,7 @@ __global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) 
         cp[j] = dL;                                 // reuse: cp now holds dL
         dLsum += dL;
       }
-      const float incl2 = wave_scan(dLsum, lane);
-      const float all2 = __shfl(incl2, 63, 64);
-      float suf2 = all2 - incl2;                    // sum of dL over later chunks
+      float suf2 = wave_rscan(dLsum, lane) - dLsum; // sum of dL over later chunks
       float dsb = 0.f;
       for (int j = j1 - 1; j >= j0; --j) {
         const float dlg = suf2;                     // reverse EXCLUSIVE cumsum: sum_{k>j} dL_k

@@ -62,6 +62,8 @@ class OracleHParams:
     post_proj_width: int = 3
     reduction_factor: int = 4
     max_iters: int = 200
+    prioritize_loss: bool = False         # hparams.py:133 (training loss only)
+    sample_rate: int = 24000              # hparams.py:28
 
     def to_dict(self):
         return asdict(self)

@@ -79,3 +79,95 @@ def test_gradients_match_autograd(atype, ragged):
         if k.endswith(("/moving_mean", "/moving_variance")):
             assert not got[k].any(), k
     tr.close()
+
+
+def _grad_report(got, g):
+    gn = np.sqrt(sum(float((v ** 2).sum()) for v in g.values()))
+    worst = []
+    for k, v in g.items():
+        err = float(np.abs(got[k] - v).max())
+        worst.append((err / max(float(np.abs(v).max()), 1e-3 * gn), k, err))
+    worst.sort(reverse=True)
+    return worst, gn
+
+
+def test_gradients_long_input_clipped_monotonic_and_priority_loss():
+    """T_in = 72: the exclusive cumprod of (1-p) falls below the 1e-10 clip of monotonic_attention('parallel'), so the
+    clip's zero-gradient branch is exercised; prioritize_loss adds the 165 Hz..5 kHz band term (tacotron.py:283-296)."""
+    import torch
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", B=5, T_in=72, T_out=24, seed=9, prioritize_loss=True, max_iters=9)
+    assert hp.prioritize_loss
+    loss, g, out = TF.train_grads(w, hp, ids, L, mt, lt, co, prioritize_loss=True, sample_rate=24000)
+    tr = _trainer(hp, w)
+    losses = tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 1e-5
+    assert maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
+    worst, gn = _grad_report(tr.grad_dict(), g)
+    assert worst[0][0] < 2e-3, worst[:5]
+
+
+def test_gradients_mid_size_batch_of_17():
+    """Wider model (reference widths / 4), odd batch, several 64-row tiles in every weight-gradient GEMM."""
+    import torch
+    hp = O.OracleHParams.scaled(4, num_mels=20, num_freq=65, enc_bank_size=6, post_bank_size=5, max_iters=10, reduction_factor=4)
+    w = O.init_weights(hp, 1, 3)
+    B, T_in, T_out = 17, 21, 36
+    ids, L = O.synthetic_inputs(B, T_in, 4, ragged=True)
+    rs = np.random.RandomState(8)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    loss, g, _ = TF.train_grads(w, hp, ids, L, mt, lt)
+    tr = _trainer(hp, w)
+    losses = tr.forward_backward(ids, L, mt, lt)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 1e-5
+    worst, gn = _grad_report(tr.grad_dict(), g)
+    assert worst[0][0] < 2e-3, worst[:5]
+
+
+def test_train_step_matches_clip_and_adam_of_the_checker_and_loss_goes_down():
+    """train.py:217-219: one step = fwd + bwd + clip_by_global_norm(1.0) + Adam with the schedule's learning rate; the
+    updated parameters must equal the checker's update applied to the checker's gradients.  Then 30 more steps on the
+    same batch must reduce the loss."""
+    import torch
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=12)
+    loss0, g, _ = TF.train_grads(w, hp, ids, L, mt, lt, co)
+    tr = _trainer(hp, w)
+    names = [k for k, _ in tr.spec]
+    flat = lambda d: np.concatenate([np.asarray(d[k], np.float64).reshape(-1) for k in names])
+    gflat = flat({k: (g[k] if k in g else np.zeros_like(np.asarray(w[k], np.float64))) for k in names})
+    lr = O.learning_rate(0, 0.002, 0, True)
+    assert abs(tr.learning_rate - lr) < 1e-12 + 1e-6 * lr
+    want, _, _, gn = O.adam_clip_step(flat(w), gflat, np.zeros_like(gflat), np.zeros_like(gflat), 1, lr)
+    step, lwc = tr.train_step(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    assert step == 1 and abs(float(tr.adam.gnorm) - gn) < 1e-4 * gn
+    now = tr.get_weights()
+    upd = {}
+    O.forward(w, hp, ids, L, n_steps=mt.shape[1] // hp.reduction_factor, honor_stop=False,
+              teacher_frames=mt[:, hp.reduction_factor - 1::hp.reduction_factor], training=True, bn_updates=upd)
+    for k in names:
+        ref = upd[k] if k in upd else want[tr.offsets[k][0]:tr.offsets[k][0] + tr.offsets[k][1]].reshape(np.shape(w[k]))
+        # Adam's first update is lr * g/(|g| + eps): elements with |g| ~ 1e-8 are ill-conditioned -> compare loosely, in units of lr
+        assert maxabs(now[k], ref) < 0.02 * lr + 1e-6, k
+    first = float(lwc)
+    for _ in range(30):
+        step, lwc = tr.train_step(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    assert step == 31 and float(lwc) < first - 0.005      # warm-up schedule: lr is only 5e-7 * step here
+    assert np.isfinite(tr.params.cpu().numpy()).all()
+    tr.close()
+
+
+def test_training_rejects_unsupported_configurations():
+    import taco_amd
+    hp = tiny_hp(attention_type="bah_norm")
+    with pytest.raises(Exception):
+        _trainer(hp, O.init_weights(hp, 1, 1))
+    hp, w, ids, L, mt, lt, co = _setup()
+    tr = _trainer(hp, w)
+    with pytest.raises(taco_amd._lib.TacoError):
+        tr.forward_backward(ids, L, mt[:, :11], lt[:, :11])          # T_out not a multiple of r
+    with pytest.raises(taco_amd._lib.TacoError):
+        big = np.zeros((3, hp.reduction_factor * (hp.max_iters + 1), hp.num_mels))
+        tr.forward_backward(ids, L, big, np.zeros((3, big.shape[1], hp.num_freq)))   # T_out / r > max_iters

@@ -213,4 +213,4 @@ def train_grads(w, hp, ids, lengths, mel_targets, linear_targets, loss_coeff=Non
     loss = add_loss(out["mel"], mt, out["linear"], lt, co, prioritize_loss, sample_rate)
     loss.backward()
     grads = {k: (t.grad.numpy() if t.grad is not None else None) for k, t in wt.items() if t.requires_grad}
-    return float(loss), grads, {k: v.detach().numpy() for k, v in out.items()}
+    return float(loss.detach()), grads, {k: v.detach().numpy() for k, v in out.items()}
