@@ -101,17 +101,26 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
   const bool kok = (k0 + i) < g.K, nok = (n0 + i) < g.N;
   wg_f32x16 acc;
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  int t = (g.T > 0) ? (m0 + kk) % g.T : 0;
-  for (int m = m0 + kk; m < m1; m += 2) {
-    float av = 0.f, bv = 0.f;
-    bool rok = true;
-    if (g.T > 0) { const int ts = t + shift; rok = (ts >= 0) && (ts < g.T); t += 2; while (t >= g.T) t -= g.T; }
-    if (kok && rok) {
-      const size_t xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift);
-      av = g.x[xr * g.ldx + k0 + i];
+  // WG_U row pairs per trip: all 2*WG_U loads are issued before the first MFMA (one memory round trip per trip, not per row pair)
+  constexpr int WG_U = 8;
+  for (int mb = m0 + kk; mb < m1; mb += 2 * WG_U) {
+    float av[WG_U], bv[WG_U];
+#pragma unroll
+    for (int u = 0; u < WG_U; ++u) {
+      const int m = mb + 2 * u;
+      av[u] = 0.f; bv[u] = 0.f;
+      if (m < m1) {
+        bool rok = true;
+        if (g.T > 0) { const int ts = m % g.T + shift; rok = (ts >= 0) && (ts < g.T); }
+        if (kok && rok) {
+          const size_t xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift);
+          av[u] = g.x[xr * g.ldx + k0 + i];
+        }
+        if (nok) bv[u] = g.dy[(size_t)m * g.ldy + n0 + i];
+      }
     }
-    if (nok) bv = g.dy[(size_t)m * g.ldy + n0 + i];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < WG_U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
   float* dw = g.dw + (size_t)tap * g.K * g.lddw;
   if (nok) {
@@ -322,18 +331,6 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in)
   }
 }
 
-// ---- attention backward, one workgroup per batch row (mirror of k_attention; recomputes the forward quantities) ----
-struct AttnBArgs {
-  const float* hq; const float* wq; const float* wqT;      // h_att(t) [B, ldhq]; query kernel [As, A] and its transpose [A, As]
-  const float* keys; const float* values; const float* v; const float* score_bias;
-  const float* alpha; const float* alpha_prev;             // tape rows [B, ldal]
-  const float* dctx;                                       // [B, lddctx] total gradient of context(t)
-  float* dalpha;        // [B, T_in] in: gradient of alpha(t) arriving from step t+1; out: gradient of alpha(t-1)
-  float* dkeys; float* dvalues;                            // accumulators [B, T_in, A] / [B, T_in, D]
-  float* dv_acc; float* dsb_acc;                           // per-row accumulators [B, A], [B]
-  float* dq; float* dhq;                                   // out [B, lddq]; in/out [B, lddhq]: += dq . Wq^T
-  int ldhq, ldal, lddctx, lddq, lddhq, T_in, A, D, As, type;
-};
 // inclusive wave64 SUFFIX sum (lane l gets sum over lanes >= l); never formed as total - prefix, which cancels
 // catastrophically when the tail is many orders of magnitude below the head (it is: the tail carries cumprod(1-p))
 __device__ __forceinline__ float wave_rscan(float x, int lane) {
@@ -344,38 +341,59 @@ __device__ __forceinline__ float wave_rscan(float x, int lane) {
   }
   return x;
 }
-#define ATB_NT 512
-__global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) {
+
+// ---- attention backward ----
+// In the BPTT loop only what the recurrence needs (k_attention_bwd, one 16-wave workgroup per batch row, the mirror of
+// k_attention): d alpha(t) = carry + dctx . V ; normaliser backward -> d e(t), d alpha(t-1) ; d q = sum_j de_j v (1-th^2) ;
+// d h_att += d q . Wq^T.  The forward saved q(t) and the raw scores e(t), so nothing is recomputed but tanh.
+// Everything that is a plain sum over steps is hoisted out of the loop: d values (a [T_in x n].[n x D] product per batch
+// row, k_wgrad), d keys and d attention_v (k_attention_keys_bwd, parallel over (row, position, channel)).
+struct AttnBArgs {
+  const float* q; const float* e;                          // tape: processed query [B, ldq], raw scores [B, lde] of step t
+  const float* wqT;                                        // query kernel transposed [A, As]
+  const float* keys; const float* values; const float* v; const float* score_bias;
+  const float* alpha; const float* alpha_prev;             // tape rows [B, ldal]
+  float* dctx;          // [B, lddctx] total gradient of context(t) (also copied to the tape slice dctx_out)
+  float* dctx_out;      // [B, lddco]
+  float* dalpha;        // [B, T_in] in: gradient of alpha(t) arriving from step t+1; out: gradient of alpha(t-1)
+  float* de_out;        // [B, ldde] tape: gradient of the raw scores of step t
+  float* dsb_acc;       // [B] per-row accumulator of d score_bias
+  float* dq; float* dhq;                                   // out [B, lddq]; in/out [B, lddhq]: += dq . Wq^T
+  int ldq, lde, ldal, lddctx, lddco, ldde, lddq, lddhq, T_in, A, D, As, type;
+};
+#define ATB_NW 16
+__global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a_in) {
   AttnBArgs a = a_in;
-  __shared__ float q[1024], dqv[1024], dcx[1024];     // A, D, As <= 1024 (host checks)
-  __shared__ float p[ATT_MAXT], cp[ATT_MAXT], ss[ATT_MAXT], da[ATT_MAXT], de[ATT_MAXT], w1[ATT_MAXT];
-  __shared__ float red[ATB_NT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NWV = ATB_NT / 64;
+  PIN(a.q); PIN(a.e); PIN(a.wqT); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.score_bias); PIN(a.alpha); PIN(a.alpha_prev);
+  PIN(a.dctx); PIN(a.dctx_out); PIN(a.dalpha); PIN(a.de_out); PIN(a.dsb_acc); PIN(a.dq); PIN(a.dhq);
+  // dynamic LDS (host: attn_bwd_lds_bytes): q[A4] dq[A4] dctx[D4] | p cp ss da de [T4 each] | red[ATB_NW*256]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int A4 = (a_in.A + 3) & ~3, D4 = (a_in.D + 3) & ~3, T4 = (a_in.T_in + 3) & ~3;
+  float* qs = smem; float* dqv = qs + A4; float* dcx = dqv + A4;
+  float* p = dcx + D4; float* cp = p + T4; float* ss = cp + T4; float* da = ss + T4; float* de = da + T4;
+  float* w1 = da;                      // d alpha_prev overwrites d alpha position by position (each is read before it is written)
+  float* red = de + T4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x, T = a.T_in, A = a.A, D = a.D, As = a.As;
-  const float* hq = a.hq + (size_t)b * a.ldhq;
   const float* krow = a.keys + (size_t)b * T * A;
   const float* vrow = a.values + (size_t)b * T * D;
   const float* al = a.alpha + (size_t)b * a.ldal;
   const float* alp = a.alpha_prev + (size_t)b * a.ldal;
-  // q = hq . Wq ; dctx row
-  for (int n2 = tid; n2 < A; n2 += ATB_NT) {
-    float s = 0.f;
-    for (int k = 0; k < As; ++k) s = fmaf(hq[k], a.wq[(size_t)k * A + n2], s);
-    q[n2] = s;
-  }
-  for (int d2 = tid; d2 < D; d2 += ATB_NT) dcx[d2] = a.dctx[(size_t)b * a.lddctx + d2];
+  for (int i = tid; i < A; i += 64 * ATB_NW) qs[i] = a.q[(size_t)b * a.ldq + i];
+  for (int i = tid; i < D; i += 64 * ATB_NW) { const float x = a.dctx[(size_t)b * a.lddctx + i]; dcx[i] = x; a.dctx_out[(size_t)b * a.lddco + i] = x; }
+  for (int j = tid; j < T; j += 64 * ATB_NW) de[j] = a.e[(size_t)b * a.lde + j];
   __syncthreads();
-  // scores e_j (kept in de[] for now) ; d alpha_j = carry + dctx . V_j ; dV_j += alpha_j * dctx
-  for (int j = wave; j < T; j += NWV) {
-    float se = 0.f, sd = 0.f;
-    for (int c = lane; c < A; c += 64) se += a.v[c] * tanhf(krow[(size_t)j * A + c] + q[c]);
-    const float aj = al[j];
-    for (int c = lane; c < D; c += 64) {
-      sd += dcx[c] * vrow[(size_t)j * D + c];
-      a.dvalues[((size_t)b * T + j) * D + c] += aj * dcx[c];
+  // d alpha_j = carry_j + dctx . V_j : one wave per position, lanes over channels (float4)
+  for (int j = wave; j < T; j += ATB_NW) {
+    float sd = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+      const float4 v4 = *reinterpret_cast<const float4*>(vrow + (size_t)j * D + c);
+      const float4 d4 = *reinterpret_cast<const float4*>(&dcx[c]);
+      sd += v4.x * d4.x + v4.y * d4.y + v4.z * d4.z + v4.w * d4.w;
     }
-    se = wave_sum(se); sd = wave_sum(sd);
-    if (lane == 0) { de[j] = se; da[j] = a.dalpha[(size_t)b * T + j] + sd; }
+    sd = wave_sum(sd);
+    if (lane == 0) da[j] = a.dalpha[(size_t)b * T + j] + sd;
   }
   __syncthreads();
   // normaliser backward (single wave, chunked scans like the forward)
@@ -408,12 +426,12 @@ __global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) 
       for (int j = j1 - 1; j >= j0; --j) {
         suffix += da[j] * p[j] * cp[j];             // rc_j
         const float cj = fminf(fmaxf(cp[j], 1e-10f), 1.f);
-        w1[j] = suffix / cj;                        // d alpha_prev_j
         float dcp = da[j] * p[j] * ss[j];
         if (cp[j] >= 1e-10f && cp[j] <= 1.f) dcp += -suffix * alp[j] / (cj * cj);
         const float dL = dcp * cp[j];
         ss[j] = da[j] * cp[j] * ss[j];              // dp_j (direct term); ss no longer needed as s
         cp[j] = dL;                                 // reuse: cp now holds dL
+        w1[j] = suffix / cj;                        // d alpha_prev_j (aliases da[j]: last use of da[j] is above)
         dLsum += dL;
       }
       float suf2 = wave_rscan(dLsum, lane) - dLsum; // sum of dL over later chunks
@@ -439,33 +457,99 @@ __global__ __launch_bounds__(ATB_NT) void k_attention_bwd(const AttnBArgs a_in) 
     }
   }
   __syncthreads();
-  // score backward: g = de_j * v_a * (1 - th^2): dq_a = sum_j g ; dkeys[j,a] += g ; dv_a += sum_j de_j * th
+  for (int j = tid; j < T; j += 64 * ATB_NW) a.de_out[(size_t)b * a.ldde + j] = de[j];
+  // d q_c = v_c * sum_j de_j * (1 - tanh^2(K_jc + q_c)) : 16 lanes per position (4 channels each per 64-channel stripe), like the forward
   {
-    const int NG = ATB_NT / 256;                     // j-groups (256 channels per pass)
+    const int l16 = lane & 15, grp = lane >> 4;
     for (int c0 = 0; c0 < A; c0 += 256) {
-      const int c = c0 + (tid & 255), grp = tid >> 8;
-      float sq = 0.f, sv = 0.f;
-      if (c < A) {
-        const float qc = q[c], vc = a.v[c];
-        for (int j = grp; j < T; j += NG) {
-          const float th = tanhf(krow[(size_t)j * A + c] + qc);
-          const float g = de[j] * vc * (1.f - th * th);
-          sq += g; sv += de[j] * th;
-          a.dkeys[((size_t)b * T + j) * A + c] += g;
+      float4 acc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = wave * 4 + grp; j < T; j += 4 * ATB_NW) {
+        const float dj = de[j];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int c = c0 + l16 * 4 + 64 * m;
+          if (c < A) {
+            const float4 k4 = *reinterpret_cast<const float4*>(krow + (size_t)j * A + c);
+            const float4 q4 = *reinterpret_cast<const float4*>(&qs[c]);
+            const float t0 = taco_tanh_fast(k4.x + q4.x), t1 = taco_tanh_fast(k4.y + q4.y), t2 = taco_tanh_fast(k4.z + q4.z), t3 = taco_tanh_fast(k4.w + q4.w);
+            acc[m].x += dj * (1.f - t0 * t0); acc[m].y += dj * (1.f - t1 * t1); acc[m].z += dj * (1.f - t2 * t2); acc[m].w += dj * (1.f - t3 * t3);
+          }
         }
       }
-      red[tid] = sq; __syncthreads();
-      if (tid < 256 && c < A) { float s = 0.f; for (int g2 = 0; g2 < NG; ++g2) s += red[g2 * 256 + tid]; dqv[c] = s; a.dq[(size_t)b * a.lddq + c] = s; }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {      // fold the 4 positions a wave works on at once
+        acc[m].x += __shfl_xor(acc[m].x, 16, 64); acc[m].x += __shfl_xor(acc[m].x, 32, 64);
+        acc[m].y += __shfl_xor(acc[m].y, 16, 64); acc[m].y += __shfl_xor(acc[m].y, 32, 64);
+        acc[m].z += __shfl_xor(acc[m].z, 16, 64); acc[m].z += __shfl_xor(acc[m].z, 32, 64);
+        acc[m].w += __shfl_xor(acc[m].w, 16, 64); acc[m].w += __shfl_xor(acc[m].w, 32, 64);
+        if (grp == 0) *reinterpret_cast<float4*>(&red[wave * 256 + l16 * 4 + 64 * m]) = acc[m];
+      }
       __syncthreads();
-      red[tid] = sv; __syncthreads();
-      if (tid < 256 && c < A) { float s = 0.f; for (int g2 = 0; g2 < NG; ++g2) s += red[g2 * 256 + tid]; a.dv_acc[(size_t)b * A + c] += s; }
+      if (tid < 256 && c0 + tid < A) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < ATB_NW; ++w) s += red[w * 256 + tid];
+        s *= a.v[c0 + tid];
+        dqv[c0 + tid] = s; a.dq[(size_t)b * a.lddq + c0 + tid] = s;
+      }
       __syncthreads();
     }
   }
-  // dhq += dq . Wq^T
-  for (int k = tid; k < As; k += ATB_NT) {
-    float s = 0.f;
-    for (int c = 0; c < A; ++c) s = fmaf(dqv[c], a.wqT[(size_t)c * As + k], s);
-    a.dhq[(size_t)b * a.lddhq + k] += s;
+  // dhq += dq . Wq^T : 4 columns per thread, K split over thread groups, reduced through LDS
+  {
+    const int NC = As >> 2;
+    int KS = (64 * ATB_NW) / NC; if (KS > A) KS = A; if (KS * As > ATB_NW * 256) KS = (ATB_NW * 256) / As; if (KS < 1) KS = 1;
+    const int kper = (A + KS - 1) / KS, cg = tid % NC, ks = tid / NC;
+    if (ks < KS) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* wp = reinterpret_cast<const float4*>(a.wqT) + cg;
+      const int k1 = min(A, (ks + 1) * kper);
+      for (int k = ks * kper; k < k1; ++k) {
+        const float4 w = wp[(size_t)k * NC]; const float xv = dqv[k];
+        acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(&red[(size_t)ks * As + 4 * cg]) = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < As; k += 64 * ATB_NW) {
+      float s = 0.f;
+      for (int k2 = 0; k2 < KS; ++k2) s += red[(size_t)k2 * As + k];
+      a.dhq[(size_t)b * a.lddhq + k] += s;
+    }
+  }
+}
+
+// hoisted out of the BPTT loop: dkeys[b,j,c] = v_c * sum_t de_t[j] * (1 - th^2), dv_c += sum_{b,j,t} de_t[j] * th,
+// th = tanh(keys[b,j,c] + q_t[b,c]).  Workgroup = 256 channels x ATK_J positions of one batch row, loop over the steps.
+#define ATK_J 8
+struct AttnKArgs { const float* keys; const float* q; const float* de; const float* v; float* dkeys; float* dv; int T_in, A, n; };
+__global__ __launch_bounds__(256) void k_attention_keys_bwd(const AttnKArgs a) {
+  __shared__ float sde[ATK_J];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.z, j0 = blockIdx.y * ATK_J, c = blockIdx.x * 256 + tid;
+  const bool cok = c < a.A;
+  float kv[ATK_J], ak[ATK_J], av = 0.f;
+#pragma unroll
+  for (int u = 0; u < ATK_J; ++u) { kv[u] = (cok && j0 + u < a.T_in) ? a.keys[((size_t)b * a.T_in + j0 + u) * a.A + c] : 0.f; ak[u] = 0.f; }
+  for (int t = 0; t < a.n; ++t) {
+    __syncthreads();
+    if (tid < ATK_J) sde[tid] = (j0 + tid < a.T_in) ? a.de[((size_t)b * a.n + t) * a.T_in + j0 + tid] : 0.f;
+    __syncthreads();
+    const float qc = cok ? a.q[((size_t)b * a.n + t) * a.A + c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < ATK_J; ++u) {
+      const float th = taco_tanh_fast(kv[u] + qc);
+      ak[u] += sde[u] * (1.f - th * th);
+      av += sde[u] * th;
+    }
+  }
+  if (cok) {
+    const float vc = a.v[c];
+#pragma unroll
+    for (int u = 0; u < ATK_J; ++u)
+      if (j0 + u < a.T_in) a.dkeys[((size_t)b * a.T_in + j0 + u) * a.A + c] = vc * ak[u];
+    atomicAdd(a.dv + c, av);
   }
 }

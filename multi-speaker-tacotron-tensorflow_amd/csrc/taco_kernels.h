@@ -889,6 +889,7 @@ struct AttnArgs {
   int T_in, A, D, type, step, n_steps, As, ldctx;   // ldctx: row stride of ctx (D, or D + speaker columns)
   const float* align_prev;  // training tape: previous alignments read from here (align is then write-only); null = align
   int ldalign, ldhq;        // row strides of align/align_prev and hq (0 = T_in / As)
+  float* q_out; float* e_out; int ldq_out, lde_out;   // training tape (nullable): processed query [B, A] and raw scores [B, T_in] of this step
 };
 
 #define ATT_NW 16    // waves per workgroup (1024 threads: more key/value loads and tanh evaluations in flight)
@@ -978,6 +979,7 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
         float sum = 0.f;
         for (int k2 = 0; k2 < KS; ++k2) sum += qpart[(size_t)k2 * a.A + n];
         cred[n] = sum;                                        // cred is free until the context phase
+        if (a.q_out) a.q_out[(size_t)b * a.ldq_out + n] = sum;
       }
       __syncthreads();
     }
@@ -1018,7 +1020,7 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
         float p = part[u];
         p += __shfl_xor(p, 8, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 1, 64);
         const int j = j0 + 4 * ATT_NW * u + wave * 4 + grp;
-        if (l16 == 0 && j < T) sc[j] = p;
+        if (l16 == 0 && j < T) { sc[j] = p; if (a.e_out) a.e_out[(size_t)b * a.lde_out + j] = p; }
       }
     }
     __syncthreads();
@@ -1102,7 +1104,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
   AttnArgs a = a_in;
   PIN(a.q); PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.battn); PIN(a.score_bias); PIN(a.manual); PIN(a.align);
   PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.A); PIN(a.D); PIN(a.type); PIN(a.step); PIN(a.n_steps); PIN(a.ldctx);
-  PIN(a.align_prev); PIN(a.ldalign); PIN(a.ldhq);
+  PIN(a.align_prev); PIN(a.ldalign); PIN(a.ldhq); PIN(a.q_out); PIN(a.e_out); PIN(a.ldq_out); PIN(a.lde_out);
   __shared__ float sc[ATT_MAXT];     // scores -> alignments
   __shared__ float tmp[ATT_MAXT];
   __shared__ float tmp2[ATT_MAXT];

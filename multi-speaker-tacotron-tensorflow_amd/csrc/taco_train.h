@@ -166,7 +166,11 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
 static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
                      int M, int T, int K, int N, int kw = 1, int padl = 0) {
   WgArgs g; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
-  g.kw = kw; g.padl = padl; g.rpb = 512;
+  g.kw = kw; g.padl = padl;
+  // rows per workgroup: enough workgroups to fill 256 CUs several times over, at least 64 rows each
+  { const long tiles = (long)cdiv(K, 64) * cdiv(N, 64) * kw; int rpb = 512;
+    while (rpb > 64 && tiles * cdiv(M, rpb) < 2048) rpb >>= 1;
+    g.rpb = rpb; }
   hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * cdiv(M, g.rpb)), dim3(256), 0, st, g);
   HIPCHK(hipGetLastError());
   return 0;
@@ -211,6 +215,7 @@ struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (
   // backward
   float *dkeys, *dvalues, *dv_acc, *dsb_acc, *dalpha, *dctx, *dctx_t, *dhA, *dh[4], *dht, *dhp, *tmp1, *tmp2, *do_[5];
   float *g_dgp[4], *g_dcp[4], *g_dgpA, *g_dcpA, *g_do0, *g_dq, *g_dz[4], *dpz, *dIn;
+  float *g_q, *g_e, *g_de, *g_dctx;   // attention tape: processed query, raw scores, their gradients' inputs
 };
 static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int n, DecTape& w) {
   const taco_hparams& hp = m->hp;
@@ -236,6 +241,7 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   w.g_dgpA = cv.f(R * 2 * As); w.g_dcpA = cv.f(R * As); w.g_do0 = cv.f(R * Hd); w.g_dq = cv.f(R * A);
   for (int i = 0; i < hp.dec_prenet_n; ++i) w.g_dz[i] = cv.f(R * hp.dec_prenet[i]);
   w.dpz = cv.f((size_t)B * W2); w.dIn = cv.f((size_t)B * W2);
+  w.g_q = cv.f(R * A); w.g_e = cv.f(R * T_in); w.g_de = cv.f(R * T_in); w.g_dctx = cv.f(R * D);
 }
 struct TrainWs {
   float* pre[4]; float* dpre[4];
@@ -479,6 +485,7 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
       a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v);
       a.score_bias = AP(m, m->att_sb); a.align = w.alpha + (size_t)(t + 1) * T_in; a.align_prev = w.alpha + (size_t)t * T_in; a.ldalign = ldal;
       a.hist = align_hist; a.ctx = w.ctx + (size_t)t * D; a.ldctx = n * D;
+      a.q_out = w.g_q + (size_t)t * A; a.ldq_out = n * A; a.e_out = w.g_e + (size_t)t * T_in; a.lde_out = n * T_in;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
       hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
       HIPCHK(hipGetLastError()); }
@@ -543,6 +550,8 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   HIPCHK(hipMemsetAsync(w.dctx, 0, (size_t)B * D * sizeof(float), st));
   HIPCHK(hipMemsetAsync(w.dhA, 0, (size_t)B * As * sizeof(float), st));
   for (int i = 0; i < L; ++i) HIPCHK(hipMemsetAsync(w.dh[i], 0, (size_t)B * Hd * sizeof(float), st));
+  const size_t attn_lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 5 * ((T_in + 3) & ~3) + ATB_NW * 256) * sizeof(float);
+  if (attn_lds > 160 * 1024 || (As % 4) || (D % 4) || (A % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the backward kernel");
   for (int t = n - 1; t >= 0; --t) {
     const size_t oh = (size_t)t * Hd, oa = (size_t)t * As;
     { SkJob j = sk_T(m, tp.frame_T, dmel + (size_t)t * rM, n * rM, w.do_[L], Hd); TRY(run_skinny(st, B, &j, 1)); }
@@ -557,11 +566,13 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, w.tmp1, As + D, B, As);
     hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * D), 0, st, w.dctx, D, w.tmp1 + As, As + D, B, D);
     { AttnBArgs a; memset(&a, 0, sizeof a);
-      a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.wqT = AP(m, tp.wqT); a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v);
-      a.score_bias = AP(m, m->att_sb); a.alpha = w.alpha + (size_t)(t + 1) * T_in; a.alpha_prev = w.alpha + (size_t)t * T_in; a.ldal = ldal;
-      a.dctx = w.dctx; a.lddctx = D; a.dalpha = w.dalpha; a.dkeys = w.dkeys; a.dvalues = w.dvalues; a.dv_acc = w.dv_acc; a.dsb_acc = w.dsb_acc;
+      a.q = w.g_q + (size_t)t * A; a.ldq = n * A; a.e = w.g_e + (size_t)t * T_in; a.lde = n * T_in; a.wqT = AP(m, tp.wqT);
+      a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.score_bias = AP(m, m->att_sb);
+      a.alpha = w.alpha + (size_t)(t + 1) * T_in; a.alpha_prev = w.alpha + (size_t)t * T_in; a.ldal = ldal;
+      a.dctx = w.dctx; a.lddctx = D; a.dctx_out = w.g_dctx + (size_t)t * D; a.lddco = n * D; a.dalpha = w.dalpha;
+      a.de_out = w.g_de + (size_t)t * T_in; a.ldde = n * T_in; a.dsb_acc = w.dsb_acc;
       a.dq = w.g_dq + (size_t)t * A; a.lddq = n * A; a.dhq = w.dhA; a.lddhq = As; a.T_in = T_in; a.A = A; a.D = D; a.As = As; a.type = hp.attention_type;
-      hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(ATB_NT), 0, st, a);
+      hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(64 * ATB_NW), attn_lds, st, a);
       HIPCHK(hipGetLastError()); }
     { const float* hprev = (t == 0) ? nullptr : w.hA + (size_t)(t - 1) * As;
       TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
@@ -600,7 +611,13 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     }
     TRY(run_colsum(st, w.g_dz[i], P, nullptr, 0, nullptr, nullptr, x.g(nm + "/bias"), nullptr, R, P, 0));
   }
-  TRY(run_colsum(st, w.dv_acc, A, nullptr, 0, nullptr, nullptr, x.g("attention/attention_v"), nullptr, B, A, 0));
+  { AttnKArgs k; k.keys = w.keys; k.q = w.g_q; k.de = w.g_de; k.v = AP(m, m->att_v); k.dkeys = w.dkeys; k.dv = x.g("attention/attention_v");
+    k.T_in = T_in; k.A = A; k.n = n;
+    hipLaunchKernelGGL(k_attention_keys_bwd, dim3(cdiv(A, 256), cdiv(T_in, ATK_J), B), dim3(256), 0, st, k);
+    HIPCHK(hipGetLastError()); }
+  for (int b = 0; b < B; ++b)    // d values[b] = alpha[b]^T . dctx[b]  ([T_in x n] . [n x D])
+    TRY(run_wgrad(st, w.alpha + ((size_t)b * (n + 1) + 1) * T_in, nullptr, T_in, w.g_dctx + (size_t)b * n * D, D,
+                  w.dvalues + (size_t)b * T_in * D, D, n, 0, T_in, D));
   if (hp.attention_type == 2) { hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, st, w.dsb_acc, B, x.g("attention/attention_score_bias")); HIPCHK(hipGetLastError()); }
   TRY(run_wgrad(st, enc_out, nullptr, D, w.dkeys, A, x.g("attention/memory_layer/kernel"), A, B * T_in, 0, D, A));
   TRY(run_dgrad(m, st, tp.mem_d, w.dkeys, A, B * T_in, 0, denc, D, w.dvalues, D));

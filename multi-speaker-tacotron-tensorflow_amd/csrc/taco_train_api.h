@@ -31,6 +31,7 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = t;
   return 0;
 }

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Train-step timing at config C4's per-GPU shard (B=32, T_in=128, T_out=512, r=4): forward with tape +
+loss + backward + gradient all-reduce (RCCL, when launched with torch.distributed.run) + clip/Adam + pack refresh.
+Prints one JSON line on rank 0.  Synthetic batch, random-init weights."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--t-in", type=int, default=128)
+    ap.add_argument("--t-out", type=int, default=512)
+    args = ap.parse_args()
+    import numpy as np, torch, taco_amd
+    from taco_amd import dist as D
+    rank, local_rank, world = D.env_rank()
+    torch.cuda.set_device(local_rank if world > 1 else 0)
+    dist = D.init_process_group("nccl") if world > 1 else None
+    dev = torch.device("cuda", torch.cuda.current_device())
+    hp = taco_amd.hparams.copy(max_iters=max(200, args.t_out // 4))
+    tr = taco_amd.Trainer(hp, taco_amd.weights.random_weights(hp, 1, seed=4321), device=str(dev))
+    rs = np.random.RandomState(77 + rank)
+    B, T_in, T_out = args.batch, args.t_in, args.t_out
+    ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32); ids[:, -1] = 1
+    lens = taco_amd.input_lengths_from_tokens(ids)
+    ids, lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
+    mt = torch.from_numpy(rs.rand(B, T_out, hp.num_mels).astype(np.float32)).to(dev)
+    lt = torch.from_numpy(rs.rand(B, T_out, hp.num_freq).astype(np.float32)).to(dev)
+    first = None
+    for _ in range(args.warmup):
+        _, l = tr.train_step(ids, lens, mt, lt)
+        first = float(l) if first is None else first
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(args.steps):
+        _, l = tr.train_step(ids, lens, mt, lt)
+    e1.record(); torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    wall = D.max_over_ranks(time.perf_counter() - t0, device=dev if dist is not None else "cpu")
+    # phase split on one more step
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record(); tr.forward_backward(ids, lens, mt, lt, backward=False); ev[1].record()
+    tr.forward_backward(ids, lens, mt, lt, backward=True); ev[2].record()
+    tr.adam.step(tr.grads); tr.refresh(); ev[3].record(); torch.cuda.synchronize()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
+            "n_gpus": world, "global_batch": world * B, "ms_per_step": wall / args.steps * 1e3,
+            "target_frames_per_s": world * B * T_out * args.steps / wall, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 shard: B=%d/GPU, T_in=%d, T_out=%d, r=%d, teacher-forced, batch-stat BN" % (B, T_in, T_out, hp.reduction_factor),
+                       "parallelism": "data-parallel x%d, one flat-bucket RCCL all-reduce of %d floats" % (world, tr.num_params)},
+            "phase_ms": {"forward_only": ev[0].elapsed_time(ev[1]), "forward_plus_backward": ev[1].elapsed_time(ev[2]),
+                         "adam_plus_refresh": ev[2].elapsed_time(ev[3])},
+            "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9}))
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
