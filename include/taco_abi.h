@@ -181,12 +181,14 @@ size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_ou
  * in place (UPDATE_OPS dependency, tacotron.py:334).  d_mel_targets [B,T_out,num_mels], d_linear_targets [B,T_out,num_freq],
  * T_out a multiple of r, T_out/r <= max_iters (helpers.py:44-48).  d_losses[4] = loss, mel_loss, linear_loss,
  * loss_without_coeff (nullable).  d_mel_out / d_linear_out / d_alignments ([B,T_in,T_out/r]) nullable.
- * d_grads (flat, overwritten) = d loss / d parameter; moving statistics get zero. */
+ * d_grads (flat, overwritten) = d loss / d parameter; moving statistics get zero.
+ * rnn_decoder_test_mode != 0 (helpers.py:63-64, the test model of train.py:158-166): the decoder is fed its own previous
+ * output instead of the target frame; forward/loss only (d_grads must be NULL). */
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
                                 const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
                                 const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate,
-                                float* d_losses, float* d_mel_out, float* d_linear_out, float* d_alignments, void* d_workspace,
-                                size_t workspace_bytes);
+                                float* d_losses, float* d_mel_out, float* d_linear_out, float* d_alignments,
+                                int rnn_decoder_test_mode, void* d_workspace, size_t workspace_bytes);
 
 /* Persistent (multi-workgroup, in-kernel synchronised) kernels bound every spin; if one ever expires it sets a
  * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;

@@ -450,7 +450,7 @@ static int gru_cell_train(const taco_model* m, hipStream_t st, const GruDec& g, 
   return 0;
 }
 static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, float* mel,
-                                 float* align_hist, const DecTape& w) {
+                                 float* align_hist, const DecTape& w, bool feed_back) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const taco_hparams& hp = m->hp;
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
@@ -468,7 +468,9 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
   HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
   const int Pl = hp.dec_prenet[np - 1];
   for (int t = 0; t < n; ++t) {
-    const float* frame = (t == 0) ? w.zero : teach + (size_t)(t - 1) * Mm; const int ldf = (t == 0) ? Mm : n * Mm;   // helpers.py:44,66,70-72
+    // helpers.py:44,66,70-72: previous teacher frame; rnn_decoder_test_mode (:63-64): last of the r frames the decoder just emitted
+    const float* frame = (t == 0) ? w.zero : (feed_back ? mel + (size_t)(t - 1) * rM + (rM - Mm) : teach + (size_t)(t - 1) * Mm);
+    const int ldf = (t == 0) ? Mm : (feed_back ? n * rM : n * Mm);
     const float* cprev = (t == 0) ? w.zero : w.ctx + (size_t)(t - 1) * D; const int ldcp = (t == 0) ? D : n * D;
     for (int i = 0; i < np; ++i) {
       const int P = hp.dec_prenet[i];
@@ -630,7 +632,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
 static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float* G, const int* ids, const int* lengths, const float* mel_tgt,
                                   const float* lin_tgt, const float* loss_coeff, int B, int T_in, int T_out, int prioritize_loss,
                                   int sample_rate, float* d_losses, float* mel_out, float* lin_out, float* align_out, void* ws, size_t ws_bytes,
-                                  bool do_backward) {
+                                  bool do_backward, bool feed_back) {
   taco_model* m = t->sm;
   const taco_hparams& hp = m->hp;
   const int r = hp.reduction_factor, Mm = hp.num_mels, F = hp.num_freq;
@@ -656,7 +658,8 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * n * Mm), 0, st, mel_tgt + (size_t)(r - 1) * Mm, r * Mm, w.teach, Mm, B * n, Mm);
   HIPCHK(hipGetLastError());
   float* mel = mel_out ? mel_out : w.mel; float* lin = lin_out ? lin_out : w.linear;
-  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec));
+  if (feed_back && do_backward) return fail(TACO_ERR_UNSUPPORTED, "rnn_decoder_test_mode is forward-only (the reference uses it for the test model's loss, train.py:158-166)");
+  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec, feed_back));
   TRY(cbhg_forward_train(x, m->post, t->tp.post, "post_cbhg", mel, B, T_out, nullptr, w.post));
   { GemmCall g; g.x = w.post.out; g.ldx = 2 * hp.post_rnn_size; g.M = Mp; g.out = lin; g.ldo = F; TRY(run_gemm(m, st, &m->linear, 1, false, g)); }
   // ---- loss (tacotron.py:274-302) ----

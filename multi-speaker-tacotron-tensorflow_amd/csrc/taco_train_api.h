@@ -73,11 +73,12 @@ size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_ou
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
                                 const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
                                 const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate, float* d_losses,
-                                float* d_mel_out, float* d_linear_out, float* d_alignments, void* d_workspace, size_t workspace_bytes) {
+                                float* d_mel_out, float* d_linear_out, float* d_alignments, int rnn_decoder_test_mode, void* d_workspace,
+                                size_t workspace_bytes) {
   if (!t || !d_params || !d_inputs || !d_input_lengths || !d_mel_targets || !d_linear_targets || !d_workspace)
     return fail(TACO_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->sm->device));
   return train_forward_backward(t, (hipStream_t)hip_stream, d_params, d_grads, d_inputs, d_input_lengths, d_mel_targets, d_linear_targets,
                                 d_loss_coeff, B, T_in, T_out, prioritize_loss, sample_rate, d_losses, d_mel_out, d_linear_out, d_alignments,
-                                d_workspace, workspace_bytes, d_grads != nullptr);
+                                d_workspace, workspace_bytes, d_grads != nullptr, rnn_decoder_test_mode != 0);
 }

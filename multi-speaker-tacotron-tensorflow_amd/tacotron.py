@@ -239,9 +239,8 @@ class Tacotron(object):
         and `run()` supplies the feed later."""
         is_training = linear_targets is not None                          # tacotron.py:26
         if is_training:
-            raise NotImplementedError(
-                "training forward/backward (teacher forcing helpers.py:35-67, add_loss, add_optimizer) is not built "
-                "yet in the HIP path -- see DESIGN.md 'what comes next'")
+            return self._initialize_training(inputs, input_lengths, num_speakers, speaker_id, mel_targets, linear_targets,
+                                             loss_coeff, rnn_decoder_test_mode, is_randomly_initialized, device)
         self.is_randomly_initialized = is_randomly_initialized
         self.num_speakers = num_speakers
         if self._handle is None:
@@ -253,6 +252,83 @@ class Tacotron(object):
         if inputs is not None:
             self.run()
         return self
+
+    # ---- training graph (tacotron.py:26,199-202,274-336; train.py:145-166,215-219) ----
+    def _initialize_training(self, inputs, input_lengths, num_speakers, speaker_id, mel_targets, linear_targets, loss_coeff,
+                             rnn_decoder_test_mode, is_randomly_initialized, device):
+        """`linear_targets` given => is_training (tacotron.py:26): batch-statistics BatchNorm, TacoTrainingHelper teacher forcing
+        (or, with rnn_decoder_test_mode, the decoder's own outputs fed back: the test model of train.py:158-166), decoder
+        steps = T_out / r.  The parameters move into a Trainer (one flat device buffer); add_loss() / add_optimizer() expose the
+        reference's attributes; train_step() is the sess.run of train.py:217-219."""
+        from .trainer import Trainer
+        if num_speakers > 1:
+            raise _lib.TacoError(_lib.TACO_ERR_UNSUPPORTED, "the training path supports single-speaker models only")
+        self.is_randomly_initialized = is_randomly_initialized
+        self.num_speakers = num_speakers
+        self.rnn_decoder_test_mode = bool(rnn_decoder_test_mode)
+        if getattr(self, "_trainer", None) is None:
+            w = self._weights if self._weights is not None else random_weights(self._hparams, num_speakers, seed=0)
+            dev = device or ("cuda:%d" % torch.cuda.current_device())
+            self._trainer = Trainer(self._hparams, w, device=dev, is_randomly_initialized=is_randomly_initialized)
+            self.device = self._trainer.device
+        self.inputs, self.speaker_id, self.input_lengths = inputs, speaker_id, input_lengths
+        self.loss_coeff, self.mel_targets, self.linear_targets = loss_coeff, mel_targets, linear_targets
+        self.mel_outputs = self.linear_outputs = self.alignments = None
+        self.loss = self.mel_loss = self.linear_loss = self.loss_without_coeff = None
+        if inputs is not None:
+            self._train_forward()
+        return self
+
+    def share_variables_with(self, other):
+        """train.py:158-159 builds the test model under reuse=True: same variables as the training model."""
+        self._trainer = other._trainer
+        return self
+
+    def _train_forward(self):
+        tr = self._trainer
+        losses = tr.forward_backward(self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff,
+                                     backward=False, keep_outputs=True, rnn_decoder_test_mode=self.rnn_decoder_test_mode)
+        self.mel_outputs, self.linear_outputs, self.alignments = tr.mel_outputs, tr.linear_outputs, tr.alignments
+        self._losses = losses.clone()
+        return self._losses
+
+    def add_loss(self):
+        """tacotron.py:274-302: sets loss, mel_loss, linear_loss, loss_without_coeff (device scalars) for the current feed."""
+        if getattr(self, "_trainer", None) is None:
+            raise RuntimeError("initialize(..., mel_targets, linear_targets) must be called first")
+        if self.inputs is not None:
+            l = self._losses if getattr(self, "_losses", None) is not None else self._train_forward()
+            self.loss, self.mel_loss, self.linear_loss, self.loss_without_coeff = l[0], l[1], l[2], l[3]
+        return self
+
+    def add_optimizer(self, global_step=0):
+        """tacotron.py:305-336: learning-rate schedule, Adam(beta1, beta2), clip_by_global_norm(1.0); `optimize` applies one update
+        to the current feed (with the BatchNorm moving-average updates it depends on, :334)."""
+        tr = self._trainer
+        tr.adam.global_step = int(global_step)
+        self.learning_rate = tr.learning_rate
+        self.optimize = lambda: self.train_step()
+        self.gradients = tr.grads
+        return self
+
+    def train_step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, loss_coeff=None):
+        """sess.run([global_step, loss_without_coeff, optimize]) of train.py:217-219 -> (global_step, loss_without_coeff)."""
+        if self.rnn_decoder_test_mode:
+            raise _lib.TacoError(_lib.TACO_ERR_UNSUPPORTED, "the rnn_decoder_test_mode model is forward-only (train.py:158-166 never optimises it)")
+        if inputs is not None:
+            self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff = \
+                inputs, input_lengths, mel_targets, linear_targets, loss_coeff
+        tr = self._trainer
+        step, lwc = tr.train_step(self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff)
+        l = tr.losses
+        self.loss, self.mel_loss, self.linear_loss, self.loss_without_coeff = l[0], l[1], l[2], l[3]
+        self.learning_rate = tr.learning_rate
+        self._losses = None
+        return step, lwc
+
+    def trained_weights(self):
+        """Current parameters as a dict (tf.train.Saver.save of train.py:242-244 -> weights.save_weights)."""
+        return self._trainer.get_weights()
 
     def get_dummy_feed_dict(self):
         """tacotron.py:338-343."""

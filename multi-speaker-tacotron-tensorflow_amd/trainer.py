@@ -88,7 +88,8 @@ class Trainer(object):
             _lib.check(self._lib.taco_train_refresh(self._h, _st(), _p(self.params)))
 
     # ---- one forward (+ backward) ----
-    def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False):
+    def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False,
+                         rnn_decoder_test_mode=False):
         """Fills self.grads (when backward) and returns the device tensor [4] = loss, mel_loss, linear_loss, loss_without_coeff."""
         dev = self.device
         ids = torch.as_tensor(np.asarray(inputs) if not torch.is_tensor(inputs) else inputs).to(dev, torch.int32).contiguous()
@@ -113,7 +114,7 @@ class Trainer(object):
             _lib.check(self._lib.taco_train_forward_backward(
                 self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(mt), _p(lt), _p(co),
                 B, T_in, T_out, int(bool(getattr(hp, "prioritize_loss", False))), int(getattr(hp, "sample_rate", 24000)), _p(self.losses),
-                _p(mel), _p(lin), _p(ali), _p(self._ws), self._ws.numel()))
+                _p(mel), _p(lin), _p(ali), int(bool(rnn_decoder_test_mode)), _p(self._ws), self._ws.numel()))
         self.mel_outputs, self.linear_outputs, self.alignments = mel, lin, ali
         return self.losses
 

@@ -171,3 +171,46 @@ def test_training_rejects_unsupported_configurations():
     with pytest.raises(taco_amd._lib.TacoError):
         big = np.zeros((3, hp.reduction_factor * (hp.max_iters + 1), hp.num_mels))
         tr.forward_backward(ids, L, big, np.zeros((3, big.shape[1], hp.num_freq)))   # T_out / r > max_iters
+
+
+def test_tacotron_training_surface_mirrors_train_py():
+    """train.py:145-166,215-219 through the model object: initialize(..., targets) + add_loss + add_optimizer, a test model
+    sharing the variables with rnn_decoder_test_mode, steps via train_step, then the trained weights drive the inference model."""
+    import torch
+    import taco_amd
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=21)
+    php = to_product_hp(hp)
+    model = taco_amd.create_model(php)
+    model.load_weights(w)
+    model.initialize(ids, L, 1, None, mel_targets=mt, linear_targets=lt, loss_coeff=co, is_randomly_initialized=True)
+    model.add_loss()
+    model.add_optimizer(0)
+    ref = O.forward(w, hp, ids, L, n_steps=mt.shape[1] // hp.reduction_factor, honor_stop=False,
+                    teacher_frames=mt[:, hp.reduction_factor - 1::hp.reduction_factor], training=True)
+    want = O.add_loss(ref["mel"], mt, ref["linear"], lt, co)
+    assert abs(float(model.loss) - want["loss"]) < 1e-5 and abs(float(model.loss_without_coeff) - want["loss_without_coeff"]) < 1e-5
+    assert maxabs(model.linear_outputs.cpu().numpy(), ref["linear"]) < 1e-4
+    assert abs(model.learning_rate - O.learning_rate(0)) < 1e-9
+    # the test model: same variables, decoder fed its own outputs (helpers.py:63-64); forward/loss only
+    test_model = taco_amd.create_model(php).share_variables_with(model)
+    test_model.initialize(ids, L, 1, None, mel_targets=mt, linear_targets=lt, loss_coeff=co, rnn_decoder_test_mode=True)
+    test_model.add_loss()
+    fb = O.forward(w, hp, ids, L, n_steps=mt.shape[1] // hp.reduction_factor, honor_stop=False, training=True)
+    assert maxabs(test_model.mel_outputs.cpu().numpy(), fb["mel"]) < 1e-4
+    assert abs(float(test_model.loss) - O.add_loss(fb["mel"], mt, fb["linear"], lt, co)["loss"]) < 1e-5
+    with pytest.raises(taco_amd._lib.TacoError):
+        test_model.train_step()
+    losses = []
+    for _ in range(5):
+        step, lwc = model.train_step(ids, L, mt, lt, co)
+        losses.append(float(lwc))
+    assert step == 5 and losses[-1] < losses[0]
+    # trained weights -> inference model
+    tw = model.trained_weights()
+    inf = taco_amd.create_model(php)
+    inf.load_weights(tw)
+    inf.initialize(None, None, 1, None)
+    lin, al = inf.run(inputs=ids, input_lengths=L, honor_stop=False)
+    torch.cuda.synchronize()
+    chk = O.forward(tw, hp, ids, L, honor_stop=False)
+    assert maxabs(lin.cpu().numpy(), chk["linear"]) < 1e-3
