@@ -118,9 +118,41 @@ class Trainer(object):
         self.mel_outputs, self.linear_outputs, self.alignments = mel, lin, ali
         return self.losses
 
+    def capture(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None):
+        """Record forward+backward for these shapes as ONE hipGraph over static input buffers (the ~6000 kernel launches
+        of a step become one graph launch).  Later train_step() calls with the same shapes copy into the static buffers and
+        replay.  Returns self."""
+        dev = self.device
+        cv = lambda x, dt: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous().clone()
+        self._g_in = [cv(inputs, torch.int32), cv(input_lengths, torch.int32), cv(mel_targets, torch.float32),
+                      cv(linear_targets, torch.float32), None if loss_coeff is None else cv(loss_coeff, torch.float32)]
+        with torch.cuda.device(dev):
+            self.forward_backward(*self._g_in)            # sizes the workspace outside the capture
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.forward_backward(*self._g_in)
+        return self
+
+    def _replay(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff):
+        src = [inputs, input_lengths, mel_targets, linear_targets, loss_coeff]
+        for dst, x in zip(self._g_in, src):
+            if dst is None or x is None:
+                if (dst is None) != (x is None):
+                    return False
+                continue
+            x = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+            if tuple(x.shape) != tuple(dst.shape):
+                return False
+            if x.data_ptr() != dst.data_ptr():
+                dst.copy_(x)
+        self._graph.replay()
+        return True
+
     def train_step(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None):
         """train.py:217-219: one fwd+bwd+update; returns (global_step, loss_without_coeff) like the reference's fetch."""
-        self.forward_backward(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, backward=True)
+        if not (getattr(self, "_graph", None) is not None and self._replay(inputs, input_lengths, mel_targets, linear_targets, loss_coeff)):
+            self.forward_backward(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, backward=True)
         allreduce_gradients(self.grads)          # no-op on one process; RCCL all-reduce of the flat bucket otherwise
         self.adam.step(self.grads)
         self.refresh()

@@ -214,3 +214,25 @@ def test_tacotron_training_surface_mirrors_train_py():
     torch.cuda.synchronize()
     chk = O.forward(tw, hp, ids, L, honor_stop=False)
     assert maxabs(lin.cpu().numpy(), chk["linear"]) < 1e-3
+
+
+def test_gradients_at_full_reference_widths():
+    """The reference's real layer widths (hparams.py:33-69: 256-wide embedding/attention/decoder, 16x128 and 8x256 conv banks,
+    1025 linear bins) on a short batch, so every kernel runs with its production tile shapes."""
+    import torch
+    hp = O.OracleHParams(max_iters=16)
+    w = O.init_weights(hp, 1, 41)
+    B, T_in, T_out = 4, 16, 32
+    ids, L = O.synthetic_inputs(B, T_in, 42, ragged=True)
+    rs = np.random.RandomState(43)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    co = rs.uniform(0.5, 1.5, size=B)
+    loss, g, out = TF.train_grads(w, hp, ids, L, mt, lt, co)
+    tr = _trainer(hp, w)
+    losses = tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 2e-5
+    assert maxabs(tr.mel_outputs.cpu().numpy(), out["mel"]) < 1e-4 and maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4
+    worst, gn = _grad_report(tr.grad_dict(), g)
+    assert worst[0][0] < 3e-3, worst[:5]
+    tr.close()

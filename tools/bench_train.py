@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--t-in", type=int, default=128)
     ap.add_argument("--t-out", type=int, default=512)
+    ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
     args = ap.parse_args()
     import numpy as np, torch, taco_amd
     from taco_amd import dist as D
@@ -30,6 +31,8 @@ def main():
     ids, lens = torch.from_numpy(ids).to(dev), torch.from_numpy(lens).to(dev)
     mt = torch.from_numpy(rs.rand(B, T_out, hp.num_mels).astype(np.float32)).to(dev)
     lt = torch.from_numpy(rs.rand(B, T_out, hp.num_freq).astype(np.float32)).to(dev)
+    if args.graph:
+        tr.capture(ids, lens, mt, lt)
     first = None
     for _ in range(args.warmup):
         _, l = tr.train_step(ids, lens, mt, lt)
@@ -54,7 +57,7 @@ def main():
         print(json.dumps({
             "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
             "n_gpus": world, "global_batch": world * B, "ms_per_step": wall / args.steps * 1e3,
-            "target_frames_per_s": world * B * T_out * args.steps / wall, "dtype": "f32", "data": "synthetic",
+            "target_frames_per_s": world * B * T_out * args.steps / wall, "dtype": "f32", "data": "synthetic", "launch": "hipGraph" if args.graph else "eager",
             "config": {"workload": "C4 shard: B=%d/GPU, T_in=%d, T_out=%d, r=%d, teacher-forced, batch-stat BN" % (B, T_in, T_out, hp.reduction_factor),
                        "parallelism": "data-parallel x%d, one flat-bucket RCCL all-reduce of %d floats" % (world, tr.num_params)},
             "phase_ms": {"forward_only": ev[0].elapsed_time(ev[1]), "forward_plus_backward": ev[1].elapsed_time(ev[2]),
