@@ -144,7 +144,7 @@ int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell
 int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
                       float* d_out_res, void* d_workspace, size_t workspace_bytes);
 
-/* ---- training-side entry points that need no backward pass (the backward itself is not built yet) ---- */
+/* ---- training-side entry points on flat buffers (loss, schedule, clip + Adam); forward/backward: taco_train_* below ---- */
 /* add_loss (tacotron.py:274-302).  d_mel_* [B,T,num_mels], d_lin_* [B,T,num_freq], d_loss_coeff [B] (nullable = 1).
  * d_losses[4] = loss, mel_loss, linear_loss, loss_without_coeff.  Workspace >= 64 KiB. */
 int taco_loss_f32(void* hip_stream, const float* d_mel_out, const float* d_mel_tgt, const float* d_lin_out,

@@ -1,4 +1,4 @@
-"""Training-side operators that exist so far (the backward pass K22 is NOT built yet):
+"""Training-side operators around the forward/backward of trainer.py:
 
 * `l1_losses`      -- Tacotron.add_loss (models/tacotron.py:274-302) on device tensors (HIP reduction kernels)
 * `FlatAdam`       -- Tacotron.add_optimizer's update (tacotron.py:305-336): LR schedule, clip_by_global_norm(1.0),
