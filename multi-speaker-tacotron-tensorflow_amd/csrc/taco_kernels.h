@@ -344,7 +344,7 @@ __device__ __forceinline__ void taco_split_bf16(float x, unsigned short& hi, uns
   lo = taco_bf16_rne(x - __uint_as_float((unsigned)hi << 16));
 }
 
-template <int WM, int WN, int TM, int TN, bool DUAL>
+template <int WM, int WN, int TM, int TN, bool DUAL, int GPI>
 __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -400,6 +400,32 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) 
     const int idx = tid + u * NTHR;
     if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), 4 * (idx % (TACO_KC / 4)));
   }
+  // B fragments (packed weights, straight from L2) are register double-buffered in groups of GPI k16 steps: the loads of
+  // the next group are issued before the GPI x 3 x TM x TN MFMAs of the current one, and the prefetch keeps running across
+  // the LDS re-staging at every 64-channel chunk.  GPI = 2 (~770 cycles of MFMA per group at 64x256 tiles vs ~700 cycles of L2
+  // latency) pays when the grid leaves one workgroup per CU anyway; GPI = 1 keeps 2 waves/SIMD for layers with many workgroups.
+  auto load_pair = [&](int c0, int ng, int pi, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
+                       uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+    const int j = pi / (ng / GPI), g0 = GPI * (pi - j * (ng / GPI));
+#pragma unroll
+    for (int h = 0; h < GPI; ++h) {
+      const int k16 = ((j * v.cin_pad16 + c0) >> 4) + g0 + h;
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        uh[h][tn] = z; ul[h][tn] = z;
+        if constexpr (DUAL) { uh2[h][tn] = z; ul2[h][tn] = z; }
+        if (ntile[tn] < v.NT) {
+          const size_t off = ((((size_t)ntile[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
+          uh[h][tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[h][tn] = *reinterpret_cast<const uint4*>(v.bl + off);
+          if constexpr (DUAL) { uh2[h][tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[h][tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
+        }
+      }
+    }
+  };
+  uint4 cbh[GPI][TN], cbl[GPI][TN], cbh2[GPI][DUAL ? TN : 1], cbl2[GPI][DUAL ? TN : 1];
+  uint4 nbh[GPI][TN], nbl[GPI][TN], nbh2[GPI][DUAL ? TN : 1], nbl2[GPI][DUAL ? TN : 1];
+  load_pair(0, min(TACO_KC, v.cin_pad16) >> 4, 0, cbh, cbl, cbh2, cbl2);
   for (int c0 = 0; c0 < v.cin_pad16; c0 += TACO_KC) {
     __syncthreads();
 #pragma unroll
@@ -422,62 +448,54 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) 
         if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), c0 + TACO_KC + 4 * (idx % (TACO_KC / 4)));
       }
     }
-    // B fragments are register double-buffered: the loads of iteration it+1 are issued before the MFMAs of
-    // iteration it (L2 latency ~700 cycles vs ~400 cycles of MFMA per iteration at 2-3 waves/SIMD)
-    const int ng = min(TACO_KC, v.cin_pad16 - c0) >> 4;
-    const int nit = v.kw * ng;
-    auto load_b = [&](int it, uint4 (&uh)[TN], uint4 (&ul)[TN], uint4 (&uh2)[DUAL ? TN : 1], uint4 (&ul2)[DUAL ? TN : 1]) {
-      const int j = it / ng, g = it - j * ng;
-      const int k16 = ((j * v.cin_pad16 + c0) >> 4) + g;
+    // (see the pair loop below)
+    const int ng = min(TACO_KC, v.cin_pad16 - c0) >> 4;          // even: cin_pad16 is a multiple of 32
+    const int npair = v.kw * (ng / GPI);
+    for (int pi = 0; pi < npair; ++pi) {
+      // prefetch the next pair of k16 groups -- of this chunk or, across the staging barriers, of the next one
+      {
+        int nc0 = c0, npi = pi + 1, nng = ng;
+        if (npi == npair) { nc0 = c0 + TACO_KC; npi = 0; nng = min(TACO_KC, v.cin_pad16 - nc0) >> 4; }
+        if (nc0 < v.cin_pad16) load_pair(nc0, nng, npi, nbh, nbl, nbh2, nbl2);
+      }
+      const int j = pi / (ng / GPI), g0 = GPI * (pi - j * (ng / GPI));
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        uh[tn] = z; ul[tn] = z;
-        if constexpr (DUAL) { uh2[tn] = z; ul2[tn] = z; }
-        if (ntile[tn] < v.NT) {
-          const size_t off = ((((size_t)ntile[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
-          uh[tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[tn] = *reinterpret_cast<const uint4*>(v.bl + off);
-          if constexpr (DUAL) { uh2[tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
+      for (int h = 0; h < GPI; ++h) {
+        const int g = g0 + h;
+        bf16x8 ah[TM], al[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          const int srow = (wm * TM + tm) * 32 + l31 + j;
+          const int off = srow * BF3_LDSW + 16 * g + 8 * lh;
+          uint4 xh = *reinterpret_cast<const uint4*>(thi + off), xl = *reinterpret_cast<const uint4*>(tlo + off);
+          const int tt = tloc[tm] + j - v.padl;   // SAME zero padding + batch-row boundary (A.2)
+          if (!((tt >= 0) && (tt < a.T))) { xh = make_uint4(0u, 0u, 0u, 0u); xl = xh; }
+          ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
         }
-      }
-    };
-    uint4 cbh[TN], cbl[TN], cbh2[DUAL ? TN : 1], cbl2[DUAL ? TN : 1];
-    uint4 nbh[TN], nbl[TN], nbh2[DUAL ? TN : 1], nbl2[DUAL ? TN : 1];
-    load_b(0, cbh, cbl, cbh2, cbl2);
-    for (int it = 0; it < nit; ++it) {
-      if (it + 1 < nit) load_b(it + 1, nbh, nbl, nbh2, nbl2);
-      const int j = it / ng, g = it - j * ng;
-      bf16x8 ah[TM], al[TM];
+        // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int srow = (wm * TM + tm) * 32 + l31 + j;
-        const int off = srow * BF3_LDSW + 16 * g + 8 * lh;
-        uint4 xh = *reinterpret_cast<const uint4*>(thi + off), xl = *reinterpret_cast<const uint4*>(tlo + off);
-        const int tt = tloc[tm] + j - v.padl;   // SAME zero padding + batch-row boundary (A.2)
-        if (!((tt >= 0) && (tt < a.T))) { xh = make_uint4(0u, 0u, 0u, 0u); xl = xh; }
-        ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
-      }
-      // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
+        for (int term = 0; term < 3; ++term)
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+          for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, cbh[tn]), bl = __builtin_bit_cast(bf16x8, cbl[tn]);
-            const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
-            const bf16x8 bb = (term == 1) ? bl : bh;
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
-            if constexpr (DUAL) {
-              const bf16x8 bh2 = __builtin_bit_cast(bf16x8, cbh2[tn]), bl2 = __builtin_bit_cast(bf16x8, cbl2[tn]);
-              acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn) {
+              const bf16x8 bh = __builtin_bit_cast(bf16x8, cbh[h][tn]), bl = __builtin_bit_cast(bf16x8, cbl[h][tn]);
+              const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
+              const bf16x8 bb = (term == 1) ? bl : bh;
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
+              if constexpr (DUAL) {
+                const bf16x8 bh2 = __builtin_bit_cast(bf16x8, cbh2[h][tn]), bl2 = __builtin_bit_cast(bf16x8, cbl2[h][tn]);
+                acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
+              }
             }
-          }
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        cbh[tn] = nbh[tn]; cbl[tn] = nbl[tn];
-        if constexpr (DUAL) { cbh2[tn] = nbh2[tn]; cbl2[tn] = nbl2[tn]; }
       }
+#pragma unroll
+      for (int h = 0; h < GPI; ++h)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          cbh[h][tn] = nbh[h][tn]; cbl[h][tn] = nbl[h][tn];
+          if constexpr (DUAL) { cbh2[h][tn] = nbh2[h][tn]; cbl2[h][tn] = nbl2[h][tn]; }
+        }
     }
   }
 
@@ -784,7 +802,7 @@ struct BigruRArgs {
   int B, T, H;
 };
 
-template <int R>
+template <int R, bool TAPE>
 __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BigruRArgs a = a_in;
@@ -810,7 +828,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
 #pragma unroll
   for (int e = 0; e < NE1; ++e) {
     const int o = tid + e * RP_NT, b = r0 + o / (2 * H);
-    Lg[e] = (a.gsave && a.lengths && o < R * 2 * H && b < B) ? a.lengths[b] : T;
+    Lg[e] = (TAPE && a.lengths && o < R * 2 * H && b < B) ? a.lengths[b] : T;
   }
   for (int s = 0; s < T; ++s) {
     // x-parts of this thread's outputs: requested now, consumed after the weight stream
@@ -840,7 +858,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
         const float sg = taco_sigmoid(rp_reduce(part, KS, R * 2 * H, o) + xg[e]);
         if (n < H) rhs[r * H + n] = sg * hs[r * H + n];
         else us[r * H + (n - H)] = sg;
-        if (a.gsave && s < Lg[e] && r0 + r < B) {
+        if (TAPE && s < Lg[e] && r0 + r < B) {
           const int t = d ? (Lg[e] - 1 - s) : s;
           a.gsave[((size_t)(r0 + r) * T + t) * 6 * H + d * 3 * H + n] = sg;
         }
@@ -863,7 +881,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
         const int t = (d && active) ? (Lr[e] - 1 - s) : s;
         if (active) hs[o] = hn;
         if (b < B) a.out[((size_t)b * T + t) * 2 * H + d * H + n] = active ? hn : 0.f;
-        if (a.gsave && active && b < B) a.gsave[((size_t)b * T + t) * 6 * H + d * 3 * H + 2 * H + n] = c;
+        if (TAPE && active && b < B) a.gsave[((size_t)b * T + t) * 6 * H + d * 3 * H + 2 * H + n] = c;
       }
     }
     __syncthreads();

@@ -232,7 +232,7 @@ static unsigned short bf16_rne_host(float x) {
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size_t* hi_out, size_t* lo_out, int* K16_out, int* cp16_out) {
-  const int cp16 = rup(cin, 16), K16 = kw * cp16 / 16, NT = cdiv(N, 32);
+  const int cp16 = rup(cin, 32), K16 = kw * cp16 / 16, NT = cdiv(N, 32);   // multiple of 32: k_gemm_bf3 walks k16 groups in pairs
   std::vector<unsigned short> hi((size_t)NT * K16 * 2 * 32 * 8, 0), lo(hi.size(), 0);
   for (int nt = 0; nt < NT; ++nt)
     for (int k16 = 0; k16 < K16; ++k16)
@@ -416,7 +416,7 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
 }
 
 template <int WM, int WN, int TM, int TN, bool DUAL>
-static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax) {
+static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax, int gpi = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const size_t lds = (size_t)2 * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
   GemmArgs aa = a;
@@ -424,7 +424,11 @@ static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   if (a.t_len > 0) { aa.tiles_per_b = cdiv(a.t_len, BM); gx = (a.M / a.T) * aa.tiles_per_b; }
   (void)kw_max;
   dim3 grid(gx, cdiv(Nmax, BN), nvar);
-  hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL>), grid, dim3(64 * WM * WN), lds, st, aa);
+  // prefetch depth: two k16 steps ahead when the grid leaves at most ~2 workgroups per CU (occupancy is grid-limited there)
+  // (measured: 64x256 tile of proj_1, 256 workgroups: 390 -> 330 us; highway / linear with 512-1280 workgroups get slower)
+  if (gpi == 0) gpi = (!DUAL && TN == 4 && (long)grid.x * grid.y * grid.z <= 320) ? 2 : 1;
+  if (gpi == 2) hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 2>), grid, dim3(64 * WM * WN), lds, st, aa);
+  else hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1>), grid, dim3(64 * WM * WN), lds, st, aa);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -597,8 +601,8 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
       a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
       a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T; a.H = H;
       const dim3 grid(2 * cdiv(B, R));
-      if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, grid, dim3(RP_NT), lds, st, a);
-      else hipLaunchKernelGGL(k_bigru_rows<1>, grid, dim3(RP_NT), lds, st, a);
+      if (R == 2) hipLaunchKernelGGL((k_bigru_rows<2, false>), grid, dim3(RP_NT), lds, st, a);
+      else hipLaunchKernelGGL((k_bigru_rows<1, false>), grid, dim3(RP_NT), lds, st, a);
       HIPCHK(hipGetLastError());
       return 0;
     }
@@ -1142,8 +1146,10 @@ int taco_model_finalize(taco_model* m) {
     v.bh2 = (const unsigned short*)AP(m, (size_t)v.bh2); v.bl2 = (const unsigned short*)AP(m, (size_t)v.bl2);
   }
   // persistent kernels carve up to the full 160 KiB of LDS
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   m->events.resize(192);
   for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));

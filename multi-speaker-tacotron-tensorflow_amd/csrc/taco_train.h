@@ -336,8 +336,8 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   BigruRArgs a; memset(&a, 0, sizeof a);
   a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
   a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H;
-  if (R == 2) hipLaunchKernelGGL(k_bigru_rows<2>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
-  else hipLaunchKernelGGL(k_bigru_rows<1>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  if (R == 2) hipLaunchKernelGGL((k_bigru_rows<2, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  else hipLaunchKernelGGL((k_bigru_rows<1, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
