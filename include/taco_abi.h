@@ -204,6 +204,9 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream
  * (fork/join by events, a parallel branch in the hipGraph) in chunks of max(on,16) decoder steps; 0 (default) =
  * strictly sequential, which measures faster on MI355X (profiles/README.md) */
+/* debug/test: 0 = run decoder prenet layer 1 as its own launch every step (default 1: folded into the previous step's
+ * frame-projection launch through composite weights; same function, rounding differs at the 1e-7 level) */
+int taco_debug_set_fuse_prenet(taco_model* m, int on);
 int taco_debug_set_overlap(taco_model* m, int on);
 
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */

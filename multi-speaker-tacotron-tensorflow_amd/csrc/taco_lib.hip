@@ -101,6 +101,8 @@ struct taco_model {
   GruDec att_gru;
   std::vector<GruDec> dec_gru;
   SkW query, concat_proj, frame_proj, lin_spk;   // lin_spk: speaker rows of the linear head ('simple')
+  SkW prenet1_next;   // decoder prenet layer 1 of step t+1 as a function of step t's [GRU-stack output | context] (frame projection folded in)
+  int fuse_prenet1 = 1;
   size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0, raw_wq = 0;
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
   std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
@@ -834,11 +836,15 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     else { frame = mel + (size_t)(t - 1) * rM + (rM - Mm); ldf = ldY; }
     // DecoderPrenetWrapper (rnn_wrappers.py:249,367-378): prenet(concat(frame, previous context))
     const float* cur = nullptr; int curd = 0;
+    // layer 1 of steps t >= 1 was already produced by step t-1's frame-projection launch (prenet1_next), unless frames are teacher-forced
+    const bool fuse_p1 = m->fuse_prenet1 && !teacher && np > 1;
     for (int i = 0; i < hp.dec_prenet_n; ++i) {
       const int ldo = (i == np - 1) ? ldz : hp.dec_prenet[i];
-      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, w.ctx, ldc, ACT_RELU, w.pz[0], ldo)
-                         : sk_linear(m, m->dec_prenet[i], cur, curd, curd, nullptr, 0, ACT_RELU, w.pz[i], ldo);
-      TRY(run_skinny(st, B, &j, 1));
+      if (!(i == 0 && fuse_p1 && t > 0)) {
+        SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, w.ctx, ldc, ACT_RELU, w.pz[0], ldo)
+                           : sk_linear(m, m->dec_prenet[i], cur, curd, curd, nullptr, 0, ACT_RELU, w.pz[i], ldo);
+        TRY(run_skinny(st, B, &j, 1));
+      }
       cur = w.pz[i]; curd = hp.dec_prenet[i];
     }
     // attention GRUCell (tacotron.py:127-130); 'simple': input = concat(prenet_out, speaker_embed) (rnn_wrappers.py:372-376)
@@ -860,9 +866,12 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     // residual GRU stack (tacotron.py:171-172)
     for (int i = 0; i < L; ++i) TRY(run_gru_cell(m, st, m->dec_gru[i], B, w.o[i], Hd, w.hd[i], w.rh, w.u, w.xc, w.o[i + 1]));
     // frame projection to r frames (tacotron.py:178-179), written straight into the mel buffer
-    { SkJob j = sk_linear(m, m->frame_proj, w.o[L], Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, ldY);
-      j.o2 = reinterpret_cast<float*>(w.nz + (size_t)t * B);
-      TRY(run_skinny(st, B, &j, 1)); }
+    { SkJob j[2];
+      j[0] = sk_linear(m, m->frame_proj, w.o[L], Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, ldY);
+      j[0].o2 = reinterpret_cast<float*>(w.nz + (size_t)t * B);
+      int nj = 1;
+      if (fuse_p1 && t + 1 < n) { j[1] = sk_linear(m, m->prenet1_next, w.o[L], Hd, Hd, w.ctx, ldc, ACT_RELU, w.pz[0], hp.dec_prenet[0]); nj = 2; }
+      TRY(run_skinny(st, B, j, nj)); }
     if (after_step) TRY((*after_step)(t));
     if (dbg) {
       float* d = dbg + (size_t)t * B * dbgw;
@@ -1095,6 +1104,28 @@ int taco_model_finalize(taco_model* m) {
   const int rM = hp.num_mels * hp.reduction_factor;
   m->frame_proj = pack_w16(m, T_(m, "decoder/frame_projection/kernel").data.data(), rM, 0, Hd, 0, rM, T_(m, "decoder/frame_projection/bias").data.data());
   m->skinny["decoder/frame_projection"] = m->frame_proj;
+  {  // prenet layer 1 of the NEXT step, fed with this step's outputs (helpers.py:31 feeds back the last of the r frames):
+     //   relu([frame, ctx] . W1 + b1), frame = o . Wf[:, rM-M:] + bf[rM-M:]   =>   relu([o, ctx] . [Wf_last . W1a ; W1b] + (b1 + bf_last . W1a))
+     // computed in the same launch as the frame projection: one dependent launch less per decoder step.
+    const int Mm = hp.num_mels, P0 = hp.dec_prenet[0];
+    const auto& Wf = T_(m, "decoder/frame_projection/kernel").data; const auto& bf = T_(m, "decoder/frame_projection/bias").data;
+    const auto& W1 = T_(m, "decoder/prenet/dense_1/kernel").data; const auto& b1 = T_(m, "decoder/prenet/dense_1/bias").data;
+    std::vector<float> Wc((size_t)(Hd + D) * P0), bc(P0);
+    for (int k = 0; k < Hd; ++k)
+      for (int q = 0; q < P0; ++q) {
+        double acc = 0;
+        for (int j = 0; j < Mm; ++j) acc += (double)Wf[(size_t)k * rM + (rM - Mm) + j] * (double)W1[(size_t)j * P0 + q];
+        Wc[(size_t)k * P0 + q] = (float)acc;
+      }
+    for (int k = 0; k < D; ++k)
+      for (int q = 0; q < P0; ++q) Wc[(size_t)(Hd + k) * P0 + q] = W1[(size_t)(Mm + k) * P0 + q];
+    for (int q = 0; q < P0; ++q) {
+      double acc = b1[q];
+      for (int j = 0; j < Mm; ++j) acc += (double)bf[(rM - Mm) + j] * (double)W1[(size_t)j * P0 + q];
+      bc[q] = (float)acc;
+    }
+    m->prenet1_next = pack_w16(m, Wc.data(), P0, 0, Hd + D, 0, P0, bc.data());
+  }
   {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
     std::vector<float> v = T_(m, "attention/attention_v").data;
     if (hp.attention_type == 1) {
@@ -1187,6 +1218,11 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   return 0;
 }
 
+int taco_debug_set_fuse_prenet(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->fuse_prenet1 = on ? 1 : 0;
+  return 0;
+}
 int taco_debug_set_overlap(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->overlap = on;

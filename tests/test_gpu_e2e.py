@@ -347,3 +347,24 @@ def test_plan_pool_lanes_are_independent_and_exact(mt, ns):
     _check(got[5], ref)
     m.check_device_errors()
     pool.close()
+
+
+@pytest.mark.parametrize("mt,ns", [("single", 1), ("simple", 3)])
+def test_prenet_layer_folded_into_frame_projection_is_the_same_function(mt, ns):
+    """Default: layer 1 of the decoder prenet of step t+1 comes out of step t's frame-projection launch (composite weights
+    Wf[:, last frame] . W1[frame rows]); with the fold switched off it is its own launch.  Same function up to rounding."""
+    ohp = tiny_hp(model_type=mt, speaker_embedding_size=4, max_iters=11) if ns > 1 else tiny_hp(max_iters=11)
+    w = O.init_weights(ohp, ns, 77)
+    ids, L = O.synthetic_inputs(5, 12, 78, ragged=True)
+    spk = (np.arange(5) % ns).astype(np.int32) if ns > 1 else None
+    m = build_model(ohp, w, num_speakers=ns)
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, honor_stop=False)
+    folded = _run(m, ids, L, spk, honor_stop=False)
+    _check(folded, ref)
+    m._plans.clear()
+    m._lib.taco_debug_set_fuse_prenet(m._handle, 0)
+    plain = _run(m, ids, L, spk, honor_stop=False)
+    _check(plain, ref)
+    for a, b in zip(folded, plain):
+        assert maxabs(a, b) < 2e-5
+    m._lib.taco_debug_set_fuse_prenet(m._handle, 1)
