@@ -17,16 +17,18 @@ from .weights import load_weights
 
 
 def get_most_recent_checkpoint(checkpoint_dir, checkpoint_step=None):
-    """synthesizer.py:289-299 analogue for `model.ckpt-<step>.safetensors` packs."""
+    """synthesizer.py:289-299: `model.ckpt-<step>.safetensors` packs written here, or the reference's own TensorFlow
+    checkpoints (`model.ckpt-<step>.index` + `.data-*`, read by tf_checkpoint.py without TensorFlow)."""
     if checkpoint_step is None:
-        paths = glob.glob(os.path.join(checkpoint_dir, "*.safetensors"))
+        paths = glob.glob(os.path.join(checkpoint_dir, "*.safetensors")) + glob.glob(os.path.join(checkpoint_dir, "model.ckpt-*.index"))
         if not paths:
             raise Exception(" [!] No checkpoint found in {}".format(checkpoint_dir))
         def step_of(p):
             m = re.search(r"ckpt-(\d+)", os.path.basename(p))
             return int(m.group(1)) if m else -1
         return max(paths, key=step_of)
-    return os.path.join(checkpoint_dir, "model.ckpt-{}.safetensors".format(checkpoint_step))
+    st = os.path.join(checkpoint_dir, "model.ckpt-{}.safetensors".format(checkpoint_step))
+    return st if os.path.exists(st) or not os.path.exists(st[:-len("safetensors")] + "index") else st[:-len("safetensors")] + "index"
 
 
 class Synthesizer(object):
@@ -47,7 +49,12 @@ class Synthesizer(object):
         self.hparams = hparams.copy()
         load_hparams(self.hparams, load_path)
         self.model = create_model(self.hparams)
-        self.model.load_weights(load_weights(checkpoint_path))
+        if checkpoint_path.endswith(".index") or os.path.exists(checkpoint_path + ".index"):      # a TensorFlow checkpoint of the reference
+            from .tf_checkpoint import import_tf_checkpoint
+            prefix = checkpoint_path[:-len(".index")] if checkpoint_path.endswith(".index") else checkpoint_path
+            self.model.load_weights(import_tf_checkpoint(prefix, self.hparams, num_speakers))
+        else:
+            self.model.load_weights(load_weights(checkpoint_path))
         self.model.initialize(None, None, self.num_speakers, None, device=device)   # placeholders (:39-52)
         return self
 

@@ -1,0 +1,404 @@
+"""TF1 checkpoint importer: `tf.train.Saver` V2 "tensor bundle" files -> canonical weight dict.
+
+Replaces `saver.restore(sess, checkpoint)` of synthesizer.py:66-67 / train.py:189-206 for models trained with the
+reference.  No TensorFlow needed: a bundle is
+  <prefix>.index                 a LevelDB-format table (tensorflow/core/lib/io/table): key = variable name,
+                                 value = BundleEntryProto {dtype, shape, shard_id, offset, size, crc32c}; key "" = header
+  <prefix>.data-SSSSS-of-NNNNN   raw little-endian tensor bytes
+TF writes these tables uncompressed; snappy-compressed blocks are rejected with a clear error.
+
+Variable names are matched by their stable suffixes and by SHAPE, not by the full tf.contrib wrapper scope strings, which
+differ between TF 1.x versions.  Weight layouts need no conversion: the canonical pack already uses TF's
+(dense [in,out]; conv1d [k,in,out]; GRUCell gates [in+n, 2n] with columns r|u and rows [x;h]).
+
+UNPINNED: no checkpoint written by real TensorFlow exists in this environment; the reader is tested against bundles
+produced by `write_checkpoint` below, which follows the same format description."""
+import os
+import re
+import struct
+
+import numpy as np
+
+_MAGIC = 0xdb4775248b80fb57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 4: np.uint8, 6: np.int8, 5: np.int16, 10: np.bool_, 19: np.float16}
+_DTYPE_IDS = {np.dtype(v).name: k for k, v in _DTYPES.items()}
+
+
+# ---- crc32c (Castagnoli), as masked by leveldb ----
+def _crc_table():
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+        tab.append(c)
+    return tab
+
+
+_CRC = _crc_table()
+
+
+def crc32c(data, crc=0):
+    c = crc ^ 0xFFFFFFFF
+    for b in data:
+        c = _CRC[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _mask(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+# ---- varints / protobuf ----
+def _varint(buf, pos):
+    out = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+
+
+def _put_varint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        if v:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _pb_fields(buf):
+    """Yields (field_number, wire_type, value) of one protobuf message."""
+    pos = 0
+    while pos < len(buf):
+        key, pos = _varint(buf, pos)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = buf[pos:pos + 8]; pos += 8
+        elif wt == 2:
+            n, pos = _varint(buf, pos)
+            v = buf[pos:pos + n]; pos += n
+        elif wt == 5:
+            v = buf[pos:pos + 4]; pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fn, wt, v
+
+
+def _parse_entry(buf):
+    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    for fn, wt, v in _pb_fields(buf):
+        if fn == 1:
+            e["dtype"] = v
+        elif fn == 2:
+            for f2, _, v2 in _pb_fields(v):
+                if f2 == 2:
+                    size = 0
+                    for f3, _, v3 in _pb_fields(v2):
+                        if f3 == 1:
+                            size = v3
+                    e["shape"].append(size)
+        elif fn == 3:
+            e["shard_id"] = v
+        elif fn == 4:
+            e["offset"] = v
+        elif fn == 5:
+            e["size"] = v
+        elif fn == 6:
+            e["crc32c"] = struct.unpack("<I", v)[0]
+        elif fn == 7:
+            e["sliced"] = True
+    return e
+
+
+# ---- LevelDB table ----
+def _read_block(buf, offset, size, verify):
+    body = buf[offset:offset + size]
+    ctype = buf[offset + size]
+    if verify:
+        stored = struct.unpack("<I", buf[offset + size + 1:offset + size + 5])[0]
+        if _mask(crc32c(buf[offset:offset + size + 1])) != stored:
+            raise IOError("checkpoint index: block checksum mismatch at offset %d" % offset)
+    if ctype != 0:
+        raise IOError("checkpoint index: compressed blocks (type %d) are not supported; TF's BundleWriter writes none" % ctype)
+    return body
+
+
+def _block_entries(block):
+    nrestarts = struct.unpack("<I", block[-4:])[0]
+    end = len(block) - 4 - 4 * nrestarts
+    pos, key = 0, b""
+    while pos < end:
+        shared, pos = _varint(block, pos)
+        non_shared, pos = _varint(block, pos)
+        vlen, pos = _varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]
+        pos += non_shared
+        yield key, block[pos:pos + vlen]
+        pos += vlen
+
+
+def read_index(path, verify=True):
+    """{variable name: entry dict} of a `<prefix>.index` file (+ key '' -> header bytes)."""
+    buf = open(path, "rb").read()
+    if len(buf) < 48 or struct.unpack("<Q", buf[-8:])[0] != _MAGIC:
+        raise IOError("%s is not a TensorFlow V2 checkpoint index (bad table magic)" % path)
+    footer = buf[-48:]
+    pos = 0
+    _, pos = _varint(footer, pos); _, pos = _varint(footer, pos)            # metaindex handle
+    ioff, pos = _varint(footer, pos); isz, pos = _varint(footer, pos)       # index handle
+    out = {}
+    for _, handle in _block_entries(_read_block(buf, ioff, isz, verify)):
+        boff, p2 = _varint(handle, 0)
+        bsz, _ = _varint(handle, p2)
+        for key, val in _block_entries(_read_block(buf, boff, bsz, verify)):
+            out[key.decode("utf-8")] = val if key == b"" else _parse_entry(val)
+    return out
+
+
+def read_checkpoint(prefix, verify=True, names=None):
+    """All (or the named) tensors of the bundle `<prefix>.index` + `<prefix>.data-*` as {name: ndarray}."""
+    idx = read_index(prefix + ".index", verify)
+    nshards = 1
+    for fn, _, v in _pb_fields(idx.get("", b"")):
+        if fn == 1:
+            nshards = v
+    shards = {}
+    out = {}
+    for name, e in idx.items():
+        if name == "" or (names is not None and name not in names):
+            continue
+        if e["sliced"]:
+            raise IOError("variable '%s' is stored in slices (partitioned variable): not supported" % name)
+        if e["dtype"] not in _DTYPES:
+            continue                                   # strings etc.: nothing the model needs
+        sid = e["shard_id"]
+        if sid not in shards:
+            shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb")
+        f = shards[sid]
+        f.seek(e["offset"])
+        raw = f.read(e["size"])
+        if verify and e["crc32c"] is not None and _mask(crc32c(raw)) != e["crc32c"]:
+            raise IOError("variable '%s': data checksum mismatch" % name)
+        out[name] = np.frombuffer(raw, dtype=np.dtype(_DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"]).copy()
+    for f in shards.values():
+        f.close()
+    return out
+
+
+def latest_checkpoint(directory):
+    """tf.train.latest_checkpoint / get_most_recent_checkpoint (utils/__init__.py): highest-step `model.ckpt-<n>` prefix."""
+    best = None
+    for fn in os.listdir(directory):
+        mo = re.match(r"(model\.ckpt-(\d+))\.index$", fn)
+        if mo and (best is None or int(mo.group(2)) > best[0]):
+            best = (int(mo.group(2)), os.path.join(directory, mo.group(1)))
+    return None if best is None else best[1]
+
+
+# ---- writer (tests, and exporting weights trained here for the reference to load) ----
+def _block(entries):
+    body = bytearray()
+    for key, val in entries:
+        body += _put_varint(0) + _put_varint(len(key)) + _put_varint(len(val)) + key + val
+    body += struct.pack("<I", 0) + struct.pack("<I", 1)        # one restart point at offset 0
+    return bytes(body)
+
+
+def _entry_proto(dtype_id, shape, offset, size, crc):
+    dims = b"".join(b"\x12" + _put_varint(len(d)) + d for d in (b"\x08" + _put_varint(int(s)) for s in shape))
+    msg = b"\x08" + _put_varint(dtype_id) + b"\x12" + _put_varint(len(dims)) + dims
+    msg += b"\x20" + _put_varint(offset) + b"\x28" + _put_varint(size) + b"\x35" + struct.pack("<I", crc)
+    return msg
+
+
+def write_checkpoint(prefix, tensors):
+    """Writes {name: array} as a single-shard V2 bundle (uncompressed table, one data block per 64 entries)."""
+    names = sorted(tensors)
+    data = bytearray()
+    entries = [(b"", b"\x08\x01\x1a\x02\x08\x01")]               # header: num_shards = 1, version { producer: 1 }
+    for n in names:
+        a = np.array(tensors[n], order="C")          # (ascontiguousarray would turn 0-d into 1-d)
+        raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
+        entries.append((n.encode("utf-8"), _entry_proto(_DTYPE_IDS[a.dtype.name], a.shape, len(data), len(raw), _mask(crc32c(raw)))))
+        data += raw
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+    out = bytearray()
+    index_entries = []
+
+    def put(block):
+        off = len(out)
+        trailer = b"\x00"
+        out.extend(block + trailer + struct.pack("<I", _mask(crc32c(block + trailer))))
+        return _put_varint(off) + _put_varint(len(block))
+
+    for i in range(0, len(entries), 64):
+        chunk = entries[i:i + 64]
+        index_entries.append((chunk[-1][0] + b"\x00", put(_block(chunk))))     # separator >= last key of the block
+    meta = put(_block([]))
+    index = put(_block(index_entries))
+    footer = meta + index
+    footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
+    out.extend(footer)
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+
+
+# ---- TF variable names -> canonical names ----
+def _strip(name):
+    for pre in ("model/inference/", "inference/"):
+        i = name.find(pre)
+        if i >= 0:
+            return name[i + len(pre):]
+    return name
+
+
+def _cbhg_rules(scope):
+    r = []
+    for kind, tfk in (("kernel", "conv1d/kernel"), ("bias", "conv1d/bias"), ("gamma", "batch_normalization/gamma"),
+                      ("beta", "batch_normalization/beta"), ("moving_mean", "batch_normalization/moving_mean"),
+                      ("moving_variance", "batch_normalization/moving_variance")):
+        r.append((re.compile(r"^%s/conv_bank/conv1d_(\d+)/%s$" % (scope, tfk)), scope + r"/conv_bank/conv1d_\1/" + kind))
+        r.append((re.compile(r"^%s/proj_(\d+)/%s$" % (scope, tfk)), scope + r"/proj_\1/" + kind))
+    r.append((re.compile(r"^%s/highway_(\d+)/([HT])/(kernel|bias)$" % scope), scope + r"/highway_\1/\2/\3"))
+    r.append((re.compile(r"^%s/bidirectional_rnn/(fw|bw)/gru_cell/(gates|candidate)/(kernel|bias)$" % scope), scope + r"/bigru/\1/\2/\3"))
+    r.append((re.compile(r"^%s/dense/(kernel|bias)$" % scope), scope + r"/dense/\1"))
+    return r
+
+
+def map_tf_names(tf_vars, spec):
+    """tf_vars {tf name: array}, spec [(canonical name, shape)] -> {canonical: array}.  Raises listing what is missing."""
+    want = dict(spec)
+    out = {}
+    rules = [(re.compile(r"^embedding$"), "embedding"), (re.compile(r"^speaker_embedding$"), "speaker_embedding"),
+             (re.compile(r"^prenet/dense_(\d+)/(kernel|bias)$"), r"prenet/dense_\1/\2"),
+             # get_embed tables of the speaker_embedding_size == 1 deepvoice variant (tacotron.py:52-66)
+             (re.compile(r"^before_highway$"), "spk/before_highway/table"), (re.compile(r"^encoder_rnn_init_state$"), "spk/encoder_rnn_init/table"),
+             (re.compile(r"^attention_rnn_init_state$"), "spk/attention_rnn_init/table"),
+             (re.compile(r"^decoder_rnn_init_states(\d+)$"), r"spk/decoder_rnn_init_\1/table"),
+             (re.compile(r"(^|/)memory_layer/kernel$"), "attention/memory_layer/kernel"),
+             (re.compile(r"/query_layer/kernel$"), "attention/query_layer/kernel"),
+             (re.compile(r"/attention_v$"), "attention/attention_v"), (re.compile(r"/attention_score_bias$"), "attention/attention_score_bias"),
+             (re.compile(r"/attention_g$"), "attention/attention_g"), (re.compile(r"/attention_b$"), "attention/attention_b"),
+             (re.compile(r"decoder.*/decoder_prenet/dense_(\d+)/(kernel|bias)$"), r"decoder/prenet/dense_\1/\2"),
+             (re.compile(r"decoder.*/cell_([1-9])/.*gru_cell/(gates|candidate)/(kernel|bias)$"), r"decoder/gru_\1/\2/\3"),
+             (re.compile(r"decoder.*/cell_0/.*gru_cell/(gates|candidate)/(kernel|bias)$"), r"decoder/attention_gru/\1/\2"),
+             ] + _cbhg_rules("encoder_cbhg") + _cbhg_rules("post_cbhg")
+    leftovers = {}
+    for tfn, arr in tf_vars.items():
+        n = _strip(tfn)
+        if n == "global_step" or re.search(r"/Adam(_1)?$|beta[12]_power$", n):
+            continue                                                     # optimizer slots
+        for rx, repl in rules:
+            mo = rx.search(n)
+            if mo:
+                out[mo.expand(repl)] = arr
+                break
+        else:
+            leftovers[n] = arr
+    # what is left is told apart by shape: the two output_projection_wrappers, the deepvoice dense layers, the linear head
+    def take(canon_kernel, canon_bias, pred):
+        if canon_kernel not in want or canon_kernel in out:
+            return
+        ks = want[canon_kernel]
+        for n, a in sorted(leftovers.items()):
+            if n.endswith("/kernel") and tuple(a.shape) == tuple(ks) and pred(n):
+                out[canon_kernel] = a
+                b = n[:-len("kernel")] + "bias"
+                if b in leftovers and canon_bias in want:
+                    out[canon_bias] = leftovers.pop(b)
+                del leftovers[n]
+                return
+    take("decoder/concat_projection/kernel", "decoder/concat_projection/bias", lambda n: "cell_0" in n and "output_projection" in n)
+    take("decoder/frame_projection/kernel", "decoder/frame_projection/bias", lambda n: n.startswith("decoder") and "output_projection" in n)
+    for i, nm in enumerate(["before_highway", "encoder_rnn_init", "attention_rnn_init", "decoder_rnn_init_1", "decoder_rnn_init_2",
+                            "decoder_rnn_init_3", "decoder_rnn_init_4"]):
+        tfd = "dense" if i == 0 else "dense_%d" % i                       # creation order, tacotron.py:71-79
+        take("spk/%s/kernel" % nm, "spk/%s/bias" % nm, lambda n, tfd=tfd: n == tfd + "/kernel")
+    take("linear/kernel", "linear/bias", lambda n: re.match(r"^dense(_\d+)?/kernel$", n) is not None)
+    missing = [k for k in want if k not in out]
+    bad = [k for k in want if k in out and tuple(np.shape(out[k])) != tuple(want[k])]
+    if missing or bad:
+        raise KeyError("TF checkpoint does not provide %s; wrong shapes for %s; unmatched TF variables: %s"
+                       % (missing[:8], [(k, np.shape(out[k]), want[k]) for k in bad[:4]], sorted(leftovers)[:8]))
+    return {k: np.asarray(out[k], np.float32) for k in want}
+
+
+def import_tf_checkpoint(prefix_or_dir, hparams, num_speakers=1, verify=True):
+    """Canonical weight dict (weights.weight_spec order) from a reference-trained checkpoint."""
+    from .weights import weight_spec
+    prefix = prefix_or_dir
+    if os.path.isdir(prefix_or_dir):
+        prefix = latest_checkpoint(prefix_or_dir)
+        if prefix is None:
+            raise IOError("no model.ckpt-<step>.index under %s" % prefix_or_dir)
+    return map_tf_names(read_checkpoint(prefix, verify), weight_spec(hparams, num_speakers))
+
+
+def tf_names_for(spec, attention_type="bah_mon"):
+    """Canonical spec -> the TF 1.4-era variable names the reference creates (App. B); used by the exporter and the tests."""
+    att = {"bah_mon": "bahdanau_monotonic_attention", "bah": "bahdanau_attention", "bah_norm": "bahdanau_attention"}[attention_type]
+    base = "decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/concat_output_and_attention_wrapper/attention_wrapper"
+    out = {}
+    spk_order = ["before_highway", "encoder_rnn_init", "attention_rnn_init", "decoder_rnn_init_1", "decoder_rnn_init_2"]
+    n_spk_dense = sum(1 for n, _ in spec if n.startswith("spk/") and n.endswith("/kernel"))
+    for name, _ in spec:
+        p = name.split("/")
+        if name in ("embedding", "speaker_embedding"):
+            t = name
+        elif p[0] == "prenet":
+            t = name
+        elif p[0] in ("encoder_cbhg", "post_cbhg"):
+            if p[1] in ("conv_bank",):
+                leaf = p[3]
+                t = "%s/conv_bank/%s/%s" % (p[0], p[2], ("conv1d/" + leaf) if leaf in ("kernel", "bias") else "batch_normalization/" + leaf)
+            elif p[1].startswith("proj_"):
+                leaf = p[2]
+                t = "%s/%s/%s" % (p[0], p[1], ("conv1d/" + leaf) if leaf in ("kernel", "bias") else "batch_normalization/" + leaf)
+            elif p[1] == "bigru":
+                t = "%s/bidirectional_rnn/%s/gru_cell/%s/%s" % (p[0], p[2], p[3], p[4])
+            else:
+                t = name
+        elif name == "attention/memory_layer/kernel":
+            t = "memory_layer/kernel"
+        elif p[0] == "attention":
+            t = "%s/%s/%s" % (base, att, "/".join(p[1:]))
+        elif p[:2] == ["decoder", "prenet"]:
+            t = "%s/decoder_prenet_wrapper/decoder_prenet/%s" % (base, "/".join(p[2:]))
+        elif p[:2] == ["decoder", "attention_gru"]:
+            t = "%s/decoder_prenet_wrapper/gru_cell/%s" % (base, "/".join(p[2:]))
+        elif p[:2] == ["decoder", "concat_projection"]:
+            t = "decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/" + p[2]
+        elif p[0] == "decoder" and p[1].startswith("gru_"):
+            t = "decoder/output_projection_wrapper/multi_rnn_cell/cell_%s/gru_cell/%s" % (p[1][4:], "/".join(p[2:]))
+        elif p[:2] == ["decoder", "frame_projection"]:
+            t = "decoder/output_projection_wrapper/" + p[2]
+        elif p[0] == "spk" and p[2] == "table":
+            t = {"before_highway": "before_highway", "encoder_rnn_init": "encoder_rnn_init_state",
+                 "attention_rnn_init": "attention_rnn_init_state"}.get(p[1]) or "decoder_rnn_init_states" + p[1].rsplit("_", 1)[1]
+        elif p[0] == "spk":
+            i = spk_order.index(p[1]) if p[1] in spk_order else int(p[1].rsplit("_", 1)[1]) + 2
+            t = ("dense" if i == 0 else "dense_%d" % i) + "/" + p[2]
+        elif p[0] == "linear":
+            t = ("dense" if n_spk_dense == 0 else "dense_%d" % n_spk_dense) + "/" + p[1]
+        else:
+            t = name
+        out[name] = "model/inference/" + t
+    return out
+
+
+def export_tf_checkpoint(prefix, weights, spec, attention_type="bah_mon", global_step=0):
+    """Writes canonical weights as a bundle with the reference's variable names (for `saver.restore` on the TF side)."""
+    names = tf_names_for(spec, attention_type)
+    tensors = {names[n]: np.asarray(weights[n], np.float32) for n, _ in spec}
+    tensors["global_step"] = np.asarray(global_step, np.int32)
+    write_checkpoint(prefix, tensors)

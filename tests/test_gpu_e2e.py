@@ -265,6 +265,23 @@ def test_synthesizer_surface(tmp_path):
     s.close()
 
 
+def test_synthesizer_loads_a_tensorflow_checkpoint_of_the_reference(tmp_path):
+    """synthesizer.py:66-67 `saver.restore`: a V2 bundle with the reference's variable names is read without TensorFlow."""
+    import taco_amd
+    from taco_amd import tf_checkpoint as T
+    ohp = tiny_hp()
+    w = O.init_weights(ohp, 1, 32)
+    hp = to_product_hp(ohp)
+    taco_amd.save_hparams(str(tmp_path), hp)
+    T.export_tf_checkpoint(str(tmp_path / "model.ckpt-7000"), w, taco_amd.weights.weight_spec(hp, 1), "bah_mon", 7000)
+    ids, L = O.synthetic_inputs(2, 9, 42)
+    s = taco_amd.Synthesizer().load(str(tmp_path), num_speakers=1)
+    lin, al = s.synthesize(tokens=ids)
+    ref = O.forward(w, ohp, ids, L)
+    assert maxabs(lin, ref["linear"]) < 2e-4 and maxabs(al, ref["alignments"]) < 2e-4
+    s.close()
+
+
 def test_full_size_C2_parity_and_properties():
     """BASELINE.json configs[1]: B=32, T_in=128, T_mel=512 at full widths against the float64 oracle."""
     B, T_in, r, n, ns, mt = O.CONFIGS["C2"]
