@@ -144,6 +144,12 @@ int taco_attention_step_f32(taco_model* m, void* hip_stream, const float* d_cell
 int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const float* d_x, float* d_h, int R,
                       float* d_out_res, void* d_workspace, size_t workspace_bytes);
 
+/* attention-based end-of-speech trimming (synthesizer.py:242-262, attention_trim && end_of_sentence): per batch row the number of
+ * spectrogram frames to keep, reduction_factor * j + 3, from the argmax walk over d_alignments [B, T_in, n_steps];
+ * d_seq_len[b] = len(sequence) of the row (tokens incl. EOS and padding, as the reference passes it).  d_spec_end [B]. */
+int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32_t* d_seq_len, int B, int T_in, int n_steps,
+                        int reduction_factor, int32_t* d_spec_end);
+
 /* ---- training-side entry points on flat buffers (loss, schedule, clip + Adam); forward/backward: taco_train_* below ---- */
 /* add_loss (tacotron.py:274-302).  d_mel_* [B,T,num_mels], d_lin_* [B,T,num_freq], d_loss_coeff [B] (nullable = 1).
  * d_losses[4] = loss, mel_loss, linear_loss, loss_without_coeff.  Workspace >= 64 KiB. */

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "taco_bigru_f32": (_I, [_P, _P, C.c_char_p, _P, _P, _P, _I, _I, _P, _P, _S]),
     "taco_attention_step_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _S]),
     "taco_gru_cell_f32": (_I, [_P, _P, C.c_char_p, _P, _P, _I, _P, _P, _S]),
+    "taco_attention_trim": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "taco_loss_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
     "taco_learning_rate": (C.c_float, [C.c_longlong, C.c_float, _I, _I]),
     "taco_adam_step_f32": (_I, [_P, _P, _P, _P, _P, _S, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _S]),

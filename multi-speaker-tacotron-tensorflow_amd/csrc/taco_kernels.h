@@ -1158,6 +1158,38 @@ __global__ void k_stop_step(const int* nz, int B, int n_steps, int* stop) {
   }
 }
 
+// attention-based trimming of the synthesised spectrogram (synthesizer.py:242-262, `attention_trim`): walk the per-step argmax of
+// the alignments until the attention has dwelt on the last attended input position; spec_end = r*j + 3.
+// One wave per batch row; align [B, T_in, n] (tacotron.py:238-239 layout), seq_len[b] = len(sequence) of the row.
+__global__ __launch_bounds__(64) void k_attention_trim(const float* align, const int* seq_len, int T_in, int n, int r, int* spec_end) {
+  extern __shared__ int amax[];          // [n] argmax over input positions of every decoder step
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* a = align + (size_t)b * T_in * n;
+  for (int t = lane; t < n; t += 64) {
+    float best = a[t]; int arg = 0;
+    for (int j = 1; j < T_in; ++j) { const float v = a[(size_t)j * n + t]; if (v > best) { best = v; arg = j; } }   // first maximum, like np.argmax
+    amax[t] = arg;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int mx = 0;
+    for (int t = 0; t < n; ++t) mx = max(mx, amax[t]);
+    const int end_idx = min(seq_len[b] - 1, mx);
+    int cnt = 0;
+    for (int t = 0; t < n; ++t) cnt += (amax[t] == end_idx);
+    const int max_counter = min(cnt, 5);
+    int counter = 0, jdx = 0;
+    for (jdx = 0; jdx < n; ++jdx) {
+      if (n > jdx + 1) {
+        if (amax[jdx] == end_idx) ++counter;
+        if (amax[jdx] == end_idx && amax[jdx + 1] > end_idx) break;
+        if (counter >= max_counter) break;
+      } else break;
+    }
+    spec_end[b] = r * jdx + 3;
+  }
+}
+
 // initial alignments (TF-sem: zeros for Bahdanau, one_hot(0) for BahdanauMonotonic)
 __global__ void k_init_align(float* al, int B, int T, int mono) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1218,6 +1218,16 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   return 0;
 }
 
+int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32_t* d_seq_len, int B, int T_in, int n_steps,
+                        int reduction_factor, int32_t* d_spec_end) {
+  if (!d_alignments || !d_seq_len || !d_spec_end || B <= 0 || T_in <= 0 || n_steps <= 0) return fail(TACO_ERR_ARG, "bad argument");
+  if ((size_t)n_steps * sizeof(int) > 64 * 1024) return fail(TACO_ERR_UNSUPPORTED, "more than 16384 decoder steps");
+  hipLaunchKernelGGL(k_attention_trim, dim3(B), dim3(64), (size_t)n_steps * sizeof(int), (hipStream_t)hip_stream, d_alignments, d_seq_len, T_in,
+                     n_steps, reduction_factor, d_spec_end);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int taco_debug_set_fuse_prenet(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->fuse_prenet1 = on ? 1 : 0;

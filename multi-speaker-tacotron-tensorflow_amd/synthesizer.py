@@ -103,4 +103,24 @@ class Synthesizer(object):
                 inputs=sequences.astype(np.int32), input_lengths=input_lengths, speaker_id=speaker_ids,
                 manual_alignments=new_alignments, is_manual_attention=True)
             linear, alignments = linear.cpu().numpy(), alignments.cpu().numpy()
+        # attention_trim (:242-262): frames to keep per utterance, from the argmax walk over the alignments (device kernel)
+        self.spec_end_idx = None
+        if attention_trim and end_of_sentence:
+            self.spec_end_idx = self.attention_trim_end(alignments, [len(seq) for seq in sequences])
         return linear, alignments
+
+    def attention_trim_end(self, alignments, sequence_lengths):
+        """spec_end_idx = reduction_factor * j + 3 per utterance (synthesizer.py:242-262); alignments [N, T_in, T_dec]."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        m = self.model
+        al = m._as_dev(alignments, torch.float32)
+        sl = m._as_dev(np.asarray(sequence_lengths, np.int32), torch.int32)
+        N, T_in, n = al.shape
+        out = torch.zeros((N,), dtype=torch.int32, device=al.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        with torch.cuda.device(al.device):
+            _lib.check(m._lib.taco_attention_trim(C.c_void_p(torch.cuda.current_stream().cuda_stream), p(al), p(sl), N, T_in, n,
+                                                  self.hparams.reduction_factor, p(out)))
+        return out.cpu().numpy()

@@ -630,6 +630,30 @@ def algorithmic_bytes(hp: OracleHParams, B, T_in, n, num_speakers=1):
 
 
 # ----------------------------------------------------------------------------------------
+# post-processing next to the path: attention-based trimming, synthesizer.py:242-262
+# ----------------------------------------------------------------------------------------
+
+def attention_trim_end(alignment, sequence_len, reduction_factor):
+    """alignment [T_in, T_dec] of one utterance -> spec_end_idx = r*jdx + 3 (the `attention_trim and end_of_sentence` branch)."""
+    end_idx_counter = 0
+    attention_argmax = alignment.argmax(0)
+    end_idx = min(sequence_len - 1, max(attention_argmax))
+    max_counter = min((attention_argmax == end_idx).sum(), 5)
+    jdx = 0
+    for jdx, attend_idx in enumerate(attention_argmax):
+        if len(attention_argmax) > jdx + 1:
+            if attend_idx == end_idx:
+                end_idx_counter += 1
+            if attend_idx == end_idx and attention_argmax[jdx + 1] > end_idx:
+                break
+            if end_idx_counter >= max_counter:
+                break
+        else:
+            break
+    return reduction_factor * jdx + 3
+
+
+# ----------------------------------------------------------------------------------------
 # training-side pieces that do not need a backward pass (tacotron.py:274-336)
 # ----------------------------------------------------------------------------------------
 

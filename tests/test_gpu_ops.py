@@ -259,3 +259,29 @@ def test_flat_adam_clip_lr_schedule(mode, rnd):
         assert abs(float(opt.gnorm.item()) - gn) < 1e-4 * gn
     assert np.abs(opt.params.cpu().numpy() - p).max() < 2e-6
     assert np.abs(opt.m.cpu().numpy() - m).max() < 1e-6 and np.abs(opt.v.cpu().numpy() - v).max() < 1e-6
+
+
+def test_attention_trim_matches_reference_walk():
+    """synthesizer.py:242-262 (attention_trim && end_of_sentence) as a device kernel vs its line-by-line restatement."""
+    import ctypes as C
+    import torch
+    import taco_amd
+    lib = taco_amd._lib.load_library()
+    rs = np.random.RandomState(3)
+    for case in range(6):
+        N, T_in, n, r = 5, 11 + case, 23 + 7 * case, 2 + case % 4
+        al = rs.rand(N, T_in, n).astype(np.float32) * 0.1
+        seq_len = rs.randint(3, T_in + 1, size=N).astype(np.int32)
+        for b in range(N):              # a mostly monotonic path, with dwell on the last symbol for some rows, ties and early stops for others
+            pos = np.minimum((np.arange(n) * (T_in + 3) // n), T_in - 1)
+            if b % 2:
+                pos = np.minimum(pos, seq_len[b] - 1)
+            if b == 3:
+                pos[:] = 0
+            al[b, pos, np.arange(n)] += 1.0
+        want = np.array([O.attention_trim_end(al[b], int(seq_len[b]), r) for b in range(N)])
+        ad, sd = dev(al), dev(seq_len)
+        out = torch.zeros(N, dtype=torch.int32, device="cuda")
+        taco_amd._lib.check(lib.taco_attention_trim(stream(), ptr(ad), ptr(sd), N, T_in, n, r, ptr(out)))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), (case, out.cpu().numpy(), want)
