@@ -150,6 +150,22 @@ int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const f
 int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32_t* d_seq_len, int B, int T_in, int n_steps,
                         int reduction_factor, int32_t* d_spec_end);
 
+/* ---- spectrogram -> waveform (audio/__init__.py:54-56,76-96,118-122,149-165; synthesizer.py:264) ---- */
+typedef struct {
+  int32_t num_freq, sample_rate, griffin_lim_iters;
+  float frame_length_ms, frame_shift_ms, preemphasis, min_level_db, ref_level_db, power;
+} taco_audio_hparams;                       /* hparams.py:16-23,144-145 */
+typedef struct taco_gl taco_gl;
+int taco_gl_create(const taco_audio_hparams* hp, int device, taco_gl** out);
+void taco_gl_destroy(taco_gl* g);
+int taco_gl_num_samples(const taco_gl* g, int T);            /* hop_length * (T - 1), librosa istft with center=True */
+size_t taco_gl_workspace_bytes(const taco_gl* g, int B, int T);
+/* inv_spectrogram of B utterances: d_spec [B, T, num_freq] in the model's linear_outputs layout (the reference transposes to
+ * [num_freq, T] first).  d_init_uniform [B, T, num_freq] in [0,1) plays np.random.rand of _griffin_lim (NULL: counter-based
+ * hash of `seed`).  iters < 0: griffin_lim_iters.  d_wav [B, taco_gl_num_samples(T)].  Needs hop*(T-1) > n_fft/2. */
+int taco_gl_inv_spectrogram(taco_gl* g, void* hip_stream, const float* d_spec, const float* d_init_uniform,
+                            unsigned long long seed, int B, int T, int iters, float* d_wav, void* d_workspace, size_t workspace_bytes);
+
 /* ---- training-side entry points on flat buffers (loss, schedule, clip + Adam); forward/backward: taco_train_* below ---- */
 /* add_loss (tacotron.py:274-302).  d_mel_* [B,T,num_mels], d_lin_* [B,T,num_freq], d_loss_coeff [B] (nullable = 1).
  * d_losses[4] = loss, mel_loss, linear_loss, loss_without_coeff.  Workspace >= 64 KiB. */

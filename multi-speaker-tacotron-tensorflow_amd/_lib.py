@@ -30,6 +30,12 @@ class TacoHParams(C.Structure):
     ]
 
 
+class TacoAudioHParams(C.Structure):
+    _fields_ = [("num_freq", C.c_int32), ("sample_rate", C.c_int32), ("griffin_lim_iters", C.c_int32),
+                ("frame_length_ms", C.c_float), ("frame_shift_ms", C.c_float), ("preemphasis", C.c_float),
+                ("min_level_db", C.c_float), ("ref_level_db", C.c_float), ("power", C.c_float)]
+
+
 class TacoError(Exception):
     """Raised for every non-zero return of the C ABI.  The reference raises bare `Exception`
     for unknown model/attention types and shape mismatches (tacotron.py:88,152,192-194)."""
@@ -107,6 +113,11 @@ PROTOTYPES = {
     "taco_bigru_f32": (_I, [_P, _P, C.c_char_p, _P, _P, _P, _I, _I, _P, _P, _S]),
     "taco_attention_step_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _S]),
     "taco_gru_cell_f32": (_I, [_P, _P, C.c_char_p, _P, _P, _I, _P, _P, _S]),
+    "taco_gl_create": (_I, [C.POINTER(TacoAudioHParams), _I, C.POINTER(_P)]),
+    "taco_gl_destroy": (None, [_P]),
+    "taco_gl_num_samples": (_I, [_P, _I]),
+    "taco_gl_workspace_bytes": (_S, [_P, _I, _I]),
+    "taco_gl_inv_spectrogram": (_I, [_P, _P, _P, _P, C.c_ulonglong, _I, _I, _I, _P, _P, _S]),
     "taco_attention_trim": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "taco_loss_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
     "taco_learning_rate": (C.c_float, [C.c_longlong, C.c_float, _I, _I]),

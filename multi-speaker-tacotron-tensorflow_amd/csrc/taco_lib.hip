@@ -982,6 +982,7 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
 // C ABI
 // ------------------------------------------------------------------------------------------------
 #include "taco_train.h"
+#include "taco_audio.h"
 
 extern "C" {
 
@@ -1523,5 +1524,6 @@ int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, 
 }
 
 #include "taco_train_api.h"
+#include "taco_audio_api.h"
 
 }  // extern "C"

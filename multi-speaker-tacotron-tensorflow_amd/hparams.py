@@ -57,6 +57,14 @@ basic_params = {
     'initial_learning_rate': 0.002,
     'decay_learning_rate_mode': 0,
     'prioritize_loss': False,
+    # audio keys of the spectrogram -> waveform step (hparams.py:16-23,144-145)
+    'frame_length_ms': 50,
+    'frame_shift_ms': 12.5,
+    'preemphasis': 0.97,
+    'min_level_db': -100,
+    'ref_level_db': 20,
+    'griffin_lim_iters': 60,
+    'power': 1.5,
 }
 
 MODEL_TYPES = {'single': 0, 'simple': 1, 'deepvoice': 2}

@@ -62,7 +62,7 @@ class Synthesizer(object):
                    start_of_sentence=None, end_of_sentence=True, pre_word_num=0, post_word_num=0,
                    pre_surplus_idx=0, post_surplus_idx=1, use_short_concat=False,
                    manual_attention_mode=0, base_alignment_path=None, librosa_trim=False,
-                   attention_trim=True, manual_alignments=None):
+                   attention_trim=True, manual_alignments=None, vocode=False):
         if type(texts) == str:
             texts = [texts]
         if texts is not None and tokens is None:
@@ -107,7 +107,27 @@ class Synthesizer(object):
         self.spec_end_idx = None
         if attention_trim and end_of_sentence:
             self.spec_end_idx = self.attention_trim_end(alignments, [len(seq) for seq in sequences])
+        # plot_graph_and_save_audio (:264): wav = wav[:spec_end_idx]; audio_out = inv_spectrogram(wav.T) -- on the GPU, whole batch at once
+        self.wavs = None
+        if vocode:
+            self.wavs = self.inv_spectrogram(linear, self.spec_end_idx)
         return linear, alignments
+
+    def inv_spectrogram(self, linear, spec_end_idx=None):
+        """audio/__init__.py:54-56 for a batch [N, T, num_freq]; returns a list of 1-D float32 arrays (each cut to the samples its
+        own frames produce when spec_end_idx is given: Griffin-Lim runs on the padded batch, frames past the end are silence-level)."""
+        from .audio import GriffinLim
+        if getattr(self, "_gl", None) is None:
+            self._gl = GriffinLim(self.hparams, device=str(self.model.device))
+        x = np.array(linear, np.float32, copy=True)
+        if spec_end_idx is not None:
+            for i, e in enumerate(spec_end_idx):
+                x[i, int(e):] = 0.0                       # normalised 0 = min_level_db: the reference would not have synthesised these frames
+        wav = self._gl.inv_spectrogram(x).cpu().numpy()
+        hop = self._gl.num_samples(2)
+        if spec_end_idx is None:
+            return [w for w in wav]
+        return [w[:hop * max(int(e) - 1, 1)] for w, e in zip(wav, spec_end_idx)]
 
     def attention_trim_end(self, alignments, sequence_lengths):
         """spec_end_idx = reduction_factor * j + 3 per utterance (synthesizer.py:242-262); alignments [N, T_in, T_dec]."""
