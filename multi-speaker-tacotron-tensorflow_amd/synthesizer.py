@@ -32,7 +32,9 @@ def get_most_recent_checkpoint(checkpoint_dir, checkpoint_step=None):
 
 
 class Synthesizer(object):
-    text_to_sequence = None   # optional callable text -> list of ids ending in EOS (text/__init__.py:23-58)
+    # text -> ids ending in EOS (text/__init__.py:23-58): jamo tokeniser of text.py; the reference's Korean number / abbreviation
+    # normaliser is not part of it -- assign a callable that includes one if the input needs it
+    text_to_sequence = None
 
     def close(self):
         if getattr(self, "model", None) is not None:
@@ -67,9 +69,13 @@ class Synthesizer(object):
             texts = [texts]
         if texts is not None and tokens is None:
             if self.text_to_sequence is None:
-                raise Exception("text front-end (text/__init__.py) is outside the accelerated path: pass tokens=, "
-                                "or set Synthesizer.text_to_sequence")
-            sequences = [self.text_to_sequence(text) for text in texts]
+                from .text import text_to_sequence as _t2s
+                sequences = [_t2s(text) for text in texts]
+            else:
+                sequences = [self.text_to_sequence(text) for text in texts]
+            if len(set(len(x) for x in sequences)) > 1:            # the reference needs equal lengths here (App. C); pad like the feeder
+                from .text import prepare_inputs
+                sequences = prepare_inputs(sequences)
         elif tokens is not None:
             sequences = tokens
         else:

@@ -1,0 +1,122 @@
+"""Input side of the path: text -> ids and the feeder's batch contract, host code.
+
+* symbols (text/korean.py:11-21, text/symbols.py): PAD '_' (0), EOS '~' (1), 19 lead + 21 vowel + 27 tail Hangul jamo
+  (U+1100.., U+1161.., U+11A8..), punctuation !'(),-.:;? and space = 80 symbols -- the `num_symbols` the embedding table has.
+* text_to_sequence (text/__init__.py:23-58): clean -> jamo decomposition -> ids of the symbols that exist -> EOS.  The Hangul
+  decomposition is the Unicode algorithm (syllable = 0xAC00 + (lead*21 + vowel)*28 + tail), which is what the `jamo` package
+  the reference imports does for precomposed syllables.
+* The reference's Korean *normaliser* (numbers, Latin letters, abbreviation dictionaries: text/korean.py:139-319,
+  ko_dictionary.py) is dictionary-driven text normalisation and stays out of scope; plug one in through `normalizer=`.
+  Characters that have no symbol are dropped, exactly as `_should_keep_symbol` does.
+* prepare_batch (datasets/datafeeder.py:289-328): inputs padded with 0 to the longest; targets padded with 0 to
+  round_up(longest + 1, reduction_factor); input_lengths = token count INCLUDING the EOS (the feeder's convention; the
+  synthesizer instead uses the index of the EOS, synthesizer.py:120)."""
+import re
+
+import numpy as np
+
+PAD, EOS = "_", "~"
+PUNC, SPACE = "!'(),-.:;?", " "
+JAMO_LEADS = "".join(chr(c) for c in range(0x1100, 0x1113))
+JAMO_VOWELS = "".join(chr(c) for c in range(0x1161, 0x1176))
+JAMO_TAILS = "".join(chr(c) for c in range(0x11A8, 0x11C3))
+symbols = PAD + EOS + JAMO_LEADS + JAMO_VOWELS + JAMO_TAILS + PUNC + SPACE
+_symbol_to_id = {s: i for i, s in enumerate(symbols)}
+_id_to_symbol = {i: s for i, s in enumerate(symbols)}
+_curly = re.compile(r"(.*?)\{(.+?)\}(.*)", re.S)
+_HANGUL0, _HANGUL1 = 0xAC00, 0xD7A3
+
+
+def hangul_to_jamo(text):
+    """Precomposed Hangul syllables -> (lead, vowel[, tail]) conjoining jamo; everything else unchanged."""
+    out = []
+    for ch in text:
+        c = ord(ch)
+        if _HANGUL0 <= c <= _HANGUL1:
+            i = c - _HANGUL0
+            out.append(chr(0x1100 + i // (21 * 28)))
+            out.append(chr(0x1161 + (i % (21 * 28)) // 28))
+            if i % 28:
+                out.append(chr(0x11A7 + i % 28))
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def jamo_to_korean(text):
+    """Recombine runs of lead + vowel (+ tail) into syllables (text/korean.py:54-88); anything else passes through."""
+    text = hangul_to_jamo(text)
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch in JAMO_LEADS and i + 1 < n and text[i + 1] in JAMO_VOWELS:
+            lead, vowel, tail = ord(ch) - 0x1100, ord(text[i + 1]) - 0x1161, 0
+            i += 2
+            if i < n and text[i] in JAMO_TAILS:
+                tail = ord(text[i]) - 0x11A7
+                i += 1
+            out.append(chr(_HANGUL0 + (lead * 21 + vowel) * 28 + tail))
+        else:
+            out.append(ch)
+            i += 1
+    return "".join(out)
+
+
+def _symbols_to_sequence(chars):
+    return [_symbol_to_id[s] for s in chars if s in _symbol_to_id and s != PAD and s != EOS]      # _should_keep_symbol
+
+
+def text_to_sequence(text, normalizer=None, as_token=False):
+    """ids (int32) of `text`, EOS appended.  `{...}` spans are ARPAbet in the reference; its Korean symbol table has no ARPAbet
+    entries, so their content maps to nothing."""
+    norm = (lambda s: s.strip()) if normalizer is None else normalizer
+    seq = []
+    while len(text):
+        m = _curly.match(text)
+        if not m:
+            seq += _symbols_to_sequence(hangul_to_jamo(norm(text)))
+            break
+        seq += _symbols_to_sequence(hangul_to_jamo(norm(m.group(1))))
+        text = m.group(3)
+    seq.append(_symbol_to_id[EOS])
+    if as_token:
+        return sequence_to_text(seq, combine_jamo=True)
+    return np.array(seq, dtype=np.int32)
+
+
+def sequence_to_text(sequence, skip_eos_and_pad=False, combine_jamo=False):
+    s = "".join(_id_to_symbol[int(i)] for i in sequence
+                if int(i) in _id_to_symbol and not (skip_eos_and_pad and _id_to_symbol[int(i)] in (EOS, PAD)))
+    return jamo_to_korean(s) if combine_jamo else s
+
+
+# ---- the feeder's batch contract (datasets/datafeeder.py:289-328) ----
+def _round_up(x, multiple):
+    r = x % multiple
+    return x if r == 0 else x + multiple - r
+
+
+def prepare_inputs(inputs):
+    n = max(len(x) for x in inputs)
+    return np.stack([np.pad(np.asarray(x), (0, n - len(x)), mode="constant", constant_values=0) for x in inputs])
+
+
+def prepare_targets(targets, alignment):
+    n = _round_up(max(len(t) for t in targets) + 1, alignment)
+    return np.stack([np.pad(np.asarray(t), [(0, n - len(t)), (0, 0)], mode="constant", constant_values=0) for t in targets])
+
+
+def prepare_batch(batch, reduction_factor, rng=None, data_type=None):
+    """batch: list of (input ids, loss_coeff, mel_target [T,M], linear_target [T,F][, speaker_id, n_frames]) ->
+    (inputs, input_lengths, loss_coeff, mel_targets, linear_targets[, speaker_id])."""
+    batch = list(batch)
+    if data_type == "train" and rng is not None:
+        rng.shuffle(batch)
+    inputs = prepare_inputs([x[0] for x in batch]).astype(np.int32)
+    input_lengths = np.asarray([len(x[0]) for x in batch], dtype=np.int32)
+    loss_coeff = np.asarray([x[1] for x in batch], dtype=np.float32)
+    mel = prepare_targets([x[2] for x in batch], reduction_factor).astype(np.float32)
+    lin = prepare_targets([x[3] for x in batch], reduction_factor).astype(np.float32)
+    if len(batch[0]) == 6:
+        return inputs, input_lengths, loss_coeff, mel, lin, np.asarray([x[4] for x in batch], dtype=np.int32)
+    return inputs, input_lengths, loss_coeff, mel, lin
