@@ -889,6 +889,208 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows(const BigruRArgs a_in) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_bigru_res : BiGRU scan with the recurrent weights RESIDENT on the CU
+// ------------------------------------------------------------------------------------------------
+// k_bigru_rows re-streams all recurrent weights of a direction (768 KB at H=256) from L2 every step, and one CU can take
+// 64 B/clk (~150 GB/s): 5.1 us of the 7.1 us step.  A CU has 512 KB of vector registers and 160 KB of LDS -- together
+// almost the whole matrix.  Here a 512-thread workgroup (2 waves/SIMD -> 256 VGPRs per thread) owns R batch rows of one
+// direction; thread (j, q) owns hidden unit j and the K-slice q of size KS = H*H/512; of its KS rows of the recurrent
+// kernels it keeps KR in registers (3 floats per row: r, u, c columns of unit j), KL in LDS, and streams the remaining
+// KG = KS-KR-KL from L2 every step (H=256: 58 / 22 / 48 of 128 -> 288 KB per step instead of 768; H=128: all 32 in
+// registers, nothing streamed).  No cross-workgroup synchronisation.  Weights: g2[k][j] = (Wg_h[k][j], Wg_h[k][H+j]),
+// c1[k][j] = Wc_h[k][j] (built at finalize).
+struct BigruSArgs {
+  const float* xproj;                      // [B*T, 6H] hoisted input projection (backward direction time-reversed)
+  const float2* g2_0; const float2* g2_1;  // [H, H] per direction
+  const float* c1_0; const float* c1_1;    // [H, H]
+  const float* h0; const int* lengths; float* out;
+  float* gsave;                            // training tape (TAPE only): [B*T, 6H] (r | u | c) per direction at the true time index
+  int B, T;
+};
+template <int H, int KR, int KL, int R, bool TAPE>
+__global__ __launch_bounds__(512) void k_bigru_res(const BigruSArgs a_in) {
+  constexpr int NT = 512, NQ = NT / H, KS = H / NQ, KG = KS - KR - KL, CH = 8;
+  static_assert(KG >= 0 && KG % CH == 0 && KR % 4 == 0, "K-slice split must come in groups of 4");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BigruSArgs a = a_in;
+  PIN(a.xproj); PIN(a.g2_0); PIN(a.g2_1); PIN(a.c1_0); PIN(a.c1_1); PIN(a.h0); PIN(a.lengths); PIN(a.out); PIN(a.gsave); PIN(a.B); PIN(a.T);
+  const int tid = threadIdx.x;
+  const int ngrp = (a.B + R - 1) / R;
+  const int d = blockIdx.x / ngrp, r0 = (blockIdx.x % ngrp) * R;
+  const int B = a.B, T = a.T;
+  const float2* G2 = d ? a.g2_1 : a.g2_0;
+  const float* C1 = d ? a.c1_1 : a.c1_0;
+  const int j = tid % H, q = tid / H, k0 = q * KS;
+  float* hs = smem;                      // [R][H] state
+  float* xs = hs + R * H;                // [R][H] r * h
+  float* us = xs + R * H;                // [R][H] u
+  float* part = us + R * H;              // [NQ][R][3][H] partial sums (r, u, c)
+  float2* wl_g = reinterpret_cast<float2*>(part + NQ * R * 3 * H);   // [KL][NQ][H]
+  float* wl_c = reinterpret_cast<float*>(wl_g + KL * NQ * H);        // [KL][NQ][H]
+  // ---- resident weights ----
+  float2 wg[KR > 0 ? KR : 1]; float wc[KR > 0 ? KR : 1];
+#pragma unroll
+  for (int i = 0; i < KR; ++i) { wg[i] = G2[(size_t)(k0 + i) * H + j]; wc[i] = C1[(size_t)(k0 + i) * H + j]; }
+  for (int i = 0; i < KL; ++i) {
+    wl_g[(i * NQ + q) * H + j] = G2[(size_t)(k0 + KR + i) * H + j];
+    wl_c[(i * NQ + q) * H + j] = C1[(size_t)(k0 + KR + i) * H + j];
+  }
+  const float2* Gs = G2 + (size_t)(k0 + KR + KL) * H + j;     // streamed rows of this thread
+  const float* Cs = C1 + (size_t)(k0 + KR + KL) * H + j;
+  for (int i = tid; i < R * H; i += NT) {
+    const int r = i / H, c = i % H, b = r0 + r;
+    hs[i] = (a.h0 && b < B) ? a.h0[(size_t)b * 2 * H + d * H + c] : 0.f;
+  }
+  // epilogue items of this thread: gates: e1 = tid + i*NT < R*2H ; candidate: e2 = tid + i*NT < R*H
+  constexpr int NE1 = (R * 2 * H + NT - 1) / NT, NE2 = (R * H + NT - 1) / NT;
+  int Lr[NE2];
+#pragma unroll
+  for (int e = 0; e < NE2; ++e) { const int o = tid + e * NT, b = r0 + o / H; Lr[e] = (a.lengths && o < R * H && b < B) ? a.lengths[b] : T; }
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < T; ++s) {
+    // x-parts of this thread's epilogue items: requested now, consumed after the mat-vec
+    float xg[NE1], xc[NE2];
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) {
+      const int o = tid + e * NT; xg[e] = 0.f;
+      if (o < R * 2 * H) { const int r = o / (2 * H), n = o % (2 * H), b = r0 + r; if (b < B) xg[e] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + n]; }
+    }
+#pragma unroll
+    for (int e = 0; e < NE2; ++e) {
+      const int o = tid + e * NT; xc[e] = 0.f;
+      if (o < R * H) { const int r = o / H, n = o % H, b = r0 + r; if (b < B) xc[e] = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + 2 * H + n]; }
+    }
+    // ---- gates: partial sums over this thread's K-slice ----
+    float ar[R], au[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ar[r] = 0.f; au[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      float4 h4[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) h4[r] = *reinterpret_cast<const float4*>(&hs[r * H + k0 + i]);
+      asm volatile("" ::: "memory");          // keeps the scheduler from hoisting every group's LDS reads to the top (register pressure)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        ar[r] = fmaf(h4[r].x, wg[i].x, ar[r]); au[r] = fmaf(h4[r].x, wg[i].y, au[r]);
+        ar[r] = fmaf(h4[r].y, wg[i + 1].x, ar[r]); au[r] = fmaf(h4[r].y, wg[i + 1].y, au[r]);
+        ar[r] = fmaf(h4[r].z, wg[i + 2].x, ar[r]); au[r] = fmaf(h4[r].z, wg[i + 2].y, au[r]);
+        ar[r] = fmaf(h4[r].w, wg[i + 3].x, ar[r]); au[r] = fmaf(h4[r].w, wg[i + 3].y, au[r]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; i += 2) {
+      const float2 w0 = wl_g[(i * NQ + q) * H + j], w1 = wl_g[((i + 1) * NQ + q) * H + j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float2 hv = *reinterpret_cast<const float2*>(&hs[r * H + k0 + KR + i]);
+        ar[r] = fmaf(hv.x, w0.x, ar[r]); au[r] = fmaf(hv.x, w0.y, au[r]);
+        ar[r] = fmaf(hv.y, w1.x, ar[r]); au[r] = fmaf(hv.y, w1.y, au[r]);
+      }
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float2 cur[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) cur[u] = Gs[(size_t)(c0 + u) * H];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int h4 = 0; h4 < CH; h4 += 4) {
+        const float4 hv = *reinterpret_cast<const float4*>(&hs[r * H + k0 + KR + KL + c0 + h4]);
+        ar[r] = fmaf(hv.x, cur[h4 + 0].x, ar[r]); au[r] = fmaf(hv.x, cur[h4 + 0].y, au[r]);
+        ar[r] = fmaf(hv.y, cur[h4 + 1].x, ar[r]); au[r] = fmaf(hv.y, cur[h4 + 1].y, au[r]);
+        ar[r] = fmaf(hv.z, cur[h4 + 2].x, ar[r]); au[r] = fmaf(hv.z, cur[h4 + 2].y, au[r]);
+        ar[r] = fmaf(hv.w, cur[h4 + 3].x, ar[r]); au[r] = fmaf(hv.w, cur[h4 + 3].y, au[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { part[((q * R + r) * 3 + 0) * H + j] = ar[r]; part[((q * R + r) * 3 + 1) * H + j] = au[r]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) {
+      const int o = tid + e * NT;
+      if (o < R * 2 * H) {
+        const int r = o / (2 * H), n = o % (2 * H), g = n / H, nn = n % H;
+        float sum = xg[e];
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) sum += part[((qq * R + r) * 3 + g) * H + nn];
+        const float sgm = taco_sigmoid(sum);
+        if (g == 0) xs[r * H + nn] = sgm * hs[r * H + nn]; else us[r * H + nn] = sgm;
+        if (TAPE) {
+          const int b = r0 + r, L = (a.lengths && b < B) ? a.lengths[b] : T;
+          if (b < B && s < L) a.gsave[((size_t)b * T + (d ? L - 1 - s : s)) * 6 * H + d * 3 * H + n] = sgm;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- candidate ----
+    float ac[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ac[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      float4 x4[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) x4[r] = *reinterpret_cast<const float4*>(&xs[r * H + k0 + i]);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        ac[r] = fmaf(x4[r].x, wc[i], ac[r]); ac[r] = fmaf(x4[r].y, wc[i + 1], ac[r]);
+        ac[r] = fmaf(x4[r].z, wc[i + 2], ac[r]); ac[r] = fmaf(x4[r].w, wc[i + 3], ac[r]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; i += 2) {
+      const float w0 = wl_c[(i * NQ + q) * H + j], w1 = wl_c[((i + 1) * NQ + q) * H + j];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const float2 xv = *reinterpret_cast<const float2*>(&xs[r * H + k0 + KR + i]);
+        ac[r] = fmaf(xv.x, w0, ac[r]); ac[r] = fmaf(xv.y, w1, ac[r]);
+      }
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float cur[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) cur[u] = Cs[(size_t)(c0 + u) * H];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int h4 = 0; h4 < CH; h4 += 4) {
+        const float4 xv = *reinterpret_cast<const float4*>(&xs[r * H + k0 + KR + KL + c0 + h4]);
+        ac[r] = fmaf(xv.x, cur[h4 + 0], ac[r]); ac[r] = fmaf(xv.y, cur[h4 + 1], ac[r]); ac[r] = fmaf(xv.z, cur[h4 + 2], ac[r]); ac[r] = fmaf(xv.w, cur[h4 + 3], ac[r]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) part[((q * R + r) * 3 + 2) * H + j] = ac[r];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE2; ++e) {
+      const int o = tid + e * NT;
+      if (o < R * H) {
+        const int r = o / H, n = o % H, b = r0 + r;
+        float sum = xc[e];
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) sum += part[((qq * R + r) * 3 + 2) * H + n];
+        const float c = tanhf(sum);
+        const float h = hs[o], u = us[o];
+        const float hn = u * h + (1.f - u) * c;
+        const bool active = s < Lr[e];                       // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+        const int t = (d && active) ? (Lr[e] - 1 - s) : s;
+        if (active) hs[o] = hn;
+        if (b < B) a.out[((size_t)b * T + t) * 2 * H + d * H + n] = active ? hn : 0.f;
+        if (TAPE && active && b < B) a.gsave[((size_t)b * T + t) * 6 * H + d * 3 * H + 2 * H + n] = c;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_attention : one workgroup per batch row
 // ------------------------------------------------------------------------------------------------
 struct AttnArgs {

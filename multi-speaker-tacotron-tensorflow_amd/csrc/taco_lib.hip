@@ -78,6 +78,7 @@ struct Cbhg {
   ConvL xproj;              // N = 2 directions x (2H gates | H candidate), biases folded in
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
+  size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
 };
 
 struct taco_model {
@@ -366,6 +367,10 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
     c.ch[dir] = pack_w16(m, ck.data(), H, I, H, 0, H, nullptr);
     c.raw_gh[dir] = arena_put(m, gk.data() + (size_t)I * 2 * H, (size_t)H * 2 * H);
     c.raw_ch[dir] = arena_put(m, ck.data() + (size_t)I * H, (size_t)H * H);
+    { std::vector<float> g2((size_t)H * H * 2);
+      for (int k = 0; k < H; ++k)
+        for (int j = 0; j < H; ++j) { g2[((size_t)k * H + j) * 2] = gk[(size_t)(I + k) * 2 * H + j]; g2[((size_t)k * H + j) * 2 + 1] = gk[(size_t)(I + k) * 2 * H + H + j]; }
+      c.res_g2[dir] = arena_put(m, g2.data(), g2.size()); }
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
@@ -590,15 +595,31 @@ static bool bigru_rows_cfg(int B, int H, int* R_out, size_t* lds_out) {
   return false;
 }
 
+static size_t bigru_res_lds(int H, int KL, int R) {
+  const int NQ = 512 / H;
+  return ((size_t)3 * R * H + (size_t)NQ * R * 3 * H) * sizeof(float) + (size_t)KL * NQ * H * 3 * sizeof(float);
+}
+
 // BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
 // directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
 // directions side by side in each launch.  x [B*T, rnn], out [B*T, 2*rnn].
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
+  if (m->persist == 1 && (H == 256 || H == 128)) {
+    // weights resident on the CU (registers + LDS), one batch row per workgroup: no re-streaming of the recurrent kernels
+    BigruSArgs a; memset(&a, 0, sizeof a);
+    a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
+    a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T;
+    const dim3 grid(2 * B);
+    if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, false>), grid, dim3(512), bigru_res_lds(256, 24, 1), st, a);
+    else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, false>), grid, dim3(512), bigru_res_lds(128, 0, 1), st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   {  // row-parallel persistent kernel: the whole scan in one launch, weights streamed from L2 every step
     int R = 0; size_t lds = 0;
-    if (m->persist && bigru_rows_cfg(B, H, &R, &lds)) {
+    if (m->persist && bigru_rows_cfg(B, H, &R, &lds)) {   // persist == 2: this kernel even where the resident one applies (A/B tests)
       BigruRArgs a; memset(&a, 0, sizeof a);
       a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
       a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T; a.H = H;
@@ -1178,6 +1199,10 @@ int taco_model_finalize(taco_model* m) {
     v.bh2 = (const unsigned short*)AP(m, (size_t)v.bh2); v.bl2 = (const unsigned short*)AP(m, (size_t)v.bl2);
   }
   // persistent kernels carve up to the full 160 KiB of LDS
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<256, 64, 24, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<128, 32, 0, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<256, 64, 24, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<128, 32, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

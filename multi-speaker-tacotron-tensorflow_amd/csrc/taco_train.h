@@ -330,14 +330,22 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   const int H = c.rnn;
   { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
-  int R = 0; size_t lds = 0;
-  if (!bigru_rows_cfg(B, H, &R, &lds)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the row-parallel BiGRU kernel", H);
   HIPCHK(hipMemsetAsync(w.gsave, 0, (size_t)M * 6 * H * sizeof(float), st));
-  BigruRArgs a; memset(&a, 0, sizeof a);
-  a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
-  a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H;
-  if (R == 2) hipLaunchKernelGGL((k_bigru_rows<2, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
-  else hipLaunchKernelGGL((k_bigru_rows<1, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res), gates saved for the backward scan
+    BigruSArgs a; memset(&a, 0, sizeof a);
+    a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
+    a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T;
+    if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(256, 24, 1), st, a);
+    else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(128, 0, 1), st, a);
+  } else {
+    int R = 0; size_t lds = 0;
+    if (!bigru_rows_cfg(B, H, &R, &lds)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the row-parallel BiGRU kernel", H);
+    BigruRArgs a; memset(&a, 0, sizeof a);
+    a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
+    a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H;
+    if (R == 2) hipLaunchKernelGGL((k_bigru_rows<2, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+    else hipLaunchKernelGGL((k_bigru_rows<1, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

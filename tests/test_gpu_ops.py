@@ -134,16 +134,20 @@ def test_bigru_with_lengths_and_init_state(ctx, B, persist):
     m.check_device_errors()
 
 
-def test_bigru_persistent_full_width_repeatable():
-    """Full-width post-net BiGRU (H=256, 4 rows per workgroup), T=64, run three times: results must
-    match the oracle and be bit-identical run to run."""
+@pytest.mark.parametrize("persist", [1, 2])
+@pytest.mark.parametrize("B", [32, 5])
+def test_bigru_persistent_full_width_repeatable(persist, B):
+    """Full-width BiGRUs, T=64, three runs: results must match the oracle and be bit-identical run to run.
+    persist=1: k_bigru_res (recurrent weights resident in registers + LDS, one row per workgroup);
+    persist=2: k_bigru_rows (weights re-streamed from L2 every step)."""
     import torch
     import taco_amd
     ohp = O.OracleHParams(max_iters=4)
     w = O.init_weights(ohp, 1, 11)
     m = build_model(ohp, w)
+    m._lib.taco_debug_set_persistent(m._handle, persist)
     rs = np.random.RandomState(12)
-    B, T, H = 32, 64, ohp.post_rnn_size
+    T, H = 64, ohp.post_rnn_size
     x = rs.randn(B, T, H) * 0.5
     ref = O.bidirectional_gru(x, None, w, "post_cbhg/bigru")
     xd = dev(x, torch.float32)
@@ -159,17 +163,19 @@ def test_bigru_persistent_full_width_repeatable():
     m.check_device_errors()
     assert maxabs(outs[0], ref) < 1e-4
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
-    # encoder flavour with ragged lengths
+    # encoder flavour with ragged lengths and an initial state (deepvoice encoder_rnn_init, modules.py:82-86)
     He = ohp.enc_rnn_size
     xe = rs.randn(B, T, He) * 0.5
-    lens = rs.randint(1, T + 1, size=B).astype(np.int32)
-    xed, ld = dev(xe, torch.float32), dev(lens)
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32)
+    lens[0] = T
+    init = rs.randn(B, 2 * He) * 0.5
+    xed, ld, idv = dev(xe, torch.float32), dev(lens), dev(init, torch.float32)
     oute = torch.full((B, T, 2 * He), float("nan"), device="cuda")
-    taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(xed), ptr(ld), ptr(None), B, T,
+    taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(xed), ptr(ld), ptr(idv), B, T,
                                               ptr(oute), ptr(ws), n))
     torch.cuda.synchronize()
     m.check_device_errors()
-    assert maxabs(oute.cpu().numpy(), O.bidirectional_gru(xe, lens, w, "encoder_cbhg/bigru")) < 1e-4
+    assert maxabs(oute.cpu().numpy(), O.bidirectional_gru(xe, lens, w, "encoder_cbhg/bigru", init)) < 1e-4
 
 
 @pytest.mark.parametrize("name,res", [("decoder/attention_gru", False), ("decoder/gru_1", True), ("decoder/gru_2", True)])
