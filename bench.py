@@ -4,7 +4,9 @@
 A "step" = one pass of the hot path (taco_forward_infer, replayed from its hipGraph plan) over one
 synthetic batch: ids -> encoder CBHG -> attention decoder (max_iters steps) -> post-net CBHG ->
 linear spectrogram, inputs/outputs resident in HBM.  Workload at N=1 is BASELINE.json configs[1]
-(C2: B=32, T_in=128, T_mel=512).  N>1: one process per GPU, per-GPU batch fixed (weak scaling),
+(C2: B=32, T_in=128, T_mel=512).  The K steps are issued round-robin over `--lanes` (default 4) PlanPool lanes -- one plan,
+workspace and HIP stream each -- so up to 4 independent B=32 forwards are in flight (`--lanes 1`: strictly serial; the JSON
+also carries the latency of one forward alone).  N>1: one process per GPU, per-GPU batch fixed (weak scaling),
 no data-path collective; barrier + synchronize on both sides, MAX over ranks.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md 'Measurement' for every field)."""
