@@ -1090,6 +1090,156 @@ __global__ __launch_bounds__(512) void k_bigru_res(const BigruSArgs a_in) {
   }
 }
 
+// k_bigru_resu : the same idea with UJ hidden units per thread and a K-slice UJ times shorter, so that one LDS read of the state
+// vector feeds UJ times more FMAs (at H=256 the broadcast reads of h / r*h were the busiest pipe of k_bigru_res: 64 ds_read_b128
+// per thread per step).  One batch row per workgroup.  Thread (jb, q): units jb + u*HJ (u < UJ, HJ = H/UJ), K-slice q of KS = H*HJ/512
+// rows: KR in registers, KL in LDS, the rest streamed in chunks of CH rows.
+template <int H, int UJ, int KR, int KL, int CH, bool TAPE>
+__global__ __launch_bounds__(512) void k_bigru_resu(const BigruSArgs a_in) {
+  constexpr int NT = 512, HJ = H / UJ, NQ = NT / HJ, KS = H / NQ, KG = KS - KR - KL;
+  static_assert(KG >= 0 && KG % CH == 0 && KR % 4 == 0 && NQ * HJ == NT && NQ * KS == H, "bad split");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BigruSArgs a = a_in;
+  PIN(a.xproj); PIN(a.g2_0); PIN(a.g2_1); PIN(a.c1_0); PIN(a.c1_1); PIN(a.h0); PIN(a.lengths); PIN(a.out); PIN(a.gsave); PIN(a.B); PIN(a.T);
+  const int tid = threadIdx.x;
+  const int d = blockIdx.x / a.B, b = blockIdx.x % a.B;
+  const int T = a.T;
+  const float2* G2 = d ? a.g2_1 : a.g2_0;
+  const float* C1 = d ? a.c1_1 : a.c1_0;
+  const int jb = tid % HJ, q = tid / HJ, k0 = q * KS;
+  float* hs = smem;                      // [H] state
+  float* xs = hs + H;                    // [H] r * h
+  float* us = xs + H;                    // [H] u
+  float* part = us + H;                  // [NQ][3][H] partial sums (r, u, c)
+  float2* wl_g = reinterpret_cast<float2*>(part + NQ * 3 * H);   // [KL][NQ][H]
+  float* wl_c = reinterpret_cast<float*>(wl_g + KL * NQ * H);    // [KL][NQ][H]
+  float2 wg[KR][UJ]; float wc[KR][UJ];
+#pragma unroll
+  for (int i = 0; i < KR; ++i)
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { wg[i][u] = G2[(size_t)(k0 + i) * H + jb + u * HJ]; wc[i][u] = C1[(size_t)(k0 + i) * H + jb + u * HJ]; }
+  for (int i = 0; i < KL; ++i)
+    for (int u = 0; u < UJ; ++u) {
+      wl_g[(i * NQ + q) * H + jb + u * HJ] = G2[(size_t)(k0 + KR + i) * H + jb + u * HJ];
+      wl_c[(i * NQ + q) * H + jb + u * HJ] = C1[(size_t)(k0 + KR + i) * H + jb + u * HJ];
+    }
+  const float2* Gs = G2 + (size_t)(k0 + KR + KL) * H + jb;
+  const float* Cs = C1 + (size_t)(k0 + KR + KL) * H + jb;
+  for (int i = tid; i < H; i += NT) hs[i] = a.h0 ? a.h0[(size_t)b * 2 * H + d * H + i] : 0.f;
+  const int L = a.lengths ? a.lengths[b] : T;
+  constexpr int NE1 = (2 * H + NT - 1) / NT;
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < T; ++s) {
+    float xg[NE1], xc = 0.f;
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) { const int o = tid + e * NT; xg[e] = (o < 2 * H) ? a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + o] : 0.f; }
+    if (tid < H) xc = a.xproj[((size_t)b * T + s) * 6 * H + d * 3 * H + 2 * H + tid];
+    // ---- gates ----
+    float ar[UJ], au[UJ];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { ar[u] = 0.f; au[u] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      const float4 h4 = *reinterpret_cast<const float4*>(&hs[k0 + i]);
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        ar[u] = fmaf(h4.x, wg[i][u].x, ar[u]); au[u] = fmaf(h4.x, wg[i][u].y, au[u]);
+        ar[u] = fmaf(h4.y, wg[i + 1][u].x, ar[u]); au[u] = fmaf(h4.y, wg[i + 1][u].y, au[u]);
+        ar[u] = fmaf(h4.z, wg[i + 2][u].x, ar[u]); au[u] = fmaf(h4.z, wg[i + 2][u].y, au[u]);
+        ar[u] = fmaf(h4.w, wg[i + 3][u].x, ar[u]); au[u] = fmaf(h4.w, wg[i + 3][u].y, au[u]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; ++i) {
+      const float hv = hs[k0 + KR + i];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) { const float2 w = wl_g[(i * NQ + q) * H + jb + u * HJ]; ar[u] = fmaf(hv, w.x, ar[u]); au[u] = fmaf(hv, w.y, au[u]); }
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float2 cur[CH][UJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v)
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) cur[v][u] = Gs[(size_t)(c0 + v) * H + u * HJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v) {
+        const float hv = hs[k0 + KR + KL + c0 + v];
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) { ar[u] = fmaf(hv, cur[v][u].x, ar[u]); au[u] = fmaf(hv, cur[v][u].y, au[u]); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { part[(q * 3 + 0) * H + jb + u * HJ] = ar[u]; part[(q * 3 + 1) * H + jb + u * HJ] = au[u]; }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE1; ++e) {
+      const int o = tid + e * NT;
+      if (o < 2 * H) {
+        const int g = o / H, nn = o % H;
+        float sum = xg[e];
+#pragma unroll
+        for (int qq = 0; qq < NQ; ++qq) sum += part[(qq * 3 + g) * H + nn];
+        const float sgm = taco_sigmoid(sum);
+        if (g == 0) xs[nn] = sgm * hs[nn]; else us[nn] = sgm;
+        if (TAPE && s < L) a.gsave[((size_t)b * T + (d ? L - 1 - s : s)) * 6 * H + d * 3 * H + o] = sgm;
+      }
+    }
+    __syncthreads();
+    // ---- candidate ----
+    float ac[UJ];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) ac[u] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      const float4 x4 = *reinterpret_cast<const float4*>(&xs[k0 + i]);
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        ac[u] = fmaf(x4.x, wc[i][u], ac[u]); ac[u] = fmaf(x4.y, wc[i + 1][u], ac[u]);
+        ac[u] = fmaf(x4.z, wc[i + 2][u], ac[u]); ac[u] = fmaf(x4.w, wc[i + 3][u], ac[u]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; ++i) {
+      const float xv = xs[k0 + KR + i];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) ac[u] = fmaf(xv, wl_c[(i * NQ + q) * H + jb + u * HJ], ac[u]);
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float cur[CH][UJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v)
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) cur[v][u] = Cs[(size_t)(c0 + v) * H + u * HJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v) {
+        const float xv = xs[k0 + KR + KL + c0 + v];
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) ac[u] = fmaf(xv, cur[v][u], ac[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) part[(q * 3 + 2) * H + jb + u * HJ] = ac[u];
+    __syncthreads();
+    if (tid < H) {
+      float sum = xc;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) sum += part[(qq * 3 + 2) * H + tid];
+      const float c = tanhf(sum);
+      const float h = hs[tid], u = us[tid];
+      const float hn = u * h + (1.f - u) * c;
+      const bool active = s < L;                           // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+      const int t = (d && active) ? (L - 1 - s) : s;
+      if (active) hs[tid] = hn;
+      a.out[((size_t)b * T + t) * 2 * H + d * H + tid] = active ? hn : 0.f;
+      if (TAPE && active) a.gsave[((size_t)b * T + t) * 6 * H + d * 3 * H + 2 * H + tid] = c;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_attention : one workgroup per batch row
 // ------------------------------------------------------------------------------------------------

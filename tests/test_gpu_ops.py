@@ -134,7 +134,7 @@ def test_bigru_with_lengths_and_init_state(ctx, B, persist):
     m.check_device_errors()
 
 
-@pytest.mark.parametrize("persist", [1, 2])
+@pytest.mark.parametrize("persist", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("B", [32, 5])
 def test_bigru_persistent_full_width_repeatable(persist, B):
     """Full-width BiGRUs, T=64, three runs: results must match the oracle and be bit-identical run to run.

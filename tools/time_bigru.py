@@ -15,6 +15,8 @@ def timeit(fn, n=10):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
+import os
+L.taco_debug_set_persistent(m._handle, int(os.environ.get("PERSIST", "1")))
 for scope, I in (("post_cbhg", 256), ("encoder_cbhg", 128)):
     for B in (32, 8):
         prev = None
