@@ -385,3 +385,63 @@ def test_prenet_layer_folded_into_frame_projection_is_the_same_function(mt, ns):
     for a, b in zip(folded, plain):
         assert maxabs(a, b) < 2e-5
     m._lib.taco_debug_set_fuse_prenet(m._handle, 1)
+
+
+def test_edge_lengths_zero_and_full_and_no_eos():
+    """synthesizer.py:120: input_lengths = argmax(ids == EOS): a row without EOS gets length 0 (its BiGRU output is all zero),
+    a row whose first token is EOS too; rows at full length sit beside them in the same batch."""
+    import taco_amd
+    ohp = tiny_hp()
+    w = O.init_weights(ohp, 1, 51)
+    rs = np.random.RandomState(52)
+    ids = rs.randint(2, 80, size=(5, 10)).astype(np.int32)
+    ids[1, 0] = 1                      # EOS first  -> length 0
+    ids[2, 9] = 1                      # EOS last   -> length 9
+    ids[3, 4] = 1; ids[3, 5:] = 0      # padded
+    L = taco_amd.input_lengths_from_tokens(ids)          # row 0 and 4: no EOS at all -> 0
+    assert list(L) == [0, 0, 9, 4, 0]
+    m = build_model(ohp, w)
+    hip = _run(m, ids, L, honor_stop=False)
+    ref = O.forward(w, ohp, ids, L, honor_stop=False)
+    _check(hip, ref)
+    enc = m.encoder(ids, L).cpu().numpy()
+    assert not enc[0].any() and not enc[1].any() and enc[2, :9].any() and not enc[2, 9:].any()
+
+
+@pytest.mark.parametrize("B", [1, 64])
+def test_batch_limits(B):
+    ohp = tiny_hp(max_iters=3)
+    w = O.init_weights(ohp, 1, 53)
+    ids, L = O.synthetic_inputs(B, 7, 54, ragged=True)
+    m = build_model(ohp, w)
+    _check(_run(m, ids, L, honor_stop=False), O.forward(w, ohp, ids, L, honor_stop=False))
+
+
+def test_batch_above_the_limit_and_bad_shapes_are_errors():
+    import taco_amd
+    ohp = tiny_hp(max_iters=2)
+    m = build_model(ohp, O.init_weights(ohp, 1, 55))
+    ids, L = O.synthetic_inputs(65, 5, 56)
+    with pytest.raises(Exception) as e:
+        m.run(inputs=ids, input_lengths=L)
+    assert "64" in str(e.value)
+    with pytest.raises(Exception):
+        m.run(inputs=ids[0], input_lengths=L[:1])          # rank-1 inputs
+
+
+def test_single_decoder_step_and_longest_supported_input():
+    """n_steps = 1 (initial alignments only) and T_in = 2048, the attention kernel's LDS limit; 2049 is refused."""
+    import taco_amd
+    ohp = tiny_hp(max_iters=1)
+    w = O.init_weights(ohp, 1, 57)
+    m = build_model(ohp, w)
+    ids, L = O.synthetic_inputs(2, 9, 58)
+    _check(_run(m, ids, L, honor_stop=False), O.forward(w, ohp, ids, L, honor_stop=False))
+    ohp2 = tiny_hp(max_iters=2)
+    w2 = O.init_weights(ohp2, 1, 59)
+    m2 = build_model(ohp2, w2)
+    ids, L = O.synthetic_inputs(2, 2048, 60, ragged=True)
+    _check(_run(m2, ids, L, honor_stop=False), O.forward(w2, ohp2, ids, L, honor_stop=False))
+    ids, L = O.synthetic_inputs(1, 2049, 61)
+    with pytest.raises(taco_amd._lib.TacoError):
+        m2.run(inputs=ids, input_lengths=L)
