@@ -1486,6 +1486,154 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attention(const AttnArgs a_in) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// split attention for small batches / long inputs (C5: B=8, T_in=512)
+// ------------------------------------------------------------------------------------------------
+// k_attention gives every batch row ONE workgroup; with 8 rows and 1 MB of keys+values per row that is 8 CUs pulling 64 B/clk
+// each.  Two launches instead: k_att_scores (grid B x S) -- every workgroup redoes the query mat-vec and scores its slice of
+// the encoder positions; k_att_context (grid B x S) -- every workgroup redoes the (cheap) normaliser over the whole row and
+// computes its slice of the context channels, slice 0 also writes the alignments.  No cross-workgroup exchange inside a launch.
+#define ATS_NW 8
+__global__ __launch_bounds__(64 * ATS_NW) void k_att_scores(const AttnArgs a_in, float* escr, int S) {
+  AttnArgs a = a_in;
+  PIN(a.hq); PIN(a.wq); PIN(a.As); PIN(a.keys); PIN(a.v); PIN(a.battn); PIN(a.T_in); PIN(a.A);
+  __shared__ __attribute__((aligned(16))) float qs[1024];
+  __shared__ __attribute__((aligned(16))) float part[ATS_NW * 1024 / 2];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, sl = blockIdx.y, T = a.T_in, A = a.A, As = a.As;
+  const int ldh = a.ldhq ? a.ldhq : As;
+  const float* hb = a.hq + (size_t)b * ldh;
+  {  // q = h_att . W_q (4 columns per thread, K split over thread groups)
+    const int NC = A >> 2;
+    int KS = (64 * ATS_NW) / NC; if (KS > As) KS = As; if (KS * A > ATS_NW * 512) KS = (ATS_NW * 512) / A; if (KS < 1) KS = 1;
+    const int kper = (As + KS - 1) / KS, cg = tid % NC, ks = tid / NC;
+    if (ks < KS) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* wp = reinterpret_cast<const float4*>(a.wq) + cg;
+      const int k1 = min(As, (ks + 1) * kper);
+#pragma unroll 8
+      for (int k = ks * kper; k < k1; ++k) {
+        const float4 w = wp[(size_t)k * NC]; const float xv = hb[k];
+        acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(part + (size_t)ks * A + 4 * cg) = acc;
+    }
+    __syncthreads();
+    for (int n = tid; n < A; n += 64 * ATS_NW) {
+      float sum = a.battn ? a.battn[n] : 0.f;
+      for (int k2 = 0; k2 < KS; ++k2) sum += part[(size_t)k2 * A + n];
+      qs[n] = sum;
+      if (sl == 0 && a.q_out) a.q_out[(size_t)b * a.ldq_out + n] = sum;
+    }
+    __syncthreads();
+  }
+  const int per = (T + S - 1) / S, j0 = sl * per, j1 = min(T, j0 + per);
+  const float* krow = a.keys + (size_t)b * T * A;
+  const int l16 = lane & 15, grp = lane >> 4;
+  for (int jb = j0 + wave * 4; jb < j1; jb += 4 * ATS_NW) {      // 16 lanes per encoder position, 4 positions per wave
+    const int j = jb + grp;
+    float p = 0.f;
+    if (j < j1) {
+      for (int c = l16 * 4; c < A; c += 64) {
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + (size_t)j * A + c);
+        const float4 q4 = *reinterpret_cast<const float4*>(&qs[c]);
+        const float4 v4 = *reinterpret_cast<const float4*>(a.v + c);
+        p += v4.x * taco_tanh_fast(k4.x + q4.x) + v4.y * taco_tanh_fast(k4.y + q4.y) + v4.z * taco_tanh_fast(k4.z + q4.z) + v4.w * taco_tanh_fast(k4.w + q4.w);
+      }
+    }
+    p += __shfl_xor(p, 8, 64); p += __shfl_xor(p, 4, 64); p += __shfl_xor(p, 2, 64); p += __shfl_xor(p, 1, 64);
+    if (l16 == 0 && j < j1) escr[(size_t)b * T + j] = p;
+  }
+}
+
+__global__ __launch_bounds__(64 * ATS_NW) void k_att_context(const AttnArgs a_in, const float* escr, int S) {
+  AttnArgs a = a_in;
+  PIN(a.values); PIN(a.score_bias); PIN(a.manual); PIN(a.align); PIN(a.hist); PIN(a.ctx); PIN(a.T_in); PIN(a.D); PIN(a.type); PIN(a.step);
+  PIN(a.n_steps); PIN(a.ldctx);
+  __shared__ float sc[ATT_MAXT], tmp[ATT_MAXT], tmp2[ATT_MAXT];
+  __shared__ float red[ATS_NW][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.x, sl = blockIdx.y, T = a.T_in, D = a.D;
+  const int lda = a.ldalign ? a.ldalign : T;
+  float* al = a.align + (size_t)b * lda;
+  const float* alp = a.align_prev ? a.align_prev + (size_t)b * lda : al;
+  for (int j = tid; j < T; j += 64 * ATS_NW) {
+    sc[j] = a.manual ? a.manual[((size_t)b * a.n_steps + a.step) * T + j] : escr[(size_t)b * T + j];
+    tmp2[j] = alp[j];                       // previous alignments, read before slice 0 overwrites them
+  }
+  __syncthreads();
+  if (wave == 0 && !a.manual) {
+    const int C = (T + 63) >> 6, j0 = lane * C, j1 = min(j0 + C, T);
+    if (a.type == 2) {   // monotonic_attention(mode='parallel'), same arithmetic as k_attention
+      const float sb = a.score_bias ? a.score_bias[0] : 0.f;
+      float run = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const float p = taco_sigmoid(sc[j] + sb);
+        const float lg = logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f));
+        sc[j] = p; tmp[j] = run; run += lg;
+      }
+      const float off = wave_scan(run, lane) - run;
+      float run2 = 0.f;
+      for (int j = j0; j < j1; ++j) {
+        const float cp = expf(tmp[j] + off);
+        tmp[j] = cp;
+        run2 += tmp2[j] / fminf(fmaxf(cp, 1e-10f), 1.f);
+        tmp2[j] = run2;
+      }
+      const float off2 = wave_scan(run2, lane) - run2;
+      for (int j = j0; j < j1; ++j) sc[j] = sc[j] * tmp[j] * (tmp2[j] + off2);
+    } else {
+      float mx = -INFINITY;
+      for (int j = j0; j < j1; ++j) mx = fmaxf(mx, sc[j]);
+      mx = wave_max(mx);
+      float sm = 0.f;
+      for (int j = j0; j < j1; ++j) { const float e = expf(sc[j] - mx); sc[j] = e; sm += e; }
+      sm = wave_sum(sm);
+      for (int j = j0; j < j1; ++j) sc[j] = sc[j] / sm;
+    }
+  }
+  __syncthreads();
+  if (sl == 0) {
+    for (int j = tid; j < T; j += 64 * ATS_NW) {
+      const float x = sc[j];
+      al[j] = x;
+      if (a.hist) a.hist[((size_t)b * T + j) * a.n_steps + a.step] = x;
+    }
+  }
+  // context channels [d0, d1) of this slice: 16 lanes x float4 cover 64 channels, the 4 lane groups x ATS_NW waves split the positions
+  const int per = ((D + S - 1) / S + 3) & ~3, d0 = sl * per, d1 = min(D, d0 + per);
+  const float* vrow = a.values + (size_t)b * T * D;
+  const int l16 = lane & 15, grp = lane >> 4;
+  float* red4 = &red[0][0];                                  // [ATS_NW][64]
+  for (int dc = d0; dc < d1; dc += 64) {
+    const int d = dc + 4 * l16;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d < d1) {
+#pragma unroll 4
+      for (int j = wave * 4 + grp; j < T; j += 4 * ATS_NW) {
+        const float wj = sc[j];
+        const float4 v4 = *reinterpret_cast<const float4*>(vrow + (size_t)j * D + d);
+        acc.x = fmaf(wj, v4.x, acc.x); acc.y = fmaf(wj, v4.y, acc.y); acc.z = fmaf(wj, v4.z, acc.z); acc.w = fmaf(wj, v4.w, acc.w);
+      }
+    }
+    acc.x += __shfl_xor(acc.x, 16, 64); acc.x += __shfl_xor(acc.x, 32, 64);
+    acc.y += __shfl_xor(acc.y, 16, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+    acc.z += __shfl_xor(acc.z, 16, 64); acc.z += __shfl_xor(acc.z, 32, 64);
+    acc.w += __shfl_xor(acc.w, 16, 64); acc.w += __shfl_xor(acc.w, 32, 64);
+    if (grp == 0) { red4[wave * 64 + 4 * l16 + 0] = acc.x; red4[wave * 64 + 4 * l16 + 1] = acc.y; red4[wave * 64 + 4 * l16 + 2] = acc.z; red4[wave * 64 + 4 * l16 + 3] = acc.w; }
+    __syncthreads();
+    if (wave == 0 && dc + lane < d1) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < ATS_NW; ++w) s2 += red4[w * 64 + lane];
+      a.ctx[(size_t)b * a.ldctx + dc + lane] = s2;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
 // stop rule of helpers.py:29 + TF dynamic_decode: a row is finished once a step's r*num_mels outputs are

@@ -104,6 +104,7 @@ struct taco_model {
   SkW query, concat_proj, frame_proj, lin_spk;   // lin_spk: speaker rows of the linear head ('simple')
   SkW prenet1_next;   // decoder prenet layer 1 of step t+1 as a function of step t's [GRU-stack output | context] (frame projection folded in)
   int fuse_prenet1 = 1;
+  int att_split = -1;   // -1: heuristic; 0/1: one workgroup per row; >1: k_att_scores + k_att_context with that many slices per row
   size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0, raw_wq = 0;
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
   std::vector<size_t> spk_table;   // speaker_embedding_size == 1 variant
@@ -805,7 +806,7 @@ static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, 
 
 // ---- decoder (tacotron.py:120-214) ----
 struct DecWs {
-  float *keys, *zero, *ctx, *pz[4], *h_att, *rh, *u, *xc, *q, *align, *o[5], *hd[4], *Y;
+  float *keys, *zero, *ctx, *pz[4], *h_att, *rh, *u, *xc, *q, *align, *o[5], *hd[4], *Y, *escr;
   int* nz;
   SpkWs spk;
 };
@@ -821,6 +822,7 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
   w.h_att = cv.f((size_t)B * As); w.rh = cv.f((size_t)B * Hmax); w.u = cv.f((size_t)B * Hmax); w.xc = cv.f((size_t)B * Hmax);
   w.q = cv.f((size_t)B * hp.attention_size);
   w.align = cv.f((size_t)B * T_in);
+  w.escr = cv.f((size_t)B * T_in);
   for (int i = 0; i <= hp.dec_layer_num; ++i) w.o[i] = cv.f((size_t)B * Hd);
   for (int i = 0; i < hp.dec_layer_num; ++i) w.hd[i] = cv.f((size_t)B * Hd);
   w.Y = nullptr;
@@ -892,7 +894,14 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
       a.q = fuse_q ? nullptr : w.q; a.hq = w.h_att; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
       a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx; a.ldctx = ldc;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
-      hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
+      // few rows x many encoder positions (C5): two launches that spread every row over att_split workgroups
+      const int att_split = (m->att_split >= 0) ? m->att_split : ((B <= 16 && T_in >= 256 && A % 4 == 0 && A <= 1024 && A / 4 <= 64 * ATS_NW) ? 4 : 0);
+      if (att_split > 1 && fuse_q) {
+        if (!manual) hipLaunchKernelGGL(k_att_scores, dim3(B, att_split), dim3(64 * ATS_NW), 0, st, a, w.escr, att_split);
+        hipLaunchKernelGGL(k_att_context, dim3(B, att_split), dim3(64 * ATS_NW), 0, st, a, (const float*)w.escr, att_split);
+      } else {
+        hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
+      }
       HIPCHK(hipGetLastError()); }
     // ConcatOutputAndAttentionWrapper + OutputProjectionWrapper (rnn_wrappers.py:405-415; tacotron.py:166-170)
     { SkJob j = sk_linear(m, m->concat_proj, w.h_att, As, As, w.ctx, ldc, ACT_NONE, w.o[0], Hd);   // 'simple': + speaker_embed (rnn_wrappers.py:408-413)
@@ -1270,6 +1279,11 @@ int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32
   return 0;
 }
 
+int taco_debug_set_att_split(taco_model* m, int slices) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->att_split = slices;
+  return 0;
+}
 int taco_debug_set_fuse_prenet(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->fuse_prenet1 = on ? 1 : 0;

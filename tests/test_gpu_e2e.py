@@ -445,3 +445,29 @@ def test_single_decoder_step_and_longest_supported_input():
     ids, L = O.synthetic_inputs(1, 2049, 61)
     with pytest.raises(taco_amd._lib.TacoError):
         m2.run(inputs=ids, input_lengths=L)
+
+
+@pytest.mark.parametrize("atype", ["bah_mon", "bah", "bah_norm"])
+@pytest.mark.parametrize("slices", [4, 3])
+def test_split_attention_for_small_batches_is_the_same_function(atype, slices):
+    """k_att_scores + k_att_context (rows spread over several workgroups; the default for B <= 16, T_in >= 256) vs the
+    one-workgroup-per-row kernel and vs the oracle, incl. manual alignments and ragged slice boundaries (T_in = 37)."""
+    ohp = tiny_hp(attention_type=atype, max_iters=9)
+    w = O.init_weights(ohp, 1, 71)
+    ids, L = O.synthetic_inputs(3, 37, 72, ragged=True)
+    ref = O.forward(w, ohp, ids, L, honor_stop=False)
+    m = build_model(ohp, w)
+    m._lib.taco_debug_set_att_split(m._handle, 0)
+    one = _run(m, ids, L, honor_stop=False)
+    m._plans.clear()
+    m._lib.taco_debug_set_att_split(m._handle, slices)
+    split = _run(m, ids, L, honor_stop=False)
+    _check(one, ref); _check(split, ref)
+    for a, b in zip(one, split):
+        assert maxabs(a, b) < 2e-5
+    man = np.random.RandomState(5).rand(3, 9, 37).astype(np.float32)
+    man /= man.sum(-1, keepdims=True)
+    m._plans.clear()
+    got = _run(m, ids, L, manual_alignments=man, is_manual_attention=True, honor_stop=False)
+    _check(got, O.forward(w, ohp, ids, L, manual_alignments=man, honor_stop=False), tol=2e-4)
+    m._lib.taco_debug_set_att_split(m._handle, -1)
