@@ -236,3 +236,33 @@ def test_gradients_at_full_reference_widths():
     worst, gn = _grad_report(tr.grad_dict(), g)
     assert worst[0][0] < 3e-3, worst[:5]
     tr.close()
+
+
+def test_train_step_through_the_collective_path():
+    """The data-parallel step with a real RCCL process group (one rank: the all-reduce and the division by the world size
+    must leave the single-process result untouched)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import taco_amd
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=33)
+    a = _trainer(hp, w)
+    a.train_step(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    want = a.params.clone()
+    a.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        b = _trainer(hp, w)
+        step, _ = b.train_step(ids, L, mt, lt, co)
+        torch.cuda.synchronize()
+        # gradients are accumulated with fp32 atomics (order not fixed): allow a few Adam-step quanta (lr = 5e-7 here)
+        assert step == 1 and float((b.params - want).abs().max()) < 2e-6
+        b.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
