@@ -46,6 +46,19 @@ def algorithmic_bytes(spec, hp, B, T_in, n):
     return 4 * total, 4 * per_step
 
 
+def stage_bytes(spec, hp, B, T_in, n):
+    """The same streaming model split by stage (encoder + attention keys | decoder loop | post-net + linear head)."""
+    import numpy as np
+    cnt = lambda pred: sum(int(np.prod(s)) if len(s) else 1 for k, s in spec if pred(k))
+    W_dec = cnt(lambda k: k.startswith("decoder/") or k.startswith("attention/query") or k.startswith("attention/attention_"))
+    W_post = cnt(lambda k: k.startswith("post_cbhg/") or k.startswith("linear/"))
+    W_enc = cnt(lambda k: True) - W_dec - W_post
+    A, D = hp.attention_size, 2 * hp.enc_rnn_size
+    M, F, r = hp.num_mels, hp.num_freq, hp.reduction_factor
+    _, per_step = algorithmic_bytes(spec, hp, B, T_in, n)
+    return {"encoder": 4 * (W_enc + B * T_in * (1 + D + A)), "decoder": n * per_step, "postnet": 4 * (W_post + B * n * r * (M + F))}
+
+
 def algorithmic_flops(hp, B, T_in, n):
     """2*MAC of every contraction of the forward (180.3 GFLOP at C2)."""
     r, M = hp.reduction_factor, hp.num_mels
@@ -206,6 +219,25 @@ def main():
         lat1.record()
     torch.cuda.synchronize()
     latency_ms = lat0.elapsed_time(lat1) / 3
+    # the three stages of the path one by one (stage-level C ABI, eager launches, nothing else in flight), HIP events on their stream
+    stage_ms = {}
+    if rank == 0:
+        p0 = pool.plans[0]
+        spk0 = p0.speaker_id if ns > 1 else None
+        with torch.cuda.stream(pool.streams[0]):
+            enc = model.encoder(p0.inputs, p0.lengths, spk0)
+            mel0 = model.decoder(enc, n, spk0)[0]
+            for name, fn in (("encoder", lambda: model.encoder(p0.inputs, p0.lengths, spk0)),
+                             ("decoder", lambda: model.decoder(enc, n, spk0)),
+                             ("postnet", lambda: model.postnet(mel0, speaker_id=spk0))):
+                fn()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(3):
+                    fn()
+                s1.record()
+                torch.cuda.synchronize()
+                stage_ms[name] = s0.elapsed_time(s1) / 3
     finite = all(bool(torch.isfinite(p.mel).all().item() and torch.isfinite(p.linear).all().item()) for p in pool.plans)
 
     if rank == 0:
@@ -213,6 +245,7 @@ def main():
         spec = taco_amd.weights.weight_spec(hp, ns)
         abytes, per_step = algorithmic_bytes(spec, hp, B, T_in, n)
         flops = algorithmic_flops(hp, B, T_in, n)
+        sb = stage_bytes(spec, hp, B, T_in, n)
         fwd_s = dev_ms / 1e3 / args.steps      # device time per forward (HIP events over the timed region / forwards in it)
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
@@ -230,6 +263,9 @@ def main():
                                    "%.2f MB per decoder step; duration = timed region / forwards (%d in flight)"
                                    % (abytes / 1e9, per_step / 1e6, lanes),
                          "forward_ms": fwd_s * 1e3,
+                         "stages": {k: {"ms_alone_eager": stage_ms[k], "algorithmic_GB": sb[k] / 1e9,
+                                        "achieved_GBps": sb[k] / (stage_ms[k] * 1e-3) / 1e9, "frac": sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                    for k in ("encoder", "decoder", "postnet")},
                          "mfma_f32": {"achieved": flops / fwd_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                       "frac": flops / fwd_s / 1e12 / MFMA_F32_PEAK_TF, "gflop_per_forward": flops / 1e9}},
             "outputs_finite": finite,
