@@ -235,16 +235,43 @@ __global__ void k_gru_bwd_b(const float* tmp1, int ld1, int I, const float* hpre
   dgp[(size_t)b * lddgp + n] = drh * hp * rr * (1.f - rr);
   dhp[i] = dht[i] * u[(size_t)b * ldu + n] + drh * rr;
 }
-// c: tmp2 = dgp . Wg^T ([B, I+H]): dx = tmp1[0..I) + tmp2[0..I) (+ dres); carry = dhp + tmp2[I..)
+// c: tmp2 = dgp . Wg^T ([B, I+H]): dx = tmp1[0..I) + tmp2[0..I) (+ dres), optionally masked by relu_of > 0 (the layer below is a
+// ReLU: saves its own mask kernel); carry = dhp + tmp2[I..)
 __global__ void k_gru_bwd_c(const float* tmp1, const float* tmp2, int ld, int I, const float* dres, int lddres, const float* dhp,
-                            float* dx, int lddx, float* carry, int B, int H) {
+                            float* dx, int lddx, float* carry, int B, int H, const float* relu_of, int ldrelu) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int W = I + H;
   if (i >= B * W) return;
   const int b = i / W, n = i % W;
   const float s = tmp1[(size_t)b * ld + n] + tmp2[(size_t)b * ld + n];
-  if (n < I) dx[(size_t)b * lddx + n] = s + (dres ? dres[(size_t)b * lddres + n] : 0.f);
-  else carry[(size_t)b * H + (n - I)] = dhp[(size_t)b * H + (n - I)] + tmp2[(size_t)b * ld + n];
+  if (n < I) {
+    float v = s + (dres ? dres[(size_t)b * lddres + n] : 0.f);
+    if (relu_of && !(relu_of[(size_t)b * ldrelu + n] > 0.f)) v = 0.f;
+    dx[(size_t)b * lddx + n] = v;
+  } else carry[(size_t)b * H + (n - I)] = dhp[(size_t)b * H + (n - I)] + tmp2[(size_t)b * ld + n];
+}
+// c of the upper GRU and a of the GRU below it in one launch (the residual stack: the lower cell's output gradient IS the dx just
+// computed; I == H there): dx as above, then dht/dcp/dgp_u of the lower cell from it.
+__global__ void k_gru_bwd_ca(const float* tmp1, const float* tmp2, int ld, int I, const float* dres, int lddres, const float* dhp,
+                             float* dx, int lddx, float* carry, int B, int H,
+                             const float* carry2, const float* u2, int ldu2, const float* c2, int ldc2, const float* hprev2, int ldh2,
+                             float* dht2, float* dcp2, int lddcp2, float* dgp2, int lddgp2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = I + H;
+  if (i >= B * W) return;
+  const int b = i / W, n = i % W;
+  const float s = tmp1[(size_t)b * ld + n] + tmp2[(size_t)b * ld + n];
+  if (n < I) {
+    const float g = s + (dres ? dres[(size_t)b * lddres + n] : 0.f);
+    dx[(size_t)b * lddx + n] = g;
+    // lower cell, unit n (I == H)
+    const float gt = g + carry2[(size_t)b * H + n];
+    const float uu = u2[(size_t)b * ldu2 + n], cc = c2[(size_t)b * ldc2 + n];
+    const float hp = hprev2 ? hprev2[(size_t)b * ldh2 + n] : 0.f;
+    dht2[(size_t)b * H + n] = gt;
+    dcp2[(size_t)b * lddcp2 + n] = gt * (1.f - uu) * (1.f - cc * cc);
+    dgp2[(size_t)b * lddgp2 + H + n] = gt * (hp - cc) * uu * (1.f - uu);
+  } else carry[(size_t)b * H + (n - I)] = dhp[(size_t)b * H + (n - I)] + tmp2[(size_t)b * ld + n];
 }
 
 // ---- BiGRU backward scan: the mirror of k_bigru_rows (row-parallel, transposed h-weights streamed from L2) ----
@@ -359,13 +386,14 @@ struct AttnBArgs {
   float* de_out;        // [B, ldde] tape: gradient of the raw scores of step t
   float* dsb_acc;       // [B] per-row accumulator of d score_bias
   float* dq; float* dhq;                                   // out [B, lddq]; in/out [B, lddhq]: += dq . Wq^T
-  int ldq, lde, ldal, lddctx, lddco, ldde, lddq, lddhq, T_in, A, D, As, type;
+  const float* cat;     // nullable [B, ldcat] = d(concat projection input): columns [0,As) are added to dhq, [As,As+D) to dctx first
+  int ldq, lde, ldal, lddctx, lddco, ldde, lddq, lddhq, T_in, A, D, As, type, ldcat;
 };
 #define ATB_NW 16
 __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a_in) {
   AttnBArgs a = a_in;
   PIN(a.q); PIN(a.e); PIN(a.wqT); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.score_bias); PIN(a.alpha); PIN(a.alpha_prev);
-  PIN(a.dctx); PIN(a.dctx_out); PIN(a.dalpha); PIN(a.de_out); PIN(a.dsb_acc); PIN(a.dq); PIN(a.dhq);
+  PIN(a.dctx); PIN(a.dctx_out); PIN(a.dalpha); PIN(a.de_out); PIN(a.dsb_acc); PIN(a.dq); PIN(a.dhq); PIN(a.cat); PIN(a.ldcat);
   // dynamic LDS (host: attn_bwd_lds_bytes): q[A4] dq[A4] dctx[D4] | p cp ss da de [T4 each] | red[ATB_NW*256]
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int A4 = (a_in.A + 3) & ~3, D4 = (a_in.D + 3) & ~3, T4 = (a_in.T_in + 3) & ~3;
@@ -381,7 +409,11 @@ __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a
   const float* al = a.alpha + (size_t)b * a.ldal;
   const float* alp = a.alpha_prev + (size_t)b * a.ldal;
   for (int i = tid; i < A; i += 64 * ATB_NW) qs[i] = a.q[(size_t)b * a.ldq + i];
-  for (int i = tid; i < D; i += 64 * ATB_NW) { const float x = a.dctx[(size_t)b * a.lddctx + i]; dcx[i] = x; a.dctx_out[(size_t)b * a.lddco + i] = x; }
+  for (int i = tid; i < D; i += 64 * ATB_NW) {
+    float x = a.dctx[(size_t)b * a.lddctx + i];
+    if (a.cat) x += a.cat[(size_t)b * a.ldcat + As + i];
+    dcx[i] = x; a.dctx_out[(size_t)b * a.lddco + i] = x;
+  }
   for (int j = tid; j < T; j += 64 * ATB_NW) de[j] = a.e[(size_t)b * a.lde + j];
   __syncthreads();
   // d alpha_j = carry_j + dctx . V_j : one wave per position, lanes over channels (float4)
@@ -516,6 +548,7 @@ __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a
     for (int k = tid; k < As; k += 64 * ATB_NW) {
       float s = 0.f;
       for (int k2 = 0; k2 < KS; ++k2) s += red[(size_t)k2 * As + k];
+      if (a.cat) s += a.cat[(size_t)b * a.ldcat + k];
       a.dhq[(size_t)b * a.lddhq + k] += s;
     }
   }

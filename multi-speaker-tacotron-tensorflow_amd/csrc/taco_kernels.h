@@ -635,6 +635,7 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
     const int rr = valid ? r : 0, nn = valid ? n : 0;    // clamped so every load below is unconditional
     pb[e] = jb.bias ? jb.bias[nn] : 0.f;
     pe0[e] = pe1[e] = pe2[e] = pe3[e] = 0.f; pL[e] = jb.T;
+    if (EPI == EPI_LINEAR) { if (jb.e0) pe0[e] = jb.e0[(size_t)rr * jb.lde0 + nn]; }
     if (EPI != EPI_LINEAR) {
       if (jb.lengths) pL[e] = jb.lengths[rr];
       const size_t xrow = (jb.T > 0) ? ((size_t)rr * jb.T + jb.step) : (size_t)rr;
@@ -708,7 +709,8 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
     const int r = row0 + rt * 16 + (ln >> 4) * 4 + reg;
     const int n = nt * 16 + (ln & 15);
     if (EPI == EPI_LINEAR) {
-      const float y = taco_act(s, jb.act);
+      float y = taco_act(s, jb.act);
+      if (jb.e0 && !(pe0[e] > 0.f)) y = 0.f;        // backward through a ReLU: masked by the forward activation (training path)
       jb.o0[(size_t)r * jb.ldo0 + n] = y;
       if (jb.o2 && y != 0.f) reinterpret_cast<int*>(jb.o2)[r] = 1;   // stop rule helpers.py:29
     } else if (EPI == EPI_GRU_GATES) {

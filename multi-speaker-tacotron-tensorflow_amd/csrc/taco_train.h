@@ -25,6 +25,7 @@ struct TrainPacks {
   CbhgT enc, post;
   ConvL mem_d, lin_d;
   std::vector<SkW> decpre_T;
+  SkW decpre0_ctxT;                     // transposed decoder prenet layer 1, context rows only: [P0 -> D] (the teacher frame gets no gradient)
   GruT att, dec[4];
   SkW concat_T, frame_T;
   size_t wqT = 0;
@@ -142,6 +143,10 @@ static int build_train_packs(taco_model* m) {
     tp.decpre_T.push_back(pack_w16_T(m, T_(m, "decoder/prenet/dense_" + std::to_string(i + 1) + "/kernel").data.data(), d, hp.dec_prenet[i]));
     d = hp.dec_prenet[i];
   }
+  { const HostTensor& k = T_(m, "decoder/prenet/dense_1/kernel");      // [Mm + D, P0]: rows Mm.. transposed -> [P0, D]
+    const int Mm = hp.num_mels, P0 = hp.dec_prenet[0];
+    std::vector<float> Tt = transpose2d(k.data.data(), Mm + D, P0, Mm, D);
+    tp.decpre0_ctxT = pack_w16(m, Tt.data(), D, 0, P0, 0, D, nullptr); }
   tp.att = make_gru_T(m, "decoder/attention_gru", d, As);
   for (int i = 0; i < hp.dec_layer_num; ++i) tp.dec[i] = make_gru_T(m, "decoder/gru_" + std::to_string(i + 1), Hd, Hd);
   tp.concat_T = pack_w16_T(m, T_(m, "decoder/concat_projection/kernel").data.data(), As + D, Hd);
@@ -517,18 +522,27 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
 static SkJob sk_T(const taco_model* m, const SkW& wT, const float* dy, int lddy, float* out, int ldo) {
   return sk_linear(m, wT, dy, lddy, wT.K, nullptr, 0, ACT_NONE, out, ldo);
 }
-// one GRUCell backward: dout [B,H] (+carry) -> dx [B,I] (+dres), new carry; tape slices at step t
+// one GRUCell backward: dout [B,H] (+carry) -> dx [B,I] (+dres), new carry; tape slices at step t.
+// skip_a: the 'a' part (dht, dcp, dgp_u) was already produced by the k_gru_bwd_ca of the cell above.
+// next: when given, the 'c' part also runs the 'a' part of the cell below (k_gru_bwd_ca).  relu_of: mask dx by relu_of > 0.
+struct GruBwdNext { const float* carry; const float* u; const float* c; const float* hprev; float* dcp; float* dgp; };
 static int gru_cell_backward(const TrainCtx& x, const GruT& gt, int B, const float* dout, int lddo, float* carry, bool add_carry,
                              const float* u, const float* c, const float* r, const float* hprev, int ld, float* g_dcp, float* g_dgp,
-                             const float* dres, int lddres, float* dx, int lddx, const DecTape& w) {
+                             const float* dres, int lddres, float* dx, int lddx, const DecTape& w, bool skip_a = false,
+                             const GruBwdNext* next = nullptr, const float* relu_of = nullptr, int ldrelu = 0) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int H = gt.H, I = gt.I, W = I + H;
-  hipLaunchKernelGGL(k_gru_bwd_a, EWGRID((size_t)B * H), 0, st, dout, lddo, add_carry ? carry : (const float*)nullptr, u, ld, c, ld, hprev, ld,
-                     w.dht, g_dcp, ld, g_dgp, 2 * ld, B, H);
+  if (!skip_a)
+    hipLaunchKernelGGL(k_gru_bwd_a, EWGRID((size_t)B * H), 0, st, dout, lddo, add_carry ? carry : (const float*)nullptr, u, ld, c, ld, hprev, ld,
+                       w.dht, g_dcp, ld, g_dgp, 2 * ld, B, H);
   { SkJob j = sk_T(m, gt.cT, g_dcp, ld, w.tmp1, W); TRY(run_skinny(st, B, &j, 1)); }
   hipLaunchKernelGGL(k_gru_bwd_b, EWGRID((size_t)B * H), 0, st, w.tmp1, W, I, hprev, ld, r, ld, u, ld, w.dht, g_dgp, 2 * ld, w.dhp, B, H);
   { SkJob j = sk_T(m, gt.gT, g_dgp, 2 * ld, w.tmp2, W); TRY(run_skinny(st, B, &j, 1)); }
-  hipLaunchKernelGGL(k_gru_bwd_c, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H);
+  if (next)   // note: dht of the lower cell overwrites w.dht -- this cell's dht was consumed by its 'b' part above
+    hipLaunchKernelGGL(k_gru_bwd_ca, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H,
+                       next->carry, next->u, ld, next->c, ld, next->hprev, ld, w.dht, next->dcp, ld, next->dgp, 2 * ld);
+  else
+    hipLaunchKernelGGL(k_gru_bwd_c, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H, relu_of, ldrelu);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -568,13 +582,16 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     for (int i = L - 1; i >= 0; --i) {
       const float* hprev = (t == 0) ? nullptr : w.h[i] + (size_t)(t - 1) * Hd;
       float* dx = (i == 0) ? w.g_do0 + oh : w.do_[i]; const int lddx = (i == 0) ? n * Hd : Hd;
+      GruBwdNext nx; const GruBwdNext* pnx = nullptr;
+      if (i > 0) {   // the cell below consumes this dx at once: its 'a' part rides in this cell's 'c' launch
+        nx.carry = w.dh[i - 1]; nx.u = w.u[i - 1] + oh; nx.c = w.c[i - 1] + oh; nx.hprev = (t == 0) ? nullptr : w.h[i - 1] + (size_t)(t - 1) * Hd;
+        nx.dcp = w.g_dcp[i - 1] + oh; nx.dgp = w.g_dgp[i - 1] + 2 * oh; pnx = &nx;
+      }
       TRY(gru_cell_backward(x, tp.dec[i], B, w.do_[i + 1], Hd, w.dh[i], true, w.u[i] + oh, w.c[i] + oh, w.r[i] + oh, hprev, n * Hd,
-                            w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w));
+                            w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w, i < L - 1, pnx));
     }
-    // concat projection: [h_att | ctx] <- d o0
-    { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.tmp1, As + D); TRY(run_skinny(st, B, &j, 1)); }
-    hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, w.tmp1, As + D, B, As);
-    hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * D), 0, st, w.dctx, D, w.tmp1 + As, As + D, B, D);
+    // concat projection: [h_att | ctx] <- d o0; the attention backward adds the two halves to dhA / dctx itself
+    { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.dIn, As + D); TRY(run_skinny(st, B, &j, 1)); }
     { AttnBArgs a; memset(&a, 0, sizeof a);
       a.q = w.g_q + (size_t)t * A; a.ldq = n * A; a.e = w.g_e + (size_t)t * T_in; a.lde = n * T_in; a.wqT = AP(m, tp.wqT);
       a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.score_bias = AP(m, m->att_sb);
@@ -582,21 +599,22 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
       a.dctx = w.dctx; a.lddctx = D; a.dctx_out = w.g_dctx + (size_t)t * D; a.lddco = n * D; a.dalpha = w.dalpha;
       a.de_out = w.g_de + (size_t)t * T_in; a.ldde = n * T_in; a.dsb_acc = w.dsb_acc;
       a.dq = w.g_dq + (size_t)t * A; a.lddq = n * A; a.dhq = w.dhA; a.lddhq = As; a.T_in = T_in; a.A = A; a.D = D; a.As = As; a.type = hp.attention_type;
+      a.cat = w.dIn; a.ldcat = As + D;
       hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(64 * ATB_NW), attn_lds, st, a);
       HIPCHK(hipGetLastError()); }
     { const float* hprev = (t == 0) ? nullptr : w.hA + (size_t)(t - 1) * As;
+      // dx of the attention GRU = gradient of the (ReLU) prenet output: masked here, written straight to the tape
       TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
-                            w.g_dgpA + 2 * oa, nullptr, 0, w.dpz, Pl, w)); }
-    for (int i = np - 1; i >= 0; --i) {
-      const int P = hp.dec_prenet[i];
-      float* gz = w.g_dz[i] + (size_t)t * P;
-      hipLaunchKernelGGL(k_relu_bwd, EWGRID((size_t)B * P), 0, st, w.dpz, P, w.pz[i] + (size_t)t * P, n * P, gz, n * P, B, P);
-      if (i > 0) { SkJob j = sk_T(m, tp.decpre_T[i], gz, n * P, w.dpz, hp.dec_prenet[i - 1]); TRY(run_skinny(st, B, &j, 1)); }
-      else {
-        SkJob j = sk_T(m, tp.decpre_T[0], gz, n * P, w.dIn, Mm + D); TRY(run_skinny(st, B, &j, 1));
-        hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * D), 0, st, w.dIn + Mm, Mm + D, w.dctx, D, B, D);   // gradient of context(t-1)
-      }
+                            w.g_dgpA + 2 * oa, nullptr, 0, w.g_dz[np - 1] + (size_t)t * Pl, n * Pl, w, false, nullptr,
+                            w.pz[np - 1] + (size_t)t * Pl, n * Pl)); }
+    for (int i = np - 1; i >= 1; --i) {   // prenet layers np..2: d z_{i-1} = (d z_i . W_i^T) masked by the ReLU of layer i-1 (skinny epilogue)
+      const int P = hp.dec_prenet[i], Pm = hp.dec_prenet[i - 1];
+      SkJob j = sk_T(m, tp.decpre_T[i], w.g_dz[i] + (size_t)t * P, n * P, w.g_dz[i - 1] + (size_t)t * Pm, n * Pm);
+      j.e0 = w.pz[i - 1] + (size_t)t * Pm; j.lde0 = n * Pm;
+      TRY(run_skinny(st, B, &j, 1));
     }
+    // layer 1: only the context columns of its input carry a gradient (the frame is the teacher's): d ctx(t-1) = d z_0 . W1[Mm:,:]^T
+    { SkJob j = sk_T(m, tp.decpre0_ctxT, w.g_dz[0] + (size_t)t * hp.dec_prenet[0], n * hp.dec_prenet[0], w.dctx, D); TRY(run_skinny(st, B, &j, 1)); }
     HIPCHK(hipGetLastError());
   }
   // ---- weight gradients, hoisted over all steps: rows (b, t) of the [B, n, .] tapes ----
