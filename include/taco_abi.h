@@ -188,7 +188,7 @@ int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, 
  * the single all-reduce bucket of the data-parallel step.  A taco_train owns only index maps and weight packs that it
  * regenerates from the flat parameters (taco_train_refresh) after every optimizer step.
  * modules.py:24 calls tf.layers.dropout without training=True, so the reference applies no prenet dropout even when
- * training; neither does this path.  Supported: num_speakers == 1, attention bah / bah_mon. ---- */
+ * training; neither does this path.  Supported: single-speaker and multi-speaker 'deepvoice' models, attention bah / bah_mon. ---- */
 typedef struct taco_train taco_train;
 int taco_train_create(const taco_hparams* hp, int device, taco_train** out);
 void taco_train_destroy(taco_train* t);
@@ -207,7 +207,8 @@ size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_ou
  * rnn_decoder_test_mode != 0 (helpers.py:63-64, the test model of train.py:158-166): the decoder is fed its own previous
  * output instead of the target frame; forward/loss only (d_grads must be NULL). */
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
-                                const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
+                                const int32_t* d_input_lengths, const int32_t* d_speaker_id /* nullable: single speaker */,
+                                const float* d_mel_targets, const float* d_linear_targets,
                                 const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate,
                                 float* d_losses, float* d_mel_out, float* d_linear_out, float* d_alignments,
                                 int rnn_decoder_test_mode, void* d_workspace, size_t workspace_bytes);

@@ -87,7 +87,8 @@ __global__ void k_bn_bwd(const float* a, int lda, const float* dy, int ldy, cons
 // Rows m = b*T + t never reach across batch rows (SAME zero padding, A.2); T <= 0: no time structure.  With `gather`
 // row m of x is x[gather[m]] (embedding lookup fused into the first encoder prenet layer).  Workgroup = 4 waves =
 // 64 (k) x 64 (n) tile over `rpb` rows; partial sums leave through fp32 atomics.
-struct WgArgs { const float* x; const int* gather; const float* dy; float* dw; int ldx, ldy, lddw, M, T, K, N, kw, padl, rpb; };
+struct WgArgs { const float* x; const int* gather; const float* dy; float* dw; int ldx, ldy, lddw, M, T, K, N, kw, padl, rpb;
+                const int* ygather; };   // optional: row m of dy is dy[ygather[m]] (first-step terms of recurrent kernels with ragged lengths)
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
           const size_t xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift);
           av[u] = g.x[xr * g.ldx + k0 + i];
         }
-        if (nok) bv[u] = g.dy[(size_t)m * g.ldy + n0 + i];
+        if (nok) bv[u] = g.dy[(size_t)(g.ygather ? g.ygather[m] : m) * g.ldy + n0 + i];
       }
     }
 #pragma unroll
@@ -176,6 +177,13 @@ __global__ void k_relu_bwd(const float* dy, int lddy, const float* y, int ldy, f
   const int m = (int)(i / C), c = (int)(i % C);
   dz[(size_t)m * ldz + c] = (y[(size_t)m * ldy + c] > 0.f) ? dy[(size_t)m * lddy + c] : 0.f;
 }
+// x[m, c] += vec[m / T, c]  (a per-utterance vector tiled over time)
+__global__ void k_add_rowvec(float* x, const float* vec, int M, int T, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * C) return;
+  const int m = (int)(i / C), c = (int)(i % C);
+  x[i] += vec[(size_t)(m / T) * C + c];
+}
 __global__ void k_add2d(float* dst, int ldd, const float* src, int lds, int M, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * C) return;
@@ -198,6 +206,25 @@ __global__ void k_embed_bwd(const float* dx, const int* ids, float* dE, int M, i
   if (i >= (size_t)M * E) return;
   const int m = (int)(i / E), c = (int)(i % E);
   atomicAdd(dE + (size_t)ids[m] * E + c, dx[i]);
+}
+// y = softsign(z) = z / (1 + |z|)  =>  dz = dy * (1 - |y|)^2   (deepvoice speaker layers, tacotron.py:68-79)
+__global__ void k_softsign_bwd(const float* dy, const float* y, float* dz, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float t = 1.f - fabsf(y[i]); dz[i] = dy[i] * t * t; }
+}
+// out[b, c] = sum_t x[b, t, c]  (gradient of a vector broadcast over time: before_highway)
+__global__ void k_time_sum(const float* x, float* out, int B, int T, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += x[((size_t)b * T + t) * C + c];
+  out[i] = s;
+}
+// idx[b] = b*T + max(L_b - 1, 0): the row of the first backward-direction step of every sequence
+__global__ void k_last_row_index(const int* lengths, int* idx, int B, int T) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) { const int L = lengths ? lengths[b] : T; idx[b] = b * T + (L > 0 ? L - 1 : 0); }
 }
 __global__ void k_sum_all(const float* x, int n, float* out) {   // out[0] += sum x  (attention score bias gradient)
   __shared__ float sm[256];
@@ -284,6 +311,8 @@ struct BigruBArgs {
   const int* lengths;
   float* dg;            // [B*T, 6H] out: (d r_pre | d u_pre | d c_pre) per direction at the true time index (host pre-zeroes)
   float* rh;            // [B*T, 2H] out: r * h_prev (input rows of the candidate kernel's h part, for its weight gradient; host pre-zeroes)
+  const float* h0;      // [B, 2H] initial states (fw | bw) or null (deepvoice encoder_rnn_init, modules.py:82-86)
+  float* dh0;           // [B, 2H] out: gradient of the initial states (nullable)
   int B, T, H;
 };
 template <int R>
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   BigruBArgs a = a_in;
   PIN(a.dout); PIN(a.out); PIN(a.gsave); PIN(a.wgT0); PIN(a.wgT1); PIN(a.wcT0); PIN(a.wcT1); PIN(a.lengths); PIN(a.dg); PIN(a.rh);
-  PIN(a.B); PIN(a.T); PIN(a.H);
+  PIN(a.h0); PIN(a.dh0); PIN(a.B); PIN(a.T); PIN(a.H);
   const int tid = threadIdx.x;
   const int ngrp = (a.B + R - 1) / R;
   const int d = blockIdx.x / ngrp, r0 = (blockIdx.x % ngrp) * R;
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in)
         rg = a.gsave[row * 6 * H + d * 3 * H + n];
         const float ug = a.gsave[row * 6 * H + d * 3 * H + H + n];
         const float cg = a.gsave[row * 6 * H + d * 3 * H + 2 * H + n];
-        hp = (s > 0) ? a.out[((size_t)b * T + tp) * 2 * H + d * H + n] : 0.f;
+        hp = (s > 0) ? a.out[((size_t)b * T + tp) * 2 * H + d * H + n] : (a.h0 ? a.h0[(size_t)b * 2 * H + d * H + n] : 0.f);
         dcp = g * (1.f - ug) * (1.f - cg * cg);
         dgu = g * (hp - cg) * ug * (1.f - ug);
         keep = g * ug;
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in)
     }
     __syncthreads();
   }
+  if (a.dh0 && brow) a.dh0[(size_t)b * 2 * H + d * H + n] = dh[o];
 }
 
 // inclusive wave64 SUFFIX sum (lane l gets sum over lanes >= l); never formed as total - prefix, which cancels

@@ -8,7 +8,7 @@
 //     laid out like the parameters (the single RCCL all-reduce bucket of the data-parallel step).
 // modules.py:24 calls tf.layers.dropout without training=True, so the prenet dropout is the identity in the
 // reference even when training; nothing is dropped here either.
-// Supported for training: num_speakers == 1, attention bah / bah_mon.
+// Supported for training: single-speaker and multi-speaker 'deepvoice' models, attention bah / bah_mon.
 #pragma once
 
 struct CbhgT {
@@ -29,6 +29,7 @@ struct TrainPacks {
   GruT att, dec[4];
   SkW concat_T, frame_T;
   size_t wqT = 0;
+  std::vector<SkW> spk_T;              // deepvoice speaker layers transposed: [dim_i -> S]
 };
 
 struct taco_train {
@@ -130,7 +131,8 @@ static GruT make_gru_T(taco_model* m, const std::string& name, int I, int H) {
 static int build_train_packs(taco_model* m) {
   TrainPacks& tp = *m->tp;
   const taco_hparams& hp = m->hp;
-  if (hp.num_speakers > 1) return fail(TACO_ERR_UNSUPPORTED, "training supports single-speaker models only");
+  if (hp.num_speakers > 1 && hp.model_type != 2)
+    return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
   if (hp.attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
   for (int i = 0; i < hp.enc_prenet_n; ++i) tp.encpre_d.push_back(make_conv_T_named(m, "prenet/dense_" + std::to_string(i + 1)));
   build_cbhg_T(m, m->enc, "encoder_cbhg", tp.enc);
@@ -153,6 +155,14 @@ static int build_train_packs(taco_model* m) {
   tp.frame_T = pack_w16_T(m, T_(m, "decoder/frame_projection/kernel").data.data(), Hd, hp.num_mels * hp.reduction_factor);
   { std::vector<float> wqT = transpose2d(T_(m, "attention/query_layer/kernel").data.data(), As, A);
     tp.wqT = arena_put(m, wqT.data(), wqT.size()); }
+  if (is_deepvoice(m) && hp.speaker_embedding_size != 1) {
+    std::vector<std::string> names = {kSpkNames[0], kSpkNames[1], kSpkNames[2]};
+    for (int i = 0; i < hp.dec_layer_num; ++i) names.push_back("decoder_rnn_init_" + std::to_string(i + 1));
+    for (auto& n : names) {
+      const HostTensor& k = T_(m, "spk/" + n + "/kernel");
+      tp.spk_T.push_back(pack_w16_T(m, k.data.data(), (int)k.shape[0], (int)k.shape[1]));
+    }
+  }
   return 0;
 }
 
@@ -169,8 +179,8 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
   return 0;
 }
 static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
-                     int M, int T, int K, int N, int kw = 1, int padl = 0) {
-  WgArgs g; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
+                     int M, int T, int K, int N, int kw = 1, int padl = 0, const int* ygather = nullptr) {
+  WgArgs g; g.ygather = ygather; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
   g.kw = kw; g.padl = padl;
   // rows per workgroup: enough workgroups to fill 256 CUs several times over, at least 64 rows each
   { const long tiles = (long)cdiv(K, 64) * cdiv(N, 64) * kw; int rpb = 512;
@@ -253,6 +263,7 @@ struct TrainWs {
   CbhgTape enc, post;
   DecTape dec;
   float *teach, *mel, *linear, *dmel, *dlin, *denc, *dpost, *dmel_post, *demb, *losspart;
+  SpkWs spk; float* dvec[8]; float* dspk_emb; float* dzs; int* rowidx;   // deepvoice: speaker vectors, their gradients, scratch
 };
 static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n, TrainWs& w) {
   const taco_model* m = t->sm;
@@ -268,6 +279,11 @@ static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n,
   w.denc = cv.f(Me * 2 * hp.enc_rnn_size);
   w.dpost = cv.f(Mp * 2 * hp.post_rnn_size); w.dmel_post = cv.f(Mp * hp.num_mels); w.demb = cv.f(Me * hp.embedding_size);
   w.losspart = (float*)cv.raw((size_t)TR_MAXBLK * 8 * sizeof(double));
+  carve_spk(cv, m, B, w.spk);
+  { const int dims[3] = {hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_rnn_size * 2, hp.attention_state_size};
+    int dmax = 1;
+    for (int i = 0; i < 3 + hp.dec_layer_num; ++i) { const int dd = i < 3 ? dims[i] : hp.dec_rnn_size; w.dvec[i] = cv.f((size_t)B * dd); dmax = std::max(dmax, dd); }
+    w.dspk_emb = cv.f((size_t)B * std::max(hp.speaker_embedding_size, 1)); w.dzs = cv.f((size_t)B * dmax); w.rowidx = cv.i(B); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -296,7 +312,7 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
   return 0;
 }
 static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, const std::string& sc, const float* in, int B, int T,
-                              const int* lengths, const CbhgTape& w) {
+                              const int* lengths, const CbhgTape& w, const float* before_highway = nullptr, const float* init_state = nullptr) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int M = B * T, KC = c.K * c.C;
   { GemmCall g; g.x = in; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank_a; g.ldo = KC;
@@ -325,6 +341,7 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   // residual (modules.py:62-69)
   hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.in_dim), 0, st, cur, c.in_dim, w.res, c.in_dim, M, c.in_dim);
   hipLaunchKernelGGL(k_add2d, EWGRID((size_t)M * c.in_dim), 0, st, w.res, c.in_dim, in, c.in_dim, M, c.in_dim);
+  if (before_highway) hipLaunchKernelGGL(k_add_rowvec, EWGRID((size_t)M * c.in_dim), 0, st, w.res, before_highway, M, T, c.in_dim);   // modules.py:66-69
   HIPCHK(hipGetLastError());
   if (c.has_dense) { GemmCall d; d.x = w.res; d.ldx = c.in_dim; d.M = M; d.out = w.hx[0]; d.ldo = c.rnn; TRY(run_gemm(m, st, &c.dense, 1, false, d)); }
   else hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.rnn), 0, st, w.res, c.rnn, w.hx[0], c.rnn, M, c.rnn);
@@ -340,6 +357,7 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
     BigruSArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T;
+    a.h0 = init_state;
     if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(256, 24, 1), st, a);
     else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(128, 0, 1), st, a);
   } else {
@@ -347,7 +365,7 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
     if (!bigru_rows_cfg(B, H, &R, &lds)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the row-parallel BiGRU kernel", H);
     BigruRArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.wg0 = AP(m, c.raw_gh[0]); a.wg1 = AP(m, c.raw_gh[1]); a.wc0 = AP(m, c.raw_ch[0]); a.wc1 = AP(m, c.raw_ch[1]);
-    a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H;
+    a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T; a.H = H; a.h0 = init_state;
     if (R == 2) hipLaunchKernelGGL((k_bigru_rows<2, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
     else hipLaunchKernelGGL((k_bigru_rows<1, true>), dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
   }
@@ -368,7 +386,8 @@ static int conv_bn_backward(const TrainCtx& x, const std::string& name, const fl
 }
 // dout [M, 2*rnn] -> din [M, in_dim]
 static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, const std::string& sc, const float* in, const int* in_gather,
-                         int B, int T, const int* lengths, const float* dout, float* din, const CbhgTape& w) {
+                         int B, int T, const int* lengths, const float* dout, float* din, const CbhgTape& w,
+                         const float* h0 = nullptr, float* dh0 = nullptr, float* d_before = nullptr, int* rowidx = nullptr) {
   (void)in_gather;
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int M = B * T, KC = c.K * c.C, H = c.rnn, I = c.rnn;
@@ -381,7 +400,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     const size_t lds = ((size_t)4 * R * H + (size_t)RP_NT * R * 4 + 64) * sizeof(float);
     BigruBArgs a; memset(&a, 0, sizeof a);
     a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.wgT0 = AP(m, ct.ghT[0]); a.wgT1 = AP(m, ct.ghT[1]); a.wcT0 = AP(m, ct.chT[0]); a.wcT1 = AP(m, ct.chT[1]);
-    a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.B = B; a.T = T; a.H = H;
+    a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.B = B; a.T = T; a.H = H; a.h0 = h0; a.dh0 = dh0;
     if (R == 2) hipLaunchKernelGGL(k_bigru_rows_bwd<2>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
     else hipLaunchKernelGGL(k_bigru_rows_bwd<1>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
     HIPCHK(hipGetLastError());
@@ -396,6 +415,13 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     // h rows: state before the step = output one step earlier in the direction's own time (zero at the sequence start / past the length)
     TRY(run_wgrad(st, w.out + dir * H, nullptr, 2 * H, dgg, 6 * H, Gg + (size_t)I * 2 * H, 2 * H, M, T, H, 2 * H, 1, dir ? -1 : 1));
     TRY(run_wgrad(st, w.rh + dir * H, nullptr, 2 * H, dgg + 2 * H, 6 * H, Gc + (size_t)I * H, H, M, T, H, H));
+    if (h0) {   // first step of the direction: the state before it is the initial state, not a row of the output tape
+      if (dir == 0) TRY(run_wgrad(st, h0, nullptr, 2 * H, dgg, T * 6 * H, Gg + (size_t)I * 2 * H, 2 * H, B, 0, H, 2 * H));
+      else {
+        hipLaunchKernelGGL(k_last_row_index, EWGRID(B), 0, st, lengths, rowidx, B, T);
+        TRY(run_wgrad(st, h0 + H, nullptr, 2 * H, dgg, 6 * H, Gg + (size_t)I * 2 * H, 2 * H, B, 0, H, 2 * H, 1, 0, rowidx));
+      }
+    }
     TRY(run_colsum(st, dgg, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/gates/bias"), nullptr, M, 2 * H, 0));
     TRY(run_colsum(st, dgg + 2 * H, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/candidate/bias"), nullptr, M, H, 0));
   }
@@ -420,7 +446,8 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(run_dgrad(m, st, ct.dense_d, dcur, H, M, 0, dalt, c.in_dim));
     std::swap(dcur, dalt);
   }
-  // dcur = gradient of (proj_last + x): keep a copy for the residual path
+  // dcur = gradient of (proj_last + x (+ before_highway)): keep a copy for the residual path
+  if (d_before) { hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * c.in_dim), 0, st, dcur, d_before, B, T, c.in_dim); HIPCHK(hipGetLastError()); }
   float* dres = din;
   hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)M * c.in_dim), 0, st, dcur, c.in_dim, dres, c.in_dim, M, c.in_dim);
   HIPCHK(hipGetLastError());
@@ -463,7 +490,8 @@ static int gru_cell_train(const taco_model* m, hipStream_t st, const GruDec& g, 
   return 0;
 }
 static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, float* mel,
-                                 float* align_hist, const DecTape& w, bool feed_back) {
+                                 float* align_hist, const DecTape& w, bool feed_back, const float* att_init = nullptr,
+                                 const float* const* dec_init = nullptr) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const taco_hparams& hp = m->hp;
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
@@ -492,7 +520,7 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
                                      hp.dec_prenet[i - 1], nullptr, 0, ACT_RELU, w.pz[i] + (size_t)t * P, n * P);
       TRY(run_skinny(st, B, &j, 1));
     }
-    const float* hAp = (t == 0) ? w.zero : w.hA + (size_t)(t - 1) * As; const int ldhA = (t == 0) ? As : n * As;
+    const float* hAp = (t == 0) ? (att_init ? att_init : w.zero) : w.hA + (size_t)(t - 1) * As; const int ldhA = (t == 0) ? As : n * As;   // tacotron.py:183-197
     const size_t oa = (size_t)t * As;
     TRY(gru_cell_train(m, st, m->att_gru, B, w.pz[np - 1] + (size_t)t * Pl, n * Pl, hAp, ldhA, w.hA + oa, w.rhA + oa, w.uA + oa, w.xcA + oa,
                        w.rA + oa, w.cA + oa, n * As, nullptr));
@@ -508,7 +536,7 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
       TRY(run_skinny(st, B, &j, 1)); }
     const size_t oh = (size_t)t * Hd;
     for (int i = 0; i < L; ++i) {
-      const float* hp_ = (t == 0) ? w.zero : w.h[i] + (size_t)(t - 1) * Hd; const int ldhp = (t == 0) ? Hd : n * Hd;
+      const float* hp_ = (t == 0) ? ((dec_init && dec_init[i]) ? dec_init[i] : w.zero) : w.h[i] + (size_t)(t - 1) * Hd; const int ldhp = (t == 0) ? Hd : n * Hd;
       TRY(gru_cell_train(m, st, m->dec_gru[i], B, w.o[i] + oh, n * Hd, hp_, ldhp, w.h[i] + oh, w.rh[i] + oh, w.u[i] + oh, w.xc[i] + oh,
                          w.r[i] + oh, w.c[i] + oh, n * Hd, w.o[i + 1] + oh));
     }
@@ -525,22 +553,23 @@ static SkJob sk_T(const taco_model* m, const SkW& wT, const float* dy, int lddy,
 // one GRUCell backward: dout [B,H] (+carry) -> dx [B,I] (+dres), new carry; tape slices at step t.
 // skip_a: the 'a' part (dht, dcp, dgp_u) was already produced by the k_gru_bwd_ca of the cell above.
 // next: when given, the 'c' part also runs the 'a' part of the cell below (k_gru_bwd_ca).  relu_of: mask dx by relu_of > 0.
-struct GruBwdNext { const float* carry; const float* u; const float* c; const float* hprev; float* dcp; float* dgp; };
+struct GruBwdNext { const float* carry; const float* u; const float* c; const float* hprev; float* dcp; float* dgp; int ldh; };
 static int gru_cell_backward(const TrainCtx& x, const GruT& gt, int B, const float* dout, int lddo, float* carry, bool add_carry,
                              const float* u, const float* c, const float* r, const float* hprev, int ld, float* g_dcp, float* g_dgp,
                              const float* dres, int lddres, float* dx, int lddx, const DecTape& w, bool skip_a = false,
-                             const GruBwdNext* next = nullptr, const float* relu_of = nullptr, int ldrelu = 0) {
+                             const GruBwdNext* next = nullptr, const float* relu_of = nullptr, int ldrelu = 0, int ldh = -1) {
+  if (ldh < 0) ldh = ld;
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int H = gt.H, I = gt.I, W = I + H;
   if (!skip_a)
-    hipLaunchKernelGGL(k_gru_bwd_a, EWGRID((size_t)B * H), 0, st, dout, lddo, add_carry ? carry : (const float*)nullptr, u, ld, c, ld, hprev, ld,
+    hipLaunchKernelGGL(k_gru_bwd_a, EWGRID((size_t)B * H), 0, st, dout, lddo, add_carry ? carry : (const float*)nullptr, u, ld, c, ld, hprev, ldh,
                        w.dht, g_dcp, ld, g_dgp, 2 * ld, B, H);
   { SkJob j = sk_T(m, gt.cT, g_dcp, ld, w.tmp1, W); TRY(run_skinny(st, B, &j, 1)); }
-  hipLaunchKernelGGL(k_gru_bwd_b, EWGRID((size_t)B * H), 0, st, w.tmp1, W, I, hprev, ld, r, ld, u, ld, w.dht, g_dgp, 2 * ld, w.dhp, B, H);
+  hipLaunchKernelGGL(k_gru_bwd_b, EWGRID((size_t)B * H), 0, st, w.tmp1, W, I, hprev, ldh, r, ld, u, ld, w.dht, g_dgp, 2 * ld, w.dhp, B, H);
   { SkJob j = sk_T(m, gt.gT, g_dgp, 2 * ld, w.tmp2, W); TRY(run_skinny(st, B, &j, 1)); }
   if (next)   // note: dht of the lower cell overwrites w.dht -- this cell's dht was consumed by its 'b' part above
     hipLaunchKernelGGL(k_gru_bwd_ca, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H,
-                       next->carry, next->u, ld, next->c, ld, next->hprev, ld, w.dht, next->dcp, ld, next->dgp, 2 * ld);
+                       next->carry, next->u, ld, next->c, ld, next->hprev, next->ldh, w.dht, next->dcp, ld, next->dgp, 2 * ld);
   else
     hipLaunchKernelGGL(k_gru_bwd_c, EWGRID((size_t)B * W), 0, st, w.tmp1, w.tmp2, W, I, dres, lddres, w.dhp, dx, lddx, carry, B, H, relu_of, ldrelu);
   HIPCHK(hipGetLastError());
@@ -559,7 +588,8 @@ static int gru_weight_grads(const TrainCtx& x, const std::string& name, int I, i
   return 0;
 }
 static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, const float* dmel,
-                            float* denc, const DecTape& w) {
+                            float* denc, const DecTape& w, const float* att_init = nullptr, const float* const* dec_init = nullptr,
+                            float* d_att_init = nullptr, float* const* d_dec_init = nullptr) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const TrainPacks& tp = x.t->tp;
   const taco_hparams& hp = m->hp;
@@ -580,15 +610,17 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     const size_t oh = (size_t)t * Hd, oa = (size_t)t * As;
     { SkJob j = sk_T(m, tp.frame_T, dmel + (size_t)t * rM, n * rM, w.do_[L], Hd); TRY(run_skinny(st, B, &j, 1)); }
     for (int i = L - 1; i >= 0; --i) {
-      const float* hprev = (t == 0) ? nullptr : w.h[i] + (size_t)(t - 1) * Hd;
+      auto hp_of = [&](int l) -> const float* { return (t == 0) ? ((dec_init && dec_init[l]) ? dec_init[l] : nullptr) : w.h[l] + (size_t)(t - 1) * Hd; };
+      const float* hprev = hp_of(i);
+      const int ldh = (t == 0) ? Hd : n * Hd;
       float* dx = (i == 0) ? w.g_do0 + oh : w.do_[i]; const int lddx = (i == 0) ? n * Hd : Hd;
       GruBwdNext nx; const GruBwdNext* pnx = nullptr;
       if (i > 0) {   // the cell below consumes this dx at once: its 'a' part rides in this cell's 'c' launch
-        nx.carry = w.dh[i - 1]; nx.u = w.u[i - 1] + oh; nx.c = w.c[i - 1] + oh; nx.hprev = (t == 0) ? nullptr : w.h[i - 1] + (size_t)(t - 1) * Hd;
+        nx.carry = w.dh[i - 1]; nx.u = w.u[i - 1] + oh; nx.c = w.c[i - 1] + oh; nx.hprev = hp_of(i - 1); nx.ldh = ldh;
         nx.dcp = w.g_dcp[i - 1] + oh; nx.dgp = w.g_dgp[i - 1] + 2 * oh; pnx = &nx;
       }
       TRY(gru_cell_backward(x, tp.dec[i], B, w.do_[i + 1], Hd, w.dh[i], true, w.u[i] + oh, w.c[i] + oh, w.r[i] + oh, hprev, n * Hd,
-                            w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w, i < L - 1, pnx));
+                            w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w, i < L - 1, pnx, nullptr, 0, ldh));
     }
     // concat projection: [h_att | ctx] <- d o0; the attention backward adds the two halves to dhA / dctx itself
     { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.dIn, As + D); TRY(run_skinny(st, B, &j, 1)); }
@@ -602,11 +634,11 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
       a.cat = w.dIn; a.ldcat = As + D;
       hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(64 * ATB_NW), attn_lds, st, a);
       HIPCHK(hipGetLastError()); }
-    { const float* hprev = (t == 0) ? nullptr : w.hA + (size_t)(t - 1) * As;
+    { const float* hprev = (t == 0) ? att_init : w.hA + (size_t)(t - 1) * As;
       // dx of the attention GRU = gradient of the (ReLU) prenet output: masked here, written straight to the tape
       TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
                             w.g_dgpA + 2 * oa, nullptr, 0, w.g_dz[np - 1] + (size_t)t * Pl, n * Pl, w, false, nullptr,
-                            w.pz[np - 1] + (size_t)t * Pl, n * Pl)); }
+                            w.pz[np - 1] + (size_t)t * Pl, n * Pl, (t == 0) ? As : n * As)); }
     for (int i = np - 1; i >= 1; --i) {   // prenet layers np..2: d z_{i-1} = (d z_i . W_i^T) masked by the ReLU of layer i-1 (skinny epilogue)
       const int P = hp.dec_prenet[i], Pm = hp.dec_prenet[i - 1];
       SkJob j = sk_T(m, tp.decpre_T[i], w.g_dz[i] + (size_t)t * P, n * P, w.g_dz[i - 1] + (size_t)t * Pm, n * Pm);
@@ -617,6 +649,16 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     { SkJob j = sk_T(m, tp.decpre0_ctxT, w.g_dz[0] + (size_t)t * hp.dec_prenet[0], n * hp.dec_prenet[0], w.dctx, D); TRY(run_skinny(st, B, &j, 1)); }
     HIPCHK(hipGetLastError());
   }
+  // gradients of the initial states (deepvoice: they come from the speaker layers) = the carries left after step 0
+  if (d_att_init) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, d_att_init, As, B, As);
+  for (int i = 0; i < L; ++i)
+    if (d_dec_init && d_dec_init[i]) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * Hd), 0, st, w.dh[i], Hd, d_dec_init[i], Hd, B, Hd);
+  HIPCHK(hipGetLastError());
+  // first-step terms of the recurrent kernels' gates rows: the state before step 0 is the initial state, not a tape row
+  if (att_init) TRY(run_wgrad(st, att_init, nullptr, As, w.g_dgpA, n * 2 * As, x.g("decoder/attention_gru/gates/kernel") + (size_t)Pl * 2 * As, 2 * As, B, 0, As, 2 * As));
+  for (int i = 0; i < L; ++i)
+    if (dec_init && dec_init[i])
+      TRY(run_wgrad(st, dec_init[i], nullptr, Hd, w.g_dgp[i], n * 2 * Hd, x.g("decoder/gru_" + std::to_string(i + 1) + "/gates/kernel") + (size_t)Hd * 2 * Hd, 2 * Hd, B, 0, Hd, 2 * Hd));
   // ---- weight gradients, hoisted over all steps: rows (b, t) of the [B, n, .] tapes ----
   TRY(run_wgrad(st, w.o[L], nullptr, Hd, dmel, rM, x.g("decoder/frame_projection/kernel"), rM, R, 0, Hd, rM));
   TRY(run_colsum(st, dmel, rM, nullptr, 0, nullptr, nullptr, x.g("decoder/frame_projection/bias"), nullptr, R, rM, 0));
@@ -655,7 +697,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
 // ---------------------------------------------------------------------------------------------------------------
 // whole step: forward (tape) + loss + backward
 // ---------------------------------------------------------------------------------------------------------------
-static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float* G, const int* ids, const int* lengths, const float* mel_tgt,
+static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float* G, const int* ids, const int* lengths, const int* speaker_id, const float* mel_tgt,
                                   const float* lin_tgt, const float* loss_coeff, int B, int T_in, int T_out, int prioritize_loss,
                                   int sample_rate, float* d_losses, float* mel_out, float* lin_out, float* align_out, void* ws, size_t ws_bytes,
                                   bool do_backward, bool feed_back) {
@@ -678,14 +720,20 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     TRY(run_gemm(m, st, &m->enc_prenet[i], 1, false, g));
     cur = w.pre[i]; curd = hp.enc_prenet[i];
   }
-  TRY(cbhg_forward_train(x, m->enc, t->tp.enc, "encoder_cbhg", cur, B, T_in, lengths, w.enc));
+  const bool dv = is_deepvoice(m);
+  if (dv && !speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  if (dv) TRY(spk_forward(m, st, speaker_id, B, w.spk));       // before_highway, encoder / attention / decoder initial states (tacotron.py:52-79)
+  const int L = hp.dec_layer_num;
+  const float* dec_init[4] = {nullptr, nullptr, nullptr, nullptr}; float* d_dec_init[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int i = 0; i < L && dv; ++i) { dec_init[i] = w.spk.vec[3 + i]; d_dec_init[i] = w.dvec[3 + i]; }
+  TRY(cbhg_forward_train(x, m->enc, t->tp.enc, "encoder_cbhg", cur, B, T_in, lengths, w.enc, dv ? w.spk.vec[0] : nullptr, dv ? w.spk.vec[1] : nullptr));
   const float* enc_out = w.enc.out;
   // teacher inputs: every r-th target frame (helpers.py:44): teach[b, t] = mel_targets[b, t*r + r-1]
   hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * n * Mm), 0, st, mel_tgt + (size_t)(r - 1) * Mm, r * Mm, w.teach, Mm, B * n, Mm);
   HIPCHK(hipGetLastError());
   float* mel = mel_out ? mel_out : w.mel; float* lin = lin_out ? lin_out : w.linear;
   if (feed_back && do_backward) return fail(TACO_ERR_UNSUPPORTED, "rnn_decoder_test_mode is forward-only (the reference uses it for the test model's loss, train.py:158-166)");
-  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec, feed_back));
+  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec, feed_back, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr));
   TRY(cbhg_forward_train(x, m->post, t->tp.post, "post_cbhg", mel, B, T_out, nullptr, w.post));
   { GemmCall g; g.x = w.post.out; g.ldx = 2 * hp.post_rnn_size; g.M = Mp; g.out = lin; g.ldo = F; TRY(run_gemm(m, st, &m->linear, 1, false, g)); }
   // ---- loss (tacotron.py:274-302) ----
@@ -710,9 +758,36 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   TRY(cbhg_backward(x, m->post, t->tp.post, "post_cbhg", mel, nullptr, B, T_out, nullptr, dpost, dmel_post, w.post));
   hipLaunchKernelGGL(k_add2d, EWGRID((size_t)Mp * Mm), 0, st, w.dmel, Mm, dmel_post, Mm, Mp, Mm);
   HIPCHK(hipGetLastError());
-  TRY(decoder_backward(x, enc_out, B, T_in, n, w.teach, w.dmel, w.denc, w.dec));
+  TRY(decoder_backward(x, enc_out, B, T_in, n, w.teach, w.dmel, w.denc, w.dec, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr,
+                       dv ? w.dvec[2] : nullptr, dv ? d_dec_init : nullptr));
   float* dpre = w.dpre[hp.enc_prenet_n - 1];
-  TRY(cbhg_backward(x, m->enc, t->tp.enc, "encoder_cbhg", cur, nullptr, B, T_in, lengths, w.denc, dpre, w.enc));
+  TRY(cbhg_backward(x, m->enc, t->tp.enc, "encoder_cbhg", cur, nullptr, B, T_in, lengths, w.denc, dpre, w.enc,
+                    dv ? w.spk.vec[1] : nullptr, dv ? w.dvec[1] : nullptr, dv ? w.dvec[0] : nullptr, w.rowidx));
+  if (dv) {   // speaker conditioning backward (tacotron.py:52-79)
+    std::vector<std::string> names = {kSpkNames[0], kSpkNames[1], kSpkNames[2]};
+    for (int i = 0; i < L; ++i) names.push_back("decoder_rnn_init_" + std::to_string(i + 1));
+    const int dims[3] = {hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_rnn_size * 2, hp.attention_state_size};
+    const int S = hp.speaker_embedding_size;
+    if (S == 1) {
+      for (size_t i = 0; i < names.size(); ++i) {
+        const int dd = i < 3 ? dims[i] : hp.dec_rnn_size;
+        hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * dd), 0, st, w.dvec[i], speaker_id, x.g("spk/" + names[i] + "/table"), B, dd);
+      }
+    } else {
+      HIPCHK(hipMemsetAsync(w.dspk_emb, 0, (size_t)B * S * sizeof(float), st));
+      for (size_t i = 0; i < names.size(); ++i) {
+        const int dd = i < 3 ? dims[i] : hp.dec_rnn_size;
+        hipLaunchKernelGGL(k_softsign_bwd, EWGRID((size_t)B * dd), 0, st, w.dvec[i], w.spk.vec[i], w.dzs, B * dd);
+        TRY(run_wgrad(st, w.spk.emb, nullptr, S, w.dzs, dd, x.g("spk/" + names[i] + "/kernel"), dd, B, 0, S, dd));
+        TRY(run_colsum(st, w.dzs, dd, nullptr, 0, nullptr, nullptr, x.g("spk/" + names[i] + "/bias"), nullptr, B, dd, 0));
+        SkJob j = sk_T(m, t->tp.spk_T[i], w.dzs, dd, w.dec.tmp1, S);
+        TRY(run_skinny(st, B, &j, 1));
+        hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, w.dspk_emb, S, w.dec.tmp1, S, B, S);
+      }
+      hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * S), 0, st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S);
+    }
+    HIPCHK(hipGetLastError());
+  }
   for (int i = hp.enc_prenet_n - 1; i >= 0; --i) {
     const int N = hp.enc_prenet[i];
     const std::string nm = "prenet/dense_" + std::to_string(i + 1);

@@ -2,7 +2,8 @@
 
 int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
   if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
-  if (hp->num_speakers > 1) return fail(TACO_ERR_UNSUPPORTED, "training supports single-speaker models only");
+  if (hp->num_speakers > 1 && hp->model_type != 2)
+    return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
   if (hp->attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
   taco_train* t = new taco_train();
   int rc = taco_model_create(hp, device, &t->sm);
@@ -71,14 +72,14 @@ size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_ou
 }
 
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
-                                const int32_t* d_input_lengths, const float* d_mel_targets, const float* d_linear_targets,
+                                const int32_t* d_input_lengths, const int32_t* d_speaker_id, const float* d_mel_targets, const float* d_linear_targets,
                                 const float* d_loss_coeff, int B, int T_in, int T_out, int prioritize_loss, int sample_rate, float* d_losses,
                                 float* d_mel_out, float* d_linear_out, float* d_alignments, int rnn_decoder_test_mode, void* d_workspace,
                                 size_t workspace_bytes) {
   if (!t || !d_params || !d_inputs || !d_input_lengths || !d_mel_targets || !d_linear_targets || !d_workspace)
     return fail(TACO_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->sm->device));
-  return train_forward_backward(t, (hipStream_t)hip_stream, d_params, d_grads, d_inputs, d_input_lengths, d_mel_targets, d_linear_targets,
+  return train_forward_backward(t, (hipStream_t)hip_stream, d_params, d_grads, d_inputs, d_input_lengths, d_speaker_id, d_mel_targets, d_linear_targets,
                                 d_loss_coeff, B, T_in, T_out, prioritize_loss, sample_rate, d_losses, d_mel_out, d_linear_out, d_alignments,
                                 d_workspace, workspace_bytes, d_grads != nullptr, rnn_decoder_test_mode != 0);
 }

@@ -261,15 +261,13 @@ class Tacotron(object):
         steps = T_out / r.  The parameters move into a Trainer (one flat device buffer); add_loss() / add_optimizer() expose the
         reference's attributes; train_step() is the sess.run of train.py:217-219."""
         from .trainer import Trainer
-        if num_speakers > 1:
-            raise _lib.TacoError(_lib.TACO_ERR_UNSUPPORTED, "the training path supports single-speaker models only")
         self.is_randomly_initialized = is_randomly_initialized
         self.num_speakers = num_speakers
         self.rnn_decoder_test_mode = bool(rnn_decoder_test_mode)
         if getattr(self, "_trainer", None) is None:
             w = self._weights if self._weights is not None else random_weights(self._hparams, num_speakers, seed=0)
             dev = device or ("cuda:%d" % torch.cuda.current_device())
-            self._trainer = Trainer(self._hparams, w, device=dev, is_randomly_initialized=is_randomly_initialized)
+            self._trainer = Trainer(self._hparams, w, device=dev, is_randomly_initialized=is_randomly_initialized, num_speakers=num_speakers)
             self.device = self._trainer.device
         self.inputs, self.speaker_id, self.input_lengths = inputs, speaker_id, input_lengths
         self.loss_coeff, self.mel_targets, self.linear_targets = loss_coeff, mel_targets, linear_targets
@@ -287,7 +285,8 @@ class Tacotron(object):
     def _train_forward(self):
         tr = self._trainer
         losses = tr.forward_backward(self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff,
-                                     backward=False, keep_outputs=True, rnn_decoder_test_mode=self.rnn_decoder_test_mode)
+                                     backward=False, keep_outputs=True, rnn_decoder_test_mode=self.rnn_decoder_test_mode,
+                                     speaker_id=self.speaker_id)
         self.mel_outputs, self.linear_outputs, self.alignments = tr.mel_outputs, tr.linear_outputs, tr.alignments
         self._losses = losses.clone()
         return self._losses
@@ -311,15 +310,18 @@ class Tacotron(object):
         self.gradients = tr.grads
         return self
 
-    def train_step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, loss_coeff=None):
+    def train_step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, loss_coeff=None, speaker_id=None):
         """sess.run([global_step, loss_without_coeff, optimize]) of train.py:217-219 -> (global_step, loss_without_coeff)."""
         if self.rnn_decoder_test_mode:
             raise _lib.TacoError(_lib.TACO_ERR_UNSUPPORTED, "the rnn_decoder_test_mode model is forward-only (train.py:158-166 never optimises it)")
         if inputs is not None:
             self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff = \
                 inputs, input_lengths, mel_targets, linear_targets, loss_coeff
+            if speaker_id is not None:
+                self.speaker_id = speaker_id
         tr = self._trainer
-        step, lwc = tr.train_step(self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff)
+        step, lwc = tr.train_step(self.inputs, self.input_lengths, self.mel_targets, self.linear_targets, self.loss_coeff,
+                                  speaker_id=self.speaker_id)
         l = tr.losses
         self.loss, self.mel_loss, self.linear_loss, self.loss_without_coeff = l[0], l[1], l[2], l[3]
         self.learning_rate = tr.learning_rate

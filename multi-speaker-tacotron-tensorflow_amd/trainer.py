@@ -26,14 +26,15 @@ def _st():
 
 
 class Trainer(object):
-    def __init__(self, hparams, weights, device="cuda:0", is_randomly_initialized=True):
-        """`weights`: dict canonical name -> array (weights.random_weights / load_weights)."""
+    def __init__(self, hparams, weights, device="cuda:0", is_randomly_initialized=True, num_speakers=1):
+        """`weights`: dict canonical name -> array (weights.random_weights / load_weights).  num_speakers > 1: model_type 'deepvoice'."""
         self.hp = hparams
+        self.num_speakers = int(num_speakers)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.TacoError(_lib.TACO_ERR_ARG, "the training path runs on a GPU (got device %s); there is no CPU fallback" % device)
         self._lib = _lib.load_library()
-        chp = _lib.to_c_hparams(hparams, 1)
+        chp = _lib.to_c_hparams(hparams, self.num_speakers)
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         with torch.cuda.device(self.device):
@@ -89,7 +90,7 @@ class Trainer(object):
 
     # ---- one forward (+ backward) ----
     def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False,
-                         rnn_decoder_test_mode=False):
+                         rnn_decoder_test_mode=False, speaker_id=None):
         """Fills self.grads (when backward) and returns the device tensor [4] = loss, mel_loss, linear_loss, loss_without_coeff."""
         dev = self.device
         ids = torch.as_tensor(np.asarray(inputs) if not torch.is_tensor(inputs) else inputs).to(dev, torch.int32).contiguous()
@@ -100,6 +101,10 @@ class Trainer(object):
         B, T_in = ids.shape
         T_out = mt.shape[1]
         hp = self.hp
+        spk = None
+        if self.num_speakers > 1:
+            spk = torch.zeros(B, dtype=torch.int32, device=dev) if speaker_id is None else \
+                torch.as_tensor(np.asarray(speaker_id) if not torch.is_tensor(speaker_id) else speaker_id).to(dev, torch.int32).contiguous()
         if mt.shape != (B, T_out, hp.num_mels) or lt.shape != (B, T_out, hp.num_freq):
             raise Exception("targets must be [B, T_out, num_mels] / [B, T_out, num_freq], got %s / %s" % (tuple(mt.shape), tuple(lt.shape)))
         nb = int(self._lib.taco_train_workspace_bytes(self._h, B, T_in, T_out))
@@ -112,13 +117,13 @@ class Trainer(object):
             ali = torch.empty((B, T_in, T_out // hp.reduction_factor), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(self._lib.taco_train_forward_backward(
-                self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(mt), _p(lt), _p(co),
+                self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(spk), _p(mt), _p(lt), _p(co),
                 B, T_in, T_out, int(bool(getattr(hp, "prioritize_loss", False))), int(getattr(hp, "sample_rate", 24000)), _p(self.losses),
                 _p(mel), _p(lin), _p(ali), int(bool(rnn_decoder_test_mode)), _p(self._ws), self._ws.numel()))
         self.mel_outputs, self.linear_outputs, self.alignments = mel, lin, ali
         return self.losses
 
-    def capture(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None):
+    def capture(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, speaker_id=None):
         """Record forward+backward for these shapes as ONE hipGraph over static input buffers (the ~6000 kernel launches
         of a step become one graph launch).  Later train_step() calls with the same shapes copy into the static buffers and
         replay.  Returns self."""
@@ -126,17 +131,18 @@ class Trainer(object):
         cv = lambda x, dt: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous().clone()
         self._g_in = [cv(inputs, torch.int32), cv(input_lengths, torch.int32), cv(mel_targets, torch.float32),
                       cv(linear_targets, torch.float32), None if loss_coeff is None else cv(loss_coeff, torch.float32)]
+        self._g_spk = None if speaker_id is None else cv(speaker_id, torch.int32)
         with torch.cuda.device(dev):
-            self.forward_backward(*self._g_in)            # sizes the workspace outside the capture
+            self.forward_backward(*self._g_in, speaker_id=self._g_spk)            # sizes the workspace outside the capture
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self.forward_backward(*self._g_in)
+                self.forward_backward(*self._g_in, speaker_id=self._g_spk)
         return self
 
-    def _replay(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff):
-        src = [inputs, input_lengths, mel_targets, linear_targets, loss_coeff]
-        for dst, x in zip(self._g_in, src):
+    def _replay(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id=None):
+        src = [inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id]
+        for dst, x in zip(self._g_in + [self._g_spk], src):
             if dst is None or x is None:
                 if (dst is None) != (x is None):
                     return False
@@ -149,10 +155,10 @@ class Trainer(object):
         self._graph.replay()
         return True
 
-    def train_step(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None):
+    def train_step(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, speaker_id=None):
         """train.py:217-219: one fwd+bwd+update; returns (global_step, loss_without_coeff) like the reference's fetch."""
-        if not (getattr(self, "_graph", None) is not None and self._replay(inputs, input_lengths, mel_targets, linear_targets, loss_coeff)):
-            self.forward_backward(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, backward=True)
+        if not (getattr(self, "_graph", None) is not None and self._replay(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id)):
+            self.forward_backward(inputs, input_lengths, mel_targets, linear_targets, loss_coeff, backward=True, speaker_id=speaker_id)
         allreduce_gradients(self.grads)          # no-op on one process; RCCL all-reduce of the flat bucket otherwise
         self.adam.step(self.grads)
         self.refresh()

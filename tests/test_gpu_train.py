@@ -266,3 +266,37 @@ def test_train_step_through_the_collective_path():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ses,atype", [(4, "bah_mon"), (1, "bah")])
+def test_deepvoice_multispeaker_training_gradients(ses, atype):
+    """model_type 'deepvoice' (tacotron.py:52-94): speaker embedding -> five softsign dense layers (or five per-speaker tables when
+    speaker_embedding_size == 1) -> encoder residual offset + initial states of the encoder BiGRU, the attention GRU and the decoder
+    GRUs; all of it trained.  Forward, loss and every gradient vs float64 autograd."""
+    import torch
+    import taco_amd
+    ns = 3
+    hp = tiny_hp(model_type="deepvoice", speaker_embedding_size=ses, attention_type=atype)
+    w = O.init_weights(hp, ns, 61)
+    B, T_in, T_out = 5, 10, 12
+    ids, L = O.synthetic_inputs(B, T_in, 62, ragged=True)
+    rs = np.random.RandomState(63)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    co = rs.uniform(0.5, 1.5, size=B)
+    spk = np.array([2, 0, 1, 2, 2], np.int32)
+    loss, g, out = TF.train_grads(w, hp, ids, L, mt, lt, co, speaker_id=spk, num_speakers=ns)
+    tr = taco_amd.Trainer(to_product_hp(hp), w, num_speakers=ns)
+    losses = tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 1e-5
+    assert maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4 and maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
+    worst, gn = _grad_report(tr.grad_dict(), g)
+    assert worst[0][0] < 2e-3, worst[:6]
+    spk_names = [k for k in g if k.startswith("spk/") or k == "speaker_embedding"]
+    assert spk_names and all(np.abs(g[k]).max() > 0 for k in spk_names)
+    step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)
+    assert step == 1 and np.isfinite(float(lwc))
+    tr.close()
+    with pytest.raises(Exception):
+        hp2 = tiny_hp(model_type="simple", speaker_embedding_size=4)
+        taco_amd.Trainer(to_product_hp(hp2), O.init_weights(hp2, ns, 1), num_speakers=ns)
