@@ -226,6 +226,27 @@ __global__ void k_last_row_index(const int* lengths, int* idx, int B, int T) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b < B) { const int L = lengths ? lengths[b] : T; idx[b] = b * T + (L > 0 ? L - 1 : 0); }
 }
+// bah_norm (A.9): v_hat = g * v / |v|.  Forward fold (pack refresh) and its backward: dg = (dv_hat . v) / |v| ;
+// dv = g/|v| * (dv_hat - v * (dv_hat . v) / |v|^2).  One workgroup.
+__global__ __launch_bounds__(256) void k_vnorm_fold(const float* v, const float* g, float* vhat, int A) {
+  __shared__ float sm[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < A; i += 256) s += v[i] * v[i];
+  sm[threadIdx.x] = s; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+  const float sc = g[0] / sqrtf(sm[0]);
+  for (int i = threadIdx.x; i < A; i += 256) vhat[i] = v[i] * sc;
+}
+__global__ __launch_bounds__(256) void k_vnorm_bwd(const float* v, const float* g, const float* dvhat, float* dv, float* dg, int A) {
+  __shared__ float s1[256], s2[256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < A; i += 256) { a += v[i] * v[i]; b += dvhat[i] * v[i]; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; } __syncthreads(); }
+  const float n2 = s1[0], dot = s2[0], nrm = sqrtf(n2);
+  for (int i = threadIdx.x; i < A; i += 256) dv[i] += g[0] / nrm * (dvhat[i] - v[i] * dot / n2);
+  if (threadIdx.x == 0) dg[0] += dot / nrm;
+}
 __global__ void k_sum_all(const float* x, int n, float* out) {   // out[0] += sum x  (attention score bias gradient)
   __shared__ float sm[256];
   float s = 0.f;
@@ -409,6 +430,7 @@ struct AttnBArgs {
   const float* q; const float* e;                          // tape: processed query [B, ldq], raw scores [B, lde] of step t
   const float* wqT;                                        // query kernel transposed [A, As]
   const float* keys; const float* values; const float* v; const float* score_bias;
+  const float* battn;   // attention_b (bah_norm) or null: added to the query inside the tanh
   const float* alpha; const float* alpha_prev;             // tape rows [B, ldal]
   float* dctx;          // [B, lddctx] total gradient of context(t) (also copied to the tape slice dctx_out)
   float* dctx_out;      // [B, lddco]
@@ -422,7 +444,7 @@ struct AttnBArgs {
 #define ATB_NW 16
 __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a_in) {
   AttnBArgs a = a_in;
-  PIN(a.q); PIN(a.e); PIN(a.wqT); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.score_bias); PIN(a.alpha); PIN(a.alpha_prev);
+  PIN(a.q); PIN(a.e); PIN(a.wqT); PIN(a.keys); PIN(a.values); PIN(a.v); PIN(a.score_bias); PIN(a.battn); PIN(a.alpha); PIN(a.alpha_prev);
   PIN(a.dctx); PIN(a.dctx_out); PIN(a.dalpha); PIN(a.de_out); PIN(a.dsb_acc); PIN(a.dq); PIN(a.dhq); PIN(a.cat); PIN(a.ldcat);
   // dynamic LDS (host: attn_bwd_lds_bytes): q[A4] dq[A4] dctx[D4] | p cp ss da de [T4 each] | red[ATB_NW*256]
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -438,7 +460,7 @@ __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a
   const float* vrow = a.values + (size_t)b * T * D;
   const float* al = a.alpha + (size_t)b * a.ldal;
   const float* alp = a.alpha_prev + (size_t)b * a.ldal;
-  for (int i = tid; i < A; i += 64 * ATB_NW) qs[i] = a.q[(size_t)b * a.ldq + i];
+  for (int i = tid; i < A; i += 64 * ATB_NW) qs[i] = a.q[(size_t)b * a.ldq + i] + (a.battn ? a.battn[i] : 0.f);
   for (int i = tid; i < D; i += 64 * ATB_NW) {
     float x = a.dctx[(size_t)b * a.lddctx + i];
     if (a.cat) x += a.cat[(size_t)b * a.ldcat + As + i];
@@ -587,7 +609,7 @@ __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a
 // hoisted out of the BPTT loop: dkeys[b,j,c] = v_c * sum_t de_t[j] * (1 - th^2), dv_c += sum_{b,j,t} de_t[j] * th,
 // th = tanh(keys[b,j,c] + q_t[b,c]).  Workgroup = 256 channels x ATK_J positions of one batch row, loop over the steps.
 #define ATK_J 8
-struct AttnKArgs { const float* keys; const float* q; const float* de; const float* v; float* dkeys; float* dv; int T_in, A, n; };
+struct AttnKArgs { const float* keys; const float* q; const float* de; const float* v; const float* battn; float* dkeys; float* dv; int T_in, A, n; };
 __global__ __launch_bounds__(256) void k_attention_keys_bwd(const AttnKArgs a) {
   __shared__ float sde[ATK_J];
   const int tid = threadIdx.x;
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(256) void k_attention_keys_bwd(const AttnKArgs a) {
     __syncthreads();
     if (tid < ATK_J) sde[tid] = (j0 + tid < a.T_in) ? a.de[((size_t)b * a.n + t) * a.T_in + j0 + tid] : 0.f;
     __syncthreads();
-    const float qc = cok ? a.q[((size_t)b * a.n + t) * a.A + c] : 0.f;
+    const float qc = cok ? a.q[((size_t)b * a.n + t) * a.A + c] + (a.battn ? a.battn[c] : 0.f) : 0.f;
 #pragma unroll
     for (int u = 0; u < ATK_J; ++u) {
       const float th = taco_tanh_fast(kv[u] + qc);

@@ -8,7 +8,7 @@
 //     laid out like the parameters (the single RCCL all-reduce bucket of the data-parallel step).
 // modules.py:24 calls tf.layers.dropout without training=True, so the prenet dropout is the identity in the
 // reference even when training; nothing is dropped here either.
-// Supported for training: single-speaker and multi-speaker 'deepvoice' models, attention bah / bah_mon.
+// Supported for training: single-speaker and multi-speaker 'deepvoice' models, attention bah / bah_norm / bah_mon.
 #pragma once
 
 struct CbhgT {
@@ -133,7 +133,6 @@ static int build_train_packs(taco_model* m) {
   const taco_hparams& hp = m->hp;
   if (hp.num_speakers > 1 && hp.model_type != 2)
     return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
-  if (hp.attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
   for (int i = 0; i < hp.enc_prenet_n; ++i) tp.encpre_d.push_back(make_conv_T_named(m, "prenet/dense_" + std::to_string(i + 1)));
   build_cbhg_T(m, m->enc, "encoder_cbhg", tp.enc);
   build_cbhg_T(m, m->post, "post_cbhg", tp.post);
@@ -525,7 +524,7 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
     TRY(gru_cell_train(m, st, m->att_gru, B, w.pz[np - 1] + (size_t)t * Pl, n * Pl, hAp, ldhA, w.hA + oa, w.rhA + oa, w.uA + oa, w.xcA + oa,
                        w.rA + oa, w.cA + oa, n * As, nullptr));
     { AttnArgs a; memset(&a, 0, sizeof a);
-      a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v);
+      a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
       a.score_bias = AP(m, m->att_sb); a.align = w.alpha + (size_t)(t + 1) * T_in; a.align_prev = w.alpha + (size_t)t * T_in; a.ldalign = ldal;
       a.hist = align_hist; a.ctx = w.ctx + (size_t)t * D; a.ldctx = n * D;
       a.q_out = w.g_q + (size_t)t * A; a.ldq_out = n * A; a.e_out = w.g_e + (size_t)t * T_in; a.lde_out = n * T_in;
@@ -626,7 +625,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.dIn, As + D); TRY(run_skinny(st, B, &j, 1)); }
     { AttnBArgs a; memset(&a, 0, sizeof a);
       a.q = w.g_q + (size_t)t * A; a.ldq = n * A; a.e = w.g_e + (size_t)t * T_in; a.lde = n * T_in; a.wqT = AP(m, tp.wqT);
-      a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.score_bias = AP(m, m->att_sb);
+      a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.score_bias = AP(m, m->att_sb); a.battn = AP(m, m->att_b);
       a.alpha = w.alpha + (size_t)(t + 1) * T_in; a.alpha_prev = w.alpha + (size_t)t * T_in; a.ldal = ldal;
       a.dctx = w.dctx; a.lddctx = D; a.dctx_out = w.g_dctx + (size_t)t * D; a.lddco = n * D; a.dalpha = w.dalpha;
       a.de_out = w.g_de + (size_t)t * T_in; a.ldde = n * T_in; a.dsb_acc = w.dsb_acc;
@@ -681,9 +680,17 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     }
     TRY(run_colsum(st, w.g_dz[i], P, nullptr, 0, nullptr, nullptr, x.g(nm + "/bias"), nullptr, R, P, 0));
   }
-  { AttnKArgs k; k.keys = w.keys; k.q = w.g_q; k.de = w.g_de; k.v = AP(m, m->att_v); k.dkeys = w.dkeys; k.dv = x.g("attention/attention_v");
+  { const bool vn = hp.attention_type == 1;   // bah_norm: the kernels see v_hat = g*v/|v|; its gradient is mapped back to v and g below
+    float* dvdst = vn ? w.dv_acc : x.g("attention/attention_v");
+    if (vn) HIPCHK(hipMemsetAsync(w.dv_acc, 0, (size_t)A * sizeof(float), st));
+    AttnKArgs k; k.keys = w.keys; k.q = w.g_q; k.de = w.g_de; k.v = AP(m, m->att_v); k.battn = AP(m, m->att_b); k.dkeys = w.dkeys; k.dv = dvdst;
     k.T_in = T_in; k.A = A; k.n = n;
     hipLaunchKernelGGL(k_attention_keys_bwd, dim3(cdiv(A, 256), cdiv(T_in, ATK_J), B), dim3(256), 0, st, k);
+    if (vn) {
+      hipLaunchKernelGGL(k_vnorm_bwd, dim3(1), dim3(256), 0, st, x.p("attention/attention_v"), x.p("attention/attention_g"), w.dv_acc,
+                         x.g("attention/attention_v"), x.g("attention/attention_g"), A);
+      TRY(run_colsum(st, w.g_dq, A, nullptr, 0, nullptr, nullptr, x.g("attention/attention_b"), nullptr, R, A, 0));   // b enters like the query
+    }
     HIPCHK(hipGetLastError()); }
   for (int b = 0; b < B; ++b)    // d values[b] = alpha[b]^T . dctx[b]  ([T_in x n] . [n x D])
     TRY(run_wgrad(st, w.alpha + ((size_t)b * (n + 1) + 1) * T_in, nullptr, T_in, w.g_dctx + (size_t)b * n * D, D,

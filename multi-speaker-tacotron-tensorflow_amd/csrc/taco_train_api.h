@@ -4,7 +4,6 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
   if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
   if (hp->num_speakers > 1 && hp->model_type != 2)
     return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
-  if (hp->attention_type == 1) return fail(TACO_ERR_UNSUPPORTED, "training supports attention 'bah' and 'bah_mon' only");
   taco_train* t = new taco_train();
   int rc = taco_model_create(hp, device, &t->sm);
   if (rc != 0) { delete t; return rc; }
@@ -59,6 +58,9 @@ int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params) {
   if (!t || !d_params) return fail(TACO_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->sm->device));
   hipLaunchKernelGGL(k_pack_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, t->d_map, d_params, t->sm->darena, t->arena_n, (unsigned)t->NP);
+  if (t->sm->hp.attention_type == 1)    // bah_norm: the pack holds v_hat = g * v / |v| (computed, not copied)
+    hipLaunchKernelGGL(k_vnorm_fold, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, d_params + t->poff.at("attention/attention_v"),
+                       d_params + t->poff.at("attention/attention_g"), t->sm->darena + (t->sm->att_v - 1), t->sm->hp.attention_size);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -30,7 +30,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
-@pytest.mark.parametrize("atype", ["bah_mon", "bah"])
+@pytest.mark.parametrize("atype", ["bah_mon", "bah", "bah_norm"])
 def test_training_forward_matches_oracle(atype):
     import torch
     hp, w, ids, L, mt, lt, co = _setup(atype)
@@ -57,7 +57,7 @@ def test_training_forward_matches_oracle(atype):
             assert np.array_equal(now[k], np.asarray(w[k], np.float32)), k
 
 
-@pytest.mark.parametrize("atype,ragged", [("bah_mon", True), ("bah", False)])
+@pytest.mark.parametrize("atype,ragged", [("bah_mon", True), ("bah", False), ("bah_norm", True)])
 def test_gradients_match_autograd(atype, ragged):
     import torch
     hp, w, ids, L, mt, lt, co = _setup(atype, ragged=ragged)
@@ -161,9 +161,9 @@ def test_train_step_matches_clip_and_adam_of_the_checker_and_loss_goes_down():
 
 def test_training_rejects_unsupported_configurations():
     import taco_amd
-    hp = tiny_hp(attention_type="bah_norm")
+    hp = tiny_hp(model_type="simple", speaker_embedding_size=4)
     with pytest.raises(Exception):
-        _trainer(hp, O.init_weights(hp, 1, 1))
+        taco_amd.Trainer(to_product_hp(hp), O.init_weights(hp, 2, 1), num_speakers=2)     # 'simple' speaker mode: inference only
     hp, w, ids, L, mt, lt, co = _setup()
     tr = _trainer(hp, w)
     with pytest.raises(taco_amd._lib.TacoError):
