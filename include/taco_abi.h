@@ -188,7 +188,7 @@ int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, 
  * the single all-reduce bucket of the data-parallel step.  A taco_train owns only index maps and weight packs that it
  * regenerates from the flat parameters (taco_train_refresh) after every optimizer step.
  * modules.py:24 calls tf.layers.dropout without training=True, so the reference applies no prenet dropout even when
- * training; neither does this path.  Supported: single-speaker and multi-speaker 'deepvoice' models, all three attention types. ---- */
+ * training; neither does this path.  Supported: single-speaker and multi-speaker ('simple', 'deepvoice') models, all three attention types. ---- */
 typedef struct taco_train taco_train;
 int taco_train_create(const taco_hparams* hp, int device, taco_train** out);
 void taco_train_destroy(taco_train* t);

@@ -212,6 +212,13 @@ __global__ void k_softsign_bwd(const float* dy, const float* y, float* dz, int n
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const float t = 1.f - fabsf(y[i]); dz[i] = dy[i] * t * t; }
 }
+// dst[(b*n + t)*ld + col0 + c] = src[b*C + c]: a per-utterance vector parked behind every step's row of a [B, n, .] tape ('simple' speaker mode)
+__global__ void k_tile_rows(const float* src, float* dst, int ld, int col0, int B, int n, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * n * C) return;
+  const int c = (int)(i % C); const size_t row = i / C;
+  dst[row * ld + col0 + c] = src[(row / n) * C + c];
+}
 // out[b, c] = sum_t x[b, t, c]  (gradient of a vector broadcast over time: before_highway)
 __global__ void k_time_sum(const float* x, float* out, int B, int T, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1117,6 +1117,8 @@ int taco_model_finalize(taco_model* m) {
     const int S = hp.speaker_embedding_size, F = hp.num_freq;
     HostTensor& k = m->raw["linear/kernel"];
     m->lin_spk = pack_w16(m, k.data.data(), F, 0, S, 0, F, nullptr);
+    { HostTensor head; head.shape = {(int64_t)S, (int64_t)F}; head.data.assign(k.data.begin(), k.data.begin() + (size_t)S * F); head.set = true;
+      m->raw["linear/kernel_spk"] = head; }     // kept for the training packs (transposed speaker rows)
     HostTensor rest; rest.shape = {k.shape[0] - S, (int64_t)F};
     rest.data.assign(k.data.begin() + (size_t)S * F, k.data.end());
     rest.set = true;

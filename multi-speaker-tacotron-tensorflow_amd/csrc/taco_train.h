@@ -8,7 +8,7 @@
 //     laid out like the parameters (the single RCCL all-reduce bucket of the data-parallel step).
 // modules.py:24 calls tf.layers.dropout without training=True, so the prenet dropout is the identity in the
 // reference even when training; nothing is dropped here either.
-// Supported for training: single-speaker and multi-speaker 'deepvoice' models, attention bah / bah_norm / bah_mon.
+// Supported for training: single-speaker and multi-speaker ('simple', 'deepvoice') models, attention bah / bah_norm / bah_mon.
 #pragma once
 
 struct CbhgT {
@@ -30,6 +30,7 @@ struct TrainPacks {
   SkW concat_T, frame_T;
   size_t wqT = 0;
   std::vector<SkW> spk_T;              // deepvoice speaker layers transposed: [dim_i -> S]
+  SkW lin_spk_T;                       // 'simple': speaker rows of the linear head transposed [F -> S]
 };
 
 struct taco_train {
@@ -131,8 +132,6 @@ static GruT make_gru_T(taco_model* m, const std::string& name, int I, int H) {
 static int build_train_packs(taco_model* m) {
   TrainPacks& tp = *m->tp;
   const taco_hparams& hp = m->hp;
-  if (hp.num_speakers > 1 && hp.model_type != 2)
-    return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
   for (int i = 0; i < hp.enc_prenet_n; ++i) tp.encpre_d.push_back(make_conv_T_named(m, "prenet/dense_" + std::to_string(i + 1)));
   build_cbhg_T(m, m->enc, "encoder_cbhg", tp.enc);
   build_cbhg_T(m, m->post, "post_cbhg", tp.post);
@@ -148,9 +147,10 @@ static int build_train_packs(taco_model* m) {
     const int Mm = hp.num_mels, P0 = hp.dec_prenet[0];
     std::vector<float> Tt = transpose2d(k.data.data(), Mm + D, P0, Mm, D);
     tp.decpre0_ctxT = pack_w16(m, Tt.data(), D, 0, P0, 0, D, nullptr); }
-  tp.att = make_gru_T(m, "decoder/attention_gru", d, As);
+  tp.att = make_gru_T(m, "decoder/attention_gru", d + simple_S(m), As);
   for (int i = 0; i < hp.dec_layer_num; ++i) tp.dec[i] = make_gru_T(m, "decoder/gru_" + std::to_string(i + 1), Hd, Hd);
-  tp.concat_T = pack_w16_T(m, T_(m, "decoder/concat_projection/kernel").data.data(), As + D, Hd);
+  tp.concat_T = pack_w16_T(m, T_(m, "decoder/concat_projection/kernel").data.data(), As + D + simple_S(m), Hd);
+  if (is_simple(m)) tp.lin_spk_T = pack_w16_T(m, T_(m, "linear/kernel_spk").data.data(), hp.speaker_embedding_size, hp.num_freq);
   tp.frame_T = pack_w16_T(m, T_(m, "decoder/frame_projection/kernel").data.data(), Hd, hp.num_mels * hp.reduction_factor);
   { std::vector<float> wqT = transpose2d(T_(m, "attention/query_layer/kernel").data.data(), As, A);
     tp.wqT = arena_put(m, wqT.data(), wqT.size()); }
@@ -236,8 +236,9 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size, L = hp.dec_layer_num;
   const size_t R = (size_t)B * n;
   w.keys = cv.f((size_t)B * T_in * A); w.zero = cv.f((size_t)B * std::max(std::max(hp.num_mels, As), std::max(Hd, D)));
-  w.ctx = cv.f(R * D);
-  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f(R * hp.dec_prenet[i]);
+  const int S = simple_S(m);      // 'simple': the speaker embedding rides behind the context and behind the last prenet output of every step
+  w.ctx = cv.f(R * (D + S));
+  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f(R * (hp.dec_prenet[i] + (i == hp.dec_prenet_n - 1 ? S : 0)));
   w.hA = cv.f(R * As); w.rA = cv.f(R * As); w.uA = cv.f(R * As); w.cA = cv.f(R * As); w.rhA = cv.f(R * As); w.xcA = cv.f(R * As);
   w.alpha = cv.f((size_t)B * (n + 1) * T_in); w.alpha0 = cv.f((size_t)B * T_in);   // slot 0 = initial alignments, slot t+1 = step t
   for (int i = 0; i <= L; ++i) w.o[i] = cv.f(R * Hd);
@@ -248,7 +249,7 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   for (int i = 0; i < L; ++i) w.dh[i] = cv.f((size_t)B * Hd);
   const int Wmax = std::max(std::max(As, Hd), D);
   w.dht = cv.f((size_t)B * Wmax); w.dhp = cv.f((size_t)B * Wmax);
-  const int W2 = std::max(std::max(2 * Hd, As + D), std::max(hp.dec_prenet[hp.dec_prenet_n - 1] + As, hp.num_mels + D)) + Wmax;
+  const int W2 = std::max(std::max(2 * Hd, As + D), std::max(hp.dec_prenet[hp.dec_prenet_n - 1] + As, hp.num_mels + D)) + Wmax + S;
   w.tmp1 = cv.f((size_t)B * W2); w.tmp2 = cv.f((size_t)B * W2);
   for (int i = 0; i <= L; ++i) w.do_[i] = cv.f((size_t)B * Hd);
   for (int i = 0; i < L; ++i) { w.g_dgp[i] = cv.f(R * 2 * Hd); w.g_dcp[i] = cv.f(R * Hd); }
@@ -263,6 +264,7 @@ struct TrainWs {
   DecTape dec;
   float *teach, *mel, *linear, *dmel, *dlin, *denc, *dpost, *dmel_post, *demb, *losspart;
   SpkWs spk; float* dvec[8]; float* dspk_emb; float* dzs; int* rowidx;   // deepvoice: speaker vectors, their gradients, scratch
+  float *linrv, *dlin_sum;                                               // simple: speaker term of the linear head [B, F], time-summed dlin
 };
 static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n, TrainWs& w) {
   const taco_model* m = t->sm;
@@ -283,6 +285,8 @@ static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n,
     int dmax = 1;
     for (int i = 0; i < 3 + hp.dec_layer_num; ++i) { const int dd = i < 3 ? dims[i] : hp.dec_rnn_size; w.dvec[i] = cv.f((size_t)B * dd); dmax = std::max(dmax, dd); }
     w.dspk_emb = cv.f((size_t)B * std::max(hp.speaker_embedding_size, 1)); w.dzs = cv.f((size_t)B * dmax); w.rowidx = cv.i(B); }
+  const size_t nrv = is_simple(m) ? (size_t)B * hp.num_freq : 1;
+  w.linrv = cv.f(nrv); w.dlin_sum = cv.f(nrv);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -490,7 +494,7 @@ static int gru_cell_train(const taco_model* m, hipStream_t st, const GruDec& g, 
 }
 static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, float* mel,
                                  float* align_hist, const DecTape& w, bool feed_back, const float* att_init = nullptr,
-                                 const float* const* dec_init = nullptr) {
+                                 const float* const* dec_init = nullptr, const float* spk_emb = nullptr) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const taco_hparams& hp = m->hp;
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
@@ -507,31 +511,38 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
   const int Pl = hp.dec_prenet[np - 1];
+  const int S = simple_S(m), Dc = D + S, Pz = Pl + S;      // 'simple': speaker embedding parked behind ctx and behind the last prenet output
+  if (S) {
+    if (!spk_emb) return fail(TACO_ERR_ARG, "speaker embedding missing");
+    hipLaunchKernelGGL(k_tile_rows, EWGRID((size_t)B * n * S), 0, st, spk_emb, w.ctx, Dc, D, B, n, S);
+    hipLaunchKernelGGL(k_tile_rows, EWGRID((size_t)B * n * S), 0, st, spk_emb, w.pz[np - 1], Pz, Pl, B, n, S);
+    HIPCHK(hipGetLastError());
+  }
   for (int t = 0; t < n; ++t) {
     // helpers.py:44,66,70-72: previous teacher frame; rnn_decoder_test_mode (:63-64): last of the r frames the decoder just emitted
     const float* frame = (t == 0) ? w.zero : (feed_back ? mel + (size_t)(t - 1) * rM + (rM - Mm) : teach + (size_t)(t - 1) * Mm);
     const int ldf = (t == 0) ? Mm : (feed_back ? n * rM : n * Mm);
-    const float* cprev = (t == 0) ? w.zero : w.ctx + (size_t)(t - 1) * D; const int ldcp = (t == 0) ? D : n * D;
+    const float* cprev = (t == 0) ? w.zero : w.ctx + (size_t)(t - 1) * Dc; const int ldcp = (t == 0) ? D : n * Dc;
     for (int i = 0; i < np; ++i) {
-      const int P = hp.dec_prenet[i];
-      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, cprev, ldcp, ACT_RELU, w.pz[0] + (size_t)t * P, n * P)
+      const int P = hp.dec_prenet[i], Pw = (i == np - 1) ? Pz : P;      // row width of this layer's tape
+      SkJob j = (i == 0) ? sk_linear(m, m->dec_prenet[0], frame, ldf, Mm, cprev, ldcp, ACT_RELU, w.pz[0] + (size_t)t * Pw, n * Pw)
                          : sk_linear(m, m->dec_prenet[i], w.pz[i - 1] + (size_t)t * hp.dec_prenet[i - 1], n * hp.dec_prenet[i - 1],
-                                     hp.dec_prenet[i - 1], nullptr, 0, ACT_RELU, w.pz[i] + (size_t)t * P, n * P);
+                                     hp.dec_prenet[i - 1], nullptr, 0, ACT_RELU, w.pz[i] + (size_t)t * Pw, n * Pw);
       TRY(run_skinny(st, B, &j, 1));
     }
     const float* hAp = (t == 0) ? (att_init ? att_init : w.zero) : w.hA + (size_t)(t - 1) * As; const int ldhA = (t == 0) ? As : n * As;   // tacotron.py:183-197
     const size_t oa = (size_t)t * As;
-    TRY(gru_cell_train(m, st, m->att_gru, B, w.pz[np - 1] + (size_t)t * Pl, n * Pl, hAp, ldhA, w.hA + oa, w.rhA + oa, w.uA + oa, w.xcA + oa,
+    TRY(gru_cell_train(m, st, m->att_gru, B, w.pz[np - 1] + (size_t)t * Pz, n * Pz, hAp, ldhA, w.hA + oa, w.rhA + oa, w.uA + oa, w.xcA + oa,
                        w.rA + oa, w.cA + oa, n * As, nullptr));
     { AttnArgs a; memset(&a, 0, sizeof a);
       a.hq = w.hA + oa; a.ldhq = n * As; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
       a.score_bias = AP(m, m->att_sb); a.align = w.alpha + (size_t)(t + 1) * T_in; a.align_prev = w.alpha + (size_t)t * T_in; a.ldalign = ldal;
-      a.hist = align_hist; a.ctx = w.ctx + (size_t)t * D; a.ldctx = n * D;
+      a.hist = align_hist; a.ctx = w.ctx + (size_t)t * Dc; a.ldctx = n * Dc;
       a.q_out = w.g_q + (size_t)t * A; a.ldq_out = n * A; a.e_out = w.g_e + (size_t)t * T_in; a.lde_out = n * T_in;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
       hipLaunchKernelGGL(k_attention, dim3(B), dim3(64 * ATT_NW), 0, st, a);
       HIPCHK(hipGetLastError()); }
-    { SkJob j = sk_linear(m, m->concat_proj, w.hA + oa, n * As, As, w.ctx + (size_t)t * D, n * D, ACT_NONE, w.o[0] + (size_t)t * Hd, n * Hd);
+    { SkJob j = sk_linear(m, m->concat_proj, w.hA + oa, n * As, As, w.ctx + (size_t)t * Dc, n * Dc, ACT_NONE, w.o[0] + (size_t)t * Hd, n * Hd);
       TRY(run_skinny(st, B, &j, 1)); }
     const size_t oh = (size_t)t * Hd;
     for (int i = 0; i < L; ++i) {
@@ -588,13 +599,15 @@ static int gru_weight_grads(const TrainCtx& x, const std::string& name, int I, i
 }
 static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int T_in, int n, const float* teach, const float* dmel,
                             float* denc, const DecTape& w, const float* att_init = nullptr, const float* const* dec_init = nullptr,
-                            float* d_att_init = nullptr, float* const* d_dec_init = nullptr) {
+                            float* d_att_init = nullptr, float* const* d_dec_init = nullptr, float* dspk = nullptr) {
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const TrainPacks& tp = x.t->tp;
   const taco_hparams& hp = m->hp;
   const int D = 2 * hp.enc_rnn_size, As = hp.attention_state_size, Hd = hp.dec_rnn_size, A = hp.attention_size;
   const int Mm = hp.num_mels, rM = Mm * hp.reduction_factor, L = hp.dec_layer_num, np = hp.dec_prenet_n, Pl = hp.dec_prenet[np - 1];
   const int ldal = (n + 1) * T_in, R = B * n;
+  const int S = simple_S(m), Dc = D + S, Pz = Pl + S;
+  if (S && !dspk) return fail(TACO_ERR_ARG, "speaker-embedding gradient buffer missing");
   HIPCHK(hipMemsetAsync(w.dkeys, 0, (size_t)B * T_in * A * sizeof(float), st));
   HIPCHK(hipMemsetAsync(w.dvalues, 0, (size_t)B * T_in * D * sizeof(float), st));
   HIPCHK(hipMemsetAsync(w.dv_acc, 0, (size_t)B * A * sizeof(float), st));
@@ -622,7 +635,8 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
                             w.g_dcp[i] + oh, w.g_dgp[i] + 2 * oh, w.do_[i + 1], Hd, dx, lddx, w, i < L - 1, pnx, nullptr, 0, ldh));
     }
     // concat projection: [h_att | ctx] <- d o0; the attention backward adds the two halves to dhA / dctx itself
-    { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.dIn, As + D); TRY(run_skinny(st, B, &j, 1)); }
+    { SkJob j = sk_T(m, tp.concat_T, w.g_do0 + oh, n * Hd, w.dIn, As + Dc); TRY(run_skinny(st, B, &j, 1)); }
+    if (S) hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, dspk, S, w.dIn + As + D, As + Dc, B, S);
     { AttnBArgs a; memset(&a, 0, sizeof a);
       a.q = w.g_q + (size_t)t * A; a.ldq = n * A; a.e = w.g_e + (size_t)t * T_in; a.lde = n * T_in; a.wqT = AP(m, tp.wqT);
       a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.score_bias = AP(m, m->att_sb); a.battn = AP(m, m->att_b);
@@ -630,14 +644,21 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
       a.dctx = w.dctx; a.lddctx = D; a.dctx_out = w.g_dctx + (size_t)t * D; a.lddco = n * D; a.dalpha = w.dalpha;
       a.de_out = w.g_de + (size_t)t * T_in; a.ldde = n * T_in; a.dsb_acc = w.dsb_acc;
       a.dq = w.g_dq + (size_t)t * A; a.lddq = n * A; a.dhq = w.dhA; a.lddhq = As; a.T_in = T_in; a.A = A; a.D = D; a.As = As; a.type = hp.attention_type;
-      a.cat = w.dIn; a.ldcat = As + D;
+      a.cat = w.dIn; a.ldcat = As + Dc;
       hipLaunchKernelGGL(k_attention_bwd, dim3(B), dim3(64 * ATB_NW), attn_lds, st, a);
       HIPCHK(hipGetLastError()); }
     { const float* hprev = (t == 0) ? att_init : w.hA + (size_t)(t - 1) * As;
       // dx of the attention GRU = gradient of the (ReLU) prenet output: masked here, written straight to the tape
-      TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
-                            w.g_dgpA + 2 * oa, nullptr, 0, w.g_dz[np - 1] + (size_t)t * Pl, n * Pl, w, false, nullptr,
-                            w.pz[np - 1] + (size_t)t * Pl, n * Pl, (t == 0) ? As : n * As)); }
+      if (!S) {
+        TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
+                              w.g_dgpA + 2 * oa, nullptr, 0, w.g_dz[np - 1] + (size_t)t * Pl, n * Pl, w, false, nullptr,
+                              w.pz[np - 1] + (size_t)t * Pl, n * Pl, (t == 0) ? As : n * As));
+      } else {   // 'simple': the cell input is [prenet output | speaker embedding]: split its gradient
+        TRY(gru_cell_backward(x, tp.att, B, w.dhA, As, w.dhA, false, w.uA + oa, w.cA + oa, w.rA + oa, hprev, n * As, w.g_dcpA + oa,
+                              w.g_dgpA + 2 * oa, nullptr, 0, w.dpz, Pz, w, false, nullptr, nullptr, 0, (t == 0) ? As : n * As));
+        hipLaunchKernelGGL(k_relu_bwd, EWGRID((size_t)B * Pl), 0, st, w.dpz, Pz, w.pz[np - 1] + (size_t)t * Pz, n * Pz, w.g_dz[np - 1] + (size_t)t * Pl, n * Pl, B, Pl);
+        hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, dspk, S, w.dpz + Pl, Pz, B, S);
+      } }
     for (int i = np - 1; i >= 1; --i) {   // prenet layers np..2: d z_{i-1} = (d z_i . W_i^T) masked by the ReLU of layer i-1 (skinny epilogue)
       const int P = hp.dec_prenet[i], Pm = hp.dec_prenet[i - 1];
       SkJob j = sk_T(m, tp.decpre_T[i], w.g_dz[i] + (size_t)t * P, n * P, w.g_dz[i - 1] + (size_t)t * Pm, n * Pm);
@@ -654,7 +675,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     if (d_dec_init && d_dec_init[i]) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * Hd), 0, st, w.dh[i], Hd, d_dec_init[i], Hd, B, Hd);
   HIPCHK(hipGetLastError());
   // first-step terms of the recurrent kernels' gates rows: the state before step 0 is the initial state, not a tape row
-  if (att_init) TRY(run_wgrad(st, att_init, nullptr, As, w.g_dgpA, n * 2 * As, x.g("decoder/attention_gru/gates/kernel") + (size_t)Pl * 2 * As, 2 * As, B, 0, As, 2 * As));
+  if (att_init) TRY(run_wgrad(st, att_init, nullptr, As, w.g_dgpA, n * 2 * As, x.g("decoder/attention_gru/gates/kernel") + (size_t)Pz * 2 * As, 2 * As, B, 0, As, 2 * As));
   for (int i = 0; i < L; ++i)
     if (dec_init && dec_init[i])
       TRY(run_wgrad(st, dec_init[i], nullptr, Hd, w.g_dgp[i], n * 2 * Hd, x.g("decoder/gru_" + std::to_string(i + 1) + "/gates/kernel") + (size_t)Hd * 2 * Hd, 2 * Hd, B, 0, Hd, 2 * Hd));
@@ -665,10 +686,10 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     TRY(gru_weight_grads(x, "decoder/gru_" + std::to_string(i + 1), Hd, Hd, w.o[i], Hd, w.h[i], w.rh[i], w.g_dgp[i], w.g_dcp[i], R, n));
   { float* Gk = x.g("decoder/concat_projection/kernel");
     TRY(run_wgrad(st, w.hA, nullptr, As, w.g_do0, Hd, Gk, Hd, R, 0, As, Hd));
-    TRY(run_wgrad(st, w.ctx, nullptr, D, w.g_do0, Hd, Gk + (size_t)As * Hd, Hd, R, 0, D, Hd));
+    TRY(run_wgrad(st, w.ctx, nullptr, Dc, w.g_do0, Hd, Gk + (size_t)As * Hd, Hd, R, 0, Dc, Hd));     // context (+ speaker) rows
     TRY(run_colsum(st, w.g_do0, Hd, nullptr, 0, nullptr, nullptr, x.g("decoder/concat_projection/bias"), nullptr, R, Hd, 0)); }
   TRY(run_wgrad(st, w.hA, nullptr, As, w.g_dq, A, x.g("attention/query_layer/kernel"), A, R, 0, As, A));
-  TRY(gru_weight_grads(x, "decoder/attention_gru", Pl, As, w.pz[np - 1], Pl, w.hA, w.rhA, w.g_dgpA, w.g_dcpA, R, n));
+  TRY(gru_weight_grads(x, "decoder/attention_gru", Pz, As, w.pz[np - 1], Pz, w.hA, w.rhA, w.g_dgpA, w.g_dcpA, R, n));
   for (int i = np - 1; i >= 0; --i) {
     const int P = hp.dec_prenet[i];
     const std::string nm = "decoder/prenet/dense_" + std::to_string(i + 1);
@@ -676,7 +697,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     if (i > 0) TRY(run_wgrad(st, w.pz[i - 1], nullptr, hp.dec_prenet[i - 1], w.g_dz[i], P, Gk, P, R, 0, hp.dec_prenet[i - 1], P));
     else {   // input = concat(previous teacher frame, previous context): both one step earlier, zero at t = 0
       TRY(run_wgrad(st, teach, nullptr, Mm, w.g_dz[0], P, Gk, P, R, n, Mm, P, 1, 1));
-      TRY(run_wgrad(st, w.ctx, nullptr, D, w.g_dz[0], P, Gk + (size_t)Mm * P, P, R, n, D, P, 1, 1));
+      TRY(run_wgrad(st, w.ctx, nullptr, Dc, w.g_dz[0], P, Gk + (size_t)Mm * P, P, R, n, D, P, 1, 1));
     }
     TRY(run_colsum(st, w.g_dz[i], P, nullptr, 0, nullptr, nullptr, x.g(nm + "/bias"), nullptr, R, P, 0));
   }
@@ -727,8 +748,13 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     TRY(run_gemm(m, st, &m->enc_prenet[i], 1, false, g));
     cur = w.pre[i]; curd = hp.enc_prenet[i];
   }
-  const bool dv = is_deepvoice(m);
-  if (dv && !speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  const bool dv = is_deepvoice(m), simple = is_simple(m);
+  const int S = hp.speaker_embedding_size;
+  if ((dv || simple) && !speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
+  if (simple) {      // the embedding row of every utterance (tacotron.py:47-50); concatenated in the decoder and the linear head
+    hipLaunchKernelGGL(k_gather_rows, EWGRID((size_t)B * S), 0, st, AP(m, m->spk_emb), speaker_id, B, S, w.spk.emb);
+    HIPCHK(hipGetLastError());
+  }
   if (dv) TRY(spk_forward(m, st, speaker_id, B, w.spk));       // before_highway, encoder / attention / decoder initial states (tacotron.py:52-79)
   const int L = hp.dec_layer_num;
   const float* dec_init[4] = {nullptr, nullptr, nullptr, nullptr}; float* d_dec_init[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -740,9 +766,16 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   HIPCHK(hipGetLastError());
   float* mel = mel_out ? mel_out : w.mel; float* lin = lin_out ? lin_out : w.linear;
   if (feed_back && do_backward) return fail(TACO_ERR_UNSUPPORTED, "rnn_decoder_test_mode is forward-only (the reference uses it for the test model's loss, train.py:158-166)");
-  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec, feed_back, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr));
+  TRY(decoder_forward_train(x, enc_out, B, T_in, n, w.teach, mel, align_out, w.dec, feed_back, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr,
+                            simple ? w.spk.emb : nullptr));
   TRY(cbhg_forward_train(x, m->post, t->tp.post, "post_cbhg", mel, B, T_out, nullptr, w.post));
-  { GemmCall g; g.x = w.post.out; g.ldx = 2 * hp.post_rnn_size; g.M = Mp; g.out = lin; g.ldo = F; TRY(run_gemm(m, st, &m->linear, 1, false, g)); }
+  { GemmCall g; g.x = w.post.out; g.ldx = 2 * hp.post_rnn_size; g.M = Mp; g.out = lin; g.ldo = F;
+    if (simple) {    // linear(concat(tiled speaker_embed, post)) (tacotron.py:226-235): the speaker rows give one vector per utterance
+      SkJob j = sk_linear(m, m->lin_spk, w.spk.emb, S, S, nullptr, 0, ACT_NONE, w.linrv, F);
+      TRY(run_skinny(st, B, &j, 1));
+      g.T = T_out; g.rowvec = w.linrv; g.ldrv = F;
+    }
+    TRY(run_gemm(m, st, &m->linear, 1, false, g)); }
   // ---- loss (tacotron.py:274-302) ----
   if (d_losses) TRY(taco_loss_f32((void*)st, mel, mel_tgt, lin, lin_tgt, loss_coeff, B, T_out, Mm, F, prioritize_loss, sample_rate, d_losses,
                                   w.losspart, (size_t)TR_MAXBLK * 8 * sizeof(double)));
@@ -758,7 +791,15 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   hipLaunchKernelGGL(k_l1_grad, EWGRID((size_t)Mp * F), 0, st, lin, lin_tgt, loss_coeff, Mp, T_out, F, s_lin, c_lo, c_hi, s_band, w.dlin);
   HIPCHK(hipGetLastError());
   const int Hp2 = 2 * hp.post_rnn_size;
-  TRY(run_wgrad(st, w.post.out, nullptr, Hp2, w.dlin, F, x.g("linear/kernel"), F, Mp, 0, Hp2, F));
+  TRY(run_wgrad(st, w.post.out, nullptr, Hp2, w.dlin, F, x.g("linear/kernel") + (simple ? (size_t)S * F : 0), F, Mp, 0, Hp2, F));
+  if (simple) {      // speaker rows of the head: the embedding is constant over time, so they see the time-summed gradient
+    HIPCHK(hipMemsetAsync(w.dspk_emb, 0, (size_t)B * S * sizeof(float), st));
+    hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * F), 0, st, w.dlin, w.dlin_sum, B, T_out, F);
+    HIPCHK(hipGetLastError());
+    TRY(run_wgrad(st, w.spk.emb, nullptr, S, w.dlin_sum, F, x.g("linear/kernel"), F, B, 0, S, F));
+    SkJob j = sk_T(m, t->tp.lin_spk_T, w.dlin_sum, F, w.dspk_emb, S);
+    TRY(run_skinny(st, B, &j, 1));
+  }
   TRY(run_colsum(st, w.dlin, F, nullptr, 0, nullptr, nullptr, x.g("linear/bias"), nullptr, Mp, F, 0));
   float* dpost = w.dpost; float* dmel_post = w.dmel_post;
   TRY(run_dgrad(m, st, t->tp.lin_d, w.dlin, F, Mp, 0, dpost, Hp2));
@@ -766,7 +807,11 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   hipLaunchKernelGGL(k_add2d, EWGRID((size_t)Mp * Mm), 0, st, w.dmel, Mm, dmel_post, Mm, Mp, Mm);
   HIPCHK(hipGetLastError());
   TRY(decoder_backward(x, enc_out, B, T_in, n, w.teach, w.dmel, w.denc, w.dec, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr,
-                       dv ? w.dvec[2] : nullptr, dv ? d_dec_init : nullptr));
+                       dv ? w.dvec[2] : nullptr, dv ? d_dec_init : nullptr, simple ? w.dspk_emb : nullptr));
+  if (simple) {
+    hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * S), 0, st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S);
+    HIPCHK(hipGetLastError());
+  }
   float* dpre = w.dpre[hp.enc_prenet_n - 1];
   TRY(cbhg_backward(x, m->enc, t->tp.enc, "encoder_cbhg", cur, nullptr, B, T_in, lengths, w.denc, dpre, w.enc,
                     dv ? w.spk.vec[1] : nullptr, dv ? w.dvec[1] : nullptr, dv ? w.dvec[0] : nullptr, w.rowidx));
@@ -774,7 +819,6 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     std::vector<std::string> names = {kSpkNames[0], kSpkNames[1], kSpkNames[2]};
     for (int i = 0; i < L; ++i) names.push_back("decoder_rnn_init_" + std::to_string(i + 1));
     const int dims[3] = {hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_rnn_size * 2, hp.attention_state_size};
-    const int S = hp.speaker_embedding_size;
     if (S == 1) {
       for (size_t i = 0; i < names.size(); ++i) {
         const int dd = i < 3 ? dims[i] : hp.dec_rnn_size;

@@ -2,8 +2,6 @@
 
 int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
   if (!hp || !out) return fail(TACO_ERR_ARG, "null argument");
-  if (hp->num_speakers > 1 && hp->model_type != 2)
-    return fail(TACO_ERR_UNSUPPORTED, "multi-speaker training supports model_type 'deepvoice' only ('simple' is inference-only here)");
   taco_train* t = new taco_train();
   int rc = taco_model_create(hp, device, &t->sm);
   if (rc != 0) { delete t; return rc; }

@@ -27,7 +27,7 @@ def _st():
 
 class Trainer(object):
     def __init__(self, hparams, weights, device="cuda:0", is_randomly_initialized=True, num_speakers=1):
-        """`weights`: dict canonical name -> array (weights.random_weights / load_weights).  num_speakers > 1: model_type 'deepvoice'."""
+        """`weights`: dict canonical name -> array (weights.random_weights / load_weights).  num_speakers > 1: model_type 'deepvoice' or 'simple' (pass speaker_id to every step)."""
         self.hp = hparams
         self.num_speakers = int(num_speakers)
         self.device = torch.device(device)

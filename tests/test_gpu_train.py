@@ -161,9 +161,6 @@ def test_train_step_matches_clip_and_adam_of_the_checker_and_loss_goes_down():
 
 def test_training_rejects_unsupported_configurations():
     import taco_amd
-    hp = tiny_hp(model_type="simple", speaker_embedding_size=4)
-    with pytest.raises(Exception):
-        taco_amd.Trainer(to_product_hp(hp), O.init_weights(hp, 2, 1), num_speakers=2)     # 'simple' speaker mode: inference only
     hp, w, ids, L, mt, lt, co = _setup()
     tr = _trainer(hp, w)
     with pytest.raises(taco_amd._lib.TacoError):
@@ -297,6 +294,35 @@ def test_deepvoice_multispeaker_training_gradients(ses, atype):
     step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)
     assert step == 1 and np.isfinite(float(lwc))
     tr.close()
-    with pytest.raises(Exception):
-        hp2 = tiny_hp(model_type="simple", speaker_embedding_size=4)
-        taco_amd.Trainer(to_product_hp(hp2), O.init_weights(hp2, ns, 1), num_speakers=ns)
+
+
+@pytest.mark.parametrize("ses,atype", [(4, "bah_mon"), (8, "bah_norm")])
+def test_simple_multispeaker_training_gradients(ses, atype):
+    """model_type 'simple' (tacotron.py:47-50, rnn_wrappers.py:172-195,253-263, tacotron.py:226-235): the speaker embedding row is
+    concatenated to the attention-GRU input, to the concat-projection input and (tiled over time) to the linear-head input.
+    Forward, loss and every gradient -- the widened kernels and the embedding table included -- vs float64 autograd."""
+    import torch
+    import taco_amd
+    ns = 3
+    hp = tiny_hp(model_type="simple", speaker_embedding_size=ses, attention_type=atype)
+    w = O.init_weights(hp, ns, 71)
+    B, T_in, T_out = 5, 10, 12
+    ids, L = O.synthetic_inputs(B, T_in, 72, ragged=True)
+    rs = np.random.RandomState(73)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    co = rs.uniform(0.5, 1.5, size=B)
+    spk = np.array([2, 0, 1, 2, 2], np.int32)
+    loss, g, out = TF.train_grads(w, hp, ids, L, mt, lt, co, speaker_id=spk, num_speakers=ns)
+    tr = taco_amd.Trainer(to_product_hp(hp), w, num_speakers=ns)
+    losses = tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 1e-5
+    assert maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4 and maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
+    got = tr.grad_dict()
+    worst, gn = _grad_report(got, g)
+    assert worst[0][0] < 2e-3, worst[:6]
+    assert np.abs(g["speaker_embedding"]).max() > 0 and np.abs(got["speaker_embedding"][1]).max() > 0
+    assert got["linear/kernel"].shape[0] == ses + 2 * hp.post_rnn_size and np.abs(got["linear/kernel"][:ses]).max() > 0
+    step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)
+    assert step == 1 and np.isfinite(float(lwc))
+    tr.close()
