@@ -27,6 +27,7 @@ WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speake
     "C2": (32, 128, 4, 128, 1, "single"),
     "C3": (32, 128, 4, 128, 4, "deepvoice"),
     "C5": (8, 512, 4, 1000, 1, "single"),
+    "C2x2": (64, 128, 4, 128, 1, "single"),   # two C2 batches served as one (not a BASELINE config; see DESIGN "coalescing")
 }
 
 

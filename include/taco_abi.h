@@ -230,6 +230,10 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 /* debug/test: 0 = run decoder prenet layer 1 as its own launch every step (default 1: folded into the previous step's
  * frame-projection launch through composite weights; same function, rounding differs at the 1e-7 level) */
 int taco_debug_set_fuse_prenet(taco_model* m, int on);
+/* debug/test: 0 = run the concat projection (rnn_wrappers.py:405-415 + OutputProjectionWrapper, tacotron.py:166-170) as its own
+ * launch every step (default 1: folded into the gates launch of the first decoder GRU through composite weights Wc . Wg_x; the
+ * same launch emits the projection output for the residual connection; rounding differs at the 1e-7 level) */
+int taco_debug_set_fuse_concat(taco_model* m, int on);
 /* debug/test: attention launch shape.  -1 (default): one workgroup per batch row, or -- few rows, long inputs (B <= 16, T_in >= 256) --
  * two launches with 4 slices per row; 0: always one workgroup per row; n > 1: always n slices per row */
 int taco_debug_set_att_split(taco_model* m, int slices);

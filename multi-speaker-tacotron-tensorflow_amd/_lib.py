@@ -134,6 +134,7 @@ PROTOTYPES = {
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),
     "taco_debug_set_fuse_prenet": (_I, [_P, _I]),
+    "taco_debug_set_fuse_concat": (_I, [_P, _I]),
     "taco_debug_set_att_split": (_I, [_P, _I]),
     "taco_debug_set_bf3": (_I, [_P, _I, _I]),
     "taco_model_device_errors": (_I, [_P, C.POINTER(_I)]),

@@ -29,7 +29,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // its first use inside a branch and waits for it there: dozens of serialized scalar-memory round trips
 // per launch (measured: ~5 us of a 7 us launch).  PIN forces a value to be materialised in an SGPR at
 // the top of the kernel, so all fields arrive in one batch of s_load_dwordx8/x16.
-#define PIN(x) asm volatile("" : "+s"(x))
+// Pointers are pinned as address-space-1 values: left generic (as anything read out of a by-value struct array is, and as the
+// empty asm makes every pointer), each access through them becomes a FLAT instruction, which counts on lgkmcnt as well as
+// vmcnt -- so every wait for an LDS read also drained all outstanding global prefetches.  Typed as global before the asm and
+// cast back after it, the address-space inference turns the accesses into global_load / global_store.
+template <class T> __device__ __forceinline__ void taco_pin(T*& p) {
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm volatile("" : "+s"(g));
+  p = (T*)g;
+}
+template <class T> __device__ __forceinline__ void taco_pin(T& v) { asm volatile("" : "+s"(v)); }
+#define PIN(x) taco_pin(x)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_SOFTSIGN = 4 };
 
@@ -335,17 +345,23 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define BF3_LDSW (TACO_KC + 8)    // bf16 elements per LDS row: 144 bytes = 9 x 16 B (odd) -> conflict-free ds_read_b128
 
-__device__ __forceinline__ unsigned short taco_bf16_rne(float x) {
-  const unsigned u = __float_as_uint(x);
-  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+// fp32 -> (hi, lo) bf16 halves with hi + lo ~ x to 16 mantissa bits: hi = RNE(x), lo = RNE(x - hi).  gfx950 rounds two floats
+// per instruction (v_cvt_pk_bf16_f32): 12 VALU per float4 instead of ~50 with integer rounding -- this conversion sits between
+// the two staging barriers of every chunk, where no wave of the workgroup issues MFMAs.
+typedef __bf16 taco_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float taco_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned taco_pk_bf16(float a, float b) {
+  const taco_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, taco_bf16x2));
 }
-__device__ __forceinline__ void taco_split_bf16(float x, unsigned short& hi, unsigned short& lo) {
-  hi = taco_bf16_rne(x);
-  lo = taco_bf16_rne(x - __uint_as_float((unsigned)hi << 16));
+__device__ __forceinline__ void taco_split_bf16x4(const float4 f, uint2& hi, uint2& lo) {
+  hi.x = taco_pk_bf16(f.x, f.y); hi.y = taco_pk_bf16(f.z, f.w);
+  lo.x = taco_pk_bf16(f.x - __uint_as_float(hi.x << 16), f.y - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = taco_pk_bf16(f.z - __uint_as_float(hi.y << 16), f.w - __uint_as_float(hi.y & 0xffff0000u));
 }
 
 template <int WM, int WN, int TM, int TN, bool DUAL, int GPI>
-__global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) {
+__global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
   constexpr int NTHR = 64 * WM * WN;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -400,44 +416,88 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) 
     const int idx = tid + u * NTHR;
     if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), 4 * (idx % (TACO_KC / 4)));
   }
-  // B fragments (packed weights, straight from L2) are register double-buffered in groups of GPI k16 steps: the loads of
-  // the next group are issued before the GPI x 3 x TM x TN MFMAs of the current one, and the prefetch keeps running across
-  // the LDS re-staging at every 64-channel chunk.  GPI = 2 (~770 cycles of MFMA per group at 64x256 tiles vs ~700 cycles of L2
-  // latency) pays when the grid leaves one workgroup per CU anyway; GPI = 1 keeps 2 waves/SIMD for layers with many workgroups.
-  auto load_pair = [&](int c0, int ng, int pi, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
-                       uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
-    const int j = pi / (ng / GPI), g0 = GPI * (pi - j * (ng / GPI));
+  // B fragments (packed weights, straight from L2) ping-pong between two register sets in groups of GPI k16 steps: the loads
+  // of group i+1 are issued before the GPI x 3 x TM x TN MFMAs of group i and are first waited for a full group later
+  // (s_waitcnt vmcnt(#loads of one group)), also across the LDS re-staging at every 64-channel chunk.  For that count to be
+  // static every load is unconditional: column tiles past the pack are clamped to the last one (their accumulators are
+  // never stored), and past the end of K the last group is simply fetched again.  The group count per chunk is even
+  // (kw x {2,4} k16 steps; GPI = 2 is only launched when every chunk has 4), so the two sets swap roles without copies.
+  int ntc[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) ntc[tn] = min(ntile[tn], v.NT - 1);
+  auto load_grp = [&](int c0, int pi, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
+                      uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+    const int gpc = (min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI;      // groups per tap in this chunk
+    const int j = pi / gpc, g0 = GPI * (pi - j * gpc);
 #pragma unroll
     for (int h = 0; h < GPI; ++h) {
       const int k16 = ((j * v.cin_pad16 + c0) >> 4) + g0 + h;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-        uh[h][tn] = z; ul[h][tn] = z;
-        if constexpr (DUAL) { uh2[h][tn] = z; ul2[h][tn] = z; }
-        if (ntile[tn] < v.NT) {
-          const size_t off = ((((size_t)ntile[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
-          uh[h][tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[h][tn] = *reinterpret_cast<const uint4*>(v.bl + off);
-          if constexpr (DUAL) { uh2[h][tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[h][tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
-        }
+        const size_t off = ((((size_t)ntc[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
+        uh[h][tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[h][tn] = *reinterpret_cast<const uint4*>(v.bl + off);
+        if constexpr (DUAL) { uh2[h][tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[h][tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
       }
     }
   };
-  uint4 cbh[GPI][TN], cbl[GPI][TN], cbh2[GPI][DUAL ? TN : 1], cbl2[GPI][DUAL ? TN : 1];
-  uint4 nbh[GPI][TN], nbl[GPI][TN], nbh2[GPI][DUAL ? TN : 1], nbl2[GPI][DUAL ? TN : 1];
-  load_pair(0, min(TACO_KC, v.cin_pad16) >> 4, 0, cbh, cbl, cbh2, cbl2);
+  // the group after (c0, pi): next one of this chunk, first one of the next chunk, or (end of K) this one again
+  auto load_next = [&](int c0, int pi, int npair, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
+                       uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+    int nc0 = c0, npi = pi + 1;
+    if (npi == npair) { nc0 = c0 + TACO_KC; npi = 0; }
+    if (nc0 >= v.cin_pad16) { nc0 = c0; npi = pi; }
+    load_grp(nc0, npi, uh, ul, uh2, ul2);
+  };
+  auto mma_grp = [&](int c0, int pi, const uint4 (&uh)[GPI][TN], const uint4 (&ul)[GPI][TN], const uint4 (&uh2)[GPI][DUAL ? TN : 1],
+                     const uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+    const int gpc = (min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI;
+    const int j = pi / gpc, g0 = GPI * (pi - j * gpc);
+#pragma unroll
+    for (int h = 0; h < GPI; ++h) {
+      const int g = g0 + h;
+      bf16x8 ah[TM], al[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int srow = (wm * TM + tm) * 32 + l31 + j;
+        const int off = srow * BF3_LDSW + 16 * g + 8 * lh;
+        uint4 xh = *reinterpret_cast<const uint4*>(thi + off), xl = *reinterpret_cast<const uint4*>(tlo + off);
+        const int tt = tloc[tm] + j - v.padl;   // SAME zero padding + batch-row boundary (A.2): masked, not branched
+        const unsigned keep = ((tt >= 0) && (tt < a.T)) ? 0xffffffffu : 0u;
+        xh.x &= keep; xh.y &= keep; xh.z &= keep; xh.w &= keep; xl.x &= keep; xl.y &= keep; xl.z &= keep; xl.w &= keep;
+        ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
+      }
+      // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, uh[h][tn]), bl = __builtin_bit_cast(bf16x8, ul[h][tn]);
+            const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
+            const bf16x8 bb = (term == 1) ? bl : bh;
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
+            if constexpr (DUAL) {
+              const bf16x8 bh2 = __builtin_bit_cast(bf16x8, uh2[h][tn]), bl2 = __builtin_bit_cast(bf16x8, ul2[h][tn]);
+              acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
+            }
+          }
+    }
+  };
+  uint4 pbh[GPI][TN], pbl[GPI][TN], pbh2[GPI][DUAL ? TN : 1], pbl2[GPI][DUAL ? TN : 1];     // set P
+  uint4 qbh[GPI][TN], qbl[GPI][TN], qbh2[GPI][DUAL ? TN : 1], qbl2[GPI][DUAL ? TN : 1];     // set Q
+  load_grp(0, 0, pbh, pbl, pbh2, pbl2);
   for (int c0 = 0; c0 < v.cin_pad16; c0 += TACO_KC) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
       const int idx = tid + u * NTHR;
       if (idx < nstage) {
-        ushort4 h4, l4;
-        taco_split_bf16(pre[u].x, h4.x, l4.x); taco_split_bf16(pre[u].y, h4.y, l4.y);
-        taco_split_bf16(pre[u].z, h4.z, l4.z); taco_split_bf16(pre[u].w, h4.w, l4.w);
+        uint2 h4, l4;
+        taco_split_bf16x4(pre[u], h4, l4);
         const int off = (idx / (TACO_KC / 4)) * BF3_LDSW + 4 * (idx % (TACO_KC / 4));
-        *reinterpret_cast<ushort4*>(thi + off) = h4;
-        *reinterpret_cast<ushort4*>(tlo + off) = l4;
+        *reinterpret_cast<uint2*>(thi + off) = h4;
+        *reinterpret_cast<uint2*>(tlo + off) = l4;
       }
     }
     __syncthreads();
@@ -448,54 +508,18 @@ __global__ __launch_bounds__(64 * WM * WN) void k_gemm_bf3(const GemmArgs a_in) 
         if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), c0 + TACO_KC + 4 * (idx % (TACO_KC / 4)));
       }
     }
-    // (see the pair loop below)
-    const int ng = min(TACO_KC, v.cin_pad16 - c0) >> 4;          // even: cin_pad16 is a multiple of 32
-    const int npair = v.kw * (ng / GPI);
-    for (int pi = 0; pi < npair; ++pi) {
-      // prefetch the next pair of k16 groups -- of this chunk or, across the staging barriers, of the next one
-      {
-        int nc0 = c0, npi = pi + 1, nng = ng;
-        if (npi == npair) { nc0 = c0 + TACO_KC; npi = 0; nng = min(TACO_KC, v.cin_pad16 - nc0) >> 4; }
-        if (nc0 < v.cin_pad16) load_pair(nc0, nng, npi, nbh, nbl, nbh2, nbl2);
-      }
-      const int j = pi / (ng / GPI), g0 = GPI * (pi - j * (ng / GPI));
-#pragma unroll
-      for (int h = 0; h < GPI; ++h) {
-        const int g = g0 + h;
-        bf16x8 ah[TM], al[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          const int srow = (wm * TM + tm) * 32 + l31 + j;
-          const int off = srow * BF3_LDSW + 16 * g + 8 * lh;
-          uint4 xh = *reinterpret_cast<const uint4*>(thi + off), xl = *reinterpret_cast<const uint4*>(tlo + off);
-          const int tt = tloc[tm] + j - v.padl;   // SAME zero padding + batch-row boundary (A.2)
-          if (!((tt >= 0) && (tt < a.T))) { xh = make_uint4(0u, 0u, 0u, 0u); xl = xh; }
-          ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
-        }
-        // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
-#pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-              const bf16x8 bh = __builtin_bit_cast(bf16x8, cbh[h][tn]), bl = __builtin_bit_cast(bf16x8, cbl[h][tn]);
-              const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
-              const bf16x8 bb = (term == 1) ? bl : bh;
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
-              if constexpr (DUAL) {
-                const bf16x8 bh2 = __builtin_bit_cast(bf16x8, cbh2[h][tn]), bl2 = __builtin_bit_cast(bf16x8, cbl2[h][tn]);
-                acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
-              }
-            }
-      }
-#pragma unroll
-      for (int h = 0; h < GPI; ++h)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          cbh[h][tn] = nbh[h][tn]; cbl[h][tn] = nbl[h][tn];
-          if constexpr (DUAL) { cbh2[h][tn] = nbh2[h][tn]; cbl2[h][tn] = nbl2[h][tn]; }
-        }
+    const int npair = v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI);          // even
+    for (int pi = 0; pi < npair; pi += 2) {
+      // the scheduling barriers keep the loads ahead of the MFMA group they are meant to hide behind (left alone, the
+      // scheduler sinks each load to just before its use to save registers)
+      load_next(c0, pi, npair, qbh, qbl, qbh2, qbl2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_grp(c0, pi, pbh, pbl, pbh2, pbl2);
+      __builtin_amdgcn_sched_barrier(0);
+      load_next(c0, pi + 1, npair, pbh, pbl, pbh2, pbl2);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_grp(c0, pi + 1, qbh, qbl, qbh2, qbl2);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 

@@ -104,6 +104,8 @@ struct taco_model {
   SkW query, concat_proj, frame_proj, lin_spk;   // lin_spk: speaker rows of the linear head ('simple')
   SkW prenet1_next;   // decoder prenet layer 1 of step t+1 as a function of step t's [GRU-stack output | context] (frame projection folded in)
   int fuse_prenet1 = 1;
+  GruDec gru1_fold;   // decoder GRU 1 with the concat projection folded into its x rows: input [h_att | ctx (| spk)], extra columns = o0
+  int fuse_concat = 0;
   int att_split = -1;   // -1: heuristic; 0/1: one workgroup per row; >1: k_att_scores + k_att_context with that many slices per row
   size_t att_v = 0, att_b = 0, att_sb = 0, emb = 0, spk_emb = 0, raw_wq = 0;
   std::vector<SkW> spk_dense;      // deepvoice: before_highway, enc_init, att_init, dec_init_i
@@ -435,6 +437,7 @@ static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   // prefetch depth: two k16 steps ahead when the grid leaves at most ~2 workgroups per CU (occupancy is grid-limited there)
   // (measured: 64x256 tile of proj_1, 256 workgroups: 390 -> 330 us; highway / linear with 512-1280 workgroups get slower)
   if (gpi == 0) gpi = (!DUAL && TN == 4 && (long)grid.x * grid.y * grid.z <= 320) ? 2 : 1;
+  for (int i = 0; i < nvar; ++i) if (a.v[i].cin_pad16 % 64) gpi = 1;     // GPI = 2 needs four k16 steps in every chunk (even group count)
   if (gpi == 2) hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 2>), grid, dim3(64 * WM * WN), lds, st, aa);
   else hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1>), grid, dim3(64 * WM * WN), lds, st, aa);
   HIPCHK(hipGetLastError());
@@ -545,15 +548,22 @@ static int run_skinny(hipStream_t st, int R, SkJob* jobs, int njobs, int epi = E
 
 // One GRUCell step for a decoder GRU (A.6), two launches: gates (+ x-part of candidate) then candidate.
 //   x [R, I] (ldx), h [R, H] updated in place; out_res (optional) = h' + x (ResidualWrapper, tacotron.py:172)
+//   ldh: row stride of h (0 = H).  ldxc > 0: the gates launch writes [x-part of candidate | extra columns] rows of that stride into xc
+//   (folded cells: the extra columns are the cell input itself, which the residual then reads from there instead of from x).
 static int run_gru_cell(const taco_model* m, hipStream_t st, const GruDec& g, int R, const float* x, int ldx,
-                        float* h, float* rh, float* u, float* xc, float* out_res) {
-  SkJob ja = sk_base(m, g.gx, x, ldx, g.I, h, g.H);
-  ja.H = g.H; ja.e0 = h; ja.lde0 = g.H; ja.o0 = rh; ja.ldo0 = g.H; ja.o1 = u; ja.ldo1 = g.H; ja.o2 = xc; ja.ldo2 = g.H;
+                        float* h, float* rh, float* u, float* xc, float* out_res, int ldh = 0, int ldxc = 0) {
+  if (!ldh) ldh = g.H;
+  const int lxc = ldxc ? ldxc : g.H;
+  SkJob ja = sk_base(m, g.gx, x, ldx, g.I, h, ldh);
+  ja.H = g.H; ja.e0 = h; ja.lde0 = ldh; ja.o0 = rh; ja.ldo0 = g.H; ja.o1 = u; ja.ldo1 = g.H; ja.o2 = xc; ja.ldo2 = lxc;
   TRY(run_skinny(st, R, &ja, 1, EPI_GRU_GATES));
   SkJob jb = sk_base(m, g.ch, rh, g.H, g.H, nullptr, 0);
-  jb.H = g.H; jb.e0 = h; jb.lde0 = g.H; jb.e1 = xc; jb.lde1 = g.H; jb.e2 = u; jb.lde2 = g.H;
-  jb.o0 = h; jb.ldo0 = g.H;
-  if (out_res) { jb.e3 = x; jb.lde3 = ldx; jb.o1 = out_res; jb.ldo1 = g.H; }
+  jb.H = g.H; jb.e0 = h; jb.lde0 = ldh; jb.e1 = xc; jb.lde1 = lxc; jb.e2 = u; jb.lde2 = g.H;
+  jb.o0 = h; jb.ldo0 = ldh;
+  if (out_res) {
+    if (ldxc) { jb.e3 = xc + g.H; jb.lde3 = lxc; } else { jb.e3 = x; jb.lde3 = ldx; }
+    jb.o1 = out_res; jb.ldo1 = g.H;
+  }
   TRY(run_skinny(st, R, &jb, 1, EPI_GRU_CAND));
   return 0;
 }
@@ -817,9 +827,10 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
   w.keys = cv.f((size_t)B * T_in * hp.attention_size);
   w.zero = cv.f((size_t)B * hp.num_mels);
   const int S = simple_S(m);     // 'simple': the speaker embedding rides in the last S columns of ctx and of the prenet output
-  w.ctx = cv.f((size_t)B * (D + S));
+  // [h_att | ctx (| spk)] share one row (stride As + D + S): the concat projection's input is then ONE contiguous segment
+  w.h_att = cv.f((size_t)B * (As + D + S)); w.ctx = w.h_att ? w.h_att + As : nullptr;
   for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f((size_t)B * (hp.dec_prenet[i] + S));
-  w.h_att = cv.f((size_t)B * As); w.rh = cv.f((size_t)B * Hmax); w.u = cv.f((size_t)B * Hmax); w.xc = cv.f((size_t)B * Hmax);
+  w.rh = cv.f((size_t)B * Hmax); w.u = cv.f((size_t)B * Hmax); w.xc = cv.f((size_t)B * 2 * Hmax);
   w.q = cv.f((size_t)B * hp.attention_size);
   w.align = cv.f((size_t)B * T_in);
   w.escr = cv.f((size_t)B * T_in);
@@ -849,7 +860,8 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * C, 256)), dim3(256), 0, st, src, lds, dst, C, B, C);
   };
   const bool dv = is_deepvoice(m);
-  const int S = simple_S(m), ldc = D + S, np = hp.dec_prenet_n, Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
+  const int S = simple_S(m), ldc = As + D + S, np = hp.dec_prenet_n;   // ldc: row stride of [h_att | ctx | spk]
+  const int Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
   fill(nullptr, 0, w.zero, Mm);
   hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const float*)nullptr, 0, w.ctx, ldc, B, D);
   if (S) {  // speaker_embed = embedding_lookup(table, speaker_id) (tacotron.py:44-49), parked behind ctx and behind the prenet output
@@ -857,7 +869,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * S, 256)), dim3(256), 0, st, spk->emb, S, w.ctx + D, ldc, B, S);
     hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * S, 256)), dim3(256), 0, st, spk->emb, S, w.pz[np - 1] + Ilast, ldz, B, S);
   }
-  fill(dv ? spk->vec[2] : nullptr, As, w.h_att, As);
+  hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, dv ? (const float*)spk->vec[2] : (const float*)nullptr, As, w.h_att, ldc, B, As);
   for (int i = 0; i < L; ++i) fill(dv ? spk->vec[3 + i] : nullptr, Hd, w.hd[i], Hd);
   hipLaunchKernelGGL(k_init_align, dim3(cdiv(B * T_in, 256)), dim3(256), 0, st, w.align, B, T_in, hp.attention_type == 2 ? 1 : 0);
   HIPCHK(hipGetLastError());
@@ -884,14 +896,14 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
       cur = w.pz[i]; curd = hp.dec_prenet[i];
     }
     // attention GRUCell (tacotron.py:127-130); 'simple': input = concat(prenet_out, speaker_embed) (rnn_wrappers.py:372-376)
-    TRY(run_gru_cell(m, st, m->att_gru, B, cur, ldz, w.h_att, w.rh, w.u, w.xc, nullptr));
+    TRY(run_gru_cell(m, st, m->att_gru, B, cur, ldz, w.h_att, w.rh, w.u, w.xc, nullptr, ldc));
     // query + score + normaliser + context (rnn_wrappers.py:304-341)
     // the query mat-vec runs inside the attention kernel (one launch less) when its partials fit the kernel's LDS
     const bool fuse_q = (A % 4 == 0) && A <= ATT_MAXT && A / 4 <= 64 * ATT_NW;
-    if (!fuse_q) { SkJob j = sk_linear(m, m->query, w.h_att, As, As, nullptr, 0, ACT_NONE, w.q, A);
+    if (!fuse_q) { SkJob j = sk_linear(m, m->query, w.h_att, ldc, As, nullptr, 0, ACT_NONE, w.q, A);
       TRY(run_skinny(st, B, &j, 1)); }
     { AttnArgs a; memset(&a, 0, sizeof a);
-      a.q = fuse_q ? nullptr : w.q; a.hq = w.h_att; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
+      a.q = fuse_q ? nullptr : w.q; a.hq = w.h_att; a.ldhq = ldc; a.wq = AP(m, m->raw_wq); a.As = As; a.keys = w.keys; a.values = enc_out; a.v = AP(m, m->att_v); a.battn = AP(m, m->att_b);
       a.score_bias = AP(m, m->att_sb); a.manual = manual; a.align = w.align; a.hist = align_out; a.ctx = w.ctx; a.ldctx = ldc;
       a.T_in = T_in; a.A = A; a.D = D; a.type = hp.attention_type; a.step = t; a.n_steps = n;
       // few rows x many encoder positions (C5): two launches that spread every row over att_split workgroups
@@ -904,10 +916,16 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
       }
       HIPCHK(hipGetLastError()); }
     // ConcatOutputAndAttentionWrapper + OutputProjectionWrapper (rnn_wrappers.py:405-415; tacotron.py:166-170)
-    { SkJob j = sk_linear(m, m->concat_proj, w.h_att, As, As, w.ctx, ldc, ACT_NONE, w.o[0], Hd);   // 'simple': + speaker_embed (rnn_wrappers.py:408-413)
+    // 'simple': + speaker_embed (rnn_wrappers.py:408-413).  The projection is linear, so by default it is folded into the x rows
+    // of the first decoder GRU (gru1_fold): its gates launch reads [h_att | ctx | spk] directly and also emits o0 for the residual.
+    const bool fold = m->fuse_concat && L > 0;
+    if (!fold) { SkJob j = sk_linear(m, m->concat_proj, w.h_att, ldc, As, w.ctx, ldc, ACT_NONE, w.o[0], Hd);
       TRY(run_skinny(st, B, &j, 1)); }
     // residual GRU stack (tacotron.py:171-172)
-    for (int i = 0; i < L; ++i) TRY(run_gru_cell(m, st, m->dec_gru[i], B, w.o[i], Hd, w.hd[i], w.rh, w.u, w.xc, w.o[i + 1]));
+    for (int i = 0; i < L; ++i) {
+      if (i == 0 && fold) TRY(run_gru_cell(m, st, m->gru1_fold, B, w.h_att, ldc, w.hd[0], w.rh, w.u, w.xc, w.o[1], 0, 2 * Hd));
+      else TRY(run_gru_cell(m, st, m->dec_gru[i], B, w.o[i], Hd, w.hd[i], w.rh, w.u, w.xc, w.o[i + 1]));
+    }
     // frame projection to r frames (tacotron.py:178-179), written straight into the mel buffer
     { SkJob j[2];
       j[0] = sk_linear(m, m->frame_proj, w.o[L], Hd, Hd, nullptr, 0, ACT_NONE, mel + (size_t)t * rM, ldY);
@@ -918,7 +936,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     if (after_step) TRY((*after_step)(t));
     if (dbg) {
       float* d = dbg + (size_t)t * B * dbgw;
-      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, w.h_att, As, d, dbgw, B, As);
+      hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * As, 256)), dim3(256), 0, st, w.h_att, ldc, d, dbgw, B, As);
       hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, w.ctx, ldc, d + As, dbgw, B, D);
       for (int i = 0; i < L; ++i)
         hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, w.hd[i], Hd, d + As + D + i * Hd, dbgw, B, Hd);
@@ -1172,6 +1190,40 @@ int taco_model_finalize(taco_model* m) {
     }
     m->prenet1_next = pack_w16(m, Wc.data(), P0, 0, Hd + D, 0, P0, bc.data());
   }
+  if (!m->tp && hp.dec_layer_num > 0) {
+    // Decoder GRU 1 with the concat projection folded in.  o0 = z . Wc + bc is linear in z = [h_att | ctx (| spk)], so
+    //   gates:      [o0, h] . Wg + bg = z . (Wc . Wg_x) + h . Wg_h + (bg + bc . Wg_x)
+    //   candidate x: o0 . Wk_x       = z . (Wc . Wk_x) + bc . Wk_x
+    // and o0 itself (the ResidualWrapper input, tacotron.py:172) comes out of the same launch as Hd extra columns: one dependent
+    // launch less per decoder step.  Products are formed in double and rounded once.  (Not built for the training shadow model.)
+    const int Z = As + D + simple_S(m), N4 = 4 * Hd;
+    const auto& Wc = T_(m, "decoder/concat_projection/kernel").data; const auto& bcv = T_(m, "decoder/concat_projection/bias").data;
+    const auto& gk = T_(m, "decoder/gru_1/gates/kernel").data; const auto& gb = T_(m, "decoder/gru_1/gates/bias").data;
+    const auto& ck = T_(m, "decoder/gru_1/candidate/kernel").data; const auto& cb = T_(m, "decoder/gru_1/candidate/bias").data;
+    std::vector<float> W((size_t)(Z + Hd) * N4, 0.f), bb(N4, 0.f);
+    std::vector<double> row(3 * Hd);
+    for (int z = 0; z <= Z; ++z) {      // row Z of this loop = the bias row (z . Wc replaced by bc)
+      std::fill(row.begin(), row.end(), 0.0);
+      for (int k = 0; k < Hd; ++k) {
+        const double c = (z < Z) ? (double)Wc[(size_t)z * Hd + k] : (double)bcv[k];
+        for (int j = 0; j < 2 * Hd; ++j) row[j] += c * (double)gk[(size_t)k * 2 * Hd + j];
+        for (int j = 0; j < Hd; ++j) row[2 * Hd + j] += c * (double)ck[(size_t)k * Hd + j];
+      }
+      if (z < Z) {
+        for (int j = 0; j < 3 * Hd; ++j) W[(size_t)z * N4 + j] = (float)row[j];
+        for (int j = 0; j < Hd; ++j) W[(size_t)z * N4 + 3 * Hd + j] = Wc[(size_t)z * Hd + j];
+      } else {
+        for (int j = 0; j < 2 * Hd; ++j) bb[j] = (float)(row[j] + (double)gb[j]);
+        for (int j = 0; j < Hd; ++j) { bb[2 * Hd + j] = (float)row[2 * Hd + j]; bb[3 * Hd + j] = bcv[j]; }
+      }
+    }
+    for (int k = 0; k < Hd; ++k)
+      for (int j = 0; j < 2 * Hd; ++j) W[(size_t)(Z + k) * N4 + j] = gk[(size_t)(Hd + k) * 2 * Hd + j];
+    m->gru1_fold.I = Z; m->gru1_fold.H = Hd;
+    m->gru1_fold.gx = pack_w16(m, W.data(), N4, 0, Z + Hd, 0, N4, bb.data());
+    m->gru1_fold.ch = pack_w16(m, ck.data(), Hd, Hd, Hd, 0, Hd, cb.data());
+    m->fuse_concat = 1;
+  }
   {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
     std::vector<float> v = T_(m, "attention/attention_v").data;
     if (hp.attention_type == 1) {
@@ -1289,6 +1341,12 @@ int taco_debug_set_att_split(taco_model* m, int slices) {
 int taco_debug_set_fuse_prenet(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->fuse_prenet1 = on ? 1 : 0;
+  return 0;
+}
+int taco_debug_set_fuse_concat(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  if (on && !m->gru1_fold.H) return fail(TACO_ERR_STATE, "the folded GRU pack was not built for this model");
+  m->fuse_concat = on ? 1 : 0;
   return 0;
 }
 int taco_debug_set_overlap(taco_model* m, int on) {

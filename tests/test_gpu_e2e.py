@@ -387,6 +387,30 @@ def test_prenet_layer_folded_into_frame_projection_is_the_same_function(mt, ns):
     m._lib.taco_debug_set_fuse_prenet(m._handle, 1)
 
 
+@pytest.mark.parametrize("mt,ns", [("single", 1), ("simple", 3), ("deepvoice", 2)])
+def test_concat_projection_folded_into_first_decoder_gru_is_the_same_function(mt, ns):
+    """Default: the concat projection (rnn_wrappers.py:405-415, tacotron.py:166-170) is folded into the gates launch of decoder GRU 1
+    (composite weights Wc . Wg_x; the projection output for the residual comes out of the same launch).  With the fold switched
+    off it is its own launch.  Same function up to rounding; both against the oracle."""
+    ohp = tiny_hp(model_type=mt, speaker_embedding_size=4, max_iters=11) if ns > 1 else tiny_hp(max_iters=11)
+    w = O.init_weights(ohp, ns, 79)
+    ids, L = O.synthetic_inputs(5, 12, 80, ragged=True)
+    spk = (np.arange(5) % ns).astype(np.int32) if ns > 1 else None
+    m = build_model(ohp, w, num_speakers=ns)
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, honor_stop=False)
+    folded = _run(m, ids, L, spk, honor_stop=False)
+    _check(folded, ref)
+    m._plans.clear()
+    taco_check = __import__("taco_amd")._lib.check
+    taco_check(m._lib.taco_debug_set_fuse_concat(m._handle, 0))
+    plain = _run(m, ids, L, spk, honor_stop=False)
+    _check(plain, ref)
+    for a, b in zip(folded, plain):
+        assert maxabs(a, b) < 2e-5
+    assert max(maxabs(a, b) for a, b in zip(folded, plain)) > 0        # the two paths really are different launches
+    taco_check(m._lib.taco_debug_set_fuse_concat(m._handle, 1))
+
+
 def test_edge_lengths_zero_and_full_and_no_eos():
     """synthesizer.py:120: input_lengths = argmax(ids == EOS): a row without EOS gets length 0 (its BiGRU output is all zero),
     a row whose first token is EOS too; rows at full length sit beside them in the same batch."""
