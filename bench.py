@@ -255,7 +255,7 @@ def main():
             "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
                                    % (args.workload, B, T_in, n * r, r, mt),
                        "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
-                       "arithmetic": "fp32 storage and accumulation; exact-fp32 MFMA in encoder/decoder, post-net GEMMs as 3-term split-bf16 MFMA (max err vs float64 oracle 3.5e-6)",
+                       "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, recurrent and decoder mat-vecs exact-fp32 MFMA (max err vs float64 oracle 3.4e-6)",
                        "launch": "eager" if args.eager else "hipGraph plan (%d nodes)" % plan.num_nodes,
                        "forwards_in_flight": lanes, "forward_latency_ms_alone": latency_ms},
             "roofline": {"bound": "hbm", "achieved": abytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

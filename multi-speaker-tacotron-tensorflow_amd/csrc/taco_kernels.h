@@ -360,9 +360,15 @@ __device__ __forceinline__ void taco_split_bf16x4(const float4 f, uint2& hi, uin
   lo.y = taco_pk_bf16(f.z - __uint_as_float(hi.y << 16), f.w - __uint_as_float(hi.y & 0xffff0000u));
 }
 
-template <int WM, int WN, int TM, int TN, bool DUAL, int GPI>
-__global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
-  constexpr int NTHR = 64 * WM * WN;
+// KS > 1 (small-M layers, where even 64x64 tiles leave most CUs without a workgroup): KS groups of WM x WN waves share the
+// workgroup.  Every staging round brings in KS consecutive 64-channel sub-chunks (one LDS tile each); group ks runs the same
+// tap x k16 loop over sub-chunk ks, so all groups issue MFMAs at once (KS waves per SIMD hide each other's L2 latency), and the
+// partial accumulators are summed through LDS before the epilogue.
+template <int WM, int WN, int TM, int TN, bool DUAL, int GPI, int KS = 1>
+__global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
+  constexpr int NTHR = 64 * WM * WN * KS;
+  constexpr int SUBSZ = 2 * (WM * TM * 32 + 15) * BF3_LDSW;     // bf16 elements of one sub-chunk tile (hi plane, then lo plane)
+  constexpr int KCS = TACO_KC * KS;                              // channels per staging round
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
   PIN(v.kw); PIN(v.padl); PIN(v.NT); PIN(v.N); PIN(v.coff); PIN(v.K16); PIN(v.cin_pad16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int ks = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
   int m0 = blockIdx.x * BM, row_limit = a.M;
   if (a.t_len > 0) {
     const int bb = blockIdx.x / a.tiles_per_b, tile = blockIdx.x - bb * a.tiles_per_b;
@@ -387,7 +393,8 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
   const int n0 = blockIdx.y * BN;
   const int l31 = lane & 31, lh = lane >> 5;
   const int rows = BM + v.kw - 1;
-  unsigned short* thi = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* tall = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* thi = tall + (size_t)ks * SUBSZ;                 // this wave group's tile
   unsigned short* tlo = thi + (size_t)(BM + 15) * BF3_LDSW;
 
   int tloc[TM];
@@ -408,13 +415,13 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
         for (int r = 0; r < 16; ++r) acc2[tm][tn][r] = 0.f;
     }
 
-  constexpr int NPRE = ((BM + 15) * (TACO_KC / 4) + NTHR - 1) / NTHR;
+  constexpr int NPRE = ((BM + 15) * (KCS / 4) + NTHR - 1) / NTHR;
   float4 pre[NPRE];
-  const int nstage = rows * (TACO_KC / 4);
+  const int nstage = rows * (KCS / 4);
 #pragma unroll
   for (int u = 0; u < NPRE; ++u) {
     const int idx = tid + u * NTHR;
-    if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), 4 * (idx % (TACO_KC / 4)));
+    if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (KCS / 4), 4 * (idx % (KCS / 4)));
   }
   // B fragments (packed weights, straight from L2) ping-pong between two register sets in groups of GPI k16 steps: the loads
   // of group i+1 are issued before the GPI x 3 x TM x TN MFMAs of group i and are first waited for a full group later
@@ -444,7 +451,7 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
   auto load_next = [&](int c0, int pi, int npair, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
                        uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
     int nc0 = c0, npi = pi + 1;
-    if (npi == npair) { nc0 = c0 + TACO_KC; npi = 0; }
+    if (npi == npair) { nc0 = c0 + KCS; npi = 0; }
     if (nc0 >= v.cin_pad16) { nc0 = c0; npi = pi; }
     load_grp(nc0, npi, uh, ul, uh2, ul2);
   };
@@ -486,8 +493,8 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
   };
   uint4 pbh[GPI][TN], pbl[GPI][TN], pbh2[GPI][DUAL ? TN : 1], pbl2[GPI][DUAL ? TN : 1];     // set P
   uint4 qbh[GPI][TN], qbl[GPI][TN], qbh2[GPI][DUAL ? TN : 1], qbl2[GPI][DUAL ? TN : 1];     // set Q
-  load_grp(0, 0, pbh, pbl, pbh2, pbl2);
-  for (int c0 = 0; c0 < v.cin_pad16; c0 += TACO_KC) {
+  load_grp((ks * TACO_KC < v.cin_pad16) ? ks * TACO_KC : 0, 0, pbh, pbl, pbh2, pbl2);
+  for (int cr = 0; cr < v.cin_pad16; cr += KCS) {
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
@@ -495,20 +502,22 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
       if (idx < nstage) {
         uint2 h4, l4;
         taco_split_bf16x4(pre[u], h4, l4);
-        const int off = (idx / (TACO_KC / 4)) * BF3_LDSW + 4 * (idx % (TACO_KC / 4));
-        *reinterpret_cast<uint2*>(thi + off) = h4;
-        *reinterpret_cast<uint2*>(tlo + off) = l4;
+        const int cq = idx % (KCS / 4);
+        const int off = (cq / (TACO_KC / 4)) * SUBSZ + (idx / (KCS / 4)) * BF3_LDSW + 4 * (cq % (TACO_KC / 4));
+        *reinterpret_cast<uint2*>(tall + off) = h4;
+        *reinterpret_cast<uint2*>(tall + off + (BM + 15) * BF3_LDSW) = l4;
       }
     }
     __syncthreads();
-    if (c0 + TACO_KC < v.cin_pad16) {
+    if (cr + KCS < v.cin_pad16) {
 #pragma unroll
       for (int u = 0; u < NPRE; ++u) {
         const int idx = tid + u * NTHR;
-        if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (TACO_KC / 4), c0 + TACO_KC + 4 * (idx % (TACO_KC / 4)));
+        if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (KCS / 4), cr + KCS + 4 * (idx % (KCS / 4)));
       }
     }
-    const int npair = v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI);          // even
+    const int c0 = cr + ks * TACO_KC;                                                  // this wave group's sub-chunk
+    const int npair = (c0 < v.cin_pad16) ? v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI) : 0;          // even
     for (int pi = 0; pi < npair; pi += 2) {
       // the scheduling barriers keep the loads ahead of the MFMA group they are meant to hide behind (left alone, the
       // scheduler sinks each load to just before its use to save registers)
@@ -520,6 +529,37 @@ __global__ __launch_bounds__(64 * WM * WN, (GPI == 1 && !(DUAL && TM * TN >= 4))
       __builtin_amdgcn_sched_barrier(0);
       mma_grp(c0, pi + 1, qbh, qbl, qbh2, qbl2);
       __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if constexpr (KS > 1) {     // sum the KS partial tiles through LDS (the staged tiles are dead by now)
+    constexpr int PER_WAVE = TM * TN * 16 * 64 * (DUAL ? 2 : 1);
+    __syncthreads();
+    if (ks > 0) {
+      float* dst = smem + ((size_t)(ks - 1) * WM * WN + wmn) * PER_WAVE;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            dst[((tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
+            if constexpr (DUAL) dst[TM * TN * 1024 + ((tm * TN + tn) * 16 + r) * 64 + lane] = acc2[tm][tn][r];
+          }
+    }
+    __syncthreads();
+    if (ks > 0) return;
+    for (int k2 = 1; k2 < KS; ++k2) {
+      const float* src = smem + ((size_t)(k2 - 1) * WM * WN + wmn) * PER_WAVE;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            acc[tm][tn][r] += src[((tm * TN + tn) * 16 + r) * 64 + lane];
+            if constexpr (DUAL) acc2[tm][tn][r] += src[TM * TN * 1024 + ((tm * TN + tn) * 16 + r) * 64 + lane];
+          }
     }
   }
 

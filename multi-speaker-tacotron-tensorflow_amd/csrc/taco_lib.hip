@@ -425,17 +425,24 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   return 0;
 }
 
-template <int WM, int WN, int TM, int TN, bool DUAL>
+template <int WM, int WN, int TM, int TN, bool DUAL, int KS = 1>
 static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax, int gpi = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  const size_t lds = (size_t)2 * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
+  size_t lds = (size_t)KS * 2 * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
+  if (KS > 1) lds = std::max(lds, (size_t)(KS - 1) * WM * WN * TM * TN * 16 * 64 * (DUAL ? 2 : 1) * sizeof(float));   // split-K reduction
   GemmArgs aa = a;
   int gx = cdiv(a.M, BM);
   if (a.t_len > 0) { aa.tiles_per_b = cdiv(a.t_len, BM); gx = (a.M / a.T) * aa.tiles_per_b; }
   (void)kw_max;
   dim3 grid(gx, cdiv(Nmax, BN), nvar);
+  if constexpr (KS > 1) {
+    static bool attr_set = false;      // > 64 KB of dynamic LDS has to be asked for once per kernel
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS>), grid, dim3(64 * WM * WN * KS), lds, st, aa);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   // prefetch depth: two k16 steps ahead when the grid leaves at most ~2 workgroups per CU (occupancy is grid-limited there)
-  // (measured: 64x256 tile of proj_1, 256 workgroups: 390 -> 330 us; highway / linear with 512-1280 workgroups get slower)
   if (gpi == 0) gpi = (!DUAL && TN == 4 && (long)grid.x * grid.y * grid.z <= 320) ? 2 : 1;
   for (int i = 0; i < nvar; ++i) if (a.v[i].cin_pad16 % 64) gpi = 1;     // GPI = 2 needs four k16 steps in every chunk (even group count)
   if (gpi == 2) hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 2>), grid, dim3(64 * WM * WN), lds, st, aa);
@@ -444,7 +451,6 @@ static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   return 0;
 }
 
-// cfg: 0 = 128x64 tile (4 waves), 1 = 64x64 (4 waves), 2 = 32x64 split-K 4 (8 waves), 3 = 128x128 (4 waves)
 static int pick_cfg(const taco_model* m, int M, int N, int nvar) {
   if (m->force_cfg >= 0) return m->force_cfg;
   // measured (tools/time_gemm_layers.py): the 64x64 tile (32 VGPRs, 8 waves/SIMD) beats 128x64 and 128x128 on
@@ -474,11 +480,23 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     // tiles (rows x cols): 1 = 128x64, 2 = 128x128, 3 = 64x256 (one staged 64-row tile feeds 8 MFMA column tiles)
     // measured (tools/time_gemm_layers.py): 64x256 wins when K or N is large (proj_1, linear, GRU projection), 128x64 otherwise
     const int Ktot = L0.kw * L0.cin;
-    const int tn = m->bf3_tn ? m->bf3_tn : ((Ktot >= 1024 || Nmax > 512) ? 3 : 1);
+    const long Meff = c.t_len > 0 ? (long)(c.M / a.T) * c.t_len : c.M;
+    // small-M layers (encoder, short utterances): 64x64 tiles; if even those leave most CUs idle, four wave groups per
+    // workgroup split K (tile 4 / 5).  Otherwise the measured choices of tools/time_gemm_layers.py.
+    int tn = m->bf3_tn;
+    if (!tn) {
+      const long g128 = (long)cdiv(Meff, 128) * cdiv(Nmax, 64) * nvar, g64 = (long)cdiv(Meff, 64) * cdiv(Nmax, 64) * nvar;
+      if (g128 < 384 && !((Ktot >= 1024 || Nmax > 512) && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar >= 192)) tn = (g64 >= 384) ? 4 : 5;
+      else tn = (Ktot >= 1024 || Nmax > 512) ? 3 : 1;
+    }
     if (dual) {
+      if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, true, 4>(st, a, nvar, kw_max, Nmax);
+      if (tn == 4) return launch_gemm_bf3<2, 2, 1, 1, true>(st, a, nvar, kw_max, Nmax);
       if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, true>(st, a, nvar, kw_max, Nmax);
       return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, true>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, true>(st, a, nvar, kw_max, Nmax);
     }
+    if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, false, 4>(st, a, nvar, kw_max, Nmax);
+    if (tn == 4) return launch_gemm_bf3<2, 2, 1, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, false>(st, a, nvar, kw_max, Nmax);
     return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, false>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, false>(st, a, nvar, kw_max, Nmax);
   }
@@ -1125,7 +1143,7 @@ int taco_model_finalize(taco_model* m) {
     m->enc_prenet.push_back(make_conv(m, n, false));
   }
   make_cbhg(m, m->enc, "encoder_cbhg", hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_bank_size, hp.enc_bank_channels,
-            hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width);
+            hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width, true);
   m->memory_layer = make_conv(m, "attention/memory_layer", false, false);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
             hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width, true);

@@ -10,6 +10,7 @@ from util import tiny_hp, build_model, dev, ptr, stream, maxabs
 
 pytestmark = pytest.mark.gpu
 TOL = 3e-5
+TOL_SPLIT = 1e-4   # feed-forward GEMMs run as 3-term split-bf16 products (~2^-16 relative per product): N(0,1) inputs, K = 3 x 128 channels
 
 
 @pytest.fixture(scope="module")
@@ -64,9 +65,9 @@ def test_projection_with_fused_maxpool(ctx):
     C_in = ohp.enc_bank_size * ohp.enc_bank_channel_size      # > 64 channels -> several LDS chunks
     x = rs.randn(2, 29, C_in)
     ref = O.conv1d_bn(O.maxpool_same_stride1(x, 2), w, "encoder_cbhg/proj_1", O.relu)
-    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 1, mpw=2), ref) < TOL
+    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 1, mpw=2), ref) < TOL_SPLIT
     ref = O.conv1d_bn(x, w, "encoder_cbhg/proj_1", None)
-    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 0, mpw=1), ref) < TOL
+    assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", x, 0, mpw=1), ref) < TOL_SPLIT
 
 
 @pytest.mark.parametrize("layer,rows", [("prenet/dense_2", 50), ("linear", 70), ("post_cbhg/dense", 33),
