@@ -340,7 +340,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
 // Weights are split once at finalize; activations are split when the tile is staged in LDS (two bf16
 // tiles, same bytes as one fp32 tile).  Measured error vs the float64 oracle ~1e-5 on O(1) outputs --
 // used for the post-net stages (121 of 180 GFLOP @C2), whose results feed no long recurrence.
-// Pack layout: b?[(((nt*K16 + k16)*2 + h)*32 + j)*8 + e] = W[16*k16 + 8*h + e][32*nt + j]; A fragment of lane
+// Pack layout (k16-major: the TN column tiles a wave loads for one k16 step are adjacent 1 KB blocks, so its 2 x TN loads cover
+// consecutive cache lines on different L2 channels; tile-major put them K16 KB apart -- a power of two for the usual K, i.e. all
+// on one channel, and every CU of the XCD asks for the same lines at the same time):
+//   b?[(((k16*NT + nt)*2 + h)*32 + j)*8 + e] = W[16*k16 + 8*h + e][32*nt + j]; A fragment of lane
 // (i = l&31, h = l>>5) = X[i][16*g + 8*h + e], e < 8 -- A and B use the same (h, e) -> k pairing.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define BF3_LDSW (TACO_KC + 8)    // bf16 elements per LDS row: 144 bytes = 9 x 16 B (odd) -> conflict-free ds_read_b128
@@ -360,6 +363,12 @@ __device__ __forceinline__ void taco_split_bf16x4(const float4 f, uint2& hi, uin
   lo.y = taco_pk_bf16(f.z - __uint_as_float(hi.y << 16), f.w - __uint_as_float(hi.y & 0xffff0000u));
 }
 
+#ifdef TACO_TRACE
+__device__ long long taco_trace[64];
+#define TRC(i) do { if (trc) taco_trace[i] = clock64(); } while (0)
+#else
+#define TRC(i) do {} while (0)
+#endif
 // KS > 1 (small-M layers, where even 64x64 tiles leave most CUs without a workgroup): KS groups of WM x WN waves share the
 // workgroup.  Every staging round brings in KS consecutive 64-channel sub-chunks (one LDS tile each); group ks runs the same
 // tap x k16 loop over sub-chunk ks, so all groups issue MFMAs at once (KS waves per SIMD hide each other's L2 latency), and the
@@ -369,6 +378,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
   constexpr int NTHR = 64 * WM * WN * KS;
   constexpr int SUBSZ = 2 * (WM * TM * 32 + 15) * BF3_LDSW;     // bf16 elements of one sub-chunk tile (hi plane, then lo plane)
   constexpr int KCS = TACO_KC * KS;                              // channels per staging round
+#ifdef TACO_TRACE
+  const bool trc = (blockIdx.x == gridDim.x / 2) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
+  TRC(0);
+#endif
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
@@ -404,6 +417,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ntile[tn] = (n0 >> 5) + wn * TN + tn;
 
+  // per-column epilogue operands, requested now: fetched at the end they cost one cold-miss round trip per column tile
+  float ebia[TN], ebia2[TN], esc[TN], esh[TN];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int col = n0 + (wn * TN + tn) * 32 + l31, cc = col < v.N ? col : 0;
+    ebia[tn] = v.bias ? v.bias[cc] : 0.f;
+    ebia2[tn] = (DUAL && v.bias2) ? v.bias2[cc] : 0.f;
+    esc[tn] = (!DUAL && v.bn_scale) ? v.bn_scale[cc] : 1.f;
+    esh[tn] = (!DUAL && v.bn_shift) ? v.bn_shift[cc] : 0.f;
+  }
+
   f32x16 acc[TM][TN];
   f32x16 acc2[DUAL ? TM : 1][DUAL ? TN : 1];
 #pragma unroll
@@ -429,6 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
   // static every load is unconditional: column tiles past the pack are clamped to the last one (their accumulators are
   // never stored), and past the end of K the last group is simply fetched again.  The group count per chunk is even
   // (kw x {2,4} k16 steps; GPI = 2 is only launched when every chunk has 4), so the two sets swap roles without copies.
+  TRC(1);
   int ntc[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ntc[tn] = min(ntile[tn], v.NT - 1);
@@ -441,7 +466,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
       const int k16 = ((j * v.cin_pad16 + c0) >> 4) + g0 + h;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const size_t off = ((((size_t)ntc[tn] * v.K16 + k16) * 2 + lh) * 32 + l31) * 8;
+        const size_t off = ((((size_t)k16 * v.NT + ntc[tn]) * 2 + lh) * 32 + l31) * 8;
         uh[h][tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[h][tn] = *reinterpret_cast<const uint4*>(v.bl + off);
         if constexpr (DUAL) { uh2[h][tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[h][tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
       }
@@ -494,8 +519,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
   uint4 pbh[GPI][TN], pbl[GPI][TN], pbh2[GPI][DUAL ? TN : 1], pbl2[GPI][DUAL ? TN : 1];     // set P
   uint4 qbh[GPI][TN], qbl[GPI][TN], qbh2[GPI][DUAL ? TN : 1], qbl2[GPI][DUAL ? TN : 1];     // set Q
   load_grp((ks * TACO_KC < v.cin_pad16) ? ks * TACO_KC : 0, 0, pbh, pbl, pbh2, pbl2);
+  int trci = 3;
+  TRC(2);
   for (int cr = 0; cr < v.cin_pad16; cr += KCS) {
     __syncthreads();
+    TRC(trci); ++trci;
 #pragma unroll
     for (int u = 0; u < NPRE; ++u) {
       const int idx = tid + u * NTHR;
@@ -516,6 +544,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
         if (idx < nstage) pre[u] = taco_stage_load(a, m0 - v.padl + idx / (KCS / 4), cr + KCS + 4 * (idx % (KCS / 4)));
       }
     }
+    TRC(trci); ++trci;
     const int c0 = cr + ks * TACO_KC;                                                  // this wave group's sub-chunk
     const int npair = (c0 < v.cin_pad16) ? v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI) : 0;          // even
     for (int pi = 0; pi < npair; pi += 2) {
@@ -532,6 +561,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
     }
   }
 
+  TRC(trci); ++trci;
   if constexpr (KS > 1) {     // sum the KS partial tiles through LDS (the staged tiles are dead by now)
     constexpr int PER_WAVE = TM * TN * 16 * 64 * (DUAL ? 2 : 1);
     __syncthreads();
@@ -563,43 +593,76 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
     }
   }
 
-  // epilogue: identical to k_gemm (C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5))
+  // epilogue (C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  Everything that does not depend on
+  // the element is decided once: the row mapping (time reversal of the BiGRU's backward half) per row tile, the activation and
+  // the optional operands per launch -- the common case (bias, none/ReLU, BatchNorm affine) is 16 short store sequences per
+  // tile instead of 16 copies of a five-way activation switch with its exp/tanh bodies (that version spent a third of a
+  // short-K workgroup's life here, mostly fetching instructions).
+  const bool relu = a.act == ACT_RELU, simple_act = a.act == ACT_NONE || a.act == ACT_RELU;
+  const bool extras = a.res || a.rowvec;
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+  for (int tm = 0; tm < TM; ++tm) {
+    int rowv[16], orev[16], bidx[16];
+    const int rbase = m0 + (wm * TM + tm) * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rowv[r] = rbase + (r & 3) + 8 * (r >> 2); orev[r] = rowv[r]; bidx[r] = 0; }
+    const bool anyrev = a.rev_col0 >= 0;
+    if (a.rev_col0 >= 0 || a.rowvec) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int bb = rowv[r] / a.T, tt = rowv[r] - bb * a.T;
+        bidx[r] = bb;
+        if (a.rev_col0 >= 0) {
+          const int L = a.rev_len ? a.rev_len[rowv[r] < row_limit ? bb : 0] : a.T;
+          if (tt < L) orev[r] = bb * a.T + (L - 1 - tt);
+        }
+      }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = n0 + (wn * TN + tn) * 32 + l31;
       if (col >= v.N) continue;
-      const float bia = v.bias ? v.bias[col] : 0.f;
-      float bia2 = 0.f;
-      if constexpr (DUAL) bia2 = v.bias2 ? v.bias2[col] : 0.f;
-      const float sc = v.bn_scale ? v.bn_scale[col] : 1.f;
-      const float sh = v.bn_shift ? v.bn_shift[col] : 0.f;
+      const float bia = ebia[tn];
+      const bool rev = anyrev && col >= a.rev_col0;
+      float* outc = a.out + v.coff + col;
+      // row r of this tile starts ldo floats after row r-1 of the same quad, 8 rows per quad group: pointer walks instead of
+      // a 64-bit multiply per element (only the reversed half of the BiGRU projection needs the general form)
+      float* const obase = outc + (size_t)rbase * a.ldo;
+      if constexpr (DUAL) {
+        const float bia2 = ebia2[tn];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= row_limit) continue;
-        float val;
-        if constexpr (DUAL) {
+        for (int r = 0; r < 16; ++r) {
+          if (rowv[r] >= row_limit) continue;
           const float H = fmaxf(acc[tm][tn][r] + bia, 0.f);
           const float Tg = taco_sigmoid(acc2[tm][tn][r] + bia2);
-          const float xin = a.x[(size_t)row * a.ldx + col];
-          val = H * Tg + xin * (1.f - Tg);
+          const float xin = a.x[(size_t)rowv[r] * a.ldx + col];
+          outc[(size_t)rowv[r] * a.ldo] = H * Tg + xin * (1.f - Tg);
+        }
+      } else {
+        const float sc = esc[tn], sh = esh[tn];
+        if (simple_act && !extras) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (rowv[r] >= row_limit) continue;
+            float val = acc[tm][tn][r] + bia;             // conv/dense + bias -> activation -> BatchNorm (modules.py:131)
+            val = (relu && val < 0.f) ? 0.f : val;
+            float* po = anyrev ? outc + (size_t)(rev ? orev[r] : rowv[r]) * a.ldo : obase + (size_t)((r & 3) + 8 * (r >> 2)) * a.ldo;
+            *po = val * sc + sh;
+          }
         } else {
-          val = taco_act(acc[tm][tn][r] + bia, a.act);
-          val = val * sc + sh;
-          if (a.res) val += a.res[(size_t)row * a.ldres + col];
-          if (a.rowvec) val += a.rowvec[(size_t)(row / a.T) * a.ldrv + col];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (rowv[r] >= row_limit) continue;
+            float val = taco_act(acc[tm][tn][r] + bia, a.act) * sc + sh;
+            if (a.res) val += a.res[(size_t)rowv[r] * a.ldres + col];          // modules.py:62-69
+            if (a.rowvec) val += a.rowvec[(size_t)bidx[r] * a.ldrv + col];
+            outc[(size_t)(rev ? orev[r] : rowv[r]) * a.ldo] = val;
+          }
         }
-        int orow = row;
-        if (a.rev_col0 >= 0 && col >= a.rev_col0) {
-          const int bb = row / a.T, tt = row - bb * a.T;
-          const int L = a.rev_len ? a.rev_len[bb] : a.T;
-          if (tt < L) orow = bb * a.T + (L - 1 - tt);
-        }
-        a.out[(size_t)orow * a.ldo + v.coff + col] = val;
       }
     }
+  }
+  TRC(trci);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -250,7 +250,7 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
               const float w = W[((size_t)tap * cin + c) * N + n];
               const unsigned short hb = bf16_rne_host(w);
               unsigned hu = (unsigned)hb << 16; float hf; memcpy(&hf, &hu, 4);
-              const size_t o = ((((size_t)nt * K16 + k16) * 2 + h) * 32 + j) * 8 + e;
+              const size_t o = ((((size_t)k16 * NT + nt) * 2 + h) * 32 + j) * 8 + e;   // k16-major: see the layout note in taco_kernels.h
               hi[o] = hb; lo[o] = bf16_rne_host(w - hf);
             }
           }
@@ -1361,6 +1361,9 @@ int taco_debug_set_fuse_prenet(taco_model* m, int on) {
   m->fuse_prenet1 = on ? 1 : 0;
   return 0;
 }
+#ifdef TACO_TRACE
+int taco_debug_read_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
+#endif
 int taco_debug_set_fuse_concat(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   if (on && !m->gru1_fold.H) return fail(TACO_ERR_STATE, "the folded GRU pack was not built for this model");
