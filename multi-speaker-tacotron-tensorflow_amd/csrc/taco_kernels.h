@@ -39,6 +39,12 @@ template <class T> __device__ __forceinline__ void taco_pin(T*& p) {
   p = (T*)g;
 }
 template <class T> __device__ __forceinline__ void taco_pin(T& v) { asm volatile("" : "+s"(v)); }
+// per-lane pointer: forces the value to exist at this point of the program (same address-space round trip)
+template <class T> __device__ __forceinline__ void taco_pin_v(T*& p) {
+  __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)p;
+  asm volatile("" : "+v"(g));
+  p = (T*)g;
+}
 #define PIN(x) taco_pin(x)
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2, ACT_TANH = 3, ACT_SOFTSIGN = 4 };
@@ -748,6 +754,23 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   PIN(R);
   const int row0 = blockIdx.y * (RT * 16);          // grid.y splits the batch rows into groups of RT*16
 
+  // ---- (0) row base pointers.  A gathered row index (embedding lookups) is the only load another address depends on: it goes
+  // first, so the wait the compiler puts in front of its use (unconditionally -- also when gather0 is null) finds nothing else in
+  // flight.  Behind the epilogue operands that wait serialised two memory round trips per launch. ----
+  f32x4 acc[RT];
+  const float* xp0[RT]; const float* xp1[RT]; bool rok[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r = row0 + rt * 16 + l15;
+    rok[rt] = r < R;
+    const int rr = rok[rt] ? r : 0;
+    xp0[rt] = jb.x0 + (size_t)(jb.gather0 ? jb.gather0[rr] : rr) * jb.ldx0;
+    xp1[rt] = jb.x1 ? jb.x1 + (size_t)rr * jb.ldx1 : jb.x0;
+    taco_pin_v(xp0[rt]);                  // materialise the pointer HERE (otherwise the multiply, and the wait, sink to the loop)
+  }
+  __builtin_amdgcn_sched_barrier(0);     // nothing below may be hoisted above the (possible) gather round trip
+
   // ---- (1) epilogue operands ----
   float pb[NE], pe0[NE], pe1[NE], pe2[NE], pe3[NE];
   int pL[NE]; bool pvalid[NE];
@@ -779,17 +802,6 @@ __global__ __launch_bounds__(64 * SK_NW) void k_skinny(const SkArgs a) {
   }
 
   // ---- (2) fragments, (3) MFMA ----
-  f32x4 acc[RT];
-  const float* xp0[RT]; const float* xp1[RT]; bool rok[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int r = row0 + rt * 16 + l15;
-    rok[rt] = r < R;
-    const int rr = rok[rt] ? r : 0;
-    xp0[rt] = jb.x0 + (size_t)(jb.gather0 ? jb.gather0[rr] : rr) * jb.ldx0;
-    xp1[rt] = jb.x1 ? jb.x1 + (size_t)rr * jb.ldx1 : jb.x0;
-  }
   const int ngroups = jb.Kq >> 2;
   const float* wbase = jb.wp + ((size_t)nt * jb.Kq * 16 + l15) * 4;
   for (int g0 = wave; g0 < ngroups; g0 += SK_NW * SK_CH) {
