@@ -1407,6 +1407,7 @@ struct AttnArgs {
 #define ATT_MAXT 2048
 #define ATT_JU 2     // score iterations (of 4*ATT_NW encoder positions each) whose key loads are issued together
 #define ATT_VU 8     // value rows per wave whose loads are issued together (before the normaliser)
+#define ATT_QU 16    // rows of W_q per thread whose loads are issued together (query mat-vec)
 
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
@@ -1447,9 +1448,10 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
   const int T = a.T_in;
   const float* vrow = a.values + (size_t)b * T * a.D;
 
-  // values burst for the first 256 output channels: wave w owns positions j = w + 8*i
+  // values burst for the first 256 output channels: wave w owns positions j = w + 8*i.  Requested after the scores are
+  // done (the serial normaliser covers its latency); the KEYS burst is what goes out first, before the query mat-vec.
   float4 vpre[ATT_VU];
-  {
+  auto load_values = [&]() {
     const int d = lane * 4;
 #pragma unroll
     for (int i = 0; i < ATT_VU; ++i) {
@@ -1457,15 +1459,32 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
       vpre[i] = (j < T && d < a.D) ? *reinterpret_cast<const float4*>(vrow + (size_t)j * a.D + d)
                                    : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-  }
+  };
+  const int l16 = lane & 15, grp = lane >> 4;
+  const float* krow = a.keys + (size_t)b * T * a.A;
+  float4 k4[ATT_JU][4];
+  auto load_keys = [&](int j0, int c0) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = c0 + l16 * 4 + 64 * m;
+#pragma unroll
+      for (int u = 0; u < ATT_JU; ++u) {
+        const int j = j0 + 4 * ATT_NW * u + wave * 4 + grp;
+        k4[u][m] = (c < a.A && j < T) ? *reinterpret_cast<const float4*>(krow + (size_t)j * a.A + c)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  if (!a.manual) load_keys(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
 
   if (a.manual) {
+    load_values();
     for (int j = tid; j < T; j += 64 * ATT_NW) sc[j] = a.manual[((size_t)b * a.n_steps + a.step) * T + j];
     __syncthreads();
   } else {
     // scores: e[j] = sum_a v[a] * tanh(keys[b,j,a] + q[b,a] (+ b[a]))   (_bahdanau_score, A.9)
     // 16 lanes per encoder position; lane covers channels c = (lane&15)*4 + 64*m.
-    const int l16 = lane & 15, grp = lane >> 4;
     const float* qb = a.q ? a.q + (size_t)b * a.A : cred;
     if (!a.q) {
       // q[b,:] = h_att[b,:] . W_q : 4 columns per thread, K split over thread groups, reduced through LDS
@@ -1478,10 +1497,27 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
         const float* hb = hq_row;
         const float4* wp = reinterpret_cast<const float4*>(a.wq) + cg;
         const int k1 = min(a.As, (ks + 1) * kper);
+        if ((NC & 15) == 0) {
+          // all of a thread's K-slice (16 rows at the reference widths) is requested before the first FMA: one round trip.
+          // The 16 lanes of a group share ks, so each loads ONE element of h and the group passes them round by lane shuffles.
+          for (int k = ks * kper; k < k1; k += ATT_QU) {
+            float4 w[ATT_QU];
+            const float hv = hb[min(k + (lane & 15), k1 - 1)];
+#pragma unroll
+            for (int u = 0; u < ATT_QU; ++u) w[u] = wp[(size_t)min(k + u, k1 - 1) * NC];
+#pragma unroll
+            for (int u = 0; u < ATT_QU; ++u) {
+              float x1 = __shfl(hv, (lane & 48) | u, 64);
+              x1 = (k + u < k1) ? x1 : 0.f;
+              acc.x = fmaf(x1, w[u].x, acc.x); acc.y = fmaf(x1, w[u].y, acc.y); acc.z = fmaf(x1, w[u].z, acc.z); acc.w = fmaf(x1, w[u].w, acc.w);
+            }
+          }
+        } else {
 #pragma unroll 8
-        for (int k = ks * kper; k < k1; ++k) {
-          const float4 w = wp[(size_t)k * NC]; const float xv = hb[k];
-          acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+          for (int k = ks * kper; k < k1; ++k) {
+            const float4 w = wp[(size_t)k * NC]; const float xv = hb[k];
+            acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+          }
         }
         *reinterpret_cast<float4*>(qpart + (size_t)ks * a.A + 4 * cg) = acc;
       }
@@ -1494,13 +1530,13 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
       }
       __syncthreads();
     }
-    const float* krow = a.keys + (size_t)b * T * a.A;
     for (int j0 = 0; j0 < T; j0 += 4 * ATT_NW * ATT_JU) {
       float part[ATT_JU];
 #pragma unroll
       for (int u = 0; u < ATT_JU; ++u) part[u] = 0.f;
       for (int c0 = 0; c0 < a.A; c0 += 256) {
-        float4 q4[4], v4[4], k4[ATT_JU][4];
+        if (j0 | c0) load_keys(j0, c0);
+        float4 q4[4], v4[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int c = c0 + l16 * 4 + 64 * m;
@@ -1510,12 +1546,6 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
           if (ok && a.battn) {
             const float4 b4 = *reinterpret_cast<const float4*>(a.battn + c);
             q4[m].x += b4.x; q4[m].y += b4.y; q4[m].z += b4.z; q4[m].w += b4.w;
-          }
-#pragma unroll
-          for (int u = 0; u < ATT_JU; ++u) {
-            const int j = j0 + 4 * ATT_NW * u + wave * 4 + grp;
-            k4[u][m] = (ok && j < T) ? *reinterpret_cast<const float4*>(krow + (size_t)j * a.A + c)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
           }
         }
 #pragma unroll
@@ -1534,6 +1564,7 @@ __device__ __forceinline__ void att_core(const AttnArgs& a, int b, float* sc, fl
         if (l16 == 0 && j < T) { sc[j] = p; if (a.e_out) a.e_out[(size_t)b * a.lde_out + j] = p; }
       }
     }
+    load_values();
     __syncthreads();
     if (wave == 0) {
       const int C = (T + 63) >> 6;          // contiguous elements per lane
