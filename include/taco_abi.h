@@ -199,6 +199,16 @@ int taco_train_param_offset(const taco_train* t, const char* name, size_t* offse
 /* regenerate every weight pack from the flat parameter buffer (call after loading parameters and after every update) */
 int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params);
 size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_out);
+/* Synchronised BatchNorm for the data-parallel step: with a callback set, every BatchNorm layer's batch
+ * statistics (forward: sum, centred sum of squares; backward: sum dy, sum dy*xhat) are handed to `fn` as a device vector that
+ * the host must replace, in place and ordered on the stream of the running taco_train_forward_backward call, by its sum over
+ * all `world_size` ranks (RCCL all-reduce).  Mean, variance, moving averages and the input gradient are then those of the
+ * global batch, i.e. of the reference's single-device step over the whole batch (modules.py:131, train.py:145-166); the
+ * gamma/beta gradients stay per-rank sums and are averaged by the flat gradient all-reduce like every other parameter.
+ * fn == NULL (default): statistics of this rank's rows only.  40 calls per step at the reference architecture (12 forward,
+ * 28 backward), 80 to 4096 floats each.  Not capturable into a hipGraph. */
+typedef void (*taco_sync_sum_fn)(void* user, float* d_vec, int n);
+int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int world_size);
 /* One training forward (+ backward when d_grads != NULL).  d_params is in/out: the BatchNorm moving averages are updated
  * in place (UPDATE_OPS dependency, tacotron.py:334).  d_mel_targets [B,T_out,num_mels], d_linear_targets [B,T_out,num_freq],
  * T_out a multiple of r, T_out/r <= max_iters (helpers.py:44-48).  d_losses[4] = loss, mel_loss, linear_loss,
@@ -220,8 +230,9 @@ int taco_model_device_errors(taco_model* m, int* out);
 /* test hook: 0 = per-step launches for the sequential loops, 1 (default) = persistent row-parallel kernels when they fit */
 int taco_debug_set_persistent(taco_model* m, int on);
 
-/* test hook: on = 1 (default) runs the post-net feed-forward GEMMs on the bf16 matrix cores with 3-term split
- * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128 */
+/* test hook: on = 1 (default) runs the feed-forward GEMMs of inference on the bf16 matrix cores with 3-term split
+ * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128,
+ * 3 = 64x256, 4 = 64x64, 5 = 64x64 with four wave groups splitting K inside the workgroup */
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream

@@ -86,6 +86,8 @@ def to_c_hparams(hp, num_speakers):
 _P = C.c_void_p
 _I = C.c_int
 _S = C.c_size_t
+# taco_sync_sum_fn (include/taco_abi.h): void (*)(void* user, float* d_vec, int n)
+SYNC_SUM_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int)
 
 # name -> (restype, argtypes); every symbol declared in include/taco_abi.h
 PROTOTYPES = {
@@ -128,6 +130,7 @@ PROTOTYPES = {
     "taco_train_num_params": (_S, [_P]),
     "taco_train_param_offset": (_I, [_P, C.c_char_p, C.POINTER(_S)]),
     "taco_train_refresh": (_I, [_P, _P, _P]),
+    "taco_train_set_sync_bn": (_I, [_P, _P, _P, _I]),
     "taco_train_workspace_bytes": (_S, [_P, _I, _I, _I]),
     "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),

@@ -39,6 +39,11 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
+  // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
+  // (ordered on the step's stream); null = statistics of this rank's rows only
+  void (*sync_fn)(void* user, float* d_vec, int n) = nullptr;
+  void* sync_user = nullptr;
+  int sync_world = 1;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -301,14 +306,20 @@ struct TrainCtx {
 static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, float* mu, float* rstd, float* scratch,
                     const std::string* names, const int* cols, int nnames) {
   hipStream_t st = x.st;
+  // data-parallel SyncBN: both passes are summed over the ranks, so mean and (two-pass, centred) variance are those of the global
+  // batch -- what the reference's single-device step over the whole batch computes (modules.py:131)
+  const bool sync = x.t->sync_fn && x.t->sync_world > 1;
+  const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
   HIPCHK(hipMemsetAsync(scratch, 0, (size_t)2 * C * sizeof(float), st));
   TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0));
-  hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, 1.0f / M);
+  if (sync) x.t->sync_fn(x.t->sync_user, scratch, C);
+  hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, invM);
   TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1));
+  if (sync) x.t->sync_fn(x.t->sync_user, scratch + C, C);
   int c0 = 0;
   for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix
     hipLaunchKernelGGL(k_bn_finalize, EWGRID(cols[i]), 0, st, mu + c0, scratch + C + c0, rstd + c0, x.p(names[i] + "/moving_mean"),
-                       x.p(names[i] + "/moving_variance"), cols[i], 1.0f / M, 1e-3f, 0.99f);
+                       x.p(names[i] + "/moving_variance"), cols[i], invM, 1e-3f, 0.99f);
     c0 += cols[i];
   }
   HIPCHK(hipGetLastError());
@@ -378,11 +389,22 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
 
 // one conv1d+act+BN(train) layer backward: dy (grad of BN output) -> weight/bias/gamma/beta grads and dz (pre-activation grad).
 static int conv_bn_backward(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
-                            const float* rstd, bool relu, float* dz, int lddz, int M, int C) {
+                            const float* rstd, bool relu, float* dz, int lddz, int M, int C, float* sync_scratch) {
   hipStream_t st = x.st;
   TRY(run_colsum(st, a, lda, dy, lddy, mu, rstd, x.g(name + "/beta"), x.g(name + "/gamma"), M, C, 2));
-  hipLaunchKernelGGL(k_bn_bwd, EWGRID((size_t)M * C), 0, st, a, lda, dy, lddy, mu, rstd, x.p(name + "/gamma"), x.g(name + "/beta"),
-                     x.g(name + "/gamma"), relu ? 1 : 0, dz, lddz, M, C, 1.0f / M);
+  const float* sdy = x.g(name + "/beta"); const float* sdyxh = x.g(name + "/gamma");
+  float invM = 1.0f / M;
+  if (x.t->sync_fn && x.t->sync_world > 1) {
+    // SyncBN: the two per-channel sums inside dz run over every rank's rows.  The gradient buffers keep this rank's own sums
+    // (the flat all-reduce after backward averages them like every other gradient); the global copies live in scratch.
+    HIPCHK(hipMemcpyAsync(sync_scratch, sdy, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(sync_scratch + C, sdyxh, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    x.t->sync_fn(x.t->sync_user, sync_scratch, 2 * C);
+    sdy = sync_scratch; sdyxh = sync_scratch + C;
+    invM = 1.0f / ((float)M * x.t->sync_world);
+  }
+  hipLaunchKernelGGL(k_bn_bwd, EWGRID((size_t)M * C), 0, st, a, lda, dy, lddy, mu, rstd, x.p(name + "/gamma"), sdy,
+                     sdyxh, relu ? 1 : 0, dz, lddz, M, C, invM);
   TRY(run_colsum(st, dz, lddz, nullptr, 0, nullptr, nullptr, x.g(name + "/bias"), nullptr, M, C, 0));
   HIPCHK(hipGetLastError());
   return 0;
@@ -459,7 +481,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     const std::string n = sc + "/proj_" + std::to_string(i + 1);
     const int N = c.proj_dim[i];
     const float* xin = (i == 0) ? w.pool : w.py[i - 1]; const int xd = (i == 0) ? KC : c.proj_dim[i - 1];
-    TRY(conv_bn_backward(x, n, w.pa[i], N, dcur, N, w.pmu[i], w.prs[i], i + 1 != c.nproj, dalt, N, M, N));
+    TRY(conv_bn_backward(x, n, w.pa[i], N, dcur, N, w.pmu[i], w.prs[i], i + 1 != c.nproj, dalt, N, M, N, w.stat));
     TRY(run_wgrad(st, xin, nullptr, xd, dalt, N, x.g(n + "/kernel"), N, M, T, xd, N, c.pw, (c.pw - 1) / 2));
     float* dnext = (i == 0) ? w.dbig0 : dcur;
     TRY(run_dgrad(m, st, ct.proj_d[i], dalt, N, M, T, dnext, xd));
@@ -471,7 +493,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
-    TRY(conv_bn_backward(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C));
+    TRY(conv_bn_backward(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat));
     TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
     TRY(run_dgrad(m, st, ct.bank_d[bi], w.dbig0 + c0, KC, M, T, din, c.in_dim, din, c.in_dim));   // accumulates onto the residual path
   }

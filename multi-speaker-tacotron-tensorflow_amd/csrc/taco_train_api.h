@@ -42,6 +42,13 @@ void taco_train_destroy(taco_train* t) {
 }
 
 taco_model* taco_train_model(taco_train* t) { return t ? t->sm : nullptr; }
+
+int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int world_size) {
+  if (!t) return fail(TACO_ERR_ARG, "null argument");
+  if (fn && world_size < 1) return fail(TACO_ERR_ARG, "world_size %d", world_size);
+  t->sync_fn = fn; t->sync_user = user; t->sync_world = fn ? world_size : 1;
+  return 0;
+}
 size_t taco_train_num_params(const taco_train* t) { return t ? t->NP : 0; }
 
 int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset) {

@@ -60,7 +60,36 @@ class Trainer(object):
         self.adam = FlatAdam(self.params, g("initial_learning_rate", 0.002), g("adam_beta1", 0.9), g("adam_beta2", 0.999), 1e-8,
                              g("decay_learning_rate_mode", 0), is_randomly_initialized, 1.0)
         self._ws = None
+        self._sync_cb = None
+        self._sync_err = None
         self.mel_outputs = self.linear_outputs = self.alignments = None
+
+    # ---- data-parallel SyncBN ----
+    def enable_sync_bn(self, on=True, group=None):
+        """BatchNorm statistics over the GLOBAL batch of the data-parallel group: every per-channel sum of the BatchNorm layers
+        (forward and backward) is all-reduced over `group` (RCCL on GPUs) inside the step, so a step over W shards equals the
+        reference's single-device step over the whole batch (modules.py:131, train.py:145-166) -- up to summation order.  Without it
+        (default) each rank normalises with its own rows.  Returns True when synchronisation is active (world size > 1)."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (on and dist.is_available() and dist.is_initialized()) else 1
+        if world <= 1:
+            _lib.check(self._lib.taco_train_set_sync_bn(self._h, None, None, 1))
+            self._sync_cb = None
+            return False
+        if getattr(self, "_graph", None) is not None:
+            raise _lib.TacoError(_lib.TACO_ERR_STATE, "SyncBN calls back into the host: it cannot be combined with a captured step")
+
+        def _sum(user, ptr, n):
+            try:            # the vector lives in this step's workspace: view it as a tensor and sum it over the ranks, stream-ordered
+                off = int(ptr) - self._ws.data_ptr()
+                if off < 0 or off + 4 * n > self._ws.numel():
+                    raise RuntimeError("statistics vector outside the workspace")
+                dist.all_reduce(self._ws[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
+            except Exception as e:     # an exception must not unwind through the C frames: it is re-raised after the call returns
+                self._sync_err = e
+        self._sync_cb = _lib.SYNC_SUM_FN(_sum)
+        _lib.check(self._lib.taco_train_set_sync_bn(self._h, C.cast(self._sync_cb, C.c_void_p), None, world))
+        return True
 
     # ---- parameters ----
     def set_weights(self, weights):
@@ -120,6 +149,9 @@ class Trainer(object):
                 self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(spk), _p(mt), _p(lt), _p(co),
                 B, T_in, T_out, int(bool(getattr(hp, "prioritize_loss", False))), int(getattr(hp, "sample_rate", 24000)), _p(self.losses),
                 _p(mel), _p(lin), _p(ali), int(bool(rnn_decoder_test_mode)), _p(self._ws), self._ws.numel()))
+        if self._sync_err is not None:
+            e, self._sync_err = self._sync_err, None
+            raise e
         self.mel_outputs, self.linear_outputs, self.alignments = mel, lin, ali
         return self.losses
 
@@ -128,6 +160,8 @@ class Trainer(object):
         of a step become one graph launch).  Later train_step() calls with the same shapes copy into the static buffers and
         replay.  Returns self."""
         dev = self.device
+        if self._sync_cb is not None:
+            raise _lib.TacoError(_lib.TACO_ERR_STATE, "SyncBN calls back into the host: it cannot be combined with a captured step")
         cv = lambda x, dt: (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(dev, dt).contiguous().clone()
         self._g_in = [cv(inputs, torch.int32), cv(input_lengths, torch.int32), cv(mel_targets, torch.float32),
                       cv(linear_targets, torch.float32), None if loss_coeff is None else cv(loss_coeff, torch.float32)]

@@ -265,6 +265,44 @@ def test_train_step_through_the_collective_path():
             dist.destroy_process_group()
 
 
+def test_sync_bn_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
+    """with SyncBN a data-parallel step over W shards IS the reference's single-device step over the whole batch
+    (BatchNorm statistics, moving averages and every gradient).  Two processes (gloo transport, both on this GPU) take half of a
+    batch of 4 each; one process takes all 4 with plain BatchNorm.  Also shows the unsynchronised DP step is a different function."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", B=4, seed=41)
+    one = _trainer(hp, w)
+    l1 = one.forward_backward(ids, L, mt, lt, co).cpu().numpy().copy()
+    torch.cuda.synchronize()
+    g1, p1 = one.grads.cpu().numpy().copy(), one.params.cpu().numpy().copy()
+    # the same two shards without synchronisation: a different (per-shard statistics) function
+    ga = []
+    for r in range(2):
+        t = _trainer(hp, w)
+        t.forward_backward(ids[2 * r:2 * r + 2], L[2 * r:2 * r + 2], mt[2 * r:2 * r + 2], lt[2 * r:2 * r + 2], co[2 * r:2 * r + 2])
+        ga.append(t.grads.cpu().numpy().copy()); t.close()
+    one.close()
+    np.savez(os.path.join(tmp_path, "case.npz"), ids=ids, L=L, mt=mt, lt=lt, co=co, seed=41)
+    port = str(29600 + os.getpid() % 300)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_syncbn_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, str(tmp_path)], env=env) for r in range(2)]
+    for pr in procs:
+        assert pr.wait(timeout=600) == 0
+    res = np.load(os.path.join(tmp_path, "result.npz"))
+    scale = np.abs(g1).max()
+    assert np.abs(res["losses"] - l1).max() < 2e-5, (res["losses"], l1)
+    worst = float(np.abs(res["grads"] - g1).max() / scale)
+    assert worst < 2e-5, worst                                         # summation order (shards, atomics) only
+    assert float(np.abs(res["params"] - p1).max()) < 2e-5               # the moving statistics were updated with global-batch values
+    unsync = float(np.abs(0.5 * (ga[0] + ga[1]) - g1).max() / scale)
+    print("syncbn: worst %.2e  unsync %.2e  loss diff %.2e" % (worst, unsync, float(np.abs(res["losses"] - l1).max())))
+    assert unsync > 20 * worst, (unsync, worst)
+
+
 @pytest.mark.parametrize("ses,atype", [(4, "bah_mon"), (1, "bah")])
 def test_deepvoice_multispeaker_training_gradients(ses, atype):
     """model_type 'deepvoice' (tacotron.py:52-94): speaker embedding -> five softsign dense layers (or five per-speaker tables when

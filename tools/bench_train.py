@@ -15,6 +15,8 @@ def main():
     ap.add_argument("--t-in", type=int, default=128)
     ap.add_argument("--t-out", type=int, default=512)
     ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
+    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (40 small all-reduces per step); "
+                                                           "0: per-rank statistics.  No effect on one GPU")
     args = ap.parse_args()
     import numpy as np, torch, taco_amd
     from taco_amd import dist as D
@@ -24,6 +26,7 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
     hp = taco_amd.hparams.copy(max_iters=max(200, args.t_out // 4))
     tr = taco_amd.Trainer(hp, taco_amd.weights.random_weights(hp, 1, seed=4321), device=str(dev))
+    sync_bn = bool(args.sync_bn) and tr.enable_sync_bn(True)
     rs = np.random.RandomState(77 + rank)
     B, T_in, T_out = args.batch, args.t_in, args.t_out
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32); ids[:, -1] = 1
@@ -58,7 +61,8 @@ def main():
             "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
             "n_gpus": world, "global_batch": world * B, "ms_per_step": wall / args.steps * 1e3,
             "target_frames_per_s": world * B * T_out * args.steps / wall, "dtype": "f32", "data": "synthetic", "launch": "hipGraph" if args.graph else "eager",
-            "config": {"workload": "C4 shard: B=%d/GPU, T_in=%d, T_out=%d, r=%d, teacher-forced, batch-stat BN" % (B, T_in, T_out, hp.reduction_factor),
+            "config": {"workload": "C4 shard: B=%d/GPU, T_in=%d, T_out=%d, r=%d, teacher-forced, batch-stat BN (%s)" % (
+                           B, T_in, T_out, hp.reduction_factor, "synchronised over the ranks" if sync_bn else "per-rank statistics"),
                        "parallelism": "data-parallel x%d, one flat-bucket RCCL all-reduce of %d floats" % (world, tr.num_params)},
             "phase_ms": {"forward_only": ev[0].elapsed_time(ev[1]), "forward_plus_backward": ev[1].elapsed_time(ev[2]),
                          "adam_plus_refresh": ev[2].elapsed_time(ev[3])},
