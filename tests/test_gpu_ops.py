@@ -101,6 +101,45 @@ def test_highway(ctx):
         assert maxabs(out.cpu().numpy(), O.highwaynet(x, w, scope + "/highway_2")) < TOL
 
 
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
+def test_split_bf16_gemm_every_tile_shape(ctx, tile):
+    """k_gemm_bf3 under each of its tile shapes (1: 128x64, 2: 128x128, 3: 64x256, 4: 64x64, 5: 64x64 with four wave groups
+    splitting K inside the workgroup): conv with taps over ragged row counts and several batch rows, projection with the fused
+    max-pool and several LDS chunks, dense with an odd column count, highway (two weight matrices).  The automatic choice picks
+    4/5 at these sizes, so the large-layer tiles are pinned here."""
+    import torch
+    ohp, w, m, L = ctx
+    L.check(m._lib.taco_debug_set_bf3(m._handle, 1, tile))
+    try:
+        rs = np.random.RandomState(40 + tile)
+        x = rs.randn(5, 61, ohp.enc_prenet_sizes[-1])
+        for k in (1, 4, 5):
+            name = "encoder_cbhg/conv_bank/conv1d_%d" % k
+            assert maxabs(_conv(ctx, name, x, 1), O.conv1d_bn(x, w, name, O.relu)) < TOL_SPLIT
+        xc = rs.randn(3, 70, ohp.enc_bank_size * ohp.enc_bank_channel_size)
+        ref = O.conv1d_bn(O.maxpool_same_stride1(xc, 2), w, "encoder_cbhg/proj_1", O.relu)
+        assert maxabs(_conv(ctx, "encoder_cbhg/proj_1", xc, 1, mpw=2), ref) < TOL_SPLIT
+        xp = rs.randn(2, 131, ohp.post_bank_size * ohp.post_bank_channel_size)
+        ref = O.conv1d_bn(xp, w, "post_cbhg/proj_1", O.relu)
+        assert maxabs(_conv(ctx, "post_cbhg/proj_1", xp, 1, mpw=1), ref) < TOL_SPLIT
+        rows = 201
+        xd0 = rs.randn(rows, w["linear/kernel"].shape[0])
+        out = torch.full((rows, w["linear/kernel"].shape[1]), float("nan"), device="cuda")
+        xd = dev(xd0, torch.float32)
+        L.check(m._lib.taco_dense_f32(m._handle, stream(), b"linear", ptr(xd), rows, 0, ptr(out)))
+        torch.cuda.synchronize()
+        assert maxabs(out.cpu().numpy(), O.dense(xd0, w, "linear", None)) < TOL_SPLIT
+        for scope, D in (("encoder_cbhg", ohp.enc_rnn_size), ("post_cbhg", ohp.post_rnn_size)):
+            xh = rs.randn(150, D)
+            outh = torch.full((150, D), float("nan"), device="cuda")
+            xhd = dev(xh, torch.float32)
+            L.check(m._lib.taco_highway_f32(m._handle, stream(), (scope + "/highway_1").encode(), ptr(xhd), 150, ptr(outh)))
+            torch.cuda.synchronize()
+            assert maxabs(outh.cpu().numpy(), O.highwaynet(xh, w, scope + "/highway_1")) < TOL_SPLIT
+    finally:
+        L.check(m._lib.taco_debug_set_bf3(m._handle, 1, 0))
+
+
 @pytest.mark.parametrize("persist", [1, 0])
 @pytest.mark.parametrize("B", [1, 5, 17, 32, 33])
 def test_bigru_with_lengths_and_init_state(ctx, B, persist):
