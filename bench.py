@@ -27,7 +27,6 @@ WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speake
     "C2": (32, 128, 4, 128, 1, "single"),
     "C3": (32, 128, 4, 128, 4, "deepvoice"),
     "C5": (8, 512, 4, 1000, 1, "single"),
-    "C2x2": (64, 128, 4, 128, 1, "single"),   # two C2 batches served as one (not a BASELINE config; see DESIGN "coalescing")
 }
 
 
@@ -131,7 +130,12 @@ def main():
     ap.add_argument("--eager", action="store_true", help="enqueue kernels directly instead of replaying the hipGraph plan")
     ap.add_argument("--lanes", type=int, default=4,
                     help="forwards in flight per GPU (PlanPool: one plan + buffers + HIP stream each); 1 = strictly serial")
+    ap.add_argument("--coalesce", type=int, default=1,
+                    help="requests served per forward (PlanPool coalesce): c > 1 rides c batches of the workload's B rows through one "
+                         "plan of c*B rows; a step is still one batch of B rows.  Default 1 = the BASELINE.json configuration as is")
     args = ap.parse_args()
+    if args.coalesce < 1 or (args.coalesce > 1 and (args.eager or args.steps % args.coalesce or args.warmup % args.coalesce)):
+        ap.error("--coalesce c needs hipGraph plans and steps / warmup that are multiples of c")
 
     import numpy as np
     import torch
@@ -163,16 +167,21 @@ def main():
     ids[:, T_in - 1] = 1                                                       # fixed-length batches
     lengths = taco_amd.input_lengths_from_tokens(ids)
     lanes = max(1, args.lanes)
-    pool = model.plan_pool(B, T_in, n, lanes=lanes)
+    co = args.coalesce
+    pool = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=co)
     for plan in pool.plans:                                                    # inputs resident in HBM before the timed region
-        plan.inputs.copy_(torch.from_numpy(ids))
-        plan.lengths.copy_(torch.from_numpy(lengths))
+        plan.inputs.copy_(torch.from_numpy(np.tile(ids, (co, 1))))
+        plan.lengths.copy_(torch.from_numpy(np.tile(lengths, co)))
         if ns > 1:
-            plan.speaker_id.copy_(torch.from_numpy((np.arange(B) % ns).astype(np.int32)))
+            plan.speaker_id.copy_(torch.from_numpy(np.tile((np.arange(B) % ns).astype(np.int32), co)))
     torch.cuda.synchronize()
     plan = pool.plans[0]
 
     def step(i):
+        if co > 1:                      # a step is one batch of B rows: every co-th step launches the forward that carries co of them
+            if i % co == co - 1:
+                pool.launch((i // co) % lanes)
+            return
         lane = i % lanes
         if args.eager:
             p = pool.plans[lane]
@@ -257,7 +266,7 @@ def main():
                        "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
                        "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, recurrent and decoder mat-vecs exact-fp32 MFMA (max err vs float64 oracle 3.4e-6)",
                        "launch": "eager" if args.eager else "hipGraph plan (%d nodes)" % plan.num_nodes,
-                       "forwards_in_flight": lanes, "forward_latency_ms_alone": latency_ms},
+                       "forwards_in_flight": lanes, "requests_per_forward": co, "forward_latency_ms_alone": latency_ms},
             "roofline": {"bound": "hbm", "achieved": abytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": abytes / fwd_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "whole forward (one hipGraph launch); algorithmic bytes %.3f GB per forward, "
@@ -277,7 +286,7 @@ def main():
             pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
             if pm:
                 rec = json.load(open(pm[-1]))
-                if rec.get("workload") == args.workload:
+                if rec.get("workload") == args.workload and co == 1:
                     out["roofline"]["traffic"] = rec["traffic_bytes_per_forward"]
                     out["roofline"]["traffic_source"] = os.path.basename(pm[-1])
         except Exception:

@@ -149,6 +149,11 @@ int taco_gru_cell_f32(taco_model* m, void* hip_stream, const char* name, const f
  * d_seq_len[b] = len(sequence) of the row (tokens incl. EOS and padding, as the reference passes it).  d_spec_end [B]. */
 int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32_t* d_seq_len, int B, int T_in, int n_steps,
                         int reduction_factor, int32_t* d_spec_end);
+/* The stop rule (helpers.py:29 + dynamic_decode: the loop ends after the first step at which every row has emitted an all-zero
+ * step) evaluated on a finished mel buffer d_mel [B, n_steps, width = r*num_mels] per group of rows_per_group consecutive rows:
+ * d_stop[B / rows_per_group].  For requests that were served together through one plan (PlanPool coalesce > 1), whose plan-wide
+ * stop step covers all of them; with rows_per_group = B it equals the stop step the forward itself reports. */
+int taco_stop_steps(void* hip_stream, const float* d_mel, int B, int n_steps, int width, int rows_per_group, int32_t* d_stop);
 
 /* ---- spectrogram -> waveform (audio/__init__.py:54-56,76-96,118-122,149-165; synthesizer.py:264) ---- */
 typedef struct {

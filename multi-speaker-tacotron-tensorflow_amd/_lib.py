@@ -136,6 +136,7 @@ PROTOTYPES = {
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),
+    "taco_stop_steps": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "taco_debug_set_fuse_prenet": (_I, [_P, _I]),
     "taco_debug_set_fuse_concat": (_I, [_P, _I]),
     "taco_debug_set_att_split": (_I, [_P, _I]),

@@ -1830,6 +1830,25 @@ __global__ void k_stop_step(const int* nz, int B, int n_steps, int* stop) {
   }
 }
 
+// The same stop rule evaluated on a finished mel buffer for groups of `rows` consecutive batch rows (requests that were served
+// together through one plan): stop[g] = min(max over the group's rows of (first step whose r*num_mels outputs are all 0) + 1, n).
+// One workgroup per batch row; stop must be zeroed before the launch.  y [B, n_steps, width].
+__global__ __launch_bounds__(256) void k_stop_groups(const float* y, int n_steps, int width, int rows, int* stop) {
+  __shared__ int first;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) first = n_steps;
+  __syncthreads();
+  const float* yb = y + (size_t)b * n_steps * width;
+  for (int t = wave; t < n_steps; t += 4) {          // a wave per step: any non-zero among the step's outputs?
+    if (t >= *(volatile int*)&first) break;          // later steps cannot lower the minimum
+    bool nz = false;
+    for (int c = lane; c < width; c += 64) nz |= yb[(size_t)t * width + c] != 0.f;
+    if (!__any(nz) && lane == 0) atomicMin(&first, t);
+  }
+  __syncthreads();
+  if (tid == 0) atomicMax(stop + b / rows, min(first + 1, n_steps));
+}
+
 // attention-based trimming of the synthesised spectrogram (synthesizer.py:242-262, `attention_trim`): walk the per-step argmax of
 // the alignments until the attention has dwelt on the last attended input position; spec_end = r*j + 3.
 // One wave per batch row; align [B, T_in, n] (tacotron.py:238-239 layout), seq_len[b] = len(sequence) of the row.

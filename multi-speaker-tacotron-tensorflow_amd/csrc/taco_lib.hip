@@ -1351,6 +1351,16 @@ int taco_attention_trim(void* hip_stream, const float* d_alignments, const int32
   return 0;
 }
 
+int taco_stop_steps(void* hip_stream, const float* d_mel, int B, int n_steps, int width, int rows_per_group, int32_t* d_stop) {
+  if (!d_mel || !d_stop || B <= 0 || n_steps <= 0 || width <= 0 || rows_per_group <= 0 || B % rows_per_group)
+    return fail(TACO_ERR_ARG, "bad argument");
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(hipMemsetAsync(d_stop, 0, (size_t)(B / rows_per_group) * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_stop_groups, dim3(B), dim3(256), 0, st, d_mel, n_steps, width, rows_per_group, d_stop);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int taco_debug_set_att_split(taco_model* m, int slices) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->att_split = slices;

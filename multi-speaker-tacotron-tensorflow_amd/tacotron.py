@@ -119,24 +119,34 @@ class PlanPool(object):
     The reference serves one `sess.run` at a time (synthesizer.py:166-167); this is the same call with
     several requests outstanding.  submit() enqueues and returns immediately; result() waits for that lane."""
 
-    def __init__(self, model, B, T_in, n_steps=None, lanes=4):
+    def __init__(self, model, B, T_in, n_steps=None, lanes=4, coalesce=1):
+        """coalesce > 1: every lane's plan serves `coalesce` requests of B rows at once (one forward over coalesce*B rows: rows are
+        independent at inference, and the decoder stages and scans cost almost the same for twice the rows).  submit() then
+        returns a ticket (lane, slot), the lane is launched when its last slot is filled (or by flush()), and result(ticket)
+        returns that request's rows -- the same function of the request as serving it alone (rows never interact; a layer may pick a
+        different tile shape for the larger row count, so equality is to rounding, ~1e-6, not bitwise)."""
         if model._handle is None:
             raise RuntimeError("initialize() must be called first")
-        if lanes < 1:
-            raise ValueError("lanes must be >= 1")
+        if lanes < 1 or coalesce < 1:
+            raise ValueError("lanes and coalesce must be >= 1")
         n = model._hparams.max_iters if n_steps is None else n_steps
-        self.model, self.B, self.T_in, self.n, self.lanes = model, B, T_in, n, lanes
+        self.model, self.B, self.T_in, self.n, self.lanes, self.coalesce = model, B, T_in, n, lanes, coalesce
         self.streams, self.plans, self.done, self.pending = [], [], [], []
+        self.filled = [0] * lanes            # slots of the lane that hold a submitted request
+        self.taken = [0] * lanes             # of those, how many results were collected
+        self.slot_stop = []
         with torch.cuda.device(model.device):
             self.streams = _concurrent_streams(model.device, lanes)
             for st in self.streams:
                 with torch.cuda.stream(st):
-                    self.plans.append(_Plan(model, B, T_in, n, False))
+                    self.plans.append(_Plan(model, B * coalesce, T_in, n, False))
                     self.plans[-1].launch()      # first replay uploads the graph: keep that out of the serving path
                 self.done.append(torch.cuda.Event())
                 self.pending.append(False)
+                self.slot_stop.append(torch.zeros((coalesce,), dtype=torch.int32, device=model.device))
             torch.cuda.synchronize()
         self._next = 0
+        self._filling = None
 
     def next_lane(self):
         lane = self._next
@@ -145,47 +155,87 @@ class PlanPool(object):
 
     def launch(self, lane):
         """Replay lane's plan on its stream over whatever its input buffers hold."""
+        hp = self.model._hparams
         with torch.cuda.stream(self.streams[lane]):
-            self.plans[lane].launch()
+            p = self.plans[lane]
+            p.launch()
+            if self.coalesce > 1:        # per-request stop steps (the plan's own covers all its rows)
+                _lib.check(self.model._lib.taco_stop_steps(_stream(), _ptr(p.mel), p.B, self.n, hp.reduction_factor * hp.num_mels,
+                                                           self.B, _ptr(self.slot_stop[lane])))
             self.done[lane].record()
         self.pending[lane] = True
+        if self.filled[lane] == 0:
+            self.filled[lane] = self.coalesce       # launched directly (bench): every slot counts
+        self.taken[lane] = 0
 
     def submit(self, inputs, input_lengths, speaker_id=None, lane=None):
-        """Enqueue one forward; returns the lane to pass to result().  Inputs may be host or device arrays."""
-        lane = self.next_lane() if lane is None else lane
+        """Enqueue one request of B rows.  Returns what result() takes: the lane (coalesce == 1) or the ticket (lane, slot).
+        Inputs may be host or device arrays."""
+        if self.coalesce > 1:
+            if lane is not None:
+                raise ValueError("with coalesce > 1 the pool picks the lane")
+            if self._filling is None:
+                self._filling = self.next_lane()
+            lane = self._filling
+        else:
+            lane = self.next_lane() if lane is None else lane
         if self.pending[lane]:
-            raise RuntimeError("lane %d still holds an uncollected result; call result(%d) first" % (lane, lane))
+            raise RuntimeError("lane %d still holds an uncollected result; call result() for it first" % lane)
         m, plan = self.model, self.plans[lane]
         ids = m._as_dev(inputs, torch.int32)
         lens = m._as_dev(input_lengths, torch.int32)
         if tuple(ids.shape) != (self.B, self.T_in):
             raise Exception("inputs must be [%d, %d], got shape %s" % (self.B, self.T_in, tuple(ids.shape)))
+        slot = self.filled[lane] if self.coalesce > 1 else 0
+        rows = slice(slot * self.B, (slot + 1) * self.B)
         cur = torch.cuda.current_stream(m.device)
         with torch.cuda.stream(self.streams[lane]):
             self.streams[lane].wait_stream(cur)      # ids/lens may have been produced on the caller's stream
-            plan.inputs.copy_(ids, non_blocking=True)
-            plan.lengths.copy_(lens, non_blocking=True)
+            plan.inputs[rows].copy_(ids, non_blocking=True)
+            plan.lengths[rows].copy_(lens, non_blocking=True)
             if m.num_speakers > 1:
                 if speaker_id is None:
-                    plan.speaker_id.zero_()
+                    plan.speaker_id[rows].zero_()
                 else:
-                    plan.speaker_id.copy_(m._as_dev(speaker_id, torch.int32), non_blocking=True)
-        self.launch(lane)
-        return lane
+                    plan.speaker_id[rows].copy_(m._as_dev(speaker_id, torch.int32), non_blocking=True)
+        if self.coalesce == 1:
+            self.filled[lane] = 1
+            self.launch(lane)
+            return lane
+        self.filled[lane] += 1
+        if self.filled[lane] == self.coalesce:
+            self.flush()
+        return (lane, slot)
 
-    def result(self, lane, copy=True):
-        """Waits for lane's forward.  Returns dict(linear, mel, alignments, stop_step); with copy=False the
-        tensors are the lane's own buffers and are overwritten by the lane's next forward."""
-        if not self.pending[lane]:
-            raise RuntimeError("lane %d has no forward in flight" % lane)
+    def flush(self):
+        """coalesce > 1: launch the lane that is being filled even if some of its slots are empty (they recompute stale rows)."""
+        if self._filling is not None and self.filled[self._filling] > 0:
+            lane, self._filling = self._filling, None
+            self.launch(lane)
+
+    def result(self, ticket, copy=True):
+        """Waits for the forward that holds the request.  Returns dict(linear, mel, alignments, stop_step); with copy=False the
+        tensors are views of the lane's own buffers and are overwritten by the lane's next forward."""
+        lane, slot = (ticket, 0) if self.coalesce == 1 else ticket
+        if lane == self._filling:
+            self.flush()
+        if not self.pending[lane] or slot >= self.filled[lane]:
+            raise RuntimeError("lane %d slot %d has no forward in flight" % (lane, slot))
         self.done[lane].synchronize()
-        self.pending[lane] = False
         p = self.plans[lane]
+        rows = slice(slot * self.B, (slot + 1) * self.B)
         f = (lambda t: t.clone()) if copy else (lambda t: t)
         with torch.cuda.device(self.model.device):
-            return {"linear": f(p.linear), "mel": f(p.mel), "alignments": f(p.align), "stop_step": int(p.stop.item())}
+            stop = int(p.stop.item()) if self.coalesce == 1 else int(self.slot_stop[lane][slot].item())
+            out = {"linear": f(p.linear[rows]), "mel": f(p.mel[rows]), "alignments": f(p.align[rows]), "stop_step": stop}
+        self.taken[lane] += 1
+        if self.taken[lane] >= self.filled[lane]:
+            self.pending[lane] = False
+            self.filled[lane] = 0
+        return out
 
     def wait_all(self):
+        self.flush()
         for lane in range(self.lanes):
             if self.pending[lane]:
                 self.done[lane].synchronize()
@@ -352,9 +402,9 @@ class Tacotron(object):
                 self._plans[key] = _Plan(self, B, T_in, n, manual)
         return self._plans[key]
 
-    def plan_pool(self, B, T_in, n_steps=None, lanes=4):
-        """`lanes` forwards of this shape in flight at once (PlanPool)."""
-        return PlanPool(self, B, T_in, n_steps, lanes)
+    def plan_pool(self, B, T_in, n_steps=None, lanes=4, coalesce=1):
+        """`lanes` forwards of this shape in flight at once, each serving `coalesce` requests of B rows (PlanPool)."""
+        return PlanPool(self, B, T_in, n_steps, lanes, coalesce)
 
     def run(self, inputs=None, input_lengths=None, speaker_id=None, manual_alignments=None,
             is_manual_attention=None, n_steps=None, honor_stop=True):

@@ -366,6 +366,48 @@ def test_plan_pool_lanes_are_independent_and_exact(mt, ns):
     pool.close()
 
 
+@pytest.mark.parametrize("mt,ns", [("single", 1), ("deepvoice", 3)])
+def test_plan_pool_coalesces_requests_into_one_forward(mt, ns):
+    """PlanPool(coalesce=2): two requests of B rows ride through one plan of 2B rows; five requests over two lanes (the last lane
+    is flushed half full).  Every request gets its own rows and its own stop step, equal to serving it alone (to rounding: a
+    layer may pick another tile shape for the larger row count) and within tolerance of the checker."""
+    ohp = tiny_hp(model_type=mt, speaker_embedding_size=4) if ns > 1 else tiny_hp()
+    w = O.init_weights(ohp, ns, 93)
+    m = build_model(ohp, w, num_speakers=ns)
+    B, T_in = 3, 11
+    reqs = []
+    for i in range(5):
+        ids, L = O.synthetic_inputs(B, T_in, 400 + i, ragged=(i % 2 == 0))
+        spk = ((np.arange(B) + i) % ns).astype(np.int32) if ns > 1 else None
+        reqs.append((ids, L, spk))
+    single = m.plan_pool(B, T_in, lanes=1)
+    alone = []
+    for rq in reqs:
+        r = single.result(single.submit(*rq))
+        alone.append((r["mel"].cpu().numpy(), r["linear"].cpu().numpy(), r["alignments"].cpu().numpy(), r["stop_step"]))
+    single.close()
+    pool = m.plan_pool(B, T_in, lanes=2, coalesce=2)
+    tickets = [pool.submit(*rq) for rq in reqs[:4]]
+    assert tickets == [(0, 0), (0, 1), (1, 0), (1, 1)]
+    got = {}
+    for i in (3, 0, 2, 1):                                   # collect out of order
+        got[i] = pool.result(tickets[i])
+    t4 = pool.submit(*reqs[4])                               # half-filled lane: result() flushes it
+    assert t4 == (0, 0)
+    got[4] = pool.result(t4)
+    with pytest.raises(RuntimeError):
+        pool.result((0, 1))                                  # that slot held no request
+    for i in range(5):
+        r = got[i]
+        for a, b in zip(alone[i][:3], (r["mel"].cpu().numpy(), r["linear"].cpu().numpy(), r["alignments"].cpu().numpy())):
+            assert a.shape == b.shape and maxabs(a, b) < 2e-5, "request %d" % i
+        assert r["stop_step"] == alone[i][3], (i, r["stop_step"], alone[i][3])
+    ref = O.forward(w, ohp, reqs[3][0], reqs[3][1], speaker_id=reqs[3][2], num_speakers=ns, honor_stop=False)
+    _check((got[3]["mel"].cpu().numpy(), got[3]["linear"].cpu().numpy(), got[3]["alignments"].cpu().numpy()), ref)
+    m.check_device_errors()
+    pool.close()
+
+
 @pytest.mark.parametrize("mt,ns", [("single", 1), ("simple", 3)])
 def test_prenet_layer_folded_into_frame_projection_is_the_same_function(mt, ns):
     """Default: layer 1 of the decoder prenet of step t+1 comes out of step t's frame-projection launch (composite weights

@@ -101,6 +101,31 @@ def test_highway(ctx):
         assert maxabs(out.cpu().numpy(), O.highwaynet(x, w, scope + "/highway_2")) < TOL
 
 
+def test_stop_steps_per_group_of_rows(ctx):
+    """taco_stop_steps: helpers.py:29 + dynamic_decode on a finished mel buffer, per group of rows (requests served together):
+    stop = min(max over the group's rows of (first all-zero step) + 1, n); rows that never emit an all-zero step keep it at n."""
+    import torch
+    ohp, w, m, L = ctx
+    rs = np.random.RandomState(12)
+    B, n, width, rows = 12, 37, 20, 3
+    y = rs.randn(B, n, width).astype(np.float32)
+    first = rs.randint(0, n + 6, size=B)                  # >= n: the row never stops
+    for b in range(B):
+        if first[b] < n:
+            y[b, first[b]] = 0.0
+            if first[b] + 3 < n:
+                y[b, first[b] + 3] = 0.0                  # later zero steps do not matter
+        y[b, :min(first[b], n), 0] += 10.0                # no accidental earlier zero step
+    want = np.array([min(max(min(f, n) for f in first[g * rows:(g + 1) * rows]) + 1, n) for g in range(B // rows)], np.int32)
+    yd = dev(y, torch.float32)
+    out = torch.full((B // rows,), -1, dtype=torch.int32, device="cuda")
+    L.check(m._lib.taco_stop_steps(stream(), ptr(yd), B, n, width, rows, ptr(out)))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want), (out.cpu().numpy(), want, first)
+    with pytest.raises(L.TacoError):
+        L.check(m._lib.taco_stop_steps(stream(), ptr(yd), B, n, width, 5, ptr(out)))      # 12 rows do not split into groups of 5
+
+
 @pytest.mark.parametrize("tile", [1, 2, 3, 4, 5])
 def test_split_bf16_gemm_every_tile_shape(ctx, tile):
     """k_gemm_bf3 under each of its tile shapes (1: 128x64, 2: 128x128, 3: 64x256, 4: 64x64, 5: 64x64 with four wave groups

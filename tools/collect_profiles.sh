@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
 for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
-timeout 300 python bench.py --no-cpu-baseline --workload C2x2 --steps 12 --warmup 3 > $out/bench_C2x2.json 2>> $out/bench_C2.err
+timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
