@@ -344,11 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void k_gemm(const GemmArgs a_in)
 // into hi = bf16(x) and lo = bf16(x - hi) (16 mantissa bits together) and each k16 group issues three
 // MFMAs: hi*hi + hi*lo + lo*hi (the dropped lo*lo term is ~2^-16 relative), all accumulated in fp32.
 // Weights are split once at finalize; activations are split when the tile is staged in LDS (two bf16
-// tiles, same bytes as one fp32 tile).  Measured error vs the float64 oracle ~1e-5 on O(1) outputs --
-// used for the post-net stages (121 of 180 GFLOP @C2), whose results feed no long recurrence.
-// Pack layout (k16-major: the TN column tiles a wave loads for one k16 step are adjacent 1 KB blocks, so its 2 x TN loads cover
-// consecutive cache lines on different L2 channels; tile-major put them K16 KB apart -- a power of two for the usual K, i.e. all
-// on one channel, and every CU of the XCD asks for the same lines at the same time):
+// tiles, same bytes as one fp32 tile).  Measured error vs the float64 oracle ~1e-5 on O(1) outputs per layer; used for every
+// feed-forward GEMM of inference (167 of 180 GFLOP @C2): end to end mel 2.7e-6, linear 3.4e-6, alignment argmax identical.
+// Pack layout (k16-major: the TN column tiles a wave loads for one k16 step are adjacent 1 KB blocks, i.e. consecutive cache
+// lines; a tile-major order measured the same):
 //   b?[(((k16*NT + nt)*2 + h)*32 + j)*8 + e] = W[16*k16 + 8*h + e][32*nt + j]; A fragment of lane
 // (i = l&31, h = l>>5) = X[i][16*g + 8*h + e], e < 8 -- A and B use the same (h, e) -> k pairing.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -113,7 +113,7 @@ struct taco_model {
   int force_cfg = -1;
   unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
   int persist = 1;             // use the persistent BiGRU kernel when it fits
-  int bf3 = 1;                 // post-net feed-forward GEMMs on the bf16 matrix cores with 3-term split operands
+  int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
@@ -476,7 +476,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     a.v[i] = m->hvars[layers[i].var_index];
   }
   if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
-  if (m->bf3 && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (post-net layers): 128-row tiles
+  if (m->bf3 && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (every feed-forward layer of inference)
     // tiles (rows x cols): 1 = 128x64, 2 = 128x128, 3 = 64x256 (one staged 64-row tile feeds 8 MFMA column tiles)
     // measured (tools/time_gemm_layers.py): 64x256 wins when K or N is large (proj_1, linear, GRU projection), 128x64 otherwise
     const int Ktot = L0.kw * L0.cin;

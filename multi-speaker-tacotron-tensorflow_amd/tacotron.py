@@ -112,8 +112,8 @@ class PlanPool(object):
 
     The decoder loop and the BiGRU scans are chains of small dependent kernels that occupy a few dozen of
     the 256 CUs; a second, third and fourth forward running beside them use CUs that would otherwise idle.
-    Measured on MI355X at C2 (tools/time_multistream.py): 12.5 ms/forward with one lane, 7.0 with two,
-    4.4 with four (the default number of hardware queues); more lanes than hardware queues is slower.
+    Measured on MI355X at C2 (bench.py --lanes N): 9.7 ms/forward with one lane, 3.6 with four (the default number of
+    hardware queues; 12.5 / 7.0 / 4.4 for 1 / 2 / 4 lanes when this was introduced); more lanes than hardware queues is slower.
     The model object is read-only during a forward, so lanes share it.
 
     The reference serves one `sess.run` at a time (synthesizer.py:166-167); this is the same call with
