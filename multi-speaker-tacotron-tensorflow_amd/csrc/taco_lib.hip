@@ -443,7 +443,7 @@ static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
     return 0;
   }
   // prefetch depth: two k16 steps ahead when the grid leaves at most ~2 workgroups per CU (occupancy is grid-limited there)
-  if (gpi == 0) gpi = (!DUAL && TN == 4 && (long)grid.x * grid.y * grid.z <= 320) ? 2 : 1;
+  if (gpi == 0) gpi = (!DUAL && BN == 256 && (long)grid.x * grid.y * grid.z <= 320) ? 2 : 1;
   for (int i = 0; i < nvar; ++i) if (a.v[i].cin_pad16 % 64) gpi = 1;     // GPI = 2 needs four k16 steps in every chunk (even group count)
   if (gpi == 2) hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 2>), grid, dim3(64 * WM * WN), lds, st, aa);
   else hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1>), grid, dim3(64 * WM * WN), lds, st, aa);
@@ -482,19 +482,26 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     const int Ktot = L0.kw * L0.cin;
     const long Meff = c.t_len > 0 ? (long)(c.M / a.T) * c.t_len : c.M;
     // small-M layers (encoder, short utterances): 64x64 tiles; if even those leave most CUs idle, four wave groups per
-    // workgroup split K (tile 4 / 5).  Otherwise the measured choices of tools/time_gemm_layers.py.
+    // workgroup split K (tile 4 / 5).  Otherwise one row of waves side by side over the columns (tile 7: 64x256 by 1x8 waves,
+    // tile 9: 64x128 by 1x4): every wave streams its OWN weight columns and all of them share the staged activation tile, so no
+    // weight fragment is fetched twice by a workgroup (the 2x2 arrangements of tiles 1-3 fetch each one twice through a 16 KB L1
+    // that cannot hold them: measured 20-30 % slower on every large layer, tools/time_gemm_layers.py).
     int tn = m->bf3_tn;
     if (!tn) {
       const long g128 = (long)cdiv(Meff, 128) * cdiv(Nmax, 64) * nvar, g64 = (long)cdiv(Meff, 64) * cdiv(Nmax, 64) * nvar;
       if (g128 < 384 && !((Ktot >= 1024 || Nmax > 512) && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar >= 192)) tn = (g64 >= 384) ? 4 : 5;
-      else tn = (Ktot >= 1024 || Nmax > 512) ? 3 : 1;
+      else tn = (Nmax > 128) ? 7 : 9;
     }
     if (dual) {
+      if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, true>(st, a, nvar, kw_max, Nmax);
+      if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, true>(st, a, nvar, kw_max, Nmax);
       if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, true, 4>(st, a, nvar, kw_max, Nmax);
       if (tn == 4) return launch_gemm_bf3<2, 2, 1, 1, true>(st, a, nvar, kw_max, Nmax);
       if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, true>(st, a, nvar, kw_max, Nmax);
       return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, true>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, true>(st, a, nvar, kw_max, Nmax);
     }
+    if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, false>(st, a, nvar, kw_max, Nmax);
+    if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, false, 4>(st, a, nvar, kw_max, Nmax);
     if (tn == 4) return launch_gemm_bf3<2, 2, 1, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, false>(st, a, nvar, kw_max, Nmax);

@@ -18,7 +18,11 @@ cases = [  # (kind, layer, B, T, Cin, Cout, kw, mpw, act)
     ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 2, 1),
     ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 1, 1),
     ("conv", "post_cbhg/conv_bank/conv1d_8", 32, 512, 80, 256, 8, 1, 1),
+    ("conv", "post_cbhg/proj_2", 32, 512, 256, 80, 3, 1, 0),
+    ("dense", "post_cbhg/dense", 32, 512, 80, 256, 1, 1, 0),
     ("conv", "encoder_cbhg/proj_1", 32, 128, 2048, 128, 3, 2, 1),
+    ("conv", "encoder_cbhg/proj_2", 32, 128, 128, 128, 3, 1, 0),
+    ("hw", "encoder_cbhg/highway_1", 32, 128, 128, 128, 1, 1, 0),
     ("conv", "encoder_cbhg/conv_bank/conv1d_16", 32, 128, 128, 128, 16, 1, 1),
     ("dense", "linear", 32, 512, 512, 1025, 1, 1, 0),
     ("hw", "post_cbhg/highway_1", 32, 512, 256, 256, 1, 1, 0),
@@ -39,8 +43,8 @@ for kind, layer, B, T, Cin, Cout, kw, mpw, act in cases:
         us = timeit(fn)
         row.append("cfg%d %7.1f us %5.1f TF" % (cfg, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else gf / (us * 1e-6) / 1e3))
     L.taco_debug_force_gemm_config(m._handle, -1)
-    if layer.startswith(("post_cbhg", "linear")):
-        for tn in (1, 2, 3):
+    if True:
+        for tn in (1, 3, 4, 5, 7, 9):
             L.taco_debug_set_bf3(m._handle, 1, tn)
             us = timeit(fn)
             row.append("bf3t%d %7.1f us %5.1f TFeq" % (tn, us, gf / (us * 1e-6) / 1e3))
