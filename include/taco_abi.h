@@ -238,7 +238,7 @@ int taco_debug_set_persistent(taco_model* m, int on);
 /* test hook: on = 1 (default) runs the feed-forward GEMMs of inference on the bf16 matrix cores with 3-term split
  * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128,
  * 3 = 64x256 (2x2 waves), 4 = 64x64, 5 = 64x64 with four wave groups splitting K inside the workgroup, 7 = 64x256 by 1x8 waves,
- * 9 = 64x128 by 1x4 waves (auto picks 4 / 5 / 7 / 9) */
+ * 9 = 64x128 by 1x4 waves, 10 = tile 7 with two wave groups splitting K (auto picks 4 / 5 / 7 / 9 / 10) */
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream

@@ -490,7 +490,8 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     if (!tn) {
       const long g128 = (long)cdiv(Meff, 128) * cdiv(Nmax, 64) * nvar, g64 = (long)cdiv(Meff, 64) * cdiv(Nmax, 64) * nvar;
       if (g128 < 384 && !((Ktot >= 1024 || Nmax > 512) && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar >= 192)) tn = (g64 >= 384) ? 4 : 5;
-      else tn = (Nmax > 128) ? 7 : 9;
+      else if (Nmax <= 128) tn = 9;
+      else tn = (!dual && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar <= 320) ? 10 : 7;   // few workgroups: two wave groups split K (16 waves/CU)
     }
     if (dual) {
       if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, true>(st, a, nvar, kw_max, Nmax);
@@ -500,6 +501,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, true>(st, a, nvar, kw_max, Nmax);
       return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, true>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, true>(st, a, nvar, kw_max, Nmax);
     }
+    if (tn == 10) return launch_gemm_bf3<1, 8, 2, 1, false, 2>(st, a, nvar, kw_max, Nmax);
     if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, false, 4>(st, a, nvar, kw_max, Nmax);

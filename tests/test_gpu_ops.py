@@ -126,10 +126,10 @@ def test_stop_steps_per_group_of_rows(ctx):
         L.check(m._lib.taco_stop_steps(stream(), ptr(yd), B, n, width, 5, ptr(out)))      # 12 rows do not split into groups of 5
 
 
-@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 9])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 5, 7, 9, 10])
 def test_split_bf16_gemm_every_tile_shape(ctx, tile):
     """k_gemm_bf3 under each of its tile shapes (1: 128x64, 2: 128x128, 3: 64x256, 4: 64x64, 5: 64x64 with four wave groups
-    splitting K inside the workgroup, 7: 64x256 by 1x8 waves, 9: 64x128 by 1x4 waves): conv with taps over ragged row counts and several batch rows, projection with the fused
+    splitting K inside the workgroup, 7: 64x256 by 1x8 waves, 9: 64x128 by 1x4 waves, 10: tile 7 with two wave groups splitting K): conv with taps over ragged row counts and several batch rows, projection with the fused
     max-pool and several LDS chunks, dense with an odd column count, highway (two weight matrices).  The automatic choice picks
     4/5 at these sizes, so the large-layer tiles (7, 9 and the older 1-3) are pinned here."""
     import torch

@@ -44,7 +44,7 @@ for kind, layer, B, T, Cin, Cout, kw, mpw, act in cases:
         row.append("cfg%d %7.1f us %5.1f TF" % (cfg, us, gf / us * 1e-3 * 1e3 / 1e3 * 1e3 / 1e3 if False else gf / (us * 1e-6) / 1e3))
     L.taco_debug_force_gemm_config(m._handle, -1)
     if True:
-        for tn in (1, 3, 4, 5, 7, 9):
+        for tn in (1, 3, 4, 5, 7, 9, 10):
             L.taco_debug_set_bf3(m._handle, 1, tn)
             us = timeit(fn)
             row.append("bf3t%d %7.1f us %5.1f TFeq" % (tn, us, gf / (us * 1e-6) / 1e3))
