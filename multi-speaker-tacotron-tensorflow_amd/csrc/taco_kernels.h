@@ -1380,6 +1380,157 @@ __global__ __launch_bounds__(512) void k_bigru_resu(const BigruSArgs a_in) {
   }
 }
 
+// k_bigru_resw : k_bigru_resu (H = 256, 4 units per thread) with the per-step exchanges made wave-local.  Thread (jb, q) works on
+// K-slice q, and q is the wave index -- so the 32 state values a wave multiplies by are exactly the 32 units whose gates and
+// update that wave can finish itself: after the partial sums are out (one barrier) wave q reduces r and u of units
+// 32q..32q+31 on its 64 lanes, keeps u in registers, writes r*h where only it will read it; after the candidate partials (second
+// barrier) lanes 32..63 finish those units and write the new state where, again, only this wave reads it.  Two barriers per
+// step instead of four, same arithmetic in the same order (bit-identical to k_bigru_resu).
+template <int KR, int KL, int CH>
+__global__ __launch_bounds__(512) void k_bigru_resw(const BigruSArgs a_in) {
+  constexpr int H = 256, UJ = 4; constexpr bool TAPE = false;
+  constexpr int NT = 512, HJ = H / UJ, NQ = NT / HJ, KS = H / NQ, KG = KS - KR - KL;
+  static_assert(HJ == 64 && 2 * KS == 64, "a wave = one K-slice; its 64 lanes = the r and u gates of the slice's 32 units");
+  static_assert(KG >= 0 && KG % CH == 0 && KR % 4 == 0 && NQ * HJ == NT && NQ * KS == H, "bad split");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BigruSArgs a = a_in;
+  PIN(a.xproj); PIN(a.g2_0); PIN(a.g2_1); PIN(a.c1_0); PIN(a.c1_1); PIN(a.h0); PIN(a.lengths); PIN(a.out); PIN(a.gsave); PIN(a.B); PIN(a.T);
+  const int tid = threadIdx.x;
+  const int d = blockIdx.x / a.B, b = blockIdx.x % a.B;
+  const int T = a.T;
+  const float2* G2 = d ? a.g2_1 : a.g2_0;
+  const float* C1 = d ? a.c1_1 : a.c1_0;
+  const int jb = tid & 63, q = __builtin_amdgcn_readfirstlane(tid >> 6), k0 = q * KS;   // q is the wave index: uniform, lives in an SGPR
+  float* hs = smem;                      // [H] state
+  float* xs = hs + H;                    // [H] r * h
+  float* us = xs + H;                    // [H] u
+  float* part = us + H;                  // [NQ][3][H] partial sums (r, u, c)
+  float2* wl_g = reinterpret_cast<float2*>(part + NQ * 3 * H);   // [KL][NQ][H]
+  float* wl_c = reinterpret_cast<float*>(wl_g + KL * NQ * H);    // [KL][NQ][H]
+  float2 wg[KR][UJ]; float wc[KR][UJ];
+#pragma unroll
+  for (int i = 0; i < KR; ++i)
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { wg[i][u] = G2[(size_t)(k0 + i) * H + jb * UJ + u]; wc[i][u] = C1[(size_t)(k0 + i) * H + jb * UJ + u]; }
+  for (int i = 0; i < KL; ++i)
+    for (int u = 0; u < UJ; ++u) {
+      wl_g[(i * NQ + q) * H + jb + u * HJ] = G2[(size_t)(k0 + KR + i) * H + jb * UJ + u];
+      wl_c[(i * NQ + q) * H + jb + u * HJ] = C1[(size_t)(k0 + KR + i) * H + jb * UJ + u];
+    }
+  const float2* Gs = G2 + (size_t)(k0 + KR + KL) * H + jb * UJ;     // packs with permuted columns: the thread's UJ units are adjacent
+  const float* Cs = C1 + (size_t)(k0 + KR + KL) * H + jb * UJ;
+  for (int i = tid; i < H; i += NT) hs[i] = a.h0 ? a.h0[(size_t)b * 2 * H + d * H + i] : 0.f;
+  const int L = a.lengths ? a.lengths[b] : T;
+  __syncthreads();
+#pragma unroll 1
+  for (int s = 0; s < T; ++s) {
+    // the wave's own units: lane l finishes gate g = l>>5 (r, u) of unit nn = k0 + (l & 31); lanes 32..63 also the candidate
+    const int lane = tid & 63, gsel = lane >> 5, nn = k0 + (lane & 31);
+    const float* xrow = a.xproj + ((size_t)b * T + s) * 6 * H + d * 3 * H;
+    const float xg = xrow[gsel * H + nn];
+    const float xc = gsel ? xrow[2 * H + nn] : 0.f;
+    // ---- gates ----
+    float ar[UJ], au[UJ];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { ar[u] = 0.f; au[u] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      const float4 h4 = *reinterpret_cast<const float4*>(&hs[k0 + i]);
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        ar[u] = fmaf(h4.x, wg[i][u].x, ar[u]); au[u] = fmaf(h4.x, wg[i][u].y, au[u]);
+        ar[u] = fmaf(h4.y, wg[i + 1][u].x, ar[u]); au[u] = fmaf(h4.y, wg[i + 1][u].y, au[u]);
+        ar[u] = fmaf(h4.z, wg[i + 2][u].x, ar[u]); au[u] = fmaf(h4.z, wg[i + 2][u].y, au[u]);
+        ar[u] = fmaf(h4.w, wg[i + 3][u].x, ar[u]); au[u] = fmaf(h4.w, wg[i + 3][u].y, au[u]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; ++i) {
+      const float hv = hs[k0 + KR + i];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) { const float2 w = wl_g[(i * NQ + q) * H + jb + u * HJ]; ar[u] = fmaf(hv, w.x, ar[u]); au[u] = fmaf(hv, w.y, au[u]); }
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float2 cur[CH][UJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v)
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) cur[v][u] = Gs[(size_t)(c0 + v) * H + u];
+#pragma unroll
+      for (int v = 0; v < CH; ++v) {
+        const float hv = hs[k0 + KR + KL + c0 + v];
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) { ar[u] = fmaf(hv, cur[v][u].x, ar[u]); au[u] = fmaf(hv, cur[v][u].y, au[u]); }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) { part[(q * 3 + 0) * H + jb + u * HJ] = ar[u]; part[(q * 3 + 1) * H + jb + u * HJ] = au[u]; }
+    __syncthreads();
+    // gate epilogue, wave-local: the 8 partial sums of the slice's own 32 units.  r*h goes to this wave's part of xs (read back
+    // by this wave only: LDS operations of one wave execute in order), u stays in a register of the lane that will finish the unit
+    float ureg;
+    {
+      float sum = xg;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) sum += part[(qq * 3 + gsel) * H + nn];
+      const float sgm = taco_sigmoid(sum);
+      ureg = sgm;
+      if (!gsel) xs[nn] = sgm * hs[nn];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- candidate ----
+    float ac[UJ];
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) ac[u] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KR; i += 4) {
+      const float4 x4 = *reinterpret_cast<const float4*>(&xs[k0 + i]);
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) {
+        ac[u] = fmaf(x4.x, wc[i][u], ac[u]); ac[u] = fmaf(x4.y, wc[i + 1][u], ac[u]);
+        ac[u] = fmaf(x4.z, wc[i + 2][u], ac[u]); ac[u] = fmaf(x4.w, wc[i + 3][u], ac[u]);
+      }
+    }
+#pragma unroll 1
+    for (int i = 0; i < KL; ++i) {
+      const float xv = xs[k0 + KR + i];
+#pragma unroll
+      for (int u = 0; u < UJ; ++u) ac[u] = fmaf(xv, wl_c[(i * NQ + q) * H + jb + u * HJ], ac[u]);
+    }
+#pragma unroll 1
+    for (int c0 = 0; c0 < KG; c0 += CH) {
+      float cur[CH][UJ];
+#pragma unroll
+      for (int v = 0; v < CH; ++v)
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) cur[v][u] = Cs[(size_t)(c0 + v) * H + u];
+#pragma unroll
+      for (int v = 0; v < CH; ++v) {
+        const float xv = xs[k0 + KR + KL + c0 + v];
+#pragma unroll
+        for (int u = 0; u < UJ; ++u) ac[u] = fmaf(xv, cur[v][u], ac[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UJ; ++u) part[(q * 3 + 2) * H + jb + u * HJ] = ac[u];
+    __syncthreads();
+    if (gsel) {                                              // lanes 32..63: the unit whose u they hold
+      float sum = xc;
+#pragma unroll
+      for (int qq = 0; qq < NQ; ++qq) sum += part[(qq * 3 + 2) * H + nn];
+      const float c = tanhf(sum);
+      const float h = hs[nn];
+      const float hn = ureg * h + (1.f - ureg) * c;
+      const bool active = s < L;                           // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+      const int t = (d && active) ? (L - 1 - s) : s;
+      if (active) hs[nn] = hn;                             // read next step by this wave only (its K-slice = its own units)
+      a.out[((size_t)b * T + t) * 2 * H + d * H + nn] = active ? hn : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_attention : one workgroup per batch row
 // ------------------------------------------------------------------------------------------------

@@ -79,6 +79,8 @@ struct Cbhg {
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
+  size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
+                                                   // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
 };
 
 struct taco_model {
@@ -373,7 +375,19 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
     { std::vector<float> g2((size_t)H * H * 2);
       for (int k = 0; k < H; ++k)
         for (int j = 0; j < H; ++j) { g2[((size_t)k * H + j) * 2] = gk[(size_t)(I + k) * 2 * H + j]; g2[((size_t)k * H + j) * 2 + 1] = gk[(size_t)(I + k) * 2 * H + H + j]; }
-      c.res_g2[dir] = arena_put(m, g2.data(), g2.size()); }
+      c.res_g2[dir] = arena_put(m, g2.data(), g2.size());
+      if (H == 256) {
+        std::vector<float> g2p(g2.size()), c1p((size_t)H * H);
+        for (int k = 0; k < H; ++k)
+          for (int jb = 0; jb < 64; ++jb)
+            for (int u = 0; u < 4; ++u) {
+              const int j = jb + 64 * u, cp = jb * 4 + u;
+              g2p[((size_t)k * H + cp) * 2] = g2[((size_t)k * H + j) * 2]; g2p[((size_t)k * H + cp) * 2 + 1] = g2[((size_t)k * H + j) * 2 + 1];
+              c1p[(size_t)k * H + cp] = ck[(size_t)(I + k) * H + j];
+            }
+        c.res_g2p[dir] = arena_put(m, g2p.data(), g2p.size());
+        c.res_c1p[dir] = arena_put(m, c1p.data(), c1p.size());
+      } }
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
@@ -645,15 +659,19 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
   if ((m->persist == 1 || m->persist >= 4) && H == 256) {
-    // weights resident on the CU, 4 hidden units per thread (k_bigru_resu): measured 5.45 us/step vs 5.86 for one unit per thread
-    // (k_bigru_res, persist 3) and 7.1 for re-streaming everything (k_bigru_rows, persist 2); other splits (persist 4, 5) are slower
+    // weights resident on the CU, 4 hidden units per thread: k_bigru_resw 3.74 us/step; its predecessor k_bigru_resu (persist 6)
+    // 5.16, one unit per thread (k_bigru_res, persist 3) 5.7, re-streaming everything (k_bigru_rows, persist 2) 7.1
     BigruSArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T;
     auto lds = [&](int UJ, int KL) { const int NQ = 512 / (H / UJ); return ((size_t)3 * H + (size_t)NQ * 3 * H) * sizeof(float) + (size_t)KL * NQ * H * 12; };
-    if (m->persist == 4) hipLaunchKernelGGL((k_bigru_resu<256, 4, 12, 5, 3, false>), dim3(2 * B), dim3(512), lds(4, 5), st, a);
+    if (m->persist == 1) {      // default: wave-local exchanges, a thread's four units adjacent in the (column-permuted) packs
+      a.g2_0 = (const float2*)AP(m, c.res_g2p[0]); a.g2_1 = (const float2*)AP(m, c.res_g2p[1]); a.c1_0 = AP(m, c.res_c1p[0]); a.c1_1 = AP(m, c.res_c1p[1]);
+      hipLaunchKernelGGL((k_bigru_resw<16, 4, 2>), dim3(2 * B), dim3(512), lds(4, 4), st, a);
+    }
+    else if (m->persist == 4) hipLaunchKernelGGL((k_bigru_resu<256, 4, 12, 5, 3, false>), dim3(2 * B), dim3(512), lds(4, 5), st, a);
     else if (m->persist == 5) hipLaunchKernelGGL((k_bigru_resu<256, 2, 32, 10, 2, false>), dim3(2 * B), dim3(512), lds(2, 10), st, a);
-    else hipLaunchKernelGGL((k_bigru_resu<256, 4, 16, 4, 2, false>), dim3(2 * B), dim3(512), lds(4, 4), st, a);
+    else hipLaunchKernelGGL((k_bigru_resu<256, 4, 16, 4, 2, false>), dim3(2 * B), dim3(512), lds(4, 4), st, a);      // persist 6: the predecessor
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -1307,6 +1325,7 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<256, 64, 24, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<128, 32, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_resu<256, 4, 16, 4, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_resw<16, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_resu<256, 4, 12, 5, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_resu<256, 2, 32, 10, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -199,7 +199,40 @@ def test_bigru_with_lengths_and_init_state(ctx, B, persist):
     m.check_device_errors()
 
 
-@pytest.mark.parametrize("persist", [1, 2, 3, 4, 5])
+def test_bigru_wave_local_scan_is_bit_identical_to_the_four_barrier_one():
+    """k_bigru_resw (persist 1, the default: gate and state exchanges kept inside the wave that owns the K-slice, two barriers per
+    step, column-permuted weight packs read with 16-byte loads) performs the arithmetic of its predecessor k_bigru_resu (persist 6,
+    four barriers) in the same order: identical bits, with ragged lengths and an initial state too (A.7 masking, modules.py:82-86)."""
+    import torch
+    import taco_amd
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 13)
+    m = build_model(ohp, w)
+    rs = np.random.RandomState(14)
+    B, T, H = 7, 50, ohp.post_rnn_size
+    x = rs.randn(B, T, H) * 0.5
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32); lens[0] = T; lens[1] = 0
+    init = rs.randn(B, 2 * H) * 0.5
+    xd, ld, idv = dev(x, torch.float32), dev(lens), dev(init, torch.float32)
+    n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    got = {}
+    for persist in (1, 6):
+        m._lib.taco_debug_set_persistent(m._handle, persist)
+        for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
+            out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+            taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(xd), lp, ip, B, T, ptr(out), ptr(ws), n))
+            torch.cuda.synchronize()
+            got[(persist, tag)] = out.cpu().numpy()
+    m._lib.taco_debug_set_persistent(m._handle, 1)
+    m.check_device_errors()
+    for tag in ("plain", "ragged"):
+        assert np.array_equal(got[(1, tag)], got[(6, tag)]), tag
+    assert maxabs(got[(6, "plain")], O.bidirectional_gru(x, None, w, "post_cbhg/bigru")) < 1e-4
+    assert maxabs(got[(6, "ragged")], O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init)) < 1e-4
+
+
+@pytest.mark.parametrize("persist", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("B", [32, 5])
 def test_bigru_persistent_full_width_repeatable(persist, B):
     """Full-width BiGRUs, T=64, three runs: results must match the oracle and be bit-identical run to run.
