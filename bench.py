@@ -92,31 +92,81 @@ def algorithmic_flops(hp, B, T_in, n):
     return 2 * (enc + B * n * step + post)
 
 
+def source_hash():
+    """sha256 over the kernel sources: ties a committed profile (profiles/*pmc_hbm_traffic.json) to the build it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".h", ".hip")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(csrc, fn), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(name, seed):
-    """The oracle (float32, NumPy/OpenBLAS) timed on this host: a bounded sample of the same workload."""
+    """SURVEY 8(d) / BASELINE.md section 3: the CPU restatement (oracle/taco_oracle.py, float32 NumPy/OpenBLAS -- not TF1) timed on
+    this host (i) with ONE intra-op thread, mirroring the reference session's intra_op_parallelism_threads=1 (synthesizer.py:58-61),
+    and (ii) with all cores; 3 warm-up + 10 timed runs each, median.  Bounded sample: a row slice of the workload at its full
+    T_in / T_mel (rows are independent at inference, cost is linear in rows), sized to ~10-20 s of CPU work per arm."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import taco_oracle as O
+    from threadpoolctl import threadpool_limits, threadpool_info
     B, T_in, r, n, ns, mt = WORKLOADS[name]
     ohp = O.OracleHParams(max_iters=n, reduction_factor=r, model_type=mt)
-    w = O.init_weights(ohp, ns, seed)
+    w = {k: np.asarray(v, np.float32) for k, v in O.init_weights(ohp, ns, seed).items()}
     ids, L = O.synthetic_inputs(B, T_in, seed)
     spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    reps, t_total = 0, 0.0
-    while reps < 3 and t_total < 12.0:
-        t0 = time.perf_counter()
-        O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, dtype=np.float32, honor_stop=False)
-        t_total += time.perf_counter() - t0
-        reps += 1
-    frames = B * n * r * reps
-    return {"value": frames / t_total, "unit": "mel-frames/s", "cores": int(cores), "kind": "port",
-            "sample": "%d full %s forward(s) (B=%d,T_in=%d,T_mel=%d) of oracle/taco_oracle.py in float32, %.1f s"
-                      % (reps, name, B, T_in, n * r, t_total)}
+    ncores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+
+    def arm(threads, rows):
+        rows = min(rows, B)
+        sl = slice(0, rows)
+        run = lambda: O.forward(w, ohp, ids[sl], L[sl], speaker_id=None if spk is None else spk[sl], num_speakers=ns,
+                                dtype=np.float32, honor_stop=False)
+        with threadpool_limits(limits=threads):
+            ts = []
+            for i in range(13):
+                t0 = time.perf_counter()
+                run()
+                dt = time.perf_counter() - t0
+                if i >= 3:
+                    ts.append(dt)
+                if i == 0 and dt > 4.0:        # slow host: shorten the arm (still >= 1 warm-up + 3 timed)
+                    reps_left = 3
+                    ts = []
+                    for _ in range(reps_left):
+                        t0 = time.perf_counter()
+                        run()
+                        ts.append(time.perf_counter() - t0)
+                    break
+        med = float(np.median(ts))
+        return {"value": rows * n * r / med, "unit": "mel-frames/s", "threads": int(threads), "rows": int(rows), "timed_runs": len(ts),
+                "median_s": med}
+    one = arm(1, max(1, B // 16))
+    allc = arm(ncores, max(1, B // 4))
+    return {"value": allc["value"], "unit": "mel-frames/s", "cores": int(ncores), "kind": "port",
+            "sample": "oracle/taco_oracle.py in float32 (NumPy/OpenBLAS; a CPU restatement, not TF1) on a row slice of %s at full "
+                      "T_in=%d / T_mel=%d: all %d threads on %d rows (median of %d runs, %.2f s each) -> value; one thread "
+                      "(synthesizer.py:58-61 intra_op=1) on %d rows (median of %d, %.2f s each) -> single_thread"
+                      % (name, T_in, n * r, ncores, allc["rows"], allc["timed_runs"], allc["median_s"], one["rows"], one["timed_runs"],
+                         one["median_s"]),
+            "single_thread": one, "all_cores": allc}
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` as typed: spawn the N ranks (one per GPU, RCCL rendezvous on 127.0.0.1) and relay rank 0's line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -133,7 +183,27 @@ def main():
     ap.add_argument("--coalesce", type=int, default=1,
                     help="requests served per forward (PlanPool coalesce): c > 1 rides c batches of the workload's B rows through one "
                          "plan of c*B rows; a step is still one batch of B rows.  Default 1 = the BASELINE.json configuration as is")
+    ap.add_argument("--no-companions", action="store_true", help="skip the lanes=1 and exact-fp32 companion measurements")
+    ap.add_argument("--decoder-engine", type=int, default=1, help="1 persistent XCD-local decoder (default), 0 launch per stage, 2 persistent write-through")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU test hook: run only the launcher / rendezvous / max-over-ranks path on gloo and print the world size")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+    if args.selftest_launcher:
+        from importlib import import_module
+        sys.path.insert(0, ROOT)
+        D = import_module("taco_amd").dist
+        rank, local_rank, world = D.env_rank()
+        dist = D.init_process_group("gloo") if world > 1 else None
+        t = D.max_over_ranks(1.0 + rank)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher", "world_size": world, "n_gpus": args.gpus, "max_over_ranks": t}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.coalesce < 1 or (args.coalesce > 1 and (args.eager or args.steps % args.coalesce or args.warmup % args.coalesce)):
         ap.error("--coalesce c needs hipGraph plans and steps / warmup that are multiples of c")
 

@@ -256,6 +256,20 @@ int taco_debug_set_fuse_concat(taco_model* m, int on);
 int taco_debug_set_att_split(taco_model* m, int slices);
 int taco_debug_set_overlap(taco_model* m, int on);
 
+/* Decoder loop engine (reference: rnn_wrappers.py:218-341,367-415; helpers.py:9-32).  mode 1 (default): the whole loop runs as ONE
+ * persistent, weight-stationary launch (csrc/taco_decoder_xcd.h) whenever the configuration fits it -- reference widths (256-wide
+ * cells, prenet 256/128, two decoder GRUs), model_type single or deepvoice, no manual alignments, no teacher forcing, the
+ * attention memory slice of a member fits its LDS; every other call uses the launch-per-stage loop.  mode 0: always launch per
+ * stage.  mode 2: persistent with write-through (placement-independent) exchanges even when the census finds one group per XCD.
+ * rows_per_group: 0 = smallest of 1/2/4/8 that covers the batch with 8 groups; a larger value packs the batch onto fewer XCDs. */
+int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group);
+/* after a forward: out16[0] = exchange protocol the last persistent decoder launch used (0 none ran, 1 XCD-local plain stores,
+ * 2 write-through), out16[1..8] = workgroups the census saw per XCD, out16[15] = 1 when the model has a persistent-decoder pack */
+int taco_debug_decoder_info(taco_model* m, int* out16);
+/* phase timeline of group 0 / member 0 for the first 8 decoder steps: enable = 1 allocates the stamp buffer (next launches
+ * write it), out (nullable) receives [8][16] shader-clock stamps; enable = 0 frees it */
+int taco_debug_decoder_trace(taco_model* m, int enable, long long* out);
+
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
 int taco_debug_force_gemm_config(taco_model* m, int cfg);
 

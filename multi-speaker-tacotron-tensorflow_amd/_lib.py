@@ -142,6 +142,9 @@ PROTOTYPES = {
     "taco_debug_set_att_split": (_I, [_P, _I]),
     "taco_debug_set_bf3": (_I, [_P, _I, _I]),
     "taco_model_device_errors": (_I, [_P, C.POINTER(_I)]),
+    "taco_debug_set_decoder_persist": (_I, [_P, _I, _I]),
+    "taco_debug_decoder_info": (_I, [_P, C.POINTER(_I)]),
+    "taco_debug_decoder_trace": (_I, [_P, _I, C.POINTER(C.c_longlong)]),
 }
 
 _lib = None

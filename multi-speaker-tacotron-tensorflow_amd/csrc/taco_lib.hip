@@ -3,6 +3,7 @@
 // (models/tacotron.py:21-271 of the reference) and its sess.run execution (synthesizer.py:166-167).
 // No CPU compute path exists here: every stage is a gfx950 kernel from taco_kernels.h.
 #include "taco_kernels.h"
+#include "taco_decoder_xcd.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
 #include "../../include/taco_abi.h"
@@ -119,6 +120,12 @@ struct taco_model {
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
+  // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
+  size_t dx_pack = 0, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_cp = 0, dx_b_g1g = 0, dx_b_g1c = 0,
+         dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
+  int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
+  int dx_rows = 0;             // debug: force the rows per group (1,2,4,8); 0 = smallest that covers the batch
+  long long* d_trace = nullptr;   // debug: phase stamps of group 0 / member 0 (taco_debug_decoder_trace)
   hipStream_t side = nullptr;  // that second stream
   std::vector<hipEvent_t> events;
   struct TrainPacks* tp = nullptr;   // set on the shadow model of a taco_train: finalize also builds the backward packs
@@ -322,6 +329,78 @@ static GruDec make_grudec(taco_model* m, const std::string& name, int I, int H) 
   g.gx = pack_w16(m, W.data(), 3 * H, 0, I + H, 0, 3 * H, b.data());
   g.ch = pack_w16(m, ck.data(), H, I, H, 0, H, cb.data());    // h rows of candidate/kernel (+ candidate bias)
   return g;
+}
+
+static bool is_simple(const taco_model* m);
+
+// ---- persistent XCD-local decoder: per-thread weight pack (mirror of the unit mapping in taco_decoder_xcd.h) ----
+static bool dx_widths_ok(const taco_model* m) {
+  const taco_hparams& hp = m->hp;
+  return hp.attention_state_size == DX_W && hp.dec_rnn_size == DX_W && hp.attention_size == DX_W && 2 * hp.enc_rnn_size == DX_W &&
+         hp.dec_prenet_n == 2 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2 && hp.dec_layer_num == 2 &&
+         hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP && !is_simple(m);
+}
+// W: row-major [K][ldw]; col(c) = column of the matrix held by lane-column c of this member, or -1
+template <class U, class ColFn>
+static void dx_fill_unit(std::vector<float>& pack, int member, const float* W, int ldw, ColFn col) {
+  for (int tid = 0; tid < DX_NT; ++tid) {
+    const int wave = tid >> 6, lane = tid & 63, ks = lane & (U::KSL - 1), c = lane / U::KSL;
+    if (wave >= U::NWV) continue;
+    const int n = col(c);
+    if (n < 0) continue;
+    for (int j = 0; j < U::NCH; ++j)
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * U::KSL * (wave + U::NWV * j) + 2 * ks + e;
+        pack[((size_t)member * DX_NREG + U::REG0 + 2 * j + e) * DX_NT + tid] = W[(size_t)k * ldw + n];
+      }
+  }
+}
+static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std::vector<float>& bc) {
+  if (!dx_widths_ok(m)) return 0;
+  const taco_hparams& hp = m->hp;
+  const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, NCF = cdiv(rM, DX_GROUP);
+  std::vector<float> pack((size_t)DX_GROUP * DX_NREG * DX_NT, 0.f);
+  const auto& W2 = T_(m, "decoder/prenet/dense_2/kernel").data;
+  const auto& agk = T_(m, "decoder/attention_gru/gates/kernel").data; const auto& ack = T_(m, "decoder/attention_gru/candidate/kernel").data;
+  const auto& wq = T_(m, "attention/query_layer/kernel").data;
+  const auto& cpk = T_(m, "decoder/concat_projection/kernel").data;
+  const auto& g1k = T_(m, "decoder/gru_1/gates/kernel").data; const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
+  const auto& g2k = T_(m, "decoder/gru_2/gates/kernel").data; const auto& c2k = T_(m, "decoder/gru_2/candidate/kernel").data;
+  const auto& fk = T_(m, "decoder/frame_projection/kernel").data;
+  for (int mem = 0; mem < DX_GROUP; ++mem) {
+    auto col8 = [&](int c) { return c < 8 ? mem * 8 + c : -1; };
+    auto colg = [&](int c) { return c < 8 ? mem * 8 + c : H + mem * 8 + (c - 8); };   // r columns, then u columns (A.6: r | u)
+    auto col4 = [&](int c) { return c < 4 ? mem * 4 + c : -1; };
+    auto colf = [&](int c) { const int n = mem * NCF + c; return (c < NCF && n < rM) ? n : -1; };
+    dx_fill_unit<DxU_P1>(pack, mem, Wc.data(), DX_W, col8);
+    dx_fill_unit<DxU_P2>(pack, mem, W2.data(), DX_P2, col4);
+    dx_fill_unit<DxU_AG>(pack, mem, agk.data(), 2 * H, colg);                         // rows [p2 (128) ; h (256)]
+    dx_fill_unit<DxU_AX>(pack, mem, ack.data(), H, col8);                             // candidate rows of x
+    dx_fill_unit<DxU_AC>(pack, mem, ack.data() + (size_t)DX_P2 * H, H, col8);         // candidate rows of h
+    dx_fill_unit<DxU_Q>(pack, mem, wq.data(), H, col8);
+    dx_fill_unit<DxU_CP>(pack, mem, cpk.data(), H, col8);
+    dx_fill_unit<DxU_G1G>(pack, mem, g1k.data(), 2 * H, colg);
+    dx_fill_unit<DxU_G1X>(pack, mem, c1k.data(), H, col8);
+    dx_fill_unit<DxU_G1C>(pack, mem, c1k.data() + (size_t)H * H, H, col8);
+    dx_fill_unit<DxU_G2G>(pack, mem, g2k.data(), 2 * H, colg);
+    dx_fill_unit<DxU_G2X>(pack, mem, c2k.data(), H, col8);
+    dx_fill_unit<DxU_G2C>(pack, mem, c2k.data() + (size_t)H * H, H, col8);
+    dx_fill_unit<DxU_F>(pack, mem, fk.data(), rM, colf);
+  }
+  m->dx_pack = arena_put(m, pack.data(), pack.size());
+  auto putv = [&](const std::vector<float>& v) { return arena_put(m, v.data(), v.size()); };
+  m->dx_b_p1_0 = putv(T_(m, "decoder/prenet/dense_1/bias").data);
+  m->dx_b_p1c = putv(bc);
+  m->dx_b_p2 = putv(T_(m, "decoder/prenet/dense_2/bias").data);
+  m->dx_b_ag = putv(T_(m, "decoder/attention_gru/gates/bias").data);
+  m->dx_b_ac = putv(T_(m, "decoder/attention_gru/candidate/bias").data);
+  m->dx_b_cp = putv(T_(m, "decoder/concat_projection/bias").data);
+  m->dx_b_g1g = putv(T_(m, "decoder/gru_1/gates/bias").data);
+  m->dx_b_g1c = putv(T_(m, "decoder/gru_1/candidate/bias").data);
+  m->dx_b_g2g = putv(T_(m, "decoder/gru_2/gates/bias").data);
+  m->dx_b_g2c = putv(T_(m, "decoder/gru_2/candidate/bias").data);
+  m->dx_b_f = putv(T_(m, "decoder/frame_projection/bias").data);
+  return 0;
 }
 
 static void cbhg_dims(Cbhg& c, int in_dim, int K, int C, int maxpool, int depth, int rnn, const int* projs, int nproj, int pw) {
@@ -859,10 +938,17 @@ static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, 
                       is_deepvoice(m) ? w.spk.vec[1] : nullptr, enc_out, w.cb);
 }
 
+static int dx_rows_per_group(const taco_model* m, int B) {
+  if (m->dx_rows == 1 || m->dx_rows == 2 || m->dx_rows == 4 || m->dx_rows == 8) { if (m->dx_rows * DX_NGROUP >= B) return m->dx_rows; }
+  int RG = 1;
+  while (RG < 8 && RG * DX_NGROUP < B) RG *= 2;
+  return RG;
+}
 // ---- decoder (tacotron.py:120-214) ----
 struct DecWs {
   float *keys, *zero, *ctx, *pz[4], *h_att, *rh, *u, *xc, *q, *align, *o[5], *hd[4], *Y, *escr;
   int* nz;
+  unsigned long long* xbuf; size_t xbuf_bytes; unsigned* dxctl;   // persistent decoder: exchange granules, census words
   SpkWs spk;
 };
 static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, DecWs& w) {
@@ -884,6 +970,48 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
   w.Y = nullptr;
   w.nz = cv.i((size_t)n * B);
   carve_spk(cv, m, B, w.spk);
+  {  // persistent decoder (taco_decoder_xcd.h): sized for the largest rows-per-group, so a debug override cannot outgrow it
+    w.xbuf_bytes = (size_t)DX_NGROUP * dx_xlayout(8, T_in).total * sizeof(unsigned long long);
+    w.xbuf = (unsigned long long*)cv.raw(w.xbuf_bytes);
+    w.dxctl = (unsigned*)cv.raw(256);
+  }
+}
+// persistent decoder: usable for this call?  (reference widths, no manual alignments / teacher forcing, the member's LDS fits)
+static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual, const float* teacher) {
+  if (!m->dx_mode || !m->dx_pack || manual || teacher || B > 8 * DX_NGROUP) return false;
+  const int RG = dx_rows_per_group(m, B);
+  return dx_lds_floats(RG, T_in) * sizeof(float) <= 160 * 1024;
+}
+template <int RG>
+static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
+  hipLaunchKernelGGL((k_decoder_xcd<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, int B, int T_in, int n, float* mel, float* align_out,
+                     float* dbg, int dbgw, const DecWs& w, const float* h_att0, const float* h10, const float* h20) {
+  const int RG = dx_rows_per_group(m, B);
+  DxArgs a; memset(&a, 0, sizeof a);
+  a.wpack = AP(m, m->dx_pack);
+  a.b_p1_0 = AP(m, m->dx_b_p1_0); a.b_p1c = AP(m, m->dx_b_p1c); a.b_p2 = AP(m, m->dx_b_p2); a.b_ag = AP(m, m->dx_b_ag); a.b_ac = AP(m, m->dx_b_ac);
+  a.b_cp = AP(m, m->dx_b_cp); a.b_g1g = AP(m, m->dx_b_g1g); a.b_g1c = AP(m, m->dx_b_g1c); a.b_g2g = AP(m, m->dx_b_g2g); a.b_g2c = AP(m, m->dx_b_g2c);
+  a.b_f = AP(m, m->dx_b_f);
+  a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
+  a.keys = w.keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
+  a.mel = mel; a.hist = align_out; a.nz = w.nz; a.dbg = dbg; a.dbgw = dbgw;
+  a.xbuf = w.xbuf; a.ctl = w.dxctl; a.err = m->d_err; a.trace = m->d_trace;
+  a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
+  a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
+  // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
+  HIPCHK(hipMemsetAsync(w.xbuf, 0, w.xbuf_bytes, st));
+  HIPCHK(hipMemsetAsync(w.dxctl, 0, 256, st));
+  const size_t lds = dx_lds_floats(RG, T_in) * sizeof(float);
+  switch (RG) {
+    case 1: return dx_launch_rg<1>(st, a, lds);
+    case 2: return dx_launch_rg<2>(st, a, lds);
+    case 4: return dx_launch_rg<4>(st, a, lds);
+    default: return dx_launch_rg<8>(st, a, lds);
+  }
 }
 static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B,
                            int T_in, int n, const float* manual, const float* teacher, float* mel, float* align_out,
@@ -921,6 +1049,16 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
   const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
   const int dbgw = As + D + L * Hd;
+  if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
+    // the whole loop as ONE persistent launch (taco_decoder_xcd.h); the launch-per-stage loop below is the general path
+    TRY(dx_launch(m, st, enc_out, B, T_in, n, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr,
+                  dv ? spk->vec[4] : nullptr));
+    if (stop_step) {
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(64), 0, st, w.nz, B, n, stop_step);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
   for (int t = 0; t < n; ++t) {
     // frame fed to the prenet: zeros at t=0 (helpers.py:70-72), else last of the r frames (helpers.py:31)
     const float* frame; int ldf;
@@ -1234,6 +1372,7 @@ int taco_model_finalize(taco_model* m) {
       bc[q] = (float)acc;
     }
     m->prenet1_next = pack_w16(m, Wc.data(), P0, 0, Hd + D, 0, P0, bc.data());
+    if (!m->tp) TRY(dx_build_pack(m, Wc, bc));
   }
   if (!m->tp && hp.dec_layer_num > 0) {
     // Decoder GRU 1 with the concat projection folded in.  o0 = z . Wc + bc is linear in z = [h_att | ctx (| spk)], so
@@ -1332,6 +1471,10 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   m->events.resize(192);
   for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1348,6 +1491,7 @@ void taco_model_destroy(taco_model* m) {
   if (!m) return;
   if (m->darena) (void)hipFree(m->darena);
   if (m->d_err) (void)hipFree(m->d_err);
+  if (m->d_trace) (void)hipFree(m->d_trace);
   for (auto& e : m->events) (void)hipEventDestroy(e);
   if (m->side) (void)hipStreamDestroy(m->side);
   delete m;
@@ -1417,6 +1561,31 @@ int taco_debug_set_overlap(taco_model* m, int on) {
 int taco_debug_set_persistent(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->persist = on;
+  return 0;
+}
+
+int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  if (mode < 0 || mode > 2) return fail(TACO_ERR_ARG, "mode must be 0 (launch per stage), 1 (persistent) or 2 (persistent, write-through exchanges)");
+  m->dx_mode = mode; m->dx_rows = rows_per_group;
+  return 0;
+}
+int taco_debug_decoder_info(taco_model* m, int* out16) {
+  if (!m || !m->finalized || !out16) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  unsigned v[16];
+  HIPCHK(hipMemcpy(v, m->d_err + 8, sizeof v, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 16; ++i) out16[i] = (int)v[i];
+  out16[15] = m->dx_pack ? 1 : 0;
+  return 0;
+}
+int taco_debug_decoder_trace(taco_model* m, int enable, long long* out) {
+  if (!m || !m->finalized) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  const size_t bytes = (size_t)DX_TRACE_STEPS * DX_TRACE_SLOTS * sizeof(long long);
+  if (enable && !m->d_trace) { HIPCHK(hipMalloc((void**)&m->d_trace, bytes)); HIPCHK(hipMemset(m->d_trace, 0, bytes)); }
+  if (out && m->d_trace) HIPCHK(hipMemcpy(out, m->d_trace, bytes, hipMemcpyDeviceToHost));
+  if (!enable && m->d_trace) { (void)hipFree(m->d_trace); m->d_trace = nullptr; }
   return 0;
 }
 

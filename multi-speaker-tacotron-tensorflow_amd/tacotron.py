@@ -503,6 +503,27 @@ class Tacotron(object):
                                                   _ptr(ws), n))
         return (lin, post) if return_post else lin
 
+    def set_decoder_engine(self, mode=1, rows_per_group=0):
+        """Decoder loop engine: 1 = one persistent weight-stationary launch when the configuration fits (default), 0 = one launch per
+        stage, 2 = persistent with write-through exchanges.  Cached plans are dropped (they captured the previous engine)."""
+        _lib.check(self._lib.taco_debug_set_decoder_persist(self._handle, int(mode), int(rows_per_group)))
+        self._plans.clear()
+
+    def decoder_engine_info(self):
+        """After a forward (synchronises): {'protocol': 0 none / 1 XCD-local / 2 write-through, 'per_xcd': [...], 'has_pack': bool}."""
+        torch.cuda.synchronize(self.device)
+        v = (C.c_int * 16)()
+        _lib.check(self._lib.taco_debug_decoder_info(self._handle, v))
+        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15])}
+
+    def decoder_trace(self, enable=True, read=False):
+        """Phase stamps (shader clocks) of group 0 / member 0 of the persistent decoder, first 8 steps x 16 slots."""
+        out = (C.c_longlong * 128)() if read else None
+        if read:
+            torch.cuda.synchronize(self.device)
+        _lib.check(self._lib.taco_debug_decoder_trace(self._handle, 1 if enable else 0, out))
+        return np.array(out[:], np.int64).reshape(8, 16) if read else None
+
     def check_device_errors(self):
         """Synchronises and raises if a persistent kernel's bounded spin expired (outputs invalid)."""
         v = C.c_int(0)

@@ -1,0 +1,184 @@
+"""Persistent XCD-local decoder (csrc/taco_decoder_xcd.h) at the reference widths: every step against the float64 oracle,
+against the launch-per-stage engine, across batch sizes / rows-per-group / exchange protocols, and the horizons VERDICT r01
+asked for (C5 at real widths, C1 and C3 at full length).  Reference: rnn_wrappers.py:218-341,367-415; helpers.py:9-32."""
+import numpy as np
+import pytest
+
+import taco_oracle as O
+from util import build_model, maxabs, argmax_match
+
+pytestmark = pytest.mark.gpu
+
+
+def _decoder_vs_oracle(ohp, w, ids, L, n, spk=None, ns=1, mode=1, rows=0, tol=2e-4):
+    import torch
+    taps = {}
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, taps=taps, honor_stop=False)
+    m = build_model(ohp, w, num_speakers=ns)
+    m.set_decoder_engine(mode, rows)
+    mel, al, stop, dbg = m.decoder(taps["encoder"], n, speaker_id=spk, debug=True)
+    torch.cuda.synchronize()
+    info = m.decoder_engine_info()
+    m.check_device_errors()
+    dbg = dbg.cpu().numpy()
+    As, D, H = ohp.attention_state_size, 2 * ohp.enc_rnn_size, ohp.dec_rnn_size
+    for t, st in enumerate(taps["steps"]):
+        assert maxabs(dbg[t, :, :As], st["h_att"]) < tol, "h_att step %d" % t
+        assert maxabs(dbg[t, :, As:As + D], st["ctx"]) < tol, "ctx step %d" % t
+        for i, h in enumerate(st["h"]):
+            o = As + D + i * H
+            assert maxabs(dbg[t, :, o:o + H], h) < tol, "h_%d step %d" % (i + 1, t)
+    assert maxabs(mel.cpu().numpy(), ref["mel"]) < tol
+    assert maxabs(al.cpu().numpy(), ref["alignments"]) < tol
+    nchk, bad = argmax_match(al.cpu().numpy(), ref["alignments"])
+    assert bad == 0
+    assert int(stop.item()) == n
+    return m, info, (mel.cpu().numpy(), al.cpu().numpy()), taps
+
+
+@pytest.mark.parametrize("atype", ["bah_mon", "bah", "bah_norm"])
+def test_every_step_matches_the_oracle_at_reference_widths(atype):
+    ohp = O.OracleHParams(max_iters=6, attention_type=atype)
+    w = O.init_weights(ohp, 1, 311)
+    ids, L = O.synthetic_inputs(5, 37, 312, ragged=True)
+    m, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, 6)
+    assert info["has_pack"] and info["protocol"] in (1, 2), info
+    assert sum(info["per_xcd"]) == 256, info
+
+
+def test_deepvoice_initial_states_and_reduction_factor_5():
+    ohp = O.OracleHParams(max_iters=5, reduction_factor=5, model_type="deepvoice")
+    w = O.init_weights(ohp, 4, 313)
+    ids, L = O.synthetic_inputs(6, 20, 314, ragged=True)
+    spk = (np.arange(6) % 4).astype(np.int32)
+    _, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, 5, spk=spk, ns=4)
+    assert info["protocol"] in (1, 2)
+
+
+@pytest.mark.parametrize("B,rows", [(1, 0), (8, 0), (13, 0), (32, 0), (33, 0), (64, 0), (8, 2), (8, 8), (16, 4)])
+def test_batch_sizes_and_rows_per_group(B, rows):
+    """rows per group 1 / 2 / 4 / 8 (B <= 8, 16, 32, 64), ragged last group, and batches packed onto fewer XCDs."""
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 315)
+    ids, L = O.synthetic_inputs(B, 32, 316 + B, ragged=True)
+    _, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, 4, rows=rows)
+    assert info["protocol"] in (1, 2)
+
+
+def test_write_through_protocol_and_launch_engine_agree():
+    """mode 2 (sc1 stores, placement-independent) and mode 1 must give bit-identical results (same arithmetic, different cache
+    policy); the launch-per-stage engine (mode 0) is the same function up to summation order."""
+    import torch
+    ohp = O.OracleHParams(max_iters=12)
+    w = O.init_weights(ohp, 1, 317)
+    ids, L = O.synthetic_inputs(9, 50, 318, ragged=True)
+    m, info, (mel1, al1), taps = _decoder_vs_oracle(ohp, w, ids, L, 12)
+    m.set_decoder_engine(2)
+    mel2, al2, _, _ = m.decoder(taps["encoder"], 12)
+    info2 = m.decoder_engine_info()
+    assert info2["protocol"] == 2
+    assert np.array_equal(mel2.cpu().numpy(), mel1) and np.array_equal(al2.cpu().numpy(), al1)
+    m.set_decoder_engine(1)
+    mel3, al3, _, _ = m.decoder(taps["encoder"], 12)
+    torch.cuda.synchronize()
+    assert np.array_equal(mel3.cpu().numpy(), mel1), "persistent decoder is not bit-repeatable"
+    m.set_decoder_engine(0)
+    mel0, al0, _, _ = m.decoder(taps["encoder"], 12)
+    torch.cuda.synchronize()
+    assert maxabs(mel0.cpu().numpy(), mel1) < 2e-5 and maxabs(al0.cpu().numpy(), al1) < 2e-5
+    m.check_device_errors()
+
+
+def test_stop_flags_of_the_persistent_decoder():
+    """helpers.py:29: a row is finished when all r*num_mels outputs of a step are exactly 0."""
+    import torch
+    ohp = O.OracleHParams(max_iters=5)
+    w = O.init_weights(ohp, 1, 319)
+    w["decoder/frame_projection/kernel"][:] = 0
+    w["decoder/frame_projection/bias"][:] = 0
+    ids, L = O.synthetic_inputs(3, 16, 320)
+    taps = {}
+    O.forward(w, ohp, ids, L, taps=taps, honor_stop=False)
+    m = build_model(ohp, w)
+    mel, al, stop, _ = m.decoder(taps["encoder"], 5)
+    torch.cuda.synchronize()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    assert int(stop.item()) == 1 and not mel.cpu().numpy().any()
+
+
+def test_unsupported_calls_fall_back_to_the_launch_engine():
+    """manual alignments and teacher forcing are served by the launch-per-stage loop (same results as before)."""
+    import torch
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 321)
+    ids, L = O.synthetic_inputs(2, 16, 322)
+    man = np.random.RandomState(3).dirichlet(np.ones(16), (2, 4))
+    taps = {}
+    ref = O.forward(w, ohp, ids, L, manual_alignments=man, taps=taps, honor_stop=False)
+    m = build_model(ohp, w)
+    mel, al, _, _ = m.decoder(taps["encoder"], 4, manual_alignments=man)
+    torch.cuda.synchronize()
+    assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4
+    assert maxabs(al.cpu().numpy(), np.transpose(man, (0, 2, 1))) < 1e-6
+
+
+def test_C5_real_widths_against_the_oracle():
+    """the long-input regime (T_in = 512) at reference widths, 24 steps, B = 2: persistent engine (one row
+    per group, 32 members per row) and the launch engine with the split attention forced and automatic."""
+    import torch
+    ohp = O.OracleHParams(max_iters=24)
+    w = O.init_weights(ohp, 1, 1234 + 4)
+    ids, L = O.synthetic_inputs(2, 512, 323, ragged=True)
+    m, info, (mel1, al1), taps = _decoder_vs_oracle(ohp, w, ids, L, 24)
+    assert info["protocol"] in (1, 2)
+    ref_mel = O.forward(w, ohp, ids, L, n_steps=24, honor_stop=False)["mel"]
+    for split in (-1, 4):
+        m.set_decoder_engine(0)
+        m._lib.taco_debug_set_att_split(m._handle, split)
+        mel0, al0, _, _ = m.decoder(taps["encoder"], 24)
+        torch.cuda.synchronize()
+        assert maxabs(mel0.cpu().numpy(), ref_mel) < 2e-4, "launch engine, att_split %d" % split
+        assert maxabs(al0.cpu().numpy(), al1) < 2e-5
+    m._lib.taco_debug_set_att_split(m._handle, -1)
+
+
+def test_C1_full_length_200_steps():
+    """C1 (B=1, T_in=64, r=5) over all 200 decoder steps, end to end."""
+    import torch
+    B, T_in, r, n, ns, mt = O.CONFIGS["C1"]
+    ohp = O.OracleHParams(max_iters=n, reduction_factor=r)
+    w = O.init_weights(ohp, 1, 1234)
+    ids, L = O.synthetic_inputs(B, T_in, 1234)
+    m = build_model(ohp, w)
+    lin, al = m.run(inputs=ids, input_lengths=L)
+    torch.cuda.synchronize()
+    ref = O.forward(w, ohp, ids, L)
+    assert maxabs(m.mel_outputs.cpu().numpy(), ref["mel"]) < 1e-3
+    assert maxabs(lin.cpu().numpy(), ref["linear"]) < 1e-3
+    nchk, bad = argmax_match(al.cpu().numpy(), ref["alignments"])
+    print("C1: argmax compared at %d of %d steps" % (nchk, al.shape[0] * al.shape[2]))
+    assert bad == 0
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    m.check_device_errors()
+
+
+def test_C3_full_length_128_steps_on_8_of_the_32_rows():
+    """C3 (deepvoice, 4 speakers) at all 128 steps; the float64 oracle runs 8 of the 32 rows (rows are
+    independent at inference), the device runs all 32."""
+    import torch
+    B, T_in, r, n, ns, mt = O.CONFIGS["C3"]
+    ohp = O.OracleHParams(max_iters=n, reduction_factor=r, model_type=mt)
+    w = O.init_weights(ohp, ns, 1234 + 2)
+    ids, L = O.synthetic_inputs(B, T_in, 1234 + 2, ragged=True)
+    spk = (np.arange(B) % ns).astype(np.int32)
+    m = build_model(ohp, w, num_speakers=ns)
+    lin, al = m.run(inputs=ids, input_lengths=L, speaker_id=spk, honor_stop=False)
+    torch.cuda.synchronize()
+    rows = np.arange(0, 32, 4)
+    ref = O.forward(w, ohp, ids[rows], L[rows], speaker_id=spk[rows], num_speakers=ns, honor_stop=False)
+    assert maxabs(m.mel_outputs.cpu().numpy()[rows], ref["mel"]) < 1e-3
+    assert maxabs(lin.cpu().numpy()[rows], ref["linear"]) < 1e-3
+    nchk, bad = argmax_match(al.cpu().numpy()[rows], ref["alignments"])
+    print("C3: argmax compared at %d of %d steps" % (nchk, len(rows) * n))
+    assert bad == 0
+    m.check_device_errors()
