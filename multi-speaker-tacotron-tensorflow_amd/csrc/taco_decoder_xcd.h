@@ -5,28 +5,29 @@
 // (ConcatOutputAndAttentionWrapper); tacotron.py:127-181 (cells), helpers.py:9-32 (TacoTestHelper: feed back the last of the r
 // frames, stop flags); SURVEY App. A.6 (TF GRUCell), A.9-A.11 (scores and normalisers).
 //
-// Why this shape.  A decoder step is a chain of 12 dependent mat-vec / attention stages over [B, <=768] activations and
-// 6.1 MB of weights.  As one launch per stage the chain costs ~4.5 us per link on MI355X (profiles/r01_*: kernel boundary +
-// cold weight fetch + a short MFMA chain), 42.5 us per step at C2.  Here the step never leaves the chip's registers:
-//   * 256 workgroups of 512 threads (two waves per SIMD: 256 VGPRs per thread), one per CU.  The 32 CUs of one XCD form a GROUP that owns RG batch rows for the whole
-//     loop (C2: 8 groups x 4 rows; C5: 8 x 1).  Groups never talk to each other.
-//   * Weight-stationary: member m of a group owns 1/32 of the output columns of every stage and keeps exactly those weights
-//     in VGPRs for the whole launch (96 registers per thread = 192 KB per CU; loaded once, coalesced, from a per-thread pack).
-//   * Attention memory stationary: the member also keeps its slice of the keys (a block of encoder positions of one of the
-//     group's rows, all channels) and of the values (all positions, a block of channels) in LDS -- the per-step K/V stream of
-//     the launch-per-stage path (8.4 MB per step at C2) disappears.
+// Why this shape.  A decoder step is a chain of dependent mat-vec / attention stages over [B, <=768] activations and 6 MB of
+// weights.  As one launch per stage the chain costs ~4.5 us per link on MI355X (profiles/r01_*: kernel boundary + cold weight
+// fetch + a short MFMA chain), 42.5 us per step at C2.  Here the step never leaves the chip's registers:
+//   * 256 workgroups of 512 threads (two waves per SIMD: 256 VGPRs per thread), one per CU.  The 32 CUs of one XCD form a
+//     GROUP that owns RG batch rows for the whole loop (C2: 8 groups x 4 rows; C5: 8 x 1).  Groups never talk to each other.
+//   * Weight-stationary: member m of a group owns 8 of the 256 output columns of every stage, wave w of the member owns
+//     column 8m + w, and every lane keeps its K-slice (4 consecutive inputs per 256) of that column's weights in VGPRs for
+//     the whole launch (106 registers per thread + the member's slice of the query layer; loaded once, coalesced, from a
+//     per-thread pack built at finalize).  A GRU unit (reset gate, update gate, candidate) lives entirely in one wave.
+//   * Attention memory stationary: the member also keeps, for ONE of the group's rows, a channel block of the keys and of the
+//     values (all encoder positions x 256*RG/32 channels) in LDS -- the per-step K/V stream of the launch-per-stage path
+//     (8.4 MB per step at C2) disappears.  Scores are summed over channel blocks, so the query is needed only for the
+//     member's own channels and is computed locally (no exchange of the query).
 //   * Between stages the members exchange their column slices through the XCD's own L2: 8-byte {value, tag = step+1}
 //     granules (the data is the flag), producer store -> consumer poll with L1-bypassing (sc1) loads.  When every XCD runs
-//     exactly one 32-member group (checked by an in-kernel census of HW_REG_XCC_ID) the producer stores are PLAIN stores:
-//     the line stays in the shared L2 and the hop costs an L2 round trip.  Otherwise (or with force_wt) the stores are
-//     write-through (sc1) and the protocol is placement-independent (MI355X_MICROARCH.md, inter-workgroup visibility).
+//     exactly one 32-member group (checked by an in-kernel census of HW_REG_XCC_ID) the producer stores stay in the shared L2
+//     (sc0) and a hop costs an L2 round trip.  Otherwise (or with force_wt) the stores are write-through (sc1) and the protocol
+//     is placement-independent (MI355X_MICROARCH.md, inter-workgroup visibility).  10 exchanges per step.
+//   * A stage is: gather the previous stage's vector into LDS -> one barrier -> every wave: one float4 of each row's input per
+//     lane, FMAs against its resident weights, a full-rate DPP wave reduction, the epilogue in lanes 0..RG-1, publish.  The parts
+//     of a stage that do not depend on the vector in flight (the h rows of the gates, the context rows of the next prenet, ...)
+//     run before the wait for it.
 //   * Every spin is bounded; a timeout raises a.err and the launch drains without hanging.
-//
-// Thread mapping of a mat-vec unit U<K, NCW, NWV> on a member: lane = c*KSL + ks with KSL = 64/NCW lanes per column, wave w <
-// NWV takes the w-th K super-slice; thread (w, c, ks) holds W[k][col(c)] for k = 2*(ks + KSL*(w + NWV*j)) + e, j < NCH,
-// e < 2 in registers REG0 + 2j + e, reads the matching float2 of every row's input vector from LDS (conflict-free: a wave
-// reads KSL consecutive float2), reduces over ks with 2-4 full-rate DPP steps and leaves NWV partial sums per output in LDS
-// for the epilogue threads.
 #pragma once
 #include "taco_kernels.h"
 
@@ -40,89 +41,73 @@ typedef __attribute__((address_space(1))) unsigned dx_gu32;
 #define DX_W 256             // attention_state_size = dec_rnn_size = attention_size = 2*enc_rnn_size = dec_prenet[0]
 #define DX_P2 128            // dec_prenet[1]
 #define DX_SPIN_LIMIT (1u << 21)
-#define DX_XREGS 32          // registers a mat-vec unit may spend on input values in flight
 #define DX_TRACE_STEPS 8
 #define DX_TRACE_SLOTS 16
 
-// register map of the per-thread weight pack (host mirror: dx_build_pack in taco_lib.hip)
+// Register map of the per-thread weight pack (host mirror: dx_build_pack in taco_lib.hip).  A PASS multiplies one 256-wide
+// (AGX: 128-wide) input vector with NCOLS weight columns of the wave; lane l holds inputs 4l..4l+3 (AGX: 2l, 2l+1) of each:
+// register REG0 + 4*col + e  (AGX: REG0 + 2*col + e).
 enum {
-  DXR_P1 = 0,    // [out2 | ctx] (512) -> 8 columns: composite of frame projection and prenet layer 1 (taco_lib.hip, prenet1_next)
-  DXR_P2 = 8,    // 256 -> 4 columns
-  DXR_AG = 10,   // attention GRU gates: [p2 | h] (384) -> r (8 cols) | u (8 cols) of this member
-  DXR_AX = 22,   // attention GRU candidate, x rows: p2 (128) -> 8
-  DXR_AC = 24,   // attention GRU candidate, h rows: r*h (256) -> 8
-  DXR_Q = 28,    // query layer 256 -> 8
-  DXR_CP = 32,   // concat projection [h_att | ctx] (512) -> 8
-  DXR_G1G = 40, DXR_G1X = 56, DXR_G1C = 60,   // decoder GRU 1: [o0 | h1] (512) -> 16; o0 -> 8; r*h1 -> 8
-  DXR_G2G = 64, DXR_G2X = 80, DXR_G2C = 84,   // decoder GRU 2
-  DXR_F = 88,    // frame projection 256 -> up to 16 columns of r*num_mels
-  DX_NREG = 96
+  DXR_P2 = 0,     // prenet layer 2: p1 -> column 4m + w (waves 0-3)                                   1 col
+  DXR_AGH = 4,    // attention GRU gates, h rows: h_att -> r, u                                        2 cols
+  DXR_AGX = 12,   // attention GRU, x rows (128): p2 -> r, u, candidate-x                              3 cols x 2 regs
+  DXR_AC = 18,    // attention GRU candidate, h rows: r*h -> c                                         1 col
+  DXR_G1H = 22,   // decoder GRU 1 gates, h rows: h1 -> r, u                                           2 cols
+  DXR_G1A = 30,   // GRU 1 with the concat projection folded in, h_att rows: -> r, u, candidate-x, o0  4 cols
+  DXR_G1B = 46,   // the same, context rows                                                            4 cols
+  DXR_G1C = 62,   // GRU 1 candidate, h rows: r*h1 -> c
+  DXR_G2H = 66,   // decoder GRU 2 gates, h rows
+  DXR_G2X = 74,   // GRU 2, x rows: out1 -> r, u, candidate-x                                          3 cols
+  DXR_G2C = 86,   // GRU 2 candidate, h rows
+  DXR_P1C = 90,   // next step's prenet layer 1 (frame projection folded in), context rows
+  DXR_P1O = 94,   // the same, GRU-stack-output rows
+  DXR_F = 98,     // frame projection: out2 -> columns NCF*m + w and NCF*m + w + 8                     2 cols
+  DX_NREG = 106
 };
-
-template <int K_, int NCW_, int NWV_, int REG0_>
-struct DxU {
-  static constexpr int K = K_, NCW = NCW_, NWV = NWV_, REG0 = REG0_;
-  static constexpr int KSL = 64 / NCW_;
-  static constexpr int NCH = K_ / (2 * KSL * NWV_);
-  static_assert(NCH * 2 * KSL * NWV_ == K_ && NCH >= 1 && NWV_ <= DX_NW, "unit does not tile");
-};
-typedef DxU<512, 8, 8, DXR_P1> DxU_P1;
-typedef DxU<256, 4, 8, DXR_P2> DxU_P2;
-typedef DxU<384, 16, 8, DXR_AG> DxU_AG;
-typedef DxU<128, 8, 8, DXR_AX> DxU_AX;
-typedef DxU<256, 8, 8, DXR_AC> DxU_AC;
-typedef DxU<256, 8, 8, DXR_Q> DxU_Q;
-typedef DxU<512, 8, 8, DXR_CP> DxU_CP;
-typedef DxU<512, 16, 8, DXR_G1G> DxU_G1G;
-typedef DxU<256, 8, 8, DXR_G1X> DxU_G1X;
-typedef DxU<256, 8, 8, DXR_G1C> DxU_G1C;
-typedef DxU<512, 16, 8, DXR_G2G> DxU_G2G;
-typedef DxU<256, 8, 8, DXR_G2X> DxU_G2X;
-typedef DxU<256, 8, 8, DXR_G2C> DxU_G2C;
-typedef DxU<256, 16, 8, DXR_F> DxU_F;
-static_assert(DXR_P2 - DXR_P1 == 2 * DxU_P1::NCH && DXR_AG - DXR_P2 == 2 * DxU_P2::NCH && DXR_AX - DXR_AG == 2 * DxU_AG::NCH &&
-              DXR_AC - DXR_AX == 2 * DxU_AX::NCH && DXR_Q - DXR_AC == 2 * DxU_AC::NCH && DXR_CP - DXR_Q == 2 * DxU_Q::NCH &&
-              DXR_G1G - DXR_CP == 2 * DxU_CP::NCH && DXR_G1X - DXR_G1G == 2 * DxU_G1G::NCH && DXR_G1C - DXR_G1X == 2 * DxU_G1X::NCH &&
-              DXR_G2G - DXR_G1C == 2 * DxU_G1C::NCH && DXR_G2X - DXR_G2G == 2 * DxU_G2G::NCH && DXR_G2C - DXR_G2X == 2 * DxU_G2X::NCH &&
-              DXR_F - DXR_G2C == 2 * DxU_G2C::NCH && DX_NREG - DXR_F == 2 * DxU_F::NCH, "register map");
 
 // per-row state vectors in LDS (floats)
-enum { DXS_P2 = 0, DXS_HATT = 128, DXS_CTX = 384, DXS_OUT2 = 640, DXS_T = 896, DXS_O0 = 1152, DXS_H1 = 1408, DXS_OUT1 = 1664,
-       DXS_H2 = 1920, DXS_LD = 2176 };
+enum { DXS_P2 = 0, DXS_HATT = 128, DXS_CTX = 384, DXS_OUT2 = 640, DXS_T = 896, DXS_H1 = 1152, DXS_OUT1 = 1408, DXS_H2 = 1664,
+       DXS_LD = 1920 };
+// own-column bias table in LDS: bl[slot][wave]
+enum { DXB_P1 = 0, DXB_P2, DXB_AR, DXB_AU, DXB_AC, DXB_G1R, DXB_G1U, DXB_G1X, DXB_O0, DXB_G1C, DXB_G2R, DXB_G2U, DXB_G2C, DXB_F0, DXB_F1,
+       DXB_N };
 
-// exchange buffers of one group, in granules, for RG rows (host mirror: dx_xbuf_granules)
-struct DxX { int p1, p2, rha, ha, q, sc, ctx, o0, rh1, h1, rh2, h2, total; };
+// exchange buffers of one group, in granules, for RG rows (the host sizes the buffer with RG = 8)
+struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, total; };
 __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
   DxX x; int o = 0;
   x.p1 = o; o += RG * DX_W;  x.p2 = o; o += RG * DX_P2; x.rha = o; o += RG * DX_W; x.ha = o; o += RG * DX_W;
-  x.q = o; o += RG * DX_W;   x.sc = o; o += RG * T_in;  x.ctx = o; o += RG * DX_W; x.o0 = o; o += RG * DX_W;
-  x.rh1 = o; o += RG * DX_W; x.h1 = o; o += RG * DX_W;  x.rh2 = o; o += RG * DX_W; x.h2 = o; o += RG * DX_W;
+  x.sc = o; o += DX_GROUP * T_in;                         // partial scores: [row][member of the row][position]
+  x.ctx = o; o += RG * DX_W; x.rh1 = o; o += RG * DX_W; x.h1 = o; o += RG * DX_W; x.o1 = o; o += RG * DX_W;
+  x.rh2 = o; o += RG * DX_W; x.h2 = o; o += RG * DX_W;
   x.total = o;
   return x;
 }
-// LDS bytes of a member (host mirror of the carve in the kernel)
+// LDS floats of a member (host mirror of the carve in the kernel)
 __host__ __device__ inline size_t dx_lds_floats(int RG, int T_in) {
-  const int Pr = DX_GROUP / RG, TP = (T_in + Pr - 1) / Pr, DC = DX_W / Pr;
+  const int Pr = DX_GROUP / RG, DC = DX_W / Pr, Tpad = (T_in + 3) & ~3;
+  const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
   size_t n = 0;
   n += (size_t)RG * DXS_LD;           // state
-  n += (size_t)DX_NW * RG * 16;       // red0
-  n += (size_t)DX_NW * RG * 16;       // red1
-  n += (size_t)TP * DX_W;             // keys slice
-  n += (size_t)T_in * DC;             // values slice
-  n += 4 * (size_t)((T_in + 3) & ~3); // sc, tmp, tmp2, alp
-  n += 3 * DX_W;                      // qv, vv, bias scratch
-  n += (size_t)DX_NW * 64;            // context partials [wave][DC] (DC <= 64)
-  n += 16 * 16;                       // own-column biases of the 14 epilogues
+  n += (size_t)TS * DS;               // keys: position block x score-channel block
+  n += (size_t)T_in * DC;             // values: all positions x context-channel block
+  n += 4 * (size_t)Tpad;              // sc, tmp, tmp2, alp
+  n += 3 * 64;                        // qv, vv, bq (own channels, DC <= 64)
+  n += (size_t)DX_NW * 64;            // context partials [wave][DC]
+  n += (size_t)DXB_N * DX_NW;         // own-column biases
   n += 64;                            // control words
   return n;
 }
+__host__ __device__ inline int dx_score_blocks(int RG) { const int Pr = DX_GROUP / RG; return Pr < 8 ? Pr : 8; }   // channel blocks per row
+__host__ __device__ inline int dx_q_regs(int RG) { return (DX_W / dx_score_blocks(RG)) / 2; }   // 4 per query column, DS/8 columns per wave
 
 struct DxArgs {
   const float* wpack;                                  // [32 members][DX_NREG][DX_NT]
+  const float* qpack;                                  // [32 members][dx_q_regs(RG)][DX_NT]   (layout depends on RG)
   const float* b_p1_0; const float* b_p1c; const float* b_p2;      // prenet biases: layer 1 raw (step 0), composite (steps >= 1), layer 2
   const float* b_ag; const float* b_ac;                // attention GRU: gates [2H] (r|u), candidate [H]
-  const float* b_cp;
-  const float* b_g1g; const float* b_g1c; const float* b_g2g; const float* b_g2c;
+  const float* b_g1f;                                  // folded GRU 1: [4H] = gates (r|u) | candidate-x | o0
+  const float* b_g1c; const float* b_g2g; const float* b_g2c;
   const float* b_f;                                    // [rM]
   const float* att_v; const float* att_b; const float* score_bias;
   const float* keys; const float* values;              // [B, T_in, 256] each
@@ -132,60 +117,149 @@ struct DxArgs {
   int B, T_in, n, rM, att_type, grp0, ngroups, force_wt, dbgw;
 };
 
-#define DX_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
-// sum over the KSL lanes of a column (the low bits of the lane index); every lane of the column ends with the total
-template <int KSL>
-__device__ __forceinline__ float dx_reduce(float v) {
-  v += DX_DPP(v, 0xB1);                 // quad_perm [1,0,3,2]
-  v += DX_DPP(v, 0x4E);                 // quad_perm [2,3,0,1]
-  if (KSL >= 8) v += DX_DPP(v, 0x141);  // row_half_mirror
-  if (KSL >= 16) v += DX_DPP(v, 0x140); // row_mirror
-  return v;
+#define DX_DPP0(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
+#define DX_DPPZ(v, ctrl, rmask, bmask) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), (rmask), (bmask), true))
+// sum over the wave; every lane of a row of 16 first gets its row's total, the row totals are chained into lane 63 and read back
+// as a wave-uniform value
+__device__ __forceinline__ float dx_allsum(float v) {
+  v += DX_DPP0(v, 0xB1);                 // quad_perm [1,0,3,2]
+  v += DX_DPP0(v, 0x4E);                 // quad_perm [2,3,0,1]
+  v += DX_DPP0(v, 0x141);                // row_half_mirror
+  v += DX_DPP0(v, 0x140);                // row_mirror
+  v += DX_DPPZ(v, 0x142, 0xA, 0xF);      // row_bcast:15 -> rows 1, 3
+  v += DX_DPPZ(v, 0x143, 0xC, 0xF);      // row_bcast:31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ float dx_wave_sum(float v) {
-  v = dx_reduce<16>(v);
-  const int a = __builtin_amdgcn_readlane(__float_as_int(v), 0), b = __builtin_amdgcn_readlane(__float_as_int(v), 16);
-  const int c = __builtin_amdgcn_readlane(__float_as_int(v), 32), d = __builtin_amdgcn_readlane(__float_as_int(v), 48);
-  return (__int_as_float(a) + __int_as_float(b)) + (__int_as_float(c) + __int_as_float(d));
+__device__ __forceinline__ float dx_allmax(float v) {
+  v = fmaxf(v, DX_DPP0(v, 0xB1)); v = fmaxf(v, DX_DPP0(v, 0x4E)); v = fmaxf(v, DX_DPP0(v, 0x141)); v = fmaxf(v, DX_DPP0(v, 0x140));
+  const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
+__device__ __forceinline__ float dx_quadsum(float v) { v += DX_DPP0(v, 0xB1); v += DX_DPP0(v, 0x4E); return v; }
+// inclusive prefix sum over the wave on full-rate DPP (row_shr 1,2,3 / 4 / 8, row_bcast 15 / 31)
+__device__ __forceinline__ float dx_scan(float v) {
+  float t = v + DX_DPPZ(v, 0x111, 0xF, 0xF);
+  t += DX_DPPZ(v, 0x112, 0xF, 0xF);
+  t += DX_DPPZ(v, 0x113, 0xF, 0xF);
+  t += DX_DPPZ(t, 0x114, 0xF, 0xE);
+  t += DX_DPPZ(t, 0x118, 0xF, 0xC);
+  t += DX_DPPZ(t, 0x142, 0xA, 0xF);
+  t += DX_DPPZ(t, 0x143, 0xC, 0xF);
+  return t;
+}
+__device__ __forceinline__ float dx_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
-// partial sums of unit U for RG rows: x0 holds the first K0 inputs of a row, x1 the rest (LDS, row stride DXS_LD)
-template <class U, int RG, int K0>
-__device__ __forceinline__ void dx_matvec(const float (&W)[DX_NREG], const float* x0, const float* x1, float* red, int wave, int lane) {
-  if (wave >= U::NWV) return;
-  const int ks = lane & (U::KSL - 1), c = lane / U::KSL;
-  float acc[RG];
+// one pass: acc[c][r] += sum_e W[REG0 + 4c + e] * x[r][4*lane + e]   (x: LDS, row stride DXS_LD)
+template <int REG0, int NCOLS, int RG>
+__device__ __forceinline__ void dx_pass(const float (&W)[DX_NREG], const float* x, int lane, float (&acc)[NCOLS][RG]) {
 #pragma unroll
-  for (int r = 0; r < RG; ++r) acc[r] = 0.f;
-  // the input reads of at most DX_XREGS/2 float2 are in flight at a time (left alone, the scheduler hoists every read of the
-  // unit above the first FMA: 128 registers at RG = 8)
-  constexpr int JG = (DX_XREGS / (2 * RG)) > 0 ? (DX_XREGS / (2 * RG)) : 1;
+  for (int r = 0; r < RG; ++r) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * DXS_LD + 4 * lane);
 #pragma unroll
-  for (int j = 0; j < U::NCH; ++j) {
-    const int kb = 2 * U::KSL * (wave + U::NWV * j);            // wave-uniform: the whole wave reads one segment
-    const float* xs = (kb < K0) ? x0 + kb : x1 + (kb - K0);
-#pragma unroll
-    for (int r = 0; r < RG; ++r) {
-      const float2 xv = *reinterpret_cast<const float2*>(xs + r * DXS_LD + 2 * ks);
-      acc[r] = fmaf(W[U::REG0 + 2 * j], xv.x, acc[r]);
-      acc[r] = fmaf(W[U::REG0 + 2 * j + 1], xv.y, acc[r]);
+    for (int c = 0; c < NCOLS; ++c) {
+      acc[c][r] = fmaf(W[REG0 + 4 * c + 0], xv.x, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 4 * c + 1], xv.y, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 4 * c + 2], xv.z, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 4 * c + 3], xv.w, acc[c][r]);
     }
-    if ((j + 1) % JG == 0 && j + 1 < U::NCH) __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int r = 0; r < RG; ++r) acc[r] = dx_reduce<U::KSL>(acc[r]);
-  if (ks == 0) {
-#pragma unroll
-    for (int r = 0; r < RG; ++r) red[(wave * RG + r) * U::NCW + c] = acc[r];
   }
 }
-// the epilogue thread's sum over the NWV wave partials of output (r, c)
-template <class U, int RG>
-__device__ __forceinline__ float dx_partials(const float* red, int r, int c) {
-  float s = 0.f;
+// the 128-wide pass (attention GRU x rows): 2 inputs per lane
+template <int REG0, int NCOLS, int RG>
+__device__ __forceinline__ void dx_pass2(const float (&W)[DX_NREG], const float* x, int lane, float (&acc)[NCOLS][RG]) {
 #pragma unroll
-  for (int w = 0; w < U::NWV; ++w) s += red[(w * RG + r) * U::NCW + c];
-  return s;
+  for (int r = 0; r < RG; ++r) {
+    const float2 xv = *reinterpret_cast<const float2*>(x + r * DXS_LD + 2 * lane);
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      acc[c][r] = fmaf(W[REG0 + 2 * c + 0], xv.x, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 2 * c + 1], xv.y, acc[c][r]);
+    }
+  }
+}
+template <int NCOLS, int RG>
+__device__ __forceinline__ void dx_zero(float (&acc)[NCOLS][RG]) {
+#pragma unroll
+  for (int c = 0; c < NCOLS; ++c)
+#pragma unroll
+    for (int r = 0; r < RG; ++r) acc[c][r] = 0.f;
+}
+// Wave reduction of NC columns x RG rows of per-lane partial sums.  A plain tree costs 6 cross-lane (DPP) adds per value and DPP
+// adds are the expensive instruction here (about four times a plain VALU op), so the first two levels are a butterfly that also
+// distributes the ROWS over the lanes of a quad: at each level a lane keeps half of its rows, sends the other half to its
+// partner and adds what the partner sends -- the number of live values halves.  After two levels lane l holds, per column, the
+// RG/4 rows  (l&1)*RG/2 + ((l>>1)&1)*RG/4 + q  summed over its quad; row_ror 4 / 8 finish the row of 16 lanes and two
+// permlane swaps the four rows of the wave, all lane-position preserving.  Every lane ends with the wave totals of its rows.
+template <int RG> struct DxRL { static constexpr int value = RG >= 4 ? RG / 4 : 1; };
+template <int RG>
+__device__ __forceinline__ int dx_row(int lane, int q) {
+  if (RG >= 4) return (lane & 1) * (RG / 2) + ((lane >> 1) & 1) * (RG / 4) + q;
+  if (RG == 2) return lane & 1;
+  return 0;
+}
+__device__ __forceinline__ float dx_xrow16(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float dx_xrow32(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int NC, int RG>
+__device__ __forceinline__ void dx_reduce(const float (&a)[NC][RG], float (&out)[NC][DxRL<RG>::value], int lane) {
+  constexpr int RL = DxRL<RG>::value;
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  float d[NC][RL];
+  if (RG >= 4) {
+    constexpr int H = RG / 2, Q = RG / 4;
+    float b[NC][H];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int p = 0; p < H; ++p) {
+        const float keep = b0 ? a[c][H + p] : a[c][p], send = b0 ? a[c][p] : a[c][H + p];
+        b[c][p] = keep + DX_DPP0(send, 0xB1);
+      }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const float keep = b1 ? b[c][Q + q] : b[c][q], send = b1 ? b[c][q] : b[c][Q + q];
+        d[c][q] = keep + DX_DPP0(send, 0x4E);
+      }
+  } else if (RG == 2) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float keep = b0 ? a[c][1] : a[c][0], send = b0 ? a[c][0] : a[c][1];
+      const float t = keep + DX_DPP0(send, 0xB1);
+      d[c][0] = t + DX_DPP0(t, 0x4E);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float t = a[c][0] + DX_DPP0(a[c][0], 0xB1);
+      d[c][0] = t + DX_DPP0(t, 0x4E);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) d[c][q] += DX_DPP0(d[c][q], 0x124);     // row_ror:4
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) d[c][q] += DX_DPP0(d[c][q], 0x128);     // row_ror:8
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) d[c][q] = dx_xrow16(d[c][q]);
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) out[c][q] = dx_xrow32(d[c][q]);
 }
 
 struct DxRt {     // run-time state of a thread
@@ -194,46 +268,120 @@ struct DxRt {     // run-time state of a thread
 __device__ __forceinline__ void dx_publish(dx_gu64* p, float v, unsigned tag, const DxRt& rt) {
   const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
   if (rt.wt) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
-  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // plain: stays in this XCD's L2
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // sc0: stays in this XCD's L2
 }
-// poll one granule until it carries `tag` (L1-bypassing loads); bounded
-__device__ __forceinline__ float dx_consume(const dx_gu64* p, unsigned tag, DxRt& rt) {
-  unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (!rt.dead) {
-    unsigned spins = 0;
-    while ((unsigned)(g >> 32) != tag) {
-      g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((++spins & 1023u) == 0) {
-        if (spins >= DX_SPIN_LIMIT || __hip_atomic_load(rt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          rt.dead = true;
-          break;
-        }
+// Poll N granules (p0 + u*stride) until every one carries `tag` (L1-bypassing loads).  All N are re-requested together on every
+// round, so a late producer costs one L2 round trip after its store lands, not one per granule.  Bounded.
+template <int N>
+__device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsigned tag, float (&v)[N], DxRt& rt) {
+  unsigned long long g[N];
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < N; ++u) g[u] = __hip_atomic_load(p0 + u * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int u = 0; u < N; ++u) ok = ok && ((unsigned)(g[u] >> 32) == tag);
+    if (ok || rt.dead) break;
+    if ((++spins & 1023u) == 0) {
+      if (spins >= DX_SPIN_LIMIT || __hip_atomic_load(rt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rt.dead = true;
       }
     }
   }
-  return __uint_as_float((unsigned)g);
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = __uint_as_float((unsigned)g[u]);
 }
 // all-gather of a published [RG][N] vector into the LDS state vector at column offset `off` (N a power of two);
-// RES: dst2[r][n] = value + res[r][n] as well (ResidualWrapper output, tacotron.py:172).  All of a thread's granules are
-// requested before the first is examined; only stale ones are polled again.
+// RES: dst2[r][n] = value + res[r][n] as well (ResidualWrapper output, tacotron.py:172)
 template <int RG, int N, bool RES>
 __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float* st, int off, int off_res, int off2, int tid, DxRt& rt) {
   constexpr int NI = (RG * N + DX_NT - 1) / DX_NT;
   const bool act = (RG * N >= DX_NT) || tid < RG * N;
-  unsigned long long g[NI];
   if (act) {
-#pragma unroll
-    for (int u = 0; u < NI; ++u) g[u] = __hip_atomic_load(X + u * DX_NT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float v[NI];
+    dx_poll<NI>(X + tid, DX_NT, tag, v, rt);
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
       const int i = u * DX_NT + tid;
-      float v = __uint_as_float((unsigned)g[u]);
-      if ((unsigned)(g[u] >> 32) != tag) v = dx_consume(X + i, tag, rt);
       const int r = i / N, n = i % N;
-      st[r * DXS_LD + off + n] = v;
-      if (RES) st[r * DXS_LD + off2 + n] = v + st[r * DXS_LD + off_res + n];
+      st[r * DXS_LD + off + n] = v[u];
+      if (RES) st[r * DXS_LD + off2 + n] = v[u] + st[r * DXS_LD + off_res + n];
     }
+  }
+}
+
+// The alignment normaliser of one row by ONE wave, lane = `cnt` (<= CMAX) consecutive positions starting at j0, values held in
+// registers: sc (scores in, alignments out), alp (previous alignments).
+//   bah_mon: monotonic_attention(mode='parallel') (A.10): p = sigmoid(e + bias); cp = exp(cumsum_excl(log(clip(1-p, tiny, 1))));
+//            alpha = p * cp * cumsum(prev / clip(cp, 1e-10, 1));   else: softmax over T_in (no memory_sequence_length mask, A.8)
+template <int CMAX>
+__device__ __forceinline__ void dx_normalise(float* sc, const float* alp, int j0, int cnt, int att_type, float sbias) {
+  float e[CMAX], pv[CMAX];
+#pragma unroll
+  for (int i = 0; i < CMAX; ++i) { e[i] = i < cnt ? sc[j0 + i] : 0.f; pv[i] = i < cnt ? alp[j0 + i] : 0.f; }
+  if (att_type == 2) {
+    float p[CMAX], ex[CMAX], run = 0.f;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+      p[i] = dx_sigmoid_fast(e[i] + sbias);
+      ex[i] = run;                                      // exclusive prefix of the logs inside the lane's block
+      if (i < cnt) run += 0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(1.f - p[i], 1.17549435e-38f), 1.f));
+    }
+    const float off = dx_scan(run) - run;
+    float cp[CMAX], in2[CMAX], run2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) {
+      cp[i] = __builtin_amdgcn_exp2f(1.4426950408889634f * (ex[i] + off));
+      if (i < cnt) run2 += pv[i] * __builtin_amdgcn_rcpf(fminf(fmaxf(cp[i], 1e-10f), 1.f));
+      in2[i] = run2;                                    // inclusive
+    }
+    const float off2 = dx_scan(run2) - run2;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) if (i < cnt) sc[j0 + i] = p[i] * cp[i] * (in2[i] + off2);
+  } else {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) if (i < cnt) mx = fmaxf(mx, e[i]);
+    mx = dx_allmax(mx);
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) { e[i] = __builtin_amdgcn_exp2f(1.4426950408889634f * (e[i] - mx)); if (i < cnt) sm += e[i]; }
+    sm = dx_allsum(sm);
+    const float inv = 1.0f / sm;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) if (i < cnt) sc[j0 + i] = e[i] * inv;
+  }
+}
+// the same through LDS scratch for long inputs (more than 8 positions per lane: T_in > 512)
+__device__ __forceinline__ void dx_normalise_lds(float* sc, float* tmp, float* tmp2, const float* alp, int j0, int j1, int att_type, float sbias) {
+  if (att_type == 2) {
+    float run = 0.f;
+    for (int j = j0; j < j1; ++j) {
+      const float p = dx_sigmoid_fast(sc[j] + sbias);
+      const float lg = 0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f));
+      sc[j] = p; tmp[j] = run; run += lg;
+    }
+    const float off = dx_scan(run) - run;
+    float run2 = 0.f;
+    for (int j = j0; j < j1; ++j) {
+      const float cp = __builtin_amdgcn_exp2f(1.4426950408889634f * (tmp[j] + off));
+      tmp[j] = cp;
+      run2 += alp[j] * __builtin_amdgcn_rcpf(fminf(fmaxf(cp, 1e-10f), 1.f));
+      tmp2[j] = run2;
+    }
+    const float off2 = dx_scan(run2) - run2;
+    for (int j = j0; j < j1; ++j) sc[j] = sc[j] * tmp[j] * (tmp2[j] + off2);
+  } else {
+    float mx = -INFINITY;
+    for (int j = j0; j < j1; ++j) mx = fmaxf(mx, sc[j]);
+    mx = dx_allmax(mx);
+    float sm = 0.f;
+    for (int j = j0; j < j1; ++j) { const float e = __builtin_amdgcn_exp2f(1.4426950408889634f * (sc[j] - mx)); sc[j] = e; sm += e; }
+    sm = dx_allsum(sm);
+    const float inv = 1.0f / sm;
+    for (int j = j0; j < j1; ++j) sc[j] = sc[j] * inv;
   }
 }
 
@@ -249,25 +397,33 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int Pr = DX_GROUP / RG;          // members per row in the attention phases
-  constexpr int DC = DX_W / Pr;              // context channels per member
-  const int T = a.T_in, TP = (T + Pr - 1) / Pr, Tpad = (T + 3) & ~3;
+  constexpr int DC = DX_W / Pr;              // attention channels per member (8, 16, 32, 64)
+  // score phase: the Pr members of a row form Pc channel blocks x Pp position blocks (the partial scores a member has to collect
+  // grow with Pc * T_in, its own work with T_in / Pp * 256 / Pc)
+  constexpr int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc;
+  constexpr int DS = DX_W / Pc;              // score channels per member (32; 64 at RG = 8)
+  constexpr int QC = DS / 8;                 // query columns per wave
+  constexpr int QR = 4 * QC;                 // query-layer registers per thread
+  constexpr int CH = DS / 4;                 // channels per lane in the score phase (a quad of lanes covers a position)
+  constexpr int NP = Pc / 4;                 // score partials per lane in the gather (a quad covers the Pc channel blocks)
+  const int T = a.T_in, Tpad = (T + 3) & ~3;
+  const int TP = (T + Pr - 1) / Pr;          // positions whose history this member writes
+  const int TS = (T + Pp - 1) / Pp;          // positions it scores
 
   // ---- LDS carve (dx_lds_floats mirrors this) ----
   float* st = dx_smem;
-  float* red0 = st + RG * DXS_LD;
-  float* red1 = red0 + DX_NW * RG * 16;
-  float* Kl = red1 + DX_NW * RG * 16;
-  float* Vl = Kl + (size_t)TP * DX_W;
-  float* sc = Vl + (size_t)T * DC;
+  float* Kc = st + RG * DXS_LD;              // keys   [TS][DS]: the member's position block x channel block
+  float* Vc = Kc + (size_t)TS * DS;          // values [T][DC]: all positions x its context channels
+  float* sc = Vc + (size_t)T * DC;
   float* tmp = sc + Tpad;
   float* tmp2 = tmp + Tpad;
   float* alp = tmp2 + Tpad;
-  float* qv = alp + Tpad;
-  float* vv = qv + DX_W;
-  float* bq = vv + DX_W;
-  float* cpart = bq + DX_W;
-  float* bl = cpart + DX_NW * 64;            // [16 epilogues][16]
-  int* ictl = reinterpret_cast<int*>(bl + 16 * 16);
+  float* qv = alp + Tpad;                    // query (+ attention_b) of the member's channels
+  float* vv = qv + 64;                       // attention_v of the member's channels
+  float* bq = vv + 64;
+  float* cpart = bq + 64;                    // [DX_NW][64]
+  float* bl = cpart + DX_NW * 64;            // [DXB_N][DX_NW]
+  int* ictl = reinterpret_cast<int*>(bl + DXB_N * DX_NW);
 
   // ---- census: which XCD am I on, is every XCD hosting exactly one group? ----
   dx_gu32* ctl = (dx_gu32*)a.ctl;
@@ -303,34 +459,42 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   if (ga >= a.ngroups || member >= DX_GROUP) return;
   const int row0 = ga * RG;
   if (row0 >= a.B) return;
-  const int arow = member / Pr, asl = member % Pr;       // attention role: local row, slice
+  const int arow = member / Pr, asl = member % Pr;       // attention role: local row, slot in the row
+  const int cb = asl % Pc, pb = asl / Pc;                // score role: channel block, position block
+  const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
   const int brow = row0 + arow;                          // its batch row (may be >= B: padding)
   const bool tracer = a.trace && ga == 0 && member == 0 && tid == 0;
 
-  // ---- weights: DX_NREG registers per thread, resident for the whole loop ----
+  // ---- weights, resident for the whole loop ----
   float W[DX_NREG];
   {
     const float* wp = a.wpack + ((size_t)member * DX_NREG) * DX_NT + tid;
 #pragma unroll
     for (int j = 0; j < DX_NREG; ++j) W[j] = wp[(size_t)j * DX_NT];
   }
+  float WQ[QR];     // query layer: columns cb*DS + wave*QC + i, inputs 4*lane..4*lane+3
+  {
+    const float* wp = a.qpack + ((size_t)member * QR) * DX_NT + tid;
+#pragma unroll
+    for (int j = 0; j < QR; ++j) WQ[j] = wp[(size_t)j * DX_NT];
+  }
   const DxX xl = dx_xlayout(RG, T);
   dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)ga * xl.total;
   const int NCF = (a.rM + DX_GROUP - 1) / DX_GROUP;      // frame-projection columns per member (<= 16)
 
-  // ---- stationary attention memory: keys slice (positions), values slice (channels) ----
-  const int p0 = asl * TP, pn = max(0, min(T - p0, TP));
-  for (int i = tid; i < TP * (DX_W / 4); i += DX_NT) {
-    const int p = i / (DX_W / 4), c4 = i % (DX_W / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p < pn && brow < a.B) v = *reinterpret_cast<const float4*>(a.keys + ((size_t)brow * T + p0 + p) * DX_W + 4 * c4);
-    *reinterpret_cast<float4*>(Kl + (size_t)p * DX_W + 4 * c4) = v;
+  // ---- stationary attention memory of the member's row: keys (its position block x score channels), values (all positions x
+  // context channels) ----
+  for (int i = tid; i < TS * (DS / 4); i += DX_NT) {
+    const int j = i / (DS / 4), d4 = i % (DS / 4);
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (brow < a.B && j < psn) k4 = *reinterpret_cast<const float4*>(a.keys + ((size_t)brow * T + ps0 + j) * DX_W + cb * DS + 4 * d4);
+    *reinterpret_cast<float4*>(Kc + (size_t)j * DS + 4 * d4) = k4;
   }
   for (int i = tid; i < T * (DC / 4); i += DX_NT) {
     const int j = i / (DC / 4), d4 = i % (DC / 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (brow < a.B) v = *reinterpret_cast<const float4*>(a.values + ((size_t)brow * T + j) * DX_W + asl * DC + 4 * d4);
-    *reinterpret_cast<float4*>(Vl + (size_t)j * DC + 4 * d4) = v;
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (brow < a.B) v4 = *reinterpret_cast<const float4*>(a.values + ((size_t)brow * T + j) * DX_W + asl * DC + 4 * d4);
+    *reinterpret_cast<float4*>(Vc + (size_t)j * DC + 4 * d4) = v4;
   }
   // ---- initial state (rnn_wrappers.py:186-216, tacotron.py:183-197): zeros or the deepvoice vectors; step-0 prenet layer 1 =
   // relu(b1) because the go frame and the initial context are zero (helpers.py:70-72) ----
@@ -346,22 +510,26 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     st[r * DXS_LD + DXS_T + nn] = fmaxf(a.b_p1_0[nn], 0.f);
   }
   for (int j = tid; j < Tpad; j += DX_NT) { alp[j] = (a.att_type == 2 && j == 0) ? 1.f : 0.f; sc[j] = 0.f; tmp[j] = 0.f; tmp2[j] = 0.f; }
-  if (tid < DX_W) { vv[tid] = a.att_v[tid]; bq[tid] = a.att_b ? a.att_b[tid] : 0.f; }
-  if (tid < 16 * 16) {     // own-column biases: bl[e][c]
-    const int e = tid >> 4, c = tid & 15;
+  if (tid < DS) { vv[tid] = a.att_v[cb * DS + tid]; bq[tid] = a.att_b ? a.att_b[cb * DS + tid] : 0.f; qv[tid] = 0.f; }
+  if (tid < DXB_N * DX_NW) {     // own-column biases: bl[slot][wave]
+    const int e = tid / DX_NW, w = tid % DX_NW, n8 = member * 8 + w;
     float v = 0.f;
-    const int n8 = member * 8 + (c & 7);
     switch (e) {
-      case 0: if (c < 8) v = a.b_p1c[n8]; break;
-      case 1: if (c < 4) v = a.b_p2[member * 4 + c]; break;
-      case 2: v = a.b_ag[(c < 8 ? 0 : DX_W) + n8]; break;
-      case 3: if (c < 8) v = a.b_ac[n8]; break;
-      case 4: if (c < 8) v = a.b_cp[n8]; break;
-      case 5: v = a.b_g1g[(c < 8 ? 0 : DX_W) + n8]; break;
-      case 6: if (c < 8) v = a.b_g1c[n8]; break;
-      case 7: v = a.b_g2g[(c < 8 ? 0 : DX_W) + n8]; break;
-      case 8: if (c < 8) v = a.b_g2c[n8]; break;
-      case 9: if (c < NCF && member * NCF + c < a.rM) v = a.b_f[member * NCF + c]; break;
+      case DXB_P1: v = a.b_p1c[n8]; break;
+      case DXB_P2: if (w < 4) v = a.b_p2[member * 4 + w]; break;
+      case DXB_AR: v = a.b_ag[n8]; break;
+      case DXB_AU: v = a.b_ag[DX_W + n8]; break;
+      case DXB_AC: v = a.b_ac[n8]; break;
+      case DXB_G1R: v = a.b_g1f[n8]; break;
+      case DXB_G1U: v = a.b_g1f[DX_W + n8]; break;
+      case DXB_G1X: v = a.b_g1f[2 * DX_W + n8]; break;
+      case DXB_O0: v = a.b_g1f[3 * DX_W + n8]; break;
+      case DXB_G1C: v = a.b_g1c[n8]; break;
+      case DXB_G2R: v = a.b_g2g[n8]; break;
+      case DXB_G2U: v = a.b_g2g[DX_W + n8]; break;
+      case DXB_G2C: v = a.b_g2c[n8]; break;
+      case DXB_F0: if (w < NCF && member * NCF + w < a.rM) v = a.b_f[member * NCF + w]; break;
+      case DXB_F1: if (w + 8 < NCF && member * NCF + w + 8 < a.rM) v = a.b_f[member * NCF + w + 8]; break;
       default: break;
     }
     bl[tid] = v;
@@ -369,111 +537,155 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
   __syncthreads();
 
-  // epilogue roles: thread o < RG*8 owns output (r = o>>3, c = o&7) of every 8-column stage
-  const int er = tid >> 3, ec = tid & 7;
-  const bool epi8 = tid < RG * 8;
-  const int en = member * 8 + ec;            // its column in a 256-wide vector
-  float g_u = 0.f, g_cx = 0.f, g_h = 0.f;    // GRU gate u, x-part of the candidate, previous state: live between the two stages of a cell
+  // epilogue role: the lanes of quad 0 own the outputs (rows dx_row(lane, q), column 8*member + wave) of every 256-wide stage
+  constexpr int RL = DxRL<RG>::value;
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+  const int en = member * 8 + wave;
+  int erow[RL];
+#pragma unroll
+  for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
+  float g_u[RL], g_cx[RL], g_h[RL], g_o0[RL];            // live between the two stages of a GRU cell
+  // (accumulators of the passes that run ahead of their stage live across exactly one gather)
 
+  const int tid_outer = tid, lane_outer = lane;
   for (int t = 0; t < a.n; ++t) {
     const unsigned tag = (unsigned)t + 1u;
+    // per-iteration opaque copies of the thread indices: the address arithmetic of the ~40 LDS / exchange accesses of a step is
+    // loop invariant, and hoisted out of the loop it occupies (and spills) dozens of registers next to the resident weights
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
     DX_STAMP(0);
-    // ================= prenet layer 2 (modules.py:18-25) =================
-    dx_matvec<DxU_P2, RG, 256>(W, st + DXS_T, st + DXS_T, red0, wave, lane);
-    __syncthreads();
-    if (tid < RG * 4) {
-      const int r = tid >> 2, c = tid & 3;
-      const float s = dx_partials<DxU_P2, RG>(red0, r, c) + bl[1 * 16 + c];
-      dx_publish(X + xl.p2 + r * DX_P2 + member * 4 + c, fmaxf(s, 0.f), tag, rt);
+    // ================= prenet layer 2 (modules.py:18-25); LDS T = prenet layer 1 =================
+    if (wave < 4) {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DXR_P2, 1, RG>(W, st + DXS_T, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q)
+          dx_publish(X + xl.p2 + erow[q] * DX_P2 + member * 4 + wave, fmaxf(s[0][q] + bl[DXB_P2 * DX_NW + wave], 0.f), tag, rt);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_HATT + en];
+    float aga[3][RG];          // attention GRU: r, u, candidate-x; the h rows run ahead of the prenet output
+    dx_zero<3, RG>(aga);
+    dx_pass<DXR_AGH, 2, RG>(W, st + DXS_HATT, lane, reinterpret_cast<float (&)[2][RG]>(aga));
     dx_gather<RG, DX_P2, false>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(1);
     // ================= attention GRUCell (tacotron.py:127-130; A.6): gates, then candidate =================
-    dx_matvec<DxU_AG, RG, 128>(W, st + DXS_P2, st + DXS_HATT, red0, wave, lane);
-    dx_matvec<DxU_AX, RG, 128>(W, st + DXS_P2, st + DXS_P2, red1, wave, lane);
-    if (epi8) g_h = st[er * DXS_LD + DXS_HATT + en];
-    __syncthreads();
-    if (epi8) {
-      const float rg = taco_sigmoid(dx_partials<DxU_AG, RG>(red0, er, ec) + bl[2 * 16 + ec]);
-      g_u = taco_sigmoid(dx_partials<DxU_AG, RG>(red0, er, 8 + ec) + bl[2 * 16 + 8 + ec]);
-      g_cx = dx_partials<DxU_AX, RG>(red1, er, ec);
-      dx_publish(X + xl.rha + er * DX_W + en, rg * g_h, tag, rt);
+    {
+      float s[3][RL];
+      dx_pass2<DXR_AGX, 3, RG>(W, st + DXS_P2, lane, aga);
+      dx_reduce<3, RG>(aga, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_AR * DX_NW + wave]);
+        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_AU * DX_NW + wave]);
+        g_cx[q] = s[2][q];
+        if (epl) dx_publish(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+      }
     }
     dx_gather<RG, DX_W, false>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(2);
-    dx_matvec<DxU_AC, RG, 256>(W, st + DXS_T, st + DXS_T, red0, wave, lane);
-    __syncthreads();
-    if (epi8) {
-      const float c = tanhf(g_cx + dx_partials<DxU_AC, RG>(red0, er, ec) + bl[3 * 16 + ec]);
-      dx_publish(X + xl.ha + er * DX_W + en, g_u * g_h + (1.f - g_u) * c, tag, rt);
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DXR_AC, 1, RG>(W, st + DXS_T, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_AC * DX_NW + wave]);
+        if (epl) dx_publish(X + xl.ha + erow[q] * DX_W + en, g_u[q] * g_h[q] + (1.f - g_u[q]) * c, tag, rt);
+      }
     }
+#pragma unroll
+    for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H1 + en];
     dx_gather<RG, DX_W, false>(X + xl.ha, tag, st, DXS_HATT, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(3);
-    // ================= attention (rnn_wrappers.py:304-341): query, scores, normaliser, context =================
-    dx_matvec<DxU_Q, RG, 256>(W, st + DXS_HATT, st + DXS_HATT, red0, wave, lane);
-    __syncthreads();
-    if (epi8) dx_publish(X + xl.q + er * DX_W + en, dx_partials<DxU_Q, RG>(red0, er, ec), tag, rt);
-    if (tid < DX_W) qv[tid] = dx_consume(X + xl.q + arow * DX_W + tid, tag, rt) + bq[tid];   // this member's row only
+    // ================= attention (rnn_wrappers.py:304-341) =================
+    {  // query for the member's own score channels of its row: columns cb*DS + wave*QC + i
+      const float4 xv = *reinterpret_cast<const float4*>(st + arow * DXS_LD + DXS_HATT + 4 * lane);
+      float qa[QC][1], qs[QC][1];
+#pragma unroll
+      for (int i = 0; i < QC; ++i) {
+        float q = WQ[4 * i] * xv.x;
+        q = fmaf(WQ[4 * i + 1], xv.y, q); q = fmaf(WQ[4 * i + 2], xv.z, q); q = fmaf(WQ[4 * i + 3], xv.w, q);
+        qa[i][0] = q;
+      }
+      dx_reduce<QC, 1>(qa, qs, lane);
+      float qme = qs[0][0];
+#pragma unroll
+      for (int i = 1; i < QC; ++i) qme = (lane >= i) ? qs[i][0] : qme;
+      if (lane < QC) qv[wave * QC + lane] = qme + bq[wave * QC + lane];
+    }
     __syncthreads();
     DX_STAMP(4);
-    {  // scores of the member's block of encoder positions: one wave per position, 4 channels per lane (A.9)
-      const float4 q4 = *reinterpret_cast<const float4*>(qv + 4 * lane);
-      const float4 v4 = *reinterpret_cast<const float4*>(vv + 4 * lane);
-      for (int p = wave; p < pn; p += DX_NW) {
-        const float4 k4 = *reinterpret_cast<const float4*>(Kl + (size_t)p * DX_W + 4 * lane);
-        float e = v4.x * taco_tanh_fast(k4.x + q4.x) + v4.y * taco_tanh_fast(k4.y + q4.y) + v4.z * taco_tanh_fast(k4.z + q4.z) +
-                  v4.w * taco_tanh_fast(k4.w + q4.w);
-        e = dx_wave_sum(e);
-        if (lane == 0) dx_publish(X + xl.sc + arow * T + p0 + p, e, tag, rt);
+    {  // partial scores over the member's channel block (A.9): a quad of lanes per encoder position, CH channels per lane
+      const int jl = lane >> 2, cp = lane & 3;
+      float qreg[CH], vreg[CH];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) { qreg[c] = qv[cp * CH + c]; vreg[c] = vv[cp * CH + c]; }
+      for (int j0 = 0; j0 < psn; j0 += 16 * DX_NW) {
+        const int j = j0 + wave * 16 + jl;
+        const int jc = j < psn ? j : psn - 1;
+        const float* kp = Kc + (size_t)jc * DS + cp * CH;
+        float e = 0.f;
+#pragma unroll
+        for (int c = 0; c < CH; c += 4) {
+          const float4 k4 = *reinterpret_cast<const float4*>(kp + c);
+          e += vreg[c] * taco_tanh_fast(k4.x + qreg[c]) + vreg[c + 1] * taco_tanh_fast(k4.y + qreg[c + 1]) +
+               vreg[c + 2] * taco_tanh_fast(k4.z + qreg[c + 2]) + vreg[c + 3] * taco_tanh_fast(k4.w + qreg[c + 3]);
+        }
+        e = dx_quadsum(e);
+        if (cp == 0 && j < psn) dx_publish(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
       }
     }
-    for (int j = tid; j < T; j += DX_NT) sc[j] = dx_consume(X + xl.sc + arow * T + j, tag, rt);
+    // ahead of its turn: GRU 1 (concat projection folded in): h1 rows of the gates, then the h_att rows of r, u, candidate-x, o0
+    float g1a[4][RG];
+    dx_zero<4, RG>(g1a);
+    dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
+    dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+    {  // gather the row's partial scores and sum them over the Pc channel blocks (fixed order)
+      const int jl = lane >> 2, part = lane & 3;
+      for (int j0 = 0; j0 < T; j0 += 16 * DX_NW) {
+        const int j = j0 + wave * 16 + jl;
+        float s = 0.f;
+        if (j < T) {
+          float v[NP];
+          dx_poll<NP>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
+#pragma unroll
+          for (int u = 0; u < NP; ++u) s += v[u];
+        }
+        s = dx_quadsum(s);
+        if (part == 0 && j < T) sc[j] = s;
+      }
+    }
     __syncthreads();
     DX_STAMP(5);
-    if (wave == 0) {   // normaliser over the whole row, redundantly on each of the row's members (same code path as att_core)
+    if (wave == 0) {   // normaliser over the whole row, redundantly on each of the row's members (lane = C consecutive positions)
       const int C = (T + 63) >> 6;
-      const int j0 = lane * C, j1 = min(j0 + C, T);
-      if (a.att_type == 2) {
-        float run = 0.f;
-        for (int j = j0; j < j1; ++j) {
-          const float p = taco_sigmoid(sc[j] + sbias);
-          const float lg = logf(fminf(fmaxf(1.f - p, 1.17549435e-38f), 1.f));
-          sc[j] = p; tmp[j] = run; run += lg;
-        }
-        const float off = wave_scan(run, lane) - run;
-        float run2 = 0.f;
-        for (int j = j0; j < j1; ++j) {
-          const float cp = expf(tmp[j] + off);
-          tmp[j] = cp;
-          run2 += alp[j] / fminf(fmaxf(cp, 1e-10f), 1.f);
-          tmp2[j] = run2;
-        }
-        const float off2 = wave_scan(run2, lane) - run2;
-        for (int j = j0; j < j1; ++j) sc[j] = sc[j] * tmp[j] * (tmp2[j] + off2);
-      } else {
-        float mx = -INFINITY;
-        for (int j = j0; j < j1; ++j) mx = fmaxf(mx, sc[j]);
-        mx = wave_max(mx);
-        float sm = 0.f;
-        for (int j = j0; j < j1; ++j) { const float e = expf(sc[j] - mx); sc[j] = e; sm += e; }
-        sm = wave_sum(sm);
-        for (int j = j0; j < j1; ++j) sc[j] = sc[j] / sm;
-      }
+      const int j0 = lane * C;
+      if (C <= 2) dx_normalise<2>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
+      else if (C <= 8) dx_normalise<8>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
+      else dx_normalise_lds(sc, tmp, tmp2, alp, j0, min(j0 + C, T), a.att_type, sbias);
     }
     __syncthreads();
-    {  // alignment state + history (tacotron.py:238-239 layout) for the member's own positions; context slice
+    {  // alignment state + history (tacotron.py:238-239 layout) for the member's block of positions; context channel block
       for (int j = tid; j < T; j += DX_NT) alp[j] = sc[j];
-      if (tid < pn && brow < a.B) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = sc[p0 + tid];
+      const int p0 = asl * TP;
+      if (tid < TP && p0 + tid < T && brow < a.B) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = sc[p0 + tid];
       constexpr int JL = 64 / DC;                    // positions handled side by side inside a wave
       const int d = lane % DC, jsub = lane / DC;
       float part = 0.f;
-      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(sc[j], Vl[(size_t)j * DC + d], part);
-      if (DC <= 32) part += __shfl_xor(part, 32, 64);
-      if (DC <= 16) part += __shfl_xor(part, 16, 64);
-      if (DC <= 8) part += __shfl_xor(part, 8, 64);
+      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(sc[j], Vc[(size_t)j * DC + d], part);
+      if (DC <= 32) part = dx_xrow32(part);
+      if (DC <= 16) part = dx_xrow16(part);
+      if (DC <= 8) part += DX_DPP0(part, 0x128);
       if (lane < DC) cpart[wave * 64 + lane] = part;
     }
     __syncthreads();
@@ -486,72 +698,109 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     dx_gather<RG, DX_W, false>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(6);
-    // ================= concat projection (rnn_wrappers.py:405-415; tacotron.py:166-170) =================
-    dx_matvec<DxU_CP, RG, 512>(W, st + DXS_HATT, st + DXS_HATT, red0, wave, lane);
-    __syncthreads();
-    if (epi8) dx_publish(X + xl.o0 + er * DX_W + en, dx_partials<DxU_CP, RG>(red0, er, ec) + bl[4 * 16 + ec], tag, rt);
-    dx_gather<RG, DX_W, false>(X + xl.o0, tag, st, DXS_O0, 0, 0, tid, rt);
-    __syncthreads();
-    DX_STAMP(7);
-    // ================= residual GRU 1 (tacotron.py:171-172) =================
-    dx_matvec<DxU_G1G, RG, 256>(W, st + DXS_O0, st + DXS_H1, red0, wave, lane);
-    dx_matvec<DxU_G1X, RG, 256>(W, st + DXS_O0, st + DXS_O0, red1, wave, lane);
-    if (epi8) g_h = st[er * DXS_LD + DXS_H1 + en];
-    __syncthreads();
-    if (epi8) {
-      const float rg = taco_sigmoid(dx_partials<DxU_G1G, RG>(red0, er, ec) + bl[5 * 16 + ec]);
-      g_u = taco_sigmoid(dx_partials<DxU_G1G, RG>(red0, er, 8 + ec) + bl[5 * 16 + 8 + ec]);
-      g_cx = dx_partials<DxU_G1X, RG>(red1, er, ec);
-      dx_publish(X + xl.rh1 + er * DX_W + en, rg * g_h, tag, rt);
+    // ================= concat projection folded into residual GRU 1 (rnn_wrappers.py:405-415; tacotron.py:166-172) =================
+    {
+      float s[4][RL];
+      dx_pass<DXR_G1B, 4, RG>(W, st + DXS_CTX, lane, g1a);
+      dx_reduce<4, RG>(g1a, s, lane);
+      DX_STAMP(12);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G1R * DX_NW + wave]);
+        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G1U * DX_NW + wave]);
+        g_cx[q] = s[2][q] + bl[DXB_G1X * DX_NW + wave];
+        g_o0[q] = s[3][q] + bl[DXB_O0 * DX_NW + wave];
+        if (epl) dx_publish(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+      }
+      DX_STAMP(13);
     }
     dx_gather<RG, DX_W, false>(X + xl.rh1, tag, st, DXS_T, 0, 0, tid, rt);
+    DX_STAMP(14);
+    __syncthreads();
+    DX_STAMP(7);
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DXR_G1C, 1, RG>(W, st + DXS_T, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G1C * DX_NW + wave]);
+        const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
+        if (epl) {
+          dx_publish(X + xl.h1 + erow[q] * DX_W + en, hn, tag, rt);
+          dx_publish(X + xl.o1 + erow[q] * DX_W + en, hn + g_o0[q], tag, rt);       // ResidualWrapper: cell output + cell input
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H2 + en];
+    float g2a[3][RG];          // GRU 2: r, u, candidate-x; the h2 rows run ahead of GRU 1's output
+    dx_zero<3, RG>(g2a);
+    dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
+    dx_gather<RG, DX_W, false>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(8);
-    dx_matvec<DxU_G1C, RG, 256>(W, st + DXS_T, st + DXS_T, red0, wave, lane);
-    __syncthreads();
-    if (epi8) {
-      const float c = tanhf(g_cx + dx_partials<DxU_G1C, RG>(red0, er, ec) + bl[6 * 16 + ec]);
-      dx_publish(X + xl.h1 + er * DX_W + en, g_u * g_h + (1.f - g_u) * c, tag, rt);
-    }
-    dx_gather<RG, DX_W, true>(X + xl.h1, tag, st, DXS_H1, DXS_O0, DXS_OUT1, tid, rt);
-    __syncthreads();
-    DX_STAMP(9);
     // ================= residual GRU 2 =================
-    dx_matvec<DxU_G2G, RG, 256>(W, st + DXS_OUT1, st + DXS_H2, red0, wave, lane);
-    dx_matvec<DxU_G2X, RG, 256>(W, st + DXS_OUT1, st + DXS_OUT1, red1, wave, lane);
-    if (epi8) g_h = st[er * DXS_LD + DXS_H2 + en];
-    __syncthreads();
-    if (epi8) {
-      const float rg = taco_sigmoid(dx_partials<DxU_G2G, RG>(red0, er, ec) + bl[7 * 16 + ec]);
-      g_u = taco_sigmoid(dx_partials<DxU_G2G, RG>(red0, er, 8 + ec) + bl[7 * 16 + 8 + ec]);
-      g_cx = dx_partials<DxU_G2X, RG>(red1, er, ec);
-      dx_publish(X + xl.rh2 + er * DX_W + en, rg * g_h, tag, rt);
+    {
+      float s[3][RL];
+      dx_pass<DXR_G2X, 3, RG>(W, st + DXS_OUT1, lane, g2a);
+      dx_reduce<3, RG>(g2a, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G2R * DX_NW + wave]);
+        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G2U * DX_NW + wave]);
+        g_cx[q] = s[2][q];
+        if (epl) dx_publish(X + xl.rh2 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+      }
     }
     dx_gather<RG, DX_W, false>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
-    DX_STAMP(10);
-    dx_matvec<DxU_G2C, RG, 256>(W, st + DXS_T, st + DXS_T, red0, wave, lane);
-    __syncthreads();
-    if (epi8) {
-      const float c = tanhf(g_cx + dx_partials<DxU_G2C, RG>(red0, er, ec) + bl[8 * 16 + ec]);
-      dx_publish(X + xl.h2 + er * DX_W + en, g_u * g_h + (1.f - g_u) * c, tag, rt);
+    DX_STAMP(9);
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DXR_G2C, 1, RG>(W, st + DXS_T, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G2C * DX_NW + wave]);
+        if (epl) dx_publish(X + xl.h2 + erow[q] * DX_W + en, g_u[q] * g_h[q] + (1.f - g_u[q]) * c, tag, rt);
+      }
     }
+    // ahead of its turn: next step's prenet layer 1, context rows
+    float p1a[1][RG];
+    dx_zero<1, RG>(p1a);
+    dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, p1a);
     dx_gather<RG, DX_W, true>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
     __syncthreads();
-    DX_STAMP(11);
+    DX_STAMP(10);
     // ================= prenet layer 1 of step t+1 (composite: frame projection folded in, helpers.py:31) and the frame
     // projection of step t (tacotron.py:178-179), straight into the mel buffer =================
-    if (t + 1 < a.n) dx_matvec<DxU_P1, RG, 256>(W, st + DXS_OUT2, st + DXS_CTX, red0, wave, lane);
-    dx_matvec<DxU_F, RG, 256>(W, st + DXS_OUT2, st + DXS_OUT2, red1, wave, lane);
-    __syncthreads();
-    if (t + 1 < a.n && epi8)
-      dx_publish(X + xl.p1 + er * DX_W + en, fmaxf(dx_partials<DxU_P1, RG>(red0, er, ec) + bl[0 * 16 + ec], 0.f), tag, rt);
-    if (tid < RG * 16) {
-      const int r = tid >> 4, c = tid & 15, nn = member * NCF + c, b = row0 + r;
-      if (c < NCF && nn < a.rM && b < a.B) {
-        const float y = dx_partials<DxU_F, RG>(red1, r, c) + bl[9 * 16 + c];
-        a.mel[(size_t)b * a.n * a.rM + (size_t)t * a.rM + nn] = y;
-        if (y != 0.f) a.nz[(size_t)t * a.B + b] = 1;                    // stop rule helpers.py:29
+    {
+      float fa[3][RG], s[3][RL];
+      dx_zero<3, RG>(fa);
+#pragma unroll
+      for (int r = 0; r < RG; ++r) fa[2][r] = p1a[0][r];
+      dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[2][RG]>(fa));
+      dx_pass<DXR_P1O, 1, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
+      dx_reduce<3, RG>(fa, s, lane);
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {
+          if (t + 1 < a.n) dx_publish(X + xl.p1 + erow[q] * DX_W + en, fmaxf(s[2][q] + bl[DXB_P1 * DX_NW + wave], 0.f), tag, rt);
+          const int b = row0 + erow[q];
+          if (b < a.B) {
+            const float y0 = s[0][q] + bl[DXB_F0 * DX_NW + wave], y1 = s[1][q] + bl[DXB_F1 * DX_NW + wave];
+            const int n0 = member * NCF + wave, n1 = n0 + 8;
+            float* mrow = a.mel + (size_t)b * a.n * a.rM + (size_t)t * a.rM;
+            bool nzf = false;
+            if (wave < NCF && n0 < a.rM) { mrow[n0] = y0; nzf = nzf || (y0 != 0.f); }
+            if (wave + 8 < NCF && n1 < a.rM) { mrow[n1] = y1; nzf = nzf || (y1 != 0.f); }
+            if (nzf) a.nz[(size_t)t * a.B + b] = 1;                            // stop rule helpers.py:29
+          }
+        }
       }
     }
     if (a.dbg && member == 0) {   // per-step state dump for the stage-level parity test: [h_att | ctx | h1 | h2]
@@ -563,6 +812,6 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     }
     if (t + 1 < a.n) dx_gather<RG, DX_W, false>(X + xl.p1, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
-    DX_STAMP(12);
+    DX_STAMP(11);
   }
 }

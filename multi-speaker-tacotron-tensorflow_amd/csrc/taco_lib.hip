@@ -121,8 +121,8 @@ struct taco_model {
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
-  size_t dx_pack = 0, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_cp = 0, dx_b_g1g = 0, dx_b_g1c = 0,
-         dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
+  size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
+         dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
   int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
   int dx_rows = 0;             // debug: force the rows per group (1,2,4,8); 0 = smallest that covers the batch
   long long* d_trace = nullptr;   // debug: phase stamps of group 0 / member 0 (taco_debug_decoder_trace)
@@ -333,29 +333,27 @@ static GruDec make_grudec(taco_model* m, const std::string& name, int I, int H) 
 
 static bool is_simple(const taco_model* m);
 
-// ---- persistent XCD-local decoder: per-thread weight pack (mirror of the unit mapping in taco_decoder_xcd.h) ----
+// ---- persistent XCD-local decoder: per-thread weight packs (mirror of the pass mapping in taco_decoder_xcd.h) ----
 static bool dx_widths_ok(const taco_model* m) {
   const taco_hparams& hp = m->hp;
   return hp.attention_state_size == DX_W && hp.dec_rnn_size == DX_W && hp.attention_size == DX_W && 2 * hp.enc_rnn_size == DX_W &&
          hp.dec_prenet_n == 2 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2 && hp.dec_layer_num == 2 &&
          hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP && !is_simple(m);
 }
-// W: row-major [K][ldw]; col(c) = column of the matrix held by lane-column c of this member, or -1
-template <class U, class ColFn>
-static void dx_fill_unit(std::vector<float>& pack, int member, const float* W, int ldw, ColFn col) {
+// one weight column of a pass: registers reg0 .. reg0+kw-1 of every thread = W[row0 + kw*lane + e][col(wave)]  (col < 0: none)
+template <class ColFn>
+static void dx_fill_col(std::vector<float>& pack, int nreg, int member, int reg0, int kw, const float* W, int ldw, int row0, ColFn col) {
   for (int tid = 0; tid < DX_NT; ++tid) {
-    const int wave = tid >> 6, lane = tid & 63, ks = lane & (U::KSL - 1), c = lane / U::KSL;
-    if (wave >= U::NWV) continue;
-    const int n = col(c);
+    const int wave = tid >> 6, lane = tid & 63, n = col(wave);
     if (n < 0) continue;
-    for (int j = 0; j < U::NCH; ++j)
-      for (int e = 0; e < 2; ++e) {
-        const int k = 2 * U::KSL * (wave + U::NWV * j) + 2 * ks + e;
-        pack[((size_t)member * DX_NREG + U::REG0 + 2 * j + e) * DX_NT + tid] = W[(size_t)k * ldw + n];
-      }
+    for (int e = 0; e < kw; ++e)
+      pack[((size_t)member * nreg + reg0 + e) * DX_NT + tid] = W[(size_t)(row0 + kw * lane + e) * ldw + n];
   }
 }
-static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std::vector<float>& bc) {
+// Wc/bc: composite prenet layer 1 of the next step ([o | ctx] rows); Wf/bf: GRU 1 with the concat projection folded in
+// ([h_att | ctx | h1] rows x [r | u | candidate-x | o0] columns), both formed in double by taco_model_finalize
+static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std::vector<float>& bc, const std::vector<float>& Wf,
+                         const std::vector<float>& bf) {
   if (!dx_widths_ok(m)) return 0;
   const taco_hparams& hp = m->hp;
   const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, NCF = cdiv(rM, DX_GROUP);
@@ -363,39 +361,55 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   const auto& W2 = T_(m, "decoder/prenet/dense_2/kernel").data;
   const auto& agk = T_(m, "decoder/attention_gru/gates/kernel").data; const auto& ack = T_(m, "decoder/attention_gru/candidate/kernel").data;
   const auto& wq = T_(m, "attention/query_layer/kernel").data;
-  const auto& cpk = T_(m, "decoder/concat_projection/kernel").data;
-  const auto& g1k = T_(m, "decoder/gru_1/gates/kernel").data; const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
+  const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
   const auto& g2k = T_(m, "decoder/gru_2/gates/kernel").data; const auto& c2k = T_(m, "decoder/gru_2/candidate/kernel").data;
   const auto& fk = T_(m, "decoder/frame_projection/kernel").data;
   for (int mem = 0; mem < DX_GROUP; ++mem) {
-    auto col8 = [&](int c) { return c < 8 ? mem * 8 + c : -1; };
-    auto colg = [&](int c) { return c < 8 ? mem * 8 + c : H + mem * 8 + (c - 8); };   // r columns, then u columns (A.6: r | u)
-    auto col4 = [&](int c) { return c < 4 ? mem * 4 + c : -1; };
-    auto colf = [&](int c) { const int n = mem * NCF + c; return (c < NCF && n < rM) ? n : -1; };
-    dx_fill_unit<DxU_P1>(pack, mem, Wc.data(), DX_W, col8);
-    dx_fill_unit<DxU_P2>(pack, mem, W2.data(), DX_P2, col4);
-    dx_fill_unit<DxU_AG>(pack, mem, agk.data(), 2 * H, colg);                         // rows [p2 (128) ; h (256)]
-    dx_fill_unit<DxU_AX>(pack, mem, ack.data(), H, col8);                             // candidate rows of x
-    dx_fill_unit<DxU_AC>(pack, mem, ack.data() + (size_t)DX_P2 * H, H, col8);         // candidate rows of h
-    dx_fill_unit<DxU_Q>(pack, mem, wq.data(), H, col8);
-    dx_fill_unit<DxU_CP>(pack, mem, cpk.data(), H, col8);
-    dx_fill_unit<DxU_G1G>(pack, mem, g1k.data(), 2 * H, colg);
-    dx_fill_unit<DxU_G1X>(pack, mem, c1k.data(), H, col8);
-    dx_fill_unit<DxU_G1C>(pack, mem, c1k.data() + (size_t)H * H, H, col8);
-    dx_fill_unit<DxU_G2G>(pack, mem, g2k.data(), 2 * H, colg);
-    dx_fill_unit<DxU_G2X>(pack, mem, c2k.data(), H, col8);
-    dx_fill_unit<DxU_G2C>(pack, mem, c2k.data() + (size_t)H * H, H, col8);
-    dx_fill_unit<DxU_F>(pack, mem, fk.data(), rM, colf);
+    auto c8 = [&](int w) { return mem * 8 + w; };
+    auto cu = [&](int w) { return H + mem * 8 + w; };                       // update-gate column (A.6: gates kernel = r | u)
+    auto c4 = [&](int w) { return w < 4 ? mem * 4 + w : -1; };
+    auto f0 = [&](int w) { const int n = mem * NCF + w; return (w < NCF && n < rM) ? n : -1; };
+    auto f1 = [&](int w) { const int n = mem * NCF + w + 8; return (w + 8 < NCF && n < rM) ? n : -1; };
+    auto put = [&](int reg0, int kw, const float* W, int ldw, int row0, auto col) { dx_fill_col(pack, DX_NREG, mem, reg0, kw, W, ldw, row0, col); };
+    put(DXR_P2, 4, W2.data(), DX_P2, 0, c4);
+    put(DXR_AGH, 4, agk.data(), 2 * H, DX_P2, c8); put(DXR_AGH + 4, 4, agk.data(), 2 * H, DX_P2, cu);            // h rows
+    put(DXR_AGX, 2, agk.data(), 2 * H, 0, c8); put(DXR_AGX + 2, 2, agk.data(), 2 * H, 0, cu); put(DXR_AGX + 4, 2, ack.data(), H, 0, c8);
+    put(DXR_AC, 4, ack.data(), H, DX_P2, c8);
+    auto fx = [&](int w) { return 2 * H + mem * 8 + w; };
+    auto fo = [&](int w) { return 3 * H + mem * 8 + w; };
+    put(DXR_G1H, 4, Wf.data(), 4 * H, 2 * H, c8); put(DXR_G1H + 4, 4, Wf.data(), 4 * H, 2 * H, cu);                // h1 rows
+    put(DXR_G1A, 4, Wf.data(), 4 * H, 0, c8); put(DXR_G1A + 4, 4, Wf.data(), 4 * H, 0, cu);                        // h_att rows
+    put(DXR_G1A + 8, 4, Wf.data(), 4 * H, 0, fx); put(DXR_G1A + 12, 4, Wf.data(), 4 * H, 0, fo);
+    put(DXR_G1B, 4, Wf.data(), 4 * H, H, c8); put(DXR_G1B + 4, 4, Wf.data(), 4 * H, H, cu);                        // context rows
+    put(DXR_G1B + 8, 4, Wf.data(), 4 * H, H, fx); put(DXR_G1B + 12, 4, Wf.data(), 4 * H, H, fo);
+    put(DXR_G1C, 4, c1k.data(), H, H, c8);
+    put(DXR_G2H, 4, g2k.data(), 2 * H, H, c8); put(DXR_G2H + 4, 4, g2k.data(), 2 * H, H, cu);
+    put(DXR_G2X, 4, g2k.data(), 2 * H, 0, c8); put(DXR_G2X + 4, 4, g2k.data(), 2 * H, 0, cu); put(DXR_G2X + 8, 4, c2k.data(), H, 0, c8);
+    put(DXR_G2C, 4, c2k.data(), H, H, c8);
+    put(DXR_P1C, 4, Wc.data(), DX_W, H, c8);                                                                        // context rows of [o | ctx]
+    put(DXR_P1O, 4, Wc.data(), DX_W, 0, c8);
+    put(DXR_F, 4, fk.data(), rM, 0, f0); put(DXR_F + 4, 4, fk.data(), rM, 0, f1);
   }
   m->dx_pack = arena_put(m, pack.data(), pack.size());
+  // query layer: slot s of a row (s = member % Pr) scores channel block s % Pc and holds columns (s % Pc)*DS + w*QC + i of it; one pack
+  // per rows-per-group
+  for (int q = 0; q < 4; ++q) {
+    const int RG = 1 << q, Pr = DX_GROUP / RG, Pc = dx_score_blocks(RG), DS = DX_W / Pc, QC = DS / 8, QR = dx_q_regs(RG);
+    std::vector<float> qp((size_t)DX_GROUP * QR * DX_NT, 0.f);
+    for (int mem = 0; mem < DX_GROUP; ++mem)
+      for (int i = 0; i < QC; ++i) {
+        const int cb = (mem % Pr) % Pc;
+        dx_fill_col(qp, QR, mem, 4 * i, 4, wq.data(), H, 0, [&](int w) { return cb * DS + w * QC + i; });
+      }
+    m->dx_qpack[q] = arena_put(m, qp.data(), qp.size());
+  }
   auto putv = [&](const std::vector<float>& v) { return arena_put(m, v.data(), v.size()); };
   m->dx_b_p1_0 = putv(T_(m, "decoder/prenet/dense_1/bias").data);
   m->dx_b_p1c = putv(bc);
   m->dx_b_p2 = putv(T_(m, "decoder/prenet/dense_2/bias").data);
   m->dx_b_ag = putv(T_(m, "decoder/attention_gru/gates/bias").data);
   m->dx_b_ac = putv(T_(m, "decoder/attention_gru/candidate/bias").data);
-  m->dx_b_cp = putv(T_(m, "decoder/concat_projection/bias").data);
-  m->dx_b_g1g = putv(T_(m, "decoder/gru_1/gates/bias").data);
+  m->dx_b_g1f = putv(bf);
   m->dx_b_g1c = putv(T_(m, "decoder/gru_1/candidate/bias").data);
   m->dx_b_g2g = putv(T_(m, "decoder/gru_2/gates/bias").data);
   m->dx_b_g2c = putv(T_(m, "decoder/gru_2/candidate/bias").data);
@@ -993,8 +1007,9 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   const int RG = dx_rows_per_group(m, B);
   DxArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, m->dx_pack);
+  a.qpack = AP(m, m->dx_qpack[RG == 1 ? 0 : RG == 2 ? 1 : RG == 4 ? 2 : 3]);
   a.b_p1_0 = AP(m, m->dx_b_p1_0); a.b_p1c = AP(m, m->dx_b_p1c); a.b_p2 = AP(m, m->dx_b_p2); a.b_ag = AP(m, m->dx_b_ag); a.b_ac = AP(m, m->dx_b_ac);
-  a.b_cp = AP(m, m->dx_b_cp); a.b_g1g = AP(m, m->dx_b_g1g); a.b_g1c = AP(m, m->dx_b_g1c); a.b_g2g = AP(m, m->dx_b_g2g); a.b_g2c = AP(m, m->dx_b_g2c);
+  a.b_g1f = AP(m, m->dx_b_g1f); a.b_g1c = AP(m, m->dx_b_g1c); a.b_g2g = AP(m, m->dx_b_g2g); a.b_g2c = AP(m, m->dx_b_g2c);
   a.b_f = AP(m, m->dx_b_f);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
   a.keys = w.keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
@@ -1351,13 +1366,15 @@ int taco_model_finalize(taco_model* m) {
   const int rM = hp.num_mels * hp.reduction_factor;
   m->frame_proj = pack_w16(m, T_(m, "decoder/frame_projection/kernel").data.data(), rM, 0, Hd, 0, rM, T_(m, "decoder/frame_projection/bias").data.data());
   m->skinny["decoder/frame_projection"] = m->frame_proj;
+  std::vector<float> dx_Wc, dx_bc;   // kept for the persistent decoder's pack (dx_build_pack)
   {  // prenet layer 1 of the NEXT step, fed with this step's outputs (helpers.py:31 feeds back the last of the r frames):
      //   relu([frame, ctx] . W1 + b1), frame = o . Wf[:, rM-M:] + bf[rM-M:]   =>   relu([o, ctx] . [Wf_last . W1a ; W1b] + (b1 + bf_last . W1a))
      // computed in the same launch as the frame projection: one dependent launch less per decoder step.
     const int Mm = hp.num_mels, P0 = hp.dec_prenet[0];
     const auto& Wf = T_(m, "decoder/frame_projection/kernel").data; const auto& bf = T_(m, "decoder/frame_projection/bias").data;
     const auto& W1 = T_(m, "decoder/prenet/dense_1/kernel").data; const auto& b1 = T_(m, "decoder/prenet/dense_1/bias").data;
-    std::vector<float> Wc((size_t)(Hd + D) * P0), bc(P0);
+    std::vector<float>& Wc = dx_Wc; std::vector<float>& bc = dx_bc;
+    Wc.assign((size_t)(Hd + D) * P0, 0.f); bc.assign(P0, 0.f);
     for (int k = 0; k < Hd; ++k)
       for (int q = 0; q < P0; ++q) {
         double acc = 0;
@@ -1372,7 +1389,6 @@ int taco_model_finalize(taco_model* m) {
       bc[q] = (float)acc;
     }
     m->prenet1_next = pack_w16(m, Wc.data(), P0, 0, Hd + D, 0, P0, bc.data());
-    if (!m->tp) TRY(dx_build_pack(m, Wc, bc));
   }
   if (!m->tp && hp.dec_layer_num > 0) {
     // Decoder GRU 1 with the concat projection folded in.  o0 = z . Wc + bc is linear in z = [h_att | ctx (| spk)], so
@@ -1407,6 +1423,7 @@ int taco_model_finalize(taco_model* m) {
     m->gru1_fold.gx = pack_w16(m, W.data(), N4, 0, Z + Hd, 0, N4, bb.data());
     m->gru1_fold.ch = pack_w16(m, ck.data(), Hd, Hd, Hd, 0, Hd, cb.data());
     m->fuse_concat = 1;
+    if (hp.dec_layer_num == 2) TRY(dx_build_pack(m, dx_Wc, dx_bc, W, bb));
   }
   {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
     std::vector<float> v = T_(m, "attention/attention_v").data;

@@ -13,7 +13,7 @@ import torch
 import taco_amd
 from bench import WORKLOADS
 
-PHASES = ["prenet2", "attGRU gates", "attGRU cand", "query", "scores", "normaliser+context", "concat proj", "GRU1 gates", "GRU1 cand",
+PHASES = ["prenet2", "attGRU gates", "attGRU cand", "query(local)", "partial scores+sum", "normaliser+context", "GRU1 gates(+concat)", "GRU1 cand",
           "GRU2 gates", "GRU2 cand", "prenet1(next)+frame"]
 
 
@@ -70,7 +70,8 @@ def main():
             if mode == 1 and rows == 0:
                 tr = model.decoder_trace(True, read=True)
                 model.decoder_trace(False)
-                d = np.diff(tr[:, :13], axis=1).astype(np.float64)          # [8 steps][12 phases] shader clocks
+                d = np.diff(tr[:, :12], axis=1).astype(np.float64)          # [8 steps][11 phases] shader clocks
+                sub = np.stack([tr[:, 12] - tr[:, 6], tr[:, 13] - tr[:, 12], tr[:, 14] - tr[:, 13], tr[:, 7] - tr[:, 14]], 1).astype(np.float64)
                 step_clk = (tr[1:, 0] - tr[:-1, 0]).astype(np.float64)
                 us_step = ms * 1e3 / n
                 clk_per_us = float(np.median(step_clk)) / us_step if us_step > 0 else 0.0
@@ -79,6 +80,8 @@ def main():
                 rec[label]["clock_MHz_est"] = clk_per_us
                 print("   timeline (median of steps 1-7, us; clock ~%.0f MHz): " % clk_per_us +
                       "  ".join("%s %.2f" % (p, c / clk_per_us) for p, c in zip(PHASES, med)), flush=True)
+                sm = np.median(sub[1:], axis=0) / clk_per_us
+                print("   GRU1 gates stage split: pass+reduce %.2f  epilogue+publish %.2f  gather(poll) %.2f  barrier %.2f" % tuple(sm), flush=True)
         res[name] = rec
         model.close()
     if jpath:
