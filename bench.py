@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
 WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speakers, model_type)
     "C1": (1, 64, 5, 200, 1, "single"),
@@ -90,6 +91,22 @@ def algorithmic_flops(hp, B, T_in, n):
     post = cbhg(post_rows, M, hp.post_bank_size, hp.post_bank_channel_size, hp.post_proj_sizes, hp.post_proj_width,
                 hp.post_rnn_size, hp.post_highway_depth) + post_rows * 2 * hp.post_rnn_size * hp.num_freq
     return 2 * (enc + B * n * step + post)
+
+
+def feedforward_flops(hp, B, T_in, n):
+    """the part of algorithmic_flops that runs on the bf16 matrix cores: everything except the recurrent halves of the two BiGRU
+    scans and the decoder loop"""
+    r = hp.reduction_factor
+    total = algorithmic_flops(hp, B, T_in, n)
+    As, Hd, A, D, M = hp.attention_state_size, hp.dec_rnn_size, hp.attention_size, 2 * hp.enc_rnn_size, hp.num_mels
+    dd = M + D
+    dp = 0
+    for s_ in hp.dec_prenet_sizes:
+        dp += dd * s_
+        dd = s_
+    step = dp + (dd + As) * 3 * As + As * A + T_in * (A + D) + (As + D) * Hd + hp.dec_layer_num * (2 * Hd) * 3 * Hd + Hd * M * r
+    scans = B * T_in * 2 * hp.enc_rnn_size * 3 * hp.enc_rnn_size + B * n * r * 2 * hp.post_rnn_size * 3 * hp.post_rnn_size
+    return total - 2 * (B * n * step + scans)
 
 
 def source_hash():
@@ -215,7 +232,8 @@ def main():
 
     rank, local_rank, world = D.env_rank()
     if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        if world != args.gpus:
+            sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
         torch.cuda.set_device(local_rank)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist = D.init_process_group("nccl")
@@ -232,6 +250,8 @@ def main():
     model.initialize(None, None, ns, None, device=str(dev))
     if args.overlap is not None:
         model._lib.taco_debug_set_overlap(model._handle, args.overlap)
+    if args.decoder_engine != 1:
+        model.set_decoder_engine(args.decoder_engine)
     rs = np.random.RandomState(seed + 100 * rank)
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)
     ids[:, T_in - 1] = 1                                                       # fixed-length batches
@@ -320,21 +340,61 @@ def main():
                 stage_ms[name] = s0.elapsed_time(s1) / 3
     finite = all(bool(torch.isfinite(p.mel).all().item() and torch.isfinite(p.linear).all().item()) for p in pool.plans)
 
+    def timed_pool(pl, nlanes, nsteps):
+        """nsteps forwards round-robin over nlanes lanes of pool pl; returns seconds per forward (HIP events, as the timed region)."""
+        for i in range(nlanes):
+            pl.launch(i % nlanes)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main_st)
+        for st in pl.streams:
+            st.wait_event(e0)
+        for i in range(nsteps):
+            pl.launch(i % nlanes)
+        for st in pl.streams:
+            main_st.wait_stream(st)
+        e1.record(main_st)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / nsteps
+
+    companions = {}
+    if rank == 0 and world == 1 and not args.no_companions and co == 1 and not args.eager:
+        # (i) strictly serial forwards (one in flight), (ii) the same lanes with every GEMM in exact fp32 (no split-bf16 feed-forward)
+        ksteps = max(4, min(args.steps, 12))
+        companions["lanes_1"] = {"mel_frames_per_s": B * n * r / timed_pool(pool, 1, ksteps), "forwards_in_flight": 1}
+        model._lib.taco_debug_set_bf3(model._handle, 0, 0)
+        model._plans.clear()
+        pool32 = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=1)
+        for plan32 in pool32.plans:
+            plan32.inputs.copy_(pool.plans[0].inputs); plan32.lengths.copy_(pool.plans[0].lengths)
+            if ns > 1:
+                plan32.speaker_id.copy_(pool.plans[0].speaker_id)
+        torch.cuda.synchronize()
+        companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / timed_pool(pool32, lanes, ksteps), "forwards_in_flight": lanes,
+                                    "arithmetic": "every contraction on exact-fp32 MFMA / VALU (taco_debug_set_bf3 off)"}
+        pool32.close()
+        model._lib.taco_debug_set_bf3(model._handle, 1, 0)
+        model._plans.clear()
+
     if rank == 0:
         frames = world * B * n * r * args.steps
         spec = taco_amd.weights.weight_spec(hp, ns)
         abytes, per_step = algorithmic_bytes(spec, hp, B, T_in, n)
         flops = algorithmic_flops(hp, B, T_in, n)
+        ff_flops = feedforward_flops(hp, B, T_in, n)
         sb = stage_bytes(spec, hp, B, T_in, n)
         fwd_s = dev_ms / 1e3 / args.steps      # device time per forward (HIP events over the timed region / forwards in it)
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3); recurrent / decoder mat-vecs exact fp32",
+            "data": "synthetic", "world_size_seen": world,
             "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
                                    % (args.workload, B, T_in, n * r, r, mt),
                        "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
-                       "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, recurrent and decoder mat-vecs exact-fp32 MFMA (max err vs float64 oracle 3.4e-6)",
+                       "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, BiGRU scans and the decoder loop in exact fp32 (max err vs float64 oracle 3.4e-6)",
+                       "decoder_engine": {0: "launch per stage", 1: "persistent XCD-local (csrc/taco_decoder_xcd.h)", 2: "persistent, write-through exchanges"}[args.decoder_engine],
                        "launch": "eager" if args.eager else "hipGraph plan (%d nodes)" % plan.num_nodes,
                        "forwards_in_flight": lanes, "requests_per_forward": co, "forward_latency_ms_alone": latency_ms},
             "roofline": {"bound": "hbm", "achieved": abytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -346,19 +406,30 @@ def main():
                          "stages": {k: {"ms_alone_eager": stage_ms[k], "algorithmic_GB": sb[k] / 1e9,
                                         "achieved_GBps": sb[k] / (stage_ms[k] * 1e-3) / 1e9, "frac": sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                                     for k in ("encoder", "decoder", "postnet")},
-                         "mfma_f32": {"achieved": flops / fwd_s / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                      "frac": flops / fwd_s / 1e12 / MFMA_F32_PEAK_TF, "gflop_per_forward": flops / 1e9}},
+                         # matrix-pipe view: the feed-forward contractions (everything but the two scans and the decoder loop) are
+                         # issued as THREE bf16 MFMAs per fp32 product; utilisation is counted on that pipe against its dense peak
+                         "mfma_bf16": {"issued_gflop_per_forward": 3 * ff_flops / 1e9, "achieved": 3 * ff_flops / fwd_s / 1e12,
+                                       "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3 * ff_flops / fwd_s / 1e12 / MFMA_BF16_PEAK_TF,
+                                       "note": "fp32-equivalent work of the whole forward: %.1f GFLOP = %.1f TFLOP/s; the scans and the decoder run on the fp32 VALU"
+                                               % (flops / 1e9, flops / fwd_s / 1e12)}},
+            "companions": companions,
             "outputs_finite": finite,
         }
-        # HBM-side traffic per forward from the committed PMC passes (profiles/*pmc_hbm_traffic.json), same workload only
+        # HBM-side traffic per forward from the committed PMC passes (profiles/*pmc_hbm_traffic.json), same workload only, and only
+        # when that profile was taken from THIS build of the kernels (sha256 over csrc/, recorded by tools/pmc_traffic.py)
         try:
             import glob
-            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")))
-            if pm:
-                rec = json.load(open(pm[-1]))
-                if rec.get("workload") == args.workload and co == 1:
+            pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.json")), key=os.path.getmtime)
+            here = source_hash()
+            out["roofline"]["kernel_source_hash"] = here
+            for f in reversed(pm):
+                rec = json.load(open(f))
+                if rec.get("workload") == args.workload and co == 1 and rec.get("kernel_source_hash") == here:
                     out["roofline"]["traffic"] = rec["traffic_bytes_per_forward"]
-                    out["roofline"]["traffic_source"] = os.path.basename(pm[-1])
+                    out["roofline"]["traffic_source"] = os.path.basename(f)
+                    break
+            else:
+                out["roofline"]["traffic_source"] = "none: no committed PMC profile matches this build of the kernels (hash %s)" % here
         except Exception:
             pass
         if world == 1 and not args.no_cpu_baseline:

@@ -214,13 +214,15 @@ size_t taco_train_workspace_bytes(const taco_train* t, int B, int T_in, int T_ou
  * 28 backward), 80 to 4096 floats each.  Not capturable into a hipGraph. */
 typedef void (*taco_sync_sum_fn)(void* user, float* d_vec, int n);
 int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int world_size);
-/* One training forward (+ backward when d_grads != NULL).  d_params is in/out: the BatchNorm moving averages are updated
- * in place (UPDATE_OPS dependency, tacotron.py:334).  d_mel_targets [B,T_out,num_mels], d_linear_targets [B,T_out,num_freq],
+/* One training forward (+ backward when d_grads != NULL).  d_params is in/out: a forward+backward pass updates the BatchNorm
+ * moving averages in place (UPDATE_OPS run only as a dependency of `optimize`, tacotron.py:334); a forward-only pass
+ * (d_grads == NULL: loss fetches, the test model) leaves them untouched, as the reference does.  d_mel_targets [B,T_out,num_mels], d_linear_targets [B,T_out,num_freq],
  * T_out a multiple of r, T_out/r <= max_iters (helpers.py:44-48).  d_losses[4] = loss, mel_loss, linear_loss,
  * loss_without_coeff (nullable).  d_mel_out / d_linear_out / d_alignments ([B,T_in,T_out/r]) nullable.
  * d_grads (flat, overwritten) = d loss / d parameter; moving statistics get zero.
- * rnn_decoder_test_mode != 0 (helpers.py:63-64, the test model of train.py:158-166): the decoder is fed its own previous
- * output instead of the target frame; forward/loss only (d_grads must be NULL). */
+ * rnn_decoder_test_mode bit 0 (helpers.py:63-64, the test model of train.py:158-166): the decoder is fed its own previous
+ * output instead of the target frame; forward/loss only (d_grads must be NULL).  Bit 1: freeze the moving averages even though
+ * d_grads is given (a warm-up pass whose update is discarded, e.g. before capturing the step into a graph). */
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
                                 const int32_t* d_input_lengths, const int32_t* d_speaker_id /* nullable: single speaker */,
                                 const float* d_mel_targets, const float* d_linear_targets,

@@ -299,6 +299,7 @@ static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n,
 // ---------------------------------------------------------------------------------------------------------------
 struct TrainCtx {
   const taco_train* t; hipStream_t st; float* P; float* G;    // flat parameters (moving statistics are updated in place) and gradients
+  bool update_moving;   // BatchNorm moving averages follow this pass (UPDATE_OPS run only as a dependency of `optimize`, tacotron.py:334)
   float* p(const std::string& n) const { return P + t->poff.at(n); }
   float* g(const std::string& n) const { return G + t->poff.at(n); }
 };
@@ -318,8 +319,10 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
   if (sync) x.t->sync_fn(x.t->sync_user, scratch + C, C);
   int c0 = 0;
   for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix
-    hipLaunchKernelGGL(k_bn_finalize, EWGRID(cols[i]), 0, st, mu + c0, scratch + C + c0, rstd + c0, x.p(names[i] + "/moving_mean"),
-                       x.p(names[i] + "/moving_variance"), cols[i], invM, 1e-3f, 0.99f);
+    // forward-only passes (loss fetches, the test model, a capture warm-up) leave the moving statistics alone, as the reference does
+    hipLaunchKernelGGL(k_bn_finalize, EWGRID(cols[i]), 0, st, mu + c0, scratch + C + c0, rstd + c0,
+                       x.update_moving ? x.p(names[i] + "/moving_mean") : (float*)nullptr,
+                       x.update_moving ? x.p(names[i] + "/moving_variance") : (float*)nullptr, cols[i], invM, 1e-3f, 0.99f);
     c0 += cols[i];
   }
   HIPCHK(hipGetLastError());
@@ -750,7 +753,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
 static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float* G, const int* ids, const int* lengths, const int* speaker_id, const float* mel_tgt,
                                   const float* lin_tgt, const float* loss_coeff, int B, int T_in, int T_out, int prioritize_loss,
                                   int sample_rate, float* d_losses, float* mel_out, float* lin_out, float* align_out, void* ws, size_t ws_bytes,
-                                  bool do_backward, bool feed_back) {
+                                  bool do_backward, bool feed_back, bool freeze_moving = false) {
   taco_model* m = t->sm;
   const taco_hparams& hp = m->hp;
   const int r = hp.reduction_factor, Mm = hp.num_mels, F = hp.num_freq;
@@ -761,7 +764,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   Carver cv(ws, ws_bytes);
   TrainWs w; carve_train(cv, t, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
-  TrainCtx x{t, st, P, G};
+  TrainCtx x{t, st, P, G, do_backward && !freeze_moving};
   const int Me = B * T_in, Mp = B * T_out;
   // ---- forward ----
   const float* cur = x.p("embedding"); int curd = hp.embedding_size;

@@ -88,5 +88,5 @@ int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params
   HIPCHK(hipSetDevice(t->sm->device));
   return train_forward_backward(t, (hipStream_t)hip_stream, d_params, d_grads, d_inputs, d_input_lengths, d_speaker_id, d_mel_targets, d_linear_targets,
                                 d_loss_coeff, B, T_in, T_out, prioritize_loss, sample_rate, d_losses, d_mel_out, d_linear_out, d_alignments,
-                                d_workspace, workspace_bytes, d_grads != nullptr, rnn_decoder_test_mode != 0);
+                                d_workspace, workspace_bytes, d_grads != nullptr, (rnn_decoder_test_mode & 1) != 0, (rnn_decoder_test_mode & 2) != 0);
 }

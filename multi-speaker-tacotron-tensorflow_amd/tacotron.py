@@ -193,11 +193,17 @@ class PlanPool(object):
             self.streams[lane].wait_stream(cur)      # ids/lens may have been produced on the caller's stream
             plan.inputs[rows].copy_(ids, non_blocking=True)
             plan.lengths[rows].copy_(lens, non_blocking=True)
+            # the temporaries were allocated on the caller's stream and are read here on the lane's: tell the caching allocator,
+            # or it may hand their blocks out again while these copies are still pending
+            ids.record_stream(self.streams[lane])
+            lens.record_stream(self.streams[lane])
             if m.num_speakers > 1:
                 if speaker_id is None:
                     plan.speaker_id[rows].zero_()
                 else:
-                    plan.speaker_id[rows].copy_(m._as_dev(speaker_id, torch.int32), non_blocking=True)
+                    spk = m._as_dev(speaker_id, torch.int32)
+                    plan.speaker_id[rows].copy_(spk, non_blocking=True)
+                    spk.record_stream(self.streams[lane])
         if self.coalesce == 1:
             self.filled[lane] = 1
             self.launch(lane)
@@ -246,6 +252,8 @@ class PlanPool(object):
 
 
 class Tacotron(object):
+    MAX_PLANS = 16     # least-recently-used bound of the per-shape plan cache (plan_for)
+
     def __init__(self, hparams=None):
         self._hparams = hparams if hparams is not None else default_hparams
         self._lib = None
@@ -397,10 +405,16 @@ class Tacotron(object):
     def plan_for(self, B, T_in, n_steps=None, manual=False):
         n = self._hparams.max_iters if n_steps is None else n_steps
         key = (B, T_in, n, bool(manual))
-        if key not in self._plans:
+        plan = self._plans.pop(key, None)
+        if plan is None:
+            # every distinct shape owns a captured graph plus output / workspace buffers (tens of MB): keep the most recently used
+            # MAX_PLANS of them (a server that synthesises arbitrary text lengths would otherwise grow without bound)
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
             with torch.cuda.device(self.device):
-                self._plans[key] = _Plan(self, B, T_in, n, manual)
-        return self._plans[key]
+                plan = _Plan(self, B, T_in, n, manual)
+        self._plans[key] = plan          # (re)inserted last = most recently used
+        return plan
 
     def plan_pool(self, B, T_in, n_steps=None, lanes=4, coalesce=1):
         """`lanes` forwards of this shape in flight at once, each serving `coalesce` requests of B rows (PlanPool)."""

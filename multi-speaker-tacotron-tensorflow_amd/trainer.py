@@ -59,7 +59,11 @@ class Trainer(object):
         g = lambda k, d: getattr(hparams, k, d)
         self.adam = FlatAdam(self.params, g("initial_learning_rate", 0.002), g("adam_beta1", 0.9), g("adam_beta2", 0.999), 1e-8,
                              g("decay_learning_rate_mode", 0), is_randomly_initialized, 1.0)
-        self._ws = None
+        self._ws = None          # workspace of the (captured or only) step
+        self._ws_eager = None    # workspace of eager calls made while a captured step exists
+        self._ws_live = None
+        self._graph = None
+        self._capturing = False
         self._sync_cb = None
         self._sync_err = None
         self.mel_outputs = self.linear_outputs = self.alignments = None
@@ -81,10 +85,11 @@ class Trainer(object):
 
         def _sum(user, ptr, n):
             try:            # the vector lives in this step's workspace: view it as a tensor and sum it over the ranks, stream-ordered
-                off = int(ptr) - self._ws.data_ptr()
-                if off < 0 or off + 4 * n > self._ws.numel():
+                wsb = self._ws_live
+                off = int(ptr) - wsb.data_ptr()
+                if off < 0 or off + 4 * n > wsb.numel():
                     raise RuntimeError("statistics vector outside the workspace")
-                dist.all_reduce(self._ws[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(wsb[off:off + 4 * n].view(torch.float32), op=dist.ReduceOp.SUM, group=group)
             except Exception as e:     # an exception must not unwind through the C frames: it is re-raised after the call returns
                 self._sync_err = e
         self._sync_cb = _lib.SYNC_SUM_FN(_sum)
@@ -119,8 +124,10 @@ class Trainer(object):
 
     # ---- one forward (+ backward) ----
     def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False,
-                         rnn_decoder_test_mode=False, speaker_id=None):
-        """Fills self.grads (when backward) and returns the device tensor [4] = loss, mel_loss, linear_loss, loss_without_coeff."""
+                         rnn_decoder_test_mode=False, speaker_id=None, freeze_moving_averages=False):
+        """Fills self.grads (when backward) and returns the device tensor [4] = loss, mel_loss, linear_loss, loss_without_coeff.
+        The BatchNorm moving averages (in self.params) follow a forward+backward pass only (tacotron.py:334), and not even that with
+        freeze_moving_averages (a warm-up whose result is thrown away)."""
         dev = self.device
         ids = torch.as_tensor(np.asarray(inputs) if not torch.is_tensor(inputs) else inputs).to(dev, torch.int32).contiguous()
         lens = torch.as_tensor(np.asarray(input_lengths) if not torch.is_tensor(input_lengths) else input_lengths).to(dev, torch.int32).contiguous()
@@ -137,18 +144,26 @@ class Trainer(object):
         if mt.shape != (B, T_out, hp.num_mels) or lt.shape != (B, T_out, hp.num_freq):
             raise Exception("targets must be [B, T_out, num_mels] / [B, T_out, num_freq], got %s / %s" % (tuple(mt.shape), tuple(lt.shape)))
         nb = int(self._lib.taco_train_workspace_bytes(self._h, B, T_in, T_out))
-        if self._ws is None or self._ws.numel() < nb:
-            self._ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        # A captured step has the address of ITS workspace baked into every kernel node: that buffer is never reallocated while the
+        # graph is alive.  Eager calls beside the graph (another shape, a loss fetch) use a workspace of their own.
+        wsattr = "_ws" if (getattr(self, "_graph", None) is None or getattr(self, "_capturing", False)) else "_ws_eager"
+        ws = getattr(self, wsattr, None)
+        if ws is None or ws.numel() < nb:
+            if wsattr == "_ws" and getattr(self, "_capturing", False) and ws is not None:
+                raise _lib.TacoError(_lib.TACO_ERR_STATE, "workspace grew during graph capture")
+            ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            setattr(self, wsattr, ws)
         mel = lin = ali = None
         if keep_outputs:
             mel = torch.empty((B, T_out, hp.num_mels), dtype=torch.float32, device=dev)
             lin = torch.empty((B, T_out, hp.num_freq), dtype=torch.float32, device=dev)
             ali = torch.empty((B, T_in, T_out // hp.reduction_factor), dtype=torch.float32, device=dev)
+        self._ws_live = ws      # the workspace of the call in flight (the SyncBN callback reduces slices of it)
         with torch.cuda.device(dev):
             _lib.check(self._lib.taco_train_forward_backward(
                 self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(spk), _p(mt), _p(lt), _p(co),
                 B, T_in, T_out, int(bool(getattr(hp, "prioritize_loss", False))), int(getattr(hp, "sample_rate", 24000)), _p(self.losses),
-                _p(mel), _p(lin), _p(ali), int(bool(rnn_decoder_test_mode)), _p(self._ws), self._ws.numel()))
+                _p(mel), _p(lin), _p(ali), int(bool(rnn_decoder_test_mode)) | (2 if freeze_moving_averages else 0), _p(ws), ws.numel()))
         if self._sync_err is not None:
             e, self._sync_err = self._sync_err, None
             raise e
@@ -166,12 +181,19 @@ class Trainer(object):
         self._g_in = [cv(inputs, torch.int32), cv(input_lengths, torch.int32), cv(mel_targets, torch.float32),
                       cv(linear_targets, torch.float32), None if loss_coeff is None else cv(loss_coeff, torch.float32)]
         self._g_spk = None if speaker_id is None else cv(speaker_id, torch.int32)
+        self._graph = None
         with torch.cuda.device(dev):
-            self.forward_backward(*self._g_in, speaker_id=self._g_spk)            # sizes the workspace outside the capture
+            # sizes the workspace outside the capture; its BatchNorm update is discarded (the step itself has not happened yet)
+            self.forward_backward(*self._g_in, speaker_id=self._g_spk, freeze_moving_averages=True)
             torch.cuda.synchronize()
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self.forward_backward(*self._g_in, speaker_id=self._g_spk)
+            graph = torch.cuda.CUDAGraph()
+            self._capturing = True
+            try:
+                with torch.cuda.graph(graph):
+                    self.forward_backward(*self._g_in, speaker_id=self._g_spk)
+            finally:
+                self._capturing = False
+            self._graph = graph
         return self
 
     def _replay(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id=None):

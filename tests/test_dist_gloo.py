@@ -81,3 +81,32 @@ def test_gradient_allreduce_is_the_mean_of_the_shards():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.allclose(g, np.arange(1000) * 1.5)
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (the driver's command form): bench.py re-launches itself under torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1; --selftest-launcher runs exactly that path on gloo (no GPU work) and reports the
+    world size the ranks saw and the max-over-ranks reduction the timed region uses."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--selftest-launcher"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["world_size"] == 2 and rec["n_gpus"] == 2 and rec["max_over_ranks"] == 2.0
+
+
+def test_bench_single_process_selftest():
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--selftest-launcher"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["world_size"] == 1

@@ -47,7 +47,20 @@ def test_training_forward_matches_oracle(atype):
     got = losses.cpu().numpy()
     for i, k in enumerate(("loss", "mel_loss", "linear_loss", "loss_without_coeff")):
         assert abs(got[i] - want[k]) < 1e-5 * max(1.0, abs(want[k])), k
-    # BatchNorm moving averages were updated in the flat parameter buffer (UPDATE_OPS, tacotron.py:334)
+    # a forward-only pass (loss fetch, test model) leaves the BatchNorm moving averages alone: the reference runs UPDATE_OPS only
+    # as a dependency of `optimize` (tacotron.py:334)
+    now = tr.get_weights()
+    for k in w:
+        assert np.array_equal(now[k], np.asarray(w[k], np.float32)), k
+    # a warm-up forward+backward with frozen statistics (what Trainer.capture does before recording the step) does not either
+    tr.forward_backward(ids, L, mt, lt, co, backward=True, freeze_moving_averages=True)
+    torch.cuda.synchronize()
+    now = tr.get_weights()
+    for k in w:
+        assert np.array_equal(now[k], np.asarray(w[k], np.float32)), k
+    # forward + backward: the moving averages are updated in the flat parameter buffer, once
+    tr.forward_backward(ids, L, mt, lt, co, backward=True)
+    torch.cuda.synchronize()
     now = tr.get_weights()
     assert len(upd) == 2 * (hp.enc_bank_size + hp.post_bank_size + len(hp.enc_proj_sizes) + len(hp.post_proj_sizes))
     for k, v in upd.items():
@@ -364,3 +377,33 @@ def test_simple_multispeaker_training_gradients(ses, atype):
     step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)
     assert step == 1 and np.isfinite(float(lwc))
     tr.close()
+
+
+def test_captured_step_survives_an_eager_step_of_a_larger_shape():
+    """Trainer.capture bakes the workspace address into the graph; an eager step with a shape that needs a larger workspace must
+    not move or free that buffer: capture at a small shape, step eagerly at a larger one, replay the small shape again
+    and compare every parameter with a trainer that never captured anything.  The capture itself (warm-up + recording) must not
+    advance the BatchNorm moving averages."""
+    import torch
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=31)
+    rs = np.random.RandomState(32)
+    B2, T2, To2 = ids.shape[0] + 3, ids.shape[1] + 9, mt.shape[1] + 2 * hp.reduction_factor
+    ids2, L2 = O.synthetic_inputs(B2, T2, 33, ragged=True)
+    mt2, lt2 = rs.rand(B2, To2, hp.num_mels), rs.rand(B2, To2, hp.num_freq)
+    a, b = _trainer(hp, w), _trainer(hp, w)
+    a.capture(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    w0 = a.get_weights()
+    for k in w:
+        assert np.array_equal(w0[k], np.asarray(w[k], np.float32)), "capture changed %s" % k
+    for tr in (a, b):
+        tr.train_step(ids, L, mt, lt, co)             # a: graph replay, b: eager
+        tr.train_step(ids2, L2, mt2, lt2)              # a: eager beside the graph, with a larger workspace
+        tr.train_step(ids, L, mt, lt, co)             # a: replay into the graph's own (untouched) workspace
+    torch.cuda.synchronize()
+    assert a._graph is not None and a._ws_eager is not None and a._ws_eager.numel() > a._ws.numel()
+    wa, wb = a.get_weights(), b.get_weights()
+    for k in wa:
+        # (Adam's update is lr * m / sqrt(v): fp32-atomic summation order in the weight gradients moves near-zero-gradient entries by
+        # a visible fraction of a step; a replay into freed memory is off by orders of magnitude or not finite)
+        assert np.isfinite(wa[k]).all() and maxabs(wa[k], wb[k]) < 1e-3 * max(1.0, float(np.abs(wb[k]).max())), k

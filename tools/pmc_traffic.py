@@ -7,6 +7,8 @@ doubled.  Usage (on the GPU box, counters only -- no sys/hip/hsa trace domains):
   python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w profiles/rNN_pmc_hbm_traffic"""
 import glob, json, os, sys
 import pandas as pd
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash
 
 
 def load(d, counter):
@@ -25,7 +27,7 @@ def main():
     wk = w.groupby(w.Kernel_Name.str.slice(0, 46)).Counter_Value.sum() / nfwd_w
     calls = f.groupby(f.Kernel_Name.str.slice(0, 46)).size() / nfwd_f
     fetch_kb, write_kb = float(fk.sum()), float(wk.sum())
-    rec = {"workload": "C2", "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), %d forwards averaged" % nfwd_f,
+    rec = {"workload": "C2", "kernel_source_hash": source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), %d forwards averaged" % nfwd_f,
            "fetch_size_reported_bytes": fetch_kb * 1024, "fetch_size_corrected_bytes": 2 * fetch_kb * 1024, "write_size_bytes": write_kb * 1024,
            "traffic_bytes_per_forward": 2 * fetch_kb * 1024 + write_kb * 1024,
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); counters are L2<->fabric "
