@@ -151,11 +151,11 @@ __device__ __forceinline__ float dx_scan(float v) {
 __device__ __forceinline__ float dx_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
 
 // one pass: acc[c][r] += sum_e W[REG0 + 4c + e] * x[r][4*lane + e]   (x: LDS, row stride DXS_LD)
-template <int REG0, int NCOLS, int RG>
-__device__ __forceinline__ void dx_pass(const float (&W)[DX_NREG], const float* x, int lane, float (&acc)[NCOLS][RG]) {
+template <int REG0, int NCOLS, int RG, int NW = DX_NREG, int LD = DXS_LD>
+__device__ __forceinline__ void dx_pass(const float (&W)[NW], const float* x, int lane, float (&acc)[NCOLS][RG]) {
 #pragma unroll
   for (int r = 0; r < RG; ++r) {
-    const float4 xv = *reinterpret_cast<const float4*>(x + r * DXS_LD + 4 * lane);
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
 #pragma unroll
     for (int c = 0; c < NCOLS; ++c) {
       acc[c][r] = fmaf(W[REG0 + 4 * c + 0], xv.x, acc[c][r]);
@@ -295,7 +295,7 @@ __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsign
 }
 // all-gather of a published [RG][N] vector into the LDS state vector at column offset `off` (N a power of two);
 // RES: dst2[r][n] = value + res[r][n] as well (ResidualWrapper output, tacotron.py:172)
-template <int RG, int N, bool RES>
+template <int RG, int N, bool RES, int LD = DXS_LD>
 __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float* st, int off, int off_res, int off2, int tid, DxRt& rt) {
   constexpr int NI = (RG * N + DX_NT - 1) / DX_NT;
   const bool act = (RG * N >= DX_NT) || tid < RG * N;
@@ -306,8 +306,8 @@ __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float*
     for (int u = 0; u < NI; ++u) {
       const int i = u * DX_NT + tid;
       const int r = i / N, n = i % N;
-      st[r * DXS_LD + off + n] = v[u];
-      if (RES) st[r * DXS_LD + off2 + n] = v[u] + st[r * DXS_LD + off_res + n];
+      st[r * LD + off + n] = v[u];
+      if (RES) st[r * LD + off2 + n] = v[u] + st[r * LD + off_res + n];
     }
   }
 }
@@ -385,6 +385,38 @@ __device__ __forceinline__ void dx_normalise_lds(float* sc, float* tmp, float* t
   }
 }
 
+// Census of a persistent launch of 256 workgroups: every workgroup reports the XCD it runs on (HW_REG_XCC_ID) and takes the next
+// slot there; when all have arrived and every XCD hosts exactly 32 of them, the XCD-local protocol is used (exchange stores stay
+// in the XCD's L2) and a workgroup's place is (xcc, slot); otherwise -- or with force_wt -- places follow blockIdx and the stores
+// are write-through.  out[0] = xcc or blockIdx % 8, out[1] = slot (0..31) or blockIdx / 8, out[2] = write-through?, out[3] = failed?
+// errw[info0..info0+8] report the protocol and the per-XCD counts to the host.  Called by all threads; ends with a barrier.
+__device__ __forceinline__ void dx_census(dx_gu32* ctl, dx_gu32* errw, int force_wt, int* out, int tid, int info0) {
+  if (tid == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;      // HW_REG_XCC_ID (id 20), bits [3:0]
+    const unsigned slot = __hip_atomic_fetch_add(ctl + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0; bool ok = true;
+    while (__hip_atomic_load(ctl + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (DX_SPIN_LIMIT << 2) || __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+    }
+    bool even = ok;
+    for (int i = 0; i < DX_NGROUP; ++i)
+      even = even && (__hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)DX_GROUP);
+    const bool fast = even && !force_wt;
+    if (!ok) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    out[0] = fast ? (int)xcc : (int)(blockIdx.x & 7);
+    out[1] = fast ? (int)slot : (int)(blockIdx.x >> 3);
+    out[2] = fast ? 0 : 1;
+    out[3] = ok ? 0 : 1;
+    if (blockIdx.x == 0) {   // reported to the host (taco_debug_decoder_info): protocol used, workgroups seen per XCD
+      errw[info0] = fast ? 1u : 2u;
+      for (int i = 0; i < DX_NGROUP; ++i) errw[info0 + 1 + i] = __hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+}
+
 #define DX_STAMP(slot)                                                                                     \
   do {                                                                                                     \
     if (tracer && t < DX_TRACE_STEPS) a.trace[t * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
@@ -428,30 +460,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   // ---- census: which XCD am I on, is every XCD hosting exactly one group? ----
   dx_gu32* ctl = (dx_gu32*)a.ctl;
   dx_gu32* errw = (dx_gu32*)a.err;
-  if (tid == 0) {
-    const unsigned xcc = __builtin_amdgcn_s_getreg(6164) & 7u;      // HW_REG_XCC_ID (id 20), bits [3:0]
-    const unsigned slot = __hip_atomic_fetch_add(ctl + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0; bool ok = true;
-    while (__hip_atomic_load(ctl + 8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (DX_SPIN_LIMIT << 2) || __hip_atomic_load(errw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-    }
-    bool even = ok;
-    for (int i = 0; i < DX_NGROUP; ++i)
-      even = even && (__hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)DX_GROUP);
-    const bool fast = even && !a.force_wt;
-    if (!ok) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ictl[0] = fast ? (int)xcc : (int)(blockIdx.x & 7);
-    ictl[1] = fast ? (int)slot : (int)(blockIdx.x >> 3);
-    ictl[2] = fast ? 0 : 1;
-    ictl[3] = ok ? 0 : 1;
-    if (blockIdx.x == 0) {   // reported to the host (taco_debug_decoder_info): protocol used, workgroups seen per XCD
-      errw[8] = fast ? 1u : 2u;
-      for (int i = 0; i < DX_NGROUP; ++i) errw[9 + i] = __hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-  __syncthreads();
+  dx_census(ctl, errw, a.force_wt, ictl, tid, 8);
   const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
   const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
   DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;

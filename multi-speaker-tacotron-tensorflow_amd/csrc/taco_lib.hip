@@ -4,6 +4,7 @@
 // No CPU compute path exists here: every stage is a gfx950 kernel from taco_kernels.h.
 #include "taco_kernels.h"
 #include "taco_decoder_xcd.h"
+#include "taco_bigru_xcd.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
 #include "../../include/taco_abi.h"
@@ -80,6 +81,7 @@ struct Cbhg {
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
+  size_t gx_pack[2] = {0, 0};                      // per-thread weight packs of k_bigru_xcd (taco_bigru_xcd.h), H = 256 only
   size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
                                                    // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
 };
@@ -480,6 +482,21 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
             }
         c.res_g2p[dir] = arena_put(m, g2p.data(), g2p.size());
         c.res_c1p[dir] = arena_put(m, c1p.data(), c1p.size());
+        if (!m->tp) {   // k_bigru_xcd: member mem, wave w own units 16 mem + 2w (+1); lane l holds h rows 4l..4l+3 of r, u (both units), then c
+          std::vector<float> gp((size_t)GX_MEMBERS * GX_NREG * DX_NT, 0.f);
+          for (int mem = 0; mem < GX_MEMBERS; ++mem)
+            for (int tid = 0; tid < DX_NT; ++tid) {
+              const int w = tid >> 6, l = tid & 63, ua = mem * 16 + 2 * w;
+              for (int e = 0; e < 4; ++e) {
+                const size_t kr = (size_t)(I + 4 * l + e);
+                auto put = [&](int reg, float v) { gp[((size_t)mem * GX_NREG + reg) * DX_NT + tid] = v; };
+                put(0 + e, gk[kr * 2 * H + ua]);      put(4 + e, gk[kr * 2 * H + H + ua]);          // r_a, u_a
+                put(8 + e, gk[kr * 2 * H + ua + 1]);  put(12 + e, gk[kr * 2 * H + H + ua + 1]);     // r_b, u_b
+                put(16 + e, ck[kr * H + ua]);         put(20 + e, ck[kr * H + ua + 1]);             // c_a, c_b
+              }
+            }
+          c.gx_pack[dir] = arena_put(m, gp.data(), gp.size());
+        }
       } }
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
@@ -718,7 +735,7 @@ struct Carver {
   bool ok() const { return !base || off <= cap; }
 };
 
-struct CbhgWs { float *bank, *p[4], *hi0, *hi1, *xproj, *h, *rh, *u; };
+struct CbhgWs { float *bank, *p[4], *hi0, *hi1, *xproj, *h, *rh, *u; unsigned long long* gxbuf; size_t gxbuf_bytes; unsigned* gxctl; };
 static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
   const size_t M = (size_t)B * T;
   w.bank = cv.f(M * c.K * c.C);
@@ -726,6 +743,9 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
   w.hi0 = cv.f(M * c.rnn); w.hi1 = cv.f(M * c.rnn);
   w.xproj = cv.f(M * 6 * c.rnn);
   w.h = cv.f((size_t)2 * B * c.rnn); w.rh = cv.f((size_t)2 * B * c.rnn); w.u = cv.f((size_t)2 * B * c.rnn);
+  w.gxbuf_bytes = gx_xbuf_granules(8) * sizeof(unsigned long long);     // k_bigru_xcd exchange granules (sized for 8 rows per group)
+  w.gxbuf = (unsigned long long*)cv.raw(w.gxbuf_bytes);
+  w.gxctl = (unsigned*)cv.raw(256);
 }
 
 // Row-parallel persistent BiGRU: R rows per workgroup.  Returns false when it does not fit.
@@ -751,6 +771,28 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
+  if (m->persist == 1 && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 8 * (GX_NGROUP / 2) && T >= 2) {
+    // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h)
+    GxArgs a; memset(&a, 0, sizeof a);
+    a.wpack0 = AP(m, c.gx_pack[0]); a.wpack1 = AP(m, c.gx_pack[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
+    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = m->d_trace; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+    int RG = 1;
+    while (RG < 8 && RG * (GX_NGROUP / 2) < B) RG *= 2;
+    HIPCHK(hipMemsetAsync(w.gxbuf, 0, gx_xbuf_granules(RG) * sizeof(unsigned long long), st));
+    HIPCHK(hipMemsetAsync(w.gxctl, 0, 256, st));
+    // the kernel needs only a few KB of LDS and ~70 VGPRs: asking for more than half of the CU's LDS keeps the dispatcher from
+    // stacking two of the 256 workgroups on one CU (the census checks placement per XCD, not per CU)
+    const size_t lds = std::max(gx_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);
+    const dim3 grid(DX_NGROUP * DX_GROUP), blk(DX_NT);
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_xcd<1>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_xcd<2>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_xcd<4>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_xcd<8>), grid, blk, lds, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   if ((m->persist == 1 || m->persist >= 4) && H == 256) {
     // weights resident on the CU, 4 hidden units per thread: k_bigru_resw 3.74 us/step; its predecessor k_bigru_resu (persist 6)
     // 5.16, one unit per thread (k_bigru_res, persist 3) 5.7, re-streaming everything (k_bigru_rows, persist 2) 7.1
@@ -758,7 +800,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T;
     auto lds = [&](int UJ, int KL) { const int NQ = 512 / (H / UJ); return ((size_t)3 * H + (size_t)NQ * 3 * H) * sizeof(float) + (size_t)KL * NQ * H * 12; };
-    if (m->persist == 1) {      // default: wave-local exchanges, a thread's four units adjacent in the (column-permuted) packs
+    if (m->persist == 1 || m->persist == 7) {      // wave-local exchanges, a thread's four units adjacent in the (column-permuted) packs
       a.g2_0 = (const float2*)AP(m, c.res_g2p[0]); a.g2_1 = (const float2*)AP(m, c.res_g2p[1]); a.c1_0 = AP(m, c.res_c1p[0]); a.c1_1 = AP(m, c.res_c1p[1]);
       hipLaunchKernelGGL((k_bigru_resw<16, 4, 2>), dim3(2 * B), dim3(512), lds(4, 4), st, a);
     }
@@ -1488,6 +1530,10 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -182,3 +182,44 @@ def test_C3_full_length_128_steps_on_8_of_the_32_rows():
     print("C3: argmax compared at %d of %d steps" % (nchk, len(rows) * n))
     assert bad == 0
     m.check_device_errors()
+
+
+@pytest.mark.parametrize("B", [1, 7, 32, 64])
+def test_post_net_scan_spread_over_the_chip(B):
+    """k_bigru_xcd (csrc/taco_bigru_xcd.h; the default at H = 256): 16 groups of 16 CUs, one direction and ceil(B/8) rows each, two
+    L2 exchanges per step.  Against the oracle's bidirectional GRU (modules.py:82-96, A.6/A.7) with ragged lengths (incl. 0 and T)
+    and an initial state, against the one-CU-per-chain kernel it replaces, and bit-repeatable."""
+    import ctypes as C
+    import torch
+    import taco_amd
+    from util import dev, ptr, stream
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 41)
+    m = build_model(ohp, w)
+    rs = np.random.RandomState(42 + B)
+    T, H = 37, ohp.post_rnn_size
+    x = rs.randn(B, T, H) * 0.5
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32); lens[0] = T
+    if B > 1:
+        lens[1] = 0
+    init = rs.randn(B, 2 * H) * 0.5
+    xd, ld, idv = dev(x, torch.float32), dev(lens), dev(init, torch.float32)
+    n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    got = {}
+    for persist in (1, 1, 7):
+        m._lib.taco_debug_set_persistent(m._handle, persist)
+        for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
+            out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+            taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"post_cbhg", ptr(xd), lp, ip, B, T, ptr(out), ptr(ws), n))
+            torch.cuda.synchronize()
+            got.setdefault((persist, tag), []).append(out.cpu().numpy())
+    m._lib.taco_debug_set_persistent(m._handle, 1)
+    m.check_device_errors()
+    v = (C.c_int * 16)()
+    taco_amd._lib.check(m._lib.taco_debug_decoder_info(m._handle, v))
+    for tag, ref in (("plain", O.bidirectional_gru(x, None, w, "post_cbhg/bigru")), ("ragged", O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init))):
+        a, b = got[(1, tag)]
+        assert np.array_equal(a, b), "k_bigru_xcd is not bit-repeatable (%s)" % tag
+        assert maxabs(a, ref) < 1e-4, tag
+        assert maxabs(a, got[(7, tag)][0]) < 2e-5, tag

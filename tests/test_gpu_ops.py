@@ -200,7 +200,7 @@ def test_bigru_with_lengths_and_init_state(ctx, B, persist):
 
 
 def test_bigru_wave_local_scan_is_bit_identical_to_the_four_barrier_one():
-    """k_bigru_resw (persist 1, the default: gate and state exchanges kept inside the wave that owns the K-slice, two barriers per
+    """k_bigru_resw (persist 7; the default before k_bigru_xcd: gate and state exchanges kept inside the wave that owns the K-slice, two barriers per
     step, column-permuted weight packs read with 16-byte loads) performs the arithmetic of its predecessor k_bigru_resu (persist 6,
     four barriers) in the same order: identical bits, with ragged lengths and an initial state too (A.7 masking, modules.py:82-86)."""
     import torch
@@ -217,7 +217,7 @@ def test_bigru_wave_local_scan_is_bit_identical_to_the_four_barrier_one():
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
     got = {}
-    for persist in (1, 6):
+    for persist in (7, 6):
         m._lib.taco_debug_set_persistent(m._handle, persist)
         for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
             out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
@@ -227,7 +227,7 @@ def test_bigru_wave_local_scan_is_bit_identical_to_the_four_barrier_one():
     m._lib.taco_debug_set_persistent(m._handle, 1)
     m.check_device_errors()
     for tag in ("plain", "ragged"):
-        assert np.array_equal(got[(1, tag)], got[(6, tag)]), tag
+        assert np.array_equal(got[(7, tag)], got[(6, tag)]), tag
     assert maxabs(got[(6, "plain")], O.bidirectional_gru(x, None, w, "post_cbhg/bigru")) < 1e-4
     assert maxabs(got[(6, "ragged")], O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init)) < 1e-4
 

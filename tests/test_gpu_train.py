@@ -381,8 +381,9 @@ def test_simple_multispeaker_training_gradients(ses, atype):
 
 def test_captured_step_survives_an_eager_step_of_a_larger_shape():
     """Trainer.capture bakes the workspace address into the graph; an eager step with a shape that needs a larger workspace must
-    not move or free that buffer: capture at a small shape, step eagerly at a larger one, replay the small shape again
-    and compare every parameter with a trainer that never captured anything.  The capture itself (warm-up + recording) must not
+    not move or free that buffer, and the replay that follows it must still be the step (the trainer records the
+    step afresh on that transition): capture at a small shape, step eagerly at a larger one, replay the small shape again and
+    compare every parameter with a trainer that never captured anything.  The capture itself (warm-up + recording) must not
     advance the BatchNorm moving averages."""
     import torch
     hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=31)
