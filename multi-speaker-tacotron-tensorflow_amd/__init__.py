@@ -6,4 +6,4 @@ from .tacotron import Tacotron, create_model, input_lengths_from_tokens         
 from .synthesizer import Synthesizer                                               # noqa: F401
 from .audio import GriffinLim                                                     # noqa: F401
 from .trainer import Trainer                                                       # noqa: F401
-from . import weights, dist, _lib, train_ops, tf_checkpoint, text                                                  # noqa: F401
+from . import weights, dist, _lib, train_ops, tf_checkpoint, text, korean, feeder  # noqa: F401

@@ -69,13 +69,17 @@ class Synthesizer(object):
             texts = [texts]
         if texts is not None and tokens is None:
             if self.text_to_sequence is None:
+                # text/__init__.py:23-58 with the korean cleaner: normalise (numbers, units, Latin letters), decompose, append EOS
                 from .text import text_to_sequence as _t2s
-                sequences = [_t2s(text) for text in texts]
+                from .korean import KoreanNormalizer
+                if getattr(self, "normalizer", None) is None:
+                    self.normalizer = KoreanNormalizer()
+                sequences = [_t2s(text, normalizer=self.normalizer) for text in texts]
             else:
                 sequences = [self.text_to_sequence(text) for text in texts]
             if len(set(len(x) for x in sequences)) > 1:            # the reference needs equal lengths here (App. C); pad like the feeder
-                from .text import prepare_inputs
-                sequences = prepare_inputs(sequences)
+                from .text import pad_token_rows
+                sequences = pad_token_rows(sequences)
         elif tokens is not None:
             sequences = tokens
         else:

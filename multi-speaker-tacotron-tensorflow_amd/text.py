@@ -5,12 +5,10 @@
 * text_to_sequence (text/__init__.py:23-58): clean -> jamo decomposition -> ids of the symbols that exist -> EOS.  The Hangul
   decomposition is the Unicode algorithm (syllable = 0xAC00 + (lead*21 + vowel)*28 + tail), which is what the `jamo` package
   the reference imports does for precomposed syllables.
-* The reference's Korean *normaliser* (numbers, Latin letters, abbreviation dictionaries: text/korean.py:139-319,
-  ko_dictionary.py) is dictionary-driven text normalisation and stays out of scope; plug one in through `normalizer=`.
-  Characters that have no symbol are dropped, exactly as `_should_keep_symbol` does.
-* prepare_batch (datasets/datafeeder.py:289-328): inputs padded with 0 to the longest; targets padded with 0 to
-  round_up(longest + 1, reduction_factor); input_lengths = token count INCLUDING the EOS (the feeder's convention; the
-  synthesizer instead uses the index of the EOS, synthesizer.py:120)."""
+* The Korean normaliser (numbers, units, Latin letters, dictionaries: text/korean.py:139-306) lives in korean.py; pass
+  `normalizer=KoreanNormalizer(...)` to run it in front of the decomposition.  Characters that have no symbol are dropped,
+  exactly as `_should_keep_symbol` does.
+* The training batcher (padding contract, length bucketing) lives in feeder.py."""
 import re
 
 import numpy as np
@@ -90,33 +88,10 @@ def sequence_to_text(sequence, skip_eos_and_pad=False, combine_jamo=False):
     return jamo_to_korean(s) if combine_jamo else s
 
 
-# ---- the feeder's batch contract (datasets/datafeeder.py:289-328) ----
-def _round_up(x, multiple):
-    r = x % multiple
-    return x if r == 0 else x + multiple - r
-
-
-def prepare_inputs(inputs):
-    n = max(len(x) for x in inputs)
-    return np.stack([np.pad(np.asarray(x), (0, n - len(x)), mode="constant", constant_values=0) for x in inputs])
-
-
-def prepare_targets(targets, alignment):
-    n = _round_up(max(len(t) for t in targets) + 1, alignment)
-    return np.stack([np.pad(np.asarray(t), [(0, n - len(t)), (0, 0)], mode="constant", constant_values=0) for t in targets])
-
-
-def prepare_batch(batch, reduction_factor, rng=None, data_type=None):
-    """batch: list of (input ids, loss_coeff, mel_target [T,M], linear_target [T,F][, speaker_id, n_frames]) ->
-    (inputs, input_lengths, loss_coeff, mel_targets, linear_targets[, speaker_id])."""
-    batch = list(batch)
-    if data_type == "train" and rng is not None:
-        rng.shuffle(batch)
-    inputs = prepare_inputs([x[0] for x in batch]).astype(np.int32)
-    input_lengths = np.asarray([len(x[0]) for x in batch], dtype=np.int32)
-    loss_coeff = np.asarray([x[1] for x in batch], dtype=np.float32)
-    mel = prepare_targets([x[2] for x in batch], reduction_factor).astype(np.float32)
-    lin = prepare_targets([x[3] for x in batch], reduction_factor).astype(np.float32)
-    if len(batch[0]) == 6:
-        return inputs, input_lengths, loss_coeff, mel, lin, np.asarray([x[4] for x in batch], dtype=np.int32)
-    return inputs, input_lengths, loss_coeff, mel, lin
+def pad_token_rows(rows):
+    """Token rows of different lengths -> one int32 array, zero (PAD) filled on the right (what synthesize() feeds)."""
+    n = max(len(x) for x in rows)
+    out = np.zeros((len(rows), n), np.int32)
+    for i, x in enumerate(rows):
+        out[i, :len(x)] = np.asarray(x)
+    return out

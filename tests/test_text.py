@@ -37,19 +37,91 @@ def test_every_syllable_round_trips():
     assert X.jamo_to_korean(X.hangul_to_jamo(syl)) == syl
 
 
-def test_prepare_batch_contract():
+def test_collate_contract():
+    """datasets/datafeeder.py:289-328: zero padding, targets padded to a multiple of r strictly beyond the longest, lengths
+    include the EOS, optional speaker ids."""
+    from taco_amd import feeder as F
     rs = np.random.RandomState(0)
     r = 4
-    batch = []
+    ex = []
     for n_tok, n_frames in ((5, 9), (8, 12), (3, 7)):
-        batch.append((np.arange(2, 2 + n_tok, dtype=np.int32), 1.0 + n_tok, rs.rand(n_frames, 80), rs.rand(n_frames, 1025)))
-    inputs, lens, coeff, mel, lin = X.prepare_batch(batch, r)
-    assert inputs.shape == (3, 8) and inputs.dtype == np.int32 and list(lens) == [5, 8, 3]
-    assert (inputs[0, 5:] == 0).all() and (inputs[2, 3:] == 0).all()
-    assert mel.shape == (3, 16, 80) and lin.shape == (3, 16, 1025)        # round_up(12 + 1, 4) = 16: at least one padded frame
-    assert (mel[0, 9:] == 0).all() and np.array_equal(mel[1, :12], batch[1][2].astype(np.float32))
-    assert list(coeff) == [6.0, 9.0, 4.0]
-    with_spk = [b + (i, len(b[3])) for i, b in enumerate(batch)]
-    out = X.prepare_batch(with_spk, r, rng=np.random.RandomState(1), data_type="train")
-    assert len(out) == 6 and sorted(out[5]) == [0, 1, 2] and out[3].shape == (3, 16, 80)
-    assert X._round_up(12, 4) == 12 and X._round_up(13, 4) == 16
+        ex.append(F.Example(np.arange(2, 2 + n_tok, dtype=np.int32), 1.0 + n_tok, rs.rand(n_frames, 80), rs.rand(n_frames, 1025)))
+    b = F.collate(ex, r)
+    assert b.inputs.shape == (3, 8) and b.inputs.dtype == np.int32 and list(b.input_lengths) == [5, 8, 3]
+    assert (b.inputs[0, 5:] == 0).all() and (b.inputs[2, 3:] == 0).all()
+    assert b.mel_targets.shape == (3, 16, 80) and b.linear_targets.shape == (3, 16, 1025)     # 12 frames -> 16: at least one padded frame
+    assert (b.mel_targets[0, 9:] == 0).all() and np.array_equal(b.mel_targets[1, :12], ex[1].mel.astype(np.float32))
+    assert list(b.loss_coeff) == [6.0, 9.0, 4.0] and b.speaker_id is None
+    assert [F.padded_length(n, 4) for n in (11, 12, 13, 15, 16)] == [12, 16, 16, 16, 20]
+    with_spk = [e._replace(speaker_id=i) for i, e in enumerate(ex)]
+    assert list(F.collate(with_spk, r).speaker_id) == [0, 1, 2]
+    assert list(X.pad_token_rows([[2, 3], [4, 5, 6, 7]])[0]) == [2, 3, 0, 0]
+
+
+def test_length_bucketing_of_a_group():
+    """datasets/datafeeder.py:210-243: a group of batch_size x batches_per_group examples is sorted by target length, cut into
+    consecutive batches and the batches are shuffled: every batch spans a narrow band of lengths and nothing is lost."""
+    from taco_amd import feeder as F
+    rs = np.random.RandomState(1)
+    lens = rs.randint(20, 400, size=64)
+    ex = [F.Example(np.full(3 + i % 5, 2, np.int32), 1.0, np.zeros((n, 8), np.float32) + i, np.zeros((n, 4), np.float32)) for i, n in enumerate(lens)]
+    batches = F.bucket(ex, 8, np.random.RandomState(2))
+    assert len(batches) == 8 and all(len(b) == 8 for b in batches)
+    seen = sorted(int(e.mel[0, 0]) for b in batches for e in b)
+    assert seen == list(range(64))
+    spans = sorted((min(len(e.mel) for e in b), max(len(e.mel) for e in b)) for b in batches)
+    for (lo0, hi0), (lo1, hi1) in zip(spans, spans[1:]):
+        assert hi0 <= lo1                                       # the bands do not overlap: this is the sort + cut
+    assert [s for s in spans] != [(min(len(e.mel) for e in b), max(len(e.mel) for e in b)) for b in batches]   # and the batch order is shuffled
+    # the iterator: draws groups from two sources by ratio, collates with the reduction factor
+    it = iter(lens)
+    draw_a = lambda: F.Example(np.array([2, 3, 1], np.int32), 1.0, np.zeros((next(it), 8), np.float32), np.zeros((1, 4), np.float32), 0)
+    draw_b = lambda: F.Example(np.array([4, 1], np.int32), 0.5, np.zeros((33, 8), np.float32), np.zeros((33, 4), np.float32), 1)
+    fd = F.GroupFeeder({"a": draw_a, "b": draw_b}, batch_size=4, reduction_factor=5, batches_per_group=2, ratios={"a": 0.75, "b": 0.25})
+    b0 = next(fd)
+    assert b0.inputs.shape[0] == 4 and b0.mel_targets.shape[1] % 5 == 0 and fd.step == 1
+    b1 = next(fd)
+    assert sorted(list(b0.speaker_id) + list(b1.speaker_id)) == [0, 0, 0, 0, 0, 0, 1, 1]
+
+
+def test_korean_number_reading_known_answers():
+    """Hand-written readings (behaviour of text/korean.py:166-306: Sino-Korean numerals, native numerals before counters, the
+    silent leading one, decimals after 쩜, signs)."""
+    from taco_amd import korean as K
+    assert K.read_integer("7") == "칠" and K.read_integer("10") == "십" and K.read_integer("12") == "십이"
+    assert K.read_integer("100") == "백" and K.read_integer("10000") == "만" and K.read_integer("305") == "삼백오"
+    assert K.read_integer("2017") == "이천일십칠"                       # the reference keeps 일 in front of an inner 십
+    assert K.read_integer("1234567") == "백이십삼만사천오백육십칠"
+    assert K.read_integer("5", native=True) == "다섯" and K.read_integer("12", native=True) == "열두"
+    assert K.read_integer("19", native=True) == "열아홉" and K.read_integer("20", native=True) == "스물"
+    assert K.read_integer("24", native=True) == "스물네" and K.read_integer("55", native=True) == "쉰다섯"
+    assert K.read_integer("99", native=True) == "아흔아홉" and K.read_integer("101", native=True) == "백한"
+    assert K.read_number("-12.35") == "마이너스 십이쩜 삼오" and K.read_number("+3") == "플러스 삼"
+    assert K.read_number("0") == "영" and K.read_number("0", "개") == "영" and K.read_number("1,000") == "천"
+    assert K.read_number("24", "살") == "스물네살" and K.read_number("12", "시") == "열두시"
+    with pytest.raises(K.NumberFormatError):
+        K.read_number("1.2.3")
+
+
+def test_korean_normaliser_sentences():
+    """The sentences the reference's own __main__ exercises (text/korean.py:308-319), with readings worked out by hand."""
+    from taco_amd import korean as K
+    n = K.KoreanNormalizer(english={"track": "트랙"}, phrases={"1+1": "원플러스원"})
+    assert n("JTBC는 JTBCs를 DY는 A가 Absolute") == "제이티비씨는 JTBCs를 디와이는 에이가 Absolute"
+    assert n("오늘(13일) 101마리 강아지가") == "오늘 백한마리 강아지가"
+    assert n('"저돌"(猪突) 입니다.') == "'저돌' 입니다."
+    assert n("지금은 -12.35%였고 종류는 5가지와 19가지, 그리고 55가지였다") == \
+        "지금은 마이너스 십이쩜 삼오퍼센트였고 종류는 다섯가지와 열아홉가지, 그리고 쉰다섯가지였다"
+    assert n("JTBC는 TH와 K 양이 2017년 9월 12일 오후 12시에 24살이 된다") == \
+        "제이티비씨는 티에이치와 케이 양이 이천일십칠년 구월 십이일 오후 열두시에 스물네살이 된다"
+    assert n("“첫 문장이다. 둘째 문장이다!”") == "'첫 문장이다.' '둘째 문장이다!'"
+    assert n("  1+1 행사의 track 5km, 100m  ") == "원플러스원 행사의 트랙 오킬로미터, 백미터"
+    # through the tokeniser: ids of the 80-symbol table, EOS last
+    ids = X.text_to_sequence("24살", normalizer=n)
+    assert X.sequence_to_text(ids, skip_eos_and_pad=True, combine_jamo=True) == "스물네살"
+    assert K.tokenize("A", as_id=True)[-1] == EOS_ID and K.tokenize("12시")[-1] == "~"
+    import json, tempfile, os
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "dict.json")
+        json.dump({"english": {"idol": "아이돌"}, "phrases": {}}, open(p, "w", encoding="utf-8"))
+        assert K.load_dictionaries(p)("idol LG") == "아이돌 엘지"
