@@ -11,8 +11,13 @@ Variable names are matched by their stable suffixes and by SHAPE, not by the ful
 differ between TF 1.x versions.  Weight layouts need no conversion: the canonical pack already uses TF's
 (dense [in,out]; conv1d [k,in,out]; GRUCell gates [in+n, 2n] with columns r|u and rows [x;h]).
 
+Multi-shard bundles, prefix-compressed keys with any restart interval / block size, and partitioned variables (slices keyed by
+the ordered-code EncodeTensorNameSlice form) are read; Adam slots are skipped unread by the importer; CRCs are verified with a
+vectorised crc32c.
+
 UNPINNED: no checkpoint written by real TensorFlow exists in this environment; the reader is tested against bundles
-produced by `write_checkpoint` below, which follows the same format description."""
+produced by `write_checkpoint` below, which follows the same format description, over fuzzed layouts.  tools/tf1_dump_fixture.py
+(`prepare` + `run` on a TensorFlow 1.x box) restores a bundle written here with tf.train.Saver: that run is the pin."""
 import os
 import re
 import struct
@@ -20,6 +25,7 @@ import struct
 import numpy as np
 
 _MAGIC = 0xdb4775248b80fb57
+SLICES = "\0slices"        # key of read_index()'s dict under which the slice entries of partitioned variables are kept
 _DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 4: np.uint8, 6: np.int8, 5: np.int16, 10: np.bool_, 19: np.float16}
 _DTYPE_IDS = {np.dtype(v).name: k for k, v in _DTYPES.items()}
 
@@ -38,11 +44,77 @@ def _crc_table():
 _CRC = _crc_table()
 
 
-def crc32c(data, crc=0):
+def _crc_bytes(data, crc=0):
     c = crc ^ 0xFFFFFFFF
     for b in data:
         c = _CRC[(c ^ b) & 0xFF] ^ (c >> 8)
     return c ^ 0xFFFFFFFF
+
+
+# crc(A || B) = shift(crc(A), len(B)) ^ crc(B): the zero-byte operator as a 32x32 matrix over GF(2) (the zlib construction)
+def _gf2_times(mat, vec):
+    out, i = 0, 0
+    while vec:
+        if vec & 1:
+            out ^= mat[i]
+        vec >>= 1
+        i += 1
+    return out
+
+
+def _gf2_square(mat):
+    return [_gf2_times(mat, mat[i]) for i in range(32)]
+
+
+def _zero_operator(nbytes):
+    """matrix that advances a finalised crc32c over `nbytes` zero bytes"""
+    odd = [0x82F63B78] + [1 << (i - 1) for i in range(1, 32)]      # one zero BIT
+    even = _gf2_square(odd)                                         # two bits
+    odd = _gf2_square(even)                                         # four bits
+    result = None
+    n = nbytes
+    while n:
+        even = _gf2_square(odd)                                     # first pass: one zero byte
+        if n & 1:
+            result = even if result is None else [_gf2_times(even, r) for r in result]
+        n >>= 1
+        if not n:
+            break
+        odd = _gf2_square(even)
+        if n & 1:
+            result = odd if result is None else [_gf2_times(odd, r) for r in result]
+        n >>= 1
+    return result
+
+
+_CHUNK = 4096
+_CRC_NP = np.array(_CRC, dtype=np.uint32)
+_OP_CACHE = {}
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli).  Long buffers are cut into 4 KB chunks whose CRCs advance in lock step (one NumPy operation per byte
+    position over all chunks) and are then folded with the zero-byte operator: a 110 MB checkpoint verifies in about a second
+    instead of minutes of per-byte interpreter work."""
+    data = bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data
+    n = len(data)
+    if n < 4 * _CHUNK:
+        return _crc_bytes(data, crc)
+    nfull = n // _CHUNK
+    a = np.frombuffer(data, dtype=np.uint8, count=nfull * _CHUNK).reshape(nfull, _CHUNK)
+    st = np.full(nfull, 0xFFFFFFFF, dtype=np.uint32)
+    for j in range(_CHUNK):
+        st = _CRC_NP[(st ^ a[:, j]) & 0xFF] ^ (st >> 8)
+    part = (st ^ 0xFFFFFFFF).tolist()
+    if _CHUNK not in _OP_CACHE:
+        _OP_CACHE[_CHUNK] = _zero_operator(_CHUNK)
+    op = _OP_CACHE[_CHUNK]
+    # fold: the running value first absorbs `crc` (the CRC of what came before), then every chunk
+    total = crc
+    for i, pc in enumerate(part):
+        total = _gf2_times(op, total) ^ pc if (i or crc) else pc
+    tail = data[nfull * _CHUNK:]
+    return _crc_bytes(tail, total) if len(tail) else total
 
 
 def _mask(crc):
@@ -94,7 +166,7 @@ def _pb_fields(buf):
 
 
 def _parse_entry(buf):
-    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    e = dict(dtype=0, shape=[], shard_id=0, offset=0, size=0, crc32c=None, sliced=False, slices=[])
     for fn, wt, v in _pb_fields(buf):
         if fn == 1:
             e["dtype"] = v
@@ -114,9 +186,56 @@ def _parse_entry(buf):
             e["size"] = v
         elif fn == 6:
             e["crc32c"] = struct.unpack("<I", v)[0]
-        elif fn == 7:
+        elif fn == 7:                       # TensorSliceProto { repeated Extent extent = 1 { start = 1; length = 2 } }
             e["sliced"] = True
+            ext = []
+            for f2, _, v2 in _pb_fields(v):
+                if f2 == 1:
+                    start, length = 0, -1       # no length = the full extent of that dimension
+                    for f3, _, v3 in _pb_fields(v2):
+                        if f3 == 1:
+                            start = v3
+                        elif f3 == 2:
+                            length = v3
+                    ext.append((start, length))
+            e["slices"].append(ext)
     return e
+
+
+# ---- keys of the slices of a partitioned variable (tensorflow/core/util/saved_tensor_slice_util: EncodeTensorNameSlice over
+# tensorflow/core/lib/strings/ordered_code) ----
+def _oc_num_increasing(v):
+    b = b"" if v == 0 else int(v).to_bytes((int(v).bit_length() + 7) // 8, "big")
+    return bytes([len(b)]) + b
+
+
+def _oc_string(sb):
+    out = bytearray()
+    for b in sb:
+        out += b"\x00\xff" if b == 0 else (b"\xff\x00" if b == 0xFF else bytes([b]))
+    return bytes(out) + b"\x00\x01"
+
+
+_OC_HEADER = [(0, 0), (0x80, 0), (0xc0, 0), (0xe0, 0), (0xf0, 0), (0xf8, 0), (0xfc, 0), (0xfe, 0), (0xff, 0), (0xff, 0x80), (0xff, 0xc0)]
+
+
+def _oc_signed_increasing(val):
+    x = ~val if val < 0 else val
+    if x < 64:
+        return bytes([(0x80 ^ val) & 0xFF])
+    buf = bytearray((b"\xff\xff" if val < 0 else b"\x00\x00") + (val & 0xFFFFFFFFFFFFFFFF).to_bytes(8, "big"))
+    n = (x.bit_length() + 7) // 7
+    out = buf[len(buf) - n:]
+    out[0] ^= _OC_HEADER[n][0]
+    out[1] ^= _OC_HEADER[n][1]
+    return bytes(out)
+
+
+def slice_key(name, extents):
+    k = _oc_num_increasing(0) + _oc_string(name.encode("utf-8")) + _oc_num_increasing(len(extents))
+    for start, length in extents:
+        k += _oc_signed_increasing(start) + _oc_signed_increasing(length)
+    return k
 
 
 # ---- LevelDB table ----
@@ -160,37 +279,70 @@ def read_index(path, verify=True):
         boff, p2 = _varint(handle, 0)
         bsz, _ = _varint(handle, p2)
         for key, val in _block_entries(_read_block(buf, boff, bsz, verify)):
-            out[key.decode("utf-8")] = val if key == b"" else _parse_entry(val)
+            if key == b"":
+                out[""] = val
+            elif key[:1] == b"\x00":                        # a slice of a partitioned variable (binary ordered-code key)
+                out.setdefault(SLICES, {})[bytes(key)] = _parse_entry(val)
+            else:
+                out[key.decode("utf-8")] = _parse_entry(val)
     return out
 
 
-def read_checkpoint(prefix, verify=True, names=None):
-    """All (or the named) tensors of the bundle `<prefix>.index` + `<prefix>.data-*` as {name: ndarray}."""
+def is_optimizer_slot(name):
+    """Adam's m / v slots and the beta-power accumulators: three quarters of a training checkpoint, nothing a forward needs."""
+    return name.endswith(("/Adam", "/Adam_1")) or name in ("beta1_power", "beta2_power") or name.startswith(("beta1_power", "beta2_power"))
+
+
+def read_checkpoint(prefix, verify=True, names=None, skip=None):
+    """All (or the named) tensors of the bundle `<prefix>.index` + `<prefix>.data-*` as {name: ndarray}.  `skip(name)` true:
+    the variable is neither read nor checksummed.  Partitioned variables are reassembled from their slices."""
     idx = read_index(prefix + ".index", verify)
     nshards = 1
     for fn, _, v in _pb_fields(idx.get("", b"")):
         if fn == 1:
             nshards = v
     shards = {}
-    out = {}
-    for name, e in idx.items():
-        if name == "" or (names is not None and name not in names):
-            continue
-        if e["sliced"]:
-            raise IOError("variable '%s' is stored in slices (partitioned variable): not supported" % name)
-        if e["dtype"] not in _DTYPES:
-            continue                                   # strings etc.: nothing the model needs
+
+    def fetch(e, what):
         sid = e["shard_id"]
+        if sid >= nshards:
+            raise IOError("%s: shard %d of a %d-shard checkpoint" % (what, sid, nshards))
         if sid not in shards:
             shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, nshards), "rb")
         f = shards[sid]
         f.seek(e["offset"])
         raw = f.read(e["size"])
+        if len(raw) != e["size"]:
+            raise IOError("%s: data shard %d is truncated" % (what, sid))
         if verify and e["crc32c"] is not None and _mask(crc32c(raw)) != e["crc32c"]:
-            raise IOError("variable '%s': data checksum mismatch" % name)
-        out[name] = np.frombuffer(raw, dtype=np.dtype(_DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"]).copy()
-    for f in shards.values():
-        f.close()
+            raise IOError("%s: data checksum mismatch" % what)
+        return np.frombuffer(raw, dtype=np.dtype(_DTYPES[e["dtype"]]).newbyteorder("<")).reshape(e["shape"])
+
+    out = {}
+    try:
+        for name, e in idx.items():
+            if name in ("", SLICES) or (names is not None and name not in names) or (skip is not None and skip(name)):
+                continue
+            if e["dtype"] not in _DTYPES:
+                continue                                   # strings etc.: nothing the model needs
+            if not e["sliced"]:
+                out[name] = fetch(e, "variable '%s'" % name).copy()
+                continue
+            full = np.zeros(e["shape"], dtype=_DTYPES[e["dtype"]])
+            covered = np.zeros(e["shape"], dtype=bool)
+            for ext in e["slices"]:
+                se = idx.get(SLICES, {}).get(slice_key(name, ext))
+                if se is None:
+                    raise IOError("variable '%s': slice %s is listed but not stored" % (name, ext))
+                where = tuple(slice(st, None if ln < 0 else st + ln) for st, ln in ext)
+                full[where] = fetch(se, "variable '%s' slice %s" % (name, ext))
+                covered[where] = True
+            if not covered.all():
+                raise IOError("variable '%s': its slices do not cover the full shape %s" % (name, e["shape"]))
+            out[name] = full
+    finally:
+        for f in shards.values():
+            f.close()
     return out
 
 
@@ -205,33 +357,77 @@ def latest_checkpoint(directory):
 
 
 # ---- writer (tests, and exporting weights trained here for the reference to load) ----
-def _block(entries):
-    body = bytearray()
-    for key, val in entries:
-        body += _put_varint(0) + _put_varint(len(key)) + _put_varint(len(val)) + key + val
-    body += struct.pack("<I", 0) + struct.pack("<I", 1)        # one restart point at offset 0
+def _block(entries, restart_interval=16):
+    """LevelDB data block: entries share key prefixes with their predecessor inside a restart interval."""
+    body, restarts, prev = bytearray(), [], b""
+    for i, (key, val) in enumerate(entries):
+        shared = 0
+        if restart_interval > 0 and i % restart_interval:
+            while shared < min(len(key), len(prev)) and key[shared] == prev[shared]:
+                shared += 1
+        else:
+            restarts.append(len(body))
+        body += _put_varint(shared) + _put_varint(len(key) - shared) + _put_varint(len(val)) + key[shared:] + val
+        prev = key
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        body += struct.pack("<I", r)
+    body += struct.pack("<I", len(restarts))
     return bytes(body)
 
 
-def _entry_proto(dtype_id, shape, offset, size, crc):
+def _entry_proto(dtype_id, shape, shard, offset, size, crc, slices=None):
     dims = b"".join(b"\x12" + _put_varint(len(d)) + d for d in (b"\x08" + _put_varint(int(s)) for s in shape))
     msg = b"\x08" + _put_varint(dtype_id) + b"\x12" + _put_varint(len(dims)) + dims
+    if slices is not None:                                   # the full-tensor entry of a partitioned variable: slice specs only
+        for ext in slices:
+            body = b""
+            for start, length in ext:
+                e = (b"\x08" + _put_varint(start) if start else b"") + (b"\x10" + _put_varint(length) if length >= 0 else b"")
+                body += b"\x0a" + _put_varint(len(e)) + e
+            msg += b"\x3a" + _put_varint(len(body)) + body
+        return msg
+    if shard:
+        msg += b"\x18" + _put_varint(shard)
     msg += b"\x20" + _put_varint(offset) + b"\x28" + _put_varint(size) + b"\x35" + struct.pack("<I", crc)
     return msg
 
 
-def write_checkpoint(prefix, tensors):
-    """Writes {name: array} as a single-shard V2 bundle (uncompressed table, one data block per 64 entries)."""
-    names = sorted(tensors)
-    data = bytearray()
-    entries = [(b"", b"\x08\x01\x1a\x02\x08\x01")]               # header: num_shards = 1, version { producer: 1 }
-    for n in names:
-        a = np.array(tensors[n], order="C")          # (ascontiguousarray would turn 0-d into 1-d)
+def write_checkpoint(prefix, tensors, num_shards=1, block_bytes=4096, restart_interval=16, partition=None):
+    """Writes {name: array} as a V2 bundle: `num_shards` data files (variables dealt round robin), an uncompressed LevelDB table
+    with ~block_bytes data blocks and prefix-compressed keys.  partition = {name: n}: store that variable as n slices along its
+    first axis, the way a partitioned tf variable is saved."""
+    partition = partition or {}
+    data = [bytearray() for _ in range(num_shards)]
+    entries = [(b"", b"\x08" + _put_varint(num_shards) + b"\x1a\x02\x08\x01")]     # header: num_shards, version { producer: 1 }
+    turn = [0]
+
+    def store(a):
+        sid = turn[0] % num_shards
+        turn[0] += 1
         raw = a.astype(a.dtype.newbyteorder("<")).tobytes()
-        entries.append((n.encode("utf-8"), _entry_proto(_DTYPE_IDS[a.dtype.name], a.shape, len(data), len(raw), _mask(crc32c(raw)))))
-        data += raw
-    with open(prefix + ".data-00000-of-00001", "wb") as f:
-        f.write(bytes(data))
+        off = len(data[sid])
+        data[sid] += raw
+        return sid, off, len(raw), _mask(crc32c(raw))
+
+    for n in sorted(tensors):
+        a = np.array(tensors[n], order="C")          # (ascontiguousarray would turn 0-d into 1-d)
+        did = _DTYPE_IDS[a.dtype.name]
+        parts = int(partition.get(n, 0))
+        if parts > 1 and a.ndim >= 1 and a.shape[0] >= parts:
+            edges = np.linspace(0, a.shape[0], parts + 1).astype(int)
+            specs = [[(int(edges[i]), int(edges[i + 1] - edges[i]))] + [(0, -1)] * (a.ndim - 1) for i in range(parts)]
+            entries.append((n.encode("utf-8"), _entry_proto(did, a.shape, 0, 0, 0, 0, slices=specs)))
+            for i, ext in enumerate(specs):
+                piece = np.ascontiguousarray(a[edges[i]:edges[i + 1]])
+                entries.append((slice_key(n, ext), _entry_proto(did, piece.shape, *store(piece))))
+        else:
+            entries.append((n.encode("utf-8"), _entry_proto(did, a.shape, *store(a))))
+    entries.sort(key=lambda kv: kv[0])
+    for sid in range(num_shards):
+        with open("%s.data-%05d-of-%05d" % (prefix, sid, num_shards), "wb") as f:
+            f.write(bytes(data[sid]))
     out = bytearray()
     index_entries = []
 
@@ -241,11 +437,17 @@ def write_checkpoint(prefix, tensors):
         out.extend(block + trailer + struct.pack("<I", _mask(crc32c(block + trailer))))
         return _put_varint(off) + _put_varint(len(block))
 
-    for i in range(0, len(entries), 64):
-        chunk = entries[i:i + 64]
-        index_entries.append((chunk[-1][0] + b"\x00", put(_block(chunk))))     # separator >= last key of the block
+    chunk, size = [], 0
+    for kv in entries:
+        chunk.append(kv)
+        size += len(kv[0]) + len(kv[1]) + 3
+        if size >= block_bytes:
+            index_entries.append((chunk[-1][0], put(_block(chunk, restart_interval))))     # separator = last key of the block
+            chunk, size = [], 0
+    if chunk:
+        index_entries.append((chunk[-1][0], put(_block(chunk, restart_interval))))
     meta = put(_block([]))
-    index = put(_block(index_entries))
+    index = put(_block(index_entries, 1))
     footer = meta + index
     footer += b"\x00" * (40 - len(footer)) + struct.pack("<Q", _MAGIC)
     out.extend(footer)
@@ -341,7 +543,7 @@ def import_tf_checkpoint(prefix_or_dir, hparams, num_speakers=1, verify=True):
         prefix = latest_checkpoint(prefix_or_dir)
         if prefix is None:
             raise IOError("no model.ckpt-<step>.index under %s" % prefix_or_dir)
-    return map_tf_names(read_checkpoint(prefix, verify), weight_spec(hparams, num_speakers))
+    return map_tf_names(read_checkpoint(prefix, verify, skip=is_optimizer_slot), weight_spec(hparams, num_speakers))
 
 
 def tf_names_for(spec, attention_type="bah_mon"):
@@ -396,9 +598,9 @@ def tf_names_for(spec, attention_type="bah_mon"):
     return out
 
 
-def export_tf_checkpoint(prefix, weights, spec, attention_type="bah_mon", global_step=0):
+def export_tf_checkpoint(prefix, weights, spec, attention_type="bah_mon", global_step=0, num_shards=1):
     """Writes canonical weights as a bundle with the reference's variable names (for `saver.restore` on the TF side)."""
     names = tf_names_for(spec, attention_type)
     tensors = {names[n]: np.asarray(weights[n], np.float32) for n, _ in spec}
     tensors["global_step"] = np.asarray(global_step, np.int32)
-    write_checkpoint(prefix, tensors)
+    write_checkpoint(prefix, tensors, num_shards=num_shards)

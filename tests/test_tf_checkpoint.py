@@ -100,3 +100,95 @@ def test_missing_variable_is_reported(tmp_path):
     with pytest.raises(KeyError) as e:
         T.map_tf_names(tensors, spec)
     assert "attention/attention_v" in str(e.value)
+
+
+def test_crc32c_vectorised_path_equals_the_bytewise_one():
+    """Buffers above 16 KB take the chunked path (4 KB chunks advanced in lock step, folded with the zero-byte operator)."""
+    rs = np.random.RandomState(7)
+    for n in (16384, 16385, 40000, 123457, 1 << 20):
+        d = rs.bytes(n)
+        assert T.crc32c(d) == T._crc_bytes(d), n
+        assert T.crc32c(d, 0xDEADBEEF) == T._crc_bytes(d, 0xDEADBEEF), n        # continuation of an earlier CRC
+
+
+def test_ordered_code_keys_known_answers():
+    """tensorflow/core/lib/strings/ordered_code: the encodings the slice keys of partitioned variables are built from."""
+    sgn = lambda v: T._oc_signed_increasing(v).hex()
+    assert [sgn(v) for v in (0, 1, 63, -1, -64)] == ["80", "81", "bf", "7f", "40"]
+    assert [sgn(v) for v in (64, 300, -65, 8191, 8192)] == ["c040", "c12c", "3fbf", "dfff", "e02000"]
+    assert T._oc_num_increasing(0).hex() == "00" and T._oc_num_increasing(300).hex() == "02012c"
+    assert T._oc_string(b"a\x00b\xffc") == b"a\x00\xffb\xff\x00c\x00\x01"
+    assert T.slice_key("v", [(0, 64), (0, -1)]) == b"\x00" + b"v\x00\x01" + b"\x01\x02" + bytes.fromhex("80c040807f")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzzed_bundle_layouts(tmp_path, seed):
+    """Shard counts, data-block sizes (down to one entry per block), restart intervals (prefix compression on / off) and
+    partitioned variables, drawn at random: everything written must read back bit-exact, Adam slots must be skippable unread."""
+    rs = np.random.RandomState(100 + seed)
+    tensors = {}
+    for i in range(int(rs.randint(5, 60))):
+        nd = int(rs.randint(0, 4))
+        shape = tuple(int(x) for x in rs.randint(1, 9, size=nd))
+        name = "model/inference/%s/layer_%d/%s" % (rs.choice(["encoder_cbhg", "post_cbhg", "decoder"]), i % 7, rs.choice(["kernel", "bias", "gamma"]))
+        tensors[name + ("" if name not in tensors else "_%d" % i)] = np.asarray(rs.randn(*shape), np.float32)
+    big = "model/inference/embedding"
+    tensors[big] = rs.randn(int(rs.randint(8, 200)), 5).astype(np.float32)
+    tensors[big + "/Adam"] = np.zeros_like(tensors[big]); tensors[big + "/Adam_1"] = np.ones_like(tensors[big])
+    tensors["global_step"] = np.asarray(int(rs.randint(0, 1 << 20)), np.int32)
+    prefix = str(tmp_path / "model.ckpt-7")
+    ns, bb, ri = int(rs.randint(1, 6)), int(rs.choice([1, 40, 200, 4096, 1 << 16])), int(rs.choice([0, 1, 2, 16]))
+    part = {big: int(rs.randint(2, 6))} if seed % 2 else None
+    T.write_checkpoint(prefix, tensors, num_shards=ns, block_bytes=bb, restart_interval=ri, partition=part)
+    assert len([f for f in os.listdir(str(tmp_path)) if ".data-" in f]) == ns
+    got = T.read_checkpoint(prefix)
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    lean = T.read_checkpoint(prefix, skip=T.is_optimizer_slot)
+    assert set(lean) == {k for k in tensors if not k.endswith(("/Adam", "/Adam_1"))}
+    # a slot's bytes may be damaged without the importer noticing or caring: it never reads them
+    idx = T.read_index(prefix + ".index")
+    e = idx[big + "/Adam"]
+    if not e["sliced"] and e["size"]:
+        fn = "%s.data-%05d-of-%05d" % (prefix, e["shard_id"], ns)
+        raw = bytearray(open(fn, "rb").read()); raw[e["offset"]] ^= 0xFF
+        open(fn, "wb").write(bytes(raw))
+        T.read_checkpoint(prefix, skip=T.is_optimizer_slot)
+        with pytest.raises(IOError):
+            T.read_checkpoint(prefix)
+
+
+def test_partitioned_variable_with_a_missing_slice_is_an_error(tmp_path):
+    prefix = str(tmp_path / "model.ckpt-1")
+    T.write_checkpoint(prefix, {"v": np.arange(24, dtype=np.float32).reshape(6, 4)}, partition={"v": 3})
+    assert np.array_equal(T.read_checkpoint(prefix)["v"], np.arange(24, dtype=np.float32).reshape(6, 4))
+    idx = T.read_index(prefix + ".index")
+    assert idx["v"]["sliced"] and len(idx["v"]["slices"]) == 3 and len(idx[T.SLICES]) == 3
+
+
+def test_tf1_fixture_dumper_prepare_and_compare_stages(tmp_path):
+    """tools/tf1_dump_fixture.py: `prepare` turns the committed fixture into params.json + a reference-named checkpoint that the
+    importer maps back bit-exactly; `compare` accepts outputs equal to the oracle's and rejects perturbed ones.  (`run` needs
+    TensorFlow 1.x and the reference checkout: it is the part that executes elsewhere.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "tf1_dump_fixture.py")
+    fixture = os.path.join(root, "tests", "golden", "tiny_forward.npz")
+    work = str(tmp_path / "work")
+    r = subprocess.run([sys.executable, tool, "prepare", fixture, work, "--shards", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert os.path.exists(os.path.join(work, "params.json")) and os.path.exists(os.path.join(work, "model.ckpt-0.data-00001-of-00002"))
+    g = np.load(fixture)
+    from golden.make_golden import fixture_config
+    ohp, _, _, _, _, ns = fixture_config()
+    got = T.import_tf_checkpoint(work, to_product_hp(ohp), ns)
+    for k in got:
+        assert np.array_equal(got[k], np.asarray(g["w:" + k], np.float32)), k
+    np.savez(os.path.join(work, "tf1_outputs.npz"), linear=g["linear"], mel=g["mel"], alignments=g["alignments"], tf_version="1.4.0", n_variables=0)
+    r = subprocess.run([sys.executable, tool, "compare", fixture, work], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PINNED" in r.stdout, r.stdout + r.stderr
+    np.savez(os.path.join(work, "tf1_outputs.npz"), linear=g["linear"] + 0.01, mel=g["mel"], alignments=g["alignments"], tf_version="1.4.0", n_variables=0)
+    r = subprocess.run([sys.executable, tool, "compare", fixture, work], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "MISMATCH" in r.stdout

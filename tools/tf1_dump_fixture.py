@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""The turnkey half of pinning the oracle against TensorFlow itself.
+
+TF 1.x cannot be installed where this repository is built, and the reference ships no vectors; this script is what a box that
+HAS TensorFlow 1.3/1.4 and a checkout of GSByeon/multi-speaker-tacotron-tensorflow runs to produce reference outputs for the
+committed fixtures.  Nothing of the reference is copied: it is imported from the path given on the command line.
+
+Three stages (each is a sub-command; `prepare` and `compare` need only this repository and NumPy):
+
+  prepare  <fixture.npz> <workdir>
+           Turns a fixture (inputs + canonical weights, e.g. tests/golden/tiny_forward.npz, or --full-width for a freshly
+           generated reference-width case) into what the reference loads with its own code:
+             <workdir>/params.json          hyper-parameters in the reference's schema (utils/__init__.py:110-126 load_hparams)
+             <workdir>/model.ckpt-0.*       a V2 checkpoint with the reference's variable names (tf_checkpoint.export_tf_checkpoint)
+             <workdir>/inputs.npz           inputs, input_lengths, speaker_id, num_speakers
+           Restoring that checkpoint with tf.train.Saver is at the same time the test of tf_checkpoint's writer and name map
+           against real TensorFlow.
+
+  run      --reference /path/to/multi-speaker-tacotron-tensorflow <workdir>            (needs TensorFlow 1.x)
+           Builds the reference graph exactly as synthesizer.py:28-67 does (create_model(hparams).initialize(inputs, input_lengths,
+           num_speakers, speaker_id) under variable_scope('model')), restores the checkpoint, runs
+           [linear_outputs, mel_outputs, alignments] (synthesizer.py:122-126,166-167) and writes <workdir>/tf1_outputs.npz.
+
+  compare  <fixture.npz> <workdir> [--tol 1e-3]
+           Max-abs differences of tf1_outputs.npz against the oracle outputs stored in the fixture and the alignment-argmax check;
+           exit status 1 beyond the tolerance.  A green compare is the pin; copy tf1_outputs.npz next to the fixture as
+           tests/golden/<name>.tf1.npz and tests/test_oracle.py picks it up."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_fixture(path):
+    g = np.load(path, allow_pickle=False)
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
+    meta = json.loads(str(g["meta"])) if "meta" in g.files else None
+    return g, w, meta
+
+
+def _fixture_hparams(name_or_meta):
+    """OracleHParams of a committed fixture (tiny_forward: tests/golden/make_golden.py) or from the fixture's own meta record."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import taco_oracle as O
+    if isinstance(name_or_meta, dict):
+        return O.OracleHParams(**name_or_meta["hparams"]), int(name_or_meta["num_speakers"])
+    from golden.make_golden import fixture_config
+    hp, _, _, _, _, ns = fixture_config()
+    return hp, ns
+
+
+def make_full_width_fixture(path, seed=20260927):
+    """A reference-width case small enough for a CPU: B=2, T_in=24 (ragged), 8 decoder steps, single speaker, bah_mon."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
+    import taco_oracle as O
+    hp = O.OracleHParams(max_iters=8)
+    w = O.init_weights(hp, 1, seed)
+    ids, L = O.synthetic_inputs(2, 24, seed + 1, ragged=True)
+    out = O.forward(w, hp, ids, L)
+    meta = {"hparams": hp.to_dict(), "num_speakers": 1}
+    np.savez_compressed(path, inputs=ids, input_lengths=L, speaker_id=np.zeros(2, np.int32), mel=out["mel"], linear=out["linear"],
+                        alignments=out["alignments"], meta=json.dumps(meta), **{"w:" + k: v for k, v in w.items()})
+    return path
+
+
+def prepare(args):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import taco_amd
+    from taco_amd import tf_checkpoint as T
+    if args.full_width:
+        make_full_width_fixture(args.fixture)
+    g, w, meta = _load_fixture(args.fixture)
+    ohp, ns = _fixture_hparams(meta if meta is not None else os.path.basename(args.fixture))
+    hp = taco_amd.HParams(**ohp.to_dict())
+    os.makedirs(args.workdir, exist_ok=True)
+    taco_amd.save_hparams(args.workdir, hp)
+    spec = taco_amd.weights.weight_spec(hp, ns)
+    T.export_tf_checkpoint(os.path.join(args.workdir, "model.ckpt-0"), w, spec, hp.attention_type, 0, num_shards=args.shards)
+    with open(os.path.join(args.workdir, "checkpoint"), "w") as f:          # what tf.train.latest_checkpoint reads
+        f.write('model_checkpoint_path: "model.ckpt-0"\nall_model_checkpoint_paths: "model.ckpt-0"\n')
+    np.savez(os.path.join(args.workdir, "inputs.npz"), inputs=g["inputs"], input_lengths=g["input_lengths"],
+             speaker_id=g["speaker_id"] if "speaker_id" in g.files else np.zeros(len(g["inputs"]), np.int32), num_speakers=ns)
+    print("prepared %s: params.json, model.ckpt-0 (%d variables, %d shard(s)), inputs.npz" % (args.workdir, len(spec), args.shards))
+
+
+def run(args):
+    ref = os.path.abspath(args.reference)
+    if not os.path.isfile(os.path.join(ref, "models", "tacotron.py")):
+        sys.exit("%s does not look like a checkout of the reference (models/tacotron.py missing)" % ref)
+    sys.path.insert(0, ref)
+    import tensorflow as tf                                  # TensorFlow 1.x (requirements.txt of the reference: 1.3.0)
+    if int(tf.__version__.split(".")[0]) != 1:
+        sys.exit("TensorFlow 1.x is required (found %s): the reference uses tf.contrib.seq2seq / tf.contrib.rnn" % tf.__version__)
+    from hparams import hparams                              # the reference's modules, imported from its own tree
+    from models import create_model
+    from utils import load_hparams
+    d = np.load(os.path.join(args.workdir, "inputs.npz"))
+    ns = int(d["num_speakers"])
+    load_hparams(hparams, args.workdir)
+    inputs = tf.placeholder(tf.int32, [None, None], "inputs")
+    input_lengths = tf.placeholder(tf.int32, [None], "input_lengths")
+    speaker_id = tf.placeholder_with_default(tf.zeros([tf.shape(inputs)[0]], dtype=tf.int32), [None], "speaker_id")
+    with tf.variable_scope("model"):
+        model = create_model(hparams)
+        model.initialize(inputs, input_lengths, ns, speaker_id)
+    cfg = tf.ConfigProto(allow_soft_placement=True, intra_op_parallelism_threads=1, inter_op_parallelism_threads=2)
+    with tf.Session(config=cfg) as sess:
+        sess.run(tf.global_variables_initializer())
+        names = sorted(v.name for v in tf.global_variables())
+        with open(os.path.join(args.workdir, "tf1_variables.txt"), "w") as f:
+            f.write("\n".join("%s %s" % (v.name, v.shape.as_list()) for v in tf.global_variables()) + "\n")
+        tf.train.Saver().restore(sess, os.path.join(args.workdir, "model.ckpt-0"))
+        feed = {model.inputs: d["inputs"], model.input_lengths: d["input_lengths"]}
+        if ns > 1:
+            feed[model.speaker_id] = d["speaker_id"]
+        feed.update(model.get_dummy_feed_dict())
+        lin, mel, ali = sess.run([model.linear_outputs, model.mel_outputs, model.alignments], feed_dict=feed)
+    np.savez_compressed(os.path.join(args.workdir, "tf1_outputs.npz"), linear=lin, mel=mel, alignments=ali,
+                        tf_version=str(tf.__version__), n_variables=len(names))
+    print("wrote %s (TensorFlow %s, %d variables restored)" % (os.path.join(args.workdir, "tf1_outputs.npz"), tf.__version__, len(names)))
+
+
+def compare(args):
+    g, _, _ = _load_fixture(args.fixture)
+    t = np.load(os.path.join(args.workdir, "tf1_outputs.npz"))
+    ok = True
+    for k in ("mel", "linear", "alignments"):
+        a, b = np.asarray(t[k], np.float64), np.asarray(g[k], np.float64)
+        n = min(a.shape[1], b.shape[1]) if k != "alignments" else None     # TF stops at the stop rule as the oracle does; guard anyway
+        if k != "alignments" and a.shape != b.shape:
+            print("%s: shapes differ TF %s vs oracle %s (comparing the common %d frames)" % (k, a.shape, b.shape, n))
+            a, b = a[:, :n], b[:, :n]
+        elif a.shape != b.shape:
+            m = min(a.shape[2], b.shape[2])
+            a, b = a[:, :, :m], b[:, :, :m]
+        err = float(np.abs(a - b).max())
+        print("%-10s max|TF1 - oracle| = %.3e %s" % (k, err, "" if err < args.tol else "  <-- beyond %g" % args.tol))
+        ok = ok and err < args.tol
+    a, b = t["alignments"], g["alignments"]
+    m = min(a.shape[2], b.shape[2])
+    sel = b[:, :, :m].max(1) > 1e-6
+    same = (a[:, :, :m].argmax(1) == b[:, :, :m].argmax(1)) | ~sel
+    print("alignment argmax identical at %d of %d compared steps" % (int((same & sel).sum()), int(sel.sum())))
+    ok = ok and bool(same.all())
+    print("PINNED: the oracle reproduces TensorFlow %s on this fixture" % str(t["tf_version"]) if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    p = sub.add_parser("prepare"); p.add_argument("fixture"); p.add_argument("workdir")
+    p.add_argument("--full-width", action="store_true", help="generate the fixture first (reference widths, B=2, T_in=24, 8 steps)")
+    p.add_argument("--shards", type=int, default=1)
+    p = sub.add_parser("run"); p.add_argument("--reference", required=True); p.add_argument("workdir")
+    p = sub.add_parser("compare"); p.add_argument("fixture"); p.add_argument("workdir"); p.add_argument("--tol", type=float, default=1e-3)
+    args = ap.parse_args()
+    {"prepare": prepare, "run": run, "compare": compare}[args.cmd](args)
+
+
+if __name__ == "__main__":
+    main()
