@@ -408,3 +408,63 @@ def test_captured_step_survives_an_eager_step_of_a_larger_shape():
         # (Adam's update is lr * m / sqrt(v): fp32-atomic summation order in the weight gradients moves near-zero-gradient entries by
         # a visible fraction of a step; a replay into freed memory is off by orders of magnitude or not finite)
         assert np.isfinite(wa[k]).all() and maxabs(wa[k], wb[k]) < 1e-3 * max(1.0, float(np.abs(wb[k]).max())), k
+
+
+def test_C4_shard_shape_forward_and_properties():
+    """BASELINE.json configs[3], one shard of the data-parallel step: B=32, T_in=128, T_out=512 at the reference widths
+    (train.py:145-166,217-219; hparams.py batch_size 32).  The teacher-forced training forward against the float64 oracle at full
+    size; then the size-independent properties of the step: finite gradients, two runs agree to the tolerance of fp32 atomics,
+    five steps on the batch lower the loss."""
+    import torch
+    B, T_in, T_out = 32, 128, 512
+    hp = O.OracleHParams(max_iters=T_out // 4)
+    w = O.init_weights(hp, 1, 1234 + 3)
+    ids, L = O.synthetic_inputs(B, T_in, 1234 + 3, ragged=True)
+    rs = np.random.RandomState(1234 + 3)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)       # the normalised range of audio/__init__.py:161-162
+    r = hp.reduction_factor
+    ref = O.forward(w, hp, ids, L, n_steps=T_out // r, honor_stop=False, teacher_frames=mt[:, r - 1::r], training=True, dtype=np.float64)
+    tr = _trainer(hp, w)
+    losses = tr.forward_backward(ids, L, mt, lt, backward=False, keep_outputs=True)
+    torch.cuda.synchronize()
+    assert maxabs(tr.mel_outputs.cpu().numpy(), ref["mel"]) < 1e-3
+    assert maxabs(tr.linear_outputs.cpu().numpy(), ref["linear"]) < 1e-3
+    assert maxabs(tr.alignments.cpu().numpy(), ref["alignments"]) < 1e-3
+    want = O.add_loss(ref["mel"], mt, ref["linear"], lt, np.ones(B))
+    got = losses.cpu().numpy()
+    for i, k in enumerate(("loss", "mel_loss", "linear_loss", "loss_without_coeff")):
+        assert abs(got[i] - want[k]) < 1e-4 * max(1.0, abs(want[k])), k
+    tr.forward_backward(ids, L, mt, lt)
+    torch.cuda.synchronize()
+    g1 = tr.grads.detach().clone()
+    tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True)
+    torch.cuda.synchronize()
+    g2 = tr.grads
+    assert bool(torch.isfinite(g1).all())
+    scale = float(g1.abs().max())
+    assert float((g1 - g2).abs().max()) < 1e-4 * scale, "two runs of the same step differ beyond fp32-atomic summation order"
+    first = None
+    for _ in range(5):
+        _, lwc = tr.train_step(ids, L, mt, lt)
+        first = float(lwc) if first is None else first
+    torch.cuda.synchronize()
+    assert float(lwc) < first and np.isfinite(float(lwc))
+
+
+def test_C4_horizon_gradients_on_a_two_row_slice():
+    """The C4 horizon (T_in=128, T_out=512: 128 teacher-forced decoder steps, 512-frame post-net) at the reference widths on two
+    rows: every gradient tensor against float64 reverse-mode autograd of the independent torch formulation."""
+    import torch
+    hp = O.OracleHParams(max_iters=128)
+    w = O.init_weights(hp, 1, 1234 + 13)
+    B, T_in, T_out = 2, 128, 512
+    ids, L = O.synthetic_inputs(B, T_in, 1234 + 13, ragged=True)
+    rs = np.random.RandomState(1234 + 13)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    loss, g, _ = TF.train_grads(w, hp, ids, L, mt, lt)
+    tr = _trainer(hp, w)
+    losses = tr.forward_backward(ids, L, mt, lt)
+    torch.cuda.synchronize()
+    assert abs(float(losses[0]) - loss) < 1e-4
+    worst, gn = _grad_report(tr.grad_dict(), g)
+    assert worst[0][0] < 2e-3, worst[:5]
