@@ -4,10 +4,10 @@
 A "step" = one pass of the hot path (taco_forward_infer, replayed from its hipGraph plan) over one
 synthetic batch: ids -> encoder CBHG -> attention decoder (max_iters steps) -> post-net CBHG ->
 linear spectrogram, inputs/outputs resident in HBM.  Workload at N=1 is BASELINE.json configs[1]
-(C2: B=32, T_in=128, T_mel=512).  The K steps are issued round-robin over `--lanes` (default 4) PlanPool lanes -- one plan,
-workspace and HIP stream each -- so up to 4 independent B=32 forwards are in flight (`--lanes 1`: strictly serial; the JSON
-also carries the latency of one forward alone).  N>1: one process per GPU, per-GPU batch fixed (weak scaling),
-no data-path collective; barrier + synchronize on both sides, MAX over ranks.
+(C2: B=32, T_in=128, T_mel=512).  The K steps are issued round-robin over `--lanes` PlanPool lanes (default 1: strictly serial
+forwards; the decoder loop and the post-net scan are whole-chip persistent kernels).  `python bench.py --gpus N` launches its own
+N ranks: one process per GPU, per-GPU batch fixed (weak scaling), no data-path collective; barrier + synchronize on both sides,
+MAX over ranks.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md 'Measurement' for every field)."""
 import argparse
@@ -195,8 +195,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=None, help="debug: 0 = no decoder/post-net overlap, N>1 = chunk of N decoder steps")
     ap.add_argument("--eager", action="store_true", help="enqueue kernels directly instead of replaying the hipGraph plan")
-    ap.add_argument("--lanes", type=int, default=4,
-                    help="forwards in flight per GPU (PlanPool: one plan + buffers + HIP stream each); 1 = strictly serial")
+    ap.add_argument("--lanes", type=int, default=1,
+                    help="forwards in flight per GPU (PlanPool: one plan + buffers + HIP stream each); 1 = strictly serial (default: the "
+                         "persistent decoder / scan kernels each take the whole chip, so a second forward in flight has nothing to run on; "
+                         "with --decoder-engine 0 the launch-per-stage kernels leave CUs idle and 4 lanes fill them)")
     ap.add_argument("--coalesce", type=int, default=1,
                     help="requests served per forward (PlanPool coalesce): c > 1 rides c batches of the workload's B rows through one "
                          "plan of c*B rows; a step is still one batch of B rows.  Default 1 = the BASELINE.json configuration as is")
@@ -359,23 +361,49 @@ def main():
 
     companions = {}
     if rank == 0 and world == 1 and not args.no_companions and co == 1 and not args.eager:
-        # (i) strictly serial forwards (one in flight), (ii) the same lanes with every GEMM in exact fp32 (no split-bf16 feed-forward)
         ksteps = max(4, min(args.steps, 12))
-        companions["lanes_1"] = {"mel_frames_per_s": B * n * r / timed_pool(pool, 1, ksteps), "forwards_in_flight": 1}
+
+        def fill(pl, reps):
+            for pln in pl.plans:
+                pln.inputs.copy_(pool.plans[0].inputs.repeat(reps, 1)); pln.lengths.copy_(pool.plans[0].lengths.repeat(reps))
+                if ns > 1:
+                    pln.speaker_id.copy_(pool.plans[0].speaker_id.repeat(reps))
+            torch.cuda.synchronize()
+
+        # (i) strictly serial forwards when the headline runs several lanes
+        if lanes > 1:
+            companions["lanes_1"] = {"mel_frames_per_s": B * n * r / timed_pool(pool, 1, ksteps), "forwards_in_flight": 1}
+        # (ii) every GEMM in exact fp32 (no split-bf16 feed-forward), same lanes
         model._lib.taco_debug_set_bf3(model._handle, 0, 0)
         model._plans.clear()
-        pool32 = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=1)
-        for plan32 in pool32.plans:
-            plan32.inputs.copy_(pool.plans[0].inputs); plan32.lengths.copy_(pool.plans[0].lengths)
-            if ns > 1:
-                plan32.speaker_id.copy_(pool.plans[0].speaker_id)
-        torch.cuda.synchronize()
-        companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / timed_pool(pool32, lanes, ksteps), "forwards_in_flight": lanes,
+        p2 = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=1)
+        fill(p2, 1)
+        companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / timed_pool(p2, lanes, ksteps), "forwards_in_flight": lanes,
                                     "arithmetic": "every contraction on exact-fp32 MFMA / VALU (taco_debug_set_bf3 off)"}
-        pool32.close()
+        p2.close()
         model._lib.taco_debug_set_bf3(model._handle, 1, 0)
+        # (iii) two requests of B rows riding through one pass (PlanPool coalesce = 2)
+        p4 = model.plan_pool(B, T_in, n, lanes=1, coalesce=2)
+        fill(p4, 2)
+        companions["two_requests_per_pass"] = {"mel_frames_per_s": 2 * B * n * r / timed_pool(p4, 1, ksteps), "rows_per_pass": 2 * B,
+                                               "engine_info": model.decoder_engine_info()}
+        p4.close()
+        # (iv) the launch-per-stage engine of round 1 (decoder and scans as chains of small launches that leave most CUs idle), with
+        # four forwards in flight to fill them: higher throughput than it has latency to show for
+        if args.decoder_engine != 0:
+            model.set_decoder_engine(0)
+            p3 = model.plan_pool(B, T_in, n, lanes=4, coalesce=1)
+            fill(p3, 1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            thr = B * n * r / timed_pool(p3, 4, 3 * ksteps)
+            with torch.cuda.stream(p3.streams[0]):
+                e0.record(); p3.plans[0].launch(); p3.plans[0].launch(); e1.record()
+            torch.cuda.synchronize()
+            companions["launch_per_stage_engine_4_lanes"] = {"mel_frames_per_s": thr, "forwards_in_flight": 4,
+                                                             "forward_latency_ms_alone": e0.elapsed_time(e1) / 2}
+            p3.close()
+            model.set_decoder_engine(args.decoder_engine)
         model._plans.clear()
-
     if rank == 0:
         frames = world * B * n * r * args.steps
         spec = taco_amd.weights.weight_spec(hp, ns)

@@ -80,7 +80,7 @@ int taco_gl_inv_spectrogram(taco_gl* g, void* hip_stream, const float* d_spec, c
   const int Tr = gl_rows(g, T), F = g->F;
   const size_t R = (size_t)B * Tr, slot = gl_slot(g, T);
   if (iters < 0) iters = g->hp.griffin_lim_iters;
-  HIPCHK(hipMemsetAsync(w.ypad, 0, ((size_t)B * slot + 2 * g->n_fft + g->win) * sizeof(float), st));
+  HIPCHK(zero_async(w.ypad, ((size_t)B * slot + 2 * g->n_fft + g->win) * sizeof(float), st));
   hipLaunchKernelGGL(k_gl_wss, EWGRID((size_t)L + g->n_fft), 0, st, AP(g->gm, g->w2), w.wss, T, g->n_fft, g->hop);
   hipLaunchKernelGGL(k_gl_magnitude, EWGRID(R * F), 0, st, d_spec, w.S, B, T, Tr, F, g->hp.min_level_db, g->hp.ref_level_db, g->hp.power);
   hipLaunchKernelGGL(k_gl_init_phase, EWGRID(R * F), 0, st, w.S, d_init_uniform, seed, w.X, B, T, Tr, F);

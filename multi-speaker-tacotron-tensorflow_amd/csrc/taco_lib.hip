@@ -32,6 +32,26 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+// Stream-ordered zero fill as a kernel launch.  hipMemsetAsync nodes of a captured graph were seen to fill with a stale 16-byte
+// pattern after another plan of the process had been destroyed (round 2: the census words and the exchange tags of a decoder plan,
+// the BatchNorm sums of a captured train step); a kernel node has no such state.  p 4-byte aligned, bytes a multiple of 4.
+__global__ __launch_bounds__(256) void k_zero_fill(uint32_t* __restrict__ p, size_t n16, size_t nw) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
+}
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (!bytes) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, st);
+  const size_t nw = bytes / 4;
+  const size_t n16 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : nw / 4;
+  const size_t items = n16 ? n16 + (nw - n16 * 4) : nw;
+  const unsigned blocks = (unsigned)std::min<size_t>((items + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_zero_fill, dim3(blocks), dim3(256), 0, st, static_cast<uint32_t*>(p), n16, nw);
+  return hipGetLastError();
+}
+
 #define HIPCHK(expr)                                                                        \
   do {                                                                                      \
     hipError_t e_ = (expr);                                                                 \
@@ -778,8 +798,8 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = m->d_trace; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
     int RG = 1;
     while (RG < 8 && RG * (GX_NGROUP / 2) < B) RG *= 2;
-    HIPCHK(hipMemsetAsync(w.gxbuf, 0, gx_xbuf_granules(RG) * sizeof(unsigned long long), st));
-    HIPCHK(hipMemsetAsync(w.gxctl, 0, 256, st));
+    // granules and census words are carved back to back: one fill launch covers both
+    HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
     // the kernel needs only a few KB of LDS and ~70 VGPRs: asking for more than half of the CU's LDS keeps the dispatcher from
     // stacking two of the 256 workgroups on one CU (the census checks placement per XCD, not per CU)
     const size_t lds = std::max(gx_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);
@@ -1060,8 +1080,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
-  HIPCHK(hipMemsetAsync(w.xbuf, 0, w.xbuf_bytes, st));
-  HIPCHK(hipMemsetAsync(w.dxctl, 0, 256, st));
+  HIPCHK(zero_async(w.xbuf, (size_t)((char*)w.dxctl - (char*)w.xbuf) + 256, st));   // carved back to back: one fill launch
   const size_t lds = dx_lds_floats(RG, T_in) * sizeof(float);
   switch (RG) {
     case 1: return dx_launch_rg<1>(st, a, lds);
@@ -1103,7 +1122,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   for (int i = 0; i < L; ++i) fill(dv ? spk->vec[3 + i] : nullptr, Hd, w.hd[i], Hd);
   hipLaunchKernelGGL(k_init_align, dim3(cdiv(B * T_in, 256)), dim3(256), 0, st, w.align, B, T_in, hp.attention_type == 2 ? 1 : 0);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
+  HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
   const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
   const int dbgw = As + D + L * Hd;
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
@@ -1590,7 +1609,7 @@ int taco_stop_steps(void* hip_stream, const float* d_mel, int B, int n_steps, in
   if (!d_mel || !d_stop || B <= 0 || n_steps <= 0 || width <= 0 || rows_per_group <= 0 || B % rows_per_group)
     return fail(TACO_ERR_ARG, "bad argument");
   hipStream_t st = (hipStream_t)hip_stream;
-  HIPCHK(hipMemsetAsync(d_stop, 0, (size_t)(B / rows_per_group) * sizeof(int32_t), st));
+  HIPCHK(zero_async(d_stop, (size_t)(B / rows_per_group) * sizeof(int32_t), st));
   hipLaunchKernelGGL(k_stop_groups, dim3(B), dim3(256), 0, st, d_mel, n_steps, width, rows_per_group, d_stop);
   HIPCHK(hipGetLastError());
   return 0;

@@ -311,7 +311,7 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
   // batch -- what the reference's single-device step over the whole batch computes (modules.py:131)
   const bool sync = x.t->sync_fn && x.t->sync_world > 1;
   const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
-  HIPCHK(hipMemsetAsync(scratch, 0, (size_t)2 * C * sizeof(float), st));
+  HIPCHK(zero_async(scratch, (size_t)2 * C * sizeof(float), st));
   TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0));
   if (sync) x.t->sync_fn(x.t->sync_user, scratch, C);
   hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, invM);
@@ -369,7 +369,7 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   const int H = c.rnn;
   { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
-  HIPCHK(hipMemsetAsync(w.gsave, 0, (size_t)M * 6 * H * sizeof(float), st));
+  HIPCHK(zero_async(w.gsave, (size_t)M * 6 * H * sizeof(float), st));
   if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res), gates saved for the backward scan
     BigruSArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
@@ -420,8 +420,8 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int M = B * T, KC = c.K * c.C, H = c.rnn, I = c.rnn;
   // ---- BiGRU ----
-  HIPCHK(hipMemsetAsync(w.dg, 0, (size_t)M * 6 * H * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.rh, 0, (size_t)M * 2 * H * sizeof(float), st));
+  HIPCHK(zero_async(w.dg, (size_t)M * 6 * H * sizeof(float), st));
+  HIPCHK(zero_async(w.rh, (size_t)M * 2 * H * sizeof(float), st));
   {
     int R = (B >= 2 && 2 * H <= RP_NT) ? 2 : 1;
     if ((size_t)R * H > RP_NT || (H % 4)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the BiGRU backward kernel", H);
@@ -534,7 +534,7 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
   const int ldal = (n + 1) * T_in;
   hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * T_in), 0, st, w.alpha0, T_in, w.alpha, ldal, B, T_in);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemsetAsync(w.nz, 0, (size_t)n * B * sizeof(int), st));
+  HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
   const int Pl = hp.dec_prenet[np - 1];
   const int S = simple_S(m), Dc = D + S, Pz = Pl + S;      // 'simple': speaker embedding parked behind ctx and behind the last prenet output
   if (S) {
@@ -633,14 +633,14 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   const int ldal = (n + 1) * T_in, R = B * n;
   const int S = simple_S(m), Dc = D + S, Pz = Pl + S;
   if (S && !dspk) return fail(TACO_ERR_ARG, "speaker-embedding gradient buffer missing");
-  HIPCHK(hipMemsetAsync(w.dkeys, 0, (size_t)B * T_in * A * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dvalues, 0, (size_t)B * T_in * D * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dv_acc, 0, (size_t)B * A * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dsb_acc, 0, (size_t)B * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dalpha, 0, (size_t)B * T_in * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dctx, 0, (size_t)B * D * sizeof(float), st));
-  HIPCHK(hipMemsetAsync(w.dhA, 0, (size_t)B * As * sizeof(float), st));
-  for (int i = 0; i < L; ++i) HIPCHK(hipMemsetAsync(w.dh[i], 0, (size_t)B * Hd * sizeof(float), st));
+  HIPCHK(zero_async(w.dkeys, (size_t)B * T_in * A * sizeof(float), st));
+  HIPCHK(zero_async(w.dvalues, (size_t)B * T_in * D * sizeof(float), st));
+  HIPCHK(zero_async(w.dv_acc, (size_t)B * A * sizeof(float), st));
+  HIPCHK(zero_async(w.dsb_acc, (size_t)B * sizeof(float), st));
+  HIPCHK(zero_async(w.dalpha, (size_t)B * T_in * sizeof(float), st));
+  HIPCHK(zero_async(w.dctx, (size_t)B * D * sizeof(float), st));
+  HIPCHK(zero_async(w.dhA, (size_t)B * As * sizeof(float), st));
+  for (int i = 0; i < L; ++i) HIPCHK(zero_async(w.dh[i], (size_t)B * Hd * sizeof(float), st));
   const size_t attn_lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 5 * ((T_in + 3) & ~3) + ATB_NW * 256) * sizeof(float);
   if (attn_lds > 160 * 1024 || (As % 4) || (D % 4) || (A % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the backward kernel");
   for (int t = n - 1; t >= 0; --t) {
@@ -728,7 +728,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   }
   { const bool vn = hp.attention_type == 1;   // bah_norm: the kernels see v_hat = g*v/|v|; its gradient is mapped back to v and g below
     float* dvdst = vn ? w.dv_acc : x.g("attention/attention_v");
-    if (vn) HIPCHK(hipMemsetAsync(w.dv_acc, 0, (size_t)A * sizeof(float), st));
+    if (vn) HIPCHK(zero_async(w.dv_acc, (size_t)A * sizeof(float), st));
     AttnKArgs k; k.keys = w.keys; k.q = w.g_q; k.de = w.g_de; k.v = AP(m, m->att_v); k.battn = AP(m, m->att_b); k.dkeys = w.dkeys; k.dv = dvdst;
     k.T_in = T_in; k.A = A; k.n = n;
     hipLaunchKernelGGL(k_attention_keys_bwd, dim3(cdiv(A, 256), cdiv(T_in, ATK_J), B), dim3(256), 0, st, k);
@@ -806,7 +806,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
                                   w.losspart, (size_t)TR_MAXBLK * 8 * sizeof(double)));
   if (!do_backward) return 0;
   // ---- backward ----
-  HIPCHK(hipMemsetAsync(G, 0, t->NP * sizeof(float), st));
+  HIPCHK(zero_async(G, t->NP * sizeof(float), st));
   int c_lo = 0, c_hi = 0; float s_lin = 1.0f / ((float)Mp * F), s_band = 0.f;
   if (prioritize_loss) {
     c_hi = (int)(5000.0 / (sample_rate * 0.5) * F); c_lo = (int)(165.0 / (sample_rate * 0.5) * F);
@@ -818,7 +818,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   const int Hp2 = 2 * hp.post_rnn_size;
   TRY(run_wgrad(st, w.post.out, nullptr, Hp2, w.dlin, F, x.g("linear/kernel") + (simple ? (size_t)S * F : 0), F, Mp, 0, Hp2, F));
   if (simple) {      // speaker rows of the head: the embedding is constant over time, so they see the time-summed gradient
-    HIPCHK(hipMemsetAsync(w.dspk_emb, 0, (size_t)B * S * sizeof(float), st));
+    HIPCHK(zero_async(w.dspk_emb, (size_t)B * S * sizeof(float), st));
     hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * F), 0, st, w.dlin, w.dlin_sum, B, T_out, F);
     HIPCHK(hipGetLastError());
     TRY(run_wgrad(st, w.spk.emb, nullptr, S, w.dlin_sum, F, x.g("linear/kernel"), F, B, 0, S, F));
@@ -850,7 +850,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
         hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * dd), 0, st, w.dvec[i], speaker_id, x.g("spk/" + names[i] + "/table"), B, dd);
       }
     } else {
-      HIPCHK(hipMemsetAsync(w.dspk_emb, 0, (size_t)B * S * sizeof(float), st));
+      HIPCHK(zero_async(w.dspk_emb, (size_t)B * S * sizeof(float), st));
       for (size_t i = 0; i < names.size(); ++i) {
         const int dd = i < 3 ? dims[i] : hp.dec_rnn_size;
         hipLaunchKernelGGL(k_softsign_bwd, EWGRID((size_t)B * dd), 0, st, w.dvec[i], w.spk.vec[i], w.dzs, B * dd);

@@ -63,7 +63,6 @@ class Trainer(object):
         self._ws_eager = None    # workspace of eager calls made while a captured step exists
         self._ws_live = None
         self._graph = None
-        self._eager_since_replay = False
         self._capturing = False
         self._sync_cb = None
         self._sync_err = None
@@ -160,8 +159,6 @@ class Trainer(object):
             lin = torch.empty((B, T_out, hp.num_freq), dtype=torch.float32, device=dev)
             ali = torch.empty((B, T_in, T_out // hp.reduction_factor), dtype=torch.float32, device=dev)
         self._ws_live = ws      # the workspace of the call in flight (the SyncBN callback reduces slices of it)
-        if not self._capturing:
-            self._eager_since_replay = True
         with torch.cuda.device(dev):
             _lib.check(self._lib.taco_train_forward_backward(
                 self._h, _st(), _p(self.params), _p(self.grads if backward else None), _p(ids), _p(lens), _p(spk), _p(mt), _p(lt), _p(co),
@@ -197,8 +194,7 @@ class Trainer(object):
             finally:
                 self._capturing = False
             self._graph = graph
-            self._eager_since_replay = False
-        return self
+            return self
 
     def _replay(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id=None):
         src = [inputs, input_lengths, mel_targets, linear_targets, loss_coeff, speaker_id]
@@ -212,13 +208,9 @@ class Trainer(object):
                 return False
             if x.data_ptr() != dst.data_ptr():
                 dst.copy_(x)
-        # A replay that follows an eager step of ANOTHER shape on the same trainer was observed to compute with stale operands
-        # (MI355X, ROCm 7.2 / PyTorch 2.10: wrong BatchNorm statistics from the second replay on, also with the stream drained in
-        # between and with the graph fenced on a stream of its own; tools/scratch/dbg_capture*.py).  The captured step is therefore
-        # recorded afresh after such a step: one warm-up with frozen statistics plus the capture, only on that transition.
-        if self._eager_since_replay:
-            self._eager_since_replay = False
-            self.capture(*[x for x in src[:5]], speaker_id=src[5])
+        # (replays mixed with eager steps of other shapes are safe: every stream-ordered clear in the library is a kernel launch --
+        # hipMemsetAsync NODES of a captured graph were seen to fill with stale data once other work had run in between, see zero_async
+        # in csrc/taco_lib.hip)
         self._graph.replay()
         return True
 

@@ -110,3 +110,19 @@ def test_bench_single_process_selftest():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert rec["world_size"] == 1
+
+
+def test_bench_train_spawns_its_own_ranks():
+    """tools/bench_train.py --gpus 2 launches its own ranks; the self-test runs the launcher, the gloo rendezvous and the flat
+    gradient all-reduce (mean over ranks: element 1 of arange * (rank+1) averages to 1.5)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_train.py"), "--gpus", "2", "--selftest-launcher"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert rec["world_size"] == 2 and abs(rec["grad_mean_factor"] - 1.5) < 1e-6

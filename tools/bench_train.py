@@ -15,9 +15,31 @@ def main():
     ap.add_argument("--t-in", type=int, default=128)
     ap.add_argument("--t-out", type=int, default=512)
     ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: this script launches its own N ranks (torch.distributed.run, RCCL, 127.0.0.1)")
+    ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (40 small all-reduces per step); "
                                                            "0: per-rank statistics.  No effect on one GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket, subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    if args.selftest_launcher:
+        import torch, taco_amd
+        from taco_amd import dist as D
+        from taco_amd.train_ops import allreduce_gradients
+        rank, _, world = D.env_rank()
+        dist = D.init_process_group("gloo") if world > 1 else None
+        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        allreduce_gradients(g)
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher", "world_size": world, "grad_mean_factor": float(g[1])}))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
     import numpy as np, torch, taco_amd
     from taco_amd import dist as D
     rank, local_rank, world = D.env_rank()
@@ -56,6 +78,13 @@ def main():
     ev[0].record(); tr.forward_backward(ids, lens, mt, lt, backward=False); ev[1].record()
     tr.forward_backward(ids, lens, mt, lt, backward=True); ev[2].record()
     tr.adam.step(tr.grads); tr.refresh(); ev[3].record(); torch.cuda.synchronize()
+    from taco_amd.train_ops import allreduce_gradients
+    a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a0.record()
+    for _ in range(5):
+        allreduce_gradients(tr.grads)
+    a1.record(); torch.cuda.synchronize()
+    allreduce_ms = a0.elapsed_time(a1) / 5
     if rank == 0:
         print(json.dumps({
             "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
@@ -65,7 +94,9 @@ def main():
                            B, T_in, T_out, hp.reduction_factor, "synchronised over the ranks" if sync_bn else "per-rank statistics"),
                        "parallelism": "data-parallel x%d, one flat-bucket RCCL all-reduce of %d floats" % (world, tr.num_params)},
             "phase_ms": {"forward_only": ev[0].elapsed_time(ev[1]), "forward_plus_backward": ev[1].elapsed_time(ev[2]),
-                         "adam_plus_refresh": ev[2].elapsed_time(ev[3])},
+                         "adam_plus_refresh": ev[2].elapsed_time(ev[3]),
+                         "gradient_allreduce": allreduce_ms if world > 1 else 0.0},
+            "world_size_seen": world, "sync_bn": bool(sync_bn),
             "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9}))
     if dist is not None:
         dist.barrier(); dist.destroy_process_group()
