@@ -1961,23 +1961,27 @@ __global__ __launch_bounds__(64 * ATS_NW) void k_att_context(const AttnArgs a_in
 // stop rule of helpers.py:29 + TF dynamic_decode: a row is finished once a step's r*num_mels outputs are
 // all exactly 0; the loop ends after the first step at which every row is finished.
 // nz [n_steps, B] : 1 if row b emitted any non-zero at step t.
-__global__ void k_stop_step(const int* nz, int B, int n_steps, int* stop) {
-  __shared__ int first[1024];
+__global__ __launch_bounds__(256) void k_stop_step(const int* nz, int B, int n_steps, int* stop) {
+  // all loads independent (a per-row serial walk with an early exit was a chain of n_steps dependent cache misses: 34 us at C2)
+  __shared__ int first[1024];     // first all-zero step of the rows of one chunk
+  __shared__ int worst;
   const int tid = threadIdx.x;
-  int worst = 0;
-  for (int b = tid; b < B; b += blockDim.x) {
-    int f = n_steps;   // first all-zero step of row b
-    for (int t = 0; t < n_steps; ++t)
-      if (nz[(size_t)t * B + b] == 0) { f = t; break; }
-    worst = max(worst, f);
-  }
-  first[tid] = worst;
-  __syncthreads();
-  if (tid == 0) {
+  if (tid == 0) worst = 0;
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int nb = min(1024, B - b0);
+    for (int i = tid; i < nb; i += blockDim.x) first[i] = n_steps;
+    __syncthreads();
+    for (int i = tid; i < n_steps * nb; i += blockDim.x) {
+      const int t = i / nb, b = i - t * nb;
+      if (nz[(size_t)t * B + b0 + b] == 0) atomicMin(&first[b], t);
+    }
+    __syncthreads();
     int w = 0;
-    for (int i = 0; i < (int)blockDim.x; ++i) w = max(w, first[i]);
-    *stop = min(w + 1, n_steps);
+    for (int i = tid; i < nb; i += blockDim.x) w = max(w, first[i]);
+    if (w) atomicMax(&worst, w);
+    __syncthreads();
   }
+  if (tid == 0) *stop = min(worst + 1, n_steps);
 }
 
 // The same stop rule evaluated on a finished mel buffer for groups of `rows` consecutive batch rows (requests that were served

@@ -1130,7 +1130,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     TRY(dx_launch(m, st, enc_out, B, T_in, n, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr,
                   dv ? spk->vec[4] : nullptr));
     if (stop_step) {
-      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(64), 0, st, w.nz, B, n, stop_step);
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1203,7 +1203,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     }
   }
   if (stop_step) {
-    hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(64), 0, st, w.nz, B, n, stop_step);
+    hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
     HIPCHK(hipGetLastError());
   }
   return 0;

@@ -225,7 +225,7 @@ static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w
   w.xproj = cv.f(M * 6 * c.rnn); w.out = cv.f(M * 2 * c.rnn); w.gsave = cv.f(M * 6 * c.rnn);
   w.dg = cv.f(M * 6 * c.rnn); w.rh = cv.f(M * 2 * c.rnn);
   w.d0 = cv.f(M * wide); w.d1 = cv.f(M * wide); w.dcat = cv.f(M * 2 * c.rnn);
-  w.dbig0 = cv.f(M * KC); w.dbig1 = cv.f(M * KC); w.stat = cv.f(2 * std::max<size_t>(KC, wide));
+  w.dbig0 = cv.f(M * KC); w.dbig1 = cv.f(M * KC); w.stat = cv.f(5 * std::max<size_t>(KC, wide));   // sums, centred sums + the 3-vector SyncBN exchange pack
 }
 struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (b*n + t)*W
   float *keys, *zero, *ctx, *pz[4], *hA, *rA, *uA, *cA, *rhA, *xcA, *alpha, *alpha0;
@@ -307,16 +307,21 @@ struct TrainCtx {
 static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, float* mu, float* rstd, float* scratch,
                     const std::string* names, const int* cols, int nnames) {
   hipStream_t st = x.st;
-  // data-parallel SyncBN: both passes are summed over the ranks, so mean and (two-pass, centred) variance are those of the global
-  // batch -- what the reference's single-device step over the whole batch computes (modules.py:131)
+  // data-parallel SyncBN: mean and centred variance are those of the global batch -- what the reference's single-device step over
+  // the whole batch computes (modules.py:131) -- merged from the ranks' own (mean, centred sum) pairs
   const bool sync = x.t->sync_fn && x.t->sync_world > 1;
   const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
   HIPCHK(zero_async(scratch, (size_t)2 * C * sizeof(float), st));
   TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0));
-  if (sync) x.t->sync_fn(x.t->sync_user, scratch, C);
-  hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, invM);
+  hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, 1.0f / (float)M);
   TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1));
-  if (sync) x.t->sync_fn(x.t->sync_user, scratch + C, C);
+  if (sync) {
+    // ONE exchange per layer (the layer's columns, or all widths of a conv bank at once): rank means, centred sums, squared means
+    float* pack = scratch + 2 * C;
+    hipLaunchKernelGGL(k_bn_sync_pack, EWGRID(C), 0, st, mu, scratch + C, pack, C);
+    x.t->sync_fn(x.t->sync_user, pack, 3 * C);
+    hipLaunchKernelGGL(k_bn_sync_combine, EWGRID(C), 0, st, pack, mu, scratch + C, C, (float)M, (float)x.t->sync_world);
+  }
   int c0 = 0;
   for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix
     // forward-only passes (loss fetches, the test model, a capture warm-up) leave the moving statistics alone, as the reference does
@@ -391,26 +396,41 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
 }
 
 // one conv1d+act+BN(train) layer backward: dy (grad of BN output) -> weight/bias/gamma/beta grads and dz (pre-activation grad).
-static int conv_bn_backward(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
-                            const float* rstd, bool relu, float* dz, int lddz, int M, int C, float* sync_scratch) {
+// Two halves so that layers whose dy exist at the same time (the widths of a conv bank) share ONE SyncBN exchange:
+// _sums: per-channel sum dy, sum dy*xhat into the beta / gamma gradients (+ a copy at sync_scratch[c0], sync_scratch[Ctot + c0]);
+// _apply: dz and the bias gradient from those sums (the global ones when synchronised).
+static int conv_bn_backward_sums(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
+                                 const float* rstd, int M, int C, float* sync_scratch, int c0, int Ctot) {
   hipStream_t st = x.st;
   TRY(run_colsum(st, a, lda, dy, lddy, mu, rstd, x.g(name + "/beta"), x.g(name + "/gamma"), M, C, 2));
-  const float* sdy = x.g(name + "/beta"); const float* sdyxh = x.g(name + "/gamma");
-  float invM = 1.0f / M;
   if (x.t->sync_fn && x.t->sync_world > 1) {
-    // SyncBN: the two per-channel sums inside dz run over every rank's rows.  The gradient buffers keep this rank's own sums
-    // (the flat all-reduce after backward averages them like every other gradient); the global copies live in scratch.
-    HIPCHK(hipMemcpyAsync(sync_scratch, sdy, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(sync_scratch + C, sdyxh, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
-    x.t->sync_fn(x.t->sync_user, sync_scratch, 2 * C);
-    sdy = sync_scratch; sdyxh = sync_scratch + C;
-    invM = 1.0f / ((float)M * x.t->sync_world);
+    // the gradient buffers keep this rank's own sums (the flat all-reduce after backward averages them like every other gradient)
+    HIPCHK(hipMemcpyAsync(sync_scratch + c0, x.g(name + "/beta"), (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(sync_scratch + Ctot + c0, x.g(name + "/gamma"), (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
+  return 0;
+}
+static void conv_bn_backward_exchange(const TrainCtx& x, float* sync_scratch, int Ctot) {
+  if (x.t->sync_fn && x.t->sync_world > 1) x.t->sync_fn(x.t->sync_user, sync_scratch, 2 * Ctot);
+}
+static int conv_bn_backward_apply(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
+                                  const float* rstd, bool relu, float* dz, int lddz, int M, int C, const float* sync_scratch, int c0, int Ctot) {
+  hipStream_t st = x.st;
+  const bool sync = x.t->sync_fn && x.t->sync_world > 1;
+  const float* sdy = sync ? sync_scratch + c0 : x.g(name + "/beta");
+  const float* sdyxh = sync ? sync_scratch + Ctot + c0 : x.g(name + "/gamma");
+  const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
   hipLaunchKernelGGL(k_bn_bwd, EWGRID((size_t)M * C), 0, st, a, lda, dy, lddy, mu, rstd, x.p(name + "/gamma"), sdy,
                      sdyxh, relu ? 1 : 0, dz, lddz, M, C, invM);
   TRY(run_colsum(st, dz, lddz, nullptr, 0, nullptr, nullptr, x.g(name + "/bias"), nullptr, M, C, 0));
   HIPCHK(hipGetLastError());
   return 0;
+}
+static int conv_bn_backward(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
+                            const float* rstd, bool relu, float* dz, int lddz, int M, int C, float* sync_scratch) {
+  TRY(conv_bn_backward_sums(x, name, a, lda, dy, lddy, mu, rstd, M, C, sync_scratch, 0, C));
+  conv_bn_backward_exchange(x, sync_scratch, C);
+  return conv_bn_backward_apply(x, name, a, lda, dy, lddy, mu, rstd, relu, dz, lddz, M, C, sync_scratch, 0, C);
 }
 // dout [M, 2*rnn] -> din [M, in_dim]
 static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, const std::string& sc, const float* in, const int* in_gather,
@@ -493,10 +513,16 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   // ---- maxpool + conv bank ----
   hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
   HIPCHK(hipGetLastError());
+  for (size_t bi = 0; bi < c.bank.size(); ++bi) {     // the bank's BatchNorm sums of all widths, then one exchange for all of them
+    const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
+    const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
+    TRY(conv_bn_backward_sums(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, M, c.C, w.stat, c0, KC));
+  }
+  conv_bn_backward_exchange(x, w.stat, KC);
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
-    TRY(conv_bn_backward(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat));
+    TRY(conv_bn_backward_apply(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat, c0, KC));
     TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
     TRY(run_dgrad(m, st, ct.bank_d[bi], w.dbig0 + c0, KC, M, T, din, c.in_dim, din, c.in_dim));   // accumulates onto the residual path
   }

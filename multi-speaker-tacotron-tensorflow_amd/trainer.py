@@ -70,8 +70,9 @@ class Trainer(object):
 
     # ---- data-parallel SyncBN ----
     def enable_sync_bn(self, on=True, group=None):
-        """BatchNorm statistics over the GLOBAL batch of the data-parallel group: every per-channel sum of the BatchNorm layers
-        (forward and backward) is all-reduced over `group` (RCCL on GPUs) inside the step, so a step over W shards equals the
+        """BatchNorm statistics over the GLOBAL batch of the data-parallel group: one all-reduce per BatchNorm layer in the forward
+        pass (rank means, centred sums and squared means in one vector; the widths of a conv bank are one layer here) and one per
+        layer / per conv bank in the backward pass (sum dy, sum dy*xhat), over `group` (RCCL on GPUs) inside the step, so a step over W shards equals the
         reference's single-device step over the whole batch (modules.py:131, train.py:145-166) -- up to summation order.  Without it
         (default) each rank normalises with its own rows.  Returns True when synchronisation is active (world size > 1)."""
         import torch.distributed as dist
@@ -83,7 +84,10 @@ class Trainer(object):
         if getattr(self, "_graph", None) is not None:
             raise _lib.TacoError(_lib.TACO_ERR_STATE, "SyncBN calls back into the host: it cannot be combined with a captured step")
 
+        self.sync_exchanges = 0       # all-reduces issued by SyncBN since it was enabled (12 per forward+backward at the default depth)
+
         def _sum(user, ptr, n):
+            self.sync_exchanges += 1
             try:            # the vector lives in this step's workspace: view it as a tensor and sum it over the ranks, stream-ordered
                 wsb = self._ws_live
                 off = int(ptr) - wsb.data_ptr()

@@ -32,7 +32,7 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         np.savez(os.path.join(out, "result.npz"), grads=tr.grads.cpu().numpy(), params=tr.params.cpu().numpy(),
-                 losses=(lall / world).cpu().numpy())
+                 losses=(lall / world).cpu().numpy(), exchanges=tr.sync_exchanges)
     dist.barrier()
     tr.close()
     dist.destroy_process_group()

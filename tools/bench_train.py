@@ -17,7 +17,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
     ap.add_argument("--gpus", type=int, default=1, help="N > 1: this script launches its own N ranks (torch.distributed.run, RCCL, 127.0.0.1)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
-    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (40 small all-reduces per step); "
+    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
                                                            "0: per-rank statistics.  No effect on one GPU")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

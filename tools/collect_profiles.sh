@@ -10,10 +10,10 @@ for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
-timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 0 --lanes 1 > $out/pmc_f.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 0 --lanes 1 > $out/pmc_w.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $out/pmc_sq -o sq --output-format csv -- python bench.py --no-cpu-baseline --steps 3 --warmup 0 --lanes 1 > $out/pmc_sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_f.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_w.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $out/pmc_sq -o sq --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_sq.log 2>&1
 python tools/pmc_traffic.py $out/pmc_f $out/pmc_w $out/pmc_hbm_traffic > $out/pmc_traffic.log 2>&1
 python tools/pmc_sq.py $out/pmc_sq $out/pmc_sq.txt > /dev/null 2>&1
 cp $out/ks/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
