@@ -16,7 +16,6 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 cases = [  # (kind, layer, B, T, Cin, Cout, kw, mpw, act)
     ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 2, 1),
-    ("conv", "post_cbhg/proj_1", 32, 512, 2048, 256, 3, 1, 1),
     ("conv", "post_cbhg/conv_bank/conv1d_8", 32, 512, 80, 256, 8, 1, 1),
     ("conv", "post_cbhg/proj_2", 32, 512, 256, 80, 3, 1, 0),
     ("dense", "post_cbhg/dense", 32, 512, 80, 256, 1, 1, 0),
