@@ -5,26 +5,33 @@
 // T steps of  r,u = sigmoid(xg + h Wg_h);  c = tanh(xc + (r*h) Wc_h);  h' = u*h + (1-u)*c  -- 196 K MACs and two dependent
 // mat-vecs per step.  k_bigru_resw gives every (direction, row) chain one CU and keeps 2/3 of the recurrent weights on it:
 // 3.74 us per step on 64 of the 256 CUs (post-net, C2: 1.9 ms).  Here the 64 chains are spread over the whole chip:
-//   * 16 groups of 16 CUs (two groups per XCD); a group owns ONE direction and RG batch rows (C2: 4) for all T steps;
-//   * member m of a group owns hidden units 16m..16m+15, wave w of it the pair 16m+2w, 16m+2w+1, and every lane keeps its 4-input
-//     slice of the pair's six weight columns (r, u, candidate x 2 units) in 24 VGPRs for the whole scan: nothing is re-read;
+//   * groups of 16 members; a group owns ONE direction and RG batch rows for all T steps; member m owns hidden units
+//     16m..16m+15, wave w of it UPW = 16 / NWV consecutive units, and every lane keeps its 4-input slice of the wave's 3 UPW
+//     weight columns (r, u per unit, then the candidates) in VGPRs for the whole scan: nothing is re-read;
 //   * per step two exchanges through the XCD's L2 (8-byte {value, tag} granules, see taco_decoder_xcd.h): r*h after the gates,
 //     h' after the candidate.  The x-parts come from HBM / the Infinity Cache (100 MB at C2): the member's slice of them is fetched
 //     16 steps at a time, one block ahead, into an LDS ring -- a far load inside the step loop would be waited for at the loop's
 //     back edge (and, loads returning in order, by the very next exchange poll) on every step.
+// Two geometries (NWV = waves per workgroup):
+//   NWV = 8 (default): 256 workgroups of 512 threads, one per CU, 16 groups (two per XCD), 2 units per wave.
+//   NWV = 4 (taco_debug_set_persistent(m, 9)): 512 workgroups of 256 threads, TWO per CU, 32 groups (four per XCD) of half as
+//            many rows, 4 units per wave; the two workgroups of a CU belong to different groups, i.e. to independent chains, so
+//            one could compute alone on its SIMDs while the other waits for an exchange.  Measured at C2: 6088 clocks per step
+//            against 5224 -- the compute phases do not shrink (they are chains of dependent instructions, not issue-bound) and
+//            the epilogue of four units per lane is longer.  Kept as the record of that experiment and as a second test geometry.
 // Length masking and the reverse_sequence time mapping of the backward direction follow A.7 exactly as k_bigru_resw does.
 #pragma once
 #include "taco_decoder_xcd.h"
 
 #define GX_MEMBERS 16
-#define GX_NGROUP 16
-#define GX_NREG 24
 #define GX_H 256
 #define GX_BLK 16            // steps per block of prefetched x-parts
+__host__ __device__ inline int gx_nreg(int NWV) { return 12 * (16 / NWV); }              // weight registers per thread
+__host__ __device__ inline int gx_ngroups(int NWV) { return 8 * (16 / NWV); }            // 16 (NWV 8: two per XCD) or 32 (NWV 4: four)
 __host__ __device__ inline size_t gx_lds_floats(int RG) { return (size_t)2 * RG * GX_H + (size_t)2 * GX_BLK * RG * 48 + 64; }
 
 struct GxArgs {
-  const float* wpack0; const float* wpack1;   // [16 members][GX_NREG][DX_NT] per direction
+  const float* wpack0; const float* wpack1;   // [16 members][gx_nreg][64 NWV] per direction
   const float* xproj;                         // [B*T, 6H] hoisted input projection, biases folded, backward direction time-reversed
   const float* h0;                            // [B, 2H] initial states (fw | bw) or null
   const int* lengths;                         // [B] or null (= T)
@@ -36,12 +43,15 @@ struct GxArgs {
   do {                                                                                                            \
     if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
-__host__ __device__ inline size_t gx_xbuf_granules(int RG) { return (size_t)GX_NGROUP * 2 * RG * GX_H; }
+// exchange granules of a launch: groups x [r*h | h'] x RG rows x H (the same for both geometries at their largest RG: 16 x 8 = 32 x 4)
+__host__ __device__ inline size_t gx_xbuf_granules(int ngroups, int RG) { return (size_t)ngroups * 2 * RG * GX_H; }
 
-template <int RG>
-__global__ __launch_bounds__(DX_NT) void k_bigru_xcd(const GxArgs a_in) {
+template <int RG, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float gx_smem[];
   GxArgs a = a_in;
+  constexpr int NT = 64 * NWV, UPW = 16 / NWV, NREG = 12 * UPW;
+  constexpr int GPX = 1024 / NT;              // groups per XCD: 2 or 4
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int H = GX_H, RL = DxRL<RG>::value;
@@ -53,29 +63,30 @@ __global__ __launch_bounds__(DX_NT) void k_bigru_xcd(const GxArgs a_in) {
   dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
   const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
   DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
-  // XCD-local: the two halves of an XCD's 32 workgroups are two groups; otherwise (slot = blockIdx / 8, place = blockIdx % 8) the
-  // same arithmetic gives 16 groups of 16 by block index
-  const int group = place * 2 + (slot >> 4), member = slot & 15;
+  // XCD-local: the workgroups of an XCD are dealt round-robin to its GPX groups (two workgroups that arrive together -- the pair
+  // of one CU, most likely -- end up in different groups); otherwise (slot = blockIdx / 8, place = blockIdx % 8) the same
+  // arithmetic gives 8 GPX groups of 16 by block index
+  const int group = place * GPX + (slot % GPX), member = slot / GPX;
   const int dir = group & 1, row0 = (group >> 1) * RG;
   if (row0 >= a.B) return;
   const int T = a.T;
   const bool tracer = a.trace && group == 0 && member == 0 && tid == 0;
 
-  float W[GX_NREG];
+  float W[NREG];
   {
-    const float* wp = (dir ? a.wpack1 : a.wpack0) + ((size_t)member * GX_NREG) * DX_NT + tid;
+    const float* wp = (dir ? a.wpack1 : a.wpack0) + ((size_t)member * NREG) * NT + tid;
 #pragma unroll
-    for (int j = 0; j < GX_NREG; ++j) W[j] = wp[(size_t)j * DX_NT];
+    for (int j = 0; j < NREG; ++j) W[j] = wp[(size_t)j * NT];
   }
   dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * 2 * RG * H;       // [r*h : RG x H][h' : RG x H]
-  for (int i = tid; i < RG * H; i += DX_NT) {
+  for (int i = tid; i < RG * H; i += NT) {
     const int r = i / H, n = i % H, b = row0 + r;
     hs[i] = (a.h0 && b < a.B) ? a.h0[(size_t)b * 2 * H + dir * H + n] : 0.f;
     xs[i] = 0.f;
   }
-  // epilogue role: quad 0 of every wave owns (rows dx_row(lane, q), units ua, ua+1)
+  // epilogue role: quad 0 of every wave owns (rows dx_row(lane, q), units u0 .. u0+UPW-1)
   const bool epl = lane < (RG >= 4 ? 4 : RG);
-  const int ua = member * 16 + wave * 2;
+  const int u0 = member * 16 + wave * UPW;
   int erow[RL], eL[RL];
   bool evalid[RL];
 #pragma unroll
@@ -85,12 +96,12 @@ __global__ __launch_bounds__(DX_NT) void k_bigru_xcd(const GxArgs a_in) {
     eL[q] = evalid[q] ? (a.lengths ? a.lengths[row0 + erow[q]] : T) : 0;
   }
   // x-part blocks: item i = (step j, row r, gate g, quarter c4) of a block -> one float4 of the member's 16 units
-  constexpr int NIT = GX_BLK * RG * 3 * 4, NLD = (NIT + DX_NT - 1) / DX_NT;
+  constexpr int NIT = GX_BLK * RG * 3 * 4, NLD = (NIT + NT - 1) / NT;
   float4 xld[NLD];
   auto blk_load = [&](int s0) {          // unconditional loads from clamped addresses (nothing is waited for here)
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int i = min(u * DX_NT + tid, NIT - 1);
+      const int i = min(u * NT + tid, NIT - 1);
       const int c4 = i & 3, g = (i >> 2) % 3, r = (i / 12) % RG, j = i / (12 * RG);
       const int b = min(row0 + r, a.B - 1), sx = min(s0 + j, T - 1);
       xld[u] = *reinterpret_cast<const float4*>(a.xproj + ((size_t)b * T + sx) * 6 * H + dir * 3 * H + g * H + member * 16 + 4 * c4);
@@ -99,7 +110,7 @@ __global__ __launch_bounds__(DX_NT) void k_bigru_xcd(const GxArgs a_in) {
   auto blk_store = [&](int ring) {
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int i = u * DX_NT + tid;
+      const int i = u * NT + tid;
       if (i < NIT) *reinterpret_cast<float4*>(xq + (size_t)ring * GX_BLK * RG * 48 + 4 * i) = xld[u];
     }
   };
@@ -115,64 +126,68 @@ __global__ __launch_bounds__(DX_NT) void k_bigru_xcd(const GxArgs a_in) {
     GX_STAMP(0);
     const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
     if (sb == 0 && s > 0) blk_load(s + GX_BLK);            // the block after next ... (its ring slot was last read one step ago)
-    float2 x0[RL][3];
+    float x0[RL][3][UPW];
 #pragma unroll
     for (int q = 0; q < RL; ++q)
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
-        x0[q][g] = *reinterpret_cast<const float2*>(xq + ((size_t)(ring * GX_BLK + sb) * RG + erow[q]) * 48 + g * 16 + wave * 2);
-    float ha[RL], hb[RL], ga[RL], gb[RL];
+      for (int g = 0; g < 3; ++g) {
+        const float* xp = xq + ((size_t)(ring * GX_BLK + sb) * RG + erow[q]) * 48 + g * 16 + wave * UPW;
+        if constexpr (UPW == 4) { const float4 v = *reinterpret_cast<const float4*>(xp); x0[q][g][0] = v.x; x0[q][g][1] = v.y; x0[q][g][2] = v.z; x0[q][g][3] = v.w; }
+        else { const float2 v = *reinterpret_cast<const float2*>(xp); x0[q][g][0] = v.x; x0[q][g][1] = v.y; }
+      }
+    float hv[RL][UPW], gv[RL][UPW];
 #pragma unroll
-    for (int q = 0; q < RL; ++q) { ha[q] = hs[erow[q] * H + ua]; hb[q] = hs[erow[q] * H + ua + 1]; }
-    // ---- gates: r, u of both units ----
+    for (int q = 0; q < RL; ++q)
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) hv[q][i] = hs[erow[q] * H + u0 + i];
+    // ---- gates: r, u of the wave's units (columns r_0, u_0, r_1, u_1, ...) ----
     {
-      float acc[4][RG], sm[4][RL];
-      dx_zero<4, RG>(acc);
-      dx_pass<0, 4, RG, GX_NREG, GX_H>(W, hs, lane, acc);
-      dx_reduce<4, RG>(acc, sm, lane);
+      float acc[2 * UPW][RG], sm[2 * UPW][RL];
+      dx_zero<2 * UPW, RG>(acc);
+      dx_pass<0, 2 * UPW, RG, NREG, GX_H>(W, hs, lane, acc);
+      dx_reduce<2 * UPW, RG>(acc, sm, lane);
       GX_STAMP(1);
 #pragma unroll
-      for (int q = 0; q < RL; ++q) {
-        const float ra = dx_sigmoid_fast(sm[0][q] + x0[q][0].x), rb = dx_sigmoid_fast(sm[2][q] + x0[q][0].y);
-        ga[q] = dx_sigmoid_fast(sm[1][q] + x0[q][1].x);
-        gb[q] = dx_sigmoid_fast(sm[3][q] + x0[q][1].y);
-        if (epl) {
-          dx_publish(X + erow[q] * H + ua, ra * ha[q], tag, rt);
-          dx_publish(X + erow[q] * H + ua + 1, rb * hb[q], tag, rt);
+      for (int q = 0; q < RL; ++q)
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+          const float rr = dx_sigmoid_fast(sm[2 * i][q] + x0[q][0][i]);
+          gv[q][i] = dx_sigmoid_fast(sm[2 * i + 1][q] + x0[q][1][i]);
+          if (epl) dx_publish(X + erow[q] * H + u0 + i, rr * hv[q][i], tag, rt);
         }
-      }
     }
     GX_STAMP(2);
-    dx_gather<RG, GX_H, false, GX_H>(X, tag, xs, 0, 0, 0, tid, rt);
+    dx_gather<RG, GX_H, false, GX_H, NT>(X, tag, xs, 0, 0, 0, tid, rt);
     GX_STAMP(3);
     __syncthreads();
     GX_STAMP(4);
     // ---- candidate and the new state ----
     {
-      float acc[2][RG], sm[2][RL];
-      dx_zero<2, RG>(acc);
-      dx_pass<16, 2, RG, GX_NREG, GX_H>(W, xs, lane, acc);
-      dx_reduce<2, RG>(acc, sm, lane);
+      float acc[UPW][RG], sm[UPW][RL];
+      dx_zero<UPW, RG>(acc);
+      dx_pass<8 * UPW, UPW, RG, NREG, GX_H>(W, xs, lane, acc);
+      dx_reduce<UPW, RG>(acc, sm, lane);
       GX_STAMP(5);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float ca = taco_tanh_fast(sm[0][q] + x0[q][2].x), cb = taco_tanh_fast(sm[1][q] + x0[q][2].y);
         const bool active = s < eL[q];                       // A.7: row active iff s < L; forward t = s, backward t = L-1-s
-        const float na = active ? ga[q] * ha[q] + (1.f - ga[q]) * ca : ha[q];
-        const float nb = active ? gb[q] * hb[q] + (1.f - gb[q]) * cb : hb[q];
-        if (epl) {
-          dx_publish(X + RG * H + erow[q] * H + ua, na, tag, rt);
-          dx_publish(X + RG * H + erow[q] * H + ua + 1, nb, tag, rt);
-          if (evalid[q]) {
-            const int t = (dir && active) ? (eL[q] - 1 - s) : s;
-            *reinterpret_cast<float2*>(a.out + ((size_t)(row0 + erow[q]) * T + t) * 2 * H + dir * H + ua) =
-                active ? make_float2(na, nb) : make_float2(0.f, 0.f);
-          }
+        float nv[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+          const float cc = taco_tanh_fast(sm[i][q] + x0[q][2][i]);
+          nv[i] = active ? gv[q][i] * hv[q][i] + (1.f - gv[q][i]) * cc : hv[q][i];
+          if (epl) dx_publish(X + RG * H + erow[q] * H + u0 + i, nv[i], tag, rt);
+        }
+        if (evalid[q]) {
+          const int t = (dir && active) ? (eL[q] - 1 - s) : s;
+          float* po = a.out + ((size_t)(row0 + erow[q]) * T + t) * 2 * H + dir * H + u0;
+          if constexpr (UPW == 4) *reinterpret_cast<float4*>(po) = active ? make_float4(nv[0], nv[1], nv[2], nv[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          else *reinterpret_cast<float2*>(po) = active ? make_float2(nv[0], nv[1]) : make_float2(0.f, 0.f);
         }
       }
     }
     GX_STAMP(6);
-    dx_gather<RG, GX_H, false, GX_H>(X + RG * H, tag, hs, 0, 0, 0, tid, rt);
+    dx_gather<RG, GX_H, false, GX_H, NT>(X + RG * H, tag, hs, 0, 0, 0, tid, rt);
     GX_STAMP(7);
     if (sb == GX_BLK / 2 && s > GX_BLK) blk_store(ring ^ 1);     // ... lands half a block later in the slot the previous block vacated
     GX_STAMP(8);

@@ -301,16 +301,16 @@ __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsign
 }
 // all-gather of a published [RG][N] vector into the LDS state vector at column offset `off` (N a power of two);
 // RES: dst2[r][n] = value + res[r][n] as well (ResidualWrapper output, tacotron.py:172)
-template <int RG, int N, bool RES, int LD = DXS_LD>
+template <int RG, int N, bool RES, int LD = DXS_LD, int NT = DX_NT>
 __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float* st, int off, int off_res, int off2, int tid, DxRt& rt) {
-  constexpr int NI = (RG * N + DX_NT - 1) / DX_NT;
-  const bool act = (RG * N >= DX_NT) || tid < RG * N;
+  constexpr int NI = (RG * N + NT - 1) / NT;
+  const bool act = (RG * N >= NT) || tid < RG * N;
   if (act) {
     float v[NI];
-    dx_poll<NI>(X + tid, DX_NT, tag, v, rt);
+    dx_poll<NI>(X + tid, NT, tag, v, rt);
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
-      const int i = u * DX_NT + tid;
+      const int i = u * NT + tid;
       const int r = i / N, n = i % N;
       st[r * LD + off + n] = v[u];
       if (RES) st[r * LD + off2 + n] = v[u] + st[r * LD + off_res + n];
@@ -391,8 +391,8 @@ __device__ __forceinline__ void dx_normalise_lds(float* sc, float* tmp, float* t
   }
 }
 
-// Census of a persistent launch of 256 workgroups: every workgroup reports the XCD it runs on (HW_REG_XCC_ID) and takes the next
-// slot there; when all have arrived and every XCD hosts exactly 32 of them, the XCD-local protocol is used (exchange stores stay
+// Census of a persistent launch of 256 (or 512: two per CU) workgroups: every workgroup reports the XCD it runs on (HW_REG_XCC_ID)
+// and takes the next slot there; when all have arrived and every XCD hosts exactly gridDim.x / 8 of them, the XCD-local protocol is used (exchange stores stay
 // in the XCD's L2) and a workgroup's place is (xcc, slot); otherwise -- or with force_wt -- places follow blockIdx and the stores
 // are write-through.  out[0] = xcc or blockIdx % 8, out[1] = slot (0..31) or blockIdx / 8, out[2] = write-through?, out[3] = failed?
 // errw[info0..info0+8] report the protocol and the per-XCD counts to the host.  Called by all threads; ends with a barrier.
@@ -408,7 +408,7 @@ __device__ __forceinline__ void dx_census(dx_gu32* ctl, dx_gu32* errw, int force
     }
     bool even = ok;
     for (int i = 0; i < DX_NGROUP; ++i)
-      even = even && (__hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)DX_GROUP);
+      even = even && (__hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x / DX_NGROUP);
     const bool fast = even && !force_wt;
     if (!ok) __hip_atomic_store(errw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[0] = fast ? (int)xcc : (int)(blockIdx.x & 7);

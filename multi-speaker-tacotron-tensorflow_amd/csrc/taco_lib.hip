@@ -101,7 +101,7 @@ struct Cbhg {
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
-  size_t gx_pack[2] = {0, 0};                      // per-thread weight packs of k_bigru_xcd (taco_bigru_xcd.h), H = 256 only
+  size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
                                                    // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
 };
@@ -502,20 +502,25 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
             }
         c.res_g2p[dir] = arena_put(m, g2p.data(), g2p.size());
         c.res_c1p[dir] = arena_put(m, c1p.data(), c1p.size());
-        if (!m->tp) {   // k_bigru_xcd: member mem, wave w own units 16 mem + 2w (+1); lane l holds h rows 4l..4l+3 of r, u (both units), then c
-          std::vector<float> gp((size_t)GX_MEMBERS * GX_NREG * DX_NT, 0.f);
-          for (int mem = 0; mem < GX_MEMBERS; ++mem)
-            for (int tid = 0; tid < DX_NT; ++tid) {
-              const int w = tid >> 6, l = tid & 63, ua = mem * 16 + 2 * w;
-              for (int e = 0; e < 4; ++e) {
-                const size_t kr = (size_t)(I + 4 * l + e);
-                auto put = [&](int reg, float v) { gp[((size_t)mem * GX_NREG + reg) * DX_NT + tid] = v; };
-                put(0 + e, gk[kr * 2 * H + ua]);      put(4 + e, gk[kr * 2 * H + H + ua]);          // r_a, u_a
-                put(8 + e, gk[kr * 2 * H + ua + 1]);  put(12 + e, gk[kr * 2 * H + H + ua + 1]);     // r_b, u_b
-                put(16 + e, ck[kr * H + ua]);         put(20 + e, ck[kr * H + ua + 1]);             // c_a, c_b
+        if (!m->tp) {   // k_bigru_xcd<RG, NWV>: member mem, wave w owns units 16 mem + UPW w .. + UPW - 1 (UPW = 16 / NWV); lane l holds
+                        // h rows 4l..4l+3 of the columns r_0, u_0, r_1, u_1, ... and then of the candidates c_0, c_1, ...
+          for (int nwv = 8; nwv >= 4; nwv -= 4) {
+            const int NT = 64 * nwv, UPW = 16 / nwv, NREG = gx_nreg(nwv);
+            std::vector<float> gp((size_t)GX_MEMBERS * NREG * NT, 0.f);
+            for (int mem = 0; mem < GX_MEMBERS; ++mem)
+              for (int tid = 0; tid < NT; ++tid) {
+                const int w = tid >> 6, l = tid & 63, u0 = mem * 16 + UPW * w;
+                for (int e = 0; e < 4; ++e) {
+                  const size_t kr = (size_t)(I + 4 * l + e);
+                  auto put = [&](int reg, float v) { gp[((size_t)mem * NREG + reg) * NT + tid] = v; };
+                  for (int i = 0; i < UPW; ++i) {
+                    put(8 * i + e, gk[kr * 2 * H + u0 + i]);  put(8 * i + 4 + e, gk[kr * 2 * H + H + u0 + i]);   // r_i, u_i
+                    put(8 * UPW + 4 * i + e, ck[kr * H + u0 + i]);                                              // c_i
+                  }
+                }
               }
-            }
-          c.gx_pack[dir] = arena_put(m, gp.data(), gp.size());
+            (nwv == 8 ? c.gx_pack : c.gx_pack4)[dir] = arena_put(m, gp.data(), gp.size());
+          }
         }
       } }
   }
@@ -763,7 +768,7 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
   w.hi0 = cv.f(M * c.rnn); w.hi1 = cv.f(M * c.rnn);
   w.xproj = cv.f(M * 6 * c.rnn);
   w.h = cv.f((size_t)2 * B * c.rnn); w.rh = cv.f((size_t)2 * B * c.rnn); w.u = cv.f((size_t)2 * B * c.rnn);
-  w.gxbuf_bytes = gx_xbuf_granules(8) * sizeof(unsigned long long);     // k_bigru_xcd exchange granules (sized for 8 rows per group)
+  w.gxbuf_bytes = gx_xbuf_granules(16, 8) * sizeof(unsigned long long);  // k_bigru_xcd exchange granules (16 groups x 8 rows = 32 groups x 4 rows)
   w.gxbuf = (unsigned long long*)cv.raw(w.gxbuf_bytes);
   w.gxctl = (unsigned*)cv.raw(256);
 }
@@ -791,24 +796,36 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
-  if (m->persist == 1 && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 8 * (GX_NGROUP / 2) && T >= 2) {
-    // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h)
+  if ((m->persist == 1 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2) {
+    // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
+    // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
+    // clocks per step at C2): the phases of a step are chains of dependent instructions, a wave alone on its SIMD is no faster
+    const int NWV = m->persist == 9 ? 4 : 8, rowgroups = gx_ngroups(NWV) / 2;
     GxArgs a; memset(&a, 0, sizeof a);
-    a.wpack0 = AP(m, c.gx_pack[0]); a.wpack1 = AP(m, c.gx_pack[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
+    const size_t* pk = NWV == 8 ? c.gx_pack : c.gx_pack4;
+    a.wpack0 = AP(m, pk[0]); a.wpack1 = AP(m, pk[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
     a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = m->d_trace; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
     int RG = 1;
-    while (RG < 8 && RG * (GX_NGROUP / 2) < B) RG *= 2;
+    while (RG * rowgroups < B) RG *= 2;
     // granules and census words are carved back to back: one fill launch covers both
     HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
-    // the kernel needs only a few KB of LDS and ~70 VGPRs: asking for more than half of the CU's LDS keeps the dispatcher from
-    // stacking two of the 256 workgroups on one CU (the census checks placement per XCD, not per CU)
-    const size_t lds = std::max(gx_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);
-    const dim3 grid(DX_NGROUP * DX_GROUP), blk(DX_NT);
-    switch (RG) {
-      case 1: hipLaunchKernelGGL((k_bigru_xcd<1>), grid, blk, lds, st, a); break;
-      case 2: hipLaunchKernelGGL((k_bigru_xcd<2>), grid, blk, lds, st, a); break;
-      case 4: hipLaunchKernelGGL((k_bigru_xcd<4>), grid, blk, lds, st, a); break;
-      default: hipLaunchKernelGGL((k_bigru_xcd<8>), grid, blk, lds, st, a); break;
+    // the kernel needs only a few KB of LDS and < 110 VGPRs: the LDS request is what fixes the number of workgroups a CU takes
+    // (one of 96 KB, or two of 72 KB), so that all of them are resident at once (the census checks placement per XCD, not per CU)
+    const size_t lds = std::max(gx_lds_floats(RG) * sizeof(float), (size_t)(NWV == 8 ? 96 : 72) * 1024);
+    const dim3 grid(gx_ngroups(NWV) * GX_MEMBERS), blk(64 * NWV);
+    if (NWV == 8) {
+      switch (RG) {
+        case 1: hipLaunchKernelGGL((k_bigru_xcd<1, 8>), grid, blk, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_bigru_xcd<2, 8>), grid, blk, lds, st, a); break;
+        case 4: hipLaunchKernelGGL((k_bigru_xcd<4, 8>), grid, blk, lds, st, a); break;
+        default: hipLaunchKernelGGL((k_bigru_xcd<8, 8>), grid, blk, lds, st, a); break;
+      }
+    } else {
+      switch (RG) {
+        case 1: hipLaunchKernelGGL((k_bigru_xcd<1, 4>), grid, blk, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((k_bigru_xcd<2, 4>), grid, blk, lds, st, a); break;
+        default: hipLaunchKernelGGL((k_bigru_xcd<4, 4>), grid, blk, lds, st, a); break;
+      }
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1549,10 +1566,13 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

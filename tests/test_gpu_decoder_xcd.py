@@ -207,7 +207,7 @@ def test_post_net_scan_spread_over_the_chip(B):
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
     got = {}
-    for persist in (1, 1, 7):
+    for persist in (1, 1, 9, 7):        # 1: one 8-wave workgroup per CU (default); 9: two 4-wave workgroups per CU; 7: one CU per chain
         m._lib.taco_debug_set_persistent(m._handle, persist)
         for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
             out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
@@ -223,3 +223,4 @@ def test_post_net_scan_spread_over_the_chip(B):
         assert np.array_equal(a, b), "k_bigru_xcd is not bit-repeatable (%s)" % tag
         assert maxabs(a, ref) < 1e-4, tag
         assert maxabs(a, got[(7, tag)][0]) < 2e-5, tag
+        assert maxabs(got[(9, tag)][0], ref) < 1e-4 and maxabs(a, got[(9, tag)][0]) < 2e-5, tag

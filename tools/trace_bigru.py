@@ -5,9 +5,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, taco_amd
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+PERSIST = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # 1: one 8-wave workgroup per CU (default); 9: two 4-wave workgroups per CU
 hp = taco_amd.hparams.copy(max_iters=128)
 m = taco_amd.create_model(hp); m.initialize(None, None, 1, None)
 L = m._lib
+L.taco_debug_set_persistent(m._handle, PERSIST)
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr() if t is not None else None)
 x = torch.randn(B, T, 256, device="cuda") * 0.3; out = torch.empty(B, T, 512, device="cuda")
@@ -23,6 +25,6 @@ tr = m.decoder_trace(True, read=True); m.decoder_trace(False)
 names = ["gates pass+reduce", "gates epilogue+publish", "poll r*h", "barrier", "cand pass+reduce", "cand epilogue+publish+store", "poll h'", "x-part fetch issue", "barrier"]
 d = np.diff(tr[:, :10], axis=1).astype(np.float64)
 step = np.median((tr[1:, 0] - tr[:-1, 0]).astype(np.float64))
-print("B=%d T=%d: %.1f us total (GEMM + scan), step = %.0f clocks" % (B, T, us, step))
+print("B=%d T=%d geometry %d: %.1f us total (GEMM + scan), step = %.0f clocks" % (B, T, PERSIST, us, step))
 med = np.median(d[1:], axis=0)
 print("  " + "  ".join("%s %.0f" % (n, c) for n, c in zip(names, med)) + "   (clocks; ~2.1-2.3 per ns)")
