@@ -147,14 +147,20 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
       dx_pass<0, 2 * UPW, RG, NREG, GX_H>(W, hs, lane, acc);
       dx_reduce<2 * UPW, RG>(acc, sm, lane);
       GX_STAMP(1);
+      // straight-line epilogue: all sigmoids first (independent chains interleave), then all stores behind one branch
+      float rh[RL][UPW];
 #pragma unroll
       for (int q = 0; q < RL; ++q)
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
           const float rr = dx_sigmoid_fast(sm[2 * i][q] + x0[q][0][i]);
           gv[q][i] = dx_sigmoid_fast(sm[2 * i + 1][q] + x0[q][1][i]);
-          if (epl) dx_publish(X + erow[q] * H + u0 + i, rr * hv[q][i], tag, rt);
+          rh[q][i] = rr * hv[q][i];
         }
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) dx_publish_n<UPW>(X + erow[q] * H + u0, 1, rh[q], tag, rt);
+      }
     }
     GX_STAMP(2);
     dx_gather<RG, GX_H, false, GX_H, NT>(X, tag, xs, 0, 0, 0, tid, rt);
@@ -168,23 +174,31 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
       dx_pass<8 * UPW, UPW, RG, NREG, GX_H>(W, xs, lane, acc);
       dx_reduce<UPW, RG>(acc, sm, lane);
       GX_STAMP(5);
+      float nv[RL][UPW];
+      bool active[RL];
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const bool active = s < eL[q];                       // A.7: row active iff s < L; forward t = s, backward t = L-1-s
-        float nv[UPW];
+        active[q] = s < eL[q];                               // A.7: row active iff s < L; forward t = s, backward t = L-1-s
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
           const float cc = taco_tanh_fast(sm[i][q] + x0[q][2][i]);
-          nv[i] = active ? gv[q][i] * hv[q][i] + (1.f - gv[q][i]) * cc : hv[q][i];
-          if (epl) dx_publish(X + RG * H + erow[q] * H + u0 + i, nv[i], tag, rt);
-        }
-        if (evalid[q]) {
-          const int t = (dir && active) ? (eL[q] - 1 - s) : s;
-          float* po = a.out + ((size_t)(row0 + erow[q]) * T + t) * 2 * H + dir * H + u0;
-          if constexpr (UPW == 4) *reinterpret_cast<float4*>(po) = active ? make_float4(nv[0], nv[1], nv[2], nv[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          else *reinterpret_cast<float2*>(po) = active ? make_float2(nv[0], nv[1]) : make_float2(0.f, 0.f);
+          float blend = gv[q][i] * hv[q][i] + (1.f - gv[q][i]) * cc;
+          DX_PIN(blend);
+          nv[q][i] = active[q] ? blend : hv[q][i];
         }
       }
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) dx_publish_n<UPW>(X + RG * H + erow[q] * H + u0, 1, nv[q], tag, rt);
+      }
+#pragma unroll
+      for (int q = 0; q < RL; ++q)
+        if (evalid[q]) {
+          const int t = (dir && active[q]) ? (eL[q] - 1 - s) : s;
+          float* po = a.out + ((size_t)(row0 + erow[q]) * T + t) * 2 * H + dir * H + u0;
+          if constexpr (UPW == 4) *reinterpret_cast<float4*>(po) = active[q] ? make_float4(nv[q][0], nv[q][1], nv[q][2], nv[q][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          else *reinterpret_cast<float2*>(po) = active[q] ? make_float2(nv[q][0], nv[q][1]) : make_float2(0.f, 0.f);
+        }
     }
     GX_STAMP(6);
     dx_gather<RG, GX_H, false, GX_H, NT>(X + RG * H, tag, hs, 0, 0, 0, tid, rt);

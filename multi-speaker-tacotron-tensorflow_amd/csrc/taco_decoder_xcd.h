@@ -273,6 +273,24 @@ __device__ __forceinline__ void dx_publish(dx_gu64* p, float v, unsigned tag, co
   if (rt.wt) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
   else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // sc0: stays in this XCD's L2
 }
+// N granules of one lane at once (p + u*stride): ONE uniform branch on the protocol around all stores, so that the epilogue that
+// produced the values stays a single basic block (a branch per value kept the compiler from interleaving the exp/rcp chains of
+// independent units)
+template <int N>
+__device__ __forceinline__ void dx_publish_n(dx_gu64* p, int stride, const float (&v)[N], unsigned tag, const DxRt& rt) {
+  unsigned long long g[N];
+#pragma unroll
+  for (int u = 0; u < N; ++u) g[u] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v[u]);
+  if (rt.wt) {
+#pragma unroll
+    for (int u = 0; u < N; ++u) __hip_atomic_store(p + u * stride, g[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+#pragma unroll
+    for (int u = 0; u < N; ++u) __hip_atomic_store(p + u * stride, g[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+// keeps a value's computation where it is written (LLVM otherwise sinks an expensive operand of a select into a branch)
+#define DX_PIN(x) asm("" : "+v"(x))
 // Poll N granules (p0 + u*stride) until every one carries `tag` (L1-bypassing loads).  All N are re-requested together on every
 // round, so a late producer costs one L2 round trip after its store lands, not one per granule.  Bounded.
 template <int N>
