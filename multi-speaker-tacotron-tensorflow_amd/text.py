@@ -21,7 +21,7 @@ JAMO_TAILS = "".join(chr(c) for c in range(0x11A8, 0x11C3))
 symbols = PAD + EOS + JAMO_LEADS + JAMO_VOWELS + JAMO_TAILS + PUNC + SPACE
 _symbol_to_id = {s: i for i, s in enumerate(symbols)}
 _id_to_symbol = {i: s for i, s in enumerate(symbols)}
-_curly = re.compile(r"(.*?)\{(.+?)\}(.*)", re.S)
+_BRACED_SPAN = re.compile(r"\{.+?\}", re.S)
 _HANGUL0, _HANGUL1 = 0xAC00, 0xD7A3
 
 
@@ -60,26 +60,17 @@ def jamo_to_korean(text):
     return "".join(out)
 
 
-def _symbols_to_sequence(chars):
-    return [_symbol_to_id[s] for s in chars if s in _symbol_to_id and s != PAD and s != EOS]      # _should_keep_symbol
-
-
 def text_to_sequence(text, normalizer=None, as_token=False):
-    """ids (int32) of `text`, EOS appended.  `{...}` spans are ARPAbet in the reference; its Korean symbol table has no ARPAbet
-    entries, so their content maps to nothing."""
+    """ids (int32) of `text`, EOS appended (text/__init__.py:23-58 with the korean cleaner).  A `{...}` span is ARPAbet in the
+    reference; its Korean symbol table has no ARPAbet entries, so a span contributes nothing -- the text is cut at the spans and
+    every piece outside them is normalised and decomposed on its own, as the reference cleans piece by piece."""
     norm = (lambda s: s.strip()) if normalizer is None else normalizer
-    seq = []
-    while len(text):
-        m = _curly.match(text)
-        if not m:
-            seq += _symbols_to_sequence(hangul_to_jamo(norm(text)))
-            break
-        seq += _symbols_to_sequence(hangul_to_jamo(norm(m.group(1))))
-        text = m.group(3)
-    seq.append(_symbol_to_id[EOS])
+    ids = [_symbol_to_id[ch] for piece in _BRACED_SPAN.split(text) if piece
+           for ch in hangul_to_jamo(norm(piece)) if ch in _symbol_to_id and ch not in (PAD, EOS)]
+    ids.append(_symbol_to_id[EOS])
     if as_token:
-        return sequence_to_text(seq, combine_jamo=True)
-    return np.array(seq, dtype=np.int32)
+        return sequence_to_text(ids, combine_jamo=True)
+    return np.array(ids, dtype=np.int32)
 
 
 def sequence_to_text(sequence, skip_eos_and_pad=False, combine_jamo=False):

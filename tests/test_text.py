@@ -125,3 +125,16 @@ def test_korean_normaliser_sentences():
         p = os.path.join(d, "dict.json")
         json.dump({"english": {"idol": "아이돌"}, "phrases": {}}, open(p, "w", encoding="utf-8"))
         assert K.load_dictionaries(p)("idol LG") == "아이돌 엘지"
+
+
+def test_braced_spans_contribute_nothing_and_pieces_are_cleaned_separately():
+    """text/__init__.py:40-58: `{...}` is ARPAbet, which the Korean symbol table does not hold; unmatched or empty braces are ordinary
+    (unknown) characters and disappear with them."""
+    from taco_amd import text as T
+    plain = T.text_to_sequence("안녕하세요")
+    assert np.array_equal(T.text_to_sequence("안녕{HH AW1 S}하세요"), plain)
+    assert np.array_equal(T.text_to_sequence("안녕{}하세요"), plain) and np.array_equal(T.text_to_sequence("안녕{하세요"), plain)
+    assert T.text_to_sequence("").tolist() == [T._symbol_to_id[T.EOS]]
+    seen = []
+    T.text_to_sequence("가{X}나{Y}다", normalizer=lambda s: (seen.append(s), s)[1])
+    assert seen == ["가", "나", "다"]
