@@ -391,8 +391,7 @@ def main():
         # (iv) the launch-per-stage engine of round 1 (decoder and scans as chains of small launches that leave most CUs idle), with
         # four forwards in flight to fill them: higher throughput than it has latency to show for
         if args.decoder_engine != 0:
-            model.set_decoder_engine(0)
-            p3 = model.plan_pool(B, T_in, n, lanes=4, coalesce=1)
+            p3 = model.plan_pool(B, T_in, n, lanes=4, coalesce=1, engine="launch")
             fill(p3, 1)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             thr = B * n * r / timed_pool(p3, 4, 3 * ksteps)
@@ -402,7 +401,6 @@ def main():
             companions["launch_per_stage_engine_4_lanes"] = {"mel_frames_per_s": thr, "forwards_in_flight": 4,
                                                              "forward_latency_ms_alone": e0.elapsed_time(e1) / 2}
             p3.close()
-            model.set_decoder_engine(args.decoder_engine)
         model._plans.clear()
     if rank == 0:
         frames = world * B * n * r * args.steps
@@ -422,7 +420,8 @@ def main():
                                    % (args.workload, B, T_in, n * r, r, mt),
                        "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
                        "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, BiGRU scans and the decoder loop in exact fp32 (max err vs float64 oracle 3.4e-6)",
-                       "decoder_engine": {0: "launch per stage", 1: "persistent XCD-local (csrc/taco_decoder_xcd.h)", 2: "persistent, write-through exchanges"}[args.decoder_engine],
+                       "decoder_engine": "launch per stage" if pool.engine != "persistent" else
+                                         {1: "persistent XCD-local (csrc/taco_decoder_xcd.h)", 2: "persistent, write-through exchanges"}[args.decoder_engine],
                        "launch": "eager" if args.eager else "hipGraph plan (%d nodes)" % plan.num_nodes,
                        "forwards_in_flight": lanes, "requests_per_forward": co, "forward_latency_ms_alone": latency_ms},
             "roofline": {"bound": "hbm", "achieved": abytes / fwd_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

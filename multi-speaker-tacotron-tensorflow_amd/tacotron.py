@@ -110,16 +110,18 @@ class PlanPool(object):
     """`lanes` independent forwards of one shape in flight, each with its own hipGraph plan, buffers and
     HIP stream.
 
-    The decoder loop and the BiGRU scans are chains of small dependent kernels that occupy a few dozen of
-    the 256 CUs; a second, third and fourth forward running beside them use CUs that would otherwise idle.
-    Measured on MI355X at C2 (bench.py --lanes N): 9.7 ms/forward with one lane, 3.6 with four (the default number of
-    hardware queues; 12.5 / 7.0 / 4.4 for 1 / 2 / 4 lanes when this was introduced); more lanes than hardware queues is slower.
-    The model object is read-only during a forward, so lanes share it.
+    Two engines, two ways to use the chip.  The persistent engine (one whole-chip launch for the decoder loop, one
+    for the post-net scan) finishes a C2 forward in 3.6 ms but owns every CU while it runs: forwards of different lanes cannot
+    overlap, and two whole-chip kernels dispatched together can starve each other (the placement census then times out into the
+    slow protocol or raises a device error).  The launch-per-stage engine leaves most CUs idle per forward (8.6 ms alone) and is
+    the one several lanes can fill (4 lanes: 3.1 ms per forward).  `engine="auto"` therefore captures the plans of a one-lane pool
+    with the model's current engine and the plans of a multi-lane pool with the launch-per-stage engine; "persistent" / "launch"
+    force one.  The model object is read-only during a forward, so lanes share it.
 
     The reference serves one `sess.run` at a time (synthesizer.py:166-167); this is the same call with
     several requests outstanding.  submit() enqueues and returns immediately; result() waits for that lane."""
 
-    def __init__(self, model, B, T_in, n_steps=None, lanes=4, coalesce=1):
+    def __init__(self, model, B, T_in, n_steps=None, lanes=1, coalesce=1, engine="auto"):
         """coalesce > 1: every lane's plan serves `coalesce` requests of B rows at once (one forward over coalesce*B rows: rows are
         independent at inference, and the decoder stages and scans cost almost the same for twice the rows).  submit() then
         returns a ticket (lane, slot), the lane is launched when its last slot is filled (or by flush()), and result(ticket)
@@ -129,6 +131,16 @@ class PlanPool(object):
             raise RuntimeError("initialize() must be called first")
         if lanes < 1 or coalesce < 1:
             raise ValueError("lanes and coalesce must be >= 1")
+        if engine not in ("auto", "persistent", "launch"):
+            raise ValueError("engine must be 'auto', 'persistent' or 'launch'")
+        current = getattr(model, "_decoder_engine", (1, 0))
+        if engine == "launch" or (engine == "auto" and lanes > 1):
+            capture_with = (0, 0)
+        elif engine == "persistent" and current[0] == 0:
+            capture_with = (1, 0)
+        else:
+            capture_with = current
+        self.engine = "launch-per-stage" if capture_with[0] == 0 else "persistent"
         n = model._hparams.max_iters if n_steps is None else n_steps
         self.model, self.B, self.T_in, self.n, self.lanes, self.coalesce = model, B, T_in, n, lanes, coalesce
         self.streams, self.plans, self.done, self.pending = [], [], [], []
@@ -137,14 +149,20 @@ class PlanPool(object):
         self.slot_stop = []
         with torch.cuda.device(model.device):
             self.streams = _concurrent_streams(model.device, lanes)
-            for st in self.streams:
-                with torch.cuda.stream(st):
-                    self.plans.append(_Plan(model, B * coalesce, T_in, n, False))
-                    self.plans[-1].launch()      # first replay uploads the graph: keep that out of the serving path
-                self.done.append(torch.cuda.Event())
-                self.pending.append(False)
-                self.slot_stop.append(torch.zeros((coalesce,), dtype=torch.int32, device=model.device))
-            torch.cuda.synchronize()
+            if capture_with != current:       # a plan keeps the engine it was captured with
+                _lib.check(model._lib.taco_debug_set_decoder_persist(model._handle, *capture_with))
+            try:
+                for st in self.streams:
+                    with torch.cuda.stream(st):
+                        self.plans.append(_Plan(model, B * coalesce, T_in, n, False))
+                        self.plans[-1].launch()      # first replay uploads the graph: keep that out of the serving path
+                    self.done.append(torch.cuda.Event())
+                    self.pending.append(False)
+                    self.slot_stop.append(torch.zeros((coalesce,), dtype=torch.int32, device=model.device))
+                torch.cuda.synchronize()
+            finally:
+                if capture_with != current:
+                    _lib.check(model._lib.taco_debug_set_decoder_persist(model._handle, *current))
         self._next = 0
         self._filling = None
 
@@ -416,9 +434,9 @@ class Tacotron(object):
         self._plans[key] = plan          # (re)inserted last = most recently used
         return plan
 
-    def plan_pool(self, B, T_in, n_steps=None, lanes=4, coalesce=1):
+    def plan_pool(self, B, T_in, n_steps=None, lanes=1, coalesce=1, engine="auto"):
         """`lanes` forwards of this shape in flight at once, each serving `coalesce` requests of B rows (PlanPool)."""
-        return PlanPool(self, B, T_in, n_steps, lanes, coalesce)
+        return PlanPool(self, B, T_in, n_steps, lanes, coalesce, engine)
 
     def run(self, inputs=None, input_lengths=None, speaker_id=None, manual_alignments=None,
             is_manual_attention=None, n_steps=None, honor_stop=True):
@@ -521,6 +539,7 @@ class Tacotron(object):
         """Decoder loop engine: 1 = one persistent weight-stationary launch when the configuration fits (default), 0 = one launch per
         stage, 2 = persistent with write-through exchanges.  Cached plans are dropped (they captured the previous engine)."""
         _lib.check(self._lib.taco_debug_set_decoder_persist(self._handle, int(mode), int(rows_per_group)))
+        self._decoder_engine = (int(mode), int(rows_per_group))
         self._plans.clear()
 
     def decoder_engine_info(self):

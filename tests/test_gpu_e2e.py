@@ -346,6 +346,7 @@ def test_plan_pool_lanes_are_independent_and_exact(mt, ns):
         reqs.append((ids, L, spk))
     alone = [_run(m, ids, L, spk, honor_stop=False) for ids, L, spk in reqs]
     pool = m.plan_pool(B, T_in, lanes=4)
+    assert pool.engine == "launch-per-stage"          # whole-chip persistent kernels do not share the chip: multi-lane pools avoid them
     got = [None] * len(reqs)
     for base in (0, 4):
         lanes = [pool.submit(*reqs[base + k]) for k in range(4)]
@@ -381,6 +382,7 @@ def test_plan_pool_coalesces_requests_into_one_forward(mt, ns):
         spk = ((np.arange(B) + i) % ns).astype(np.int32) if ns > 1 else None
         reqs.append((ids, L, spk))
     single = m.plan_pool(B, T_in, lanes=1)
+    assert single.engine == "persistent" and m.plan_pool(B, T_in, lanes=1, engine="launch").engine == "launch-per-stage"
     alone = []
     for rq in reqs:
         r = single.result(single.submit(*rq))
