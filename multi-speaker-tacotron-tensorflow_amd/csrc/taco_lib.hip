@@ -1128,6 +1128,20 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   const bool dv = is_deepvoice(m);
   const int S = simple_S(m), ldc = As + D + S, np = hp.dec_prenet_n;   // ldc: row stride of [h_att | ctx | spk]
   const int Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
+  const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
+  const int dbgw = As + D + L * Hd;
+  HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
+  if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
+    // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
+    // vectors); the launch-per-stage loop below is the general path
+    TRY(dx_launch(m, st, enc_out, B, T_in, n, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr,
+                  dv ? spk->vec[4] : nullptr));
+    if (stop_step) {
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
   fill(nullptr, 0, w.zero, Mm);
   hipLaunchKernelGGL(k_copy2d, dim3(cdiv(B * D, 256)), dim3(256), 0, st, (const float*)nullptr, 0, w.ctx, ldc, B, D);
   if (S) {  // speaker_embed = embedding_lookup(table, speaker_id) (tacotron.py:44-49), parked behind ctx and behind the prenet output
@@ -1139,19 +1153,6 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   for (int i = 0; i < L; ++i) fill(dv ? spk->vec[3 + i] : nullptr, Hd, w.hd[i], Hd);
   hipLaunchKernelGGL(k_init_align, dim3(cdiv(B * T_in, 256)), dim3(256), 0, st, w.align, B, T_in, hp.attention_type == 2 ? 1 : 0);
   HIPCHK(hipGetLastError());
-  HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
-  const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
-  const int dbgw = As + D + L * Hd;
-  if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
-    // the whole loop as ONE persistent launch (taco_decoder_xcd.h); the launch-per-stage loop below is the general path
-    TRY(dx_launch(m, st, enc_out, B, T_in, n, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr,
-                  dv ? spk->vec[4] : nullptr));
-    if (stop_step) {
-      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
-      HIPCHK(hipGetLastError());
-    }
-    return 0;
-  }
   for (int t = 0; t < n; ++t) {
     // frame fed to the prenet: zeros at t=0 (helpers.py:70-72), else last of the r frames (helpers.py:31)
     const float* frame; int ldf;
