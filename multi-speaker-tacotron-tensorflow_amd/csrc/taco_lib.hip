@@ -1399,11 +1399,11 @@ int taco_model_finalize(taco_model* m) {
   m->emb = arena_put(m, T_(m, "embedding").data.data(), T_(m, "embedding").data.size());
   for (int i = 0; i < hp.enc_prenet_n; ++i) {
     const std::string n = "prenet/dense_" + std::to_string(i + 1);
-    m->enc_prenet.push_back(make_conv(m, n, false));
+    m->enc_prenet.push_back(make_conv(m, n, false, true, true));
   }
   make_cbhg(m, m->enc, "encoder_cbhg", hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_bank_size, hp.enc_bank_channels,
             hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width, true);
-  m->memory_layer = make_conv(m, "attention/memory_layer", false, false);
+  m->memory_layer = make_conv(m, "attention/memory_layer", false, false, true);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
             hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width, true);
   if (hp.num_speakers > 1 && hp.model_type == 1) {

@@ -47,12 +47,16 @@ def maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0
 
 
-def argmax_match(a_hip, a_ref, floor=1e-6):
+def argmax_match(a_hip, a_ref, floor=1e-6, tie=4e-6):
     """alignment argmax over the encoder axis must be identical wherever the reference's peak is
     above `floor` (below it the monotonic mass has leaked past the last encoder step and fp32/fp64
-    underflow differently); returns (n_checked, n_mismatch)."""
+    underflow differently); returns (n_checked, n_mismatch).  A step whose float64 peak and the value the HIP path picked differ
+    by less than `tie` of the peak is a tie at fp32 resolution (2^-23 per operation, a few operations deep) and no mismatch:
+    at C2 with tools/parity_margins.py's seed one of 2784 steps has its top two positions 1.3e-6 apart, and the exact-fp32 path
+    computes them EQUAL."""
     a_hip, a_ref = np.asarray(a_hip), np.asarray(a_ref)
     peak = a_ref.max(axis=1)
     sel = peak > floor
-    mism = (a_hip.argmax(axis=1) != a_ref.argmax(axis=1)) & sel
+    picked = np.take_along_axis(a_ref, a_hip.argmax(axis=1)[:, None, :], axis=1)[:, 0, :]     # the oracle's value where HIP peaks
+    mism = (a_hip.argmax(axis=1) != a_ref.argmax(axis=1)) & sel & ((peak - picked) > tie * peak)
     return int(sel.sum()), int(mism.sum())
