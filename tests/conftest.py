@@ -25,3 +25,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_device_memory(request):
+    """TACO_POISON=nan|big (opt-in): before every GPU test, fill a few GB of device memory with NaN / 3e38 and hand them back to
+    the caching allocator, so that a kernel reading workspace it never wrote sees garbage instead of a fresh process's zeros."""
+    mode = os.environ.get("TACO_POISON")
+    if mode and "gpu" in request.keywords:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+            x = torch.empty(int(os.environ.get("TACO_POISON_GB", "4")) << 30, dtype=torch.uint8, device="cuda").view(torch.float32)
+            x.fill_(float("nan") if mode == "nan" else 3.0e38)
+            torch.cuda.synchronize()
+            del x
+    yield
