@@ -234,13 +234,16 @@ int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params
  * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;
  * non-zero means the outputs of the affected forward are invalid. */
 int taco_model_device_errors(taco_model* m, int* out);
-/* test hook: 0 = per-step launches for the sequential loops, 1 (default) = persistent row-parallel kernels when they fit */
+/* test hook: 0 = per-step launches for the sequential loops, 1 (default) = the persistent kernels that fit (post-net scan: k_bigru_xcd);
+ * 2..7 select earlier scan kernels, 9 the two-workgroups-per-CU geometry of k_bigru_xcd (tests / A-B timing) */
 int taco_debug_set_persistent(taco_model* m, int on);
 
 /* test hook: on = 1 (default) runs the feed-forward GEMMs of inference on the bf16 matrix cores with 3-term split
  * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128,
  * 3 = 64x256 (2x2 waves), 4 = 64x64, 5 = 64x64 with four wave groups splitting K inside the workgroup, 7 = 64x256 by 1x8 waves,
- * 9 = 64x128 by 1x4 waves, 10 = tile 7 with two wave groups splitting K (auto picks 4 / 5 / 7 / 9 / 10) */
+ * 9 = 64x128 by 1x4 waves, 10 = tile 7 with two wave groups splitting K (auto picks 4 / 5 / 7 / 9 / 10).
+ * on bit 2 (on = 5): the point-wise tail of a CBHG ([dense ->] highway x depth -> BiGRU input projection; modules.py:72-96) runs as
+ * one launch per layer instead of ONE launch with the activations resident on the CU (csrc/taco_chain.h, the default with on = 1). */
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream

@@ -1,0 +1,240 @@
+// taco_chain.h -- the point-wise tail of a CBHG (modules.py:72-77 + the hoisted input projection of the BiGRU, :82-96) as ONE
+// launch: [dense ->] highway x depth -> BiGRU input projection, for a tile of 64 frames at a time.
+//
+// As separate launches (k_gemm_bf3) every link writes its [B*T, W] activation to HBM and the next one stages it again: 6 launches
+// and 5 round trips of 16 MB at the post-net of C2 for layers of only 4 GFLOP each (30 us per highway layer, 150 TF-equivalent).
+// Here a workgroup of 8 waves keeps the tile's activations on the CU from the first layer to the last:
+//   * the tile [64, W] lives in LDS as two bf16 planes (hi = bf16(x), lo = bf16(x - hi): the split-bf16 operand of k_gemm_bf3,
+//     same arithmetic, same weight packs) -- the A operand of every layer;
+//   * wave (wm, wn) owns rows 64/WM * wm .. and the 32 columns 32 wn .. of every W-wide layer, streams its weight fragments from
+//     the layer's pack (L2) one k16 step ahead, and keeps its own 32 x 32 (x TM) slice of the layer's fp32 output in registers:
+//     the highway carry  y = H*T + x*(1-T)  needs x exactly where the lane produced it one layer earlier;
+//   * between layers: barrier, the lanes write their outputs into the planes, barrier;
+//   * the last link (N = 6H columns) loops over column groups of W and stores straight to the projection buffer, the backward
+//     direction's columns time-reversed per row (tf.reverse_sequence, A.7) exactly as k_gemm_bf3's epilogue does.
+#pragma once
+#include "taco_kernels.h"
+
+#define CH_MAXL 8
+#define CH_BM 64
+enum { CH_DENSE = 0, CH_HIGHWAY = 1, CH_XPROJ = 2 };
+struct ChainLayer {
+  const unsigned short* bh; const unsigned short* bl; const unsigned short* bh2; const unsigned short* bl2;   // split-bf16 packs (pack_bf3)
+  const float* bias; const float* bias2;
+  int type, K16, NT, N, act;       // k16 steps of the layer's K (padded input width / 16), 32-column tiles in the pack, columns
+};
+struct ChainArgs {
+  const float* x; int ldx, Cin;    // input rows [M, ldx], Cin columns used
+  float* out; int ldo;             // projection output [M, ldo]
+  float* y; int ldy;               // optional: the last highway output [M, W] (null: not stored)
+  const int* rev_len; int rev_col0;
+  int M, T, nlayers;
+  ChainLayer L[CH_MAXL];
+};
+
+// one layer's K loop for the wave's TM row tiles and one 32-column tile (DUAL: two products that share the A fragments -- the H and
+// T matrices of a highway layer at the same column tile, or two column tiles nt, nt2 of one matrix): weight fragments (hi, lo) one
+// k16 step ahead in two register sets that swap roles (K16 is even: pack_bf3 pads K to a multiple of 32)
+template <int TM, int LDSW, bool DUAL>
+__device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned short* bhA, const unsigned short* blA, int nt,
+                                            const unsigned short* bhB, const unsigned short* blB, int nt2,
+                                            const unsigned short* xhi, const unsigned short* xlo, int row0,
+                                            int l31, int lh, f32x16 (&acc)[TM], f32x16 (&acc2)[TM]) {
+  auto boff = [&](int g, int t) { return ((((size_t)min(g, K16 - 1) * NT + t) * 2 + lh) * 32 + l31) * 8; };
+  uint4 ph, pl, ph2, pl2, qh, ql, qh2, ql2;
+  ph2 = pl2 = qh2 = ql2 = make_uint4(0, 0, 0, 0);
+  auto loadb = [&](int g, uint4& h, uint4& l, uint4& h2, uint4& l2) {
+    const size_t o = boff(g, nt);
+    h = *reinterpret_cast<const uint4*>(bhA + o); l = *reinterpret_cast<const uint4*>(blA + o);
+    if constexpr (DUAL) { const size_t o2 = boff(g, nt2); h2 = *reinterpret_cast<const uint4*>(bhB + o2); l2 = *reinterpret_cast<const uint4*>(blB + o2); }
+  };
+  auto mma = [&](int g, const uint4& h, const uint4& l, const uint4& h2, const uint4& l2) {
+    const bf16x8 bh = __builtin_bit_cast(bf16x8, h), bl = __builtin_bit_cast(bf16x8, l);
+    bf16x8 ah[TM], al[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int off = (row0 + tm * 32 + l31) * LDSW + 16 * g + 8 * lh;
+      ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xhi + off));
+      al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xlo + off));
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[tm], 0, 0, 0);      // small terms first
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[tm], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[tm], 0, 0, 0);
+    if constexpr (DUAL) {
+      const bf16x8 bh2 = __builtin_bit_cast(bf16x8, h2), bl2 = __builtin_bit_cast(bf16x8, l2);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc2[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh2, acc2[tm], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc2[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl2, acc2[tm], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) acc2[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh2, acc2[tm], 0, 0, 0);
+    }
+  };
+  loadb(0, ph, pl, ph2, pl2);
+  for (int g = 0; g < K16; g += 2) {
+    loadb(g + 1, qh, ql, qh2, ql2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(g, ph, pl, ph2, pl2);
+    __builtin_amdgcn_sched_barrier(0);
+    loadb(g + 2, ph, pl, ph2, pl2);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(g + 1, qh, ql, qh2, ql2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int W>
+__global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
+  constexpr int WN = W / 32, WM = 8 / WN, TM = CH_BM / 32 / WM;      // W = 256: 1 x 8 waves of 64 x 32; W = 128: 2 x 4 waves of 32 x 32
+  constexpr int LDSW = W + 8;                                          // bf16 elements per plane row: (W + 8) * 2 bytes = odd multiple of 16
+  extern __shared__ __attribute__((aligned(16))) unsigned short ch_smem[];
+  unsigned short* xhi = ch_smem;
+  unsigned short* xlo = ch_smem + CH_BM * LDSW;
+  struct { const float* x; float* out; float* y; const int* rev_len; int ldx, Cin, ldo, ldy, rev_col0, M, T, nlayers; } a =
+      {a_in.x, a_in.out, a_in.y, a_in.rev_len, a_in.ldx, a_in.Cin, a_in.ldo, a_in.ldy, a_in.rev_col0, a_in.M, a_in.T, a_in.nlayers};
+  PIN(a.x); PIN(a.out); PIN(a.y); PIN(a.rev_len); PIN(a.ldx); PIN(a.Cin); PIN(a.ldo); PIN(a.ldy); PIN(a.rev_col0); PIN(a.M); PIN(a.T);
+  PIN(a.nlayers);
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * CH_BM;
+
+  // ---- stage the input rows: fp32 -> (hi, lo) planes, zero padded to the first layer's K ----
+  {
+    const int K0 = a_in.L[0].K16 * 16;
+    for (int i = tid; i < CH_BM * (K0 / 4); i += 512) {
+      const int r = i / (K0 / 4), c = 4 * (i % (K0 / 4));
+      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = m0 + r;
+      if (row < a.M && c < a.Cin) {
+        const float* p = a.x + (size_t)row * a.ldx + c;
+        if (c + 3 < a.Cin && (a.ldx & 3) == 0) f = *reinterpret_cast<const float4*>(p);
+        else { f.x = p[0]; if (c + 1 < a.Cin) f.y = p[1]; if (c + 2 < a.Cin) f.z = p[2]; if (c + 3 < a.Cin) f.w = p[3]; }
+      }
+      uint2 h4, l4;
+      taco_split_bf16x4(f, h4, l4);
+      *reinterpret_cast<uint2*>(xhi + r * LDSW + c) = h4;
+      *reinterpret_cast<uint2*>(xlo + r * LDSW + c) = l4;
+    }
+  }
+  const int l31_outer = l31, lh_outer = lh;
+  const bool full = m0 + CH_BM <= a.M;         // every row of the tile exists: the stores need no guards (the common case)
+  float xreg[TM][16];                          // the lane's slice of the current activation in fp32 (highway carry)
+  bool have_x = false;
+  __syncthreads();
+
+  for (int li = 0; li < a.nlayers; ++li) {
+    const ChainLayer L = a_in.L[li];
+    // opaque per-layer copies of the lane coordinates: otherwise every address below (32 carry loads, 32 stores, 64 LDS writes per
+    // lane) is computed once before the loop and kept -- and spilled -- across all layers (same effect as in taco_decoder_xcd.h)
+    int l31 = l31_outer, lh = lh_outer;
+    asm volatile("" : "+v"(l31), "+v"(lh));
+    // row of the lane's C element r of row tile tm (C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+    auto rloc = [&](int tm, int r) { return (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh; };
+    const int col = wn * 32 + l31;
+    if (L.type == CH_XPROJ) {
+      // ---- last link: N = 6H columns in groups of W, stored straight to the projection buffer ----
+      const int ngroups = (L.N + W - 1) / W;
+      const int bb0 = m0 / a.T;                // a tile of 64 rows spans at most two batch rows when T >= 64
+      auto store_group = [&](int ng, const f32x16 (&acc)[TM]) {
+        const int ocol = ng * W + col;
+        if (ocol >= L.N) return;
+        const float bia = L.bias ? L.bias[ocol] : 0.f;
+        const bool rev = a.rev_col0 >= 0 && ocol >= a.rev_col0;
+        if (full && !rev) {
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            float* po = a.out + (size_t)(m0 + rloc(tm, 0)) * a.ldo + ocol;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = acc[tm][r] + bia;
+          }
+        } else {                               // the backward direction's columns go to the time-reversed row of the batch row
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = m0 + rloc(tm, r);
+              int orow = row;
+              if (rev) {
+                const int bb = a.T >= CH_BM ? bb0 + (row >= (bb0 + 1) * a.T ? 1 : 0) : row / a.T;
+                const int tt = row - bb * a.T, Lb = a.rev_len ? a.rev_len[min(bb, (a.M - 1) / a.T)] : a.T;
+                orow = tt < Lb ? bb * a.T + (Lb - 1 - tt) : row;
+              }
+              if (row < a.M) a.out[(size_t)orow * a.ldo + ocol] = acc[tm][r] + bia;
+            }
+        }
+      };
+      for (int ng = 0; ng < ngroups; ng += 2) {            // two column groups per pass share the A fragments
+        const int nt = min(ng * WN + wn, L.NT - 1), nt2 = min((ng + 1) * WN + wn, L.NT - 1);   // tiles past the pack are clamped, never stored
+        f32x16 acc[TM], acc2[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
+        ch_mma_loop<TM, LDSW, true>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        store_group(ng, acc);
+        if (ng + 1 < ngroups) store_group(ng + 1, acc2);
+      }
+      continue;
+    }
+    // ---- a W-wide hidden layer: dense or highway ----
+    const bool dual = L.type == CH_HIGHWAY;
+    if (dual && !have_x) {                     // a chain that starts with a highway layer: the carry comes from the input itself
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xreg[tm][r] = a.x[(size_t)min(m0 + rloc(tm, r), a.M - 1) * a.ldx + col];
+    }
+    have_x = true;
+    {
+      f32x16 acc[TM], acc2[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
+      const float bia = L.bias ? L.bias[col] : 0.f;
+      if (dual) {
+        const float bia2 = L.bias2 ? L.bias2[col] : 0.f;
+        ch_mma_loop<TM, LDSW, true>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {       // modules.py:105-120: H = relu(.), T = sigmoid(.), y = H*T + x*(1-T)
+            const float Hh = fmaxf(acc[tm][r] + bia, 0.f);
+            const float Tg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (acc2[tm][r] + bia2)));
+            xreg[tm][r] = Hh * Tg + xreg[tm][r] * (1.f - Tg);
+          }
+      } else {
+        ch_mma_loop<TM, LDSW, false>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        const bool relu = L.act == ACT_RELU;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float v = acc[tm][r] + bia; xreg[tm][r] = relu ? fmaxf(v, 0.f) : v; }
+      }
+    }
+    const bool last_hidden = (li + 1 == a.nlayers) || a_in.L[li + 1].type == CH_XPROJ;
+    if (last_hidden && a.y) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + rloc(tm, r);
+          if (row < a.M) a.y[(size_t)row * a.ldy + col] = xreg[tm][r];
+        }
+    }
+    __syncthreads();                            // every wave has read the planes of this layer
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float f = xreg[tm][r];
+        const unsigned hp = taco_pk_bf16(f, 0.f) & 0xffffu;
+        const unsigned lp = taco_pk_bf16(f - __uint_as_float(hp << 16), 0.f) & 0xffffu;
+        xhi[rloc(tm, r) * LDSW + col] = (unsigned short)hp;
+        xlo[rloc(tm, r) * LDSW + col] = (unsigned short)lp;
+      }
+    __syncthreads();
+  }
+}

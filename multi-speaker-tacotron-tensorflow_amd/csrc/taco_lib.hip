@@ -5,6 +5,7 @@
 #include "taco_kernels.h"
 #include "taco_decoder_xcd.h"
 #include "taco_bigru_xcd.h"
+#include "taco_chain.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
 #include "../../include/taco_abi.h"
@@ -140,6 +141,7 @@ struct taco_model {
   int persist = 1;             // use the persistent BiGRU kernel when it fits
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
+  int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
@@ -896,6 +898,39 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
   return 0;
 }
 
+// ---- the point-wise tail of a CBHG as one launch (taco_chain.h) ----
+static bool chain_fits(const Cbhg& c, int in_dim) {
+  const int W = c.rnn;
+  if (W != 128 && W != 256) return false;
+  if ((int)c.hw.size() != c.depth || c.depth + (c.has_dense ? 2 : 1) > CH_MAXL) return false;
+  if (c.has_dense) { if (!c.dense.bh || c.dense.cin != in_dim || c.dense.cin_pad16 > W || c.dense.N != W) return false; }
+  else if (in_dim != W) return false;
+  for (const ConvL& h : c.hw) if (!h.bh || !h.bh2 || h.cin != W || h.N != W) return false;
+  return c.xproj.bh && c.xproj.cin == W && c.xproj.N == 6 * W;
+}
+static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int in_dim, int M, int T, const int* lengths,
+                     const CbhgWs& w, const float** ff_out) {
+  ChainArgs a; memset(&a, 0, sizeof a);
+  a.x = x; a.ldx = in_dim; a.Cin = in_dim; a.out = w.xproj; a.ldo = 6 * c.rnn; a.rev_len = lengths; a.rev_col0 = 3 * c.rnn;
+  a.M = M; a.T = T;
+  if (ff_out) { a.y = w.hi0; a.ldy = c.rnn; *ff_out = w.hi0; }
+  auto add = [&](const ConvL& L, int type) {
+    const GemmVar& v = m->hvars[L.var_index];
+    ChainLayer& l = a.L[a.nlayers++];
+    l.bh = v.bh; l.bl = v.bl; l.bh2 = v.bh2; l.bl2 = v.bl2; l.bias = v.bias; l.bias2 = v.bias2;
+    l.type = type; l.K16 = v.K16; l.NT = v.NT; l.N = v.N; l.act = ACT_NONE;
+  };
+  if (c.has_dense) add(c.dense, CH_DENSE);
+  for (int i = 0; i < c.depth; ++i) add(c.hw[i], CH_HIGHWAY);
+  add(c.xproj, CH_XPROJ);
+  const dim3 grid(cdiv(M, CH_BM)), blk(512);
+  const size_t lds = (size_t)2 * CH_BM * (c.rnn + 8) * sizeof(unsigned short);
+  if (c.rnn == 256) hipLaunchKernelGGL((k_pointwise_chain<256>), grid, blk, lds, st, a);
+  else hipLaunchKernelGGL((k_pointwise_chain<128>), grid, blk, lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Feed-forward part of a CBHG (modules.py:27-77) with per-stage watermarks, so it can run chunk by chunk
 // behind a producer of its input frames (the decoder): every stage is advanced as far as the frames
 // available to it allow (a conv needs its right halo; the last chunk gets TF's zero padding).
@@ -911,7 +946,8 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
     if (nw > pg.w_bank) {
       GemmCall g; g.x = x; g.ldx = c.in_dim; g.M = M; g.T = T; g.act = ACT_RELU; g.out = w.bank; g.ldo = c.K * c.C;
       g.t_begin = pg.w_bank; g.t_len = nw - pg.w_bank;
-      // (dispatching the widest kernels first -- blockIdx.z reversed -- was measured slower: encoder stage 0.47 vs 0.445 ms)
+      // (c.bank is ordered widest first, so the longest workgroups are dispatched first; narrowest first measured 0.47 vs 0.445 ms
+      // for the encoder stage)
       TRY(run_gemm(m, st, c.bank.data(), c.K, false, g));
       pg.w_bank = nw;
     } }
@@ -938,6 +974,12 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
   // point-wise chain: optional dense (modules.py:72-73), highway x depth (:76-77), hoisted BiGRU input projection
   const int wlast = pg.w_p[c.proj.size() - 1];
   const int t0 = pg.w_pt, tl = wlast - pg.w_pt;
+  if (m->bf3 && m->chain && m->force_cfg < 0 && !m->bf3_tn && t0 == 0 && tl == T && chain_fits(c, curd)) {
+    // the whole tail as ONE launch, activations resident on the CU from layer to layer (taco_chain.h)
+    TRY(run_chain(m, st, c, cur, curd, M, T, lengths, w, ff_out));
+    pg.w_pt = wlast;
+    return 0;
+  }
   if (c.has_dense) {
     if (tl > 0) { GemmCall d; d.x = cur; d.ldx = curd; d.M = M; d.T = T; d.out = w.hi0; d.ldo = c.rnn; d.t_begin = t0; d.t_len = tl;
       TRY(run_gemm(m, st, &c.dense, 1, false, d)); }
@@ -1568,6 +1610,7 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1613,7 +1656,8 @@ int taco_model_device_errors(taco_model* m, int* out) {
 
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
-  m->bf3 = on; m->bf3_tn = tile_n;
+  m->bf3 = (on & 1) != 0; m->bf3_tn = tile_n;
+  m->chain = (on & 4) ? 0 : 1;     // on = 5: split-bf16 GEMMs with one launch per point-wise layer (A/B of taco_chain.h)
   return 0;
 }
 

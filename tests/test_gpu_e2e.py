@@ -539,3 +539,34 @@ def test_split_attention_for_small_batches_is_the_same_function(atype, slices):
     got = _run(m, ids, L, manual_alignments=man, is_manual_attention=True, honor_stop=False)
     _check(got, O.forward(w, ohp, ids, L, manual_alignments=man, honor_stop=False), tol=2e-4)
     m._lib.taco_debug_set_att_split(m._handle, -1)
+
+
+@pytest.mark.parametrize("model_type,ns,B,T_in,n", [("single", 1, 3, 37, 5), ("deepvoice", 3, 5, 70, 3), ("single", 1, 2, 130, 2)])
+def test_pointwise_chain_kernel_matches_the_oracle_and_the_per_layer_path(model_type, ns, B, T_in, n):
+    """csrc/taco_chain.h: [dense ->] highway x 4 -> BiGRU input projection of a CBHG as ONE launch (modules.py:72-96).  Reference
+    widths (the kernel exists for widths 128 / 256), row counts that are not multiples of the 64-row tile, T below and above the
+    tile height (the time-reversed store of the backward direction crosses batch rows inside a tile), ragged lengths incl. 0,
+    the deepvoice residual in front of the encoder's highways: both CBHG stages against the float64 oracle, and the fused tail
+    against one launch per layer."""
+    import torch
+    ohp = O.OracleHParams(max_iters=n, model_type=model_type)
+    w = O.init_weights(ohp, ns, 911)
+    ids, L = O.synthetic_inputs(B, T_in, 912, ragged=True)
+    L = L.copy(); L[-1] = 0 if B > 2 else L[-1]
+    spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
+    taps = {}
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, taps=taps)
+    m = build_model(ohp, w, num_speakers=ns)
+    got = {}
+    for flag, name in ((1, "chain"), (5, "per-layer")):           # taco_debug_set_bf3 bit 2: one launch per point-wise layer
+        m._lib.taco_debug_set_bf3(m._handle, flag, 0)
+        enc = m.encoder(ids, L, spk)
+        lin, post = m.postnet(ref["mel"], return_post=True, speaker_id=spk)
+        torch.cuda.synchronize()
+        got[name] = (enc.cpu().numpy(), post.cpu().numpy(), lin.cpu().numpy())
+    m._lib.taco_debug_set_bf3(m._handle, 1, 0)
+    for name, (enc, post, lin) in got.items():
+        assert maxabs(enc, taps["encoder"]) < 1e-4, name
+        assert maxabs(post, taps["post"][..., :post.shape[-1]]) < 2e-4 and maxabs(lin, ref["linear"]) < 2e-4, name
+    for a, b in zip(got["chain"], got["per-layer"]):
+        assert maxabs(a, b) < 2e-5
