@@ -444,7 +444,9 @@ def test_C4_shard_shape_forward_and_properties():
     assert bool(torch.isfinite(g1).all())
     scale = float(g1.abs().max())
     rerun = float((g1 - g2).abs().max())
-    assert rerun < 1e-4 * scale, ("two runs of the same step differ beyond fp32-atomic summation order", rerun, scale)
+    # the weight gradients are sums of 16 K rows accumulated with fp32 atomics in whatever order the workgroups arrive: 24 reruns on one
+    # box spread between 0.5e-4 and 1.4e-4 of the largest gradient; a stale operand or a missed update would be of the order of the scale
+    assert rerun < 1e-3 * scale, ("two runs of the same step differ beyond fp32-atomic summation order", rerun, scale)
     trace = []
     for _ in range(5):
         _, lwc = tr.train_step(ids, L, mt, lt)
