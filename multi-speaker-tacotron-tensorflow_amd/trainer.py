@@ -66,6 +66,7 @@ class Trainer(object):
         self._capturing = False
         self._sync_cb = None
         self._sync_err = None
+        self.sync_exchanges = 0
         self.mel_outputs = self.linear_outputs = self.alignments = None
 
     # ---- data-parallel SyncBN ----
