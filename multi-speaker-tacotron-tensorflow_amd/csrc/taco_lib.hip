@@ -147,6 +147,7 @@ struct taco_model {
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
+  int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
   int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
   int dx_rows = 0;             // debug: force the rows per group (1,2,4,8); 0 = smallest that covers the batch
   long long* d_trace = nullptr;   // debug: phase stamps of group 0 / member 0 (taco_debug_decoder_trace)
@@ -798,7 +799,7 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
-  if ((m->persist == 1 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2) {
+  if ((m->persist == 1 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
     // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
     // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
     // clocks per step at C2): the phases of a step are chains of dependent instructions, a wave alone on its SIMD is no faster
@@ -1114,7 +1115,9 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
 }
 // persistent decoder: usable for this call?  (reference widths, no manual alignments / teacher forcing, the member's LDS fits)
 static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual, const float* teacher) {
-  if (!m->dx_mode || !m->dx_pack || manual || teacher || B > 8 * DX_NGROUP) return false;
+  // 256 workgroups, one per CU, all resident at once: only on a whole MI355X (a partition of it -- CPX / DPX modes -- or a smaller
+  // part would leave workgroups waiting for CUs held by workgroups that wait for them)
+  if (!m->dx_mode || !m->dx_pack || manual || teacher || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
   const int RG = dx_rows_per_group(m, B);
   return dx_lds_floats(RG, T_in) * sizeof(float) <= 160 * 1024;
 }
@@ -1438,6 +1441,7 @@ int taco_model_finalize(taco_model* m) {
     if (!m->raw.count(s.first) || !m->raw[s.first].set) return fail(TACO_ERR_STATE, "weight '%s' was never set", s.first.c_str());
   const taco_hparams& hp = m->hp;
   HIPCHK(hipSetDevice(m->device));
+  HIPCHK(hipDeviceGetAttribute(&m->cu_count, hipDeviceAttributeMultiprocessorCount, m->device));
   m->harena.clear(); m->hvars.clear();
   m->emb = arena_put(m, T_(m, "embedding").data.data(), T_(m, "embedding").data.size());
   for (int i = 0; i < hp.enc_prenet_n; ++i) {
@@ -1724,6 +1728,7 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
   unsigned v[16];
   HIPCHK(hipMemcpy(v, m->d_err + 8, sizeof v, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) out16[i] = (int)v[i];
+  out16[14] = m->cu_count;
   out16[15] = m->dx_pack ? 1 : 0;
   return 0;
 }

@@ -543,11 +543,12 @@ class Tacotron(object):
         self._plans.clear()
 
     def decoder_engine_info(self):
-        """After a forward (synchronises): {'protocol': 0 none / 1 XCD-local / 2 write-through, 'per_xcd': [...], 'has_pack': bool}."""
+        """After a forward (synchronises): {'protocol': 0 none / 1 XCD-local / 2 write-through, 'per_xcd': [...], 'has_pack': bool,
+        'compute_units': CUs of the device -- the whole-chip persistent kernels run only on 256 (an unpartitioned MI355X)}."""
         torch.cuda.synchronize(self.device)
         v = (C.c_int * 16)()
         _lib.check(self._lib.taco_debug_decoder_info(self._handle, v))
-        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15])}
+        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14])}
 
     def decoder_trace(self, enable=True, read=False):
         """Phase stamps (shader clocks) of group 0 / member 0 of the persistent decoder, first 8 steps x 16 slots."""

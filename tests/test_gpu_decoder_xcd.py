@@ -43,7 +43,7 @@ def test_every_step_matches_the_oracle_at_reference_widths(atype):
     ids, L = O.synthetic_inputs(5, 37, 312, ragged=True)
     m, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, 6)
     assert info["has_pack"] and info["protocol"] in (1, 2), info
-    assert sum(info["per_xcd"]) == 256, info
+    assert sum(info["per_xcd"]) == 256 and info["compute_units"] >= 256, info      # the whole-chip kernels run only on a whole MI355X
 
 
 def test_deepvoice_initial_states_and_reduction_factor_5():
