@@ -23,6 +23,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
+# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, tools/time_decoder.py, tools/trace_bigru.py;
+# shader clock ~2.16 GHz) and of the matrix pipe (tools/ubench_mfma: 2.08 PFLOP/s bf16 dense): what `roofline.latency_floor_ms` is built from.
+HOP_US = 0.5                 # one exchange through the XCD's L2: publish -> every consumer has gathered it (0.44-0.58 measured)
+DEC_HOPS, DEC_CHAIN_US = 10, 6.5    # per decoder step: exchanges, and the dependent instruction chains between them (11.7 - 10 x 0.5, rounded down)
+SCAN_HOPS, SCAN_CHAIN_US = 2, 1.2   # per post-net scan step (2.3 us timeline: 42 % hops, the rest chains + barriers)
+ENC_SCAN_STEP_US = 0.93             # encoder scan (k_bigru_res, one CU per chain, no exchange)
+MFMA_BF16_MEASURED_TF = 2080.0      # tools/ubench_mfma on this part; a 3-term split product costs three bf16 MFMAs
+
 WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speakers, model_type)
     "C1": (1, 64, 5, 200, 1, "single"),
     "C2": (32, 128, 4, 128, 1, "single"),
@@ -107,6 +115,26 @@ def feedforward_flops(hp, B, T_in, n):
     step = dp + (dd + As) * 3 * As + As * A + T_in * (A + D) + (As + D) * Hd + hp.dec_layer_num * (2 * Hd) * 3 * Hd + Hd * M * r
     scans = B * T_in * 2 * hp.enc_rnn_size * 3 * hp.enc_rnn_size + B * n * r * 2 * hp.post_rnn_size * 3 * hp.post_rnn_size
     return total - 2 * (B * n * step + scans)
+
+
+def feedforward_flops_by_stage(hp, B, T_in, n):
+    """feedforward_flops split into the encoder side (prenet, encoder CBHG without its scan, attention memory layer) and the
+    post-net side (post CBHG without its scan, linear head); the decoder loop has no feed-forward GEMM."""
+    import copy
+    r = hp.reduction_factor
+    post_rows = B * n * r
+    K, C, pw, rnn = hp.post_bank_size, hp.post_bank_channel_size, hp.post_proj_width, hp.post_rnn_size
+    mac = sum(k * hp.num_mels * C for k in range(1, K + 1))
+    d = K * C
+    for p in hp.post_proj_sizes:
+        mac += pw * d * p
+        d = p
+    if d != rnn:
+        mac += d * rnn
+    mac += hp.post_highway_depth * 2 * rnn * rnn + rnn * 6 * rnn      # highways; hoisted BiGRU input projection (both directions)
+    mac += 2 * rnn * hp.num_freq                                       # linear head
+    post = 2 * post_rows * mac
+    return {"encoder": feedforward_flops(hp, B, T_in, n) - post, "postnet": post}
 
 
 def source_hash():
@@ -288,6 +316,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    model.check_device_errors()          # a persistent kernel that gave up would make every later forward drain early (and fast)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -310,8 +339,17 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    device_errors = False
+    try:
+        model.check_device_errors()
+    except taco_amd._lib.TacoError:
+        device_errors = True
+    headline_engine = model.decoder_engine_info() if pool.engine == "persistent" else {"protocol": 0}
+    rank_ms = dev_ms / args.steps
+    per_rank_ms = D.gather_floats(rank_ms, device=dev if dist is not None else "cpu")     # device ms per step of every rank
     wall = D.max_over_ranks(wall, device=dev if dist is not None else "cpu")
     dev_ms = D.max_over_ranks(dev_ms, device=dev if dist is not None else "cpu")
+    device_errors = D.max_over_ranks(1.0 if device_errors else 0.0, device=dev if dist is not None else "cpu") > 0
     # latency of one forward with nothing else in flight (for the record; `value` is the throughput above)
     lat0, lat1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     with torch.cuda.stream(pool.streams[0]):
@@ -340,6 +378,19 @@ def main():
                 s1.record()
                 torch.cuda.synchronize()
                 stage_ms[name] = s0.elapsed_time(s1) / 3
+            # the feed-forward part of the two CBHG stages alone (the recurrent scan launches skipped: outputs meaningless, timing only)
+            model._lib.taco_debug_set_skip_scans(model._handle, 1)
+            for name, fn in (("encoder", lambda: model.encoder(p0.inputs, p0.lengths, spk0)), ("postnet", lambda: model.postnet(mel0, speaker_id=spk0))):
+                fn()
+                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                for _ in range(3):
+                    fn()
+                s1.record()
+                torch.cuda.synchronize()
+                stage_ms[name + "_ff"] = s0.elapsed_time(s1) / 3
+            model._lib.taco_debug_set_skip_scans(model._handle, 0)
+        model.check_device_errors()
     finite = all(bool(torch.isfinite(p.mel).all().item() and torch.isfinite(p.linear).all().item()) for p in pool.plans)
 
     def timed_pool(pl, nlanes, nsteps):
@@ -378,9 +429,11 @@ def main():
         model._plans.clear()
         p2 = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=1)
         fill(p2, 1)
-        companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / timed_pool(p2, lanes, ksteps), "forwards_in_flight": lanes,
+        t_exact = timed_pool(p2, lanes, ksteps)
+        companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / t_exact, "forwards_in_flight": lanes, "forward_ms": t_exact * 1e3,
                                     "arithmetic": "every contraction on exact-fp32 MFMA / VALU (taco_debug_set_bf3 off)"}
         p2.close()
+        model.check_device_errors()
         model._lib.taco_debug_set_bf3(model._handle, 1, 0)
         # (iii) two requests of B rows riding through one pass (PlanPool coalesce = 2)
         p4 = model.plan_pool(B, T_in, n, lanes=1, coalesce=2)
@@ -388,6 +441,7 @@ def main():
         companions["two_requests_per_pass"] = {"mel_frames_per_s": 2 * B * n * r / timed_pool(p4, 1, ksteps), "rows_per_pass": 2 * B,
                                                "engine_info": model.decoder_engine_info()}
         p4.close()
+        model.check_device_errors()
         # (iv) the launch-per-stage engine of round 1 (decoder and scans as chains of small launches that leave most CUs idle), with
         # four forwards in flight to fill them: higher throughput than it has latency to show for
         if args.decoder_engine != 0:
@@ -401,6 +455,7 @@ def main():
             companions["launch_per_stage_engine_4_lanes"] = {"mel_frames_per_s": thr, "forwards_in_flight": 4,
                                                              "forward_latency_ms_alone": e0.elapsed_time(e1) / 2}
             p3.close()
+            model.check_device_errors()
         model._plans.clear()
     if rank == 0:
         frames = world * B * n * r * args.steps
@@ -410,6 +465,35 @@ def main():
         ff_flops = feedforward_flops(hp, B, T_in, n)
         sb = stage_bytes(spec, hp, B, T_in, n)
         fwd_s = dev_ms / 1e3 / args.steps      # device time per forward (HIP events over the timed region / forwards in it)
+        ffs = feedforward_flops_by_stage(hp, B, T_in, n)
+        stages = {}
+        for k in ("encoder", "decoder", "postnet"):
+            e = {"ms_alone_eager": stage_ms[k], "algorithmic_GB": sb[k] / 1e9, "achieved_GBps": sb[k] / (stage_ms[k] * 1e-3) / 1e9,
+                 "frac": sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if k == "decoder":
+                e["binding_roofline"] = "hbm (streaming model); in practice L2 round trips + dependent chains, see latency_floor_ms"
+            else:
+                ffms = stage_ms[k + "_ff"]
+                tf = 3 * ffs[k] / (ffms * 1e-3) / 1e12
+                e["feed_forward_ms"] = ffms
+                e["scan_ms"] = stage_ms[k] - ffms
+                e["mfma_bf16"] = {"issued_gflop": 3 * ffs[k] / 1e9, "achieved": tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": tf / MFMA_BF16_PEAK_TF, "frac_of_measured_pipe": tf / MFMA_BF16_MEASURED_TF,
+                                  "over": "the stage's feed-forward launches alone (scan launches skipped)"}
+                e["binding_roofline"] = "mfma (bf16, 3 MFMAs per fp32 product) for the feed-forward part; the scan is latency bound"
+            stages[k] = e
+        T_mel = n * r
+        terms = {
+            "decoder_hops": n * DEC_HOPS * HOP_US * 1e-3, "decoder_chains": n * DEC_CHAIN_US * 1e-3,
+            "postnet_scan_hops": T_mel * SCAN_HOPS * HOP_US * 1e-3, "postnet_scan_chains": T_mel * SCAN_CHAIN_US * 1e-3,
+            "encoder_scan": T_in * ENC_SCAN_STEP_US * 1e-3,
+            "feed_forward_at_measured_mfma_ceiling": 3 * ff_flops / (MFMA_BF16_MEASURED_TF * 1e12) * 1e3,
+        }
+        floor = {"total": sum(terms.values()), "terms": terms, "measured_forward_ms": fwd_s * 1e3,
+                 "frac_of_floor": sum(terms.values()) / (fwd_s * 1e3),
+                 "note": "one forward in flight; hop = %.2f us (one exchange through the XCD's L2), chains = dependent VALU/DPP work between "
+                         "exchanges (profiles/r02_decoder_timeline.txt); 0.30 of the HBM streaming roofline would need %.2f ms per forward"
+                         % (HOP_US, abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
@@ -430,15 +514,20 @@ def main():
                                    "%.2f MB per decoder step; duration = timed region / forwards (%d in flight)"
                                    % (abytes / 1e9, per_step / 1e6, lanes),
                          "forward_ms": fwd_s * 1e3,
-                         "stages": {k: {"ms_alone_eager": stage_ms[k], "algorithmic_GB": sb[k] / 1e9,
-                                        "achieved_GBps": sb[k] / (stage_ms[k] * 1e-3) / 1e9, "frac": sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                                    for k in ("encoder", "decoder", "postnet")},
+                         "stages": stages,
+                         # what bounds one forward in flight on this design: the sequential loops pay L2 round trips and dependent
+                         # instruction chains per step whatever the byte count, and the feed-forward GEMMs cannot beat the matrix pipe
+                         "latency_floor_ms": floor,
                          # matrix-pipe view: the feed-forward contractions (everything but the two scans and the decoder loop) are
                          # issued as THREE bf16 MFMAs per fp32 product; utilisation is counted on that pipe against its dense peak
                          "mfma_bf16": {"issued_gflop_per_forward": 3 * ff_flops / 1e9, "achieved": 3 * ff_flops / fwd_s / 1e12,
                                        "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": 3 * ff_flops / fwd_s / 1e12 / MFMA_BF16_PEAK_TF,
-                                       "note": "fp32-equivalent work of the whole forward: %.1f GFLOP = %.1f TFLOP/s; the scans and the decoder run on the fp32 VALU"
+                                       "note": "whole forward; per-stage fractions over the feed-forward time alone are in stages.*.mfma_bf16. "
+                                               "fp32-equivalent work of the whole forward: %.1f GFLOP = %.1f TFLOP/s; the scans and the decoder run on the fp32 VALU"
                                                % (flops / 1e9, flops / fwd_s / 1e12)}},
+            "per_rank_ms_per_step": per_rank_ms,
+            "device_errors": bool(device_errors),
+            "decoder_protocol": headline_engine.get("protocol"),
             "companions": companions,
             "outputs_finite": finite,
         }
@@ -454,11 +543,16 @@ def main():
                 if rec.get("workload") == args.workload and co == 1 and rec.get("kernel_source_hash") == here:
                     out["roofline"]["traffic"] = rec["traffic_bytes_per_forward"]
                     out["roofline"]["traffic_source"] = os.path.basename(f)
+                    # what the HBM side actually carried, against the same peak (the streaming model above is the contract figure)
+                    out["roofline"]["hbm_counter_frac"] = rec["traffic_bytes_per_forward"] / fwd_s / 1e9 / HBM_PEAK_GBS
                     break
             else:
                 out["roofline"]["traffic_source"] = "none: no committed PMC profile matches this build of the kernels (hash %s)" % here
         except Exception:
             pass
+        if "exact_fp32" in companions:      # the same roofline fraction for the exact-arithmetic run, beside the headline's
+            companions["exact_fp32"]["roofline_frac"] = abytes / (companions["exact_fp32"]["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["frac_exact_fp32"] = companions["exact_fp32"]["roofline_frac"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, seed)
         print(json.dumps(out))

@@ -84,7 +84,11 @@ int taco_forward_infer(taco_model* m, void* hip_stream,
                        float* d_alignments,              /* [B,T_in,n_steps]             tacotron.py:238-239 */
                        int32_t* d_stop_step,             /* [1]: decoder steps the reference's stop rule
                                                             (helpers.py:29 + dynamic_decode) would have run;
-                                                            == n_steps unless every row emitted an all-zero step */
+                                                            == n_steps unless every row emitted an all-zero step.
+                                                            NEGATIVE = -(device error word): a persistent kernel of
+                                                            this forward (or of an earlier one whose error was never
+                                                            acknowledged with taco_model_device_errors) gave up and
+                                                            the outputs are invalid */
                        void* d_workspace, size_t workspace_bytes);
 
 /* The same forward captured once into a hipGraph (all pointers baked in) and replayed. */
@@ -273,9 +277,15 @@ int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group);
  * persistent kernels are used only when there are 256: an unpartitioned MI355X; a CPX / DPX partition runs the launch-per-stage
  * engine), out16[15] = 1 when the model has a persistent-decoder pack */
 int taco_debug_decoder_info(taco_model* m, int* out16);
-/* phase timeline of group 0 / member 0 for the first 8 decoder steps: enable = 1 allocates the stamp buffer (next launches
- * write it), out (nullable) receives [8][16] shader-clock stamps; enable = 0 frees it */
+/* phase timeline of group 0 / member 0 for the first 8 decoder steps (scan: steps 8-15): enable bit 0 = launches enqueued from now
+ * on write their stamps (the buffer is allocated on first use and lives as long as the model, because captured plans keep its
+ * address; drop plans captured under the other setting); out (nullable) receives [8][16] shader-clock stamps of the decoder, or,
+ * with enable bit 1, of the post-net scan (k_bigru_xcd has its own half of the buffer) */
 int taco_debug_decoder_trace(taco_model* m, int enable, long long* out);
+
+/* timing hook: on = 1 leaves the recurrent scan launches of both CBHGs out of every forward / stage call enqueued from now on
+ * (their outputs are then meaningless), so that the feed-forward part of a stage can be timed alone (bench.py roofline.stages) */
+int taco_debug_set_skip_scans(taco_model* m, int on);
 
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
 int taco_debug_force_gemm_config(taco_model* m, int cfg);

@@ -134,6 +134,7 @@ PROTOTYPES = {
     "taco_train_workspace_bytes": (_S, [_P, _I, _I, _I]),
     "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
+    "taco_debug_set_skip_scans": (_I, [_P, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),
     "taco_stop_steps": (_I, [_P, _P, _I, _I, _I, _I, _P]),

@@ -1984,6 +1984,11 @@ __global__ __launch_bounds__(256) void k_stop_step(const int* nz, int B, int n_s
   if (tid == 0) *stop = min(worst + 1, n_steps);
 }
 
+// see latch_errors() in taco_lib.hip
+__global__ void k_latch_errors(const unsigned* errw, int* stop) {
+  if (threadIdx.x == 0) { const unsigned e = errw[0]; if (e) *stop = -(int)e; }
+}
+
 // The same stop rule evaluated on a finished mel buffer for groups of `rows` consecutive batch rows (requests that were served
 // together through one plan): stop[g] = min(max over the group's rows of (first step whose r*num_mels outputs are all 0) + 1, n).
 // One workgroup per batch row; stop must be zeroed before the launch.  y [B, n_steps, width].

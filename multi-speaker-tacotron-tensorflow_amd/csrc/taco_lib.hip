@@ -150,7 +150,10 @@ struct taco_model {
   int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
   int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
   int dx_rows = 0;             // debug: force the rows per group (1,2,4,8); 0 = smallest that covers the batch
-  long long* d_trace = nullptr;   // debug: phase stamps of group 0 / member 0 (taco_debug_decoder_trace)
+  long long* d_trace = nullptr;   // debug: phase stamps of group 0 / member 0 (taco_debug_decoder_trace): [decoder half | scan half];
+                                  // allocated on first use and kept until the model is destroyed (captured plans may hold the pointer)
+  int trace_on = 0;
+  int skip_scans = 0;          // timing hook (taco_debug_set_skip_scans): the recurrent scans of both CBHGs are not launched
   hipStream_t side = nullptr;  // that second stream
   std::vector<hipEvent_t> events;
   struct TrainPacks* tp = nullptr;   // set on the shadow model of a taco_train: finalize also builds the backward packs
@@ -799,6 +802,7 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
+  if (m->skip_scans) return 0;
   if ((m->persist == 1 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
     // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
     // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
@@ -807,7 +811,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     GxArgs a; memset(&a, 0, sizeof a);
     const size_t* pk = NWV == 8 ? c.gx_pack : c.gx_pack4;
     a.wpack0 = AP(m, pk[0]); a.wpack1 = AP(m, pk[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
-    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = m->d_trace; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
     int RG = 1;
     while (RG * rowgroups < B) RG *= 2;
     // granules and census words are carved back to back: one fill launch covers both
@@ -1139,7 +1143,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
   a.keys = w.keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
   a.mel = mel; a.hist = align_out; a.nz = w.nz; a.dbg = dbg; a.dbgw = dbgw;
-  a.xbuf = w.xbuf; a.ctl = w.dxctl; a.err = m->d_err; a.trace = m->d_trace;
+  a.xbuf = w.xbuf; a.ctl = w.dxctl; a.err = m->d_err; a.trace = m->trace_on ? m->d_trace : nullptr;
   a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
@@ -1321,6 +1325,16 @@ static int check_common(const taco_model* m, int B, int T) {
   return 0;
 }
 
+// Last node of a forward: if a persistent kernel of this (or an earlier, still unacknowledged) forward gave up -- the device error
+// word is sticky and makes every later persistent launch drain at once -- the forward's own stop word becomes -(error), so the
+// caller that reads the stop step learns that THIS forward's outputs are invalid without a second transfer.
+static int latch_errors(const taco_model* m, hipStream_t st, int32_t* stop) {
+  if (!stop) return 0;
+  hipLaunchKernelGGL(k_latch_errors, dim3(1), dim3(64), 0, st, (const unsigned*)m->d_err, stop);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
                            int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
                            int32_t* stop, void* ws, size_t ws_bytes) {
@@ -1337,7 +1351,8 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   const int CH = m->overlap > 16 ? m->overlap : 16;   // decoder steps per post-net chunk
   if (!m->overlap || (size_t)(n / CH + 4) > m->events.size()) {
     TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
-    return postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post);
+    TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
+    return latch_errors(m, st, stop);
   }
   // The decoder loop is a chain of tiny dependent launches that occupies < 1/5 of the CUs; the post-net's
   // feed-forward stages (conv bank, projections, highways, hoisted GRU projection: ~1.3 ms of fp32 MFMA work @C2)
@@ -1359,7 +1374,8 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk, &hook));
   HIPCHK(hipEventRecord(m->events[ev], s2));
   HIPCHK(hipStreamWaitEvent(st, m->events[ev], 0));
-  return postnet_tail(m, st, spk, B, T_mel, linear, nullptr, w.post);
+  TRY(postnet_tail(m, st, spk, B, T_mel, linear, nullptr, w.post));
+  return latch_errors(m, st, stop);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1735,10 +1751,17 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
 int taco_debug_decoder_trace(taco_model* m, int enable, long long* out) {
   if (!m || !m->finalized) return fail(TACO_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(m->device));
-  const size_t bytes = (size_t)DX_TRACE_STEPS * DX_TRACE_SLOTS * sizeof(long long);
-  if (enable && !m->d_trace) { HIPCHK(hipMalloc((void**)&m->d_trace, bytes)); HIPCHK(hipMemset(m->d_trace, 0, bytes)); }
-  if (out && m->d_trace) HIPCHK(hipMemcpy(out, m->d_trace, bytes, hipMemcpyDeviceToHost));
-  if (!enable && m->d_trace) { (void)hipFree(m->d_trace); m->d_trace = nullptr; }
+  const size_t half = (size_t)DX_TRACE_STEPS * DX_TRACE_SLOTS * sizeof(long long);
+  if ((enable & 1) && !m->d_trace) { HIPCHK(hipMalloc((void**)&m->d_trace, 2 * half)); HIPCHK(hipMemset(m->d_trace, 0, 2 * half)); }
+  // enable bit 1 selects the scan's half of the buffer for the read-back
+  if (out && m->d_trace) HIPCHK(hipMemcpy(out, (const char*)m->d_trace + ((enable & 2) ? half : 0), half, hipMemcpyDeviceToHost));
+  m->trace_on = enable & 1;      // the buffer itself stays until taco_model_destroy: a captured plan may still carry its address
+  return 0;
+}
+
+int taco_debug_set_skip_scans(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->skip_scans = on ? 1 : 0;
   return 0;
 }
 

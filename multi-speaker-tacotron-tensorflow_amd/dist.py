@@ -44,6 +44,19 @@ def sum_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def gather_floats(value, device="cpu"):
+    """every rank's python float, in rank order, on every rank (bench.py: per-rank ms per step)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=device)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
 def gather_rows(local_np, world_size):
     """all_gather of per-rank numpy row blocks (host side; outputs normally stay on their GPU)."""
     import torch.distributed as dist

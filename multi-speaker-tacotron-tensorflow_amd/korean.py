@@ -147,19 +147,28 @@ class KoreanNormalizer(object):
     def _requote(m):
         return " ".join("'%s'" % s for s in split_sentences(m.group(2))) or "''"
 
+    # the stages of normalize(), callable one by one (tests/test_reference_vectors.py replays the reference's stage outputs)
+    def apply_phrases(self, text):
+        return text if self._phrase_re is None else self._phrase_re.sub(lambda m: self.phrases[m.group()], text)
+
+    def apply_latin(self, text):
+        """dictionary words, then letter-by-letter spelling of what is left in capitals (one pass: a dictionary reading holds no Latin letters)"""
+        return _LATIN_WORD.sub(self._latin, text)
+
+    def apply_quotes(self, text):
+        return _QUOTED.sub(self._requote, text)
+
+    def apply_numbers(self, text):
+        text = self._unit_re.sub(lambda m: dict(UNIT_WORDS)[m.group()], text)
+        text = self._unit_late_re.sub(lambda m: dict(UNIT_WORDS_LATE)[m.group()], text)
+        text = _COUNTED.sub(lambda m: read_number(m.group(1), m.group(2)), text)
+        return _PLAIN_NUMBER.sub(lambda m: read_number(m.group()), text)
+
     def normalize(self, text):
         text = text.strip()
         text = _DAY_NOTE.sub("", text)
         text = _HANJA_NOTE.sub("", text)
-        if self._phrase_re is not None:
-            text = self._phrase_re.sub(lambda m: self.phrases[m.group()], text)
-        text = _LATIN_WORD.sub(self._latin, text)
-        text = _QUOTED.sub(self._requote, text)
-        text = self._unit_re.sub(lambda m: dict(UNIT_WORDS)[m.group()], text)
-        text = self._unit_late_re.sub(lambda m: dict(UNIT_WORDS_LATE)[m.group()], text)
-        text = _COUNTED.sub(lambda m: read_number(m.group(1), m.group(2)), text)
-        text = _PLAIN_NUMBER.sub(lambda m: read_number(m.group()), text)
-        return text
+        return self.apply_numbers(self.apply_quotes(self.apply_latin(self.apply_phrases(text))))
 
     __call__ = normalize
 

@@ -250,7 +250,10 @@ class PlanPool(object):
         rows = slice(slot * self.B, (slot + 1) * self.B)
         f = (lambda t: t.clone()) if copy else (lambda t: t)
         with torch.cuda.device(self.model.device):
-            stop = int(p.stop.item()) if self.coalesce == 1 else int(self.slot_stop[lane][slot].item())
+            plan_stop = int(p.stop.item())
+            if plan_stop < 0:
+                self._failed(lane)
+            stop = plan_stop if self.coalesce == 1 else int(self.slot_stop[lane][slot].item())
             out = {"linear": f(p.linear[rows]), "mel": f(p.mel[rows]), "alignments": f(p.align[rows]), "stop_step": stop}
         self.taken[lane] += 1
         if self.taken[lane] >= self.filled[lane]:
@@ -258,11 +261,31 @@ class PlanPool(object):
             self.filled[lane] = 0
         return out
 
+    def _failed(self, lane):
+        """The lane's forward reported a device error through its stop word (taco_abi.h: negative = a persistent kernel gave up; the
+        error word is sticky, so every forward enqueued before this acknowledgement reports it too).  Acknowledge (clears the word, so
+        that forwards enqueued from now on start clean), drop the lane's result and raise."""
+        self.pending[lane] = False
+        self.filled[lane] = 0
+        self.taken[lane] = 0
+        try:
+            self.model.check_device_errors()
+        except _lib.TacoError:
+            pass
+        raise _lib.TacoError(_lib.TACO_ERR_HIP, "a persistent kernel timed out waiting for a peer workgroup during the forward of lane %d; "
+                             "its outputs are invalid (the error is acknowledged: resubmit, or capture the pool with engine='launch')" % lane)
+
     def wait_all(self):
+        """Waits for every forward in flight; raises if one of them reported a device error."""
         self.flush()
+        bad = None
         for lane in range(self.lanes):
             if self.pending[lane]:
                 self.done[lane].synchronize()
+                if bad is None and int(self.plans[lane].stop.item()) < 0:
+                    bad = lane
+        if bad is not None:
+            self._failed(bad)
 
     def close(self):
         self.wait_all()
@@ -477,9 +500,13 @@ class Tacotron(object):
             plan.launch()
             mel, linear, align = plan.mel, plan.linear, plan.align
             self.stop_step = plan.n
-            if honor_stop:
-                stop = int(plan.stop.item())
+            # the stop word doubles as the forward's error latch (negative: a persistent kernel gave up, taco_abi.h); reading it is
+            # the one host sync of a run(), with or without honor_stop
+            stop = int(plan.stop.item())
+            if stop < 0:
                 self.check_device_errors()
+                raise _lib.TacoError(_lib.TACO_ERR_HIP, "a persistent kernel reported error %d; outputs are invalid" % -stop)
+            if honor_stop:
                 self.stop_step = stop
                 if stop < plan.n:   # dynamic_decode ended early: re-run the post-net on the frames that exist
                     r = self._hparams.reduction_factor
@@ -550,12 +577,17 @@ class Tacotron(object):
         _lib.check(self._lib.taco_debug_decoder_info(self._handle, v))
         return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14])}
 
-    def decoder_trace(self, enable=True, read=False):
-        """Phase stamps (shader clocks) of group 0 / member 0 of the persistent decoder, first 8 steps x 16 slots."""
+    def decoder_trace(self, enable=True, read=False, scan=False):
+        """Phase stamps (shader clocks) of group 0 / member 0 of the persistent decoder (scan=True: of the post-net scan, which has
+        its own half of the buffer), 8 steps x 16 slots.  Cached plans are dropped whenever the setting changes: a plan captured
+        with tracing on keeps stamping on every replay, one captured with it off never does."""
         out = (C.c_longlong * 128)() if read else None
         if read:
             torch.cuda.synchronize(self.device)
-        _lib.check(self._lib.taco_debug_decoder_trace(self._handle, 1 if enable else 0, out))
+        if bool(enable) != getattr(self, "_trace_on", False):
+            self._plans.clear()
+            self._trace_on = bool(enable)
+        _lib.check(self._lib.taco_debug_decoder_trace(self._handle, (1 if enable else 0) | (2 if scan else 0), out))
         return np.array(out[:], np.int64).reshape(8, 16) if read else None
 
     def check_device_errors(self):

@@ -98,8 +98,25 @@ class Trainer(object):
             except Exception as e:     # an exception must not unwind through the C frames: it is re-raised after the call returns
                 self._sync_err = e
         self._sync_cb = _lib.SYNC_SUM_FN(_sum)
+        self._sync_group, self._sync_shapes = group, set()
         _lib.check(self._lib.taco_train_set_sync_bn(self._h, C.cast(self._sync_cb, C.c_void_p), None, world))
         return True
+
+    def _check_sync_shapes(self, B, T_in, T_out):
+        """The merge of the per-rank statistics (k_bn_sync_combine) weights every rank equally: it is exact only when every rank
+        normalises the same number of rows.  Checked once per shape with one 4-element MAX all-reduce; unequal shards raise instead
+        of silently producing wrong global statistics."""
+        key = (B, T_in, T_out)
+        if key in self._sync_shapes:
+            return
+        import torch.distributed as dist
+        v = torch.tensor([B * T_in, B * T_out, -B * T_in, -B * T_out], dtype=torch.int64, device=self.device)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._sync_group)
+        hi_in, hi_out, lo_in, lo_out = (int(x) for x in v.tolist())
+        if hi_in != -lo_in or hi_out != -lo_out:
+            raise _lib.TacoError(_lib.TACO_ERR_SHAPE, "SyncBN needs the same number of rows on every rank: this rank has B*T_in = %d, "
+                                 "B*T_out = %d, the group spans %d..%d and %d..%d" % (B * T_in, B * T_out, -lo_in, hi_in, -lo_out, hi_out))
+        self._sync_shapes.add(key)
 
     # ---- parameters ----
     def set_weights(self, weights):
@@ -148,6 +165,8 @@ class Trainer(object):
                 torch.as_tensor(np.asarray(speaker_id) if not torch.is_tensor(speaker_id) else speaker_id).to(dev, torch.int32).contiguous()
         if mt.shape != (B, T_out, hp.num_mels) or lt.shape != (B, T_out, hp.num_freq):
             raise Exception("targets must be [B, T_out, num_mels] / [B, T_out, num_freq], got %s / %s" % (tuple(mt.shape), tuple(lt.shape)))
+        if self._sync_cb is not None:
+            self._check_sync_shapes(B, T_in, T_out)
         nb = int(self._lib.taco_train_workspace_bytes(self._h, B, T_in, T_out))
         # A captured step has the address of ITS workspace baked into every kernel node: that buffer is never reallocated while the
         # graph is alive.  Eager calls beside the graph (another shape, a loss fetch) use a workspace of their own.

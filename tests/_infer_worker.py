@@ -24,8 +24,14 @@ def main():
     lo, hi = D.shard_range(d["ids"].shape[0], rank, world)
     m = build_model(ohp, w, num_speakers=ns)
     spk = d["spk"][lo:hi] if ns > 1 else None
-    linear, alignments = m.run(inputs=d["ids"][lo:hi], input_lengths=d["L"][lo:hi], speaker_id=spk)
-    torch.cuda.synchronize()
+    # Both ranks share cuda:0 here, and the persistent engine's kernels need every CU of the chip at once (256 resident workgroups):
+    # two of them dispatched together can starve each other until the bounded spins expire.  On a node each rank owns a GPU; on this
+    # one the ranks take turns (the gloo barrier orders them), so the engine under test is still the persistent one.
+    for turn in range(world):
+        if turn == rank:
+            linear, alignments = m.run(inputs=d["ids"][lo:hi], input_lengths=d["L"][lo:hi], speaker_id=spk)
+            torch.cuda.synchronize()
+        dist.barrier()
     info = m.decoder_engine_info()
     m.check_device_errors()
     lin = D.gather_rows(linear.cpu().numpy(), world)

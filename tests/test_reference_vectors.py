@@ -1,0 +1,122 @@
+"""Replay of the vectors the REFERENCE produced (tools/make_reference_vectors.py, run in the build container against
+/root/reference/text/korean.py and datasets/datafeeder.py loaded by path) through korean.py / feeder.py: bit-exact.
+
+These are the two parts of SURVEY 8f rank 4 that can be pinned on the reference itself (they need no TensorFlow); everything that
+touches tf.* stays pinned on the oracle only (oracle/taco_oracle.py header: parity unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from taco_amd import korean as K
+from taco_amd import feeder as F
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def kv():
+    with open(os.path.join(GOLD, "korean_vectors.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def norm(kv):
+    return K.KoreanNormalizer(english=kv["english"], phrases=kv["phrases"])
+
+
+def test_normalize_equals_the_reference_on_2500_sentences(kv, norm):
+    assert len(kv["sentences"]) == len(kv["normalize"]) >= 2500
+    bad = [(s, e, norm.normalize(s)) for s, e in zip(kv["sentences"], kv["normalize"]) if norm.normalize(s) != e]
+    assert not bad, bad[:3]
+
+
+def test_every_stage_equals_the_reference(kv, norm):
+    """text/korean.py:151-164 stage by stage, each stage fed the previous stage's REFERENCE output (English words and upper-case
+    spelling are two passes there and one here: compared after the second)."""
+    raw, st = kv["stage_inputs"], kv["stages"]
+    assert [norm.apply_phrases(t.strip()) for t in raw] == st["dictionary"]
+    assert [norm.apply_latin(t) for t in st["dictionary"]] == st["upper"]
+    assert [norm.apply_latin(t) for t in st["english"]] == st["upper"]
+    assert [norm.apply_numbers(t) for t in st["upper"]] == st["number"]
+
+
+def test_number_readings_equal_the_reference(kv, norm):
+    assert [norm.apply_numbers(s) for s in kv["number_sweep"]] == kv["number_sweep_expected"]
+    assert [norm.apply_numbers(s) for s in kv["counted_sweep"]] == kv["counted_sweep_expected"]
+    # a few of them by hand, so that the file cannot drift unnoticed
+    table = dict(zip(kv["number_sweep"] + kv["counted_sweep"], kv["number_sweep_expected"] + kv["counted_sweep_expected"]))
+    assert table["2017"] == "이천일십칠" and table["10000"] == "만" and table["-12.35"] == "마이너스 십이쩜 삼오" and table["0"] == "영"
+
+
+def test_inputs_where_the_reference_does_not_give_a_reading(kv, norm):
+    """Recorded, not 'fixed': on these inputs the reference raises (text/korean.py:247 ast.literal_eval on a leading zero; :270
+    int('+')) or misreads (digit places taken from the un-stripped string).  The product returns a reading instead; the divergence
+    is part of the committed vectors so that it cannot change silently in either direction."""
+    div = {d["input"]: d for d in kv["divergences"]}
+    for s, d in div.items():
+        try:
+            got = {"returns": norm.normalize(s)}
+        except Exception as e:       # noqa: BLE001
+            got = {"raises": type(e).__name__}
+        assert got == d["product"], (s, got, d)
+    assert div["+5"]["reference"] == {"raises": "ValueError"} and div["+5"]["product"] == {"returns": "플러스 오"}
+    assert div["007"]["reference"] == {"raises": "SyntaxError"} and div["007"]["product"] == {"returns": "칠"}
+    assert div["0012.5"]["reference"] == {"returns": "쩜 오"} and div["0012.5"]["product"] == {"returns": "십이쩜 오"}
+    assert sum(not d["same"] for d in kv["divergences"]) == 5
+
+
+# ---- datasets/datafeeder.py ----
+@pytest.fixture(scope="module")
+def fv():
+    return np.load(os.path.join(GOLD, "feeder_vectors.npz"))
+
+
+def test_round_up_table(fv):
+    for mult in (1, 2, 3, 4, 5, 6):
+        want = fv["round_up_m%d" % mult]
+        # _prepare_targets pads to _round_up(longest + 1, r)  (datafeeder.py:313-316, :326-328)
+        got = [F.padded_length(int(x) - 1, mult) for x in fv["round_up_x"]]
+        assert got == want.tolist()
+
+
+def _examples(fv, prefix, n, spk):
+    out = []
+    for j in range(n):
+        k = "%s_in%d_" % (prefix, j)
+        out.append(F.Example(fv[k + "tokens"], float(fv[k + "coeff"]), fv[k + "mel"], fv[k + "linear"], int(fv[k + "speaker"]) if spk else None))
+    return out
+
+
+def _same(batch, fv, prefix, spk):
+    names = ["inputs", "input_lengths", "loss_coeff", "mel_targets", "linear_targets"] + (["speaker_id"] if spk else [])
+    for name in names:
+        want, got = fv[prefix + name], getattr(batch, name)
+        assert got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want), (prefix, name)
+
+
+def test_prepare_batch_cases(fv):
+    """_prepare_batch (datafeeder.py:289-306) on six seeded batches: reduction factors 1-5, 5- and 6-tuples, and the row shuffle of
+    a training batch with the feeder's generator."""
+    for ci, (r, dt, spk, nb, seed) in enumerate(fv["cases"].tolist()):
+        ex = _examples(fv, "case%d" % ci, nb, spk)
+        if dt == 1:                               # 'train': rng.shuffle(batch) first
+            np.random.RandomState(seed).shuffle(ex)
+        _same(F.collate(ex, r), fv, "case%d_out_" % ci, spk)
+
+
+def test_group_logic_equals_enqueue_next_group(fv):
+    """DataFeeder._enqueue_next_group (datafeeder.py:210-243) was driven twice per configuration on recorded example streams; the
+    product's GroupFeeder must hand out the same batches in the same order from the same streams and generator seed."""
+    for gi, row in enumerate(fv["groups"].tolist()):
+        bs, bpg, r, ndirs, step, phase, seed = row[:7]
+        ratios = [x / 1000.0 for x in row[7:7 + ndirs]]
+        dirs = ["a", "b"][:ndirs]
+        streams = {d: iter(_examples(fv, "group%d_%s" % (gi, d), int(fv["group%d_%s_count" % (gi, d)]), ndirs > 1)) for d in dirs}
+        feeder = F.GroupFeeder({d: (lambda d=d: next(streams[d])) for d in dirs}, bs, r, batches_per_group=bpg,
+                               ratios=dict(zip(dirs, ratios)), seed=seed, training=True)
+        for bi in range(int(fv["group%d_nbatches" % gi])):
+            _same(next(feeder), fv, "group%d_batch%d_" % (gi, bi), ndirs > 1)
+        for d in dirs:                            # and it drew exactly the examples the reference drew
+            assert next(streams[d], None) is None

@@ -1,0 +1,309 @@
+#!/usr/bin/env python
+"""Golden vectors produced BY THE REFERENCE for the two parts of SURVEY 8f rank 4 that can run without TensorFlow:
+
+  * text/korean.py:151-306   normalize() and its stages (dictionary phrases, English words, upper-case spelling, units + numbers)
+  * datasets/datafeeder.py:210-243,289-328   _round_up / _prepare_inputs / _prepare_targets / _prepare_batch and the group logic of
+    DataFeeder._enqueue_next_group (sort by target length, cut into batches, shuffle the batches, shuffle the rows of a training batch)
+
+Run in the BUILD container only (it reads /root/reference; the GPU box has no reference):
+
+    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json and tests/golden/feeder_vectors.npz
+
+The reference modules are loaded BY PATH from where they lie; nothing of their source is copied.  Their import lines name packages
+this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `utils` / `text` packages, which pull in TensorFlow and
+librosa).  Those names are satisfied by EMPTY stand-in modules whose functions raise if called (`log` is a no-op): no stand-in takes
+part in computing a vector -- any stage that would need one (jamo decomposition, nltk sentence splitting inside quotations) is left
+out, and the vectors say so.  tests/test_reference_vectors.py replays the files bit-exactly through korean.py / feeder.py."""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("TACO_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _refuse(name):
+    def fn(*a, **k):
+        raise RuntimeError("stand-in '%s' was called: it must not take part in computing a vector" % name)
+    return fn
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load_reference_korean():
+    _stub("jamo", hangul_to_jamo=_refuse("jamo.hangul_to_jamo"), h2j=_refuse("jamo.h2j"), j2h=_refuse("jamo.j2h"))
+    pkg = _stub("reftext")
+    pkg.__path__ = [os.path.join(REF, "text")]          # a namespace for relative imports; text/__init__.py is NOT executed
+    return importlib.import_module("reftext.korean")
+
+
+def load_reference_datafeeder():
+    _stub("tensorflow")
+    _stub("text")
+    u = _stub("utils", parallel_run=_refuse("utils.parallel_run"), remove_file=_refuse("utils.remove_file"))
+    u.__path__ = []
+    _stub("utils.infolog", log=lambda *a, **k: None)
+    a = _stub("audio", frames_to_hours=_refuse("audio.frames_to_hours"))
+    a.__path__ = []
+    _stub("audio.get_duration", get_durations=_refuse("audio.get_durations"))
+    pkg = _stub("refdatasets")
+    pkg.__path__ = [os.path.join(REF, "datasets")]
+    return importlib.import_module("refdatasets.datafeeder")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# text/korean.py
+# ------------------------------------------------------------------------------------------------------------------------------
+HANGUL_WORDS = ["오늘", "서울", "사람", "학교", "날씨", "그리고", "우리는", "약", "모두", "가격은", "에서", "까지", "이상", "정도", "합니다", "였다", "라고"]
+MIXED_LATIN = ["Hello", "iPhone", "kTx", "mVp", "Seoul", "abc", "zzz"]     # not all upper-case; checked below not to be dictionary words
+
+
+def korean_vectors(K):
+    rs = np.random.RandomState(20260927)
+    eng_all, etc_all = dict(K.english_dictionary), dict(K.etc_dictionary)
+    eng_keys = sorted(eng_all)
+    eng_sub = [eng_keys[i] for i in sorted(rs.choice(len(eng_keys), size=min(10, len(eng_keys)), replace=False))]
+    etc_sub = sorted(etc_all)                      # the phrase table is short: all of it travels with the vectors it is used by
+    counters = K.count_checker.strip("()").split("|")
+    units = list(K.unit_to_kor1) + list(K.unit_to_kor2)
+    mixed = [w for w in MIXED_LATIN if w not in eng_all]
+    caps = ["LG", "KBS", "IT", "A", "CEO", "USB", "XYZ", "UN", "MBC", "SKT"]
+    caps = [w for w in caps if w not in eng_all]
+
+    def number(lead_zero_ok=False):
+        kind = rs.randint(0, 8)
+        if kind == 0:
+            s = str(rs.randint(0, 10))
+        elif kind == 1:
+            s = str(rs.randint(10, 100))
+        elif kind == 2:
+            s = str(rs.randint(100, 10000))
+        elif kind == 3:
+            s = str(rs.randint(10000, 10 ** 9))
+        elif kind == 4:
+            s = str(int(rs.randint(1, 10 ** 9)) * int(rs.randint(1, 10 ** 9)))     # up to 10^18: 경 / 해 groups
+        elif kind == 5:
+            s = "{:,}".format(int(rs.randint(1000, 10 ** 8)))
+        elif kind == 6:
+            s = str(int(10 ** rs.randint(1, 17)) * int(rs.randint(1, 10)))          # round numbers: silent leading one, empty groups
+        else:
+            s = str(rs.randint(1, 1000)) + "0" * rs.randint(0, 5)
+        return s
+
+    def decorated_number():
+        s = number()
+        if rs.rand() < 0.25:
+            s = s.replace(",", "") + "." + "".join(str(rs.randint(0, 10)) for _ in range(rs.randint(1, 4)))
+        if rs.rand() < 0.15:
+            s = "-" + s                              # '+' is a reference crash (recorded under `divergences`)
+        return s
+
+    def sentence():
+        parts = []
+        for _ in range(rs.randint(2, 7)):
+            k = rs.randint(0, 9)
+            if k == 0:
+                parts.append(HANGUL_WORDS[rs.randint(len(HANGUL_WORDS))])
+            elif k == 1:
+                parts.append(decorated_number())
+            elif k == 2:
+                parts.append(number() + counters[rs.randint(len(counters))])
+            elif k == 3:
+                parts.append(decorated_number() + units[rs.randint(len(units))])
+            elif k == 4:
+                parts.append(eng_sub[rs.randint(len(eng_sub))])
+            elif k == 5:
+                parts.append(caps[rs.randint(len(caps))])
+            elif k == 6:
+                parts.append(mixed[rs.randint(len(mixed))])
+            elif k == 7:
+                parts.append(etc_sub[rs.randint(len(etc_sub))])
+            else:
+                parts.append(HANGUL_WORDS[rs.randint(len(HANGUL_WORDS))] + [",", ".", "!", "?"][rs.randint(4)])
+        text = " ".join(parts)
+        if rs.rand() < 0.1:
+            text = "  " + text + " "
+        if rs.rand() < 0.1:
+            text += "(%d일)" % rs.randint(1, 32)
+        if rs.rand() < 0.1:
+            text += "(漢字)"
+        return text
+
+    import re
+    quote = re.compile(K.quote_checker)
+    sentences, expected = [], []
+    while len(sentences) < 2500:
+        t = sentence()
+        if quote.search(t):
+            continue                                  # the quotation stage needs nltk: not pinned here
+        # the product gets only the dictionary subset: the sentence must not touch any other entry
+        latin = re.findall("[A-Za-z]+", t)
+        if any((w in eng_all) and (w not in eng_sub) for w in latin):
+            continue
+        sentences.append(t)
+        expected.append(K.normalize(t))
+
+    # stage by stage, chained the way the reference composes them (text/korean.py:151-164): each stage sees the previous one's output
+    stage_in = sentences[:400]
+    s1 = [K.normalize_with_dictionary(t.strip(), K.etc_dictionary) for t in stage_in]
+    s2 = [K.normalize_english(t) for t in s1]
+    s3 = [re.sub("[a-zA-Z]+", K.normalize_upper, t) for t in s2]
+    s4 = [K.normalize_number(t) for t in s3]
+    stages = {"dictionary": s1, "english": s2, "upper": s3, "number": s4}
+
+    # number_to_korean through the two patterns normalize_number applies, on a dense sweep
+    sweep = [str(i) for i in list(range(0, 130)) + [200, 1000, 1001, 1100, 2017, 9999, 10000, 10001, 10010, 11000, 100000, 1000000,
+                                                     10000000, 100000000, 100010000, 1000000000000, 10000000000000000,
+                                                     123456789012345678, 99999999, 20000, 30303, 400040004]]
+    sweep += ["1,000", "12,345,678", "3.14", "0.5", "10.05", "-7", "-12.35", "-0.25", "1,234.5", "0", "0.0", "00", "1.", "100."]
+    plain = [K.normalize_number(s) for s in sweep]
+    counted_in = [str(i) + c for i in list(range(0, 100)) + [100, 101, 110, 120, 199, 200, 999, 1000, 1234, 10000] for c in (counters[0], counters[3], counters[11])]
+    counted = [K.normalize_number(s) for s in counted_in]
+
+    # inputs on which the reference does not return a reading; recorded with what it does, next to what the product does
+    div_in = ["+5", "+3.5", "007", "0012.5", "012", "1.2.3", "1.5명", "-0명", "00.5"]
+    divergences = []
+    sys.path.insert(0, ROOT)
+    from taco_amd import korean as P
+    prod = P.KoreanNormalizer(english={k: eng_all[k] for k in eng_sub}, phrases={k: etc_all[k] for k in etc_sub})
+    for s in div_in:
+        try:
+            ref = {"returns": K.normalize_number(s)}
+        except Exception as e:           # noqa: BLE001 -- the exception type is the datum
+            ref = {"raises": type(e).__name__}
+        try:
+            got = {"returns": prod.normalize(s)}
+        except Exception as e:           # noqa: BLE001
+            got = {"raises": type(e).__name__}
+        divergences.append({"input": s, "reference": ref, "product": got, "same": ref == got})
+
+    return {
+        "generated_by": "tools/make_reference_vectors.py from /root/reference/text/korean.py (loaded by path; jamo / nltk stand-ins never called)",
+        "reference_functions": ["normalize :151-164", "normalize_with_dictionary :166-171", "normalize_english :173-182",
+                                "normalize_upper :184-190", "normalize_number :207-214", "number_to_korean :237-306"],
+        "not_covered": ["normalize_quote :192-205 (needs nltk.sent_tokenize)", "tokenize :139-147 (needs the jamo package)"],
+        "english": {k: eng_all[k] for k in eng_sub},
+        "phrases": {k: etc_all[k] for k in etc_sub},
+        "sentences": sentences, "normalize": expected,
+        "stage_inputs": stage_in, "stages": stages,
+        "number_sweep": sweep, "number_sweep_expected": plain,
+        "counted_sweep": counted_in, "counted_sweep_expected": counted,
+        "divergences": divergences,
+    }
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# datasets/datafeeder.py
+# ------------------------------------------------------------------------------------------------------------------------------
+def make_example(rs, num_mels, num_freq, with_speaker, t_lo=3, t_hi=40):
+    n_tok = int(rs.randint(2, 25))
+    T = int(rs.randint(t_lo, t_hi))
+    tokens = rs.randint(2, 80, size=n_tok).astype(np.int32)
+    tokens[-1] = 1
+    mel = rs.rand(T, num_mels).astype(np.float32)
+    lin = rs.rand(T, num_freq).astype(np.float32)
+    coeff = float(rs.choice([1.0, 0.5, 2.0]))
+    if with_speaker:
+        return (tokens, coeff, mel, lin, int(rs.randint(0, 4)), T)
+    return (tokens, coeff, mel, lin, T)
+
+
+def feeder_vectors(F):
+    out = {}
+    xs = np.arange(0, 41)
+    out["round_up_x"] = xs
+    for mult in (1, 2, 3, 4, 5, 6):
+        out["round_up_m%d" % mult] = np.array([F._round_up(int(x), mult) for x in xs], np.int64)
+    rs = np.random.RandomState(4242)
+    cases = []
+    for ci, (r, data_type, spk, nb) in enumerate([(4, "test", False, 5), (5, "train", False, 6), (4, "train", True, 7), (1, "test", True, 3),
+                                                  (2, "train", False, 1), (3, None, True, 4)]):
+        batch = [make_example(rs, 3, 5, spk) for _ in range(nb)]
+        for j, ex in enumerate(batch):
+            out["case%d_in%d_tokens" % (ci, j)] = ex[0]
+            out["case%d_in%d_coeff" % (ci, j)] = np.float32(ex[1])
+            out["case%d_in%d_mel" % (ci, j)] = ex[2]
+            out["case%d_in%d_linear" % (ci, j)] = ex[3]
+            if spk:
+                out["case%d_in%d_speaker" % (ci, j)] = np.int32(ex[4])
+        rng = np.random.RandomState(100 + ci)
+        res = F._prepare_batch(list(batch), r, rng, data_type)       # rng.shuffle(batch) when data_type == 'train' (:290-291)
+        for name, arr in zip(["inputs", "input_lengths", "loss_coeff", "mel_targets", "linear_targets", "speaker_id"], res):
+            out["case%d_out_%s" % (ci, name)] = np.asarray(arr)
+        cases.append((r, str(data_type), int(spk), nb, 100 + ci))
+    out["cases"] = np.array([[c[0], {"train": 1, "test": 2, "None": 0}[c[1]], c[2], c[3], c[4]] for c in cases], np.int64)
+
+    # the group logic: DataFeeder._enqueue_next_group (:210-243) driven on a plain namespace -- the method touches only the attributes
+    # set here; the "session" records what would have been enqueued
+    class Recorder(object):
+        def __init__(self):
+            self.feeds = []
+
+        def run(self, op, feed_dict=None):
+            self.feeds.append(feed_dict)
+
+    groups = []
+    for gi, (bs, bpg, r, dirs, data_type, step, phase) in enumerate([(4, 3, 4, ["a"], "train", 0, 100), (3, 4, 5, ["a", "b"], "train", 0, 100),
+                                                                     (4, 2, 4, ["a", "b"], "train", 500, 100)]):
+        srs = {d: np.random.RandomState(900 + 10 * gi + k) for k, d in enumerate(dirs)}
+        drawn = {d: [] for d in dirs}
+
+        def next_example(data_dir, srs=srs, drawn=drawn, dirs=dirs):
+            ex = make_example(srs[data_dir], 2, 3, len(dirs) > 1, 3, 30)
+            drawn[data_dir].append(ex)
+            return ex
+        hp = types.SimpleNamespace(reduction_factor=r, initial_data_greedy=False, initial_phase_step=phase)
+        ratio = {d: w for d, w in zip(dirs, [0.75, 0.25] if len(dirs) == 2 else [1.0])}
+        names = ["inputs", "input_lengths", "loss_coeff", "mel_targets", "linear_targets"] + (["speaker_id"] if len(dirs) > 1 else [])
+        me = types.SimpleNamespace(batch_size=bs, _hp=hp, static_batches=None, data_dirs=dirs, _step=step, _batches_per_group=bpg,
+                                   data_ratio=ratio, _get_next_example=next_example, rng=np.random.RandomState(321 + gi),
+                                   _placeholders=names, _session=Recorder(), _enqueue_op=None, data_type=data_type)
+        F.DataFeeder._enqueue_next_group(me)
+        F.DataFeeder._enqueue_next_group(me)          # a second group from the same generator state
+        for d in dirs:
+            for j, ex in enumerate(drawn[d]):
+                out["group%d_%s_in%d_tokens" % (gi, d, j)] = ex[0]
+                out["group%d_%s_in%d_coeff" % (gi, d, j)] = np.float32(ex[1])
+                out["group%d_%s_in%d_mel" % (gi, d, j)] = ex[2]
+                out["group%d_%s_in%d_linear" % (gi, d, j)] = ex[3]
+                if len(dirs) > 1:
+                    out["group%d_%s_in%d_speaker" % (gi, d, j)] = np.int32(ex[4])
+            out["group%d_%s_count" % (gi, d)] = np.int64(len(drawn[d]))
+        for bi, fd in enumerate(me._session.feeds):
+            for name in names:
+                out["group%d_batch%d_%s" % (gi, bi, name)] = np.asarray(fd[name])
+        out["group%d_nbatches" % gi] = np.int64(len(me._session.feeds))
+        ratios_used = [1.0 / len(dirs)] * len(dirs) if step < phase else [ratio[d] for d in dirs]
+        groups.append([bs, bpg, r, len(dirs), step, phase, 321 + gi] + [int(round(x * 1000)) for x in ratios_used] + [0] * (2 - len(dirs)))
+    out["groups"] = np.array(groups, np.int64)
+    return out
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("no reference checkout at %s (this script runs in the build container only)" % REF)
+    os.makedirs(GOLD, exist_ok=True)
+    K = load_reference_korean()
+    kv = korean_vectors(K)
+    with open(os.path.join(GOLD, "korean_vectors.json"), "w", encoding="utf-8") as f:
+        json.dump(kv, f, ensure_ascii=False, indent=0, sort_keys=True)
+    F = load_reference_datafeeder()
+    fv = feeder_vectors(F)
+    np.savez_compressed(os.path.join(GOLD, "feeder_vectors.npz"), **fv)
+    print("korean: %d sentences, %d + %d sweep numbers, %d divergences (%d identical); feeder: %d arrays"
+          % (len(kv["sentences"]), len(kv["number_sweep"]), len(kv["counted_sweep"]), len(kv["divergences"]),
+             sum(d["same"] for d in kv["divergences"]), len(fv)))
+
+
+if __name__ == "__main__":
+    main()

@@ -21,7 +21,7 @@ m.decoder_trace(True)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); fn(); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
-tr = m.decoder_trace(True, read=True); m.decoder_trace(False)
+tr = m.decoder_trace(True, read=True, scan=True); m.decoder_trace(False)
 names = ["gates pass+reduce", "gates epilogue+publish", "poll r*h", "barrier", "cand pass+reduce", "cand epilogue+publish+store", "poll h'", "x-part fetch issue", "barrier"]
 d = np.diff(tr[:, :10], axis=1).astype(np.float64)
 step = np.median((tr[1:, 0] - tr[:-1, 0]).astype(np.float64))
