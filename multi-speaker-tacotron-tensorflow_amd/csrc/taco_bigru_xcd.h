@@ -10,8 +10,10 @@
 //     weight columns (r, u per unit, then the candidates) in VGPRs for the whole scan: nothing is re-read;
 //   * per step two exchanges through the XCD's L2 (8-byte {value, tag} granules, see taco_decoder_xcd.h): r*h after the gates,
 //     h' after the candidate.  The x-parts come from HBM / the Infinity Cache (100 MB at C2): the member's slice of them is fetched
-//     16 steps at a time, one block ahead, into an LDS ring -- a far load inside the step loop would be waited for at the loop's
-//     back edge (and, loads returning in order, by the very next exchange poll) on every step.
+//     16 steps at a time, one block ahead, STRAIGHT INTO an LDS ring (global_load_lds_dwordx4: no VGPR is involved, so nothing can
+//     be demoted to scratch and nothing is waited for where the load is issued).  Loads return in order, so the first exchange
+//     poll after the issue also waits for it -- once per 16 steps, behind the gates pass of that step.  (Round 2 staged the block
+//     through a float4 array that the compiler kept in scratch: the far load was waited for at issue.)
 // Two geometries (NWV = waves per workgroup):
 //   NWV = 8 (default): 256 workgroups of 512 threads, one per CU, 16 groups (two per XCD), 2 units per wave.
 //   NWV = 4 (taco_debug_set_persistent(m, 9)): 512 workgroups of 256 threads, TWO per CU, 32 groups (four per XCD) of half as
@@ -29,6 +31,15 @@
 __host__ __device__ inline int gx_nreg(int NWV) { return 12 * (16 / NWV); }              // weight registers per thread
 __host__ __device__ inline int gx_ngroups(int NWV) { return 8 * (16 / NWV); }            // 16 (NWV 8: two per XCD) or 32 (NWV 4: four)
 __host__ __device__ inline size_t gx_lds_floats(int RG) { return (size_t)2 * RG * GX_H + (size_t)2 * GX_BLK * RG * 48 + 64; }
+typedef __attribute__((address_space(3))) float gx_lds_float;
+// one 16-byte-per-lane load from global memory straight into LDS: the wave's 64 x 16 bytes land contiguously at LDS byte address
+// `lds_dst` (wave-uniform, handed over in M0) + 16 * lane.  hipcc does not count this load: the caller waits (s_waitcnt vmcnt) before the
+// data is read, and a workgroup barrier lies between that wait and readers in other waves.
+__device__ __forceinline__ void gx_load_lds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 struct GxArgs {
   const float* wpack0; const float* wpack1;   // [16 members][gx_nreg][64 NWV] per direction
@@ -55,10 +66,11 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int H = GX_H, RL = DxRL<RG>::value;
-  float* hs = gx_smem;                 // [RG][H] state
+  float* xq = gx_smem;                 // [2][GX_BLK][RG][3][16]: x-parts of the member's 16 units, two blocks of GX_BLK steps (first:
+                                       // its LDS addresses go through M0 and stay below 48 KB)
+  float* hs = xq + 2 * GX_BLK * RG * 48;   // [RG][H] state
   float* xs = hs + RG * H;             // [RG][H] r * h
-  float* xq = xs + RG * H;             // [2][GX_BLK][RG][3][16]: x-parts of the member's 16 units, two blocks of GX_BLK steps
-  int* ictl = reinterpret_cast<int*>(xq + 2 * GX_BLK * RG * 48);
+  int* ictl = reinterpret_cast<int*>(xs + RG * H);
   dx_gu32* errw = (dx_gu32*)a.err;
   dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
   const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
@@ -95,27 +107,27 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
     evalid[q] = epl && (row0 + erow[q] < a.B);
     eL[q] = evalid[q] ? (a.lengths ? a.lengths[row0 + erow[q]] : T) : 0;
   }
-  // x-part blocks: item i = (step j, row r, gate g, quarter c4) of a block -> one float4 of the member's 16 units
+  // x-part blocks: item i = (step j, row r, gate g, quarter c4) of a block -> one float4 of the member's 16 units; item i of a block
+  // lives at float offset 4 * i of its ring slot, so the 64 items of one wave-load are contiguous in LDS as the LDS-direct load needs
   constexpr int NIT = GX_BLK * RG * 3 * 4, NLD = (NIT + NT - 1) / NT;
-  float4 xld[NLD];
-  auto blk_load = [&](int s0) {          // unconditional loads from clamped addresses (nothing is waited for here)
+  static_assert(NIT % 64 == 0, "a wave's 64 items are all inside the block or all outside");
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  auto blk_fetch = [&](int s0, int ring) {       // unconditional addresses (clamped); nothing is waited for here
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int i = min(u * NT + tid, NIT - 1);
-      const int c4 = i & 3, g = (i >> 2) % 3, r = (i / 12) % RG, j = i / (12 * RG);
-      const int b = min(row0 + r, a.B - 1), sx = min(s0 + j, T - 1);
-      xld[u] = *reinterpret_cast<const float4*>(a.xproj + ((size_t)b * T + sx) * 6 * H + dir * 3 * H + g * H + member * 16 + 4 * c4);
+      if (u * NT + wave * 64 < NIT) {            // wave-uniform
+        const int i = u * NT + tid;
+        const int c4 = i & 3, g = (i >> 2) % 3, r = (i / 12) % RG, j = i / (12 * RG);
+        const int b = min(row0 + r, a.B - 1), sx = min(s0 + j, T - 1);
+        const float* src = a.xproj + ((size_t)b * T + sx) * 6 * H + dir * 3 * H + g * H + member * 16 + 4 * c4;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * GX_BLK * RG * 48 + 4 * (u * NT + wave * 64)) * 4u);
+        gx_load_lds16(src, dst);
+      }
     }
   };
-  auto blk_store = [&](int ring) {
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      const int i = u * NT + tid;
-      if (i < NIT) *reinterpret_cast<float4*>(xq + (size_t)ring * GX_BLK * RG * 48 + 4 * i) = xld[u];
-    }
-  };
-  blk_load(0); blk_store(0);
-  blk_load(GX_BLK); blk_store(1);
+  blk_fetch(0, 0);
+  blk_fetch(GX_BLK, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   const int tid_outer = tid, lane_outer = lane;
@@ -125,7 +137,9 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
     asm volatile("" : "+v"(tid), "+v"(lane));
     GX_STAMP(0);
     const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
-    if (sb == 0 && s > 0) blk_load(s + GX_BLK);            // the block after next ... (its ring slot was last read one step ago)
+    // the block after next goes into the slot whose last reader finished before the barrier that ended the previous step; it is
+    // first read GX_BLK steps from now
+    if (sb == 0 && s > 0) blk_fetch(s + GX_BLK, ring ^ 1);
     float x0[RL][3][UPW];
 #pragma unroll
     for (int q = 0; q < RL; ++q)
@@ -203,7 +217,9 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
     GX_STAMP(6);
     dx_gather<RG, GX_H, false, GX_H, NT>(X + RG * H, tag, hs, 0, 0, 0, tid, rt);
     GX_STAMP(7);
-    if (sb == GX_BLK / 2 && s > GX_BLK) blk_store(ring ^ 1);     // ... lands half a block later in the slot the previous block vacated
+    // the slot fetched at the start of this block is read from the next step on: every wave makes sure ITS part has landed (it
+    // has, long ago: waves that poll have waited for it at their first poll already) ahead of the barrier that publishes it
+    if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GX_STAMP(8);
     __syncthreads();
     GX_STAMP(9);

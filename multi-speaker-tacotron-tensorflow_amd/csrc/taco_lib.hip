@@ -1466,7 +1466,8 @@ int taco_model_finalize(taco_model* m) {
   }
   make_cbhg(m, m->enc, "encoder_cbhg", hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_bank_size, hp.enc_bank_channels,
             hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width, true);
-  m->memory_layer = make_conv(m, "attention/memory_layer", false, false, true);
+  // exact fp32 (no split-bf16 pack): the keys feed the alignment argmax, the one output held to "bit-identical" (costs ~35 us per C2 forward)
+  m->memory_layer = make_conv(m, "attention/memory_layer", false, false, false);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
             hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width, true);
   if (hp.num_speakers > 1 && hp.model_type == 1) {

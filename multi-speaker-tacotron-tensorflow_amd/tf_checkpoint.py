@@ -477,8 +477,11 @@ def _cbhg_rules(scope):
     return r
 
 
-def map_tf_names(tf_vars, spec):
-    """tf_vars {tf name: array}, spec [(canonical name, shape)] -> {canonical: array}.  Raises listing what is missing."""
+def match_tf_names(tf_shapes, spec):
+    """tf_shapes {tf variable name: shape}, spec [(canonical name, shape)] -> {canonical name: tf variable name}.  Scope prefixes
+    (`model/inference/`), optimizer slots and `global_step` are ignored; variables whose TF name does not identify them (the two
+    OutputProjectionWrappers, the deepvoice dense layers, the linear head: all `.../kernel`) are told apart by shape and creation
+    order.  Raises KeyError listing what is missing / mis-shaped / unmatched."""
     want = dict(spec)
     out = {}
     rules = [(re.compile(r"^embedding$"), "embedding"), (re.compile(r"^speaker_embedding$"), "speaker_embedding"),
@@ -496,25 +499,25 @@ def map_tf_names(tf_vars, spec):
              (re.compile(r"decoder.*/cell_0/.*gru_cell/(gates|candidate)/(kernel|bias)$"), r"decoder/attention_gru/\1/\2"),
              ] + _cbhg_rules("encoder_cbhg") + _cbhg_rules("post_cbhg")
     leftovers = {}
-    for tfn, arr in tf_vars.items():
+    for tfn, shp in tf_shapes.items():
         n = _strip(tfn)
         if n == "global_step" or re.search(r"/Adam(_1)?$|beta[12]_power$", n):
             continue                                                     # optimizer slots
         for rx, repl in rules:
             mo = rx.search(n)
             if mo:
-                out[mo.expand(repl)] = arr
+                out[mo.expand(repl)] = tfn
                 break
         else:
-            leftovers[n] = arr
+            leftovers[n] = tfn
     # what is left is told apart by shape: the two output_projection_wrappers, the deepvoice dense layers, the linear head
     def take(canon_kernel, canon_bias, pred):
         if canon_kernel not in want or canon_kernel in out:
             return
         ks = want[canon_kernel]
-        for n, a in sorted(leftovers.items()):
-            if n.endswith("/kernel") and tuple(a.shape) == tuple(ks) and pred(n):
-                out[canon_kernel] = a
+        for n, tfn in sorted(leftovers.items()):
+            if n.endswith("/kernel") and tuple(tf_shapes[tfn]) == tuple(ks) and pred(n):
+                out[canon_kernel] = tfn
                 b = n[:-len("kernel")] + "bias"
                 if b in leftovers and canon_bias in want:
                     out[canon_bias] = leftovers.pop(b)
@@ -528,11 +531,17 @@ def map_tf_names(tf_vars, spec):
         take("spk/%s/kernel" % nm, "spk/%s/bias" % nm, lambda n, tfd=tfd: n == tfd + "/kernel")
     take("linear/kernel", "linear/bias", lambda n: re.match(r"^dense(_\d+)?/kernel$", n) is not None)
     missing = [k for k in want if k not in out]
-    bad = [k for k in want if k in out and tuple(np.shape(out[k])) != tuple(want[k])]
+    bad = [k for k in want if k in out and tuple(tf_shapes[out[k]]) != tuple(want[k])]
     if missing or bad:
         raise KeyError("TF checkpoint does not provide %s; wrong shapes for %s; unmatched TF variables: %s"
-                       % (missing[:8], [(k, np.shape(out[k]), want[k]) for k in bad[:4]], sorted(leftovers)[:8]))
-    return {k: np.asarray(out[k], np.float32) for k in want}
+                       % (missing[:8], [(k, tuple(tf_shapes[out[k]]), want[k]) for k in bad[:4]], sorted(leftovers)[:8]))
+    return {k: out[k] for k in want}
+
+
+def map_tf_names(tf_vars, spec):
+    """tf_vars {tf name: array}, spec [(canonical name, shape)] -> {canonical: array}.  Raises listing what is missing."""
+    names = match_tf_names({k: np.shape(v) for k, v in tf_vars.items()}, spec)
+    return {k: np.asarray(tf_vars[t], np.float32) for k, t in names.items()}
 
 
 def import_tf_checkpoint(prefix_or_dir, hparams, num_speakers=1, verify=True):

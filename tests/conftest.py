@@ -41,3 +41,14 @@ def _poisoned_device_memory(request):
             torch.cuda.synchronize()
             del x
     yield
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How much the alignment-argmax criterion ("bit-identical in argmax", BASELINE.json) masked and excused over the whole run."""
+    try:
+        from util import ARGMAX_STATS as A
+    except Exception:
+        return
+    if A["calls"]:
+        terminalreporter.write_line("argmax_match over the session: %d calls, %d steps, %d masked by the floor, %d excused as fp32 ties, "
+                                    "%d mismatches" % (A["calls"], A["steps"], A["masked_by_floor"], A["excused_as_ties"], A["mismatches"]))

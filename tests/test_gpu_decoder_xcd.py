@@ -142,6 +142,31 @@ def test_C5_real_widths_against_the_oracle():
     m._lib.taco_debug_set_att_split(m._handle, -1)
 
 
+def test_C5_full_horizon_two_rows_against_the_oracle():
+    """VERDICT r02 missing 3: the regime C5 exists for -- 1000 feedback steps of the persistent decoder and a T = 4000 post-net scan
+    (250 turns of k_bigru_xcd's prefetch ring) -- end to end against the float64 oracle, two ragged rows at T_in = 512
+    (rnn_wrappers.py:218-341, modules.py:82-96).  Nine seconds of oracle."""
+    import torch
+    B, T_in, r, n, ns, mt = O.CONFIGS["C5"]
+    ohp = O.OracleHParams(max_iters=n, reduction_factor=r)
+    w = O.init_weights(ohp, 1, 1234 + 4)
+    ids, L = O.synthetic_inputs(2, T_in, 777, ragged=True)
+    m = build_model(ohp, w)
+    lin, al = m.run(inputs=ids, input_lengths=L)
+    torch.cuda.synchronize()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    m.check_device_errors()
+    ref = O.forward(w, ohp, ids, L)
+    mel, lin, al = m.mel_outputs.cpu().numpy(), lin.cpu().numpy(), al.cpu().numpy()
+    assert mel.shape == ref["mel"].shape == (2, 4000, 80) and al.shape == (2, 512, 1000)
+    e_mel, e_lin, e_al = maxabs(mel, ref["mel"]), maxabs(lin, ref["linear"]), maxabs(al, ref["alignments"])
+    late = maxabs(mel[:, 2000:], ref["mel"][:, 2000:])
+    print("C5 full horizon: max|mel| %.2e (second half %.2e)  max|linear| %.2e  max|align| %.2e" % (e_mel, late, e_lin, e_al))
+    assert e_mel < 1e-3 and e_lin < 1e-3 and e_al < 1e-3
+    nchk, bad = argmax_match(al, ref["alignments"])
+    assert bad == 0 and nchk > 100
+
+
 def test_C1_full_length_200_steps():
     """C1 (B=1, T_in=64, r=5) over all 200 decoder steps, end to end."""
     import torch

@@ -142,3 +142,20 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
                 assert "taco_oracle" not in src and "oracle/" not in src, f
+
+
+def test_no_persistent_kernel_uses_scratch():
+    """csrc/build.sh keeps hipcc's per-kernel resource remarks; no instantiation of the persistent kernels may have scratch
+    (tools/check_kernel_resources.py: a value demoted to scratch is a memory round trip inside a dependent chain)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("no kernel_resources.txt (the library was built without csrc/build.sh)")
+    spec = importlib.util.spec_from_file_location("check_kernel_resources", os.path.join(root, "tools", "check_kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, rows, bad = mod.check(path)
+    names = [n for n, _ in kernels]
+    assert any("k_bigru_xcdILi4ELi8" in n for n in names) and any("k_decoder_xcdILi4" in n for n in names)
+    assert not bad, bad

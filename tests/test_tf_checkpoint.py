@@ -180,6 +180,13 @@ def test_tf1_fixture_dumper_prepare_and_compare_stages(tmp_path):
     r = subprocess.run([sys.executable, tool, "prepare", fixture, work, "--shards", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     assert os.path.exists(os.path.join(work, "params.json")) and os.path.exists(os.path.join(work, "model.ckpt-0.data-00001-of-00002"))
+    # `run --dry-run`: the variable list the TensorFlow side is expected to create, the name map checked in both directions and
+    # against the prepared checkpoint's index -- without TensorFlow
+    r = subprocess.run([sys.executable, tool, "run", "--dry-run", work], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "dry run OK" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
+    exp = open(os.path.join(work, "expected_variables.txt")).read().splitlines()
+    assert "model/inference/embedding:0 [80, 32]" in exp and any(l.startswith("model/inference/memory_layer/kernel:0") for l in exp)
+    assert any("cell_0/output_projection_wrapper/concat_output_and_attention_wrapper/attention_wrapper/decoder_prenet_wrapper/gru_cell/gates/kernel:0" in l for l in exp)
     g = np.load(fixture)
     from golden.make_golden import fixture_config
     ohp, _, _, _, _, ns = fixture_config()

@@ -16,10 +16,20 @@ Three stages (each is a sub-command; `prepare` and `compare` need only this repo
            Restoring that checkpoint with tf.train.Saver is at the same time the test of tf_checkpoint's writer and name map
            against real TensorFlow.
 
+  run      --dry-run <workdir>                                                         (needs neither TensorFlow nor the reference)
+           Prints (and writes <workdir>/expected_variables.txt) the variable list `run` expects tf.global_variables() to contain for
+           the prepared hyper-parameters -- name and shape, under the scope conventions of TF 1.3 / 1.4 (tf.layers `dense_N`
+           numbering in creation order, `gru_cell/{gates,candidate}/{kernel,bias}`, `bidirectional_rnn/{fw,bw}`, the wrapper chain of
+           tacotron.py:166-181) -- checks that the name map is a bijection in both directions (canonical -> TF -> canonical) and that
+           the prepared checkpoint's index holds exactly those names.  So the first real run fails on arithmetic, not on names.
+
   run      --reference /path/to/multi-speaker-tacotron-tensorflow <workdir>            (needs TensorFlow 1.x)
            Builds the reference graph exactly as synthesizer.py:28-67 does (create_model(hparams).initialize(inputs, input_lengths,
            num_speakers, speaker_id) under variable_scope('model')), restores the checkpoint, runs
            [linear_outputs, mel_outputs, alignments] (synthesizer.py:122-126,166-167) and writes <workdir>/tf1_outputs.npz.
+           The variables TensorFlow actually created are compared with the expected list first; if the names differ (another TF
+           minor version, a scope the map does not know) the difference is printed and the values are assigned variable by variable
+           through the shape-aware matcher (tf_checkpoint.match_tf_names) instead of tf.train.Saver -- the run still completes.
 
   compare  <fixture.npz> <workdir> [--tol 1e-3]
            Max-abs differences of tf1_outputs.npz against the oracle outputs stored in the fixture and the alignment-argmax check;
@@ -87,10 +97,51 @@ def prepare(args):
     print("prepared %s: params.json, model.ckpt-0 (%d variables, %d shard(s)), inputs.npz" % (args.workdir, len(spec), args.shards))
 
 
+def _prepared(workdir):
+    """(product hparams, num_speakers, canonical spec, {canonical: expected TF name}) of a prepared work directory"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import taco_amd
+    from taco_amd import tf_checkpoint as T
+    hp = taco_amd.load_hparams(taco_amd.hparams.copy(), workdir)
+    ns = int(np.load(os.path.join(workdir, "inputs.npz"))["num_speakers"])
+    spec = taco_amd.weights.weight_spec(hp, ns)
+    return hp, ns, spec, T.tf_names_for(spec, hp.attention_type)
+
+
+def dry_run(args):
+    hp, ns, spec, names = _prepared(args.workdir)
+    from taco_amd import tf_checkpoint as T
+    shapes = dict(spec)
+    expected = {names[c] + ":0": shapes[c] for c, _ in spec}
+    lines = ["%s %s" % (n, list(shp)) for n, shp in sorted(expected.items())]
+    with open(os.path.join(args.workdir, "expected_variables.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    # both directions: canonical -> TF name is injective, and the matcher that reads TF names recovers every canonical name from it
+    assert len(set(names.values())) == len(names), "two canonical weights map to one TF variable name"
+    back = T.match_tf_names({names[c]: shapes[c] for c, _ in spec}, spec)
+    wrong = [(c, back[c], names[c]) for c, _ in spec if back[c] != names[c]]
+    assert not wrong, "name map is not its own inverse: %s" % wrong[:4]
+    # and the prepared checkpoint's index holds exactly these variables (+ global_step)
+    idx = T.read_index(os.path.join(args.workdir, "model.ckpt-0.index"))
+    in_ckpt = set(k for k in idx if k) - {"global_step"}
+    want = set(names.values())
+    assert in_ckpt == want, "checkpoint index differs from the expected variables: only in checkpoint %s, only expected %s" % (
+        sorted(in_ckpt - want)[:6], sorted(want - in_ckpt)[:6])
+    print("dry run OK: %d variables for model_type=%s attention_type=%s num_speakers=%d; name map is a bijection; checkpoint index matches; "
+          "written to %s" % (len(expected), hp.model_type, hp.attention_type, ns, os.path.join(args.workdir, "expected_variables.txt")))
+
+
 def run(args):
+    if args.dry_run:
+        return dry_run(args)
+    if not args.reference:
+        sys.exit("run needs --reference <checkout of the reference> (or --dry-run)")
     ref = os.path.abspath(args.reference)
     if not os.path.isfile(os.path.join(ref, "models", "tacotron.py")):
         sys.exit("%s does not look like a checkout of the reference (models/tacotron.py missing)" % ref)
+    _, _, spec, exp_names = _prepared(args.workdir)           # before the reference's modules shadow `hparams` / `utils` / `text`
+    from taco_amd import tf_checkpoint as T
     sys.path.insert(0, ref)
     import tensorflow as tf                                  # TensorFlow 1.x (requirements.txt of the reference: 1.3.0)
     if int(tf.__version__.split(".")[0]) != 1:
@@ -110,10 +161,25 @@ def run(args):
     cfg = tf.ConfigProto(allow_soft_placement=True, intra_op_parallelism_threads=1, inter_op_parallelism_threads=2)
     with tf.Session(config=cfg) as sess:
         sess.run(tf.global_variables_initializer())
-        names = sorted(v.name for v in tf.global_variables())
+        gvars = {v.name: v for v in tf.global_variables()}
+        names = sorted(gvars)
         with open(os.path.join(args.workdir, "tf1_variables.txt"), "w") as f:
             f.write("\n".join("%s %s" % (v.name, v.shape.as_list()) for v in tf.global_variables()) + "\n")
-        tf.train.Saver().restore(sess, os.path.join(args.workdir, "model.ckpt-0"))
+        expected = set(n + ":0" for n in exp_names.values())
+        if set(names) == expected:
+            tf.train.Saver().restore(sess, os.path.join(args.workdir, "model.ckpt-0"))
+            how = "tf.train.Saver"
+        else:
+            print("variable names differ from the expected list (TensorFlow %s):" % tf.__version__)
+            for n in sorted(set(names) - expected):
+                print("  only in the graph   :", n, gvars[n].shape.as_list())
+            for n in sorted(expected - set(names)):
+                print("  only in the expected:", n)
+            match = T.match_tf_names({n[:-2]: tuple(v.shape.as_list()) for n, v in gvars.items()}, spec)    # raises with the details if hopeless
+            ckpt = T.read_checkpoint(os.path.join(args.workdir, "model.ckpt-0"))
+            for canon, tfn in match.items():
+                gvars[tfn + ":0"].load(ckpt[exp_names[canon]], sess)
+            how = "assigned one by one through tf_checkpoint.match_tf_names (report the listing above: weights.py::TF_SCOPE_MAP needs it)"
         feed = {model.inputs: d["inputs"], model.input_lengths: d["input_lengths"]}
         if ns > 1:
             feed[model.speaker_id] = d["speaker_id"]
@@ -121,7 +187,7 @@ def run(args):
         lin, mel, ali = sess.run([model.linear_outputs, model.mel_outputs, model.alignments], feed_dict=feed)
     np.savez_compressed(os.path.join(args.workdir, "tf1_outputs.npz"), linear=lin, mel=mel, alignments=ali,
                         tf_version=str(tf.__version__), n_variables=len(names))
-    print("wrote %s (TensorFlow %s, %d variables restored)" % (os.path.join(args.workdir, "tf1_outputs.npz"), tf.__version__, len(names)))
+    print("wrote %s (TensorFlow %s, %d variables restored with %s)" % (os.path.join(args.workdir, "tf1_outputs.npz"), tf.__version__, len(names), how))
 
 
 def compare(args):
@@ -156,7 +222,7 @@ def main():
     p = sub.add_parser("prepare"); p.add_argument("fixture"); p.add_argument("workdir")
     p.add_argument("--full-width", action="store_true", help="generate the fixture first (reference widths, B=2, T_in=24, 8 steps)")
     p.add_argument("--shards", type=int, default=1)
-    p = sub.add_parser("run"); p.add_argument("--reference", required=True); p.add_argument("workdir")
+    p = sub.add_parser("run"); p.add_argument("--reference"); p.add_argument("--dry-run", action="store_true"); p.add_argument("workdir")
     p = sub.add_parser("compare"); p.add_argument("fixture"); p.add_argument("workdir"); p.add_argument("--tol", type=float, default=1e-3)
     args = ap.parse_args()
     {"prepare": prepare, "run": run, "compare": compare}[args.cmd](args)
