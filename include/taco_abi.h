@@ -238,8 +238,9 @@ int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params
  * device-side error word and all workgroups leave.  This call synchronises, returns the word in *out and clears it;
  * non-zero means the outputs of the affected forward are invalid. */
 int taco_model_device_errors(taco_model* m, int* out);
-/* test hook: 0 = per-step launches for the sequential loops, 1 (default) = the persistent kernels that fit (post-net scan: k_bigru_xcd);
- * 2..7 select earlier scan kernels, 9 the two-workgroups-per-CU geometry of k_bigru_xcd (tests / A-B timing) */
+/* test hook: 0 = per-step launches for the sequential loops, 1 (default) = the persistent kernels that fit (post-net scan: k_bigru_duo);
+ * 2..7 select earlier scan kernels, 8 = k_bigru_xcd (round 2: one direction per group of 16 CUs), 9 its two-workgroups-per-CU geometry
+ * (tests / A-B timing) */
 int taco_debug_set_persistent(taco_model* m, int on);
 
 /* test hook: on = 1 (default) runs the feed-forward GEMMs of inference on the bf16 matrix cores with 3-term split

@@ -225,3 +225,254 @@ __global__ __launch_bounds__(64 * NWV) void k_bigru_xcd(const GxArgs a_in) {
     GX_STAMP(9);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_duo<RG>: the same scan with BOTH directions of RG batch rows owned by one group of 32 CUs (one XCD), the two directions
+// software-pipelined against each other inside every wave.
+//
+// k_bigru_xcd spends 42 % of a step waiting for its two exchanges: publish -> L2 -> poll is ~0.5 us and nothing else can run,
+// because the step is one dependent chain.  The forward and the backward direction of a BiGRU are two INDEPENDENT chains.  Here a
+// member owns hidden units 8m .. 8m+7 of both directions (wave w: unit 8m + w, three weight columns per direction = 24 VGPRs, the
+// same register budget as before), and a step interleaves them:
+//
+//     gates F -> publish r*h(F) | gather h'(B, previous step) | gates B -> publish r*h(B) | gather r*h(F) | candidate F -> publish
+//     h'(F) | gather r*h(B) | candidate B -> publish h'(B) | gather h'(F)
+//
+// so that every exchange has one compute phase of the other direction between its publish and its gather.  The polls are issued
+// EARLY as well: the loads of a gather are requested before the compute phase in front of it and examined after it (an L2 read
+// round trip is ~300 clocks even when the granule is already there), and only re-polled if a producer was late.  The per-wave
+// instruction count of a step is the same as k_bigru_xcd's (each direction still does RG rows per pass: the DPP reduction cost is
+// per column, not per row, so splitting the ROWS in two sets would have doubled it -- which is what the NWV = 4 geometry measured).
+// Rows per group: B <= 8: 1, <= 16: 2, <= 32: 4, <= 64: 8.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define GD_MEMBERS 32
+#define GD_NREG 24           // weight registers per thread: [dir][r | u | c][4 inputs]
+__host__ __device__ inline size_t gd_ring_floats(int RG) { return (size_t)2 * 2 * GX_BLK * RG * 24; }      // [slot][dir][step][row][gate][8 units]
+__host__ __device__ inline size_t gd_lds_floats(int RG) { return gd_ring_floats(RG) + (size_t)4 * RG * GX_H + 64; }
+__host__ __device__ inline size_t gd_xbuf_granules(int RG) { return (size_t)DX_NGROUP * 4 * RG * GX_H; }  // groups x [dir][r*h | h'] x RG x H
+
+// the loads of a gather, requested now and examined later (dx_gather split in two)
+template <int RG, int NT>
+struct GdPoll {
+  static constexpr int NI = (RG * GX_H + NT - 1) / NT;
+  unsigned long long g[NI];
+};
+template <int RG, int NT>
+__device__ __forceinline__ void gd_request(const dx_gu64* X, int tid, GdPoll<RG, NT>& p) {
+  constexpr int NI = GdPoll<RG, NT>::NI;
+  if ((RG * GX_H >= NT) || tid < RG * GX_H) {
+#pragma unroll
+    for (int u = 0; u < NI; ++u) p.g[u] = __hip_atomic_load(X + tid + u * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+// Makes the requested granules "used" at this point of the program: hipcc places the wait for the loads HERE.  Called right before a
+// phase publishes, so that the wait sees only the loads (requested a whole compute phase ago: landed) and not the publish stores
+// issued after them -- vmcnt counts in issue order, and a wait behind the stores would also wait for their acknowledgement.
+// `after` ties the statement to a value of the phase's epilogue, so that the scheduler cannot hoist it (and the wait) above the
+// phase's arithmetic.
+template <int RG, int NT>
+__device__ __forceinline__ void gd_landed(GdPoll<RG, NT>& p, float& after) {
+#pragma unroll
+  for (int u = 0; u < GdPoll<RG, NT>::NI; ++u) asm volatile("" : "+v"(p.g[u]), "+v"(after));
+}
+template <int RG, int NT>
+__device__ __forceinline__ void gd_collect(const dx_gu64* X, unsigned tag, float* st, int tid, GdPoll<RG, NT>& p, DxRt& rt) {
+  constexpr int NI = GdPoll<RG, NT>::NI;
+  if ((RG * GX_H >= NT) || tid < RG * GX_H) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) ok = ok && ((unsigned)(p.g[u] >> 32) == tag);
+    float v[NI];
+    if (ok) {
+#pragma unroll
+      for (int u = 0; u < NI; ++u) v[u] = __uint_as_float((unsigned)p.g[u]);
+    } else {
+      dx_poll<NI>(X + tid, NT, tag, v, rt);       // a producer was late: the ordinary bounded poll
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) st[u * NT + tid] = v[u];      // [RG][H] row-major == granule order
+  }
+}
+
+struct GdArgs {
+  const float* wpack;                         // [2 dirs][32 members][GD_NREG / 2][512]
+  const float* xproj;                         // [B*T, 6H] hoisted input projection, biases folded, backward direction time-reversed
+  const float* h0;                            // [B, 2H] initial states (fw | bw) or null
+  const int* lengths;                         // [B] or null (= T)
+  float* out;                                 // [B, T, 2H]
+  unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
+  int B, T, force_wt;
+};
+#define GD_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+
+template <int RG>
+__global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  constexpr int NT = 512, H = GX_H, RL = DxRL<RG>::value;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SLOT = 2 * GX_BLK * RG * 24;      // floats of one ring slot (both directions)
+  float* xq = gx_smem;                            // ring first: its LDS addresses go through M0
+  float* hs = xq + 2 * SLOT;                      // [2 dirs][RG][H] states
+  float* xs = hs + 2 * RG * H;                    // [2 dirs][RG][H] r * h
+  int* ictl = reinterpret_cast<int*>(xs + 2 * RG * H);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  const int row0 = group * RG;
+  if (row0 >= a.B || member >= GD_MEMBERS) return;
+  const int T = a.T;
+  const bool tracer = a.trace && group == 0 && member == 0 && tid == 0;
+
+  float W[GD_NREG];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float* wp = a.wpack + (((size_t)d * GD_MEMBERS + member) * 12) * NT + tid;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) W[12 * d + j] = wp[(size_t)j * NT];
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * 4 * RG * H;       // [dir][r*h : RG x H | h' : RG x H]
+  for (int i = tid; i < 2 * RG * H; i += NT) {
+    const int d = i / (RG * H), r = (i / H) % RG, n = i % H, b = row0 + r;
+    hs[i] = (a.h0 && b < a.B) ? a.h0[(size_t)b * 2 * H + d * H + n] : 0.f;
+    xs[i] = 0.f;
+  }
+  // epilogue role: quad 0 of every wave owns (rows dx_row(lane, q), unit 8 member + wave) of both directions
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+  const int u0 = member * 8 + wave;
+  int erow[RL], eL[RL];
+  bool evalid[RL];
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    erow[q] = dx_row<RG>(lane & 3, q);
+    evalid[q] = epl && (row0 + erow[q] < a.B);
+    eL[q] = evalid[q] ? (a.lengths ? a.lengths[row0 + erow[q]] : T) : 0;
+  }
+  // x-part blocks of both directions: item i = (dir, step j, row r, gate g, half c2) -> one float4 of the member's 8 units
+  constexpr int NIT = 2 * GX_BLK * RG * 3 * 2, NLD = (NIT + NT - 1) / NT;
+  static_assert(NIT % 64 == 0, "a wave's 64 items are all inside the block or all outside");
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  auto blk_fetch = [&](int s0, int ring) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      if (u * NT + wave * 64 < NIT) {            // wave-uniform
+        const int i = u * NT + tid;
+        const int c2 = i & 1, g = (i >> 1) % 3, r = (i / 6) % RG, j = (i / (6 * RG)) % GX_BLK, d = i / (6 * RG * GX_BLK);
+        const int b = min(row0 + r, a.B - 1), sx = min(s0 + j, T - 1);
+        const float* src = a.xproj + ((size_t)b * T + sx) * 6 * H + d * 3 * H + g * H + member * 8 + 4 * c2;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * SLOT + 4 * (u * NT + wave * 64)) * 4u);
+        gx_load_lds16(src, dst);
+      }
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(GX_BLK, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // per-direction registers that live from the gates phase to the candidate phase of a step
+  float x0[2][RL][3], hv[2][RL], gv[2][RL];
+  GdPoll<RG, NT> pre;       // the gather whose loads are in flight across the current compute phase
+#pragma unroll
+  for (int u = 0; u < GdPoll<RG, NT>::NI; ++u) pre.g[u] = 0ull;
+
+  const int tid_outer = tid, lane_outer = lane;
+  for (int s = 0; s < T; ++s) {
+    const unsigned tag = (unsigned)s + 1u;
+    int tid = tid_outer, lane = lane_outer;                 // opaque per-iteration copies: see taco_decoder_xcd.h
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    GD_STAMP(0);
+    const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
+    if (sb == 0 && s > 0) blk_fetch(s + GX_BLK, ring ^ 1);
+    // one lambda per phase kind; D is a compile-time direction
+    auto gates = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+      const float* hsd = hs + D * RG * H;
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g) x0[D][q][g] = xq[(size_t)ring * SLOT + ((size_t)(D * GX_BLK + sb) * RG + erow[q]) * 24 + g * 8 + wave];
+        hv[D][q] = hsd[erow[q] * H + u0];
+      }
+      float acc[2][RG], sm[2][RL];
+      dx_zero<2, RG>(acc);
+      dx_pass<12 * D, 2, RG, GD_NREG, GX_H>(W, hsd, lane, acc);
+      dx_reduce<2, RG>(acc, sm, lane);
+      float rh[RL][1];
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float rr = dx_sigmoid_fast(sm[0][q] + x0[D][q][0]);
+        gv[D][q] = dx_sigmoid_fast(sm[1][q] + x0[D][q][1]);
+        rh[q][0] = rr * hv[D][q];
+      }
+      gd_landed<RG, NT>(pre, rh[RL - 1][0]);
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)D * 2 * RG * H + erow[q] * H + u0, 1, rh[q], tag, rt);
+      }
+    };
+    auto cand = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+      float acc[1][RG], sm[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<12 * D + 8, 1, RG, GD_NREG, GX_H>(W, xs + D * RG * H, lane, acc);
+      dx_reduce<1, RG>(acc, sm, lane);
+      float nv[RL][1];
+      bool active[RL];
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        active[q] = s < eL[q];                               // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+        const float cc = taco_tanh_fast(sm[0][q] + x0[D][q][2]);
+        float blend = gv[D][q] * hv[D][q] + (1.f - gv[D][q]) * cc;
+        DX_PIN(blend);
+        nv[q][0] = active[q] ? blend : hv[D][q];
+      }
+      gd_landed<RG, NT>(pre, nv[RL - 1][0]);
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)(D * 2 + 1) * RG * H + erow[q] * H + u0, 1, nv[q], tag, rt);
+      }
+#pragma unroll
+      for (int q = 0; q < RL; ++q)
+        if (evalid[q]) {
+          const int t = (D && active[q]) ? (eL[q] - 1 - s) : s;
+          a.out[((size_t)(row0 + erow[q]) * T + t) * 2 * H + D * H + u0] = active[q] ? nv[q][0] : 0.f;
+        }
+    };
+    using F = std::integral_constant<int, 0>;
+    using Bk = std::integral_constant<int, 1>;
+    const dx_gu64* X_rhF = X;                       const dx_gu64* X_hF = X + (size_t)RG * H;
+    const dx_gu64* X_rhB = X + (size_t)2 * RG * H;  const dx_gu64* X_hB = X + (size_t)3 * RG * H;
+    // (the loads for h'(B) of the previous step were requested at the end of that step)
+    gates(F{});
+    GD_STAMP(1);
+    if (s > 0) gd_collect<RG, NT>(X_hB, tag - 1u, hs + RG * H, tid, pre, rt);
+    __syncthreads();
+    GD_STAMP(2);
+    gd_request<RG, NT>(X_rhF, tid, pre);
+    gates(Bk{});
+    GD_STAMP(3);
+    gd_collect<RG, NT>(X_rhF, tag, xs, tid, pre, rt);
+    __syncthreads();
+    GD_STAMP(4);
+    gd_request<RG, NT>(X_rhB, tid, pre);
+    cand(F{});
+    GD_STAMP(5);
+    gd_collect<RG, NT>(X_rhB, tag, xs + RG * H, tid, pre, rt);
+    __syncthreads();
+    GD_STAMP(6);
+    gd_request<RG, NT>(X_hF, tid, pre);
+    cand(Bk{});
+    GD_STAMP(7);
+    gd_collect<RG, NT>(X_hF, tag, hs, tid, pre, rt);
+    if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
+    __syncthreads();
+    GD_STAMP(8);
+    gd_request<RG, NT>(X_hB, tid, pre);
+  }
+}

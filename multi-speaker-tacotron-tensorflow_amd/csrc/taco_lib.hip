@@ -102,6 +102,7 @@ struct Cbhg {
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
+  size_t gd_pack = 0;                                  // k_bigru_duo: [2 dirs][32 members][12][512]
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
                                                    // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
@@ -530,6 +531,26 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
         }
       } }
   }
+  if (H == GX_H && !m->tp) {
+    // k_bigru_duo<RG>: member mem, wave w owns unit 8 mem + w of BOTH directions; lane l holds h rows 4l..4l+3 of its r, u and c columns
+    std::vector<float> gp((size_t)2 * GD_MEMBERS * 12 * 512, 0.f);
+    for (int dir = 0; dir < 2; ++dir) {
+      const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+      const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
+      for (int mem = 0; mem < GD_MEMBERS; ++mem)
+        for (int tid = 0; tid < 512; ++tid) {
+          const int w = tid >> 6, l = tid & 63, u = mem * 8 + w;
+          for (int e = 0; e < 4; ++e) {
+            const size_t kr = (size_t)(I + 4 * l + e);
+            float* base = &gp[(((size_t)dir * GD_MEMBERS + mem) * 12) * 512 + tid];
+            base[(size_t)(0 + e) * 512] = gk[kr * 2 * H + u];
+            base[(size_t)(4 + e) * 512] = gk[kr * 2 * H + H + u];
+            base[(size_t)(8 + e) * 512] = ck[kr * H + u];
+          }
+        }
+    }
+    c.gd_pack = arena_put(m, gp.data(), gp.size());
+  }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
   X.wp = pack_w32(m, Wx.data(), 1, I, 6 * H, &X.cin_pad, &Kq, &NT);
@@ -803,11 +824,31 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
   if (m->skip_scans) return 0;
-  if ((m->persist == 1 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
+  if (m->persist == 1 && m->dx_mode && c.gd_pack && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
+    // both directions of RG rows on one group of 32 CUs, software-pipelined against each other (k_bigru_duo, taco_bigru_xcd.h)
+    GdArgs a; memset(&a, 0, sizeof a);
+    a.wpack = AP(m, c.gd_pack); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
+    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
+    a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+    int RG = 1;
+    while (RG * DX_NGROUP < B) RG *= 2;
+    HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
+    const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+    const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo<1>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo<2>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo<4>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo<8>), grid, blk, lds, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if ((m->persist == 8 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
     // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
     // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
     // clocks per step at C2): the phases of a step are chains of dependent instructions, a wave alone on its SIMD is no faster
-    const int NWV = m->persist == 9 ? 4 : 8, rowgroups = gx_ngroups(NWV) / 2;
+    const int NWV = m->persist == 9 ? 4 : 8, rowgroups = gx_ngroups(NWV) / 2;     // persist 8: round 2's default geometry
     GxArgs a; memset(&a, 0, sizeof a);
     const size_t* pk = NWV == 8 ? c.gx_pack : c.gx_pack4;
     a.wpack0 = AP(m, pk[0]); a.wpack1 = AP(m, pk[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
@@ -837,7 +878,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     HIPCHK(hipGetLastError());
     return 0;
   }
-  if ((m->persist == 1 || m->persist >= 4) && H == 256) {
+  if ((m->persist == 1 || (m->persist >= 4 && m->persist <= 7)) && H == 256) {
     // weights resident on the CU, 4 hidden units per thread: k_bigru_resw 3.74 us/step; its predecessor k_bigru_resu (persist 6)
     // 5.16, one unit per thread (k_bigru_res, persist 3) 5.7, re-streaming everything (k_bigru_rows, persist 2) 7.1
     BigruSArgs a; memset(&a, 0, sizeof a);

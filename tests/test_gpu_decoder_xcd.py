@@ -211,9 +211,11 @@ def test_C3_full_length_128_steps_on_8_of_the_32_rows():
 
 @pytest.mark.parametrize("B", [1, 7, 32, 64])
 def test_post_net_scan_spread_over_the_chip(B):
-    """k_bigru_xcd (csrc/taco_bigru_xcd.h; the default at H = 256): 16 groups of 16 CUs, one direction and ceil(B/8) rows each, two
-    L2 exchanges per step.  Against the oracle's bidirectional GRU (modules.py:82-96, A.6/A.7) with ragged lengths (incl. 0 and T)
-    and an initial state, against the one-CU-per-chain kernel it replaces, and bit-repeatable."""
+    """The whole-chip scans of csrc/taco_bigru_xcd.h at H = 256: k_bigru_duo (the default: 8 groups of 32 CUs, BOTH directions of
+    ceil(B/8) rows each, the two directions software-pipelined against each other with early-issued polls) and k_bigru_xcd (round
+    2: 16 groups of 16 CUs, one direction each; persist 8, and its two-workgroups-per-CU geometry, persist 9).  Against the oracle's
+    bidirectional GRU (modules.py:82-96, A.6/A.7) with ragged lengths (incl. 0 and T) and an initial state, against the
+    one-CU-per-chain kernel they replace, and bit-repeatable."""
     import ctypes as C
     import torch
     import taco_amd
@@ -232,7 +234,7 @@ def test_post_net_scan_spread_over_the_chip(B):
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
     got = {}
-    for persist in (1, 1, 9, 7):        # 1: one 8-wave workgroup per CU (default); 9: two 4-wave workgroups per CU; 7: one CU per chain
+    for persist in (1, 1, 8, 8, 9, 7):  # 1: k_bigru_duo (default); 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU; 7: one CU per chain
         m._lib.taco_debug_set_persistent(m._handle, persist)
         for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
             out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
@@ -244,8 +246,10 @@ def test_post_net_scan_spread_over_the_chip(B):
     v = (C.c_int * 16)()
     taco_amd._lib.check(m._lib.taco_debug_decoder_info(m._handle, v))
     for tag, ref in (("plain", O.bidirectional_gru(x, None, w, "post_cbhg/bigru")), ("ragged", O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init))):
-        a, b = got[(1, tag)]
-        assert np.array_equal(a, b), "k_bigru_xcd is not bit-repeatable (%s)" % tag
-        assert maxabs(a, ref) < 1e-4, tag
-        assert maxabs(a, got[(7, tag)][0]) < 2e-5, tag
+        for persist, name in ((1, "k_bigru_duo"), (8, "k_bigru_xcd")):
+            a, b = got[(persist, tag)]
+            assert np.array_equal(a, b), "%s is not bit-repeatable (%s)" % (name, tag)
+            assert maxabs(a, ref) < 1e-4, (name, tag)
+            assert maxabs(a, got[(7, tag)][0]) < 2e-5, (name, tag)
+        a = got[(1, tag)][0]
         assert maxabs(got[(9, tag)][0], ref) < 1e-4 and maxabs(a, got[(9, tag)][0]) < 2e-5, tag

@@ -7,7 +7,7 @@ touches sits in registers or LDS; a value the compiler demotes to scratch turns 
 issue).  csrc/build.sh compiles with -Rpass-analysis=kernel-resource-usage and keeps the remarks in csrc/kernel_resources.txt;
 this script reads them and fails when
 
-  * any instantiation of k_bigru_xcd or k_pointwise_chain has ScratchSize > 0, or
+  * any instantiation of k_bigru_xcd, k_bigru_duo or k_pointwise_chain has ScratchSize > 0, or
   * any instantiation of k_decoder_xcd has, except the 8-rows-per-group one, whose 256-VGPR budget is known to spill
     (<= 144 bytes per lane today; it fails if that grows).
 
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
-PERSISTENT = ("k_bigru_xcd", "k_decoder_xcd", "k_pointwise_chain")
+PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_pointwise_chain")
 ALLOWED_SCRATCH = {"_Z13k_decoder_xcdILi8EEv6DxArgs": 144}        # bytes per lane
 
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, taco_amd
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-PERSIST = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # 1: one 8-wave workgroup per CU (default); 9: two 4-wave workgroups per CU
+PERSIST = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # 1: k_bigru_duo (default); 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU
 hp = taco_amd.hparams.copy(max_iters=128)
 m = taco_amd.create_model(hp); m.initialize(None, None, 1, None)
 L = m._lib
@@ -22,8 +22,13 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); fn(); e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3
 tr = m.decoder_trace(True, read=True, scan=True); m.decoder_trace(False)
-names = ["gates pass+reduce", "gates epilogue+publish", "poll r*h", "barrier", "cand pass+reduce", "cand epilogue+publish+store", "poll h'", "x-part fetch issue", "barrier"]
-d = np.diff(tr[:, :10], axis=1).astype(np.float64)
+if PERSIST == 1:
+    names = ["gates F (+publish)", "collect h'(B) + barrier", "request + gates B (+publish)", "collect r*h(F) + barrier", "request + cand F (+publish, store)",
+             "collect r*h(B) + barrier", "request + cand B (+publish, store)", "collect h'(F) + barrier"]
+    d = np.diff(tr[:, :9], axis=1).astype(np.float64)
+else:
+    names = ["gates pass+reduce", "gates epilogue+publish", "poll r*h", "barrier", "cand pass+reduce", "cand epilogue+publish+store", "poll h'", "x-part fetch issue", "barrier"]
+    d = np.diff(tr[:, :10], axis=1).astype(np.float64)
 step = np.median((tr[1:, 0] - tr[:-1, 0]).astype(np.float64))
 print("B=%d T=%d geometry %d: %.1f us total (GEMM + scan), step = %.0f clocks" % (B, T, PERSIST, us, step))
 med = np.median(d[1:], axis=0)
