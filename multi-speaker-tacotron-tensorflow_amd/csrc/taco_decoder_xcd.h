@@ -28,6 +28,12 @@
 //     of a stage that do not depend on the vector in flight (the h rows of the gates, the context rows of the next prenet, ...)
 //     run before the wait for it.
 //   * Every spin is bounded; a timeout raises a.err and the launch drains without hanging.
+//   * Manual attention (rnn_wrappers.py:313-317: `alignments = manual_alignments[:, time, :]`): the query, score, exchange and
+//     normaliser phases of a step are skipped; the row of the step is fetched at the top of the step straight into LDS
+//     (global_load_lds_dword, nothing waits for it there) and is the alignment the context / history / state are built from.
+//   * Model type 'simple' (rnn_wrappers.py:372-376, 408-413): the speaker embedding is one more input segment of the attention GRU and
+//     of the concat projection; it is constant over the loop, so its products with those rows are formed once per launch by a
+//     small kernel (k_dx_rowbias) and enter the epilogues as per-(row, column) biases.
 #pragma once
 #include "taco_kernels.h"
 
@@ -74,6 +80,9 @@ enum { DXS_P2 = 0, DXS_HATT = 128, DXS_CTX = 384, DXS_OUT2 = 640, DXS_T = 896, D
 // own-column bias table in LDS: bl[slot][wave]
 enum { DXB_P1 = 0, DXB_P2, DXB_AR, DXB_AU, DXB_AC, DXB_G1R, DXB_G1U, DXB_G1X, DXB_O0, DXB_G1C, DXB_G2R, DXB_G2U, DXB_G2C, DXB_F0, DXB_F1,
        DXB_N };
+// per-row bias slots (model type 'simple'): the speaker embedding's product with the speaker rows of the attention GRU (r, u,
+// candidate-x) and of the folded GRU 1 (r, u, candidate-x, o0); rowbias[b][slot][256]
+enum { DXRB_AR = 0, DXRB_AU, DXRB_AX, DXRB_G1R, DXRB_G1U, DXRB_G1X, DXRB_O0, DXRB_N };
 
 // exchange buffers of one group, in granules, for RG rows (the host sizes the buffer with RG = 8)
 struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, total; };
@@ -98,6 +107,8 @@ __host__ __device__ inline size_t dx_lds_floats(int RG, int T_in) {
   n += 3 * 64;                        // qv, vv, bq (own channels, DC <= 64)
   n += (size_t)DX_NW * 64;            // context partials [wave][DC]
   n += (size_t)DXB_N * DX_NW;         // own-column biases
+  n += (size_t)DXRB_N * RG * DX_NW;   // per-row biases of the own columns ('simple': speaker term)
+  n += (size_t)((T_in + 63) & ~63);   // manual alignment row of the step
   n += 64;                            // control words
   return n;
 }
@@ -115,6 +126,8 @@ struct DxArgs {
   const float* att_v; const float* att_b; const float* score_bias;
   const float* keys; const float* values;              // [B, T_in, 256] each
   const float* h_att0; const float* h10; const float* h20;   // deepvoice initial states [B, 256] or null (zeros)
+  const float* manual;                                 // [B, n, T_in] manual alignments (rnn_wrappers.py:313-317) or null
+  const float* rowbias;                                // [B, DXRB_N, 256] ('simple') or null
   float* mel; float* hist; int* nz; float* dbg;
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T_in, n, rM, att_type, grp0, ngroups, force_wt, dbgw;
@@ -409,6 +422,15 @@ __device__ __forceinline__ void dx_normalise_lds(float* sc, float* tmp, float* t
   }
 }
 
+typedef __attribute__((address_space(3))) float dx_lds_float;
+// 4 bytes per lane from global memory straight into LDS: the wave's 64 floats land at LDS byte address lds_dst (wave-uniform) + 4 * lane.
+// Not counted by hipcc: the consumer waits (any later s_waitcnt vmcnt(0) of the issuing wave covers it: loads retire in order).
+__device__ __forceinline__ void dx_load_lds4(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // Census of a persistent launch of 256 (or 512: two per CU) workgroups: every workgroup reports the XCD it runs on (HW_REG_XCC_ID)
 // and takes the next slot there; when all have arrived and every XCD hosts exactly gridDim.x / 8 of them, the XCD-local protocol is used (exchange stores stay
 // in the XCD's L2) and a workgroup's place is (xcc, slot); otherwise -- or with force_wt -- places follow blockIdx and the stores
@@ -439,6 +461,17 @@ __device__ __forceinline__ void dx_census(dx_gu32* ctl, dx_gu32* errw, int force
     }
   }
   __syncthreads();
+}
+
+// 'simple' speaker term: rowbias[b][slot][n] = sum_k table[speaker_id[b]][k] * spkw[k][slot][n]   (S = speaker_embedding_size rows)
+__global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const int* speaker_id, const float* spkw, int S, float* rowbias) {
+  const int b = blockIdx.x, n = threadIdx.x;
+  const float* e = table + (size_t)speaker_id[b] * S;
+  for (int slot = 0; slot < DXRB_N; ++slot) {
+    float acc = 0.f;
+    for (int k = 0; k < S; ++k) acc = fmaf(e[k], spkw[((size_t)k * DXRB_N + slot) * DX_W + n], acc);
+    rowbias[((size_t)b * DXRB_N + slot) * DX_W + n] = acc;
+  }
 }
 
 #define DX_STAMP(slot)                                                                                     \
@@ -479,7 +512,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   float* bq = vv + 64;
   float* cpart = bq + 64;                    // [DX_NW][64]
   float* bl = cpart + DX_NW * 64;            // [DXB_N][DX_NW]
-  int* ictl = reinterpret_cast<int*>(bl + DXB_N * DX_NW);
+  float* rbl = bl + DXB_N * DX_NW;           // [DXRB_N][RG][DX_NW]
+  float* mrow = rbl + DXRB_N * RG * DX_NW;   // [roundup(T, 64)] manual alignments of the step
+  int* ictl = reinterpret_cast<int*>(mrow + ((T + 63) & ~63));
 
   // ---- census: which XCD am I on, is every XCD hosting exactly one group? ----
   dx_gu32* ctl = (dx_gu32*)a.ctl;
@@ -567,7 +602,13 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     }
     bl[tid] = v;
   }
+  for (int i = tid; i < DXRB_N * RG * DX_NW; i += DX_NT) {      // rbl[slot][row][wave]
+    const int e = i / (RG * DX_NW), r = (i / DX_NW) % RG, w = i % DX_NW, b = row0 + r;
+    rbl[i] = (a.rowbias && b < a.B) ? a.rowbias[((size_t)b * DXRB_N + e) * DX_W + member * 8 + w] : 0.f;
+  }
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
+  const bool man = a.manual != nullptr;
+  const unsigned mrow_lds = (unsigned)(size_t)(dx_lds_float*)mrow;
   __syncthreads();
 
   // epilogue role: the lanes of quad 0 own the outputs (rows dx_row(lane, q), column 8*member + wave) of every 256-wide stage
@@ -577,6 +618,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   int erow[RL];
 #pragma unroll
   for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
+#define DX_RB(slot, q) rbl[((slot) * RG + erow[q]) * DX_NW + wave]
   float g_u[RL], g_cx[RL], g_h[RL], g_o0[RL];            // live between the two stages of a GRU cell
   // (accumulators of the passes that run ahead of their stage live across exactly one gather)
 
@@ -588,6 +630,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     int tid = tid_outer, lane = lane_outer;
     asm volatile("" : "+v"(tid), "+v"(lane));
     DX_STAMP(0);
+    if (man) {   // this step's manual alignments of the member's row -> LDS (consumed three exchanges from now)
+      const float* src = a.manual + ((size_t)min(brow, a.B - 1) * a.n + t) * T;
+      for (int j0 = wave * 64; j0 < T; j0 += DX_NT)
+        dx_load_lds4(src + min(j0 + lane, T - 1), __builtin_amdgcn_readfirstlane(mrow_lds + (unsigned)j0 * 4u));
+    }
     // ================= prenet layer 2 (modules.py:18-25); LDS T = prenet layer 1 =================
     if (wave < 4) {
       float acc[1][RG], s[1][RL];
@@ -615,9 +662,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       dx_reduce<3, RG>(aga, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_AR * DX_NW + wave]);
-        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_AU * DX_NW + wave]);
-        g_cx[q] = s[2][q];
+        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_AR * DX_NW + wave] + DX_RB(DXRB_AR, q));
+        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_AU * DX_NW + wave] + DX_RB(DXRB_AU, q));
+        g_cx[q] = s[2][q] + DX_RB(DXRB_AX, q);
         if (epl) dx_publish(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
       }
     }
@@ -641,41 +688,43 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     __syncthreads();
     DX_STAMP(3);
     // ================= attention (rnn_wrappers.py:304-341) =================
-    {  // query for the member's own score channels of its row: columns cb*DS + wave*QC + i
-      const float4 xv = *reinterpret_cast<const float4*>(st + arow * DXS_LD + DXS_HATT + 4 * lane);
-      float qa[QC][1], qs[QC][1];
+    if (!man) {
+      {  // query for the member's own score channels of its row: columns cb*DS + wave*QC + i
+        const float4 xv = *reinterpret_cast<const float4*>(st + arow * DXS_LD + DXS_HATT + 4 * lane);
+        float qa[QC][1], qs[QC][1];
 #pragma unroll
-      for (int i = 0; i < QC; ++i) {
-        float q = WQ[4 * i] * xv.x;
-        q = fmaf(WQ[4 * i + 1], xv.y, q); q = fmaf(WQ[4 * i + 2], xv.z, q); q = fmaf(WQ[4 * i + 3], xv.w, q);
-        qa[i][0] = q;
-      }
-      dx_reduce<QC, 1>(qa, qs, lane);
-      float qme = qs[0][0];
-#pragma unroll
-      for (int i = 1; i < QC; ++i) qme = (lane >= i) ? qs[i][0] : qme;
-      if (lane < QC) qv[wave * QC + lane] = qme + bq[wave * QC + lane];
-    }
-    __syncthreads();
-    DX_STAMP(4);
-    {  // partial scores over the member's channel block (A.9): a quad of lanes per encoder position, CH channels per lane
-      const int jl = lane >> 2, cp = lane & 3;
-      float qreg[CH], vreg[CH];
-#pragma unroll
-      for (int c = 0; c < CH; ++c) { qreg[c] = qv[cp * CH + c]; vreg[c] = vv[cp * CH + c]; }
-      for (int j0 = 0; j0 < psn; j0 += 16 * DX_NW) {
-        const int j = j0 + wave * 16 + jl;
-        const int jc = j < psn ? j : psn - 1;
-        const float* kp = Kc + (size_t)jc * DS + cp * CH;
-        float e = 0.f;
-#pragma unroll
-        for (int c = 0; c < CH; c += 4) {
-          const float4 k4 = *reinterpret_cast<const float4*>(kp + c);
-          e += vreg[c] * taco_tanh_fast(k4.x + qreg[c]) + vreg[c + 1] * taco_tanh_fast(k4.y + qreg[c + 1]) +
-               vreg[c + 2] * taco_tanh_fast(k4.z + qreg[c + 2]) + vreg[c + 3] * taco_tanh_fast(k4.w + qreg[c + 3]);
+        for (int i = 0; i < QC; ++i) {
+          float q = WQ[4 * i] * xv.x;
+          q = fmaf(WQ[4 * i + 1], xv.y, q); q = fmaf(WQ[4 * i + 2], xv.z, q); q = fmaf(WQ[4 * i + 3], xv.w, q);
+          qa[i][0] = q;
         }
-        e = dx_quadsum(e);
-        if (cp == 0 && j < psn) dx_publish(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
+        dx_reduce<QC, 1>(qa, qs, lane);
+        float qme = qs[0][0];
+#pragma unroll
+        for (int i = 1; i < QC; ++i) qme = (lane >= i) ? qs[i][0] : qme;
+        if (lane < QC) qv[wave * QC + lane] = qme + bq[wave * QC + lane];
+      }
+      __syncthreads();
+      DX_STAMP(4);
+      {  // partial scores over the member's channel block (A.9): a quad of lanes per encoder position, CH channels per lane
+        const int jl = lane >> 2, cp = lane & 3;
+        float qreg[CH], vreg[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { qreg[c] = qv[cp * CH + c]; vreg[c] = vv[cp * CH + c]; }
+        for (int j0 = 0; j0 < psn; j0 += 16 * DX_NW) {
+          const int j = j0 + wave * 16 + jl;
+          const int jc = j < psn ? j : psn - 1;
+          const float* kp = Kc + (size_t)jc * DS + cp * CH;
+          float e = 0.f;
+#pragma unroll
+          for (int c = 0; c < CH; c += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(kp + c);
+            e += vreg[c] * taco_tanh_fast(k4.x + qreg[c]) + vreg[c + 1] * taco_tanh_fast(k4.y + qreg[c + 1]) +
+                 vreg[c + 2] * taco_tanh_fast(k4.z + qreg[c + 2]) + vreg[c + 3] * taco_tanh_fast(k4.w + qreg[c + 3]);
+          }
+          e = dx_quadsum(e);
+          if (cp == 0 && j < psn) dx_publish(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
+        }
       }
     }
     // ahead of its turn: GRU 1 (concat projection folded in): h1 rows of the gates, then the h_att rows of r, u, candidate-x, o0
@@ -683,39 +732,47 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     dx_zero<4, RG>(g1a);
     dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
     dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
-    {  // gather the row's partial scores and sum them over the Pc channel blocks (fixed order)
-      const int jl = lane >> 2, part = lane & 3;
-      for (int j0 = 0; j0 < T; j0 += 16 * DX_NW) {
-        const int j = j0 + wave * 16 + jl;
-        float s = 0.f;
-        if (j < T) {
-          float v[NP];
-          dx_poll<NP>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
+    const float* al = sc;          // the step's alignments: computed (sc) or manual (mrow)
+    if (!man) {
+      {  // gather the row's partial scores and sum them over the Pc channel blocks (fixed order)
+        const int jl = lane >> 2, part = lane & 3;
+        for (int j0 = 0; j0 < T; j0 += 16 * DX_NW) {
+          const int j = j0 + wave * 16 + jl;
+          float s = 0.f;
+          if (j < T) {
+            float v[NP];
+            dx_poll<NP>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
 #pragma unroll
-          for (int u = 0; u < NP; ++u) s += v[u];
+            for (int u = 0; u < NP; ++u) s += v[u];
+          }
+          s = dx_quadsum(s);
+          if (part == 0 && j < T) sc[j] = s;
         }
-        s = dx_quadsum(s);
-        if (part == 0 && j < T) sc[j] = s;
       }
+      __syncthreads();
+      DX_STAMP(5);
+      if (wave == 0) {   // normaliser over the whole row, redundantly on each of the row's members (lane = C consecutive positions)
+        const int C = (T + 63) >> 6;
+        const int j0 = lane * C;
+        if (C <= 2) dx_normalise<2>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
+        else if (C <= 8) dx_normalise<8>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
+        else dx_normalise_lds(sc, tmp, tmp2, alp, j0, min(j0 + C, T), a.att_type, sbias);
+      }
+      __syncthreads();
+    } else {
+      // the row requested at the top of the step: every wave makes sure its own part has landed, the barrier publishes all parts
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      al = mrow;
     }
-    __syncthreads();
-    DX_STAMP(5);
-    if (wave == 0) {   // normaliser over the whole row, redundantly on each of the row's members (lane = C consecutive positions)
-      const int C = (T + 63) >> 6;
-      const int j0 = lane * C;
-      if (C <= 2) dx_normalise<2>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
-      else if (C <= 8) dx_normalise<8>(sc, alp, j0, min(C, max(T - j0, 0)), a.att_type, sbias);
-      else dx_normalise_lds(sc, tmp, tmp2, alp, j0, min(j0 + C, T), a.att_type, sbias);
-    }
-    __syncthreads();
     {  // alignment state + history (tacotron.py:238-239 layout) for the member's block of positions; context channel block
-      for (int j = tid; j < T; j += DX_NT) alp[j] = sc[j];
+      for (int j = tid; j < T; j += DX_NT) alp[j] = al[j];
       const int p0 = asl * TP;
-      if (tid < TP && p0 + tid < T && brow < a.B) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = sc[p0 + tid];
+      if (tid < TP && p0 + tid < T && brow < a.B) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = al[p0 + tid];
       constexpr int JL = 64 / DC;                    // positions handled side by side inside a wave
       const int d = lane % DC, jsub = lane / DC;
       float part = 0.f;
-      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(sc[j], Vc[(size_t)j * DC + d], part);
+      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(al[j], Vc[(size_t)j * DC + d], part);
       if (DC <= 32) part = dx_xrow32(part);
       if (DC <= 16) part = dx_xrow16(part);
       if (DC <= 8) part += DX_DPP0(part, 0x128);
@@ -739,10 +796,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       DX_STAMP(12);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G1R * DX_NW + wave]);
-        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G1U * DX_NW + wave]);
-        g_cx[q] = s[2][q] + bl[DXB_G1X * DX_NW + wave];
-        g_o0[q] = s[3][q] + bl[DXB_O0 * DX_NW + wave];
+        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G1R * DX_NW + wave] + DX_RB(DXRB_G1R, q));
+        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G1U * DX_NW + wave] + DX_RB(DXRB_G1U, q));
+        g_cx[q] = s[2][q] + bl[DXB_G1X * DX_NW + wave] + DX_RB(DXRB_G1X, q);
+        g_o0[q] = s[3][q] + bl[DXB_O0 * DX_NW + wave] + DX_RB(DXRB_O0, q);
         if (epl) dx_publish(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
       }
       DX_STAMP(13);

@@ -146,6 +146,7 @@ struct taco_model {
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
+  size_t dx_spkw = 0;          // 'simple': speaker rows of the attention GRU and of the folded GRU 1, [S][DXRB_N][256] (k_dx_rowbias)
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
   int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
@@ -367,7 +368,7 @@ static bool dx_widths_ok(const taco_model* m) {
   const taco_hparams& hp = m->hp;
   return hp.attention_state_size == DX_W && hp.dec_rnn_size == DX_W && hp.attention_size == DX_W && 2 * hp.enc_rnn_size == DX_W &&
          hp.dec_prenet_n == 2 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2 && hp.dec_layer_num == 2 &&
-         hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP && !is_simple(m);
+         hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP;
 }
 // one weight column of a pass: registers reg0 .. reg0+kw-1 of every thread = W[row0 + kw*lane + e][col(wave)]  (col < 0: none)
 template <class ColFn>
@@ -386,6 +387,8 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   if (!dx_widths_ok(m)) return 0;
   const taco_hparams& hp = m->hp;
   const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, NCF = cdiv(rM, DX_GROUP);
+  const int S = is_simple(m) ? hp.speaker_embedding_size : 0;     // 'simple': S speaker rows behind the prenet output / behind [h_att | ctx]
+  const int IA = DX_P2 + S, Z = 2 * H + S;                        // first h row of the attention GRU kernels / of the folded GRU 1 matrix
   std::vector<float> pack((size_t)DX_GROUP * DX_NREG * DX_NT, 0.f);
   const auto& W2 = T_(m, "decoder/prenet/dense_2/kernel").data;
   const auto& agk = T_(m, "decoder/attention_gru/gates/kernel").data; const auto& ack = T_(m, "decoder/attention_gru/candidate/kernel").data;
@@ -401,12 +404,12 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
     auto f1 = [&](int w) { const int n = mem * NCF + w + 8; return (w + 8 < NCF && n < rM) ? n : -1; };
     auto put = [&](int reg0, int kw, const float* W, int ldw, int row0, auto col) { dx_fill_col(pack, DX_NREG, mem, reg0, kw, W, ldw, row0, col); };
     put(DXR_P2, 4, W2.data(), DX_P2, 0, c4);
-    put(DXR_AGH, 4, agk.data(), 2 * H, DX_P2, c8); put(DXR_AGH + 4, 4, agk.data(), 2 * H, DX_P2, cu);            // h rows
+    put(DXR_AGH, 4, agk.data(), 2 * H, IA, c8); put(DXR_AGH + 4, 4, agk.data(), 2 * H, IA, cu);                  // h rows
     put(DXR_AGX, 2, agk.data(), 2 * H, 0, c8); put(DXR_AGX + 2, 2, agk.data(), 2 * H, 0, cu); put(DXR_AGX + 4, 2, ack.data(), H, 0, c8);
-    put(DXR_AC, 4, ack.data(), H, DX_P2, c8);
+    put(DXR_AC, 4, ack.data(), H, IA, c8);
     auto fx = [&](int w) { return 2 * H + mem * 8 + w; };
     auto fo = [&](int w) { return 3 * H + mem * 8 + w; };
-    put(DXR_G1H, 4, Wf.data(), 4 * H, 2 * H, c8); put(DXR_G1H + 4, 4, Wf.data(), 4 * H, 2 * H, cu);                // h1 rows
+    put(DXR_G1H, 4, Wf.data(), 4 * H, Z, c8); put(DXR_G1H + 4, 4, Wf.data(), 4 * H, Z, cu);                        // h1 rows
     put(DXR_G1A, 4, Wf.data(), 4 * H, 0, c8); put(DXR_G1A + 4, 4, Wf.data(), 4 * H, 0, cu);                        // h_att rows
     put(DXR_G1A + 8, 4, Wf.data(), 4 * H, 0, fx); put(DXR_G1A + 12, 4, Wf.data(), 4 * H, 0, fo);
     put(DXR_G1B, 4, Wf.data(), 4 * H, H, c8); put(DXR_G1B + 4, 4, Wf.data(), 4 * H, H, cu);                        // context rows
@@ -420,6 +423,18 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
     put(DXR_F, 4, fk.data(), rM, 0, f0); put(DXR_F + 4, 4, fk.data(), rM, 0, f1);
   }
   m->dx_pack = arena_put(m, pack.data(), pack.size());
+  if (S) {   // speaker rows: [k][slot][n], slots in DXRB_* order
+    std::vector<float> sw((size_t)S * DXRB_N * H);
+    for (int k = 0; k < S; ++k)
+      for (int n = 0; n < H; ++n) {
+        float* o = &sw[(size_t)k * DXRB_N * H + n];
+        o[DXRB_AR * H] = agk[(size_t)(DX_P2 + k) * 2 * H + n]; o[DXRB_AU * H] = agk[(size_t)(DX_P2 + k) * 2 * H + H + n];
+        o[DXRB_AX * H] = ack[(size_t)(DX_P2 + k) * H + n];
+        const float* wf = &Wf[(size_t)(2 * H + k) * 4 * H];
+        o[DXRB_G1R * H] = wf[n]; o[DXRB_G1U * H] = wf[H + n]; o[DXRB_G1X * H] = wf[2 * H + n]; o[DXRB_O0 * H] = wf[3 * H + n];
+      }
+    m->dx_spkw = arena_put(m, sw.data(), sw.size());
+  }
   // query layer: slot s of a row (s = member % Pr) scores channel block s % Pc and holds columns (s % Pc)*DS + w*QC + i of it; one pack
   // per rows-per-group
   for (int q = 0; q < 4; ++q) {
@@ -1131,6 +1146,7 @@ struct DecWs {
   float *keys, *zero, *ctx, *pz[4], *h_att, *rh, *u, *xc, *q, *align, *o[5], *hd[4], *Y, *escr;
   int* nz;
   unsigned long long* xbuf; size_t xbuf_bytes; unsigned* dxctl;   // persistent decoder: exchange granules, census words
+  float* rowbias;                                                 // persistent decoder, 'simple': [B, DXRB_N, 256]
   SpkWs spk;
 };
 static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, DecWs& w) {
@@ -1156,13 +1172,15 @@ static void carve_dec(Carver& cv, const taco_model* m, int B, int T_in, int n, D
     w.xbuf_bytes = (size_t)DX_NGROUP * dx_xlayout(8, T_in).total * sizeof(unsigned long long);
     w.xbuf = (unsigned long long*)cv.raw(w.xbuf_bytes);
     w.dxctl = (unsigned*)cv.raw(256);
+    w.rowbias = cv.f(is_simple(m) ? (size_t)B * DXRB_N * DX_W : 1);
   }
 }
-// persistent decoder: usable for this call?  (reference widths, no manual alignments / teacher forcing, the member's LDS fits)
+// persistent decoder: usable for this call?  (reference widths, no teacher forcing, the member's LDS fits)
 static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual, const float* teacher) {
   // 256 workgroups, one per CU, all resident at once: only on a whole MI355X (a partition of it -- CPX / DPX modes -- or a smaller
   // part would leave workgroups waiting for CUs held by workgroups that wait for them)
-  if (!m->dx_mode || !m->dx_pack || manual || teacher || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
+  (void)manual;   // manual alignments are a mode of the persistent kernel (the score phases are skipped)
+  if (!m->dx_mode || !m->dx_pack || teacher || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
   const int RG = dx_rows_per_group(m, B);
   return dx_lds_floats(RG, T_in) * sizeof(float) <= 160 * 1024;
 }
@@ -1172,10 +1190,16 @@ static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, int B, int T_in, int n, float* mel, float* align_out,
-                     float* dbg, int dbgw, const DecWs& w, const float* h_att0, const float* h10, const float* h20) {
+static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B, int T_in, int n, const float* manual,
+                     float* mel, float* align_out, float* dbg, int dbgw, const DecWs& w, const float* h_att0, const float* h10, const float* h20) {
   const int RG = dx_rows_per_group(m, B);
   DxArgs a; memset(&a, 0, sizeof a);
+  a.manual = manual;
+  if (is_simple(m)) {   // the speaker embedding's share of the attention GRU and GRU 1 pre-activations, once per launch
+    hipLaunchKernelGGL(k_dx_rowbias, dim3(B), dim3(DX_W), 0, st, AP(m, m->spk_emb), speaker_id, AP(m, m->dx_spkw), m->hp.speaker_embedding_size, w.rowbias);
+    HIPCHK(hipGetLastError());
+    a.rowbias = w.rowbias;
+  }
   a.wpack = AP(m, m->dx_pack);
   a.qpack = AP(m, m->dx_qpack[RG == 1 ? 0 : RG == 2 ? 1 : RG == 4 ? 2 : 3]);
   a.b_p1_0 = AP(m, m->dx_b_p1_0); a.b_p1c = AP(m, m->dx_b_p1c); a.b_p2 = AP(m, m->dx_b_p2); a.b_ag = AP(m, m->dx_b_ag); a.b_ac = AP(m, m->dx_b_ac);
@@ -1225,8 +1249,8 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
     // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
     // vectors); the launch-per-stage loop below is the general path
-    TRY(dx_launch(m, st, enc_out, B, T_in, n, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr,
-                  dv ? spk->vec[4] : nullptr));
+    TRY(dx_launch(m, st, enc_out, speaker_id, B, T_in, n, manual, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr,
+                  dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr));
     if (stop_step) {
       hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
       HIPCHK(hipGetLastError());

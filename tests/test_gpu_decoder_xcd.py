@@ -106,20 +106,74 @@ def test_stop_flags_of_the_persistent_decoder():
     assert int(stop.item()) == 1 and not mel.cpu().numpy().any()
 
 
-def test_unsupported_calls_fall_back_to_the_launch_engine():
-    """manual alignments and teacher forcing are served by the launch-per-stage loop (same results as before)."""
+@pytest.mark.parametrize("B,T_in,atype", [(2, 16, "bah_mon"), (5, 37, "bah"), (32, 128, "bah_mon"), (9, 200, "bah_norm"), (40, 70, "bah_mon")])
+def test_manual_attention_on_the_persistent_decoder(B, T_in, atype):
+    """rnn_wrappers.py:313-317: `alignments = manual_alignments[:, time, :]` -- a mode of k_decoder_xcd (the query / score /
+    normaliser phases are skipped, the step's row goes straight into LDS): every decoder state of every step against the oracle,
+    rows per group 1 / 2 / 4 / 8, input lengths that are not multiples of a wave, and against the launch-per-stage engine."""
+    import torch
+    n = 5
+    ohp = O.OracleHParams(max_iters=n, attention_type=atype)
+    w = O.init_weights(ohp, 1, 321)
+    ids, L = O.synthetic_inputs(B, T_in, 322 + B, ragged=True)
+    man = np.random.RandomState(3 + B).dirichlet(np.ones(T_in), (B, n))
+    taps = {}
+    ref = O.forward(w, ohp, ids, L, manual_alignments=man, taps=taps, honor_stop=False)
+    m = build_model(ohp, w)
+    mel, al, _, dbg = m.decoder(taps["encoder"], n, manual_alignments=man, debug=True)
+    torch.cuda.synchronize()
+    info = m.decoder_engine_info()
+    m.check_device_errors()
+    assert info["has_pack"] and info["protocol"] in (1, 2), info          # served by the persistent kernel, not by the fallback
+    dbg = dbg.cpu().numpy()
+    As, D, H = ohp.attention_state_size, 2 * ohp.enc_rnn_size, ohp.dec_rnn_size
+    for t, st in enumerate(taps["steps"]):
+        assert maxabs(dbg[t, :, :As], st["h_att"]) < 2e-4 and maxabs(dbg[t, :, As:As + D], st["ctx"]) < 2e-4, t
+        for i, h in enumerate(st["h"]):
+            assert maxabs(dbg[t, :, As + D + i * H:As + D + (i + 1) * H], h) < 2e-4, (t, i)
+    assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4
+    assert maxabs(al.cpu().numpy(), np.transpose(man, (0, 2, 1))) < 1e-6
+    m.set_decoder_engine(0)
+    mel0, al0, _, _ = m.decoder(taps["encoder"], n, manual_alignments=man)
+    torch.cuda.synchronize()
+    assert maxabs(mel0.cpu().numpy(), mel.cpu().numpy()) < 2e-5 and np.array_equal(al0.cpu().numpy(), al.cpu().numpy())
+
+
+@pytest.mark.parametrize("atype,B", [("bah_mon", 6), ("bah", 33)])
+def test_simple_multispeaker_on_the_persistent_decoder(atype, B):
+    """model_type 'simple' (rnn_wrappers.py:372-376, 408-413): the speaker embedding is an input segment of the attention GRU and of
+    the concat projection; in k_decoder_xcd its (loop-invariant) products enter as per-row biases (k_dx_rowbias).  Every state of
+    every step against the oracle, and the whole forward end to end."""
+    import torch
+    ns, n = 3, 5
+    ohp = O.OracleHParams(max_iters=n, model_type="simple", attention_type=atype)
+    w = O.init_weights(ohp, ns, 331)
+    ids, L = O.synthetic_inputs(B, 29, 332, ragged=True)
+    spk = (np.arange(B) % ns).astype(np.int32)
+    m, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, n, spk=spk, ns=ns)
+    assert info["has_pack"] and info["protocol"] in (1, 2), info
+    lin, al = m.run(inputs=ids, input_lengths=L, speaker_id=spk)
+    torch.cuda.synchronize()
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns)
+    k = ref["mel"].shape[1]
+    assert maxabs(m.mel_outputs.cpu().numpy()[:, :k], ref["mel"]) < 2e-4 and maxabs(lin.cpu().numpy()[:, :k], ref["linear"]) < 2e-4
+    m.check_device_errors()
+
+
+def test_teacher_forcing_still_runs_the_launch_engine():
+    """teacher-forced frames (helpers.py:35-67; the training forward) are not a mode of the persistent decoder: same results from
+    the launch-per-stage loop as before."""
     import torch
     ohp = O.OracleHParams(max_iters=4)
     w = O.init_weights(ohp, 1, 321)
     ids, L = O.synthetic_inputs(2, 16, 322)
-    man = np.random.RandomState(3).dirichlet(np.ones(16), (2, 4))
+    frames = np.random.RandomState(5).rand(2, 4, ohp.num_mels)
     taps = {}
-    ref = O.forward(w, ohp, ids, L, manual_alignments=man, taps=taps, honor_stop=False)
+    ref = O.forward(w, ohp, ids, L, n_steps=4, teacher_frames=frames, taps=taps)
     m = build_model(ohp, w)
-    mel, al, _, _ = m.decoder(taps["encoder"], 4, manual_alignments=man)
+    mel, al, _, _ = m.decoder(taps["encoder"], 4, teacher_frames=frames)
     torch.cuda.synchronize()
     assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4
-    assert maxabs(al.cpu().numpy(), np.transpose(man, (0, 2, 1))) < 1e-6
 
 
 def test_C5_real_widths_against_the_oracle():
