@@ -9,13 +9,32 @@
 // ---- weight packs regenerated from the flat parameter buffer after every optimizer step ----
 // map[i] = 1 + flat index of the parameter that pack element i copies (the host packers run once over
 // index-valued tensors); anything else = zero padding / unused.
+// Indices NP + 1 .. NP + NF address a second source F (computed values: the GRU-1 fold of the persistent decoder, k_dx_fold).
 __global__ __launch_bounds__(256) void k_pack_gather(const float* __restrict__ map, const float* __restrict__ P,
-                                                    float* __restrict__ arena, size_t n, unsigned NP) {
+                                                    float* __restrict__ arena, size_t n, unsigned NP, const float* __restrict__ F, unsigned NF) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const float v = map[i];
     float o = 0.f;
-    if (v >= 1.f && v <= (float)NP) { const unsigned iv = (unsigned)v; if ((float)iv == v) o = P[iv - 1]; }
+    if (v >= 1.f && v <= (float)(NP + NF)) {
+      const unsigned iv = (unsigned)v;
+      if ((float)iv == v) o = iv <= NP ? P[iv - 1] : F[iv - NP - 1];
+    }
     arena[i] = o;
+  }
+}
+// The concat projection folded into decoder GRU 1 (taco_model_finalize does it on the host, in double, for inference):
+//   F[z][j] = sum_k C[z][k] * G[k][j],  z = 0 .. Z (row Z: C = the projection's bias), j = 0 .. 3H-1,
+//   G = [gates kernel x rows (2H columns) | candidate kernel x rows (H columns)],  row Z, j < 2H additionally + gates bias[j].
+// One workgroup per row z; fp32 with a fixed summation order.
+__global__ __launch_bounds__(256) void k_dx_fold(const float* __restrict__ Wc, const float* __restrict__ bc, const float* __restrict__ gk,
+                                                const float* __restrict__ gb, const float* __restrict__ ck, float* __restrict__ F, int Z, int H) {
+  const int z = blockIdx.x;
+  const float* c = z < Z ? Wc + (size_t)z * H : bc;
+  for (int j = threadIdx.x; j < 3 * H; j += 256) {
+    float acc = 0.f;
+    if (j < 2 * H) { for (int k = 0; k < H; ++k) acc = fmaf(c[k], gk[(size_t)k * 2 * H + j], acc); if (z == Z) acc += gb[j]; }
+    else { for (int k = 0; k < H; ++k) acc = fmaf(c[k], ck[(size_t)k * H + (j - 2 * H)], acc); }
+    F[(size_t)z * 3 * H + j] = acc;
   }
 }
 

@@ -300,6 +300,7 @@ struct GdArgs {
   const float* h0;                            // [B, 2H] initial states (fw | bw) or null
   const int* lengths;                         // [B] or null (= T)
   float* out;                                 // [B, T, 2H]
+  float* gsave;                               // TAPE instantiation: [B*T, 6H] gates (r | u | c per direction) at the TRUE time index (zeroed by the caller)
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T, force_wt;
 };
@@ -308,7 +309,7 @@ struct GdArgs {
     if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
-template <int RG>
+template <int RG, bool TAPE = false>
 __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float gx_smem[];
   GdArgs a = a_in;
@@ -409,6 +410,10 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
         const float rr = dx_sigmoid_fast(sm[0][q] + x0[D][q][0]);
         gv[D][q] = dx_sigmoid_fast(sm[1][q] + x0[D][q][1]);
         rh[q][0] = rr * hv[D][q];
+        if (TAPE && evalid[q] && s < eL[q]) {      // gates of the active steps at their true time (modules.py:82-96 / A.7), for the backward scan
+          float* gs = a.gsave + ((size_t)(row0 + erow[q]) * T + (D ? eL[q] - 1 - s : s)) * 6 * H + D * 3 * H + u0;
+          gs[0] = rr; gs[H] = gv[D][q];
+        }
       }
       gd_landed<RG, NT>(pre, rh[RL - 1][0]);
       if (epl) {
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
         float blend = gv[D][q] * hv[D][q] + (1.f - gv[D][q]) * cc;
         DX_PIN(blend);
         nv[q][0] = active[q] ? blend : hv[D][q];
+        if (TAPE && evalid[q] && active[q]) a.gsave[((size_t)(row0 + erow[q]) * T + (D ? eL[q] - 1 - s : s)) * 6 * H + D * 3 * H + 2 * H + u0] = cc;
       }
       gd_landed<RG, NT>(pre, nv[RL - 1][0]);
       if (epl) {

@@ -34,6 +34,10 @@
 //   * Model type 'simple' (rnn_wrappers.py:372-376, 408-413): the speaker embedding is one more input segment of the attention GRU and
 //     of the concat projection; it is constant over the loop, so its products with those rows are formed once per launch by a
 //     small kernel (k_dx_rowbias) and enter the epilogues as per-(row, column) biases.
+//   * Training forward (TAPE instantiation; helpers.py:35-67, train.py:215-219): the frame fed to the next step's prenet comes from
+//     the teacher buffer (fetched straight into LDS one step ahead of its use) instead of the step's own output, and every value the
+//     backward pass needs (gates, candidates, r*h, states, the concat projection, the processed query, raw scores, alignments,
+//     context) is written to the tape by the lane that produces it -- [B, n, .] arrays, the layout of DecTape in taco_train.h.
 #pragma once
 #include "taco_kernels.h"
 
@@ -84,6 +88,10 @@ enum { DXB_P1 = 0, DXB_P2, DXB_AR, DXB_AU, DXB_AC, DXB_G1R, DXB_G1U, DXB_G1X, DX
 // candidate-x) and of the folded GRU 1 (r, u, candidate-x, o0); rowbias[b][slot][256]
 enum { DXRB_AR = 0, DXRB_AU, DXRB_AX, DXRB_G1R, DXRB_G1U, DXRB_G1X, DXRB_O0, DXRB_N };
 
+// tape slots of the TAPE instantiation: [B, n, 256] arrays carved back to back (carve_dec_tape), slot s at tape + s * tstride
+enum { DXT_P1 = 0, DXT_HA, DXT_RA, DXT_UA, DXT_CA, DXT_RHA, DXT_Q, DXT_O0, DXT_R1, DXT_U1, DXT_C1, DXT_RH1, DXT_H1, DXT_O1,
+       DXT_R2, DXT_U2, DXT_C2, DXT_RH2, DXT_H2, DXT_O2, DXT_N };
+
 // exchange buffers of one group, in granules, for RG rows (the host sizes the buffer with RG = 8)
 struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, total; };
 __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
@@ -96,7 +104,7 @@ __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
   return x;
 }
 // LDS floats of a member (host mirror of the carve in the kernel)
-__host__ __device__ inline size_t dx_lds_floats(int RG, int T_in) {
+__host__ __device__ inline size_t dx_lds_floats(int RG, int T_in, bool teacher = false) {
   const int Pr = DX_GROUP / RG, DC = DX_W / Pr, Tpad = (T_in + 3) & ~3;
   const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
   size_t n = 0;
@@ -109,6 +117,7 @@ __host__ __device__ inline size_t dx_lds_floats(int RG, int T_in) {
   n += (size_t)DXB_N * DX_NW;         // own-column biases
   n += (size_t)DXRB_N * RG * DX_NW;   // per-row biases of the own columns ('simple': speaker term)
   n += (size_t)((T_in + 63) & ~63);   // manual alignment row of the step
+  if (teacher) n += (size_t)RG * DX_W;   // teacher frames of the step (TAPE instantiation)
   n += 64;                            // control words
   return n;
 }
@@ -128,6 +137,12 @@ struct DxArgs {
   const float* h_att0; const float* h10; const float* h20;   // deepvoice initial states [B, 256] or null (zeros)
   const float* manual;                                 // [B, n, T_in] manual alignments (rnn_wrappers.py:313-317) or null
   const float* rowbias;                                // [B, DXRB_N, 256] ('simple') or null
+  // TAPE instantiation only (training forward):
+  const float* teacher;                                // [B, n, mels]: frame t feeds the prenet of step t + 1 (helpers.py:44,66)
+  float* tape; size_t tstride;                         // 256-wide per-step arrays: slot s, row (b, t) at tape + s*tstride + (b*n + t)*256
+  float* tp_p2; float* tp_ctx; int ld_p2, ld_ctx;      // prenet output [B, n, ld_p2], context [B, n, ld_ctx] (wider rows: 'simple' parks the speaker embedding behind them)
+  float* tp_e; float* tp_alpha;                        // raw scores [B, n, T_in]; alignments [B, n + 1, T_in] (slot t + 1 = step t)
+  int mels;
   float* mel; float* hist; int* nz; float* dbg;
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T_in, n, rM, att_type, grp0, ngroups, force_wt, dbgw;
@@ -466,7 +481,7 @@ __device__ __forceinline__ void dx_census(dx_gu32* ctl, dx_gu32* errw, int force
 // 'simple' speaker term: rowbias[b][slot][n] = sum_k table[speaker_id[b]][k] * spkw[k][slot][n]   (S = speaker_embedding_size rows)
 __global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const int* speaker_id, const float* spkw, int S, float* rowbias) {
   const int b = blockIdx.x, n = threadIdx.x;
-  const float* e = table + (size_t)speaker_id[b] * S;
+  const float* e = table + (size_t)(speaker_id ? speaker_id[b] : b) * S;      // no ids: `table` already holds the batch's rows
   for (int slot = 0; slot < DXRB_N; ++slot) {
     float acc = 0.f;
     for (int k = 0; k < S; ++k) acc = fmaf(e[k], spkw[((size_t)k * DXRB_N + slot) * DX_W + n], acc);
@@ -479,7 +494,7 @@ __global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const i
     if (tracer && t < DX_TRACE_STEPS) a.trace[t * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
-template <int RG>
+template <int RG, bool TAPE = false>
 __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float dx_smem[];
   DxArgs a = a_in;
@@ -514,7 +529,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   float* bl = cpart + DX_NW * 64;            // [DXB_N][DX_NW]
   float* rbl = bl + DXB_N * DX_NW;           // [DXRB_N][RG][DX_NW]
   float* mrow = rbl + DXRB_N * RG * DX_NW;   // [roundup(T, 64)] manual alignments of the step
-  int* ictl = reinterpret_cast<int*>(mrow + ((T + 63) & ~63));
+  float* tfb = mrow + ((T + 63) & ~63);      // [RG][DX_W] teacher frames (TAPE only)
+  int* ictl = reinterpret_cast<int*>(tfb + (TAPE ? RG * DX_W : 0));
 
   // ---- census: which XCD am I on, is every XCD hosting exactly one group? ----
   dx_gu32* ctl = (dx_gu32*)a.ctl;
@@ -609,6 +625,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
   const bool man = a.manual != nullptr;
   const unsigned mrow_lds = (unsigned)(size_t)(dx_lds_float*)mrow;
+  const unsigned tfb_lds = (unsigned)(size_t)(dx_lds_float*)tfb;
+  if (TAPE) for (int i = tid; i < RG * DX_W; i += DX_NT) tfb[i] = 0.f;
   __syncthreads();
 
   // epilogue role: the lanes of quad 0 own the outputs (rows dx_row(lane, q), column 8*member + wave) of every 256-wide stage
@@ -620,6 +638,24 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
 #define DX_RB(slot, q) rbl[((slot) * RG + erow[q]) * DX_NW + wave]
   float g_u[RL], g_cx[RL], g_h[RL], g_o0[RL];            // live between the two stages of a GRU cell
+  // tape (TAPE): the lane that owns (row, column) of a stage writes it; trow = float offset of step 0 of the lane's row in a [B, n, 256] array
+  // (32-bit element offsets: the host checks DXT_N * tstride < 2^31, so an address is the SGPR base + one VGPR)
+  unsigned trow[RL];
+  bool tval[RL];
+  float g_o1[RL];
+  const unsigned tstr = (unsigned)a.tstride;
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    trow[q] = (unsigned)(row0 + erow[q]) * (unsigned)a.n * DX_W + (unsigned)en;
+    tval[q] = TAPE && a.tape && epl && (row0 + erow[q] < a.B);
+    g_o1[q] = 0.f;
+  }
+#define DX_TAPE(slot, q, val) do { if (TAPE && tval[q]) a.tape[(unsigned)(slot) * tstr + trow[q] + (unsigned)t * DX_W] = (val); } while (0)
+  if (TAPE) {   // step 0's prenet layer 1 is the constant relu(b1)
+    const int t = 0;
+#pragma unroll
+    for (int q = 0; q < RL; ++q) DX_TAPE(DXT_P1, q, fmaxf(a.b_p1_0[en], 0.f));
+  }
   // (accumulators of the passes that run ahead of their stage live across exactly one gather)
 
   const int tid_outer = tid, lane_outer = lane;
@@ -635,6 +671,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       for (int j0 = wave * 64; j0 < T; j0 += DX_NT)
         dx_load_lds4(src + min(j0 + lane, T - 1), __builtin_amdgcn_readfirstlane(mrow_lds + (unsigned)j0 * 4u));
     }
+    if (TAPE && a.teacher && wave < RG && t + 1 < a.n) {   // teacher frame t (the input of step t + 1's prenet) of row `wave` -> LDS
+      const float* src = a.teacher + ((size_t)min(row0 + wave, a.B - 1) * a.n + t) * a.mels;
+      for (int j0 = 0; j0 < a.mels; j0 += 64)
+        dx_load_lds4(src + min(j0 + lane, a.mels - 1), __builtin_amdgcn_readfirstlane(tfb_lds + (unsigned)(wave * DX_W + j0) * 4u));
+    }
     // ================= prenet layer 2 (modules.py:18-25); LDS T = prenet layer 1 =================
     if (wave < 4) {
       float acc[1][RG], s[1][RL];
@@ -643,8 +684,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       dx_reduce<1, RG>(acc, s, lane);
       if (epl) {
 #pragma unroll
-        for (int q = 0; q < RL; ++q)
-          dx_publish(X + xl.p2 + erow[q] * DX_P2 + member * 4 + wave, fmaxf(s[0][q] + bl[DXB_P2 * DX_NW + wave], 0.f), tag, rt);
+        for (int q = 0; q < RL; ++q) {
+          const float p2v = fmaxf(s[0][q] + bl[DXB_P2 * DX_NW + wave], 0.f);
+          dx_publish(X + xl.p2 + erow[q] * DX_P2 + member * 4 + wave, p2v, tag, rt);
+          if (TAPE && tval[q] && a.tp_p2) a.tp_p2[((size_t)(row0 + erow[q]) * a.n + t) * a.ld_p2 + member * 4 + wave] = p2v;
+        }
       }
     }
 #pragma unroll
@@ -666,6 +710,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_AU * DX_NW + wave] + DX_RB(DXRB_AU, q));
         g_cx[q] = s[2][q] + DX_RB(DXRB_AX, q);
         if (epl) dx_publish(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        DX_TAPE(DXT_RA, q, rg); DX_TAPE(DXT_UA, q, g_u[q]); DX_TAPE(DXT_RHA, q, rg * g_h[q]);
       }
     }
     dx_gather<RG, DX_W, false>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
@@ -679,7 +724,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_AC * DX_NW + wave]);
-        if (epl) dx_publish(X + xl.ha + erow[q] * DX_W + en, g_u[q] * g_h[q] + (1.f - g_u[q]) * c, tag, rt);
+        const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
+        if (epl) dx_publish(X + xl.ha + erow[q] * DX_W + en, hn, tag, rt);
+        DX_TAPE(DXT_CA, q, c); DX_TAPE(DXT_HA, q, hn);
       }
     }
 #pragma unroll
@@ -703,6 +750,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
         for (int i = 1; i < QC; ++i) qme = (lane >= i) ? qs[i][0] : qme;
         if (lane < QC) qv[wave * QC + lane] = qme + bq[wave * QC + lane];
+        if (TAPE && a.tape && lane < QC && pb == 0 && brow < a.B)      // processed query W_q . h (without attention_b), once per channel block
+          a.tape[(unsigned)DXT_Q * tstr + ((unsigned)brow * (unsigned)a.n + (unsigned)t) * DX_W + cb * DS + wave * QC + lane] = qme;
       }
       __syncthreads();
       DX_STAMP(4);
@@ -751,6 +800,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       }
       __syncthreads();
       DX_STAMP(5);
+      if (TAPE && a.tp_e && tid < TP && asl * TP + tid < T && brow < a.B)     // raw scores (before the normaliser) of the member's positions
+        a.tp_e[((size_t)brow * a.n + t) * T + asl * TP + tid] = sc[asl * TP + tid];
+      if (TAPE) __syncthreads();                                              // ... read before wave 0 normalises in place
       if (wave == 0) {   // normaliser over the whole row, redundantly on each of the row's members (lane = C consecutive positions)
         const int C = (T + 63) >> 6;
         const int j0 = lane * C;
@@ -768,7 +820,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     {  // alignment state + history (tacotron.py:238-239 layout) for the member's block of positions; context channel block
       for (int j = tid; j < T; j += DX_NT) alp[j] = al[j];
       const int p0 = asl * TP;
-      if (tid < TP && p0 + tid < T && brow < a.B) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = al[p0 + tid];
+      if (tid < TP && p0 + tid < T && brow < a.B) {
+        if (a.hist) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = al[p0 + tid];
+        if (TAPE && a.tp_alpha) a.tp_alpha[((size_t)brow * (a.n + 1) + t + 1) * T + p0 + tid] = al[p0 + tid];
+      }
       constexpr int JL = 64 / DC;                    // positions handled side by side inside a wave
       const int d = lane % DC, jsub = lane / DC;
       float part = 0.f;
@@ -784,6 +839,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
       for (int w = 0; w < DX_NW; ++w) s += cpart[w * 64 + tid];
       dx_publish(X + xl.ctx + arow * DX_W + asl * DC + tid, s, tag, rt);
+      if (TAPE && a.tp_ctx && brow < a.B) a.tp_ctx[((size_t)brow * a.n + t) * a.ld_ctx + asl * DC + tid] = s;
     }
     dx_gather<RG, DX_W, false>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
     __syncthreads();
@@ -801,6 +857,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         g_cx[q] = s[2][q] + bl[DXB_G1X * DX_NW + wave] + DX_RB(DXRB_G1X, q);
         g_o0[q] = s[3][q] + bl[DXB_O0 * DX_NW + wave] + DX_RB(DXRB_O0, q);
         if (epl) dx_publish(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        DX_TAPE(DXT_R1, q, rg); DX_TAPE(DXT_U1, q, g_u[q]); DX_TAPE(DXT_RH1, q, rg * g_h[q]); DX_TAPE(DXT_O0, q, g_o0[q]);
       }
       DX_STAMP(13);
     }
@@ -817,10 +874,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G1C * DX_NW + wave]);
         const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
+        g_o1[q] = hn + g_o0[q];
         if (epl) {
           dx_publish(X + xl.h1 + erow[q] * DX_W + en, hn, tag, rt);
           dx_publish(X + xl.o1 + erow[q] * DX_W + en, hn + g_o0[q], tag, rt);       // ResidualWrapper: cell output + cell input
         }
+        DX_TAPE(DXT_C1, q, c); DX_TAPE(DXT_H1, q, hn); DX_TAPE(DXT_O1, q, g_o1[q]);
       }
     }
 #pragma unroll
@@ -843,6 +902,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G2U * DX_NW + wave]);
         g_cx[q] = s[2][q];
         if (epl) dx_publish(X + xl.rh2 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        DX_TAPE(DXT_R2, q, rg); DX_TAPE(DXT_U2, q, g_u[q]); DX_TAPE(DXT_RH2, q, rg * g_h[q]);
       }
     }
     dx_gather<RG, DX_W, false>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
@@ -856,7 +916,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G2C * DX_NW + wave]);
-        if (epl) dx_publish(X + xl.h2 + erow[q] * DX_W + en, g_u[q] * g_h[q] + (1.f - g_u[q]) * c, tag, rt);
+        const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
+        if (epl) dx_publish(X + xl.h2 + erow[q] * DX_W + en, hn, tag, rt);
+        DX_TAPE(DXT_C2, q, c); DX_TAPE(DXT_H2, q, hn); DX_TAPE(DXT_O2, q, hn + g_o1[q]);
       }
     }
     // ahead of its turn: next step's prenet layer 1, context rows
@@ -874,12 +936,19 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
       for (int r = 0; r < RG; ++r) fa[2][r] = p1a[0][r];
       dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[2][RG]>(fa));
-      dx_pass<DXR_P1O, 1, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
+      // prenet layer 1 of the next step: from this step's own output (frame projection folded into the registers), or -- teacher
+      // forcing -- from the teacher's frame (raw kernel rows in the same registers, zero beyond num_mels)
+      if (TAPE) dx_pass<DXR_P1O, 1, RG, DX_NREG, DX_W>(W, tfb, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
+      else dx_pass<DXR_P1O, 1, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
       dx_reduce<3, RG>(fa, s, lane);
       if (epl) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
-          if (t + 1 < a.n) dx_publish(X + xl.p1 + erow[q] * DX_W + en, fmaxf(s[2][q] + bl[DXB_P1 * DX_NW + wave], 0.f), tag, rt);
+          if (t + 1 < a.n) {
+            const float p1v = fmaxf(s[2][q] + bl[DXB_P1 * DX_NW + wave], 0.f);
+            dx_publish(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
+            if (TAPE && tval[q]) a.tape[(unsigned)DXT_P1 * tstr + trow[q] + (unsigned)(t + 1) * DX_W] = p1v;
+          }
           const int b = row0 + erow[q];
           if (b < a.B) {
             const float y0 = s[0][q] + bl[DXB_F0 * DX_NW + wave], y1 = s[1][q] + bl[DXB_F1 * DX_NW + wave];

@@ -146,6 +146,7 @@ struct taco_model {
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
+  size_t dx_fold_n = 0;        // training shadow model: elements of the GRU-1 fold buffer (k_dx_fold), addressed by the index map as NP + 1 + i
   size_t dx_spkw = 0;          // 'simple': speaker rows of the attention GRU and of the folded GRU 1, [S][DXRB_N][256] (k_dx_rowbias)
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
@@ -546,7 +547,7 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
         }
       } }
   }
-  if (H == GX_H && !m->tp) {
+  if (H == GX_H) {
     // k_bigru_duo<RG>: member mem, wave w owns unit 8 mem + w of BOTH directions; lane l holds h rows 4l..4l+3 of its r, u and c columns
     std::vector<float> gp((size_t)2 * GD_MEMBERS * 12 * 512, 0.f);
     for (int dir = 0; dir < 2; ++dir) {
@@ -832,6 +833,41 @@ static size_t bigru_res_lds(int H, int KL, int R) {
   return ((size_t)3 * R * H + (size_t)NQ * R * 3 * H) * sizeof(float) + (size_t)KL * NQ * H * 3 * sizeof(float);
 }
 
+// k_bigru_duo (taco_bigru_xcd.h) usable for this scan?  (H = 256, a whole MI355X, at most 64 rows)
+static bool duo_usable(const taco_model* m, const Cbhg& c, int B, int T) {
+  return m->persist == 1 && m->dx_mode && c.gd_pack && c.rnn == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256;
+}
+// both directions of RG rows on one group of 32 CUs, software-pipelined against each other; gsave != null: the TAPE instantiation
+static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* xproj, const int* lengths, const float* init_state,
+                      float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
+  GdArgs a; memset(&a, 0, sizeof a);
+  a.wpack = AP(m, c.gd_pack); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
+  a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
+  a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+  int RG = 1;
+  while (RG * DX_NGROUP < B) RG *= 2;
+  HIPCHK(zero_async(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
+  const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+  const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
+  if (gsave) {
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo<1, true>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo<2, true>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo<4, true>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo<8, true>), grid, blk, lds, st, a); break;
+    }
+  } else {
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo<1, false>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo<2, false>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo<4, false>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo<8, false>), grid, blk, lds, st, a); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
 // directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
 // directions side by side in each launch.  x [B*T, rnn], out [B*T, 2*rnn].
@@ -839,26 +875,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
   if (m->skip_scans) return 0;
-  if (m->persist == 1 && m->dx_mode && c.gd_pack && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
-    // both directions of RG rows on one group of 32 CUs, software-pipelined against each other (k_bigru_duo, taco_bigru_xcd.h)
-    GdArgs a; memset(&a, 0, sizeof a);
-    a.wpack = AP(m, c.gd_pack); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
-    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
-    a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
-    int RG = 1;
-    while (RG * DX_NGROUP < B) RG *= 2;
-    HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
-    const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
-    const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
-    switch (RG) {
-      case 1: hipLaunchKernelGGL((k_bigru_duo<1>), grid, blk, lds, st, a); break;
-      case 2: hipLaunchKernelGGL((k_bigru_duo<2>), grid, blk, lds, st, a); break;
-      case 4: hipLaunchKernelGGL((k_bigru_duo<4>), grid, blk, lds, st, a); break;
-      default: hipLaunchKernelGGL((k_bigru_duo<8>), grid, blk, lds, st, a); break;
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
+  if (duo_usable(m, c, B, T)) return duo_launch(m, st, c, B, T, w.xproj, lengths, init_state, out, nullptr, w.gxbuf, w.gxctl);
   if ((m->persist == 8 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
     // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
     // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
@@ -1180,25 +1197,32 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
   // 256 workgroups, one per CU, all resident at once: only on a whole MI355X (a partition of it -- CPX / DPX modes -- or a smaller
   // part would leave workgroups waiting for CUs held by workgroups that wait for them)
   (void)manual;   // manual alignments are a mode of the persistent kernel (the score phases are skipped)
-  if (!m->dx_mode || !m->dx_pack || teacher || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
+  // teacher forcing needs the raw prenet rows in the registers where inference keeps the frame-projection composite: only the
+  // training shadow model's pack has them (taco_model_finalize)
+  if (!m->dx_mode || !m->dx_pack || (teacher && !m->tp) || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
   const int RG = dx_rows_per_group(m, B);
-  return dx_lds_floats(RG, T_in) * sizeof(float) <= 160 * 1024;
+  return dx_lds_floats(RG, T_in, m->tp != nullptr) * sizeof(float) <= 160 * 1024;
 }
-template <int RG>
+template <int RG, bool TAPE>
 static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
-  hipLaunchKernelGGL((k_decoder_xcd<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
+  hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
-static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B, int T_in, int n, const float* manual,
-                     float* mel, float* align_out, float* dbg, int dbgw, const DecWs& w, const float* h_att0, const float* h10, const float* h20) {
+// `tape`: null (inference), or the TAPE instantiation's extra arguments already filled in (teacher, tape pointers; training forward)
+static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, const float* spk_rows, int B, int T_in, int n,
+                     const float* manual, float* mel, float* align_out, float* dbg, int dbgw, const float* keys, int* nz,
+                     unsigned long long* xbuf, unsigned* dxctl, float* rowbias, const float* h_att0, const float* h10, const float* h20,
+                     const DxArgs* tape = nullptr) {
   const int RG = dx_rows_per_group(m, B);
   DxArgs a; memset(&a, 0, sizeof a);
+  if (tape) a = *tape;
   a.manual = manual;
   if (is_simple(m)) {   // the speaker embedding's share of the attention GRU and GRU 1 pre-activations, once per launch
-    hipLaunchKernelGGL(k_dx_rowbias, dim3(B), dim3(DX_W), 0, st, AP(m, m->spk_emb), speaker_id, AP(m, m->dx_spkw), m->hp.speaker_embedding_size, w.rowbias);
+    hipLaunchKernelGGL(k_dx_rowbias, dim3(B), dim3(DX_W), 0, st, spk_rows ? spk_rows : AP(m, m->spk_emb), spk_rows ? (const int*)nullptr : speaker_id,
+                       AP(m, m->dx_spkw), m->hp.speaker_embedding_size, rowbias);
     HIPCHK(hipGetLastError());
-    a.rowbias = w.rowbias;
+    a.rowbias = rowbias;
   }
   a.wpack = AP(m, m->dx_pack);
   a.qpack = AP(m, m->dx_qpack[RG == 1 ? 0 : RG == 2 ? 1 : RG == 4 ? 2 : 3]);
@@ -1206,19 +1230,28 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.b_g1f = AP(m, m->dx_b_g1f); a.b_g1c = AP(m, m->dx_b_g1c); a.b_g2g = AP(m, m->dx_b_g2g); a.b_g2c = AP(m, m->dx_b_g2c);
   a.b_f = AP(m, m->dx_b_f);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
-  a.keys = w.keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
-  a.mel = mel; a.hist = align_out; a.nz = w.nz; a.dbg = dbg; a.dbgw = dbgw;
-  a.xbuf = w.xbuf; a.ctl = w.dxctl; a.err = m->d_err; a.trace = m->trace_on ? m->d_trace : nullptr;
+  a.keys = keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
+  a.mel = mel; a.hist = align_out; a.nz = nz; a.dbg = dbg; a.dbgw = dbgw;
+  a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err; a.trace = m->trace_on ? m->d_trace : nullptr;
   a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
+  a.mels = m->hp.num_mels;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
-  HIPCHK(zero_async(w.xbuf, (size_t)((char*)w.dxctl - (char*)w.xbuf) + 256, st));   // carved back to back: one fill launch
-  const size_t lds = dx_lds_floats(RG, T_in) * sizeof(float);
+  HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
+  const size_t lds = dx_lds_floats(RG, T_in, tape != nullptr) * sizeof(float);
+  if (tape) {
+    switch (RG) {
+      case 1: return dx_launch_rg<1, true>(st, a, lds);
+      case 2: return dx_launch_rg<2, true>(st, a, lds);
+      case 4: return dx_launch_rg<4, true>(st, a, lds);
+      default: return dx_launch_rg<8, true>(st, a, lds);
+    }
+  }
   switch (RG) {
-    case 1: return dx_launch_rg<1>(st, a, lds);
-    case 2: return dx_launch_rg<2>(st, a, lds);
-    case 4: return dx_launch_rg<4>(st, a, lds);
-    default: return dx_launch_rg<8>(st, a, lds);
+    case 1: return dx_launch_rg<1, false>(st, a, lds);
+    case 2: return dx_launch_rg<2, false>(st, a, lds);
+    case 4: return dx_launch_rg<4, false>(st, a, lds);
+    default: return dx_launch_rg<8, false>(st, a, lds);
   }
 }
 static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B,
@@ -1249,8 +1282,8 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
     // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
     // vectors); the launch-per-stage loop below is the general path
-    TRY(dx_launch(m, st, enc_out, speaker_id, B, T_in, n, manual, mel, align_out, dbg, dbgw, w, dv ? spk->vec[2] : nullptr,
-                  dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr));
+    TRY(dx_launch(m, st, enc_out, speaker_id, nullptr, B, T_in, n, manual, mel, align_out, dbg, dbgw, w.keys, w.nz, w.xbuf, w.dxctl, w.rowbias,
+                  dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr));
     if (stop_step) {
       hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
       HIPCHK(hipGetLastError());
@@ -1632,6 +1665,34 @@ int taco_model_finalize(taco_model* m) {
     m->gru1_fold.ch = pack_w16(m, ck.data(), Hd, Hd, Hd, 0, Hd, cb.data());
     m->fuse_concat = 1;
     if (hp.dec_layer_num == 2) TRY(dx_build_pack(m, dx_Wc, dx_bc, W, bb));
+  }
+  if (m->tp && hp.dec_layer_num == 2 && dx_widths_ok(m)) {
+    // Training shadow model: every "weight" here is 1 + the flat index of a parameter, and the arena doubles as the index map of
+    // taco_train_refresh.  The persistent decoder's pack is built in TEACHER form: the next step's prenet layer 1 reads the
+    // teacher's frame, so its registers hold the raw kernel rows (zero beyond num_mels) instead of the frame-projection composite;
+    // the one composite that remains -- the concat projection folded into GRU 1 -- is computed on the device after every
+    // optimizer step (k_dx_fold) into a buffer that the index map addresses as NP + 1 + i.
+    const int Mm = hp.num_mels, P0 = hp.dec_prenet[0], H = Hd, Z = As + D + simple_S(m), N4 = 4 * H;
+    const auto& W1 = T_(m, "decoder/prenet/dense_1/kernel").data;
+    std::vector<float> Wc_t((size_t)(Hd + D) * P0, 0.f);
+    for (int k = 0; k < Mm; ++k) for (int q = 0; q < P0; ++q) Wc_t[(size_t)k * P0 + q] = W1[(size_t)k * P0 + q];                 // frame rows (k < num_mels)
+    for (int k = 0; k < D; ++k) for (int q = 0; q < P0; ++q) Wc_t[(size_t)(Hd + k) * P0 + q] = W1[(size_t)(Mm + k) * P0 + q];    // context rows
+    const auto& Wcc = T_(m, "decoder/concat_projection/kernel").data; const auto& bcv = T_(m, "decoder/concat_projection/bias").data;
+    const auto& gk = T_(m, "decoder/gru_1/gates/kernel").data;
+    size_t NP = 0;
+    for (auto& sp : m->spec) { size_t c = 1; for (int64_t d : sp.second) c *= (size_t)d; NP += c; }
+    std::vector<float> Wf_t((size_t)(Z + Hd) * N4, 0.f), bf_t(N4, 0.f);
+    for (int z = 0; z <= Z; ++z)
+      for (int j = 0; j < 3 * H; ++j) {
+        const float idx = (float)(NP + 1 + (size_t)z * 3 * H + j);
+        if (z < Z) Wf_t[(size_t)z * N4 + j] = idx; else bf_t[j] = idx;
+      }
+    for (int z = 0; z < Z; ++z) for (int j = 0; j < H; ++j) Wf_t[(size_t)z * N4 + 3 * H + j] = Wcc[(size_t)z * Hd + j];
+    for (int j = 0; j < H; ++j) bf_t[3 * H + j] = bcv[j];
+    for (int k = 0; k < Hd; ++k) for (int j = 0; j < 2 * H; ++j) Wf_t[(size_t)(Z + k) * N4 + j] = gk[(size_t)(Hd + k) * 2 * H + j];
+    m->dx_fold_n = (size_t)(Z + 1) * 3 * H;
+    if (NP + m->dx_fold_n >= (1u << 24)) return fail(TACO_ERR_UNSUPPORTED, "parameter + fold indices exceed 2^24");
+    TRY(dx_build_pack(m, Wc_t, T_(m, "decoder/prenet/dense_1/bias").data, Wf_t, bf_t));
   }
   {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
     std::vector<float> v = T_(m, "attention/attention_v").data;

@@ -39,6 +39,7 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
+  float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
   // (ordered on the step's stream); null = statistics of this rank's rows only
   void (*sync_fn)(void* user, float* d_vec, int n) = nullptr;
@@ -210,6 +211,7 @@ struct CbhgTape {
   float *res, *hx[10], *hH[8], *hT[8];
   float *xproj, *out, *gsave;
   float *dg, *rh, *d0, *d1, *dcat, *dbig0, *dbig1, *stat;
+  unsigned long long* gxbuf = nullptr; unsigned* gxctl = nullptr;      // k_bigru_duo: exchange granules, census words
 };
 static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w) {
   const size_t M = (size_t)B * T, KC = (size_t)c.K * c.C;
@@ -226,11 +228,14 @@ static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w
   w.dg = cv.f(M * 6 * c.rnn); w.rh = cv.f(M * 2 * c.rnn);
   w.d0 = cv.f(M * wide); w.d1 = cv.f(M * wide); w.dcat = cv.f(M * 2 * c.rnn);
   w.dbig0 = cv.f(M * KC); w.dbig1 = cv.f(M * KC); w.stat = cv.f(5 * std::max<size_t>(KC, wide));   // sums, centred sums + the 3-vector SyncBN exchange pack
+  w.gxbuf = (unsigned long long*)cv.raw(gd_xbuf_granules(8) * sizeof(unsigned long long)); w.gxctl = (unsigned*)cv.raw(256);
 }
 struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (b*n + t)*W
   float *keys, *zero, *ctx, *pz[4], *hA, *rA, *uA, *cA, *rhA, *xcA, *alpha, *alpha0;
   float *o[5], *h[4], *r[4], *u[4], *c[4], *rh[4], *xc[4];
   int* nz;
+  float* tape256 = nullptr; size_t tstride = 0;          // the 256-wide per-step arrays in DXT_* order, back to back (persistent decoder, TAPE)
+  unsigned long long* xbuf = nullptr; unsigned* dxctl = nullptr; float* rowbias = nullptr;   // its exchange granules, census words, 'simple' row biases
   // backward
   float *dkeys, *dvalues, *dv_acc, *dsb_acc, *dalpha, *dctx, *dctx_t, *dhA, *dh[4], *dht, *dhp, *tmp1, *tmp2, *do_[5];
   float *g_dgp[4], *g_dcp[4], *g_dgpA, *g_dcpA, *g_do0, *g_dq, *g_dz[4], *dpz, *dIn;
@@ -243,11 +248,27 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   w.keys = cv.f((size_t)B * T_in * A); w.zero = cv.f((size_t)B * std::max(std::max(hp.num_mels, As), std::max(Hd, D)));
   const int S = simple_S(m);      // 'simple': the speaker embedding rides behind the context and behind the last prenet output of every step
   w.ctx = cv.f(R * (D + S));
-  for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f(R * (hp.dec_prenet[i] + (i == hp.dec_prenet_n - 1 ? S : 0)));
-  w.hA = cv.f(R * As); w.rA = cv.f(R * As); w.uA = cv.f(R * As); w.cA = cv.f(R * As); w.rhA = cv.f(R * As); w.xcA = cv.f(R * As);
+  // The persistent decoder (k_decoder_xcd<RG, true>) addresses its 256-wide per-step arrays as ONE block, slot s at tape256 + s * R * 256
+  // (DXT_* order: P1, HA, RA, UA, CA, RHA, Q, O0, R1, U1, C1, RH1, H1, O1, R2, U2, C2, RH2, H2, O2): carve them back to back in that order.
+  const bool dxl = dx_widths_ok(m);     // reference widths: every one of them is [R, 256]
+  if (dxl) {
+    float** slot[DXT_N] = {&w.pz[0], &w.hA, &w.rA, &w.uA, &w.cA, &w.rhA, &w.g_q, &w.o[0], &w.r[0], &w.u[0], &w.c[0], &w.rh[0], &w.h[0], &w.o[1],
+                           &w.r[1], &w.u[1], &w.c[1], &w.rh[1], &w.h[1], &w.o[2]};
+    for (int i = 0; i < DXT_N; ++i) *slot[i] = cv.f(R * DX_W);
+    w.tape256 = w.pz[0]; w.tstride = R * DX_W;
+    w.pz[1] = cv.f(R * (hp.dec_prenet[1] + S));
+    w.xcA = cv.f(R * As);
+    for (int i = 0; i < L; ++i) w.xc[i] = cv.f(R * Hd);
+  } else {
+    for (int i = 0; i < hp.dec_prenet_n; ++i) w.pz[i] = cv.f(R * (hp.dec_prenet[i] + (i == hp.dec_prenet_n - 1 ? S : 0)));
+    w.hA = cv.f(R * As); w.rA = cv.f(R * As); w.uA = cv.f(R * As); w.cA = cv.f(R * As); w.rhA = cv.f(R * As); w.xcA = cv.f(R * As);
+    for (int i = 0; i <= L; ++i) w.o[i] = cv.f(R * Hd);
+    for (int i = 0; i < L; ++i) { w.h[i] = cv.f(R * Hd); w.r[i] = cv.f(R * Hd); w.u[i] = cv.f(R * Hd); w.c[i] = cv.f(R * Hd); w.rh[i] = cv.f(R * Hd); w.xc[i] = cv.f(R * Hd); }
+  }
   w.alpha = cv.f((size_t)B * (n + 1) * T_in); w.alpha0 = cv.f((size_t)B * T_in);   // slot 0 = initial alignments, slot t+1 = step t
-  for (int i = 0; i <= L; ++i) w.o[i] = cv.f(R * Hd);
-  for (int i = 0; i < L; ++i) { w.h[i] = cv.f(R * Hd); w.r[i] = cv.f(R * Hd); w.u[i] = cv.f(R * Hd); w.c[i] = cv.f(R * Hd); w.rh[i] = cv.f(R * Hd); w.xc[i] = cv.f(R * Hd); }
+  { const size_t xb = (size_t)DX_NGROUP * dx_xlayout(8, T_in).total * sizeof(unsigned long long);
+    w.xbuf = (unsigned long long*)cv.raw(xb); w.dxctl = (unsigned*)cv.raw(256);
+    w.rowbias = cv.f(is_simple(m) ? (size_t)B * DXRB_N * DX_W : 1); }
   w.nz = cv.i((size_t)n * B);
   w.dkeys = cv.f((size_t)B * T_in * A); w.dvalues = cv.f((size_t)B * T_in * D); w.dv_acc = cv.f((size_t)B * A); w.dsb_acc = cv.f(B);
   w.dalpha = cv.f((size_t)B * T_in); w.dctx = cv.f((size_t)B * D); w.dctx_t = cv.f((size_t)B * D); w.dhA = cv.f((size_t)B * As);
@@ -261,7 +282,8 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   w.g_dgpA = cv.f(R * 2 * As); w.g_dcpA = cv.f(R * As); w.g_do0 = cv.f(R * Hd); w.g_dq = cv.f(R * A);
   for (int i = 0; i < hp.dec_prenet_n; ++i) w.g_dz[i] = cv.f(R * hp.dec_prenet[i]);
   w.dpz = cv.f((size_t)B * W2); w.dIn = cv.f((size_t)B * W2);
-  w.g_q = cv.f(R * A); w.g_e = cv.f(R * T_in); w.g_de = cv.f(R * T_in); w.g_dctx = cv.f(R * D);
+  if (!dxl) w.g_q = cv.f(R * A);
+  w.g_e = cv.f(R * T_in); w.g_de = cv.f(R * T_in); w.g_dctx = cv.f(R * D);
 }
 struct TrainWs {
   float* pre[4]; float* dpre[4];
@@ -375,6 +397,8 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
   HIPCHK(zero_async(w.gsave, (size_t)M * 6 * H * sizeof(float), st));
+  if (duo_usable(m, c, B, T))     // the whole-chip scan of inference with the gate tape (k_bigru_duo<RG, true>)
+    return duo_launch(m, st, c, B, T, w.xproj, lengths, init_state, w.out, w.gsave, w.gxbuf, w.gxctl);
   if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res), gates saved for the backward scan
     BigruSArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
@@ -568,6 +592,14 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
     hipLaunchKernelGGL(k_tile_rows, EWGRID((size_t)B * n * S), 0, st, spk_emb, w.ctx, Dc, D, B, n, S);
     hipLaunchKernelGGL(k_tile_rows, EWGRID((size_t)B * n * S), 0, st, spk_emb, w.pz[np - 1], Pz, Pl, B, n, S);
     HIPCHK(hipGetLastError());
+  }
+  if (!feed_back && w.tape256 && hp.dec_layer_num == 2 && (size_t)DXT_N * w.tstride < (1u << 31) && dx_usable(m, B, T_in, nullptr, teach)) {
+    // the whole teacher-forced loop as ONE persistent launch that also writes the tape (k_decoder_xcd<RG, true>, taco_decoder_xcd.h)
+    DxArgs ta; memset(&ta, 0, sizeof ta);
+    ta.teacher = teach; ta.tape = w.tape256; ta.tstride = w.tstride; ta.tp_p2 = w.pz[np - 1]; ta.ld_p2 = Pz; ta.tp_ctx = w.ctx; ta.ld_ctx = Dc;
+    ta.tp_e = w.g_e; ta.tp_alpha = w.alpha;
+    return dx_launch(m, st, enc_out, nullptr, spk_emb, B, T_in, n, nullptr, mel, align_hist, nullptr, 0, w.keys, w.nz, w.xbuf, w.dxctl, w.rowbias,
+                     att_init, dec_init ? dec_init[0] : nullptr, dec_init ? dec_init[1] : nullptr, &ta);
   }
   for (int t = 0; t < n; ++t) {
     // helpers.py:44,66,70-72: previous teacher frame; rnn_decoder_test_mode (:63-64): last of the r frames the decoder just emitted

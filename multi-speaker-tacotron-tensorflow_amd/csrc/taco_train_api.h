@@ -27,6 +27,9 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
       hipMemcpy(t->d_map, sm->darena, t->arena_n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
     taco_model_destroy(sm); delete t; return fail(TACO_ERR_HIP, "index map allocation failed");
   }
+  if (sm->dx_fold_n && hipMalloc((void**)&t->d_fold, sm->dx_fold_n * sizeof(float)) != hipSuccess) {
+    taco_model_destroy(sm); delete t; return fail(TACO_ERR_HIP, "fold buffer allocation failed");
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows_bwd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -37,6 +40,7 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
 void taco_train_destroy(taco_train* t) {
   if (!t) return;
   if (t->d_map) (void)hipFree(t->d_map);
+  if (t->d_fold) (void)hipFree(t->d_fold);
   if (t->sm) taco_model_destroy(t->sm);
   delete t;
 }
@@ -62,7 +66,15 @@ int taco_train_param_offset(const taco_train* t, const char* name, size_t* offse
 int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params) {
   if (!t || !d_params) return fail(TACO_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->sm->device));
-  hipLaunchKernelGGL(k_pack_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, t->d_map, d_params, t->sm->darena, t->arena_n, (unsigned)t->NP);
+  const taco_model* sm = t->sm;
+  if (sm->dx_fold_n) {   // the persistent decoder's one computed operand: concat projection folded into GRU 1, from the current parameters
+    const int H = sm->hp.dec_rnn_size, Z = sm->hp.attention_state_size + 2 * sm->hp.enc_rnn_size + simple_S(sm);
+    hipLaunchKernelGGL(k_dx_fold, dim3(Z + 1), dim3(256), 0, (hipStream_t)hip_stream, d_params + t->poff.at("decoder/concat_projection/kernel"),
+                       d_params + t->poff.at("decoder/concat_projection/bias"), d_params + t->poff.at("decoder/gru_1/gates/kernel"),
+                       d_params + t->poff.at("decoder/gru_1/gates/bias"), d_params + t->poff.at("decoder/gru_1/candidate/kernel"), t->d_fold, Z, H);
+  }
+  hipLaunchKernelGGL(k_pack_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, t->d_map, d_params, t->sm->darena, t->arena_n, (unsigned)t->NP,
+                     (const float*)t->d_fold, (unsigned)sm->dx_fold_n);
   if (t->sm->hp.attention_type == 1)    // bah_norm: the pack holds v_hat = g * v / |v| (computed, not copied)
     hipLaunchKernelGGL(k_vnorm_fold, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, d_params + t->poff.at("attention/attention_v"),
                        d_params + t->poff.at("attention/attention_g"), t->sm->darena + (t->sm->att_v - 1), t->sm->hp.attention_size);

@@ -118,6 +118,33 @@ class Trainer(object):
                                  "B*T_out = %d, the group spans %d..%d and %d..%d" % (B * T_in, B * T_out, -lo_in, hi_in, -lo_out, hi_out))
         self._sync_shapes.add(key)
 
+    # ---- engines ----
+    def set_decoder_engine(self, mode=1):
+        """1 (default): at the reference widths the teacher-forced decoder loop and the post-net scan of the forward run as the
+        persistent whole-chip kernels of inference with tape outputs (csrc/taco_decoder_xcd.h, taco_bigru_xcd.h); 0: one launch per
+        stage everywhere (round 1's engine; also what other widths, more than 64 rows and rnn_decoder_test_mode use)."""
+        mh = C.c_void_p(self._lib.taco_train_model(self._h))
+        _lib.check(self._lib.taco_debug_set_decoder_persist(mh, int(mode), 0))
+        if getattr(self, "_graph", None) is not None:
+            self._graph = None          # a captured step keeps the engine it was captured with
+
+    def decoder_engine_info(self):
+        """After a forward (synchronises): {'protocol': 0 launch per stage / 1 XCD-local / 2 write-through, 'per_xcd': [...]} of the last
+        persistent decoder launch of the training forward."""
+        torch.cuda.synchronize(self.device)
+        mh = C.c_void_p(self._lib.taco_train_model(self._h))
+        v = (C.c_int * 16)()
+        _lib.check(self._lib.taco_debug_decoder_info(mh, v))
+        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14])}
+
+    def check_device_errors(self):
+        """Synchronises and raises if a persistent kernel of the training forward gave up (outputs and gradients invalid)."""
+        mh = C.c_void_p(self._lib.taco_train_model(self._h))
+        v = C.c_int(0)
+        _lib.check(self._lib.taco_model_device_errors(mh, C.byref(v)))
+        if v.value:
+            raise _lib.TacoError(_lib.TACO_ERR_HIP, "a persistent kernel of the training forward timed out waiting for a peer workgroup")
+
     # ---- parameters ----
     def set_weights(self, weights):
         host = np.zeros(self.num_params, np.float32)

@@ -381,6 +381,51 @@ def test_simple_multispeaker_training_gradients(ses, atype):
     tr.close()
 
 
+@pytest.mark.parametrize("model_type,atype,B", [("single", "bah_mon", 9), ("deepvoice", "bah", 3), ("simple", "bah_norm", 5), ("single", "bah_mon", 33)])
+def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
+    """At the reference widths the teacher-forced decoder loop and the post-net scan of the training forward are the persistent
+    kernels of inference with tape outputs (k_decoder_xcd<RG, true>: teacher frames in, gates / states / scores / alignments out;
+    k_bigru_duo<RG, true>: gate tape) -- rows per group 1 / 2 / 8, deepvoice initial states, the 'simple' speaker term.  Forward, loss and
+    EVERY gradient (they are computed from that tape) against float64 autograd, and against the launch-per-stage engine."""
+    import torch
+    import taco_amd
+    ns = 1 if model_type == "single" else 3
+    hp = O.OracleHParams(max_iters=8, model_type=model_type, attention_type=atype)
+    w = O.init_weights(hp, ns, 81)
+    T_in, T_out = 14, 8 * hp.reduction_factor
+    ids, L = O.synthetic_inputs(B, T_in, 82, ragged=True)
+    rs = np.random.RandomState(83)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    co = rs.uniform(0.5, 1.5, size=B)
+    spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
+    loss, g, out = TF.train_grads(w, hp, ids, L, mt, lt, co, speaker_id=spk, num_speakers=ns)
+    tr = taco_amd.Trainer(to_product_hp(hp), w, num_speakers=ns)
+    losses = tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    tr.check_device_errors()
+    info = tr.decoder_engine_info()
+    assert info["has_pack"] and info["protocol"] in (1, 2), info
+    assert abs(float(losses[0]) - loss) < 2e-5
+    assert maxabs(tr.mel_outputs.cpu().numpy(), out["mel"]) < 1e-4 and maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4
+    assert maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
+    got = tr.grad_dict()
+    worst, gn = _grad_report(got, g)
+    assert worst[0][0] < 3e-3, worst[:6]
+    tr.set_decoder_engine(0)                      # the same step on the launch-per-stage engine
+    tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    ref = tr.grad_dict()
+    scale = max(float(np.abs(v).max()) for v in ref.values())
+    assert max(maxabs(got[k], ref[k]) for k in ref) < 2e-4 * scale
+    tr.set_decoder_engine(1)
+    step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)      # packs regenerated on the device (k_dx_fold + index-map gather)
+    losses2 = tr.forward_backward(ids, L, mt, lt, co, backward=False, speaker_id=spk)
+    torch.cuda.synchronize()
+    tr.check_device_errors()
+    assert step == 1 and np.isfinite(float(lwc)) and float(losses2[3]) < float(lwc) + 1e-3
+    tr.close()
+
+
 def test_captured_step_survives_an_eager_step_of_a_larger_shape():
     """Trainer.capture bakes the workspace address into the graph; an eager step with a shape that needs a larger workspace must
     not move or free that buffer, and the replay that follows it must still be the step (the trainer records the
