@@ -203,6 +203,11 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out);
 void taco_train_destroy(taco_train* t);
 /* the model handle whose taco_model_num_weights / taco_model_weight_name give the flat parameter order and shapes */
 taco_model* taco_train_model(taco_train* t);
+/* Deterministic reductions: on = 1 makes every sum over rows that normally leaves its workgroup through fp32 atomics (weight
+ * gradients, bias and BatchNorm sums, embedding gradients, d attention_v) a two-stage sum in a fixed order, so that a step is
+ * run-to-run reproducible, as the reference's single-device step is (train.py:215-219).  Costs 192 MB more workspace
+ * (taco_train_workspace_bytes reflects it: query it again) and a few per cent of the step.  Default 0. */
+int taco_train_set_deterministic(taco_train* t, int on);
 size_t taco_train_num_params(const taco_train* t);
 int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset);
 /* regenerate every weight pack from the flat parameter buffer (call after loading parameters and after every update) */

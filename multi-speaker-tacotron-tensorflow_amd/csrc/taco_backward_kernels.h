@@ -41,8 +41,10 @@ __global__ __launch_bounds__(256) void k_dx_fold(const float* __restrict__ Wc, c
 // ---- per-column reductions over the rows of a [M, C] matrix (bias gradients, BatchNorm statistics) ----
 // mode 0: out1[c] += sum_m a                         mode 1: out2[c] += sum_m (a - mu[c])^2
 // mode 2: out1[c] += sum_m b ; out2[c] += sum_m b * (a - mu[c]) * rstd[c]     (BN backward: b = dy, a = BN input)
+// part != null (deterministic mode): the row chunk's sums go to part[chunk][0 | 1][C] instead of being added atomically, and
+// k_colsum_reduce adds them to out1 / out2 chunk by chunk in a fixed order.
 struct ColArgs { const float* a; const float* b; const float* mu; const float* rstd; float* out1; float* out2;
-                 int lda, ldb, M, C, mode, rpb; };
+                 int lda, ldb, M, C, mode, rpb; float* part; };
 __global__ __launch_bounds__(256) void k_colsum(const ColArgs g) {
   __shared__ float s1[4][64], s2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -63,9 +65,22 @@ __global__ __launch_bounds__(256) void k_colsum(const ColArgs g) {
   if (rl == 0 && c < g.C) {
     const float t1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
     const float t2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
-    if (g.mode != 1 && g.out1) atomicAdd(g.out1 + c, t1);
-    if (g.mode != 0 && g.out2) atomicAdd(g.out2 + c, t2);
+    if (g.part) {
+      g.part[((size_t)blockIdx.y * 2 + 0) * g.C + c] = t1;
+      g.part[((size_t)blockIdx.y * 2 + 1) * g.C + c] = t2;
+    } else {
+      if (g.mode != 1 && g.out1) atomicAdd(g.out1 + c, t1);
+      if (g.mode != 0 && g.out2) atomicAdd(g.out2 + c, t2);
+    }
   }
+}
+__global__ void k_colsum_reduce(const float* part, int nchunks, int C, int mode, float* out1, float* out2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) { t1 += part[((size_t)k * 2 + 0) * C + c]; t2 += part[((size_t)k * 2 + 1) * C + c]; }
+  if (mode != 1 && out1) out1[c] += t1;
+  if (mode != 0 && out2) out2[c] += t2;
 }
 
 // BatchNorm (training): mu = S1/M; second pass gives S2 = sum (a-mu)^2; rstd = 1/sqrt(S2/M + eps) (biased variance);
@@ -123,7 +138,8 @@ __global__ void k_bn_bwd(const float* a, int lda, const float* dy, int ldy, cons
 // row m of x is x[gather[m]] (embedding lookup fused into the first encoder prenet layer).  Workgroup = 4 waves =
 // 64 (k) x 64 (n) tile over `rpb` rows; partial sums leave through fp32 atomics.
 struct WgArgs { const float* x; const int* gather; const float* dy; float* dw; int ldx, ldy, lddw, M, T, K, N, kw, padl, rpb;
-                const int* ygather; };   // optional: row m of dy is dy[ygather[m]] (first-step terms of recurrent kernels with ragged lengths)
+                const int* ygather;
+                float* part; };   // deterministic mode: the M-slice's tile goes to part[slice][tap][K][N]; k_wgrad_reduce sums the slices in order   // optional: row m of dy is dy[ygather[m]] (first-step terms of recurrent kernels with ragged lengths)
 typedef float wg_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -158,6 +174,17 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
 #pragma unroll
     for (int u = 0; u < WG_U; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
   }
+  if (g.part) {
+    float* pw = g.part + ((size_t)sp * g.kw + tap) * g.K * g.N;
+    if (nok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = k0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+        if (kr < g.K) pw[(size_t)kr * g.N + n0 + i] = acc[r];
+      }
+    }
+    return;
+  }
   float* dw = g.dw + (size_t)tap * g.K * g.lddw;
   if (nok) {
 #pragma unroll
@@ -166,6 +193,15 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
       if (kr < g.K) atomicAdd(dw + (size_t)kr * g.lddw + n0 + i, acc[r]);
     }
   }
+}
+// dw[tap][k][n] += sum over the M-slices, slice 0 first (fixed order: run-to-run reproducible)
+__global__ void k_wgrad_reduce(const float* part, int nsplit, int kw, int K, int N, float* dw, int lddw) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)kw * K * N;
+  if (i >= per) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * per + i];
+  const int n = (int)(i % N); const size_t tk = i / N;      // tk = tap * K + k
+  dw[tk * lddw + n] += s;
 }
 
 // ---- small element-wise pieces ----
@@ -241,6 +277,15 @@ __global__ void k_embed_bwd(const float* dx, const int* ids, float* dE, int M, i
   if (i >= (size_t)M * E) return;
   const int m = (int)(i / E), c = (int)(i % E);
   atomicAdd(dE + (size_t)ids[m] * E + c, dx[i]);
+}
+// deterministic variant: one thread per (table row v, column c) walks the rows in order
+__global__ void k_embed_bwd_det(const float* dx, const int* ids, float* dE, int M, int E, int V) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)V * E) return;
+  const int v = (int)(i / E), c = (int)(i % E);
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) if (ids[m] == v) s += dx[(size_t)m * E + c];
+  dE[i] += s;
 }
 // y = softsign(z) = z / (1 + |z|)  =>  dz = dy * (1 - |y|)^2   (deepvoice speaker layers, tacotron.py:68-79)
 __global__ void k_softsign_bwd(const float* dy, const float* y, float* dz, int n) {
@@ -651,7 +696,8 @@ __global__ __launch_bounds__(64 * ATB_NW) void k_attention_bwd(const AttnBArgs a
 // hoisted out of the BPTT loop: dkeys[b,j,c] = v_c * sum_t de_t[j] * (1 - th^2), dv_c += sum_{b,j,t} de_t[j] * th,
 // th = tanh(keys[b,j,c] + q_t[b,c]).  Workgroup = 256 channels x ATK_J positions of one batch row, loop over the steps.
 #define ATK_J 8
-struct AttnKArgs { const float* keys; const float* q; const float* de; const float* v; const float* battn; float* dkeys; float* dv; int T_in, A, n; };
+struct AttnKArgs { const float* keys; const float* q; const float* de; const float* v; const float* battn; float* dkeys; float* dv; int T_in, A, n;
+                   float* part; };   // deterministic mode: part[(b * gridDim.y + position chunk)][A] instead of atomics on dv; k_colsum_reduce-style sum afterwards
 __global__ __launch_bounds__(256) void k_attention_keys_bwd(const AttnKArgs a) {
   __shared__ float sde[ATK_J];
   const int tid = threadIdx.x;
@@ -677,6 +723,14 @@ __global__ __launch_bounds__(256) void k_attention_keys_bwd(const AttnKArgs a) {
 #pragma unroll
     for (int u = 0; u < ATK_J; ++u)
       if (j0 + u < a.T_in) a.dkeys[((size_t)b * a.T_in + j0 + u) * a.A + c] = vc * ak[u];
-    atomicAdd(a.dv + c, av);
+    if (a.part) a.part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * a.A + c] = av;
+    else atomicAdd(a.dv + c, av);
   }
+}
+__global__ void k_rows_reduce(const float* part, int nrows, int C, float* out) {      // out[c] += sum_r part[r][c], row 0 first
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += part[(size_t)r * C + c];
+  out[c] += s;
 }

@@ -45,7 +45,9 @@ struct taco_train {
   void (*sync_fn)(void* user, float* d_vec, int n) = nullptr;
   void* sync_user = nullptr;
   int sync_world = 1;
+  int deterministic = 0;               // taco_train_set_deterministic: ordered two-stage sums instead of fp32 atomics (needs DET_SCRATCH_FLOATS of workspace)
 };
+#define DET_SCRATCH_FLOATS ((size_t)48 << 20)      // 192 MB: e.g. 30 M-slices of the largest weight gradient (post-net proj_1, 3 x 2048 x 256)
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward packs (run inside taco_model_finalize of the shadow model, before the arena upload)
@@ -175,11 +177,24 @@ static int build_train_packs(taco_model* m) {
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------
 #define EWGRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
+// Deterministic reductions (taco_train_set_deterministic): the sums over rows that normally leave their workgroups through fp32
+// atomics (weight gradients, bias / BatchNorm sums, embedding gradients, d attention_v) are written as per-slice partials into this
+// scratch and added up in a fixed order by a second launch -- the step becomes run-to-run reproducible, as the reference's
+// single-device step is.  Scratch of the step in flight; thread-local because the launch helpers below have no context argument
+// (one step per host thread at a time: the library's threading contract).
+struct DetScratch { float* p = nullptr; size_t cap = 0; };
+static thread_local DetScratch g_det;
 static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, int ldb, const float* mu, const float* rstd,
                       float* out1, float* out2, int M, int C, int mode) {
   ColArgs g; g.a = a; g.b = b; g.mu = mu; g.rstd = rstd; g.out1 = out1; g.out2 = out2; g.lda = lda; g.ldb = ldb; g.M = M; g.C = C;
-  g.mode = mode; g.rpb = 256;
-  hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), cdiv(M, g.rpb)), dim3(256), 0, st, g);
+  g.mode = mode; g.rpb = 256; g.part = nullptr;
+  if (g_det.p) {
+    while ((size_t)cdiv(M, g.rpb) * 2 * C > g_det.cap) g.rpb *= 2;
+    g.part = g_det.p;
+  }
+  const int nchunks = cdiv(M, g.rpb);
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, g);
+  if (g.part) hipLaunchKernelGGL(k_colsum_reduce, EWGRID(C), 0, st, (const float*)g.part, nchunks, C, mode, out1, out2);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -191,9 +206,22 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
   { const long tiles = (long)cdiv(K, 64) * cdiv(N, 64) * kw; int rpb = 512;
     while (rpb > 64 && tiles * cdiv(M, rpb) < 2048) rpb >>= 1;
     g.rpb = rpb; }
-  hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * cdiv(M, g.rpb)), dim3(256), 0, st, g);
+  g.part = nullptr;
+  if (g_det.p) {   // per-slice partial tiles + an ordered sum instead of atomics; fewer, longer slices if the scratch is short
+    const size_t per = (size_t)kw * K * N;
+    if (per > g_det.cap) return fail(TACO_ERR_STATE, "deterministic-reduction scratch too small for a %d x %d x %d weight gradient", kw, K, N);
+    while ((size_t)cdiv(M, g.rpb) * per > g_det.cap) g.rpb *= 2;
+    g.part = g_det.p;
+  }
+  const int nsplit = cdiv(M, g.rpb);
+  hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * nsplit), dim3(256), 0, st, g);
+  if (g.part) hipLaunchKernelGGL(k_wgrad_reduce, EWGRID((size_t)kw * K * N), 0, st, (const float*)g.part, nsplit, kw, K, N, dw, lddw);
   HIPCHK(hipGetLastError());
   return 0;
+}
+static void run_embed_bwd(hipStream_t st, const float* dx, const int* ids, float* dE, int M, int E, int V) {
+  if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * E), 0, st, dx, ids, dE, M, E, V);
+  else hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)M * E), 0, st, dx, ids, dE, M, E);
 }
 // y = x . W^T style data gradient through k_gemm: out = conv_T(dy) (+ res)
 static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const float* dy, int lddy, int M, int T, float* out, int ldo,
@@ -292,6 +320,7 @@ struct TrainWs {
   float *teach, *mel, *linear, *dmel, *dlin, *denc, *dpost, *dmel_post, *demb, *losspart;
   SpkWs spk; float* dvec[8]; float* dspk_emb; float* dzs; int* rowidx;   // deepvoice: speaker vectors, their gradients, scratch
   float *linrv, *dlin_sum;                                               // simple: speaker term of the linear head [B, F], time-summed dlin
+  float* detscr;                                                         // deterministic reductions: per-slice partial sums
 };
 static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n, TrainWs& w) {
   const taco_model* m = t->sm;
@@ -314,6 +343,7 @@ static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n,
     w.dspk_emb = cv.f((size_t)B * std::max(hp.speaker_embedding_size, 1)); w.dzs = cv.f((size_t)B * dmax); w.rowidx = cv.i(B); }
   const size_t nrv = is_simple(m) ? (size_t)B * hp.num_freq : 1;
   w.linrv = cv.f(nrv); w.dlin_sum = cv.f(nrv);
+  w.detscr = cv.f(t->deterministic ? DET_SCRATCH_FLOATS : 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -789,7 +819,10 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     if (vn) HIPCHK(zero_async(w.dv_acc, (size_t)A * sizeof(float), st));
     AttnKArgs k; k.keys = w.keys; k.q = w.g_q; k.de = w.g_de; k.v = AP(m, m->att_v); k.battn = AP(m, m->att_b); k.dkeys = w.dkeys; k.dv = dvdst;
     k.T_in = T_in; k.A = A; k.n = n;
-    hipLaunchKernelGGL(k_attention_keys_bwd, dim3(cdiv(A, 256), cdiv(T_in, ATK_J), B), dim3(256), 0, st, k);
+    const int nj = cdiv(T_in, ATK_J);
+    k.part = (g_det.p && (size_t)B * nj * A <= g_det.cap) ? g_det.p : nullptr;
+    hipLaunchKernelGGL(k_attention_keys_bwd, dim3(cdiv(A, 256), nj, B), dim3(256), 0, st, k);
+    if (k.part) hipLaunchKernelGGL(k_rows_reduce, EWGRID(A), 0, st, (const float*)k.part, B * nj, A, dvdst);
     if (vn) {
       hipLaunchKernelGGL(k_vnorm_bwd, dim3(1), dim3(256), 0, st, x.p("attention/attention_v"), x.p("attention/attention_g"), w.dv_acc,
                          x.g("attention/attention_v"), x.g("attention/attention_g"), A);
@@ -823,6 +856,10 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   TrainWs w; carve_train(cv, t, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
   TrainCtx x{t, st, P, G, do_backward && !freeze_moving};
+  struct DetGuard {     // the reduction helpers see the scratch for the duration of this step only
+    DetGuard(float* p, size_t cap) { g_det.p = p; g_det.cap = cap; }
+    ~DetGuard() { g_det.p = nullptr; g_det.cap = 0; }
+  } det_guard(t->deterministic ? w.detscr : nullptr, t->deterministic ? DET_SCRATCH_FLOATS : 0);
   const int Me = B * T_in, Mp = B * T_out;
   // ---- forward ----
   const float* cur = x.p("embedding"); int curd = hp.embedding_size;
@@ -892,7 +929,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   TRY(decoder_backward(x, enc_out, B, T_in, n, w.teach, w.dmel, w.denc, w.dec, dv ? w.spk.vec[2] : nullptr, dv ? dec_init : nullptr,
                        dv ? w.dvec[2] : nullptr, dv ? d_dec_init : nullptr, simple ? w.dspk_emb : nullptr));
   if (simple) {
-    hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * S), 0, st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S);
+    run_embed_bwd(st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S, hp.num_speakers);
     HIPCHK(hipGetLastError());
   }
   float* dpre = w.dpre[hp.enc_prenet_n - 1];
@@ -905,7 +942,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     if (S == 1) {
       for (size_t i = 0; i < names.size(); ++i) {
         const int dd = i < 3 ? dims[i] : hp.dec_rnn_size;
-        hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * dd), 0, st, w.dvec[i], speaker_id, x.g("spk/" + names[i] + "/table"), B, dd);
+        run_embed_bwd(st, w.dvec[i], speaker_id, x.g("spk/" + names[i] + "/table"), B, dd, hp.num_speakers);
       }
     } else {
       HIPCHK(zero_async(w.dspk_emb, (size_t)B * S * sizeof(float), st));
@@ -918,7 +955,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
         TRY(run_skinny(st, B, &j, 1));
         hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, w.dspk_emb, S, w.dec.tmp1, S, B, S);
       }
-      hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)B * S), 0, st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S);
+      run_embed_bwd(st, w.dspk_emb, speaker_id, x.g("speaker_embedding"), B, S, hp.num_speakers);
     }
     HIPCHK(hipGetLastError());
   }
@@ -935,7 +972,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     TRY(run_dgrad(m, st, t->tp.encpre_d[i], dpre, N, Me, 0, dnext, nd));
     dpre = dnext;
   }
-  hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)Me * hp.embedding_size), 0, st, dpre, ids, x.g("embedding"), Me, hp.embedding_size);
+  run_embed_bwd(st, dpre, ids, x.g("embedding"), (int)Me, hp.embedding_size, hp.num_symbols);
   HIPCHK(hipGetLastError());
   return 0;
 }

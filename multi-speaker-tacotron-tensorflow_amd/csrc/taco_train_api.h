@@ -53,6 +53,11 @@ int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int w
   t->sync_fn = fn; t->sync_user = user; t->sync_world = fn ? world_size : 1;
   return 0;
 }
+int taco_train_set_deterministic(taco_train* t, int on) {
+  if (!t) return fail(TACO_ERR_ARG, "null argument");
+  t->deterministic = on ? 1 : 0;      // changes taco_train_workspace_bytes
+  return 0;
+}
 size_t taco_train_num_params(const taco_train* t) { return t ? t->NP : 0; }
 
 int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset) {

@@ -118,6 +118,15 @@ class Trainer(object):
                                  "B*T_out = %d, the group spans %d..%d and %d..%d" % (B * T_in, B * T_out, -lo_in, hi_in, -lo_out, hi_out))
         self._sync_shapes.add(key)
 
+    def set_deterministic(self, on=True):
+        """Run-to-run reproducible steps (the reference's single-device step is): every row sum that normally leaves its workgroup
+        through fp32 atomics -- weight gradients, bias / BatchNorm sums, embedding gradients -- becomes a two-stage sum in a fixed
+        order.  192 MB more workspace and a few per cent of the step."""
+        _lib.check(self._lib.taco_train_set_deterministic(self._h, 1 if on else 0))
+        self._ws = self._ws_eager = None       # the workspace size changes
+        if getattr(self, "_graph", None) is not None:
+            self._graph = None
+
     # ---- engines ----
     def set_decoder_engine(self, mode=1):
         """1 (default): at the reference widths the teacher-forced decoder loop and the post-net scan of the forward run as the

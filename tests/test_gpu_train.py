@@ -410,7 +410,13 @@ def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     assert maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
     got = tr.grad_dict()
     worst, gn = _grad_report(got, g)
-    assert worst[0][0] < 3e-3, worst[:6]
+    # a conv bias in front of a training-mode BatchNorm has an analytically ZERO gradient (the layer subtracts the batch mean,
+    # modules.py:123-131): what both sides compute there is rounding noise, measured against 1e-3 of the global gradient norm
+    # by _grad_report; it gets 1e-2 of that yardstick (1e-5 of the norm), every real gradient 3e-3 of its own scale
+    zero_by_bn = lambda k: k.endswith("/bias") and ("/conv_bank/" in k or "/proj_" in k)
+    real = [x for x in worst if not zero_by_bn(x[1])]
+    assert real[0][0] < 3e-3, real[:6]
+    assert all(x[0] < 1e-2 and float(np.abs(g[x[1]]).max()) < 1e-4 * gn for x in worst if zero_by_bn(x[1])), [x for x in worst if zero_by_bn(x[1])][:4]
     tr.set_decoder_engine(0)                      # the same step on the launch-per-stage engine
     tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
     torch.cuda.synchronize()
@@ -492,6 +498,19 @@ def test_C4_shard_shape_forward_and_properties():
     # the weight gradients are sums of 16 K rows accumulated with fp32 atomics in whatever order the workgroups arrive: 24 reruns on one
     # box spread between 0.5e-4 and 1.4e-4 of the largest gradient; a stale operand or a missed update would be of the order of the scale
     assert rerun < 1e-3 * scale, ("two runs of the same step differ beyond fp32-atomic summation order", rerun, scale)
+    # ... and with ordered two-stage sums instead of atomics (Trainer.set_deterministic) the step is reproducible to the bit, like the
+    # reference's single-device step; its gradients are the same up to that summation order
+    tr.set_deterministic(True)
+    tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True)
+    torch.cuda.synchronize()
+    d1 = tr.grads.detach().clone()
+    tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True)
+    torch.cuda.synchronize()
+    rerun_det = float((d1 - tr.grads).abs().max())
+    print("rerun difference: atomics %.2e of the gradient scale, deterministic %.2e" % (rerun / scale, rerun_det / scale))
+    assert rerun_det <= 1e-5 * scale, rerun_det
+    assert float((d1 - g1).abs().max()) < 1e-3 * scale
+    tr.set_deterministic(False)
     trace = []
     for _ in range(5):
         _, lwc = tr.train_step(ids, L, mt, lt)
