@@ -194,6 +194,99 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
     }
   }
 }
+// ---- the same weight gradient on the bf16 matrix cores (3-term split operands, fp32 accumulation: k_gemm_bf3's arithmetic) ----
+// v_mfma_f32_32x32x16_bf16 contracts 16 rows m per instruction at 16x the rate of the fp32-input MFMA.  Its operand layout wants, per
+// lane (i = lane & 31, h = lane >> 5), EIGHT consecutive contraction indices at a fixed output index: X[m0 + 8h + e][k0 + i], e < 8 --
+// eight 4-byte loads, each coalesced across the 32 lanes of a half-wave (consecutive k of one row), straight from global memory in
+// fragment order: no LDS, no transpose.  The fp32 values are split in registers (hi = bf16(x), lo = bf16(x - hi)) and every tile pair
+// issues lo*hi + hi*lo + hi*hi.  Workgroup = 4 waves = a 128 (k) x 128 (n) tile over `rpb` rows; wave (wk, wn) owns the 64 x 64 block
+// (2 x 2 MFMA tiles, 64 accumulator registers), so every loaded fragment feeds two tiles.  The next 16 rows are requested before
+// the MFMAs of the current 16.  Masks, gathers and tap shifts as in k_wgrad; partial sums leave through atomics or, in
+// deterministic mode, as per-slice partial tiles.
+typedef float wgb_f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void wgb_split(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+  uint4 h, l;
+  h.x = taco_pk_bf16(v[0], v[1]); h.y = taco_pk_bf16(v[2], v[3]); h.z = taco_pk_bf16(v[4], v[5]); h.w = taco_pk_bf16(v[6], v[7]);
+  l.x = taco_pk_bf16(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
+  l.y = taco_pk_bf16(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
+  l.z = taco_pk_bf16(v[4] - __uint_as_float(h.z << 16), v[5] - __uint_as_float(h.z & 0xffff0000u));
+  l.w = taco_pk_bf16(v[6] - __uint_as_float(h.w << 16), v[7] - __uint_as_float(h.w & 0xffff0000u));
+  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+}
+__global__ __launch_bounds__(256) void k_wgrad_bf3(const WgArgs g) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 31, h = lane >> 5;
+  const int kb = blockIdx.x * 128 + (wave >> 1) * 64, nb = blockIdx.y * 128 + (wave & 1) * 64;
+  const int nsplit = (g.M + g.rpb - 1) / g.rpb;
+  const int tap = blockIdx.z / nsplit, sp = blockIdx.z - tap * nsplit;
+  const int shift = tap - g.padl;
+  const int m0 = sp * g.rpb, m1 = min(g.M, m0 + g.rpb);
+  if (kb >= g.K || nb >= g.N) return;
+  const bool k2 = kb + 32 < g.K, n2 = nb + 32 < g.N;               // second tile of the pair inside the matrix? (wave-uniform)
+  bool kok[2], nok[2];
+  kok[0] = kb + i < g.K; kok[1] = kb + 32 + i < g.K; nok[0] = nb + i < g.N; nok[1] = nb + 32 + i < g.N;
+  wg_f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float av[2][8], bv[2][8];
+  auto fetch = [&](int mb) {          // this lane's eight rows mb + 8h .. mb + 8h + 7 of both tile pairs
+    const int mr = mb + 8 * h;
+    int tt = (g.T > 0) ? (mr % g.T) : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int m = mr + e;
+      bool rok = m < m1;
+      if (g.T > 0) { const int ts = tt + shift; rok = rok && ts >= 0 && ts < g.T; if (++tt == g.T) tt = 0; }
+      const bool mok = m < m1;
+      size_t xr = 0, yr = 0;
+      if (mok) { xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift); yr = g.ygather ? (size_t)g.ygather[m] : (size_t)m; }
+      const float* xp = g.x + xr * g.ldx + kb + i;
+      const float* yp = g.dy + yr * g.ldy + nb + i;
+      av[0][e] = (rok && kok[0]) ? xp[0] : 0.f;
+      av[1][e] = (rok && kok[1]) ? xp[32] : 0.f;
+      bv[0][e] = (mok && nok[0]) ? yp[0] : 0.f;
+      bv[1][e] = (mok && nok[1]) ? yp[32] : 0.f;
+    }
+  };
+  fetch(m0);
+  for (int mb = m0; mb < m1; mb += 16) {
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { wgb_split(av[a], ah[a], al[a]); wgb_split(bv[a], bh[a], bl[a]); }
+    if (mb + 16 < m1) fetch(mb + 16);                                // in flight across the MFMAs below
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if (a == 1 && !k2) break;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        if (b == 1 && !n2) break;
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);      // small terms first
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+      }
+    }
+  }
+  float* out = g.part ? g.part + ((size_t)sp * g.kw + tap) * g.K * g.N : g.dw + (size_t)tap * g.K * g.lddw;
+  const int ldo = g.part ? g.N : g.lddw;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      if ((a == 1 && !k2) || (b == 1 && !n2) || !nok[b]) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = kb + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (kr < g.K) {
+          float* p = out + (size_t)kr * ldo + nb + 32 * b + i;
+          if (g.part) *p = acc[a][b][r]; else atomicAdd(p, acc[a][b][r]);
+        }
+      }
+    }
+}
+
 // dw[tap][k][n] += sum over the M-slices, slice 0 first (fixed order: run-to-run reproducible)
 __global__ void k_wgrad_reduce(const float* part, int nsplit, int kw, int K, int N, float* dw, int lddw) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)kw * K * N;

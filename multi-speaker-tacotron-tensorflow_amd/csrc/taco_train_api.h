@@ -53,6 +53,11 @@ int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int w
   t->sync_fn = fn; t->sync_user = user; t->sync_world = fn ? world_size : 1;
   return 0;
 }
+int taco_train_set_exact_wgrad(taco_train* t, int on) {
+  if (!t) return fail(TACO_ERR_ARG, "null argument");
+  g_wgrad_bf3 = on ? 0 : 1;           // process-wide switch (an A/B and test hook, not a per-trainer setting)
+  return 0;
+}
 int taco_train_set_deterministic(taco_train* t, int on) {
   if (!t) return fail(TACO_ERR_ARG, "null argument");
   t->deterministic = on ? 1 : 0;      // changes taco_train_workspace_bytes

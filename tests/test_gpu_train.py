@@ -245,6 +245,20 @@ def test_gradients_at_full_reference_widths():
     assert maxabs(tr.mel_outputs.cpu().numpy(), out["mel"]) < 1e-4 and maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4
     worst, gn = _grad_report(tr.grad_dict(), g)
     assert worst[0][0] < 3e-3, worst[:5]
+    # the weight gradients above came from the split-bf16 matrix-core kernel (k_wgrad_bf3, the default); the exact-fp32 MFMA kernel
+    # (k_wgrad) must give the same gradients to the split's ~1e-5
+    got = tr.grad_dict()
+    tr.set_exact_wgrad(True)
+    try:
+        tr.forward_backward(ids, L, mt, lt, co)
+        torch.cuda.synchronize()
+        exact = tr.grad_dict()
+    finally:
+        tr.set_exact_wgrad(False)
+    worst_x, _ = _grad_report(exact, g)
+    d = max(maxabs(got[k], exact[k]) / max(float(np.abs(exact[k]).max()), 1e-3 * gn) for k in exact)
+    print("weight gradients: split-bf16 vs float64 autograd %.2e, exact fp32 vs autograd %.2e, split vs exact %.2e (relative, per tensor, worst)" % (worst[0][0], worst_x[0][0], d))
+    assert worst_x[0][0] < 3e-3 and d < 1e-3
     tr.close()
 
 
@@ -410,19 +424,25 @@ def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     assert maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
     got = tr.grad_dict()
     worst, gn = _grad_report(got, g)
-    # a conv bias in front of a training-mode BatchNorm has an analytically ZERO gradient (the layer subtracts the batch mean,
-    # modules.py:123-131): what both sides compute there is rounding noise, measured against 1e-3 of the global gradient norm
-    # by _grad_report; it gets 1e-2 of that yardstick (1e-5 of the norm), every real gradient 3e-3 of its own scale
+    # Yardsticks.  A conv bias in front of a training-mode BatchNorm has an analytically ZERO gradient (the layer subtracts the
+    # batch mean, modules.py:123-131): what both sides compute there is rounding noise, held to 2e-5 of the global gradient
+    # norm in absolute terms.  Every real gradient: 5e-3 of max(its own largest entry, 1e-3 of the global norm) -- the post-net
+    # conv-bank kernels sit on that floor (|g| < 3e-4 of the norm; their error is ~4e-6 of the norm: fp32 sums over B * T_out
+    # rows behind a batch-statistics BatchNorm) -- and 1e-3 for everything that is not a conv bank.
     zero_by_bn = lambda k: k.endswith("/bias") and ("/conv_bank/" in k or "/proj_" in k)
     real = [x for x in worst if not zero_by_bn(x[1])]
-    assert real[0][0] < 3e-3, real[:6]
-    assert all(x[0] < 1e-2 and float(np.abs(g[x[1]]).max()) < 1e-4 * gn for x in worst if zero_by_bn(x[1])), [x for x in worst if zero_by_bn(x[1])][:4]
+    noise = [x for x in worst if zero_by_bn(x[1])]
+    print("worst real:", real[:3], " worst BatchNorm-cancelled bias:", noise[:2], " |g| =", gn)
+    assert real[0][0] < 5e-3, real[:6]
+    assert all(x[0] < 1e-3 for x in real if "conv_bank" not in x[1]), [x for x in real if "conv_bank" not in x[1]][:4]
+    assert all(x[2] < 2e-5 * gn for x in noise), noise[:4]
     tr.set_decoder_engine(0)                      # the same step on the launch-per-stage engine
     tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
     torch.cuda.synchronize()
     ref = tr.grad_dict()
     scale = max(float(np.abs(v).max()) for v in ref.values())
-    assert max(maxabs(got[k], ref[k]) for k in ref) < 2e-4 * scale
+    assert max(maxabs(got[k], ref[k]) for k in ref if not zero_by_bn(k)) < 2e-4 * scale
+    assert max(maxabs(got[k], ref[k]) for k in ref) < 2e-5 * gn
     tr.set_decoder_engine(1)
     step, lwc = tr.train_step(ids, L, mt, lt, co, speaker_id=spk)      # packs regenerated on the device (k_dx_fold + index-map gather)
     losses2 = tr.forward_backward(ids, L, mt, lt, co, backward=False, speaker_id=spk)
