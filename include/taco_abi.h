@@ -208,8 +208,8 @@ taco_model* taco_train_model(taco_train* t);
  * run-to-run reproducible, as the reference's single-device step is (train.py:215-219).  Costs 192 MB more workspace
  * (taco_train_workspace_bytes reflects it: query it again) and a few per cent of the step.  Default 0. */
 int taco_train_set_deterministic(taco_train* t, int on);
-/* Weight gradients: on = 0 (default) computes dW = X^T . dY on the bf16 matrix cores with 3-term split operands and fp32
- * accumulation (k_wgrad_bf3: the arithmetic of the inference GEMMs, ~1e-5 of the gradient scale); on = 1 keeps them on the
+/* Weight gradients: on = 0 (default) computes dW = X^T . dY on the bf16 matrix cores with operands split three ways (24 bits) and
+ * six products per tile, fp32 accumulation (k_wgrad_bf3: fp32-grade, ~2^-24 per product); on = 1 keeps them on the
  * exact-fp32 MFMA (k_wgrad, round 1).  Process-wide A/B and test hook. */
 int taco_train_set_exact_wgrad(taco_train* t, int on);
 size_t taco_train_num_params(const taco_train* t);

@@ -194,35 +194,48 @@ __global__ __launch_bounds__(256) void k_wgrad(const WgArgs g) {
     }
   }
 }
-// ---- the same weight gradient on the bf16 matrix cores (3-term split operands, fp32 accumulation: k_gemm_bf3's arithmetic) ----
+// ---- the same weight gradient on the bf16 matrix cores (three-way split operands, six products, fp32 accumulation) ----
 // v_mfma_f32_32x32x16_bf16 contracts 16 rows m per instruction at 16x the rate of the fp32-input MFMA.  Its operand layout wants, per
 // lane (i = lane & 31, h = lane >> 5), EIGHT consecutive contraction indices at a fixed output index: X[m0 + 8h + e][k0 + i], e < 8 --
 // eight 4-byte loads, each coalesced across the 32 lanes of a half-wave (consecutive k of one row), straight from global memory in
-// fragment order: no LDS, no transpose.  The fp32 values are split in registers (hi = bf16(x), lo = bf16(x - hi)) and every tile pair
-// issues lo*hi + hi*lo + hi*hi.  Workgroup = 4 waves = a 128 (k) x 128 (n) tile over `rpb` rows; wave (wk, wn) owns the 64 x 64 block
+// fragment order: no LDS, no transpose.  The fp32 values are split in registers (wgb_split3).  Workgroup = 4 waves = a 128 (k) x 128 (n) tile over `rpb` rows; wave (wk, wn) owns the 64 x 64 block
 // (2 x 2 MFMA tiles, 64 accumulator registers), so every loaded fragment feeds two tiles.  The next 16 rows are requested before
 // the MFMAs of the current 16.  Masks, gathers and tap shifts as in k_wgrad; partial sums leave through atomics or, in
 // deterministic mode, as per-slice partial tiles.
-typedef float wgb_f32x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ void wgb_split(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-  uint4 h, l;
-  h.x = taco_pk_bf16(v[0], v[1]); h.y = taco_pk_bf16(v[2], v[3]); h.z = taco_pk_bf16(v[4], v[5]); h.w = taco_pk_bf16(v[6], v[7]);
-  l.x = taco_pk_bf16(v[0] - __uint_as_float(h.x << 16), v[1] - __uint_as_float(h.x & 0xffff0000u));
-  l.y = taco_pk_bf16(v[2] - __uint_as_float(h.y << 16), v[3] - __uint_as_float(h.y & 0xffff0000u));
-  l.z = taco_pk_bf16(v[4] - __uint_as_float(h.z << 16), v[5] - __uint_as_float(h.z & 0xffff0000u));
-  l.w = taco_pk_bf16(v[6] - __uint_as_float(h.w << 16), v[7] - __uint_as_float(h.w & 0xffff0000u));
-  hi = __builtin_bit_cast(bf16x8, h); lo = __builtin_bit_cast(bf16x8, l);
+// Gradients are sums of products that largely cancel (a weight gradient is small next to the sum of the magnitudes of its terms), so
+// the 2^-17 per-product error of the two-way split that serves the inference GEMMs shows: here every operand is split THREE ways,
+// x = hi + mid + lo exactly to 24 bits (hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)), and a tile pair issues the six
+// products down to 2^-24 of the result -- lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi -- fp32-grade, on the bf16 pipe.  The kernel is
+// bound by operand delivery, not by the matrix pipe: the three extra MFMAs ride in the shadow of the loads.
+__device__ __forceinline__ void wgb_split3(const float (&v)[8], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float a = v[2 * p], b = v[2 * p + 1];
+    h[p] = taco_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h[p] << 16), rb = b - __uint_as_float(h[p] & 0xffff0000u);
+    m[p] = taco_pk_bf16(ra, rb);
+    l[p] = taco_pk_bf16(ra - __uint_as_float(m[p] << 16), rb - __uint_as_float(m[p] & 0xffff0000u));
+  }
+  hi = __builtin_bit_cast(bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  mid = __builtin_bit_cast(bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+  lo = __builtin_bit_cast(bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
 }
-__global__ __launch_bounds__(256) void k_wgrad_bf3(const WgArgs g) {
+// NW = waves per workgroup: 4 (128 x 128 tile) or 1 (64 x 64 tile: small matrices with many rows, where a finer tiling buys the
+// workgroups that would otherwise have to come from splitting M -- every M-slice ends in 4096 atomics per wave).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad_bf3(const WgArgs g) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, h = lane >> 5;
-  const int kb = blockIdx.x * 128 + (wave >> 1) * 64, nb = blockIdx.y * 128 + (wave & 1) * 64;
+  constexpr int TS = NW == 4 ? 128 : 64;
+  const int kb = blockIdx.x * TS + (NW == 4 ? (wave >> 1) * 64 : 0), nb = blockIdx.y * TS + (NW == 4 ? (wave & 1) * 64 : 0);
   const int nsplit = (g.M + g.rpb - 1) / g.rpb;
   const int tap = blockIdx.z / nsplit, sp = blockIdx.z - tap * nsplit;
   const int shift = tap - g.padl;
   const int m0 = sp * g.rpb, m1 = min(g.M, m0 + g.rpb);
   if (kb >= g.K || nb >= g.N) return;
   const bool k2 = kb + 32 < g.K, n2 = nb + 32 < g.N;               // second tile of the pair inside the matrix? (wave-uniform)
+  const bool full = (kb + 64 <= g.K) && (nb + 64 <= g.N) && !g.gather && !g.ygather;   // wave-uniform: no column masks, plain row indices
   bool kok[2], nok[2];
   kok[0] = kb + i < g.K; kok[1] = kb + 32 + i < g.K; nok[0] = nb + i < g.N; nok[1] = nb + 32 + i < g.N;
   wg_f32x16 acc[2][2];
@@ -233,6 +246,20 @@ __global__ __launch_bounds__(256) void k_wgrad_bf3(const WgArgs g) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float av[2][8], bv[2][8];
   auto fetch = [&](int mb) {          // this lane's eight rows mb + 8h .. mb + 8h + 7 of both tile pairs
+    // interior block (wave-uniform test on the scalar unit): all 16 rows exist, lie in one batch row and stay inside it after the tap
+    // shift -> sixteen unconditional loads per operand from 32-bit offsets
+    const int tb = (g.T > 0) ? (mb % g.T) : 0;
+    const bool inner = full && (mb + 16 <= m1) && (g.T <= 0 || (tb + shift >= 0 && tb + 15 + shift < g.T));
+    if (inner) {
+      const unsigned xo = (unsigned)(mb + 8 * h + shift) * (unsigned)g.ldx + (unsigned)(kb + i);
+      const unsigned yo = (unsigned)(mb + 8 * h) * (unsigned)g.ldy + (unsigned)(nb + i);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        av[0][e] = g.x[xo + (unsigned)e * (unsigned)g.ldx]; av[1][e] = g.x[xo + (unsigned)e * (unsigned)g.ldx + 32u];
+        bv[0][e] = g.dy[yo + (unsigned)e * (unsigned)g.ldy]; bv[1][e] = g.dy[yo + (unsigned)e * (unsigned)g.ldy + 32u];
+      }
+      return;
+    }
     const int mr = mb + 8 * h;
     int tt = (g.T > 0) ? (mr % g.T) : 0;
 #pragma unroll
@@ -253,9 +280,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf3(const WgArgs g) {
   };
   fetch(m0);
   for (int mb = m0; mb < m1; mb += 16) {
-    bf16x8 ah[2], al[2], bh[2], bl[2];
+    bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) { wgb_split(av[a], ah[a], al[a]); wgb_split(bv[a], bh[a], bl[a]); }
+    for (int a = 0; a < 2; ++a) { wgb_split3(av[a], ah[a], am[a], al[a]); wgb_split3(bv[a], bh[a], bm[a], bl[a]); }
     if (mb + 16 < m1) fetch(mb + 16);                                // in flight across the MFMAs below
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -265,6 +292,9 @@ __global__ __launch_bounds__(256) void k_wgrad_bf3(const WgArgs g) {
         if (b == 1 && !n2) break;
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);      // small terms first
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh[b], acc[a][b], 0, 0, 0);
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm[b], acc[a][b], 0, 0, 0);
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
       }
     }

@@ -198,18 +198,21 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
   HIPCHK(hipGetLastError());
   return 0;
 }
-// 1 (default): weight gradients on the bf16 matrix cores with 3-term split operands (k_wgrad_bf3: fp32-grade, the arithmetic of the
-// inference GEMMs); 0: exact-fp32 MFMA (k_wgrad).  taco_train_set_exact_wgrad.
+// 1 (default): weight gradients on the bf16 matrix cores with operands split three ways and six products per tile (k_wgrad_bf3:
+// fp32-grade); 0: exact-fp32 MFMA (k_wgrad).  taco_train_set_exact_wgrad.
 static int g_wgrad_bf3 = 1;
 static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
                      int M, int T, int K, int N, int kw = 1, int padl = 0, const int* ygather = nullptr) {
   WgArgs g; g.ygather = ygather; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
   g.kw = kw; g.padl = padl;
   const bool bf3 = g_wgrad_bf3 != 0;
-  const int TS = bf3 ? 128 : 64;     // tile edge per workgroup
-  // rows per workgroup: enough workgroups to fill 256 CUs several times over, at least 64 rows each
-  { const long tiles = (long)cdiv(K, TS) * cdiv(N, TS) * kw; int rpb = 512;
-    while (rpb > 64 && tiles * cdiv(M, rpb) < (bf3 ? 1024 : 2048)) rpb >>= 1;
+  // split-bf16 kernel: 128 x 128 tiles (4 waves) when those alone give a few hundred workgroups, else 64 x 64 tiles (1 wave): every
+  // M-slice a workgroup takes ends in one atomic per output element, so slices are kept LONG (>= 256 rows where the grid allows)
+  const long t128 = (long)cdiv(K, 128) * cdiv(N, 128) * kw, t64 = (long)cdiv(K, 64) * cdiv(N, 64) * kw;
+  const bool big = bf3 && t128 >= 64;
+  { const long tiles = big ? t128 : t64; int rpb = 1024;
+    const long want = bf3 ? (big ? 768 : 1024) : 2048;      // workgroups (one-wave workgroups: four times as many fit a CU)
+    while (rpb > (bf3 ? 128 : 64) && tiles * cdiv(M, rpb) < want) rpb >>= 1;
     g.rpb = rpb; }
   g.part = nullptr;
   if (g_det.p) {   // per-slice partial tiles + an ordered sum instead of atomics; fewer, longer slices if the scratch is short
@@ -219,7 +222,8 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
     g.part = g_det.p;
   }
   const int nsplit = cdiv(M, g.rpb);
-  if (bf3) hipLaunchKernelGGL(k_wgrad_bf3, dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit), dim3(256), 0, st, g);
+  if (bf3 && big) hipLaunchKernelGGL((k_wgrad_bf3<4>), dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit), dim3(256), 0, st, g);
+  else if (bf3) hipLaunchKernelGGL((k_wgrad_bf3<1>), dim3(cdiv(K, 64), cdiv(N, 64), kw * nsplit), dim3(64), 0, st, g);
   else hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * nsplit), dim3(256), 0, st, g);
   if (g.part) hipLaunchKernelGGL(k_wgrad_reduce, EWGRID((size_t)kw * K * N), 0, st, (const float*)g.part, nsplit, kw, K, N, dw, lddw);
   HIPCHK(hipGetLastError());
