@@ -212,6 +212,13 @@ int taco_train_set_deterministic(taco_train* t, int on);
  * six products per tile, fp32 accumulation (k_wgrad_bf3: fp32-grade, ~2^-24 per product); on = 1 keeps them on the
  * exact-fp32 MFMA (k_wgrad, round 1).  Process-wide A/B and test hook. */
 int taco_train_set_exact_wgrad(taco_train* t, int on);
+/* Test hook: the post-net BiGRU scan alone -- forward with the gate tape, then backward -- on caller data, ragged lengths and
+ * initial states included.  persistent = 1: the whole-chip kernels k_bigru_duo<RG, true> + k_bigru_duo_bwd; 0: k_bigru_res + k_bigru_rows_bwd.
+ * d_xproj [B*T, 6H] (hoisted input projection, backward direction time-reversed per row), d_lengths [B] / NULL, d_h0 [B, 2H] / NULL,
+ * d_dout [B*T, 2H] -> d_out [B*T, 2H], d_gsave / d_dg [B*T, 6H], d_rh [B*T, 2H], d_dh0 [B, 2H] / NULL; scratch >= 1 MB. */
+int taco_train_debug_bigru(taco_train* t, void* hip_stream, const float* d_xproj, const int32_t* d_lengths, const float* d_h0,
+                           const float* d_dout, int B, int T, int persistent, float* d_out, float* d_gsave, float* d_dg, float* d_rh,
+                           float* d_dh0, void* d_scratch, size_t scratch_bytes);
 size_t taco_train_num_params(const taco_train* t);
 int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset);
 /* regenerate every weight pack from the flat parameter buffer (call after loading parameters and after every update) */

@@ -482,3 +482,272 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
     gd_request<RG, NT>(X_hB, tid, pre);
   }
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_duo_bwd<RG>: the backward scan of the same BiGRU (BPTT through modules.py:82-96 / TF GRUCell, A.6/A.7) on k_bigru_duo's
+// machinery: both directions of RG rows on one group of 32 CUs, the two directions software-pipelined against each other, polls
+// issued early.  It replaces k_bigru_rows_bwd (one workgroup per (direction, row pair), the transposed recurrent kernels streamed
+// from L2 every step: 4 us per step) for H = 256.
+//
+// Per direction, row and step s (descending; t = true time of the step, hp = the state the step started from):
+//   g = dh + dout_t;  d c_pre = g (1-u)(1-c^2);  d u_pre = g (hp - c) u (1-u);  keep = g u            [owner of the unit, local]
+//   d(r*h) = d c_pre . Wc_h^T            <- exchange 1: d c_pre of all units
+//   d r_pre = d(r*h) hp r (1-r);  keep += d(r*h) r
+//   dh(previous step) = keep + [d r_pre | d u_pre] . Wg_h^T     <- exchange 2: the 2H gate pre-activation gradients
+// dh never leaves the lane that owns the unit.  Member m owns units 8m .. 8m+7 of both directions, wave w unit 8m + w; a lane keeps
+// its 4-input slice of that unit's ROW of Wc_h (4 registers) and of Wg_h (8 registers: r half, u half) per direction.  Everything a
+// step reads from global memory (dout, the gate tape r, u, c and the previous state) comes through an LDS ring fetched 16 steps at a
+// time straight into LDS; it writes d r_pre, d u_pre, d c_pre (the gradient of the hoisted input projection) and r*hp (the input of
+// the candidate kernel's recurrent rows, for its weight gradient) at the true time index.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define GB_ARR 5             // ring arrays per (direction, step, row): dout, r, u, c, hp -- 8 units (two float4) each
+__host__ __device__ inline size_t gb_ring_floats(int RG) { return (size_t)2 * 2 * GX_BLK * RG * GB_ARR * 8; }      // [slot][dir][step][row][array][8]
+__host__ __device__ inline size_t gb_lds_floats(int RG) { return gb_ring_floats(RG) + (size_t)2 * RG * GX_H + (size_t)2 * RG * 2 * GX_H + 64; }
+__host__ __device__ inline size_t gb_xbuf_granules(int RG) { return (size_t)DX_NGROUP * 2 * RG * 3 * GX_H; }     // groups x dir x [d c_pre : H | d gates : 2H] x RG
+
+template <int RG, int W, int NT>
+struct GbPoll {
+  static constexpr int NI = (RG * W + NT - 1) / NT;
+  unsigned long long g[NI];
+};
+template <int RG, int W, int NT>
+__device__ __forceinline__ void gb_request(const dx_gu64* X, int tid, GbPoll<RG, W, NT>& p) {
+  if ((RG * W >= NT) || tid < RG * W) {
+#pragma unroll
+    for (int u = 0; u < GbPoll<RG, W, NT>::NI; ++u) p.g[u] = __hip_atomic_load(X + tid + u * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <int RG, int W, int NT>
+__device__ __forceinline__ void gb_landed(GbPoll<RG, W, NT>& p, float& after) {
+#pragma unroll
+  for (int u = 0; u < GbPoll<RG, W, NT>::NI; ++u) asm volatile("" : "+v"(p.g[u]), "+v"(after));
+}
+template <int RG, int W, int NT>
+__device__ __forceinline__ void gb_collect(const dx_gu64* X, unsigned tag, float* st, int tid, GbPoll<RG, W, NT>& p, DxRt& rt) {
+  constexpr int NI = GbPoll<RG, W, NT>::NI;
+  if ((RG * W >= NT) || tid < RG * W) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) ok = ok && ((unsigned)(p.g[u] >> 32) == tag);
+    float v[NI];
+    if (ok) {
+#pragma unroll
+      for (int u = 0; u < NI; ++u) v[u] = __uint_as_float((unsigned)p.g[u]);
+    } else {
+      dx_poll<NI>(X + tid, NT, tag, v, rt);
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) st[u * NT + tid] = v[u];
+  }
+}
+
+struct GbArgs {
+  const float* wpack;                         // [2 dirs][32 members][12][512]: rows of Wc_h (4) and of Wg_h (4 r-half + 4 u-half) of the wave's unit
+  const float* dout; const float* out; const float* gsave;     // [B*T, 2H], [B*T, 2H], [B*T, 6H]
+  const float* h0;                            // [B, 2H] or null
+  const int* lengths;                         // [B] or null
+  float* dg; float* rh; float* dh0;           // [B*T, 6H], [B*T, 2H] (both pre-zeroed by the caller), [B, 2H] or null
+  unsigned long long* xbuf; unsigned* ctl; unsigned* err;
+  int B, T, force_wt;
+};
+
+template <int RG>
+__global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GbArgs a = a_in;
+  constexpr int NT = 512, H = GX_H, RL = DxRL<RG>::value;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SLOT = 2 * GX_BLK * RG * GB_ARR * 8;      // floats of one ring slot
+  float* xq = gx_smem;                                    // ring first (M0-addressed)
+  float* v1 = xq + 2 * SLOT;                              // [2 dirs][RG][H]   d c_pre
+  float* v2 = v1 + 2 * RG * H;                            // [2 dirs][RG][2H]  d r_pre | d u_pre
+  int* ictl = reinterpret_cast<int*>(v2 + 2 * RG * 2 * H);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  const int row0 = group * RG;
+  if (row0 >= a.B || member >= GD_MEMBERS) return;
+  const int T = a.T;
+
+  float W[GD_NREG];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float* wp = a.wpack + (((size_t)d * GD_MEMBERS + member) * 12) * NT + tid;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) W[12 * d + j] = wp[(size_t)j * NT];
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * 2 * RG * 3 * H;      // [dir][d c_pre : RG x H | d gates : RG x 2H]
+  for (int i = tid; i < 2 * RG * H; i += NT) v1[i] = 0.f;
+  for (int i = tid; i < 2 * RG * 2 * H; i += NT) v2[i] = 0.f;
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+  const int u0 = member * 8 + wave;
+  int erow[RL], eL[RL];
+  bool evalid[RL];
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    erow[q] = dx_row<RG>(lane & 3, q);
+    evalid[q] = epl && (row0 + erow[q] < a.B);
+    eL[q] = evalid[q] ? (a.lengths ? a.lengths[row0 + erow[q]] : T) : 0;
+  }
+  // ring blocks: block k covers steps s = T-1-16k .. T-16-16k; item i = (dir, j, row, array, half) -> one float4 of the member's 8 units
+  constexpr int NIT = 2 * GX_BLK * RG * GB_ARR * 2, NLD = (NIT + NT - 1) / NT;
+  static_assert(NIT % 64 == 0, "a wave's 64 items are all inside the block or all outside");
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  auto blk_fetch = [&](int blk, int ring) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      if (u * NT + wave * 64 < NIT) {            // wave-uniform
+        const int i = u * NT + tid;
+        const int c2 = i & 1, ar = (i >> 1) % GB_ARR, r = (i / (2 * GB_ARR)) % RG, j = (i / (2 * GB_ARR * RG)) % GX_BLK, d = i / (2 * GB_ARR * RG * GX_BLK);
+        const int b = min(row0 + r, a.B - 1);
+        const int L = a.lengths ? a.lengths[b] : T;
+        const int s = max(T - 1 - GX_BLK * blk - j, 0);
+        const int sc = min(s, max(L - 1, 0));                                   // inactive steps: any valid row (the values are not used)
+        const int t = d ? (L - 1 - sc) : sc, tp = min(max(d ? t + 1 : t - 1, 0), T - 1);
+        const float* src;
+        if (ar == 0) src = a.dout + ((size_t)b * T + t) * 2 * H + d * H;
+        else if (ar == 4) src = a.out + ((size_t)b * T + tp) * 2 * H + d * H;
+        else src = a.gsave + ((size_t)b * T + t) * 6 * H + d * 3 * H + (ar - 1) * H;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * SLOT + 4 * (u * NT + wave * 64)) * 4u);
+        gx_load_lds16(src + member * 8 + 4 * c2, dst);
+      }
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float keep[2][RL], hp[2][RL], rg[2][RL], dgu[2][RL];
+  bool act[2][RL];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) { keep[d][q] = 0.f; hp[d][q] = 0.f; rg[d][q] = 0.f; dgu[d][q] = 0.f; act[d][q] = false; }
+  GbPoll<RG, H, NT> pre1;            // a d c_pre gather in flight
+  GbPoll<RG, 2 * H, NT> pre2;        // a d gates gather in flight
+#pragma unroll
+  for (int u = 0; u < GbPoll<RG, H, NT>::NI; ++u) pre1.g[u] = 0ull;
+#pragma unroll
+  for (int u = 0; u < GbPoll<RG, 2 * H, NT>::NI; ++u) pre2.g[u] = 0ull;
+
+  const int tid_outer = tid, lane_outer = lane;
+  // step index k = T-1-s counts up; tag of the exchanges of step k = k + 1
+  for (int k = 0; k <= T; ++k) {                 // k == T: only the trailing dh of step s = 0 (the initial-state gradient)
+    const int s = T - 1 - k;
+    const unsigned tag = (unsigned)k + 1u;
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int sb = k & (GX_BLK - 1), ring = (k / GX_BLK) & 1;
+    if (sb == 0 && k > 0 && k < T) blk_fetch(k / GX_BLK + 1, ring ^ 1);
+    // phase CA(D): finish step s+1 (dh of the previous step from the gathered gate gradients), start step s
+    auto phase_ca = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+      float dhg[RL];
+#pragma unroll
+      for (int q = 0; q < RL; ++q) dhg[q] = 0.f;
+      if (k > 0) {
+        float acc[1][RG], sm[1][RL];
+        dx_zero<1, RG>(acc);
+        dx_pass<12 * D + 4, 1, RG, GD_NREG, 2 * GX_H>(W, v2 + D * RG * 2 * H, lane, acc);               // r half of the gate gradients
+        dx_pass<12 * D + 8, 1, RG, GD_NREG, 2 * GX_H>(W, v2 + D * RG * 2 * H + H, lane, acc);           // u half
+        dx_reduce<1, RG>(acc, sm, lane);
+#pragma unroll
+        for (int q = 0; q < RL; ++q) dhg[q] = sm[0][q];
+      }
+      float dcp[RL][1];
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float dh = act[D][q] ? keep[D][q] + dhg[q] : keep[D][q];          // act = the previous step's
+        dcp[q][0] = 0.f; dgu[D][q] = 0.f;
+        keep[D][q] = dh;
+        if (k < T) {
+          const bool active = evalid[q] && s < eL[q];
+          act[D][q] = active;
+          const float* rq = xq + (size_t)ring * SLOT + (((size_t)(D * GX_BLK + sb) * RG + erow[q]) * GB_ARR) * 8 + wave;
+          const float dout = rq[0], r = rq[8], u = rq[16], c = rq[24];
+          float hprev = rq[32];
+          const int L = eL[q], t = D ? (L - 1 - s) : s;
+          if (active && s == 0) hprev = a.h0 ? a.h0[(size_t)(row0 + erow[q]) * 2 * H + D * H + u0] : 0.f;   // the step that started from the initial state
+          if (active) {
+            const float g = dh + dout;
+            dcp[q][0] = g * (1.f - u) * (1.f - c * c);
+            dgu[D][q] = g * (hprev - c) * u * (1.f - u);
+            keep[D][q] = g * u;
+            hp[D][q] = hprev; rg[D][q] = r;
+            const size_t row = (size_t)(row0 + erow[q]) * T + t;
+            a.rh[row * 2 * H + D * H + u0] = r * hprev;
+            float* dq = a.dg + row * 6 * H + D * 3 * H + u0;
+            dq[H] = dgu[D][q]; dq[2 * H] = dcp[q][0];
+          }
+        } else {
+          act[D][q] = false;
+          if (a.dh0 && evalid[q]) a.dh0[(size_t)(row0 + erow[q]) * 2 * H + D * H + u0] = dh;
+        }
+      }
+      if (k < T) {
+        gb_landed<RG, H, NT>(pre1, dcp[RL - 1][0]);        // whichever gather is in flight across this phase has landed by now:
+        gb_landed<RG, 2 * H, NT>(pre2, dcp[RL - 1][0]);    // wait for it HERE, ahead of the publish stores (see gd_landed)
+        if (epl) {
+#pragma unroll
+          for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)D * RG * 3 * H + erow[q] * H + u0, 1, dcp[q], tag, rt);
+        }
+      }
+    };
+    // phase B(D): d(r*h) from the gathered d c_pre -> d r_pre, publish both gate gradients
+    auto phase_b = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+      float acc[1][RG], sm[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<12 * D, 1, RG, GD_NREG, GX_H>(W, v1 + D * RG * H, lane, acc);
+      dx_reduce<1, RG>(acc, sm, lane);
+      float gr[RL][1], gu[RL][1];
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        float dgr = 0.f;
+        if (act[D][q]) {
+          const float drh = sm[0][q];
+          dgr = drh * hp[D][q] * rg[D][q] * (1.f - rg[D][q]);
+          keep[D][q] += drh * rg[D][q];
+          const int L = eL[q], t = D ? (L - 1 - s) : s;
+          a.dg[((size_t)(row0 + erow[q]) * T + t) * 6 * H + D * 3 * H + u0] = dgr;
+        }
+        gr[q][0] = dgr; gu[q][0] = dgu[D][q];
+      }
+      gb_landed<RG, H, NT>(pre1, gr[RL - 1][0]);
+      gb_landed<RG, 2 * H, NT>(pre2, gr[RL - 1][0]);
+      if (epl) {
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {
+          dx_publish_n<1>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + u0, 1, gr[q], tag, rt);
+          dx_publish_n<1>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + H + u0, 1, gu[q], tag, rt);
+        }
+      }
+    };
+    using F = std::integral_constant<int, 0>;
+    using Bk = std::integral_constant<int, 1>;
+    const dx_gu64* Xc0 = X;                               const dx_gu64* Xg0 = X + (size_t)RG * H;
+    const dx_gu64* Xc1 = X + (size_t)RG * 3 * H;          const dx_gu64* Xg1 = X + (size_t)RG * 3 * H + RG * H;
+    // (the gate gradients of F of the previous step were collected at the end of the previous iteration; B's are in flight)
+    phase_ca(F{});
+    if (k > 0) gb_collect<RG, 2 * H, NT>(Xg1, tag - 1u, v2 + RG * 2 * H, tid, pre2, rt);
+    __syncthreads();
+    if (k == T) { phase_ca(Bk{}); break; }
+    gb_request<RG, H, NT>(Xc0, tid, pre1);
+    phase_ca(Bk{});
+    gb_collect<RG, H, NT>(Xc0, tag, v1, tid, pre1, rt);
+    __syncthreads();
+    gb_request<RG, H, NT>(Xc1, tid, pre1);
+    phase_b(F{});
+    gb_collect<RG, H, NT>(Xc1, tag, v1 + RG * H, tid, pre1, rt);
+    __syncthreads();
+    gb_request<RG, 2 * H, NT>(Xg0, tid, pre2);
+    phase_b(Bk{});
+    gb_collect<RG, 2 * H, NT>(Xg0, tag, v2, tid, pre2, rt);
+    if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    gb_request<RG, 2 * H, NT>(Xg1, tid, pre2);
+  }
+}

@@ -102,7 +102,7 @@ struct Cbhg {
   SkW gh[2], ch[2];
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
-  size_t gd_pack = 0;                                  // k_bigru_duo: [2 dirs][32 members][12][512]
+  size_t gd_pack = 0, gb_pack = 0;                     // k_bigru_duo / k_bigru_duo_bwd: [2 dirs][32 members][12][512]
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
                                                    // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
@@ -566,6 +566,24 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
         }
     }
     c.gd_pack = arena_put(m, gp.data(), gp.size());
+    if (m->tp) {   // k_bigru_duo_bwd (training only): ROWS of the recurrent kernels -- unit u's row of Wc_h, then of Wg_h (r half, u half)
+      std::vector<float> bp((size_t)2 * GD_MEMBERS * 12 * 512, 0.f);
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+        const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
+        for (int mem = 0; mem < GD_MEMBERS; ++mem)
+          for (int tid = 0; tid < 512; ++tid) {
+            const int w = tid >> 6, l = tid & 63, u = mem * 8 + w;
+            float* base = &bp[(((size_t)dir * GD_MEMBERS + mem) * 12) * 512 + tid];
+            for (int e = 0; e < 4; ++e) {
+              base[(size_t)(0 + e) * 512] = ck[(size_t)(I + u) * H + 4 * l + e];
+              base[(size_t)(4 + e) * 512] = gk[(size_t)(I + u) * 2 * H + 4 * l + e];
+              base[(size_t)(8 + e) * 512] = gk[(size_t)(I + u) * 2 * H + H + 4 * l + e];
+            }
+          }
+      }
+      c.gb_pack = arena_put(m, bp.data(), bp.size());
+    }
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;

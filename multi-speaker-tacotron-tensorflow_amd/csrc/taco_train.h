@@ -266,7 +266,7 @@ static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w
   w.dg = cv.f(M * 6 * c.rnn); w.rh = cv.f(M * 2 * c.rnn);
   w.d0 = cv.f(M * wide); w.d1 = cv.f(M * wide); w.dcat = cv.f(M * 2 * c.rnn);
   w.dbig0 = cv.f(M * KC); w.dbig1 = cv.f(M * KC); w.stat = cv.f(5 * std::max<size_t>(KC, wide));   // sums, centred sums + the 3-vector SyncBN exchange pack
-  w.gxbuf = (unsigned long long*)cv.raw(gd_xbuf_granules(8) * sizeof(unsigned long long)); w.gxctl = (unsigned*)cv.raw(256);
+  w.gxbuf = (unsigned long long*)cv.raw(std::max(gd_xbuf_granules(8), gb_xbuf_granules(8)) * sizeof(unsigned long long)); w.gxctl = (unsigned*)cv.raw(256);
 }
 struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (b*n + t)*W
   float *keys, *zero, *ctx, *pz[4], *hA, *rA, *uA, *cA, *rhA, *xcA, *alpha, *alpha0;
@@ -506,7 +506,24 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   // ---- BiGRU ----
   HIPCHK(zero_async(w.dg, (size_t)M * 6 * H * sizeof(float), st));
   HIPCHK(zero_async(w.rh, (size_t)M * 2 * H * sizeof(float), st));
-  {
+  if (duo_usable(m, c, B, T) && c.gb_pack) {
+    // both directions of RG rows per group of 32 CUs, the directions software-pipelined against each other (k_bigru_duo_bwd)
+    GbArgs a; memset(&a, 0, sizeof a);
+    a.wpack = AP(m, c.gb_pack); a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.h0 = h0; a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.dh0 = dh0;
+    a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+    int RG = 1;
+    while (RG * DX_NGROUP < B) RG *= 2;
+    HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
+    const size_t lds = std::max(gb_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+    const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo_bwd<1>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo_bwd<2>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo_bwd<4>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo_bwd<8>), grid, blk, lds, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+  } else {
     int R = (B >= 2 && 2 * H <= RP_NT) ? 2 : 1;
     if ((size_t)R * H > RP_NT || (H % 4)) return fail(TACO_ERR_UNSUPPORTED, "rnn size %d does not fit the BiGRU backward kernel", H);
     const size_t lds = ((size_t)4 * R * H + (size_t)RP_NT * R * 4 + 64) * sizeof(float);

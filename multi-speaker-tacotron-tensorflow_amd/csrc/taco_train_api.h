@@ -63,6 +63,60 @@ int taco_train_set_deterministic(taco_train* t, int on) {
   t->deterministic = on ? 1 : 0;      // changes taco_train_workspace_bytes
   return 0;
 }
+// Test hook: the post-net BiGRU scan alone, forward with the gate tape and backward, on caller data -- ragged lengths and initial
+// states included, which the post-net itself never has.  persistent = 1: k_bigru_duo<RG, true> + k_bigru_duo_bwd (needs H = 256 on a
+// whole MI355X); 0: k_bigru_res<..., true> + k_bigru_rows_bwd.  All buffers device, caller-owned:
+//   xproj [B*T, 6H] (the hoisted input projection, backward direction time-reversed per row), lengths [B] or null, h0 [B, 2H] or null,
+//   dout [B*T, 2H]  ->  out [B*T, 2H], gsave [B*T, 6H], dg [B*T, 6H], rh [B*T, 2H], dh0 [B, 2H] (nullable); scratch: >= 1 MB.
+int taco_train_debug_bigru(taco_train* t, void* hip_stream, const float* xproj, const int32_t* lengths, const float* h0, const float* dout,
+                           int B, int T, int persistent, float* out, float* gsave, float* dg, float* rh, float* dh0, void* scratch, size_t scratch_bytes) {
+  if (!t || !xproj || !dout || !out || !gsave || !dg || !rh || !scratch) return fail(TACO_ERR_ARG, "null argument");
+  const taco_model* m = t->sm; const Cbhg& c = m->post; const int H = c.rnn;
+  hipStream_t st = (hipStream_t)hip_stream;
+  HIPCHK(hipSetDevice(m->device));
+  const size_t need = std::max(gd_xbuf_granules(8), gb_xbuf_granules(8)) * sizeof(unsigned long long) + 512;
+  if (scratch_bytes < need) return fail(TACO_ERR_STATE, "scratch too small: need %zu bytes", need);
+  unsigned long long* gxbuf = (unsigned long long*)scratch; unsigned* gxctl = (unsigned*)((char*)scratch + need - 256);
+  const size_t M = (size_t)B * T;
+  HIPCHK(zero_async(gsave, M * 6 * H * sizeof(float), st));
+  HIPCHK(zero_async(dg, M * 6 * H * sizeof(float), st));
+  HIPCHK(zero_async(rh, M * 2 * H * sizeof(float), st));
+  if (persistent) {
+    if (!duo_usable(m, c, B, T) || !c.gb_pack) return fail(TACO_ERR_UNSUPPORTED, "the whole-chip scans need H = 256, at most 64 rows and an unpartitioned MI355X");
+    TRY(duo_launch(m, st, c, B, T, xproj, lengths, h0, out, gsave, gxbuf, gxctl));
+    GbArgs a; memset(&a, 0, sizeof a);
+    a.wpack = AP(m, c.gb_pack); a.dout = dout; a.out = out; a.gsave = gsave; a.h0 = h0; a.lengths = lengths; a.dg = dg; a.rh = rh; a.dh0 = dh0;
+    a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+    int RG = 1;
+    while (RG * DX_NGROUP < B) RG *= 2;
+    HIPCHK(zero_async(gxbuf, need - 256 + 256, st));
+    const size_t lds = std::max(gb_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);
+    const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo_bwd<1>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo_bwd<2>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo_bwd<4>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo_bwd<8>), grid, blk, lds, st, a); break;
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if (H != 256) return fail(TACO_ERR_UNSUPPORTED, "post-net rnn size %d", H);
+  { BigruSArgs a; memset(&a, 0, sizeof a);
+    a.xproj = xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
+    a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.lengths = lengths; a.out = out; a.gsave = gsave; a.B = B; a.T = T; a.h0 = h0;
+    hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(256, 24, 1), st, a); }
+  { const CbhgT& ct = t->tp.post;
+    const int R = (B >= 2) ? 2 : 1;
+    const size_t lds = ((size_t)4 * R * H + (size_t)RP_NT * R * 4 + 64) * sizeof(float);
+    BigruBArgs a; memset(&a, 0, sizeof a);
+    a.dout = dout; a.out = out; a.gsave = gsave; a.wgT0 = AP(m, ct.ghT[0]); a.wgT1 = AP(m, ct.ghT[1]); a.wcT0 = AP(m, ct.chT[0]); a.wcT1 = AP(m, ct.chT[1]);
+    a.lengths = lengths; a.dg = dg; a.rh = rh; a.B = B; a.T = T; a.H = H; a.h0 = h0; a.dh0 = dh0;
+    if (R == 2) hipLaunchKernelGGL(k_bigru_rows_bwd<2>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a);
+    else hipLaunchKernelGGL(k_bigru_rows_bwd<1>, dim3(2 * cdiv(B, R)), dim3(RP_NT), lds, st, a); }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 size_t taco_train_num_params(const taco_train* t) { return t ? t->NP : 0; }
 
 int taco_train_param_offset(const taco_train* t, const char* name, size_t* offset) {

@@ -555,3 +555,75 @@ def test_C4_horizon_gradients_on_a_two_row_slice():
     assert abs(float(losses[0]) - loss) < 1e-4
     worst, gn = _grad_report(tr.grad_dict(), g)
     assert worst[0][0] < 2e-3, worst[:5]
+
+
+@pytest.mark.parametrize("B,T", [(5, 37), (32, 48), (40, 21), (1, 19)])
+def test_whole_chip_bigru_scans_forward_tape_and_backward(B, T):
+    """k_bigru_duo<RG, true> (gate tape) + k_bigru_duo_bwd (BPTT through TF's GRUCell, A.6/A.7) against the kernels they replace in
+    training (k_bigru_res + k_bigru_rows_bwd) and against float64 autograd of the recurrence itself, with what the post-net never
+    has but the kernels support: ragged lengths (0 and T included) and initial states, rows per group 1 / 2 / 4 / 8."""
+    import ctypes as C
+    import torch
+    import taco_amd
+    from util import dev, ptr, stream
+    hp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(hp, 1, 91)
+    tr = _trainer(hp, w)
+    H = hp.post_rnn_size
+    rs = np.random.RandomState(92 + B)
+    xproj = (rs.randn(B, T, 6 * H) * 0.4).astype(np.float32)
+    lens = rs.randint(0, T + 1, size=B).astype(np.int32); lens[0] = T
+    if B > 1:
+        lens[1] = 0
+    h0 = (rs.randn(B, 2 * H) * 0.5).astype(np.float32)
+    dout = rs.randn(B, T, 2 * H).astype(np.float32)
+    xd, ld, hd, dd = dev(xproj), dev(lens), dev(h0), dev(dout)
+    scratch = torch.empty((2 << 20,), dtype=torch.uint8, device="cuda")
+    res = {}
+    for eng in (1, 0):
+        o = {k: torch.full(s, float("nan"), device="cuda") for k, s in (("out", (B, T, 2 * H)), ("gsave", (B, T, 6 * H)), ("dg", (B, T, 6 * H)),
+                                                                        ("rh", (B, T, 2 * H)), ("dh0", (B, 2 * H)))}
+        taco_amd._lib.check(tr._lib.taco_train_debug_bigru(tr._h, stream(), ptr(xd), ptr(ld), ptr(hd), ptr(dd), B, T, eng, ptr(o["out"]), ptr(o["gsave"]),
+                                                           ptr(o["dg"]), ptr(o["rh"]), ptr(o["dh0"]), ptr(scratch), scratch.numel()))
+        torch.cuda.synchronize()
+        tr.check_device_errors()
+        res[eng] = {k: v.cpu().numpy() for k, v in o.items()}
+    for k in ("out", "gsave", "dg", "rh", "dh0"):
+        assert np.isfinite(res[1][k]).all(), k
+        assert maxabs(res[1][k], res[0][k]) < 2e-5 * max(1.0, float(np.abs(res[0][k]).max())), k
+    # float64 autograd of the recurrence (gates r|u, candidate; h' = u h + (1-u) c; A.7 masking and reverse_sequence time mapping)
+    tw = {k: torch.tensor(np.asarray(v, np.float64)) for k, v in w.items() if k.startswith("post_cbhg/bigru/")}
+    xp = torch.tensor(xproj.astype(np.float64), requires_grad=True)
+    h0t = torch.tensor(h0.astype(np.float64), requires_grad=True)
+    outs = torch.zeros(B, T, 2 * H, dtype=torch.float64)
+    pieces = []
+    for d, name in enumerate(("fw", "bw")):
+        Wg = tw["post_cbhg/bigru/%s/gates/kernel" % name][H:]; Wc = tw["post_cbhg/bigru/%s/candidate/kernel" % name][H:]
+        for b in range(B):
+            h = h0t[b, d * H:(d + 1) * H]
+            L = int(lens[b])
+            for s in range(L):
+                t = (L - 1 - s) if d else s
+                xg = xp[b, s, d * 3 * H:d * 3 * H + 2 * H] if d else xp[b, t, :2 * H]       # the backward columns are stored time-reversed: row s
+                xc = xp[b, s, d * 3 * H + 2 * H:(d + 1) * 3 * H] if d else xp[b, t, 2 * H:3 * H]
+                g = torch.sigmoid(xg + h @ Wg)
+                r, u = g[:H], g[H:]
+                c = torch.tanh(xc + (r * h) @ Wc)
+                h = u * h + (1 - u) * c
+                pieces.append((b, t, d, h))
+    loss = sum((hh * torch.tensor(dout[b, t, d * H:(d + 1) * H].astype(np.float64))).sum() for b, t, d, hh in pieces)
+    loss.backward()
+    for b, t, d, hh in pieces:
+        outs[b, t, d * H:(d + 1) * H] = hh.detach()
+    assert maxabs(res[1]["out"], outs.numpy()) < 2e-5
+    assert maxabs(res[1]["dh0"], h0t.grad.numpy()) < 2e-4 * max(1.0, float(h0t.grad.abs().max()))
+    # dg is the gradient of the pre-activations = of the hoisted projection; the kernel writes it at TRUE time, the projection's
+    # backward columns live at scan time: map them back for the comparison
+    want = np.zeros((B, T, 6 * H))
+    gx = xp.grad.numpy()
+    for b in range(B):
+        L = int(lens[b])
+        want[b, :L, :3 * H] = gx[b, :L, :3 * H]
+        want[b, :L, 3 * H:] = gx[b, :L, 3 * H:][::-1]
+    assert maxabs(res[1]["dg"], want) < 2e-4 * max(1.0, float(np.abs(want).max()))
+    tr.close()

@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
-PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_pointwise_chain")
+PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_pointwise_chain")  # k_bigru_duo also matches k_bigru_duo_bwd
 ALLOWED_SCRATCH = {"_Z13k_decoder_xcdILi8ELb0EEv6DxArgs": 168, "_Z13k_decoder_xcdILi8ELb1EEv6DxArgs": 204}        # bytes per lane (round 2: 144; +24 with the manual-attention / per-row-bias paths)
 
 
