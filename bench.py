@@ -23,11 +23,14 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
-# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, tools/time_decoder.py, tools/trace_bigru.py;
-# shader clock ~2.16 GHz) and of the matrix pipe (tools/ubench_mfma: 2.08 PFLOP/s bf16 dense): what `roofline.latency_floor_ms` is built from.
+# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, profiles/r03_scan_timeline.txt,
+# tools/time_decoder.py, tools/trace_bigru.py; shader clock ~2.16 GHz) and of the matrix pipe (tools/ubench_mfma: 2.08 PFLOP/s bf16
+# dense): what `roofline.latency_floor_ms` is built from.
 HOP_US = 0.5                 # one exchange through the XCD's L2: publish -> every consumer has gathered it (0.44-0.58 measured)
 DEC_HOPS, DEC_CHAIN_US = 10, 6.5    # per decoder step: exchanges, and the dependent instruction chains between them (11.7 - 10 x 0.5, rounded down)
-SCAN_HOPS, SCAN_CHAIN_US = 2, 1.2   # per post-net scan step (2.3 us timeline: 42 % hops, the rest chains + barriers)
+# per post-net scan step of k_bigru_duo (4668 clocks): the two directions hide each other's exchanges; what is left is four
+# compute phases (800 + 804 + 692 + 740 clocks) and four collect + barrier points (368 + 328 + 308 + 256)
+SCAN_PHASES_US, SCAN_SYNC_US = 1.40, 0.58
 ENC_SCAN_STEP_US = 0.93             # encoder scan (k_bigru_res, one CU per chain, no exchange)
 MFMA_BF16_MEASURED_TF = 2080.0      # tools/ubench_mfma on this part; a 3-term split product costs three bf16 MFMAs
 
@@ -485,20 +488,21 @@ def main():
         T_mel = n * r
         terms = {
             "decoder_hops": n * DEC_HOPS * HOP_US * 1e-3, "decoder_chains": n * DEC_CHAIN_US * 1e-3,
-            "postnet_scan_hops": T_mel * SCAN_HOPS * HOP_US * 1e-3, "postnet_scan_chains": T_mel * SCAN_CHAIN_US * 1e-3,
+            "postnet_scan_phases": T_mel * SCAN_PHASES_US * 1e-3, "postnet_scan_collects_and_barriers": T_mel * SCAN_SYNC_US * 1e-3,
             "encoder_scan": T_in * ENC_SCAN_STEP_US * 1e-3,
             "feed_forward_at_measured_mfma_ceiling": 3 * ff_flops / (MFMA_BF16_MEASURED_TF * 1e12) * 1e3,
         }
         floor = {"total": sum(terms.values()), "terms": terms, "measured_forward_ms": fwd_s * 1e3,
                  "frac_of_floor": sum(terms.values()) / (fwd_s * 1e3),
                  "note": "one forward in flight; hop = %.2f us (one exchange through the XCD's L2), chains = dependent VALU/DPP work between "
-                         "exchanges (profiles/r02_decoder_timeline.txt); 0.30 of the HBM streaming roofline would need %.2f ms per forward"
+                         "exchanges (profiles/r02_decoder_timeline.txt); the post-net scan hides its exchanges behind the other direction's "
+                         "phases (k_bigru_duo, profiles/r03_scan_timeline.txt); 0.30 of the HBM streaming roofline would need %.2f ms per forward"
                          % (HOP_US, abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3); recurrent / decoder mat-vecs exact fp32",
+            "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3), the attention memory layer on exact-fp32 MFMA; recurrent / decoder mat-vecs exact fp32",
             "data": "synthetic", "world_size_seen": world,
             "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
                                    % (args.workload, B, T_in, n * r, r, mt),

@@ -618,9 +618,20 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     }
     bl[tid] = v;
   }
-  for (int i = tid; i < DXRB_N * RG * DX_NW; i += DX_NT) {      // rbl[slot][row][wave]
-    const int e = i / (RG * DX_NW), r = (i / DX_NW) % RG, w = i % DX_NW, b = row0 + r;
-    rbl[i] = (a.rowbias && b < a.B) ? a.rowbias[((size_t)b * DXRB_N + e) * DX_W + member * 8 + w] : 0.f;
+  for (int i = tid; i < DXRB_N * RG * DX_NW; i += DX_NT) {      // rbl[slot][row][wave] = the column's bias + the row's speaker term: ONE read per epilogue
+    const int e = i / (RG * DX_NW), r = (i / DX_NW) % RG, w = i % DX_NW, b = row0 + r, n8 = member * 8 + w;
+    float v = 0.f;
+    switch (e) {
+      case DXRB_AR: v = a.b_ag[n8]; break;
+      case DXRB_AU: v = a.b_ag[DX_W + n8]; break;
+      case DXRB_AX: v = 0.f; break;                       // (the candidate's bias is added with its h part)
+      case DXRB_G1R: v = a.b_g1f[n8]; break;
+      case DXRB_G1U: v = a.b_g1f[DX_W + n8]; break;
+      case DXRB_G1X: v = a.b_g1f[2 * DX_W + n8]; break;
+      default: v = a.b_g1f[3 * DX_W + n8]; break;         // DXRB_O0
+    }
+    if (a.rowbias && b < a.B) v += a.rowbias[((size_t)b * DXRB_N + e) * DX_W + n8];
+    rbl[i] = v;
   }
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
   const bool man = a.manual != nullptr;
@@ -706,8 +717,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       dx_reduce<3, RG>(aga, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_AR * DX_NW + wave] + DX_RB(DXRB_AR, q));
-        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_AU * DX_NW + wave] + DX_RB(DXRB_AU, q));
+        const float rg = dx_sigmoid_fast(s[0][q] + DX_RB(DXRB_AR, q));
+        g_u[q] = dx_sigmoid_fast(s[1][q] + DX_RB(DXRB_AU, q));
         g_cx[q] = s[2][q] + DX_RB(DXRB_AX, q);
         if (epl) dx_publish(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
         DX_TAPE(DXT_RA, q, rg); DX_TAPE(DXT_UA, q, g_u[q]); DX_TAPE(DXT_RHA, q, rg * g_h[q]);
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     dx_zero<4, RG>(g1a);
     dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
     dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
-    const float* al = sc;          // the step's alignments: computed (sc) or manual (mrow)
+    int aoff = 0;                  // the step's alignments are sc[aoff + j]: computed (sc itself) or manual (mrow, a region of the same LDS array)
     if (!man) {
       {  // gather the row's partial scores and sum them over the Pc channel blocks (fixed order)
         const int jl = lane >> 2, part = lane & 3;
@@ -815,19 +826,19 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       // the row requested at the top of the step: every wave makes sure its own part has landed, the barrier publishes all parts
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      al = mrow;
+      aoff = (int)(mrow - sc);
     }
     {  // alignment state + history (tacotron.py:238-239 layout) for the member's block of positions; context channel block
-      for (int j = tid; j < T; j += DX_NT) alp[j] = al[j];
+      for (int j = tid; j < T; j += DX_NT) alp[j] = sc[aoff + j];
       const int p0 = asl * TP;
       if (tid < TP && p0 + tid < T && brow < a.B) {
-        if (a.hist) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = al[p0 + tid];
-        if (TAPE && a.tp_alpha) a.tp_alpha[((size_t)brow * (a.n + 1) + t + 1) * T + p0 + tid] = al[p0 + tid];
+        if (a.hist) a.hist[((size_t)brow * T + p0 + tid) * a.n + t] = sc[aoff + p0 + tid];
+        if (TAPE && a.tp_alpha) a.tp_alpha[((size_t)brow * (a.n + 1) + t + 1) * T + p0 + tid] = sc[aoff + p0 + tid];
       }
       constexpr int JL = 64 / DC;                    // positions handled side by side inside a wave
       const int d = lane % DC, jsub = lane / DC;
       float part = 0.f;
-      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(al[j], Vc[(size_t)j * DC + d], part);
+      for (int j = wave * JL + jsub; j < T; j += DX_NW * JL) part = fmaf(sc[aoff + j], Vc[(size_t)j * DC + d], part);
       if (DC <= 32) part = dx_xrow32(part);
       if (DC <= 16) part = dx_xrow16(part);
       if (DC <= 8) part += DX_DPP0(part, 0x128);
@@ -852,10 +863,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       DX_STAMP(12);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G1R * DX_NW + wave] + DX_RB(DXRB_G1R, q));
-        g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G1U * DX_NW + wave] + DX_RB(DXRB_G1U, q));
-        g_cx[q] = s[2][q] + bl[DXB_G1X * DX_NW + wave] + DX_RB(DXRB_G1X, q);
-        g_o0[q] = s[3][q] + bl[DXB_O0 * DX_NW + wave] + DX_RB(DXRB_O0, q);
+        const float rg = dx_sigmoid_fast(s[0][q] + DX_RB(DXRB_G1R, q));
+        g_u[q] = dx_sigmoid_fast(s[1][q] + DX_RB(DXRB_G1U, q));
+        g_cx[q] = s[2][q] + DX_RB(DXRB_G1X, q);
+        g_o0[q] = s[3][q] + DX_RB(DXRB_O0, q);
         if (epl) dx_publish(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
         DX_TAPE(DXT_R1, q, rg); DX_TAPE(DXT_U1, q, g_u[q]); DX_TAPE(DXT_RH1, q, rg * g_h[q]); DX_TAPE(DXT_O0, q, g_o0[q]);
       }

@@ -17,6 +17,9 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
     ap.add_argument("--gpus", type=int, default=1, help="N > 1: this script launches its own N ranks (torch.distributed.run, RCCL, 127.0.0.1)")
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
+    ap.add_argument("--engine", type=int, default=1, help="1: persistent whole-chip kernels for the teacher-forced decoder loop and the post-net scans (default); 0: one launch per stage (rounds 1-2)")
+    ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
+    ap.add_argument("--deterministic", type=int, default=0, help="1: ordered two-stage sums instead of fp32 atomics (reproducible steps)")
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
                                                            "0: per-rank statistics.  No effect on one GPU")
     args = ap.parse_args()
@@ -49,6 +52,12 @@ def main():
     hp = taco_amd.hparams.copy(max_iters=max(200, args.t_out // 4))
     tr = taco_amd.Trainer(hp, taco_amd.weights.random_weights(hp, 1, seed=4321), device=str(dev))
     sync_bn = bool(args.sync_bn) and tr.enable_sync_bn(True)
+    if args.engine != 1:
+        tr.set_decoder_engine(args.engine)
+    if args.exact_wgrad:
+        tr.set_exact_wgrad(True)
+    if args.deterministic:
+        tr.set_deterministic(True)
     rs = np.random.RandomState(77 + rank)
     B, T_in, T_out = args.batch, args.t_in, args.t_out
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32); ids[:, -1] = 1
@@ -85,6 +94,9 @@ def main():
         allreduce_gradients(tr.grads)
     a1.record(); torch.cuda.synchronize()
     allreduce_ms = a0.elapsed_time(a1) / 5
+    tr.check_device_errors()
+    per_rank = D.gather_floats(e0.elapsed_time(e1) / args.steps, device=dev if dist is not None else "cpu")
+    engine = tr.decoder_engine_info()
     if rank == 0:
         print(json.dumps({
             "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
@@ -96,6 +108,10 @@ def main():
             "phase_ms": {"forward_only": ev[0].elapsed_time(ev[1]), "forward_plus_backward": ev[1].elapsed_time(ev[2]),
                          "adam_plus_refresh": ev[2].elapsed_time(ev[3]),
                          "gradient_allreduce": allreduce_ms if world > 1 else 0.0},
+            "per_rank_ms_per_step": per_rank,
+            "engine": {"decoder_loop_and_postnet_scans": "persistent whole-chip kernels with tape (protocol %d)" % engine["protocol"] if args.engine and engine["protocol"] else "one launch per stage",
+                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
+                       "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
             "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9}))
     if dist is not None:
