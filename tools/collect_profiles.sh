@@ -10,6 +10,13 @@ for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
+# round 3: scan timelines (k_bigru_duo vs k_bigru_xcd), manual / simple decoder modes, feed-forward-under-the-scan experiment, training kernel statistics
+{ for p in 1 8; do python tools/trace_bigru.py 32 512 $p; python tools/trace_bigru.py 64 512 $p; python tools/trace_bigru.py 8 4000 $p; done; } 2>&1 | grep -v amdgpu.ids > $out/scan_timeline.txt
+timeout 300 python tools/time_manual.py 2>&1 | grep -v amdgpu.ids > $out/time_manual.txt
+timeout 300 python tools/overlap_scan_ff.py 2>&1 | grep -v amdgpu.ids > $out/overlap_scan_ff.txt
+timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $out/time_stages.txt
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/tks -o tks --output-format csv -- python tools/bench_train.py --steps 4 --warmup 1 > $out/tks.log 2>&1
+cp $out/tks/*kernel_stats.csv $out/train_kernel_stats.csv 2>/dev/null; rm -rf $out/tks
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_f.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_w.log 2>&1
