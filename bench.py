@@ -234,6 +234,8 @@ def main():
                     help="requests served per forward (PlanPool coalesce): c > 1 rides c batches of the workload's B rows through one "
                          "plan of c*B rows; a step is still one batch of B rows.  Default 1 = the BASELINE.json configuration as is")
     ap.add_argument("--no-companions", action="store_true", help="skip the lanes=1 and exact-fp32 companion measurements")
+    ap.add_argument("--no-stage-timing", action="store_true",
+                    help="skip the per-stage timings (roofline.stages): counter passes must see nothing but whole forwards, or their per-forward figures count the extra stage runs")
     ap.add_argument("--decoder-engine", type=int, default=1, help="1 persistent XCD-local decoder (default), 0 launch per stage, 2 persistent write-through")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU test hook: run only the launcher / rendezvous / max-over-ranks path on gloo and print the world size")
@@ -364,7 +366,7 @@ def main():
     latency_ms = lat0.elapsed_time(lat1) / 3
     # the three stages of the path one by one (stage-level C ABI, eager launches, nothing else in flight), HIP events on their stream
     stage_ms = {}
-    if rank == 0:
+    if rank == 0 and not args.no_stage_timing:
         p0 = pool.plans[0]
         spk0 = p0.speaker_id if ns > 1 else None
         with torch.cuda.stream(pool.streams[0]):
@@ -470,7 +472,7 @@ def main():
         fwd_s = dev_ms / 1e3 / args.steps      # device time per forward (HIP events over the timed region / forwards in it)
         ffs = feedforward_flops_by_stage(hp, B, T_in, n)
         stages = {}
-        for k in ("encoder", "decoder", "postnet"):
+        for k in (("encoder", "decoder", "postnet") if stage_ms else ()):
             e = {"ms_alone_eager": stage_ms[k], "algorithmic_GB": sb[k] / 1e9, "achieved_GBps": sb[k] / (stage_ms[k] * 1e-3) / 1e9,
                  "frac": sb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if k == "decoder":

@@ -89,21 +89,26 @@ __global__ void k_bn_mean(const float* S1, float* mu, int C, float invM) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < C) mu[c] = S1[c] * invM;
 }
-// SyncBN, one exchange per layer: every rank contributes (its mean m_r, its centred sum of squares S_r, m_r^2); after the sum over
-// the W ranks (equal row counts M per rank)  mu = sum m_r / W  and  sum (a - mu)^2 over all rows = sum S_r + M (sum m_r^2 - W mu^2)
-// (Chan's pairwise update; the cancellation in the bracket is over the spread of the rank means, not over the data).
-__global__ void k_bn_sync_pack(const float* mu_local, const float* S_local, float* pack, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float m = mu_local[c];
-  pack[c] = m; pack[C + c] = S_local[c]; pack[2 * C + c] = m * m;
+// SyncBN, one exchange per layer: every rank contributes (d_r = its mean - ref, its centred sum of squares S_r, d_r^2); after the sum
+// over the W ranks (equal row counts M per rank: Trainer checks it)  mu = ref + sum d_r / W  and
+// sum (a - mu)^2 over all rows = sum S_r + M (sum d_r^2 - W dbar^2)   (Chan's pairwise update).
+// `ref` is the layer's moving mean -- the same number on every rank, and close to the batch means once training is under way -- so
+// the cancellation in the bracket is over the small offsets d_r, not over the means themselves (with ref = 0 the
+// bracket lost precision when |mean| was much larger than the spread of the rank means).
+__global__ void k_bn_sync_pack(const float* mu_local, const float* S_local, const float* ref, float* pack, int C, int c0, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = c0 + i;
+  const float d = mu_local[c] - ref[i];
+  pack[c] = d; pack[C + c] = S_local[c]; pack[2 * C + c] = d * d;
 }
-__global__ void k_bn_sync_combine(const float* pack, float* mu, float* S2, int C, float M, float W) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float m = pack[c] / W;
-  mu[c] = m;
-  S2[c] = pack[C + c] + M * fmaxf(pack[2 * C + c] - W * m * m, 0.f);
+__global__ void k_bn_sync_combine(const float* pack, const float* ref, float* mu, float* S2, int C, int c0, int n, float M, float W) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = c0 + i;
+  const float dbar = pack[c] / W;
+  mu[c] = ref[i] + dbar;
+  S2[c] = pack[C + c] + M * fmaxf(pack[2 * C + c] - W * dbar * dbar, 0.f);
 }
 __global__ void k_bn_finalize(const float* mu, const float* S2, float* rstd, float* mov_mean, float* mov_var, int C,
                               float invM, float eps, float momentum) {

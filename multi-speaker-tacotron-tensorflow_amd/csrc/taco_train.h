@@ -379,10 +379,14 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
   TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1));
   if (sync) {
     // ONE exchange per layer (the layer's columns, or all widths of a conv bank at once): rank means, centred sums, squared means
+    // (means are exchanged as offsets from the layer's moving mean, which every rank holds identically: k_bn_sync_pack)
     float* pack = scratch + 2 * C;
-    hipLaunchKernelGGL(k_bn_sync_pack, EWGRID(C), 0, st, mu, scratch + C, pack, C);
+    for (int i = 0, c0 = 0; i < nnames; c0 += cols[i], ++i)
+      hipLaunchKernelGGL(k_bn_sync_pack, EWGRID(cols[i]), 0, st, mu, scratch + C, (const float*)x.p(names[i] + "/moving_mean"), pack, C, c0, cols[i]);
     x.t->sync_fn(x.t->sync_user, pack, 3 * C);
-    hipLaunchKernelGGL(k_bn_sync_combine, EWGRID(C), 0, st, pack, mu, scratch + C, C, (float)M, (float)x.t->sync_world);
+    for (int i = 0, c0 = 0; i < nnames; c0 += cols[i], ++i)
+      hipLaunchKernelGGL(k_bn_sync_combine, EWGRID(cols[i]), 0, st, pack, (const float*)x.p(names[i] + "/moving_mean"), mu, scratch + C, C, c0, cols[i],
+                         (float)M, (float)x.t->sync_world);
   }
   int c0 = 0;
   for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix

@@ -17,10 +17,10 @@ timeout 300 python tools/overlap_scan_ff.py 2>&1 | grep -v amdgpu.ids > $out/ove
 timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $out/time_stages.txt
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/tks -o tks --output-format csv -- python tools/bench_train.py --steps 4 --warmup 1 > $out/tks.log 2>&1
 cp $out/tks/*kernel_stats.csv $out/train_kernel_stats.csv 2>/dev/null; rm -rf $out/tks
-timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_f.log 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_w.log 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $out/pmc_sq -o sq --output-format csv -- python bench.py --no-cpu-baseline --no-companions --steps 3 --warmup 0 --lanes 1 > $out/pmc_sq.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 3 --warmup 0 --lanes 1 > $out/pmc_f.log 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 3 --warmup 0 --lanes 1 > $out/pmc_w.log 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $out/pmc_sq -o sq --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 3 --warmup 0 --lanes 1 > $out/pmc_sq.log 2>&1
 python tools/pmc_traffic.py $out/pmc_f $out/pmc_w $out/pmc_hbm_traffic > $out/pmc_traffic.log 2>&1
 python tools/pmc_sq.py $out/pmc_sq $out/pmc_sq.txt > /dev/null 2>&1
 cp $out/ks/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
