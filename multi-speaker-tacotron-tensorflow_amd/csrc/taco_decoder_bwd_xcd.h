@@ -1,0 +1,563 @@
+// taco_decoder_bwd_xcd.h -- back-propagation through the whole teacher-forced decoder loop (train.py:215-219 -> tf.gradients of
+// rnn_wrappers.py:218-341,367-415, tacotron.py:166-181, helpers.py:35-67) as ONE persistent launch: the mirror of k_decoder_xcd.
+//
+// The launch-per-stage backward is a chain of ~19 dependent launches per decoder step (transposed mat-vecs of k_skinny, the GRU
+// element-wise kernels, k_attention_bwd): 11.9 ms of a 29.5 ms training step at the C4 shard.  Here the step never leaves the chip:
+// same placement (one XCD = one group of 32 members = RG batch rows), same exchange (8-byte {value, tag} granules through the XCD's
+// L2), same pass / reduce / epilogue / publish / gather stages as the forward kernel, with the TRANSPOSED products of BPTT:
+// member m owns column 8m + w of every 256-wide gradient vector, wave w of it keeps the matching ROW of every kernel (its 4-input
+// slice per lane) in VGPRs for the whole launch.  What a step reads from the tape at the owner's (row, column) -- gates,
+// candidates, previous states, prenet outputs -- is loaded one step ahead into registers; the rows it needs whole (dmel, raw scores,
+// alignments) arrive one step ahead straight in LDS.  The state gradients dh2, dh1, dh_att and d ctx never leave the lane that
+// owns their column; d alpha (the monotonic recurrence's carry) lives in LDS on every member of its row.
+//
+// Per step t = n-1 .. 0 (twelve exchanges):
+//   do2 = dmel_t . Wf^T | GRU 2: d c_pre -> X | d(r*h), d x from Wc^T, gate gradients -> X | d x, dh2 from Wg^T; residual; GRU 1 the same
+//   (2 X) | d o0 -> X | concat projection^T: d h_att, d ctx -> X | attention: d alpha partials over the value-channel blocks -> X |
+//   normaliser backward (softmax, or the monotonic recurrence with both clips) -> d e; d q partials -> X | d h_att += d q . Wq^T;
+//   attention GRU (2 X) -> d p2 -> X | prenet layer 2^T, ReLU mask -> d p1 -> X | prenet layer 1 (context rows)^T -> d ctx(t-1).
+// Outputs: the pre-activation gradient tapes the hoisted weight-gradient GEMMs read (decoder_backward in taco_train.h), g_de / g_dq /
+// g_dctx for the hoisted key / value gradients, and the gradients of the initial states.
+#pragma once
+#include "taco_decoder_xcd.h"
+#include "taco_backward_kernels.h"
+
+// register map (per thread; host mirror: dbx_build_pack in taco_lib.hip).  A 256-input row = 4 registers (inputs 4l..4l+3), a 512-input
+// row = 8 (two halves), Wf's 320-input row = 4 + 1 (input 256 + l), a 128-input row = 2.
+enum {
+  DBR_F = 0,      // frame projection row en (K = rM <= 320)                                   5
+  DBR_C2X = 5,    // GRU 2 candidate kernel, x row en / h row en (K = 256 each)                4 + 4
+  DBR_C2H = 9,
+  DBR_G2X = 13,   // GRU 2 gates kernel, x row en / h row en (K = 512)                         8 + 8
+  DBR_G2H = 21,
+  DBR_C1X = 29, DBR_C1H = 33, DBR_G1X = 37, DBR_G1H = 45,                                    // GRU 1, the same
+  DBR_CCA = 53,   // concat projection, h_att row en / context row en (K = 256)                4 + 4
+  DBR_CCC = 57,
+  DBR_Q = 61,     // query layer row en (K = 256)                                              4
+  DBR_CAX = 65,   // attention GRU candidate, x row 4m + w (waves 0-3; K = 256) / h row en     4 + 4
+  DBR_CAH = 69,
+  DBR_GAX = 73,   // attention GRU gates, x row 4m + w (waves 0-3; K = 512) / h row en         8 + 8
+  DBR_GAH = 81,
+  DBR_P2 = 89,    // prenet layer 2 row en (K = 128)                                           2
+  DBR_P1C = 91,   // prenet layer 1, context row en (K = 256)                                  4
+  DB_NREG = 95
+};
+// per-row gradient vectors in LDS (floats): every gathered vector is read by the stage right behind its gather only, and a
+// barrier separates that stage from the gather after the next one, so two alternating 512-float buffers per row hold them all
+enum { DBS_DCP2 = 0, DBS_DGP2 = 512, DBS_DCP1 = 0, DBS_DGP1 = 512, DBS_DO0 = 0, DBS_DCTX = 512, DBS_DQ = 0, DBS_DCPA = 512, DBS_DGPA = 0,
+       DBS_DZ2 = 512, DBS_DZ1 = 0, DBS_LD = 1024 };
+struct DbX { int dcp2, dgp2, dcp1, dgp1, do0, dctx, da, dq, dcpa, dgpa, dz2, dz1, total; };
+__host__ __device__ inline DbX db_xlayout(int RG, int T_in) {
+  const int Pr = DX_GROUP / RG, Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc;
+  DbX x; int o = 0;
+  x.dcp2 = o; o += RG * 256; x.dgp2 = o; o += RG * 512; x.dcp1 = o; o += RG * 256; x.dgp1 = o; o += RG * 512;
+  x.do0 = o; o += RG * 256; x.dctx = o; o += RG * 256;
+  x.da = o; o += DX_GROUP * T_in;                  // [row][member of the row][position]
+  x.dq = o; o += RG * Pp * 256;                    // [row][position block][channel]
+  x.dcpa = o; o += RG * 256; x.dgpa = o; o += RG * 512; x.dz2 = o; o += RG * 128; x.dz1 = o; o += RG * 256;
+  x.total = o;
+  return x;
+}
+__host__ __device__ inline size_t db_lds_floats(int RG, int T_in) {
+  const int Pr = DX_GROUP / RG, DC = DX_W / Pr, Tpad = (T_in + 63) & ~63;
+  const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
+  size_t n = (size_t)RG * DBS_LD;
+  n += 2 * (size_t)RG * 384;                       // dmel rows, double buffered (LDS-direct, one step ahead)
+  n += (size_t)TS * DS + (size_t)T_in * DC;        // keys block, values block
+  n += 2 * 3 * (size_t)Tpad;                       // raw scores, alignments of the step and of the step before, double buffered
+  n += 6 * (size_t)Tpad;                           // da, p, cp, ss, de, d alpha carry
+  n += 3 * 64 + (size_t)DX_NW * 64 + 64;           // q + b, v, scratch; reduction partials; control words
+  return n;
+}
+
+struct DbArgs {
+  const float* wpack;                                  // [32 members][DB_NREG][DX_NT]
+  const float* tape; size_t tstride;                   // the forward's 256-wide per-step arrays (DXT_* slots)
+  const float* tp_p2; int ld_p2;                       // prenet output [B, n, ld_p2]
+  const float* tp_e; const float* tp_alpha;            // raw scores [B, n, T_in]; alignments [B, n + 1, T_in]
+  const float* keys; const float* values;              // [B, T_in, 256]
+  const float* att_v; const float* att_b; const float* score_bias;
+  const float* dmel;                                   // [B, n, rM]
+  const float* h_att0; const float* h10; const float* h20;   // initial states [B, 256] or null
+  float* g_dcp2; float* g_dgp2; float* g_dcp1; float* g_dgp1; float* g_do0; float* g_dcpA; float* g_dgpA;   // [R, 256] / [R, 512]
+  float* g_dz1; float* g_dz2; float* g_dq; float* g_de; float* g_dctx;                                     // [R, 256], [R, 128], [R, 256], [R, T_in], [R, 256]
+  float* d_att_init; float* d_h10; float* d_h20;       // [B, 256] or null
+  float* dsb_acc;                                      // [B] or null: d attention_score_bias per row (summed by the host)
+  unsigned long long* xbuf; unsigned* ctl; unsigned* err;
+  int B, T_in, n, rM, att_type, force_wt;
+};
+
+// K = 512 pass: two 256-halves of the same LD-strided row
+template <int REG0, int NCOLS, int RG, int NW, int LD>
+__device__ __forceinline__ void db_pass512(const float (&W)[NW], const float* x, int lane, float (&acc)[NCOLS][RG]) {
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float4 a = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
+    const float4 b = *reinterpret_cast<const float4*>(x + r * LD + 256 + 4 * lane);
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) {
+      acc[c][r] = fmaf(W[REG0 + 8 * c + 0], a.x, acc[c][r]); acc[c][r] = fmaf(W[REG0 + 8 * c + 1], a.y, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 8 * c + 2], a.z, acc[c][r]); acc[c][r] = fmaf(W[REG0 + 8 * c + 3], a.w, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 8 * c + 4], b.x, acc[c][r]); acc[c][r] = fmaf(W[REG0 + 8 * c + 5], b.y, acc[c][r]);
+      acc[c][r] = fmaf(W[REG0 + 8 * c + 6], b.z, acc[c][r]); acc[c][r] = fmaf(W[REG0 + 8 * c + 7], b.w, acc[c][r]);
+    }
+  }
+}
+template <int RG>
+__global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float dx_smem[];
+  const DbArgs& a = a_in;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int Pr = DX_GROUP / RG, DC = DX_W / Pr;
+  constexpr int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc;
+  const int T = a.T_in, Tpad = (T + 63) & ~63;
+  const int TP = (T + Pr - 1) / Pr, TS = (T + Pp - 1) / Pp;
+  const int n = a.n;
+
+  // ---- LDS carve (db_lds_floats mirrors this) ----
+  float* st = dx_smem;                        // [RG][DBS_LD]
+  float* dmb = st + RG * DBS_LD;              // [2][RG][384] dmel rows
+  float* Kc = dmb + 2 * RG * 384;             // keys   [TS][DS]
+  float* Vc = Kc + (size_t)TS * DS;           // values [T][DC]
+  float* rows = Vc + (size_t)T * DC;          // [2][3][Tpad]: e, alpha(t+1 slot = this step's), alpha(t slot = previous)
+  float* da = rows + 6 * Tpad;
+  float* pp = da + Tpad; float* cp = pp + Tpad; float* ss = cp + Tpad; float* de = ss + Tpad; float* dac = de + Tpad;
+  float* qv = dac + Tpad; float* vv = qv + 64; float* scr = vv + 64;
+  float* cpart = scr + 64;                    // [DX_NW][64]
+  int* ictl = reinterpret_cast<int*>(cpart + DX_NW * 64);
+
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 40);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
+  const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (member >= DX_GROUP) return;
+  const int row0 = group * RG;
+  if (row0 >= a.B) return;
+  const int arow = member / Pr, asl = member % Pr;
+  const int cb = asl % Pc, pb = asl / Pc;
+  const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
+  const int brow = row0 + arow;
+  const int browc = min(brow, a.B - 1);
+
+  float W[DB_NREG];
+  {
+    const float* wp = a.wpack + ((size_t)member * DB_NREG) * DX_NT + tid;
+#pragma unroll
+    for (int j = 0; j < DB_NREG; ++j) W[j] = wp[(size_t)j * DX_NT];
+  }
+  const DbX xl = db_xlayout(RG, T);
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * xl.total;
+
+  // stationary attention memory of the member's row (as in the forward kernel)
+  for (int i = tid; i < TS * (DS / 4); i += DX_NT) {
+    const int j = i / (DS / 4), d4 = i % (DS / 4);
+    float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (brow < a.B && j < psn) k4 = *reinterpret_cast<const float4*>(a.keys + ((size_t)brow * T + ps0 + j) * DX_W + cb * DS + 4 * d4);
+    *reinterpret_cast<float4*>(Kc + (size_t)j * DS + 4 * d4) = k4;
+  }
+  for (int i = tid; i < T * (DC / 4); i += DX_NT) {
+    const int j = i / (DC / 4), d4 = i % (DC / 4);
+    float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (brow < a.B) v4 = *reinterpret_cast<const float4*>(a.values + ((size_t)brow * T + j) * DX_W + asl * DC + 4 * d4);
+    *reinterpret_cast<float4*>(Vc + (size_t)j * DC + 4 * d4) = v4;
+  }
+  for (int i = tid; i < RG * DBS_LD; i += DX_NT) st[i] = 0.f;
+  for (int i = tid; i < 2 * RG * 384; i += DX_NT) dmb[i] = 0.f;
+  for (int j = tid; j < Tpad; j += DX_NT) { da[j] = 0.f; pp[j] = 0.f; cp[j] = 0.f; ss[j] = 0.f; de[j] = 0.f; dac[j] = 0.f; }
+  for (int j = tid; j < 6 * Tpad; j += DX_NT) rows[j] = 0.f;
+  if (tid < DS) vv[tid] = a.att_v[cb * DS + tid];
+  const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
+  __syncthreads();
+
+  constexpr int RL = DxRL<RG>::value;
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+  const int en = member * 8 + wave, en2 = member * 4 + wave;     // own column of 256-wide / (waves 0-3) of 128-wide vectors
+  int erow[RL];
+  bool ev[RL];
+  unsigned trow[RL];                                             // (row * n) : element offset of step 0 in a [B, n, W] array is trow * W
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    erow[q] = dx_row<RG>(lane & 3, q);
+    ev[q] = epl && (row0 + erow[q] < a.B);
+    trow[q] = (unsigned)min(row0 + erow[q], a.B - 1) * (unsigned)n;
+  }
+  const unsigned tstr = (unsigned)a.tstride;
+  // own-column tape values of a step: u, c, r, previous state of the three cells; both prenet outputs
+  struct Own { float u2, c2, r2, h2p, u1, c1, r1, h1p, uA, cA, rA, hAp, p2, p1; };
+  auto load_own = [&](int t, Own (&o)[RL]) {
+#pragma unroll
+    for (int q = 0; q < RL; ++q) {
+      if (!epl) { o[q] = Own{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; continue; }   // only the epilogue lanes own a (row, column)
+      const unsigned base = (trow[q] + (unsigned)t) * DX_W + (unsigned)en, prev = base - DX_W;
+      const int b = min(row0 + erow[q], a.B - 1);
+      auto TP_ = [&](int slot, unsigned off) { return a.tape[(unsigned)slot * tstr + off]; };
+      o[q].u2 = TP_(DXT_U2, base); o[q].c2 = TP_(DXT_C2, base); o[q].r2 = TP_(DXT_R2, base);
+      o[q].u1 = TP_(DXT_U1, base); o[q].c1 = TP_(DXT_C1, base); o[q].r1 = TP_(DXT_R1, base);
+      o[q].uA = TP_(DXT_UA, base); o[q].cA = TP_(DXT_CA, base); o[q].rA = TP_(DXT_RA, base);
+      o[q].p1 = TP_(DXT_P1, base);
+      o[q].p2 = (wave < 4) ? a.tp_p2[(size_t)(trow[q] + (unsigned)t) * a.ld_p2 + en2] : 0.f;
+      if (t > 0) { o[q].h2p = TP_(DXT_H2, prev); o[q].h1p = TP_(DXT_H1, prev); o[q].hAp = TP_(DXT_HA, prev); }
+      else {
+        o[q].h2p = a.h20 ? a.h20[(size_t)b * DX_W + en] : 0.f; o[q].h1p = a.h10 ? a.h10[(size_t)b * DX_W + en] : 0.f;
+        o[q].hAp = a.h_att0 ? a.h_att0[(size_t)b * DX_W + en] : 0.f;
+      }
+    }
+  };
+  // rows needed whole, one step ahead, straight into LDS: dmel_t (waves 0..RG-1), e_t / alpha_{t+1} / alpha_t of the member's row
+  const unsigned dmb_lds = (unsigned)(size_t)(dx_lds_float*)dmb, rows_lds = (unsigned)(size_t)(dx_lds_float*)rows;
+  auto fetch_rows = [&](int t, int buf) {
+    if (wave < RG) {
+      const float* src = a.dmel + ((size_t)min(row0 + wave, a.B - 1) * n + t) * a.rM;
+      for (int j0 = 0; j0 < a.rM; j0 += 64)
+        dx_load_lds4(src + min(j0 + lane, a.rM - 1), __builtin_amdgcn_readfirstlane(dmb_lds + (unsigned)((buf * RG + wave) * 384 + j0) * 4u));
+    }
+    const float* se = a.tp_e + ((size_t)browc * n + t) * T;
+    const float* sa = a.tp_alpha + ((size_t)browc * (n + 1) + t + 1) * T;
+    const float* sp = a.tp_alpha + ((size_t)browc * (n + 1) + t) * T;
+    for (int j0 = wave * 64; j0 < T; j0 += DX_NT) {
+      const int j = min(j0 + lane, T - 1);
+      dx_load_lds4(se + j, __builtin_amdgcn_readfirstlane(rows_lds + (unsigned)((buf * 3 + 0) * Tpad + j0) * 4u));
+      dx_load_lds4(sa + j, __builtin_amdgcn_readfirstlane(rows_lds + (unsigned)((buf * 3 + 1) * Tpad + j0) * 4u));
+      dx_load_lds4(sp + j, __builtin_amdgcn_readfirstlane(rows_lds + (unsigned)((buf * 3 + 2) * Tpad + j0) * 4u));
+    }
+  };
+  Own cur[RL], nxt[RL];
+  load_own(n - 1, cur);
+  fetch_rows(n - 1, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float dh2[RL], dh1[RL], dhA[RL], dctxc[RL];      // carried gradients of the owner's column
+#pragma unroll
+  for (int q = 0; q < RL; ++q) { dh2[q] = 0.f; dh1[q] = 0.f; dhA[q] = 0.f; dctxc[q] = 0.f; }
+  float dsb_row = 0.f;
+
+  const int tid_outer = tid, lane_outer = lane;
+  for (int t = n - 1; t >= 0; --t) {
+    const unsigned tag = (unsigned)(n - 1 - t) + 1u;
+    const int buf = (n - 1 - t) & 1;
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    if (t > 0) { load_own(t - 1, nxt); fetch_rows(t - 1, buf ^ 1); }
+    const float* er = rows + (size_t)(buf * 3 + 0) * Tpad;     // raw scores of step t
+    const float* al = rows + (size_t)(buf * 3 + 1) * Tpad;     // alignments of step t
+    const float* alp = rows + (size_t)(buf * 3 + 2) * Tpad;    // alignments of step t - 1 (slot 0: the initial alignments)
+#define DB_OUT(ptr, Wd, q, col, val) do { if (ev[q]) (ptr)[(size_t)(trow[q] + (unsigned)t) * (Wd) + (col)] = (val); } while (0)
+    // a GRU cell's backward, part 'a' (owner-local): from the gradient of the cell's output and the carried state gradient
+    float dht[RL], dgu[RL], tx[RL], do_[RL];
+    // ================= frame projection^T -> GRU 2 'a' =================
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DBR_F, 1, RG, DB_NREG, 384>(W, dmb + (size_t)buf * RG * 384, lane, acc);
+#pragma unroll
+      for (int r = 0; r < RG; ++r) acc[0][r] = fmaf(W[DBR_F + 4], dmb[(size_t)(buf * RG + r) * 384 + 256 + lane], acc[0][r]);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        do_[q] = s[0][q];                                        // d o2 (GRU stack output)
+        const float g = do_[q] + dh2[q];
+        const float dcp = g * (1.f - cur[q].u2) * (1.f - cur[q].c2 * cur[q].c2);
+        dgu[q] = g * (cur[q].h2p - cur[q].c2) * cur[q].u2 * (1.f - cur[q].u2);
+        dht[q] = g;
+        if (epl) dx_publish(X + xl.dcp2 + erow[q] * 256 + en, dcp, tag, rt);
+        DB_OUT(a.g_dcp2, 256, q, en, dcp); DB_OUT(a.g_dgp2, 512, q, 256 + en, dgu[q]);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
+    __syncthreads();
+    // a cell's parts 'b' and 'c' as two stages; CX/CH/GX/GH: register bases, VC/VG: LDS vectors, XG: gate-gradient exchange
+#define DB_CELL_B(CX, CH, VC, XG, HP, RR, UU, DHP, GOUT)                                                     \
+    {                                                                                                        \
+      float acc[2][RG], s[2][RL];                                                                            \
+      dx_zero<2, RG>(acc);                                                                                   \
+      dx_pass<CX, 1, RG, DB_NREG, DBS_LD>(W, st + VC, lane, reinterpret_cast<float (&)[1][RG]>(acc[0]));    \
+      dx_pass<CH, 1, RG, DB_NREG, DBS_LD>(W, st + VC, lane, reinterpret_cast<float (&)[1][RG]>(acc[1]));    \
+      dx_reduce<2, RG>(acc, s, lane);                                                                        \
+      _Pragma("unroll") for (int q = 0; q < RL; ++q) {                                                       \
+        tx[q] = s[0][q];                                                                                     \
+        const float drh = s[1][q];                                                                           \
+        const float dgr = drh * (HP) * (RR) * (1.f - (RR));                                                  \
+        DHP[q] = dht[q] * (UU) + drh * (RR);                                                                 \
+        if (epl) { dx_publish(X + (XG) + erow[q] * 512 + en, dgr, tag, rt); dx_publish(X + (XG) + erow[q] * 512 + 256 + en, dgu[q], tag, rt); } \
+        DB_OUT(GOUT, 512, q, en, dgr);                                                                       \
+      }                                                                                                      \
+    }
+    float dhp[RL];
+    // ================= GRU 2 'b' =================
+    DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, cur[q].h2p, cur[q].r2, cur[q].u2, dhp, a.g_dgp2)
+    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= GRU 2 'c' -> residual -> GRU 1 'a' =================
+    {
+      float acc[2][RG], s[2][RL];
+      dx_zero<2, RG>(acc);
+      db_pass512<DBR_G2X, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGP2, lane, reinterpret_cast<float (&)[1][RG]>(acc[0]));
+      db_pass512<DBR_G2H, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGP2, lane, reinterpret_cast<float (&)[1][RG]>(acc[1]));
+      dx_reduce<2, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        dh2[q] = dhp[q] + s[1][q];
+        do_[q] = tx[q] + s[0][q] + do_[q];                       // d o1 = d x of GRU 2 + residual (o2 = h2 + o1)
+        const float g = do_[q] + dh1[q];
+        const float dcp = g * (1.f - cur[q].u1) * (1.f - cur[q].c1 * cur[q].c1);
+        dgu[q] = g * (cur[q].h1p - cur[q].c1) * cur[q].u1 * (1.f - cur[q].u1);
+        dht[q] = g;
+        if (epl) dx_publish(X + xl.dcp1 + erow[q] * 256 + en, dcp, tag, rt);
+        DB_OUT(a.g_dcp1, 256, q, en, dcp); DB_OUT(a.g_dgp1, 512, q, 256 + en, dgu[q]);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= GRU 1 'b' =================
+    DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, cur[q].h1p, cur[q].r1, cur[q].u1, dhp, a.g_dgp1)
+    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= GRU 1 'c' -> d o0 =================
+    {
+      float acc[2][RG], s[2][RL];
+      dx_zero<2, RG>(acc);
+      db_pass512<DBR_G1X, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGP1, lane, reinterpret_cast<float (&)[1][RG]>(acc[0]));
+      db_pass512<DBR_G1H, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGP1, lane, reinterpret_cast<float (&)[1][RG]>(acc[1]));
+      dx_reduce<2, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        dh1[q] = dhp[q] + s[1][q];
+        const float do0 = tx[q] + s[0][q] + do_[q];              // d o0 = d x of GRU 1 + residual (o1 = h1 + o0)
+        if (epl) dx_publish(X + xl.do0 + erow[q] * 256 + en, do0, tag, rt);
+        DB_OUT(a.g_do0, 256, q, en, do0);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= concat projection^T: d h_att (kept), d ctx -> exchange =================
+    float dIn_hA[RL];
+    {
+      float acc[2][RG], s[2][RL];
+      dx_zero<2, RG>(acc);
+      dx_pass<DBR_CCA, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DO0, lane, reinterpret_cast<float (&)[1][RG]>(acc[0]));
+      dx_pass<DBR_CCC, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DO0, lane, reinterpret_cast<float (&)[1][RG]>(acc[1]));
+      dx_reduce<2, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        dIn_hA[q] = s[0][q];
+        const float dc = dctxc[q] + s[1][q];                     // total gradient of context(t)
+        if (epl) dx_publish(X + xl.dctx + erow[q] * 256 + en, dc, tag, rt);
+        DB_OUT(a.g_dctx, 256, q, en, dc);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= attention backward of the member's row =================
+    {  // d alpha partial over the member's value-channel block: sum_c dctx[asl*DC + c] * V[j][c], lanes over positions
+      const float* dcx = st + arow * DBS_LD + DBS_DCTX + asl * DC;
+      for (int j = tid; j < T; j += DX_NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DC; c += 4) {
+          const float4 v4 = *reinterpret_cast<const float4*>(Vc + (size_t)j * DC + c);
+          s += v4.x * dcx[c] + v4.y * dcx[c + 1] + v4.z * dcx[c + 2] + v4.w * dcx[c + 3];
+        }
+        dx_publish(X + xl.da + (size_t)(arow * Pr + asl) * T + j, s, tag, rt);
+      }
+    }
+    {  // gather the row's partials (fixed order) + the carried d alpha
+      constexpr int NPQ = Pr >= 4 ? Pr / 4 : 1;                  // partials per lane: a quad covers the Pr members (Pr >= 4), else one lane all
+      const int jl = lane >> 2, part = lane & 3;
+      for (int j0 = 0; j0 < T; j0 += 16 * DX_NW) {
+        const int j = j0 + wave * 16 + jl;
+        float s = 0.f;
+        if (j < T && (Pr >= 4 || part < Pr)) {
+          float v[NPQ];
+          dx_poll<NPQ>(X + xl.da + (size_t)(arow * Pr + (Pr >= 4 ? part * NPQ : part)) * T + j, (size_t)T, tag, v, rt);
+#pragma unroll
+          for (int u = 0; u < NPQ; ++u) s += v[u];
+        }
+        s = dx_quadsum(s);
+        if (part == 0 && j < T) da[j] = s + dac[j];
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {   // normaliser backward, redundantly on each member of the row (the arithmetic of k_attention_bwd)
+      const int C = (T + 63) >> 6, j0 = lane * C, j1 = min(j0 + C, T);
+      if (a.att_type == 2) {
+        float run = 0.f;
+        for (int j = j0; j < j1; ++j) {
+          const float pj = taco_sigmoid(er[j] + sbias);
+          pp[j] = pj; cp[j] = run;
+          run += logf(fminf(fmaxf(1.f - pj, 1.17549435e-38f), 1.f));
+        }
+        const float off = wave_scan(run, lane) - run;
+        float run2 = 0.f;
+        for (int j = j0; j < j1; ++j) {
+          const float c1 = expf(cp[j] + off);
+          cp[j] = c1;
+          run2 += alp[j] / fminf(fmaxf(c1, 1e-10f), 1.f);
+          ss[j] = run2;
+        }
+        const float off2 = wave_scan(run2, lane) - run2;
+        for (int j = j0; j < j1; ++j) ss[j] += off2;
+        float tot = 0.f;
+        for (int j = j0; j < j1; ++j) tot += da[j] * pp[j] * cp[j];
+        float suffix = wave_rscan(tot, lane) - tot;
+        float dLsum = 0.f;
+        for (int j = j1 - 1; j >= j0; --j) {
+          suffix += da[j] * pp[j] * cp[j];
+          const float cj = fminf(fmaxf(cp[j], 1e-10f), 1.f);
+          float dcp_ = da[j] * pp[j] * ss[j];
+          if (cp[j] >= 1e-10f && cp[j] <= 1.f) dcp_ += -suffix * alp[j] / (cj * cj);
+          const float dL = dcp_ * cp[j];
+          ss[j] = da[j] * cp[j] * ss[j];
+          cp[j] = dL;
+          dac[j] = suffix / cj;                                  // d alpha(t-1): the carry of the next (earlier) step
+          dLsum += dL;
+        }
+        float suf2 = wave_rscan(dLsum, lane) - dLsum;
+        float dsb = 0.f;
+        for (int j = j1 - 1; j >= j0; --j) {
+          const float dlg = suf2;
+          suf2 += cp[j];
+          const float xj = 1.f - pp[j];
+          float dp = ss[j];
+          if (xj >= 1.17549435e-38f && xj <= 1.f) dp -= dlg / xj;
+          const float dej = dp * pp[j] * (1.f - pp[j]);
+          de[j] = dej; dsb += dej;
+        }
+        dsb = wave_sum(dsb);
+        dsb_row += dsb;
+      } else {
+        float dot = 0.f;
+        for (int j = j0; j < j1; ++j) dot += al[j] * da[j];
+        dot = wave_sum(dot);
+        for (int j = j0; j < j1; ++j) { de[j] = al[j] * (da[j] - dot); dac[j] = 0.f; }
+      }
+    }
+    // the processed query of the member's score channels (+ attention_b): from the tape
+    if (tid < DS) qv[tid] = a.tape[(unsigned)DXT_Q * tstr + ((unsigned)browc * (unsigned)n + (unsigned)t) * DX_W + cb * DS + tid] + (a.att_b ? a.att_b[cb * DS + tid] : 0.f);
+    __syncthreads();
+    {
+      const int p0 = asl * TP;
+      if (tid < TP && p0 + tid < T && brow < a.B) a.g_de[((size_t)brow * n + t) * T + p0 + tid] = de[p0 + tid];
+    }
+    {  // d q partial of the member's (channel block, position block): dq_c = v_c sum_j de_j (1 - tanh^2(K_jc + q_c)); wave w: channels
+       // w, w + 8, ... of the block, lanes over positions
+      for (int c = wave; c < DS; c += DX_NW) {
+        float s = 0.f;
+        const float qc = qv[c];
+        for (int j = lane; j < psn; j += 64) {
+          const float th = taco_tanh_fast(Kc[(size_t)j * DS + c] + qc);
+          s = fmaf(de[ps0 + j], 1.f - th * th, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) dx_publish(X + xl.dq + (size_t)(arow * Pp + pb) * 256 + cb * DS + c, s * vv[c], tag, rt);
+      }
+    }
+    {  // gather d q of every row: sum over the Pp position blocks
+      constexpr int NI = (RG * 256 + DX_NT - 1) / DX_NT;
+#pragma unroll
+      for (int u = 0; u < NI; ++u) {
+        const int i = u * DX_NT + tid;
+        if (i < RG * 256) {
+          const int r = i / 256, c = i % 256;
+          float v[Pp];
+          dx_poll<Pp>(X + xl.dq + (size_t)(r * Pp) * 256 + c, (size_t)256, tag, v, rt);
+          float s = 0.f;
+#pragma unroll
+          for (int k = 0; k < Pp; ++k) s += v[k];
+          st[r * DBS_LD + DBS_DQ + c] = s;
+        }
+      }
+    }
+    __syncthreads();
+    if (asl == 0 && tid < 256 && brow < a.B) a.g_dq[((size_t)brow * n + t) * 256 + tid] = st[arow * DBS_LD + DBS_DQ + tid];
+    // ================= d h_att += d q . Wq^T -> attention GRU 'a' =================
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DBR_Q, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DQ, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float g = dhA[q] + dIn_hA[q] + s[0][q];
+        const float dcp = g * (1.f - cur[q].uA) * (1.f - cur[q].cA * cur[q].cA);
+        dgu[q] = g * (cur[q].hAp - cur[q].cA) * cur[q].uA * (1.f - cur[q].uA);
+        dht[q] = g;
+        if (epl) dx_publish(X + xl.dcpa + erow[q] * 256 + en, dcp, tag, rt);
+        DB_OUT(a.g_dcpA, 256, q, en, dcp); DB_OUT(a.g_dgpA, 512, q, 256 + en, dgu[q]);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= attention GRU 'b' (the x part has 128 inputs: rows 4m + w of waves 0-3) =================
+    DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, cur[q].hAp, cur[q].rA, cur[q].uA, dhp, a.g_dgpA)
+    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= attention GRU 'c' -> d p2 (ReLU mask) =================
+    {
+      float acc[2][RG], s[2][RL];
+      dx_zero<2, RG>(acc);
+      db_pass512<DBR_GAX, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGPA, lane, reinterpret_cast<float (&)[1][RG]>(acc[0]));
+      db_pass512<DBR_GAH, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DGPA, lane, reinterpret_cast<float (&)[1][RG]>(acc[1]));
+      dx_reduce<2, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        dhA[q] = dhp[q] + s[1][q];
+        if (wave < 4) {
+          const float dz2 = (cur[q].p2 > 0.f) ? tx[q] + s[0][q] : 0.f;
+          if (epl) dx_publish(X + xl.dz2 + erow[q] * 128 + en2, dz2, tag, rt);
+          DB_OUT(a.g_dz2, 128, q, en2, dz2);
+        }
+      }
+    }
+    dx_gather<RG, 128, false, DBS_LD>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= prenet layer 2^T, ReLU mask of layer 1 =================
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        const float2 xv = *reinterpret_cast<const float2*>(st + r * DBS_LD + DBS_DZ2 + 2 * lane);
+        acc[0][r] = fmaf(W[DBR_P2], xv.x, fmaf(W[DBR_P2 + 1], xv.y, 0.f));
+      }
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) {
+        const float dz1 = (cur[q].p1 > 0.f) ? s[0][q] : 0.f;
+        if (epl) dx_publish(X + xl.dz1 + erow[q] * 256 + en, dz1, tag, rt);
+        DB_OUT(a.g_dz1, 256, q, en, dz1);
+      }
+    }
+    dx_gather<RG, 256, false, DBS_LD>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
+    __syncthreads();
+    // ================= prenet layer 1 (context rows)^T: the gradient of context(t - 1) =================
+    {
+      float acc[1][RG], s[1][RL];
+      dx_zero<1, RG>(acc);
+      dx_pass<DBR_P1C, 1, RG, DB_NREG, DBS_LD>(W, st + DBS_DZ1, lane, acc);
+      dx_reduce<1, RG>(acc, s, lane);
+#pragma unroll
+      for (int q = 0; q < RL; ++q) dctxc[q] = s[0][q];
+    }
+#pragma unroll
+    for (int q = 0; q < RL; ++q) cur[q] = nxt[q];
+    // the rows fetched for step t - 1 have landed in every wave that issued them by now (twelve polls ago); this barrier publishes them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef DB_CELL_B
+#undef DB_OUT
+  // gradients of the initial states = the carries left after step 0 (tacotron.py:183-197: deepvoice feeds them from the speaker layers)
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    if (ev[q]) {
+      const size_t o = (size_t)(row0 + erow[q]) * DX_W + en;
+      if (a.d_att_init) a.d_att_init[o] = dhA[q];
+      if (a.d_h10) a.d_h10[o] = dh1[q];
+      if (a.d_h20) a.d_h20[o] = dh2[q];
+    }
+  }
+  if (a.dsb_acc && asl == 0 && tid == 0 && brow < a.B) a.dsb_acc[brow] = dsb_row;
+}

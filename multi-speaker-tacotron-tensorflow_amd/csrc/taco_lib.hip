@@ -8,6 +8,7 @@
 #include "taco_chain.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
+#include "taco_decoder_bwd_xcd.h"
 #include "../../include/taco_abi.h"
 
 #include <algorithm>
@@ -148,6 +149,7 @@ struct taco_model {
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
   size_t dx_fold_n = 0;        // training shadow model: elements of the GRU-1 fold buffer (k_dx_fold), addressed by the index map as NP + 1 + i
   size_t dx_spkw = 0;          // 'simple': speaker rows of the attention GRU and of the folded GRU 1, [S][DXRB_N][256] (k_dx_rowbias)
+  size_t dbx_pack = 0;         // training shadow model: the persistent BPTT kernel's rows (dbx_build_pack)
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
   int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
@@ -459,6 +461,48 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   m->dx_b_g2g = putv(T_(m, "decoder/gru_2/gates/bias").data);
   m->dx_b_g2c = putv(T_(m, "decoder/gru_2/candidate/bias").data);
   m->dx_b_f = putv(T_(m, "decoder/frame_projection/bias").data);
+  return 0;
+}
+
+// The persistent BPTT kernel's registers (taco_decoder_bwd_xcd.h, DBR_*): ROWS of the kernels -- wave w of member m holds row 8m + w
+// (128-wide inputs: row 4m + w on waves 0-3) of every matrix a gradient is pulled back through, inputs 4*lane .. 4*lane + 3 per register quad.
+static int dbx_build_pack(taco_model* m) {
+  if (!dx_widths_ok(m) || is_simple(m)) return 0;
+  const taco_hparams& hp = m->hp;
+  const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, Mm = hp.num_mels;
+  std::vector<float> pack((size_t)DX_GROUP * DB_NREG * DX_NT, 0.f);
+  const auto& fk = T_(m, "decoder/frame_projection/kernel").data;
+  const auto& g2k = T_(m, "decoder/gru_2/gates/kernel").data; const auto& c2k = T_(m, "decoder/gru_2/candidate/kernel").data;
+  const auto& g1k = T_(m, "decoder/gru_1/gates/kernel").data; const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
+  const auto& cck = T_(m, "decoder/concat_projection/kernel").data;
+  const auto& wq = T_(m, "attention/query_layer/kernel").data;
+  const auto& agk = T_(m, "decoder/attention_gru/gates/kernel").data; const auto& ack = T_(m, "decoder/attention_gru/candidate/kernel").data;
+  const auto& W2 = T_(m, "decoder/prenet/dense_2/kernel").data; const auto& W1 = T_(m, "decoder/prenet/dense_1/kernel").data;
+  for (int mem = 0; mem < DX_GROUP; ++mem)
+    for (int tid = 0; tid < DX_NT; ++tid) {
+      const int wave = tid >> 6, lane = tid & 63, en = mem * 8 + wave, en2 = wave < 4 ? mem * 4 + wave : -1;
+      float* R = &pack[((size_t)mem * DB_NREG) * DX_NT + tid];
+      // registers reg0 .. reg0 + kw - 1 = W[row][col0 + kw*lane + e] (zero past ncols)
+      auto row = [&](int reg0, int kw, const std::vector<float>& W, int ldw, int r, int col0, int ncols) {
+        if (r < 0) return;
+        for (int e = 0; e < kw; ++e) { const int c = col0 + kw * lane + e; if (c < ncols) R[(size_t)(reg0 + e) * DX_NT] = W[(size_t)r * ldw + c]; }
+      };
+      row(DBR_F, 4, fk, rM, en, 0, rM); row(DBR_F + 4, 1, fk, rM, en, 256, rM);
+      row(DBR_C2X, 4, c2k, H, en, 0, H); row(DBR_C2H, 4, c2k, H, H + en, 0, H);
+      row(DBR_G2X, 4, g2k, 2 * H, en, 0, 2 * H); row(DBR_G2X + 4, 4, g2k, 2 * H, en, 256, 2 * H);
+      row(DBR_G2H, 4, g2k, 2 * H, H + en, 0, 2 * H); row(DBR_G2H + 4, 4, g2k, 2 * H, H + en, 256, 2 * H);
+      row(DBR_C1X, 4, c1k, H, en, 0, H); row(DBR_C1H, 4, c1k, H, H + en, 0, H);
+      row(DBR_G1X, 4, g1k, 2 * H, en, 0, 2 * H); row(DBR_G1X + 4, 4, g1k, 2 * H, en, 256, 2 * H);
+      row(DBR_G1H, 4, g1k, 2 * H, H + en, 0, 2 * H); row(DBR_G1H + 4, 4, g1k, 2 * H, H + en, 256, 2 * H);
+      row(DBR_CCA, 4, cck, H, en, 0, H); row(DBR_CCC, 4, cck, H, H + en, 0, H);
+      row(DBR_Q, 4, wq, H, en, 0, H);
+      row(DBR_CAX, 4, ack, H, en2, 0, H); row(DBR_CAH, 4, ack, H, DX_P2 + en, 0, H);
+      row(DBR_GAX, 4, agk, 2 * H, en2, 0, 2 * H); row(DBR_GAX + 4, 4, agk, 2 * H, en2, 256, 2 * H);
+      row(DBR_GAH, 4, agk, 2 * H, DX_P2 + en, 0, 2 * H); row(DBR_GAH + 4, 4, agk, 2 * H, DX_P2 + en, 256, 2 * H);
+      row(DBR_P2, 2, W2, DX_P2, en, 0, DX_P2);
+      row(DBR_P1C, 4, W1, H, Mm + en, 0, H);
+    }
+  m->dbx_pack = arena_put(m, pack.data(), pack.size());
   return 0;
 }
 
@@ -1272,6 +1316,35 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
     default: return dx_launch_rg<8, false>(st, a, lds);
   }
 }
+// persistent BPTT (taco_decoder_bwd_xcd.h): same placement rules as the forward kernel
+static size_t dbx_xbuf_granules(int T_in) {
+  size_t g = 0;
+  for (int RG = 1; RG <= 8; RG *= 2) g = std::max(g, (size_t)db_xlayout(RG, T_in).total);
+  return g;
+}
+static bool dbx_usable(const taco_model* m, int B, int T_in) {
+  if (!m->dx_mode || !m->dbx_pack || !m->tp || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
+  return db_lds_floats(dx_rows_per_group(m, B), T_in) * sizeof(float) <= 160 * 1024;
+}
+static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int T_in, int n, unsigned long long* xbuf, unsigned* dxctl) {
+  const int RG = dx_rows_per_group(m, B);
+  a.wpack = AP(m, m->dbx_pack);
+  a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
+  a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err;
+  a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
+  a.force_wt = m->dx_mode == 2 ? 1 : 0;
+  HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));
+  const size_t lds = db_lds_floats(RG, T_in) * sizeof(float);
+  const dim3 grid(DX_NGROUP * DX_GROUP), blk(DX_NT);
+  switch (RG) {
+    case 1: hipLaunchKernelGGL((k_decoder_bwd_xcd<1>), grid, blk, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_decoder_bwd_xcd<2>), grid, blk, lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_decoder_bwd_xcd<4>), grid, blk, lds, st, a); break;
+    default: hipLaunchKernelGGL((k_decoder_bwd_xcd<8>), grid, blk, lds, st, a); break;
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc_out, const int* speaker_id, int B,
                            int T_in, int n, const float* manual, const float* teacher, float* mel, float* align_out,
                            int* stop_step, float* dbg, const DecWs& w, bool spk_ready, const SpkWs* spk_in,
@@ -1711,6 +1784,7 @@ int taco_model_finalize(taco_model* m) {
     m->dx_fold_n = (size_t)(Z + 1) * 3 * H;
     if (NP + m->dx_fold_n >= (1u << 24)) return fail(TACO_ERR_UNSUPPORTED, "parameter + fold indices exceed 2^24");
     TRY(dx_build_pack(m, Wc_t, T_(m, "decoder/prenet/dense_1/bias").data, Wf_t, bf_t));
+    TRY(dbx_build_pack(m));
   }
   {  // attention vectors; bah_norm: v_hat = g * v / |v| (A.9)
     std::vector<float> v = T_(m, "attention/attention_v").data;

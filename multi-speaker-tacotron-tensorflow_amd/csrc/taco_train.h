@@ -45,6 +45,7 @@ struct taco_train {
   void (*sync_fn)(void* user, float* d_vec, int n) = nullptr;
   void* sync_user = nullptr;
   int sync_world = 1;
+  int bptt_persistent = 1;             // taco_train_set_bptt_engine: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd) where it fits
   int deterministic = 0;               // taco_train_set_deterministic: ordered two-stage sums instead of fp32 atomics (needs DET_SCRATCH_FLOATS of workspace)
 };
 #define DET_SCRATCH_FLOATS ((size_t)48 << 20)      // 192 MB: e.g. 30 M-slices of the largest weight gradient (post-net proj_1, 3 x 2048 x 256)
@@ -304,7 +305,7 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
     for (int i = 0; i < L; ++i) { w.h[i] = cv.f(R * Hd); w.r[i] = cv.f(R * Hd); w.u[i] = cv.f(R * Hd); w.c[i] = cv.f(R * Hd); w.rh[i] = cv.f(R * Hd); w.xc[i] = cv.f(R * Hd); }
   }
   w.alpha = cv.f((size_t)B * (n + 1) * T_in); w.alpha0 = cv.f((size_t)B * T_in);   // slot 0 = initial alignments, slot t+1 = step t
-  { const size_t xb = (size_t)DX_NGROUP * dx_xlayout(8, T_in).total * sizeof(unsigned long long);
+  { const size_t xb = (size_t)DX_NGROUP * std::max((size_t)dx_xlayout(8, T_in).total, dbx_xbuf_granules(T_in)) * sizeof(unsigned long long);
     w.xbuf = (unsigned long long*)cv.raw(xb); w.dxctl = (unsigned*)cv.raw(256);
     w.rowbias = cv.f(is_simple(m) ? (size_t)B * DXRB_N * DX_W : 1); }
   w.nz = cv.i((size_t)n * B);
@@ -762,7 +763,22 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   for (int i = 0; i < L; ++i) HIPCHK(zero_async(w.dh[i], (size_t)B * Hd * sizeof(float), st));
   const size_t attn_lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 5 * ((T_in + 3) & ~3) + ATB_NW * 256) * sizeof(float);
   if (attn_lds > 160 * 1024 || (As % 4) || (D % 4) || (A % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the backward kernel");
-  for (int t = n - 1; t >= 0; --t) {
+  // the whole loop as ONE persistent launch (k_decoder_bwd_xcd, taco_decoder_bwd_xcd.h) when the forward left its tape in that
+  // kernel's layout; the launch-per-stage loop below is the general path (other widths, 'simple', more than 64 rows)
+  const bool persistent = x.t->bptt_persistent && w.tape256 && !S && L == 2 && np == 2 && (size_t)DXT_N * w.tstride < (1u << 31) &&
+                          dbx_usable(m, B, T_in);
+  if (persistent) {
+    DbArgs a; memset(&a, 0, sizeof a);
+    a.tape = w.tape256; a.tstride = w.tstride; a.tp_p2 = w.pz[1]; a.ld_p2 = Pz; a.tp_e = w.g_e; a.tp_alpha = w.alpha;
+    a.keys = w.keys; a.values = enc_out; a.dmel = dmel;
+    a.h_att0 = att_init; a.h10 = dec_init ? dec_init[0] : nullptr; a.h20 = dec_init ? dec_init[1] : nullptr;
+    a.g_dcp2 = w.g_dcp[1]; a.g_dgp2 = w.g_dgp[1]; a.g_dcp1 = w.g_dcp[0]; a.g_dgp1 = w.g_dgp[0]; a.g_do0 = w.g_do0;
+    a.g_dcpA = w.g_dcpA; a.g_dgpA = w.g_dgpA; a.g_dz1 = w.g_dz[0]; a.g_dz2 = w.g_dz[1]; a.g_dq = w.g_dq; a.g_de = w.g_de; a.g_dctx = w.g_dctx;
+    a.d_att_init = d_att_init; a.d_h10 = d_dec_init ? d_dec_init[0] : nullptr; a.d_h20 = d_dec_init ? d_dec_init[1] : nullptr;
+    a.dsb_acc = w.dsb_acc;
+    TRY(dbx_launch(m, st, a, B, T_in, n, w.xbuf, w.dxctl));
+  }
+  for (int t = n - 1; t >= 0 && !persistent; --t) {
     const size_t oh = (size_t)t * Hd, oa = (size_t)t * As;
     { SkJob j = sk_T(m, tp.frame_T, dmel + (size_t)t * rM, n * rM, w.do_[L], Hd); TRY(run_skinny(st, B, &j, 1)); }
     for (int i = L - 1; i >= 0; --i) {
@@ -814,8 +830,8 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     HIPCHK(hipGetLastError());
   }
   // gradients of the initial states (deepvoice: they come from the speaker layers) = the carries left after step 0
-  if (d_att_init) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, d_att_init, As, B, As);
-  for (int i = 0; i < L; ++i)
+  if (d_att_init && !persistent) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * As), 0, st, w.dhA, As, d_att_init, As, B, As);
+  for (int i = 0; i < L && !persistent; ++i)
     if (d_dec_init && d_dec_init[i]) hipLaunchKernelGGL(k_copy2d, EWGRID((size_t)B * Hd), 0, st, w.dh[i], Hd, d_dec_init[i], Hd, B, Hd);
   HIPCHK(hipGetLastError());
   // first-step terms of the recurrent kernels' gates rows: the state before step 0 is the initial state, not a tape row

@@ -58,6 +58,11 @@ int taco_train_set_exact_wgrad(taco_train* t, int on) {
   g_wgrad_bf3 = on ? 0 : 1;           // process-wide switch (an A/B and test hook, not a per-trainer setting)
   return 0;
 }
+int taco_train_set_bptt_engine(taco_train* t, int persistent) {
+  if (!t) return fail(TACO_ERR_ARG, "null argument");
+  t->bptt_persistent = persistent ? 1 : 0;
+  return 0;
+}
 int taco_train_set_deterministic(taco_train* t, int on) {
   if (!t) return fail(TACO_ERR_ARG, "null argument");
   t->deterministic = on ? 1 : 0;      // changes taco_train_workspace_bytes

@@ -144,6 +144,13 @@ class Trainer(object):
         if getattr(self, "_graph", None) is not None:
             self._graph = None          # a captured step keeps the engine it was captured with
 
+    def set_bptt_engine(self, persistent=True):
+        """True (default): back-propagation through the decoder loop is ONE whole-chip launch (csrc/taco_decoder_bwd_xcd.h) whenever the
+        forward ran on the persistent decoder; False: the chain of per-stage launches (round 1's engine; A/B and test hook)."""
+        _lib.check(self._lib.taco_train_set_bptt_engine(self._h, 1 if persistent else 0))
+        if getattr(self, "_graph", None) is not None:
+            self._graph = None
+
     def decoder_engine_info(self):
         """After a forward (synchronises): {'protocol': 0 launch per stage / 1 XCD-local / 2 write-through, 'per_xcd': [...]} of the last
         persistent decoder launch of the training forward."""

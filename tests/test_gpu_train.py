@@ -395,7 +395,8 @@ def test_simple_multispeaker_training_gradients(ses, atype):
     tr.close()
 
 
-@pytest.mark.parametrize("model_type,atype,B", [("single", "bah_mon", 9), ("deepvoice", "bah", 3), ("simple", "bah_norm", 5), ("single", "bah_mon", 33)])
+@pytest.mark.parametrize("model_type,atype,B", [("single", "bah_mon", 9), ("deepvoice", "bah", 3), ("simple", "bah_norm", 5), ("single", "bah_mon", 33),
+                                                ("deepvoice", "bah_mon", 20), ("single", "bah_norm", 18)])
 def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     """At the reference widths the teacher-forced decoder loop and the post-net scan of the training forward are the persistent
     kernels of inference with tape outputs (k_decoder_xcd<RG, true>: teacher frames in, gates / states / scores / alignments out;
@@ -434,6 +435,14 @@ def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     err2 = np.sqrt(sum(float(((got[k] - g[k]) ** 2).sum()) for k in g))
     print("gradient vs float64 autograd: |diff| / |g| = %.2e; worst tensors %s" % (err2 / gn, [(round(x[0], 4), x[1]) for x in worst[:3]]))
     assert err2 < 2e-3 * gn, (err2, gn)
+    tr.set_bptt_engine(False)                     # persistent forward, the decoder's BPTT as the chain of per-stage launches
+    tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    mid = tr.grad_dict()
+    worst_b = sorted(((maxabs(got[k], mid[k]), k) for k in mid), reverse=True)
+    print("persistent BPTT (k_decoder_bwd_xcd) vs per-stage BPTT on the same tape, worst tensors (absolute):", worst_b[:3], " |g| =", gn)
+    assert worst_b[0][0] < 2e-5 * gn, worst_b[:4]
+    tr.set_bptt_engine(True)
     tr.set_decoder_engine(0)                      # the same step on the launch-per-stage engine
     tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
     torch.cuda.synchronize()
