@@ -294,7 +294,8 @@ int taco_debug_set_overlap(taco_model* m, int on);
  * rows_per_group: 0 = smallest of 1/2/4/8 that covers the batch with 8 groups; a larger value packs the batch onto fewer XCDs. */
 int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group);
 /* after a forward: out16[0] = exchange protocol the last persistent decoder launch used (0 none ran, 1 XCD-local plain stores,
- * 2 write-through), out16[1..8] = workgroups the census saw per XCD, out16[14] = compute units of the device (the whole-chip
+ * 2 write-through), out16[1..8] = workgroups the census saw per XCD, out16[9] = protocol of the persistent BPTT launch when the
+ * last decoder backward (training shadow model) used it, else 0, out16[14] = compute units of the device (the whole-chip
  * persistent kernels are used only when there are 256: an unpartitioned MI355X; a CPX / DPX partition runs the launch-per-stage
  * engine), out16[15] = 1 when the model has a persistent-decoder pack */
 int taco_debug_decoder_info(taco_model* m, int* out16);

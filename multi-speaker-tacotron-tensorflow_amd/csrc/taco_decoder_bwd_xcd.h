@@ -63,6 +63,7 @@ __host__ __device__ inline size_t db_lds_floats(int RG, int T_in) {
   const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
   size_t n = (size_t)RG * DBS_LD;
   n += 2 * (size_t)RG * 384;                       // dmel rows, double buffered (LDS-direct, one step ahead)
+  n += 2 * (size_t)DX_NW * 128;                    // own-column tape values of the step, double buffered
   n += (size_t)TS * DS + (size_t)T_in * DC;        // keys block, values block
   n += 2 * 3 * (size_t)Tpad;                       // raw scores, alignments of the step and of the step before, double buffered
   n += 6 * (size_t)Tpad;                           // da, p, cp, ss, de, d alpha carry
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   // ---- LDS carve (db_lds_floats mirrors this) ----
   float* st = dx_smem;                        // [RG][DBS_LD]
   float* dmb = st + RG * DBS_LD;              // [2][RG][384] dmel rows
-  float* Kc = dmb + 2 * RG * 384;             // keys   [TS][DS]
+  float* Kc = dmb + 2 * RG * 384 + 2 * DX_NW * 128;   // (own-column tape values [2][DX_NW][128] in between)  keys [TS][DS]
   float* Vc = Kc + (size_t)TS * DS;           // values [T][DC]
   float* rows = Vc + (size_t)T * DC;          // [2][3][Tpad]: e, alpha(t+1 slot = this step's), alpha(t slot = previous)
   float* da = rows + 6 * Tpad;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     *reinterpret_cast<float4*>(Vc + (size_t)j * DC + 4 * d4) = v4;
   }
   for (int i = tid; i < RG * DBS_LD; i += DX_NT) st[i] = 0.f;
-  for (int i = tid; i < 2 * RG * 384; i += DX_NT) dmb[i] = 0.f;
+  for (int i = tid; i < 2 * RG * 384 + 2 * DX_NW * 128; i += DX_NT) dmb[i] = 0.f;     // (and the own-column buffers behind them)
   for (int j = tid; j < Tpad; j += DX_NT) { da[j] = 0.f; pp[j] = 0.f; cp[j] = 0.f; ss[j] = 0.f; de[j] = 0.f; dac[j] = 0.f; }
   for (int j = tid; j < 6 * Tpad; j += DX_NT) rows[j] = 0.f;
   if (tid < DS) vv[tid] = a.att_v[cb * DS + tid];
@@ -184,26 +185,37 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     trow[q] = (unsigned)min(row0 + erow[q], a.B - 1) * (unsigned)n;
   }
   const unsigned tstr = (unsigned)a.tstride;
-  // own-column tape values of a step: u, c, r, previous state of the three cells; both prenet outputs
-  struct Own { float u2, c2, r2, h2p, u1, c1, r1, h1p, uA, cA, rA, hAp, p2, p1; };
-  auto load_own = [&](int t, Own (&o)[RL]) {
+  // Own-column tape values of a step -- u, c, r and the previous state of the three cells, both prenet outputs, for the RG rows of
+  // the wave's column: OW_N * RG scalars per wave -- are gathered one step ahead by ONE LDS-direct load per 64 of them (each lane
+  // supplies the address of its (value, row) pair), so neither the values in flight nor the ones in use occupy registers.
+  enum { OW_U2 = 0, OW_C2, OW_R2, OW_H2P, OW_U1, OW_C1, OW_R1, OW_H1P, OW_UA, OW_CA, OW_RA, OW_HAP, OW_P1, OW_P2, OW_N };
+  constexpr int OW_K = (OW_N * RG + 63) / 64;
+  const float* gp[OW_K]; const float* galt[OW_K]; int gstr[OW_K]; bool gprev[OW_K], gok[OW_K];
 #pragma unroll
-    for (int q = 0; q < RL; ++q) {
-      if (!epl) { o[q] = Own{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; continue; }   // only the epilogue lanes own a (row, column)
-      const unsigned base = (trow[q] + (unsigned)t) * DX_W + (unsigned)en, prev = base - DX_W;
-      const int b = min(row0 + erow[q], a.B - 1);
-      auto TP_ = [&](int slot, unsigned off) { return a.tape[(unsigned)slot * tstr + off]; };
-      o[q].u2 = TP_(DXT_U2, base); o[q].c2 = TP_(DXT_C2, base); o[q].r2 = TP_(DXT_R2, base);
-      o[q].u1 = TP_(DXT_U1, base); o[q].c1 = TP_(DXT_C1, base); o[q].r1 = TP_(DXT_R1, base);
-      o[q].uA = TP_(DXT_UA, base); o[q].cA = TP_(DXT_CA, base); o[q].rA = TP_(DXT_RA, base);
-      o[q].p1 = TP_(DXT_P1, base);
-      o[q].p2 = (wave < 4) ? a.tp_p2[(size_t)(trow[q] + (unsigned)t) * a.ld_p2 + en2] : 0.f;
-      if (t > 0) { o[q].h2p = TP_(DXT_H2, prev); o[q].h1p = TP_(DXT_H1, prev); o[q].hAp = TP_(DXT_HA, prev); }
-      else {
-        o[q].h2p = a.h20 ? a.h20[(size_t)b * DX_W + en] : 0.f; o[q].h1p = a.h10 ? a.h10[(size_t)b * DX_W + en] : 0.f;
-        o[q].hAp = a.h_att0 ? a.h_att0[(size_t)b * DX_W + en] : 0.f;
-      }
+  for (int k = 0; k < OW_K; ++k) {
+    const int i = lane + 64 * k, v = i / RG, b = min(row0 + i % RG, a.B - 1);
+    gok[k] = i < OW_N * RG && (v != OW_P2 || wave < 4);
+    gprev[k] = v == OW_H2P || v == OW_H1P || v == OW_HAP;
+    int slot = DXT_P1;
+    switch (v) {
+      case OW_U2: slot = DXT_U2; break; case OW_C2: slot = DXT_C2; break; case OW_R2: slot = DXT_R2; break; case OW_H2P: slot = DXT_H2; break;
+      case OW_U1: slot = DXT_U1; break; case OW_C1: slot = DXT_C1; break; case OW_R1: slot = DXT_R1; break; case OW_H1P: slot = DXT_H1; break;
+      case OW_UA: slot = DXT_UA; break; case OW_CA: slot = DXT_CA; break; case OW_RA: slot = DXT_RA; break; case OW_HAP: slot = DXT_HA; break;
+      default: break;
     }
+    gp[k] = a.tape + (size_t)slot * a.tstride + (size_t)b * n * DX_W + en - (gprev[k] ? DX_W : 0);    // + t * 256: step t (previous state: step t - 1)
+    gstr[k] = DX_W;
+    if (v == OW_P2) { gp[k] = a.tp_p2 + (size_t)b * n * a.ld_p2 + (wave < 4 ? en2 : 0); gstr[k] = a.ld_p2; }
+    const float* i0 = v == OW_H2P ? a.h20 : v == OW_H1P ? a.h10 : a.h_att0;                           // the state before step 0
+    galt[k] = (gprev[k] && i0) ? i0 + (size_t)b * DX_W + en : gp[k] + gstr[k];                         // (none: any valid address; the consumer reads 0)
+  }
+  float* own = dmb + 2 * RG * 384;                   // [2][DX_NW][128]
+  const unsigned own_lds = (unsigned)(size_t)(dx_lds_float*)own;
+  auto fetch_own = [&](int t, int buf) {
+#pragma unroll
+    for (int k = 0; k < OW_K; ++k)
+      if (gok[k]) dx_load_lds4((t == 0 && gprev[k]) ? galt[k] : gp[k] + (size_t)t * gstr[k],
+                               __builtin_amdgcn_readfirstlane(own_lds + (unsigned)((buf * DX_NW + wave) * 128 + 64 * k) * 4u));
   };
   // rows needed whole, one step ahead, straight into LDS: dmel_t (waves 0..RG-1), e_t / alpha_{t+1} / alpha_t of the member's row
   const unsigned dmb_lds = (unsigned)(size_t)(dx_lds_float*)dmb, rows_lds = (unsigned)(size_t)(dx_lds_float*)rows;
@@ -223,8 +235,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       dx_load_lds4(sp + j, __builtin_amdgcn_readfirstlane(rows_lds + (unsigned)((buf * 3 + 2) * Tpad + j0) * 4u));
     }
   };
-  Own cur[RL], nxt[RL];
-  load_own(n - 1, cur);
+  fetch_own(n - 1, 0);
   fetch_rows(n - 1, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -240,7 +251,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     const int buf = (n - 1 - t) & 1;
     int tid = tid_outer, lane = lane_outer;
     asm volatile("" : "+v"(tid), "+v"(lane));
-    if (t > 0) { load_own(t - 1, nxt); fetch_rows(t - 1, buf ^ 1); }
+    if (t > 0) { fetch_own(t - 1, buf ^ 1); fetch_rows(t - 1, buf ^ 1); }
+    const float* ow = own + (buf * DX_NW + wave) * 128;
+#define OWN(v, q) ow[(v) * RG + erow[q]]
+    const bool z2 = t == 0 && !a.h20, z1 = t == 0 && !a.h10, zA = t == 0 && !a.h_att0;   // zero initial state (rnn_wrappers.py:186-216)
     const float* er = rows + (size_t)(buf * 3 + 0) * Tpad;     // raw scores of step t
     const float* al = rows + (size_t)(buf * 3 + 1) * Tpad;     // alignments of step t
     const float* alp = rows + (size_t)(buf * 3 + 2) * Tpad;    // alignments of step t - 1 (slot 0: the initial alignments)
@@ -259,8 +273,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         do_[q] = s[0][q];                                        // d o2 (GRU stack output)
         const float g = do_[q] + dh2[q];
-        const float dcp = g * (1.f - cur[q].u2) * (1.f - cur[q].c2 * cur[q].c2);
-        dgu[q] = g * (cur[q].h2p - cur[q].c2) * cur[q].u2 * (1.f - cur[q].u2);
+        const float dcp = g * (1.f - OWN(OW_U2, q)) * (1.f - OWN(OW_C2, q) * OWN(OW_C2, q));
+        dgu[q] = g * ((z2 ? 0.f : OWN(OW_H2P, q)) - OWN(OW_C2, q)) * OWN(OW_U2, q) * (1.f - OWN(OW_U2, q));
         dht[q] = g;
         if (epl) dx_publish(X + xl.dcp2 + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcp2, 256, q, en, dcp); DB_OUT(a.g_dgp2, 512, q, 256 + en, dgu[q]);
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     float dhp[RL];
     // ================= GRU 2 'b' =================
-    DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, cur[q].h2p, cur[q].r2, cur[q].u2, dhp, a.g_dgp2)
+    DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, (z2 ? 0.f : OWN(OW_H2P, q)), OWN(OW_R2, q), OWN(OW_U2, q), dhp, a.g_dgp2)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
     __syncthreads();
     // ================= GRU 2 'c' -> residual -> GRU 1 'a' =================
@@ -302,8 +316,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         dh2[q] = dhp[q] + s[1][q];
         do_[q] = tx[q] + s[0][q] + do_[q];                       // d o1 = d x of GRU 2 + residual (o2 = h2 + o1)
         const float g = do_[q] + dh1[q];
-        const float dcp = g * (1.f - cur[q].u1) * (1.f - cur[q].c1 * cur[q].c1);
-        dgu[q] = g * (cur[q].h1p - cur[q].c1) * cur[q].u1 * (1.f - cur[q].u1);
+        const float dcp = g * (1.f - OWN(OW_U1, q)) * (1.f - OWN(OW_C1, q) * OWN(OW_C1, q));
+        dgu[q] = g * ((z1 ? 0.f : OWN(OW_H1P, q)) - OWN(OW_C1, q)) * OWN(OW_U1, q) * (1.f - OWN(OW_U1, q));
         dht[q] = g;
         if (epl) dx_publish(X + xl.dcp1 + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcp1, 256, q, en, dcp); DB_OUT(a.g_dgp1, 512, q, 256 + en, dgu[q]);
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
     __syncthreads();
     // ================= GRU 1 'b' =================
-    DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, cur[q].h1p, cur[q].r1, cur[q].u1, dhp, a.g_dgp1)
+    DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, (z1 ? 0.f : OWN(OW_H1P, q)), OWN(OW_R1, q), OWN(OW_U1, q), dhp, a.g_dgp1)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
     __syncthreads();
     // ================= GRU 1 'c' -> d o0 =================
@@ -481,8 +495,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float g = dhA[q] + dIn_hA[q] + s[0][q];
-        const float dcp = g * (1.f - cur[q].uA) * (1.f - cur[q].cA * cur[q].cA);
-        dgu[q] = g * (cur[q].hAp - cur[q].cA) * cur[q].uA * (1.f - cur[q].uA);
+        const float dcp = g * (1.f - OWN(OW_UA, q)) * (1.f - OWN(OW_CA, q) * OWN(OW_CA, q));
+        dgu[q] = g * ((zA ? 0.f : OWN(OW_HAP, q)) - OWN(OW_CA, q)) * OWN(OW_UA, q) * (1.f - OWN(OW_UA, q));
         dht[q] = g;
         if (epl) dx_publish(X + xl.dcpa + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcpA, 256, q, en, dcp); DB_OUT(a.g_dgpA, 512, q, 256 + en, dgu[q]);
@@ -491,7 +505,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
     __syncthreads();
     // ================= attention GRU 'b' (the x part has 128 inputs: rows 4m + w of waves 0-3) =================
-    DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, cur[q].hAp, cur[q].rA, cur[q].uA, dhp, a.g_dgpA)
+    DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, (zA ? 0.f : OWN(OW_HAP, q)), OWN(OW_RA, q), OWN(OW_UA, q), dhp, a.g_dgpA)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
     __syncthreads();
     // ================= attention GRU 'c' -> d p2 (ReLU mask) =================
@@ -505,7 +519,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         dhA[q] = dhp[q] + s[1][q];
         if (wave < 4) {
-          const float dz2 = (cur[q].p2 > 0.f) ? tx[q] + s[0][q] : 0.f;
+          const float dz2 = (OWN(OW_P2, q) > 0.f) ? tx[q] + s[0][q] : 0.f;
           if (epl) dx_publish(X + xl.dz2 + erow[q] * 128 + en2, dz2, tag, rt);
           DB_OUT(a.g_dz2, 128, q, en2, dz2);
         }
@@ -525,7 +539,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       dx_reduce<1, RG>(acc, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        const float dz1 = (cur[q].p1 > 0.f) ? s[0][q] : 0.f;
+        const float dz1 = (OWN(OW_P1, q) > 0.f) ? s[0][q] : 0.f;
         if (epl) dx_publish(X + xl.dz1 + erow[q] * 256 + en, dz1, tag, rt);
         DB_OUT(a.g_dz1, 256, q, en, dz1);
       }
@@ -541,13 +555,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) dctxc[q] = s[0][q];
     }
-#pragma unroll
-    for (int q = 0; q < RL; ++q) cur[q] = nxt[q];
     // the rows fetched for step t - 1 have landed in every wave that issued them by now (twelve polls ago); this barrier publishes them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 #undef DB_CELL_B
+#undef OWN
 #undef DB_OUT
   // gradients of the initial states = the carries left after step 0 (tacotron.py:183-197: deepvoice feeds them from the speaker layers)
 #pragma unroll

@@ -149,6 +149,7 @@ struct taco_model {
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
   size_t dx_fold_n = 0;        // training shadow model: elements of the GRU-1 fold buffer (k_dx_fold), addressed by the index map as NP + 1 + i
   size_t dx_spkw = 0;          // 'simple': speaker rows of the attention GRU and of the folded GRU 1, [S][DXRB_N][256] (k_dx_rowbias)
+  int last_bptt = 0;           // the last decoder backward ran as the persistent launch (taco_debug_decoder_info out16[9])
   size_t dbx_pack = 0;         // training shadow model: the persistent BPTT kernel's rows (dbx_build_pack)
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
@@ -1963,6 +1964,7 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
   unsigned v[16];
   HIPCHK(hipMemcpy(v, m->d_err + 8, sizeof v, hipMemcpyDeviceToHost));
   for (int i = 0; i < 16; ++i) out16[i] = (int)v[i];
+  { unsigned b = 0; HIPCHK(hipMemcpy(&b, m->d_err + 40, sizeof b, hipMemcpyDeviceToHost)); out16[9] = m->last_bptt ? (int)b : 0; }
   out16[14] = m->cu_count;
   out16[15] = m->dx_pack ? 1 : 0;
   return 0;

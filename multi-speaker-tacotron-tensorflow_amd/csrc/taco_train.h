@@ -767,6 +767,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   // kernel's layout; the launch-per-stage loop below is the general path (other widths, 'simple', more than 64 rows)
   const bool persistent = x.t->bptt_persistent && w.tape256 && !S && L == 2 && np == 2 && (size_t)DXT_N * w.tstride < (1u << 31) &&
                           dbx_usable(m, B, T_in);
+  x.t->sm->last_bptt = persistent ? 1 : 0;
   if (persistent) {
     DbArgs a; memset(&a, 0, sizeof a);
     a.tape = w.tape256; a.tstride = w.tstride; a.tp_p2 = w.pz[1]; a.ld_p2 = Pz; a.tp_e = w.g_e; a.tp_alpha = w.alpha;

@@ -158,7 +158,8 @@ class Trainer(object):
         mh = C.c_void_p(self._lib.taco_train_model(self._h))
         v = (C.c_int * 16)()
         _lib.check(self._lib.taco_debug_decoder_info(mh, v))
-        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14])}
+        return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14]),
+                "bptt_protocol": int(v[9])}       # 0: the last decoder backward was the chain of per-stage launches
 
     def check_device_errors(self):
         """Synchronises and raises if a persistent kernel of the training forward gave up (outputs and gradients invalid)."""

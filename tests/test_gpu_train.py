@@ -421,6 +421,7 @@ def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     tr.check_device_errors()
     info = tr.decoder_engine_info()
     assert info["has_pack"] and info["protocol"] in (1, 2), info
+    assert (info["bptt_protocol"] in (1, 2)) == (model_type != "simple"), info      # 'simple' keeps the per-stage chain for the BPTT
     assert abs(float(losses[0]) - loss) < 2e-5
     assert maxabs(tr.mel_outputs.cpu().numpy(), out["mel"]) < 1e-4 and maxabs(tr.linear_outputs.cpu().numpy(), out["linear"]) < 1e-4
     assert maxabs(tr.alignments.cpu().numpy(), out["alignments"]) < 1e-4
@@ -438,6 +439,7 @@ def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
     tr.set_bptt_engine(False)                     # persistent forward, the decoder's BPTT as the chain of per-stage launches
     tr.forward_backward(ids, L, mt, lt, co, keep_outputs=True, speaker_id=spk)
     torch.cuda.synchronize()
+    assert tr.decoder_engine_info()["bptt_protocol"] == 0
     mid = tr.grad_dict()
     worst_b = sorted(((maxabs(got[k], mid[k]), k) for k in mid), reverse=True)
     print("persistent BPTT (k_decoder_bwd_xcd) vs per-stage BPTT on the same tape, worst tensors (absolute):", worst_b[:3], " |g| =", gn)
@@ -635,4 +637,36 @@ def test_whole_chip_bigru_scans_forward_tape_and_backward(B, T):
         want[b, :L, :3 * H] = gx[b, :L, :3 * H]
         want[b, :L, 3 * H:] = gx[b, :L, 3 * H:][::-1]
     assert maxabs(res[1]["dg"], want) < 2e-4 * max(1.0, float(np.abs(want).max()))
+    tr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("atype,B,T_in,n", [("bah_mon", 20, 150, 5), ("bah", 7, 300, 4), ("bah_mon", 64, 70, 3), ("bah_mon", 2, 600, 3)])
+def test_persistent_bptt_on_long_inputs_equals_the_per_stage_chain(atype, B, T_in, n):
+    """k_decoder_bwd_xcd on inputs whose positions no longer fit two per lane (the chunked normaliser-backward path), on all 64 rows, and on an
+    input too long for its LDS (T_in = 600 at one row per group still fits; the usable check falls back by itself otherwise): every
+    gradient tensor against the per-stage BPTT reading the same tape."""
+    import torch
+    import taco_amd
+    hp = O.OracleHParams(max_iters=8, attention_type=atype)
+    w = O.init_weights(hp, 1, 91)
+    T_out = n * hp.reduction_factor
+    ids, L = O.synthetic_inputs(B, T_in, 92, ragged=True)
+    rs = np.random.RandomState(93)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    tr = taco_amd.Trainer(to_product_hp(hp), w)
+    tr.forward_backward(ids, L, mt, lt, None)
+    info = tr.decoder_engine_info()
+    tr.check_device_errors()
+    assert info["protocol"] in (1, 2) and info["bptt_protocol"] in (1, 2), info
+    got = tr.grad_dict()
+    tr.set_bptt_engine(False)
+    tr.forward_backward(ids, L, mt, lt, None)
+    torch.cuda.synchronize()
+    assert tr.decoder_engine_info()["bptt_protocol"] == 0
+    ref = tr.grad_dict()
+    gn = np.sqrt(sum(float((ref[k] ** 2).sum()) for k in ref))
+    worst = sorted(((maxabs(got[k], ref[k]), k) for k in ref), reverse=True)
+    print("persistent vs per-stage BPTT, worst tensors (absolute):", worst[:3], " |g| =", gn)
+    assert worst[0][0] < 2e-5 * gn, worst[:4]
     tr.close()
