@@ -134,6 +134,7 @@ PROTOTYPES = {
     "taco_train_set_deterministic": (_I, [_P, _I]),
     "taco_train_set_exact_wgrad": (_I, [_P, _I]),
     "taco_train_set_bptt_engine": (_I, [_P, _I]),
+    "taco_train_set_exact_gemm": (_I, [_P, _I]),
     "taco_train_debug_bigru": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _S]),
     "taco_train_workspace_bytes": (_S, [_P, _I, _I, _I]),
     "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _S]),

@@ -22,6 +22,29 @@ __global__ __launch_bounds__(256) void k_pack_gather(const float* __restrict__ m
     arena[i] = o;
   }
 }
+// The split-bf16 packs of the training model (k_gemm_bf3 operands) from the live parameters: element e of the concatenated index
+// list belongs to the segment s with segs[s].start <= e < start + count and becomes hi = bf16(w), lo = bf16(w - hi) at position
+// e - start of the segment's two arrays (the same split pack_bf3 does on the host for inference).
+struct Bf3Seg { unsigned start, count; unsigned long long hi, lo; };   // [start, start + count) of the index list -> bf16 arrays at arena float offsets hi / lo
+__device__ __forceinline__ unsigned short bf16_rne_dev(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+__global__ __launch_bounds__(256) void k_bf3_gather(const unsigned* __restrict__ idx, const Bf3Seg* __restrict__ segs, int nseg, const float* __restrict__ P,
+                                                   float* __restrict__ arena, size_t n, unsigned NP) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((size_t)segs[mid].start <= e) lo = mid; else hi = mid - 1; }
+    const Bf3Seg sg = segs[lo];
+    const unsigned i = idx[e];
+    const float w = (i >= 1u && i <= NP) ? P[i - 1] : 0.f;
+    const unsigned short hb = bf16_rne_dev(w);
+    const unsigned short lb = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16));
+    const size_t k = e - sg.start;
+    reinterpret_cast<unsigned short*>(arena + sg.hi)[k] = hb;
+    reinterpret_cast<unsigned short*>(arena + sg.lo)[k] = lb;
+  }
+}
 // The concat projection folded into decoder GRU 1 (taco_model_finalize does it on the host, in double, for inference):
 //   F[z][j] = sum_k C[z][k] * G[k][j],  z = 0 .. Z (row Z: C = the projection's bias), j = 0 .. 3H-1,
 //   G = [gates kernel x rows (2H columns) | candidate kernel x rows (H columns)],  row Z, j < 2H additionally + gates bias[j].

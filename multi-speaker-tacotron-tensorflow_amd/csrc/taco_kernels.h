@@ -96,7 +96,7 @@ struct GemmArgs {
   float* out;             // [M, ldo]
   int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0;
   int t_begin, t_len, tiles_per_b;   // time-window mode (t_len > 0): rows (b, t_begin + i), i < t_len, for every batch row b
-  float* aux0; float* aux1;          // training tape (k_gemm DUAL only, nullable): highway H = relu(.) and T = sigmoid(.), [M, ldo]
+  float* aux0; float* aux1;          // training tape (DUAL only, nullable): highway H = relu(.) and T = sigmoid(.), [M, ldo]
   GemmVar v[16];          // one per blockIdx.z (conv-bank widths); by value so the fields arrive by scalar loads
 };
 
@@ -390,10 +390,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   struct { const float* x; const int* gather; const float* res; const float* rowvec; const int* rev_len; float* out;
-           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b; } a =
+           int ldx, M, T, Cin, cin_pad, mpw, act, ldres, ldrv, ldo, vec_ok, rev_col0, t_begin, t_len, tiles_per_b; float* aux0; float* aux1; } a =
       {a_in.x, a_in.gather, a_in.res, a_in.rowvec, a_in.rev_len, a_in.out, a_in.ldx, a_in.M, a_in.T, a_in.Cin, a_in.cin_pad,
-       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b};
-  PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out); PIN(a.rev_len);
+       a_in.mpw, a_in.act, a_in.ldres, a_in.ldrv, a_in.ldo, a_in.vec_ok, a_in.rev_col0, a_in.t_begin, a_in.t_len, a_in.tiles_per_b,
+       a_in.aux0, a_in.aux1};
+  PIN(a.x); PIN(a.gather); PIN(a.res); PIN(a.rowvec); PIN(a.out); PIN(a.rev_len); PIN(a.aux0); PIN(a.aux1);
   PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
   PIN(a.rev_col0); PIN(a.t_begin); PIN(a.t_len); PIN(a.tiles_per_b);
   GemmVar v = a_in.v[blockIdx.z];
@@ -642,6 +643,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
           const float Tg = taco_sigmoid(acc2[tm][tn][r] + bia2);
           const float xin = a.x[(size_t)rowv[r] * a.ldx + col];
           outc[(size_t)rowv[r] * a.ldo] = H * Tg + xin * (1.f - Tg);
+          if (a.aux0) { a.aux0[(size_t)rowv[r] * a.ldo + col] = H; a.aux1[(size_t)rowv[r] * a.ldo + col] = Tg; }     // training tape
         }
       } else {
         const float sc = esc[tn], sh = esh[tn];

@@ -149,6 +149,8 @@ struct taco_model {
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
   size_t dx_fold_n = 0;        // training shadow model: elements of the GRU-1 fold buffer (k_dx_fold), addressed by the index map as NP + 1 + i
   size_t dx_spkw = 0;          // 'simple': speaker rows of the attention GRU and of the folded GRU 1, [S][DXRB_N][256] (k_dx_rowbias)
+  // training shadow model: split-bf16 packs as index maps (pack_bf3): element e of the concatenated list copies parameter bf3_idx[e] - 1
+  std::vector<unsigned> bf3_idx; std::vector<Bf3Seg> bf3_segs;
   int last_bptt = 0;           // the last decoder backward ran as the persistent launch (taco_debug_decoder_info out16[9])
   size_t dbx_pack = 0;         // training shadow model: the persistent BPTT kernel's rows (dbx_build_pack)
   size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
@@ -283,6 +285,7 @@ static unsigned short bf16_rne_host(float x) {
 static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size_t* hi_out, size_t* lo_out, int* K16_out, int* cp16_out) {
   const int cp16 = rup(cin, 32), K16 = kw * cp16 / 16, NT = cdiv(N, 32);   // multiple of 32: k_gemm_bf3 walks k16 groups in pairs
   std::vector<unsigned short> hi((size_t)NT * K16 * 2 * 32 * 8, 0), lo(hi.size(), 0);
+  std::vector<unsigned> idx(m->tp ? hi.size() : 0, 0u);
   for (int nt = 0; nt < NT; ++nt)
     for (int k16 = 0; k16 < K16; ++k16)
       for (int h = 0; h < 2; ++h)
@@ -291,6 +294,8 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
             const int k = 16 * k16 + 8 * h + e, tap = k / cp16, c = k % cp16, n = 32 * nt + j;
             if (c < cin && n < N) {
               const float w = W[((size_t)tap * cin + c) * N + n];
+              const size_t oi = ((((size_t)k16 * NT + nt) * 2 + h) * 32 + j) * 8 + e;
+              if (m->tp) { idx[oi] = (unsigned)w; continue; }       // shadow model: `w` is 1 + a parameter index (k_bf3_gather splits the live value)
               const unsigned short hb = bf16_rne_host(w);
               unsigned hu = (unsigned)hb << 16; float hf; memcpy(&hf, &hu, 4);
               const size_t o = ((((size_t)k16 * NT + nt) * 2 + h) * 32 + j) * 8 + e;   // k16-major: see the layout note in taco_kernels.h
@@ -303,6 +308,10 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
     return arena_put(m, f.data(), f.size());
   };
   *hi_out = put(hi); *lo_out = put(lo); *K16_out = K16; *cp16_out = cp16;
+  if (m->tp) {
+    m->bf3_segs.push_back(Bf3Seg{(unsigned)m->bf3_idx.size(), (unsigned)idx.size(), (unsigned long long)(*hi_out - 1), (unsigned long long)(*lo_out - 1)});
+    m->bf3_idx.insert(m->bf3_idx.end(), idx.begin(), idx.end());
+  }
 }
 
 // W16 pack of rows [r0, r0+K) and columns [c0, c0+N) of a row-major [*, ldw] matrix.

@@ -39,6 +39,7 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
+  unsigned* d_bf3_idx = nullptr; Bf3Seg* d_bf3_segs = nullptr;   // index list and segment table of the split-bf16 packs (k_bf3_gather)
   float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
   // (ordered on the step's stream); null = statistics of this rank's rows only
@@ -63,6 +64,7 @@ static ConvL make_conv_T(taco_model* m, const float* W, int kw, int cin, int N) 
   ConvL L; L.kw = kw; L.cin = N; L.N = cin;
   int Kq, NT;
   L.wp = pack_w32(m, WT.data(), kw, N, cin, &L.cin_pad, &Kq, &NT);
+  pack_bf3(m, WT.data(), kw, N, cin, &L.bh, &L.bl, &L.K16, &L.cin_pad16);
   add_var(m, L, 0);
   m->hvars[L.var_index].padl = kw - 1 - (kw - 1) / 2;
   return L;
@@ -84,7 +86,7 @@ static SkW pack_w16_T(taco_model* m, const float* W, int rows, int cols) {   // 
   return pack_w16(m, Tt.data(), rows, 0, cols, 0, rows, nullptr);
 }
 static ConvL conv_noBN(taco_model* m, const ConvL& L, int coff) {
-  ConvL F = L; F.bns = F.bnb = 0; F.bh = F.bl = F.bh2 = F.bl2 = 0; F.var_index = -1;
+  ConvL F = L; F.bns = F.bnb = 0; F.var_index = -1;      // (the split-bf16 planes are the same weights: kept)
   add_var(m, F, coff);
   return F;
 }
@@ -109,6 +111,7 @@ static void build_cbhg_T(taco_model* m, const Cbhg& c, const std::string& sc, Cb
     ConvL L; L.kw = 1; L.cin = 2 * D; L.N = D;
     int Kq, NT;
     L.wp = pack_w32(m, cat.data(), 1, 2 * D, D, &L.cin_pad, &Kq, &NT);
+    pack_bf3(m, cat.data(), 1, 2 * D, D, &L.bh, &L.bl, &L.K16, &L.cin_pad16);
     add_var(m, L, 0);
     t.hw_d.push_back(L);
   }
@@ -129,6 +132,7 @@ static void build_cbhg_T(taco_model* m, const Cbhg& c, const std::string& sc, Cb
   ConvL X; X.kw = 1; X.cin = 6 * H; X.N = I;
   int Kq, NT;
   X.wp = pack_w32(m, WxT.data(), 1, 6 * H, I, &X.cin_pad, &Kq, &NT);
+  pack_bf3(m, WxT.data(), 1, 6 * H, I, &X.bh, &X.bl, &X.K16, &X.cin_pad16);
   add_var(m, X, 0);
   t.xproj_d = X;
 }
@@ -234,10 +238,12 @@ static void run_embed_bwd(hipStream_t st, const float* dx, const int* ids, float
   if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * E), 0, st, dx, ids, dE, M, E, V);
   else hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)M * E), 0, st, dx, ids, dE, M, E);
 }
+static int g_dgrad_exact = 0;     // taco_train_set_exact_gemm(t, 2): data gradients on the exact-fp32 MFMA, forward GEMMs split-bf16 (A/B hook)
 // y = x . W^T style data gradient through k_gemm: out = conv_T(dy) (+ res)
 static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const float* dy, int lddy, int M, int T, float* out, int ldo,
                      const float* res = nullptr, int ldres = 0) {
   GemmCall g; g.x = dy; g.ldx = lddy; g.M = M; g.T = T; g.out = out; g.ldo = ldo; g.res = res; g.ldres = ldres;
+  if (g_dgrad_exact) { ConvL E = Ld; E.bh = E.bl = 0; return run_gemm(m, st, &E, 1, false, g); }
   return run_gemm(m, st, &Ld, 1, false, g);
 }
 

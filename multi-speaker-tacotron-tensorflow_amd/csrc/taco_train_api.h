@@ -19,9 +19,18 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
   t->NP = off;
   if (off >= (1u << 24)) { taco_model_destroy(sm); delete t; return fail(TACO_ERR_UNSUPPORTED, "more than 2^24 parameters"); }
   sm->tp = &t->tp;
-  sm->bf3 = 0;                        // training keeps every GEMM on the exact-fp32 matrix-core path
+  sm->bf3 = 1;                        // finalize builds the split-bf16 packs (as index lists) next to the fp32 ones ...
   rc = taco_model_finalize(sm);
   if (rc != 0) { taco_model_destroy(sm); delete t; return rc; }
+  sm->bf3 = 0;                        // ... and the step starts on the exact-fp32 MFMA (k_gemm): taco_train_set_exact_gemm(t, 0) switches
+  if (!sm->bf3_idx.empty()) {
+    if (hipMalloc((void**)&t->d_bf3_idx, sm->bf3_idx.size() * sizeof(unsigned)) != hipSuccess ||
+        hipMalloc((void**)&t->d_bf3_segs, sm->bf3_segs.size() * sizeof(Bf3Seg)) != hipSuccess ||
+        hipMemcpy(t->d_bf3_idx, sm->bf3_idx.data(), sm->bf3_idx.size() * sizeof(unsigned), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(t->d_bf3_segs, sm->bf3_segs.data(), sm->bf3_segs.size() * sizeof(Bf3Seg), hipMemcpyHostToDevice) != hipSuccess) {
+      taco_model_destroy(sm); delete t; return fail(TACO_ERR_HIP, "split-bf16 index list allocation failed");
+    }
+  }
   t->arena_n = sm->arena_n;
   if (hipMalloc((void**)&t->d_map, t->arena_n * sizeof(float)) != hipSuccess ||
       hipMemcpy(t->d_map, sm->darena, t->arena_n * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) {
@@ -41,6 +50,8 @@ void taco_train_destroy(taco_train* t) {
   if (!t) return;
   if (t->d_map) (void)hipFree(t->d_map);
   if (t->d_fold) (void)hipFree(t->d_fold);
+  if (t->d_bf3_idx) (void)hipFree(t->d_bf3_idx);
+  if (t->d_bf3_segs) (void)hipFree(t->d_bf3_segs);
   if (t->sm) taco_model_destroy(t->sm);
   delete t;
 }
@@ -56,6 +67,12 @@ int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int w
 int taco_train_set_exact_wgrad(taco_train* t, int on) {
   if (!t) return fail(TACO_ERR_ARG, "null argument");
   g_wgrad_bf3 = on ? 0 : 1;           // process-wide switch (an A/B and test hook, not a per-trainer setting)
+  return 0;
+}
+int taco_train_set_exact_gemm(taco_train* t, int on) {
+  if (!t) return fail(TACO_ERR_ARG, "null argument");
+  t->sm->bf3 = on == 1 ? 0 : 1;
+  g_dgrad_exact = on == 2 ? 1 : 0;
   return 0;
 }
 int taco_train_set_bptt_engine(taco_train* t, int persistent) {
@@ -144,6 +161,9 @@ int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params) {
   }
   hipLaunchKernelGGL(k_pack_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, t->d_map, d_params, t->sm->darena, t->arena_n, (unsigned)t->NP,
                      (const float*)t->d_fold, (unsigned)sm->dx_fold_n);
+  if (t->d_bf3_idx)                     // the same weights as split-bf16 planes (the map holds zeros there: this runs after the fp32 gather)
+    hipLaunchKernelGGL(k_bf3_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned*)t->d_bf3_idx, (const Bf3Seg*)t->d_bf3_segs,
+                       (int)sm->bf3_segs.size(), d_params, t->sm->darena, sm->bf3_idx.size(), (unsigned)t->NP);
   if (t->sm->hp.attention_type == 1)    // bah_norm: the pack holds v_hat = g * v / |v| (computed, not copied)
     hipLaunchKernelGGL(k_vnorm_fold, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, d_params + t->poff.at("attention/attention_v"),
                        d_params + t->poff.at("attention/attention_g"), t->sm->darena + (t->sm->att_v - 1), t->sm->hp.attention_size);

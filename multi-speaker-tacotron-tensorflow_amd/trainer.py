@@ -144,6 +144,14 @@ class Trainer(object):
         if getattr(self, "_graph", None) is not None:
             self._graph = None          # a captured step keeps the engine it was captured with
 
+    def set_exact_gemm(self, on=True):
+        """True (default): feed-forward and data-gradient GEMMs on the exact-fp32 MFMA.  False: on the split-bf16 matrix-core kernels of
+        inference (k_gemm_bf3; ~2^-17 per product; the weight planes follow the parameters through taco_train_refresh): 13 % off the
+        C4-shard step, gradients within ~1e-3 of the exact engine's norm.  2: forward split-bf16, data gradients exact (A/B hook)."""
+        _lib.check(self._lib.taco_train_set_exact_gemm(self._h, int(on)))
+        if getattr(self, "_graph", None) is not None:
+            self._graph = None
+
     def set_bptt_engine(self, persistent=True):
         """True (default): back-propagation through the decoder loop is ONE whole-chip launch (csrc/taco_decoder_bwd_xcd.h) whenever the
         forward ran on the persistent decoder; False: the chain of per-stage launches (round 1's engine; A/B and test hook)."""

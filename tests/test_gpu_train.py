@@ -670,3 +670,37 @@ def test_persistent_bptt_on_long_inputs_equals_the_per_stage_chain(atype, B, T_i
     print("persistent vs per-stage BPTT, worst tensors (absolute):", worst[:3], " |g| =", gn)
     assert worst[0][0] < 2e-5 * gn, worst[:4]
     tr.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("atype,B", [("bah_mon", 9), ("bah", 20)])
+def test_split_bf16_training_gemms_track_the_exact_engine(atype, B):
+    """Opt-in speed mode of the step (Trainer.set_exact_gemm(False)): the feed-forward GEMMs and their data gradients on the split-bf16
+    kernels of inference, weight planes re-split on the device after every optimizer step.  Against the default exact-fp32 engine on
+    the same inputs: loss to 1e-5, the gradient as a whole to 3e-3 of its norm (measured 1.2e-3 at 9 rows: the ~1e-5 relative product
+    error is amplified by the BatchNorm backward's cancellations, and a ReLU / max-pool near-tie may resolve differently, which moves
+    single tensors by more), and the planes follow a parameter update."""
+    import torch
+    import taco_amd
+    hp = O.OracleHParams(max_iters=8, attention_type=atype)
+    w = O.init_weights(hp, 1, 101)
+    T_in, T_out = 14, 8 * hp.reduction_factor
+    ids, L = O.synthetic_inputs(B, T_in, 102, ragged=True)
+    rs = np.random.RandomState(103)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    tr = taco_amd.Trainer(to_product_hp(hp), w)
+    le = tr.forward_backward(ids, L, mt, lt, None).cpu().numpy().copy()
+    ref = tr.grad_dict()
+    tr.set_exact_gemm(False)
+    lf = tr.forward_backward(ids, L, mt, lt, None).cpu().numpy().copy()
+    got = tr.grad_dict()
+    gn = np.sqrt(sum(float((ref[k] ** 2).sum()) for k in ref))
+    e2 = np.sqrt(sum(float(((got[k] - ref[k]) ** 2).sum()) for k in ref))
+    print("split-bf16 vs exact GEMMs: loss %.3e, gradient |diff| / |g| = %.2e" % (abs(lf[0] - le[0]), e2 / gn))
+    assert abs(lf[0] - le[0]) < 1e-5 and e2 < 3e-3 * gn
+    step, _ = tr.train_step(ids, L, mt, lt, None)          # the planes are regenerated from the updated parameters
+    l1 = tr.forward_backward(ids, L, mt, lt, None, backward=False).cpu().numpy().copy()
+    tr.set_exact_gemm(True)
+    l2 = tr.forward_backward(ids, L, mt, lt, None, backward=False).cpu().numpy().copy()
+    assert step == 1 and abs(l1[0] - l2[0]) < 1e-5 and l1[0] < lf[0]
+    tr.close()
