@@ -309,7 +309,8 @@ int taco_debug_decoder_info(taco_model* m, int* out16);
 /* phase timeline of group 0 / member 0 for the first 8 decoder steps (scan: steps 8-15): enable bit 0 = launches enqueued from now
  * on write their stamps (the buffer is allocated on first use and lives as long as the model, because captured plans keep its
  * address; drop plans captured under the other setting); out (nullable) receives [8][16] shader-clock stamps of the decoder, or,
- * with enable bit 1, of the post-net scan (k_bigru_xcd has its own half of the buffer) */
+ * with enable bit 1, of the post-net scan (its own third of the buffer), or, with bit 2, of the persistent BPTT of a training
+ * shadow model (k_decoder_bwd_xcd, steps 8-15 of its launch) */
 int taco_debug_decoder_trace(taco_model* m, int enable, long long* out);
 
 /* timing hook: on = 1 leaves the recurrent scan launches of both CBHGs out of every forward / stage call enqueued from now on

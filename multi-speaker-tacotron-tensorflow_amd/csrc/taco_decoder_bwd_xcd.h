@@ -67,7 +67,7 @@ __host__ __device__ inline size_t db_lds_floats(int RG, int T_in) {
   n += (size_t)TS * DS + (size_t)T_in * DC;        // keys block, values block
   n += 2 * 3 * (size_t)Tpad;                       // raw scores, alignments of the step and of the step before, double buffered
   n += 6 * (size_t)Tpad;                           // da, p, cp, ss, de, d alpha carry
-  n += 3 * 64 + (size_t)DX_NW * 64 + 64;           // q + b, v, scratch; reduction partials; control words
+  n += 5 * 64 + (size_t)DX_NW * 64 + 64;           // q + b, v, b, the tape's q rows (double buffered); reduction partials; control words
   return n;
 }
 
@@ -84,7 +84,7 @@ struct DbArgs {
   float* g_dz1; float* g_dz2; float* g_dq; float* g_de; float* g_dctx;                                     // [R, 256], [R, 128], [R, 256], [R, T_in], [R, 256]
   float* d_att_init; float* d_h10; float* d_h20;       // [B, 256] or null
   float* dsb_acc;                                      // [B] or null: d attention_score_bias per row (summed by the host)
-  unsigned long long* xbuf; unsigned* ctl; unsigned* err;
+  unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T_in, n, rM, att_type, force_wt;
 };
 
@@ -104,6 +104,90 @@ __device__ __forceinline__ void db_pass512(const float (&W)[NW], const float* x,
     }
   }
 }
+// inclusive SUFFIX sum over the wave (lane l: sum over lanes >= l) on DPP: row_shl inside the rows of 16, the rows above added as
+// wave-uniform scalars.  Never total - prefix: the tail of these sums is many orders below the head (cumprod(1 - p)).
+__device__ __forceinline__ float db_rscan(float v) {
+  float t = v + DX_DPPZ(v, 0x101, 0xF, 0xF);
+  t += DX_DPPZ(v, 0x102, 0xF, 0xF);
+  t += DX_DPPZ(v, 0x103, 0xF, 0xF);
+  t += DX_DPPZ(t, 0x104, 0xF, 0xF);
+  t += DX_DPPZ(t, 0x108, 0xF, 0xF);
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 16)), r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 32)),
+              r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 48));
+  const int row = (int)(threadIdx.x & 63) >> 4;
+  return t + (row == 0 ? r1 + r2 + r3 : row == 1 ? r2 + r3 : row == 2 ? r3 : 0.f);
+}
+// Normaliser backward of one row by ONE wave in registers (the mirror of dx_normalise: lane = `cnt` <= CMAX consecutive positions from
+// j0): da = gradient of the step's alignments -> de = gradient of the raw scores, dac = gradient of the previous alignments (the
+// carry of the recurrence; zero for softmax).  Returns the row's d score_bias.  Arithmetic of k_attention_bwd (through safe_cumprod /
+// cumsum and both clips, as tf.gradients does) on the forward kernel's intrinsics.
+template <int CMAX>
+__device__ __forceinline__ float db_normalise_bwd(const float* er, const float* alp, const float* al, const float* da, float* de, float* dac,
+                                                  int j0, int cnt, int att_type, float sbias) {
+  float dav[CMAX];
+#pragma unroll
+  for (int i = 0; i < CMAX; ++i) dav[i] = i < cnt ? da[j0 + i] : 0.f;
+  if (att_type != 2) {   // softmax: de_j = alpha_j (da_j - sum_k alpha_k da_k)
+    float av[CMAX], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) { av[i] = i < cnt ? al[j0 + i] : 0.f; dot = fmaf(av[i], dav[i], dot); }
+    dot = dx_allsum(dot);
+#pragma unroll
+    for (int i = 0; i < CMAX; ++i) if (i < cnt) { de[j0 + i] = av[i] * (dav[i] - dot); dac[j0 + i] = 0.f; }
+    return 0.f;
+  }
+  float p[CMAX], pv[CMAX], ex[CMAX], run = 0.f;
+#pragma unroll
+  for (int i = 0; i < CMAX; ++i) {
+    p[i] = dx_sigmoid_fast((i < cnt ? er[j0 + i] : 0.f) + sbias);
+    pv[i] = i < cnt ? alp[j0 + i] : 0.f;
+    ex[i] = run;
+    if (i < cnt) run += 0.6931471805599453f * __builtin_amdgcn_logf(fminf(fmaxf(1.f - p[i], 1.17549435e-38f), 1.f));
+  }
+  const float off = dx_scan(run) - run;
+  float cp[CMAX], rc[CMAX], ss[CMAX], run2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CMAX; ++i) {
+    cp[i] = __builtin_amdgcn_exp2f(1.4426950408889634f * (ex[i] + off));
+    rc[i] = __builtin_amdgcn_rcpf(fminf(fmaxf(cp[i], 1e-10f), 1.f));
+    if (i < cnt) run2 = fmaf(pv[i], rc[i], run2);
+    ss[i] = run2;
+  }
+  const float off2 = dx_scan(run2) - run2;
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < CMAX; ++i) { ss[i] += off2; if (i < cnt) tot = fmaf(dav[i] * p[i], cp[i], tot); }
+  float suffix = db_rscan(tot) - tot;             // the later lanes' blocks
+  float dL[CMAX], dpd[CMAX], dLsum = 0.f;
+#pragma unroll
+  for (int i = CMAX - 1; i >= 0; --i) {
+    dL[i] = 0.f; dpd[i] = 0.f;
+    if (i < cnt) {
+      suffix = fmaf(dav[i] * p[i], cp[i], suffix);
+      float dcp = dav[i] * p[i] * ss[i];
+      if (cp[i] >= 1e-10f && cp[i] <= 1.f) dcp -= suffix * pv[i] * rc[i] * rc[i];
+      dL[i] = dcp * cp[i];
+      dpd[i] = dav[i] * cp[i] * ss[i];
+      dac[j0 + i] = suffix * rc[i];
+      dLsum += dL[i];
+    }
+  }
+  float suf2 = db_rscan(dLsum) - dLsum, dsb = 0.f;
+#pragma unroll
+  for (int i = CMAX - 1; i >= 0; --i) {
+    if (i < cnt) {
+      const float dlg = suf2;                     // reverse EXCLUSIVE sum of dL
+      suf2 += dL[i];
+      const float xj = 1.f - p[i];
+      float dp = dpd[i];
+      if (xj >= 1.17549435e-38f && xj <= 1.f) dp -= dlg * __builtin_amdgcn_rcpf(xj);
+      const float dej = dp * p[i] * xj;
+      de[j0 + i] = dej; dsb += dej;
+    }
+  }
+  return dx_allsum(dsb);
+}
+
 template <int RG>
 __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float dx_smem[];
@@ -124,8 +208,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   float* rows = Vc + (size_t)T * DC;          // [2][3][Tpad]: e, alpha(t+1 slot = this step's), alpha(t slot = previous)
   float* da = rows + 6 * Tpad;
   float* pp = da + Tpad; float* cp = pp + Tpad; float* ss = cp + Tpad; float* de = ss + Tpad; float* dac = de + Tpad;
-  float* qv = dac + Tpad; float* vv = qv + 64; float* scr = vv + 64;
-  float* cpart = scr + 64;                    // [DX_NW][64]
+  float* qv = dac + Tpad; float* vv = qv + 64; float* bq = vv + 64;
+  float* qraw = bq + 64;                      // [2][64] processed query of the member's channels (tape), one step ahead
+  float* cpart = qraw + 128;                  // [DX_NW][64]
   int* ictl = reinterpret_cast<int*>(cpart + DX_NW * 64);
 
   dx_gu32* errw = (dx_gu32*)a.err;
@@ -141,6 +226,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
   const int brow = row0 + arow;
   const int browc = min(brow, a.B - 1);
+  const bool tracer = a.trace && group == 0 && member == 0 && tid == 0;
+#define DB_STAMP(slot)                                                                                                   \
+  do {                                                                                                                   \
+    const int ks_ = n - 1 - t - 8;         /* steps 8 .. 15 of the launch: past the start-up transients */                \
+    if (tracer && ks_ >= 0 && ks_ < DX_TRACE_STEPS) a.trace[ks_ * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
 
   float W[DB_NREG];
   {
@@ -168,7 +259,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   for (int i = tid; i < 2 * RG * 384 + 2 * DX_NW * 128; i += DX_NT) dmb[i] = 0.f;     // (and the own-column buffers behind them)
   for (int j = tid; j < Tpad; j += DX_NT) { da[j] = 0.f; pp[j] = 0.f; cp[j] = 0.f; ss[j] = 0.f; de[j] = 0.f; dac[j] = 0.f; }
   for (int j = tid; j < 6 * Tpad; j += DX_NT) rows[j] = 0.f;
-  if (tid < DS) vv[tid] = a.att_v[cb * DS + tid];
+  if (tid < DS) { vv[tid] = a.att_v[cb * DS + tid]; bq[tid] = a.att_b ? a.att_b[cb * DS + tid] : 0.f; }
+  if (tid < 128) qraw[tid] = 0.f;
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
   __syncthreads();
 
@@ -184,7 +276,6 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     ev[q] = epl && (row0 + erow[q] < a.B);
     trow[q] = (unsigned)min(row0 + erow[q], a.B - 1) * (unsigned)n;
   }
-  const unsigned tstr = (unsigned)a.tstride;
   // Own-column tape values of a step -- u, c, r and the previous state of the three cells, both prenet outputs, for the RG rows of
   // the wave's column: OW_N * RG scalars per wave -- are gathered one step ahead by ONE LDS-direct load per 64 of them (each lane
   // supplies the address of its (value, row) pair), so neither the values in flight nor the ones in use occupy registers.
@@ -219,12 +310,16 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   };
   // rows needed whole, one step ahead, straight into LDS: dmel_t (waves 0..RG-1), e_t / alpha_{t+1} / alpha_t of the member's row
   const unsigned dmb_lds = (unsigned)(size_t)(dx_lds_float*)dmb, rows_lds = (unsigned)(size_t)(dx_lds_float*)rows;
+  const unsigned qraw_lds = (unsigned)(size_t)(dx_lds_float*)qraw;
   auto fetch_rows = [&](int t, int buf) {
     if (wave < RG) {
       const float* src = a.dmel + ((size_t)min(row0 + wave, a.B - 1) * n + t) * a.rM;
       for (int j0 = 0; j0 < a.rM; j0 += 64)
         dx_load_lds4(src + min(j0 + lane, a.rM - 1), __builtin_amdgcn_readfirstlane(dmb_lds + (unsigned)((buf * RG + wave) * 384 + j0) * 4u));
     }
+    if (wave == DX_NW - 1 && lane < DS)       // the processed query W_q h_att(t) of the member's score channels
+      dx_load_lds4(a.tape + (size_t)DXT_Q * a.tstride + ((size_t)browc * n + t) * DX_W + cb * DS + lane,
+                   __builtin_amdgcn_readfirstlane(qraw_lds + (unsigned)(buf * 64) * 4u));
     const float* se = a.tp_e + ((size_t)browc * n + t) * T;
     const float* sa = a.tp_alpha + ((size_t)browc * (n + 1) + t + 1) * T;
     const float* sp = a.tp_alpha + ((size_t)browc * (n + 1) + t) * T;
@@ -251,6 +346,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     const int buf = (n - 1 - t) & 1;
     int tid = tid_outer, lane = lane_outer;
     asm volatile("" : "+v"(tid), "+v"(lane));
+    DB_STAMP(0);
     if (t > 0) { fetch_own(t - 1, buf ^ 1); fetch_rows(t - 1, buf ^ 1); }
     const float* ow = own + (buf * DX_NW + wave) * 128;
 #define OWN(v, q) ow[(v) * RG + erow[q]]
@@ -282,6 +378,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(1);
     // a cell's parts 'b' and 'c' as two stages; CX/CH/GX/GH: register bases, VC/VG: LDS vectors, XG: gate-gradient exchange
 #define DB_CELL_B(CX, CH, VC, XG, HP, RR, UU, DHP, GOUT)                                                     \
     {                                                                                                        \
@@ -304,6 +401,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, (z2 ? 0.f : OWN(OW_H2P, q)), OWN(OW_R2, q), OWN(OW_U2, q), dhp, a.g_dgp2)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(2);
     // ================= GRU 2 'c' -> residual -> GRU 1 'a' =================
     {
       float acc[2][RG], s[2][RL];
@@ -325,10 +423,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(3);
     // ================= GRU 1 'b' =================
     DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, (z1 ? 0.f : OWN(OW_H1P, q)), OWN(OW_R1, q), OWN(OW_U1, q), dhp, a.g_dgp1)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(4);
     // ================= GRU 1 'c' -> d o0 =================
     {
       float acc[2][RG], s[2][RL];
@@ -346,6 +446,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(5);
     // ================= concat projection^T: d h_att (kept), d ctx -> exchange =================
     float dIn_hA[RL];
     {
@@ -364,6 +465,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(6);
     // ================= attention backward of the member's row =================
     {  // d alpha partial over the member's value-channel block: sum_c dctx[asl*DC + c] * V[j][c], lanes over positions
       const float* dcx = st + arow * DBS_LD + DBS_DCTX + asl * DC;
@@ -394,9 +496,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       }
     }
     __syncthreads();
-    if (wave == 0) {   // normaliser backward, redundantly on each member of the row (the arithmetic of k_attention_bwd)
+    DB_STAMP(7);
+    if (wave == 0) {   // normaliser backward, redundantly on each member of the row
       const int C = (T + 63) >> 6, j0 = lane * C, j1 = min(j0 + C, T);
-      if (a.att_type == 2) {
+      if (C <= 2) dsb_row += db_normalise_bwd<2>(er, alp, al, da, de, dac, j0, max(j1 - j0, 0), a.att_type, sbias);
+      else if (C <= 4) dsb_row += db_normalise_bwd<4>(er, alp, al, da, de, dac, j0, max(j1 - j0, 0), a.att_type, sbias);
+      else if (a.att_type == 2) {   // long inputs: through LDS scratch (the arithmetic of k_attention_bwd as it stands)
         float run = 0.f;
         for (int j = j0; j < j1; ++j) {
           const float pj = taco_sigmoid(er[j] + sbias);
@@ -448,24 +553,32 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         for (int j = j0; j < j1; ++j) { de[j] = al[j] * (da[j] - dot); dac[j] = 0.f; }
       }
     }
-    // the processed query of the member's score channels (+ attention_b): from the tape
-    if (tid < DS) qv[tid] = a.tape[(unsigned)DXT_Q * tstr + ((unsigned)browc * (unsigned)n + (unsigned)t) * DX_W + cb * DS + tid] + (a.att_b ? a.att_b[cb * DS + tid] : 0.f);
+    // the processed query of the member's score channels (+ attention_b): from the tape, fetched one step ahead
+    if (tid < DS) qv[tid] = qraw[buf * 64 + tid] + bq[tid];
     __syncthreads();
+    DB_STAMP(8);
     {
       const int p0 = asl * TP;
       if (tid < TP && p0 + tid < T && brow < a.B) a.g_de[((size_t)brow * n + t) * T + p0 + tid] = de[p0 + tid];
     }
-    {  // d q partial of the member's (channel block, position block): dq_c = v_c sum_j de_j (1 - tanh^2(K_jc + q_c)); wave w: channels
-       // w, w + 8, ... of the block, lanes over positions
-      for (int c = wave; c < DS; c += DX_NW) {
-        float s = 0.f;
-        const float qc = qv[c];
-        for (int j = lane; j < psn; j += 64) {
-          const float th = taco_tanh_fast(Kc[(size_t)j * DS + c] + qc);
-          s = fmaf(de[ps0 + j], 1.f - th * th, s);
-        }
-        s = wave_sum(s);
-        if (lane == 0) dx_publish(X + xl.dq + (size_t)(arow * Pp + pb) * 256 + cb * DS + c, s * vv[c], tag, rt);
+    {  // d q partial of the member's (channel block, position block): dq_c = v_c sum_j de_j (1 - tanh^2(K_jc + q_c)).  Thread = (channel c,
+       // position residue pc): NPC = 512 / DS residues side by side, so a wave reads consecutive channels of two or one key rows; the
+       // NPC partials of a channel meet in LDS (no cross-lane reduction on the chain)
+      constexpr int NPC = DX_NT / DS;
+      const int c = tid % DS, pc = tid / DS;
+      const float qc = qv[c];
+      float s = 0.f;
+      for (int j = pc; j < psn; j += NPC) {
+        const float th = taco_tanh_fast(Kc[(size_t)j * DS + c] + qc);
+        s = fmaf(de[ps0 + j], 1.f - th * th, s);
+      }
+      cpart[pc * DS + c] = s;
+      __syncthreads();
+      if (tid < DS) {
+        float tot = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) tot += cpart[k * DS + tid];
+        dx_publish(X + xl.dq + (size_t)(arow * Pp + pb) * 256 + cb * DS + tid, tot * vv[tid], tag, rt);
       }
     }
     {  // gather d q of every row: sum over the Pp position blocks
@@ -485,6 +598,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       }
     }
     __syncthreads();
+    DB_STAMP(9);
     if (asl == 0 && tid < 256 && brow < a.B) a.g_dq[((size_t)brow * n + t) * 256 + tid] = st[arow * DBS_LD + DBS_DQ + tid];
     // ================= d h_att += d q . Wq^T -> attention GRU 'a' =================
     {
@@ -504,10 +618,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(10);
     // ================= attention GRU 'b' (the x part has 128 inputs: rows 4m + w of waves 0-3) =================
     DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, (zA ? 0.f : OWN(OW_HAP, q)), OWN(OW_RA, q), OWN(OW_UA, q), dhp, a.g_dgpA)
     dx_gather<RG, 512, false, DBS_LD>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(11);
     // ================= attention GRU 'c' -> d p2 (ReLU mask) =================
     {
       float acc[2][RG], s[2][RL];
@@ -527,6 +643,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 128, false, DBS_LD>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(12);
     // ================= prenet layer 2^T, ReLU mask of layer 1 =================
     {
       float acc[1][RG], s[1][RL];
@@ -546,6 +663,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
     dx_gather<RG, 256, false, DBS_LD>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
     __syncthreads();
+    DB_STAMP(13);
     // ================= prenet layer 1 (context rows)^T: the gradient of context(t - 1) =================
     {
       float acc[1][RG], s[1][RL];
@@ -555,11 +673,13 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) dctxc[q] = s[0][q];
     }
+    DB_STAMP(14);
     // the rows fetched for step t - 1 have landed in every wave that issued them by now (twelve polls ago); this barrier publishes them
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 #undef DB_CELL_B
+#undef DB_STAMP
 #undef OWN
 #undef DB_OUT
   // gradients of the initial states = the carries left after step 0 (tacotron.py:183-197: deepvoice feeds them from the speaker layers)

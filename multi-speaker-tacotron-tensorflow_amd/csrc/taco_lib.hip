@@ -1340,7 +1340,7 @@ static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int 
   const int RG = dx_rows_per_group(m, B);
   a.wpack = AP(m, m->dbx_pack);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
-  a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err;
+  a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + 2 * DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
   a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
   a.force_wt = m->dx_mode == 2 ? 1 : 0;
   HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));
@@ -1982,9 +1982,9 @@ int taco_debug_decoder_trace(taco_model* m, int enable, long long* out) {
   if (!m || !m->finalized) return fail(TACO_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(m->device));
   const size_t half = (size_t)DX_TRACE_STEPS * DX_TRACE_SLOTS * sizeof(long long);
-  if ((enable & 1) && !m->d_trace) { HIPCHK(hipMalloc((void**)&m->d_trace, 2 * half)); HIPCHK(hipMemset(m->d_trace, 0, 2 * half)); }
-  // enable bit 1 selects the scan's half of the buffer for the read-back
-  if (out && m->d_trace) HIPCHK(hipMemcpy(out, (const char*)m->d_trace + ((enable & 2) ? half : 0), half, hipMemcpyDeviceToHost));
+  if ((enable & 1) && !m->d_trace) { HIPCHK(hipMalloc((void**)&m->d_trace, 3 * half)); HIPCHK(hipMemset(m->d_trace, 0, 3 * half)); }
+  // enable bit 1 selects the scan's third of the buffer for the read-back, bit 2 the persistent BPTT's
+  if (out && m->d_trace) HIPCHK(hipMemcpy(out, (const char*)m->d_trace + ((enable & 4) ? 2 * half : (enable & 2) ? half : 0), half, hipMemcpyDeviceToHost));
   m->trace_on = enable & 1;      // the buffer itself stays until taco_model_destroy: a captured plan may still carry its address
   return 0;
 }
