@@ -12,7 +12,7 @@
 // owns their column; d alpha (the monotonic recurrence's carry) lives in LDS on every member of its row.
 //
 // Per step t = n-1 .. 0 (twelve exchanges):
-//   do2 = dmel_t . Wf^T | GRU 2: d c_pre -> X | d(r*h), d x from Wc^T, gate gradients -> X | d x, dh2 from Wg^T; residual; GRU 1 the same
+//   (do2 = dmel_t . Wf^T: hoisted, one GEMM) GRU 2: d c_pre -> X | d(r*h), d x from Wc^T, gate gradients -> X | d x, dh2 from Wg^T; residual; GRU 1 the same
 //   (2 X) | d o0 -> X | concat projection^T: d h_att, d ctx -> X | attention: d alpha partials over the value-channel blocks -> X |
 //   normaliser backward (softmax, or the monotonic recurrence with both clips) -> d e; d q partials -> X | d h_att += d q . Wq^T;
 //   attention GRU (2 X) -> d p2 -> X | prenet layer 2^T, ReLU mask -> d p1 -> X | prenet layer 1 (context rows)^T -> d ctx(t-1).
@@ -23,24 +23,24 @@
 #include "taco_backward_kernels.h"
 
 // register map (per thread; host mirror: dbx_build_pack in taco_lib.hip).  A 256-input row = 4 registers (inputs 4l..4l+3), a 512-input
-// row = 8 (two halves), Wf's 320-input row = 4 + 1 (input 256 + l), a 128-input row = 2.
+// row = 8 (two halves), a 128-input row = 2.  (The frame projection's data gradient d o2 = dmel . Wf^T does not depend on the
+// recurrence: the host computes it for all steps with one GEMM, and the kernel reads its own column of it with the tape values.)
 enum {
-  DBR_F = 0,      // frame projection row en (K = rM <= 320)                                   5
-  DBR_C2X = 5,    // GRU 2 candidate kernel, x row en / h row en (K = 256 each)                4 + 4
-  DBR_C2H = 9,
-  DBR_G2X = 13,   // GRU 2 gates kernel, x row en / h row en (K = 512)                         8 + 8
-  DBR_G2H = 21,
-  DBR_C1X = 29, DBR_C1H = 33, DBR_G1X = 37, DBR_G1H = 45,                                    // GRU 1, the same
-  DBR_CCA = 53,   // concat projection, h_att row en / context row en (K = 256)                4 + 4
-  DBR_CCC = 57,
-  DBR_Q = 61,     // query layer row en (K = 256)                                              4
-  DBR_CAX = 65,   // attention GRU candidate, x row 4m + w (waves 0-3; K = 256) / h row en     4 + 4
-  DBR_CAH = 69,
-  DBR_GAX = 73,   // attention GRU gates, x row 4m + w (waves 0-3; K = 512) / h row en         8 + 8
-  DBR_GAH = 81,
-  DBR_P2 = 89,    // prenet layer 2 row en (K = 128)                                           2
-  DBR_P1C = 91,   // prenet layer 1, context row en (K = 256)                                  4
-  DB_NREG = 95
+  DBR_C2X = 0,    // GRU 2 candidate kernel, x row en / h row en (K = 256 each)                4 + 4
+  DBR_C2H = 4,
+  DBR_G2X = 8,    // GRU 2 gates kernel, x row en / h row en (K = 512)                         8 + 8
+  DBR_G2H = 16,
+  DBR_C1X = 24, DBR_C1H = 28, DBR_G1X = 32, DBR_G1H = 40,                                    // GRU 1, the same
+  DBR_CCA = 48,   // concat projection, h_att row en / context row en (K = 256)                4 + 4
+  DBR_CCC = 52,
+  DBR_Q = 56,     // query layer row en (K = 256)                                              4
+  DBR_CAX = 60,   // attention GRU candidate, x row 4m + w (waves 0-3; K = 256) / h row en     4 + 4
+  DBR_CAH = 64,
+  DBR_GAX = 68,   // attention GRU gates, x row 4m + w (waves 0-3; K = 512) / h row en         8 + 8
+  DBR_GAH = 76,
+  DBR_P2 = 84,    // prenet layer 2 row en (K = 128)                                           2
+  DBR_P1C = 86,   // prenet layer 1, context row en (K = 256)                                  4
+  DB_NREG = 90
 };
 // per-row gradient vectors in LDS (floats): every gathered vector is read by the stage right behind its gather only, and a
 // barrier separates that stage from the gather after the next one, so two alternating 512-float buffers per row hold them all
@@ -62,7 +62,6 @@ __host__ __device__ inline size_t db_lds_floats(int RG, int T_in) {
   const int Pr = DX_GROUP / RG, DC = DX_W / Pr, Tpad = (T_in + 63) & ~63;
   const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
   size_t n = (size_t)RG * DBS_LD;
-  n += 2 * (size_t)RG * 384;                       // dmel rows, double buffered (LDS-direct, one step ahead)
   n += 2 * (size_t)DX_NW * 128;                    // own-column tape values of the step, double buffered
   n += (size_t)TS * DS + (size_t)T_in * DC;        // keys block, values block
   n += 2 * 3 * (size_t)Tpad;                       // raw scores, alignments of the step and of the step before, double buffered
@@ -78,7 +77,7 @@ struct DbArgs {
   const float* tp_e; const float* tp_alpha;            // raw scores [B, n, T_in]; alignments [B, n + 1, T_in]
   const float* keys; const float* values;              // [B, T_in, 256]
   const float* att_v; const float* att_b; const float* score_bias;
-  const float* dmel;                                   // [B, n, rM]
+  const float* g_do2;                                  // [B, n, 256] = dmel . Wf^T (one GEMM ahead of the launch)
   const float* h_att0; const float* h10; const float* h20;   // initial states [B, 256] or null
   float* g_dcp2; float* g_dgp2; float* g_dcp1; float* g_dgp1; float* g_do0; float* g_dcpA; float* g_dgpA;   // [R, 256] / [R, 512]
   float* g_dz1; float* g_dz2; float* g_dq; float* g_de; float* g_dctx;                                     // [R, 256], [R, 128], [R, 256], [R, T_in], [R, 256]
@@ -202,8 +201,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 
   // ---- LDS carve (db_lds_floats mirrors this) ----
   float* st = dx_smem;                        // [RG][DBS_LD]
-  float* dmb = st + RG * DBS_LD;              // [2][RG][384] dmel rows
-  float* Kc = dmb + 2 * RG * 384 + 2 * DX_NW * 128;   // (own-column tape values [2][DX_NW][128] in between)  keys [TS][DS]
+  float* own = st + RG * DBS_LD;              // [2][DX_NW][128] own-column tape values of the step
+  float* Kc = own + 2 * DX_NW * 128;          // keys   [TS][DS]
   float* Vc = Kc + (size_t)TS * DS;           // values [T][DC]
   float* rows = Vc + (size_t)T * DC;          // [2][3][Tpad]: e, alpha(t+1 slot = this step's), alpha(t slot = previous)
   float* da = rows + 6 * Tpad;
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     *reinterpret_cast<float4*>(Vc + (size_t)j * DC + 4 * d4) = v4;
   }
   for (int i = tid; i < RG * DBS_LD; i += DX_NT) st[i] = 0.f;
-  for (int i = tid; i < 2 * RG * 384 + 2 * DX_NW * 128; i += DX_NT) dmb[i] = 0.f;     // (and the own-column buffers behind them)
+  for (int i = tid; i < 2 * DX_NW * 128; i += DX_NT) own[i] = 0.f;
   for (int j = tid; j < Tpad; j += DX_NT) { da[j] = 0.f; pp[j] = 0.f; cp[j] = 0.f; ss[j] = 0.f; de[j] = 0.f; dac[j] = 0.f; }
   for (int j = tid; j < 6 * Tpad; j += DX_NT) rows[j] = 0.f;
   if (tid < DS) { vv[tid] = a.att_v[cb * DS + tid]; bq[tid] = a.att_b ? a.att_b[cb * DS + tid] : 0.f; }
@@ -279,7 +278,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   // Own-column tape values of a step -- u, c, r and the previous state of the three cells, both prenet outputs, for the RG rows of
   // the wave's column: OW_N * RG scalars per wave -- are gathered one step ahead by ONE LDS-direct load per 64 of them (each lane
   // supplies the address of its (value, row) pair), so neither the values in flight nor the ones in use occupy registers.
-  enum { OW_U2 = 0, OW_C2, OW_R2, OW_H2P, OW_U1, OW_C1, OW_R1, OW_H1P, OW_UA, OW_CA, OW_RA, OW_HAP, OW_P1, OW_P2, OW_N };
+  enum { OW_U2 = 0, OW_C2, OW_R2, OW_H2P, OW_U1, OW_C1, OW_R1, OW_H1P, OW_UA, OW_CA, OW_RA, OW_HAP, OW_P1, OW_P2, OW_DO2, OW_N };
   constexpr int OW_K = (OW_N * RG + 63) / 64;
   const float* gp[OW_K]; const float* galt[OW_K]; int gstr[OW_K]; bool gprev[OW_K], gok[OW_K];
 #pragma unroll
@@ -297,10 +296,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     gp[k] = a.tape + (size_t)slot * a.tstride + (size_t)b * n * DX_W + en - (gprev[k] ? DX_W : 0);    // + t * 256: step t (previous state: step t - 1)
     gstr[k] = DX_W;
     if (v == OW_P2) { gp[k] = a.tp_p2 + (size_t)b * n * a.ld_p2 + (wave < 4 ? en2 : 0); gstr[k] = a.ld_p2; }
+    if (v == OW_DO2) gp[k] = a.g_do2 + (size_t)b * n * DX_W + en;
     const float* i0 = v == OW_H2P ? a.h20 : v == OW_H1P ? a.h10 : a.h_att0;                           // the state before step 0
     galt[k] = (gprev[k] && i0) ? i0 + (size_t)b * DX_W + en : gp[k] + gstr[k];                         // (none: any valid address; the consumer reads 0)
   }
-  float* own = dmb + 2 * RG * 384;                   // [2][DX_NW][128]
   const unsigned own_lds = (unsigned)(size_t)(dx_lds_float*)own;
   auto fetch_own = [&](int t, int buf) {
 #pragma unroll
@@ -308,15 +307,10 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       if (gok[k]) dx_load_lds4((t == 0 && gprev[k]) ? galt[k] : gp[k] + (size_t)t * gstr[k],
                                __builtin_amdgcn_readfirstlane(own_lds + (unsigned)((buf * DX_NW + wave) * 128 + 64 * k) * 4u));
   };
-  // rows needed whole, one step ahead, straight into LDS: dmel_t (waves 0..RG-1), e_t / alpha_{t+1} / alpha_t of the member's row
-  const unsigned dmb_lds = (unsigned)(size_t)(dx_lds_float*)dmb, rows_lds = (unsigned)(size_t)(dx_lds_float*)rows;
+  // rows needed whole, one step ahead, straight into LDS: e_t / alpha_{t+1} / alpha_t of the member's row, the query of its channels
+  const unsigned rows_lds = (unsigned)(size_t)(dx_lds_float*)rows;
   const unsigned qraw_lds = (unsigned)(size_t)(dx_lds_float*)qraw;
   auto fetch_rows = [&](int t, int buf) {
-    if (wave < RG) {
-      const float* src = a.dmel + ((size_t)min(row0 + wave, a.B - 1) * n + t) * a.rM;
-      for (int j0 = 0; j0 < a.rM; j0 += 64)
-        dx_load_lds4(src + min(j0 + lane, a.rM - 1), __builtin_amdgcn_readfirstlane(dmb_lds + (unsigned)((buf * RG + wave) * 384 + j0) * 4u));
-    }
     if (wave == DX_NW - 1 && lane < DS)       // the processed query W_q h_att(t) of the member's score channels
       dx_load_lds4(a.tape + (size_t)DXT_Q * a.tstride + ((size_t)browc * n + t) * DX_W + cb * DS + lane,
                    __builtin_amdgcn_readfirstlane(qraw_lds + (unsigned)(buf * 64) * 4u));
@@ -357,17 +351,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 #define DB_OUT(ptr, Wd, q, col, val) do { if (ev[q]) (ptr)[(size_t)(trow[q] + (unsigned)t) * (Wd) + (col)] = (val); } while (0)
     // a GRU cell's backward, part 'a' (owner-local): from the gradient of the cell's output and the carried state gradient
     float dht[RL], dgu[RL], tx[RL], do_[RL];
-    // ================= frame projection^T -> GRU 2 'a' =================
+    // ================= GRU 2 'a' (d o2 = dmel . Wf^T: precomputed for all steps) =================
     {
-      float acc[1][RG], s[1][RL];
-      dx_zero<1, RG>(acc);
-      dx_pass<DBR_F, 1, RG, DB_NREG, 384>(W, dmb + (size_t)buf * RG * 384, lane, acc);
-#pragma unroll
-      for (int r = 0; r < RG; ++r) acc[0][r] = fmaf(W[DBR_F + 4], dmb[(size_t)(buf * RG + r) * 384 + 256 + lane], acc[0][r]);
-      dx_reduce<1, RG>(acc, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
-        do_[q] = s[0][q];                                        // d o2 (GRU stack output)
+        do_[q] = OWN(OW_DO2, q);                                 // d o2 (GRU stack output)
         const float g = do_[q] + dh2[q];
         const float dcp = g * (1.f - OWN(OW_U2, q)) * (1.f - OWN(OW_C2, q) * OWN(OW_C2, q));
         dgu[q] = g * ((z2 ? 0.f : OWN(OW_H2P, q)) - OWN(OW_C2, q)) * OWN(OW_U2, q) * (1.f - OWN(OW_U2, q));

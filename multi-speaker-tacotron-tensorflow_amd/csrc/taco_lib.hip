@@ -479,9 +479,8 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
 static int dbx_build_pack(taco_model* m) {
   if (!dx_widths_ok(m) || is_simple(m)) return 0;
   const taco_hparams& hp = m->hp;
-  const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, Mm = hp.num_mels;
+  const int H = DX_W, Mm = hp.num_mels;
   std::vector<float> pack((size_t)DX_GROUP * DB_NREG * DX_NT, 0.f);
-  const auto& fk = T_(m, "decoder/frame_projection/kernel").data;
   const auto& g2k = T_(m, "decoder/gru_2/gates/kernel").data; const auto& c2k = T_(m, "decoder/gru_2/candidate/kernel").data;
   const auto& g1k = T_(m, "decoder/gru_1/gates/kernel").data; const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
   const auto& cck = T_(m, "decoder/concat_projection/kernel").data;
@@ -497,7 +496,6 @@ static int dbx_build_pack(taco_model* m) {
         if (r < 0) return;
         for (int e = 0; e < kw; ++e) { const int c = col0 + kw * lane + e; if (c < ncols) R[(size_t)(reg0 + e) * DX_NT] = W[(size_t)r * ldw + c]; }
       };
-      row(DBR_F, 4, fk, rM, en, 0, rM); row(DBR_F + 4, 1, fk, rM, en, 256, rM);
       row(DBR_C2X, 4, c2k, H, en, 0, H); row(DBR_C2H, 4, c2k, H, H + en, 0, H);
       row(DBR_G2X, 4, g2k, 2 * H, en, 0, 2 * H); row(DBR_G2X + 4, 4, g2k, 2 * H, en, 256, 2 * H);
       row(DBR_G2H, 4, g2k, 2 * H, H + en, 0, 2 * H); row(DBR_G2H + 4, 4, g2k, 2 * H, H + en, 256, 2 * H);

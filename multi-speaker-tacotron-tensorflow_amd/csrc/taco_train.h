@@ -23,7 +23,7 @@ struct GruT { SkW gT, cT; int I = 0, H = 0; };   // gates/kernel^T (K = 2H, N = 
 struct TrainPacks {
   std::vector<ConvL> encpre_d;
   CbhgT enc, post;
-  ConvL mem_d, lin_d;
+  ConvL mem_d, lin_d, frame_d;         // frame_d: [r*num_mels -> Hd], the frame projection's data gradient for all steps at once (persistent BPTT)
   std::vector<SkW> decpre_T;
   SkW decpre0_ctxT;                     // transposed decoder prenet layer 1, context rows only: [P0 -> D] (the teacher frame gets no gradient)
   GruT att, dec[4];
@@ -164,6 +164,7 @@ static int build_train_packs(taco_model* m) {
   for (int i = 0; i < hp.dec_layer_num; ++i) tp.dec[i] = make_gru_T(m, "decoder/gru_" + std::to_string(i + 1), Hd, Hd);
   tp.concat_T = pack_w16_T(m, T_(m, "decoder/concat_projection/kernel").data.data(), As + D + simple_S(m), Hd);
   if (is_simple(m)) tp.lin_spk_T = pack_w16_T(m, T_(m, "linear/kernel_spk").data.data(), hp.speaker_embedding_size, hp.num_freq);
+  tp.frame_d = make_conv_T_named(m, "decoder/frame_projection");
   tp.frame_T = pack_w16_T(m, T_(m, "decoder/frame_projection/kernel").data.data(), Hd, hp.num_mels * hp.reduction_factor);
   { std::vector<float> wqT = transpose2d(T_(m, "attention/query_layer/kernel").data.data(), As, A);
     tp.wqT = arena_put(m, wqT.data(), wqT.size()); }
@@ -283,7 +284,7 @@ struct DecTape {     // every per-step tensor is [B, n, W]: step t of row b at (
   unsigned long long* xbuf = nullptr; unsigned* dxctl = nullptr; float* rowbias = nullptr;   // its exchange granules, census words, 'simple' row biases
   // backward
   float *dkeys, *dvalues, *dv_acc, *dsb_acc, *dalpha, *dctx, *dctx_t, *dhA, *dh[4], *dht, *dhp, *tmp1, *tmp2, *do_[5];
-  float *g_dgp[4], *g_dcp[4], *g_dgpA, *g_dcpA, *g_do0, *g_dq, *g_dz[4], *dpz, *dIn;
+  float *g_dgp[4], *g_dcp[4], *g_dgpA, *g_dcpA, *g_do0, *g_do2, *g_dq, *g_dz[4], *dpz, *dIn;
   float *g_q, *g_e, *g_de, *g_dctx;   // attention tape: processed query, raw scores, their gradients' inputs
 };
 static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int n, DecTape& w) {
@@ -324,7 +325,7 @@ static void carve_dec_tape(Carver& cv, const taco_model* m, int B, int T_in, int
   w.tmp1 = cv.f((size_t)B * W2); w.tmp2 = cv.f((size_t)B * W2);
   for (int i = 0; i <= L; ++i) w.do_[i] = cv.f((size_t)B * Hd);
   for (int i = 0; i < L; ++i) { w.g_dgp[i] = cv.f(R * 2 * Hd); w.g_dcp[i] = cv.f(R * Hd); }
-  w.g_dgpA = cv.f(R * 2 * As); w.g_dcpA = cv.f(R * As); w.g_do0 = cv.f(R * Hd); w.g_dq = cv.f(R * A);
+  w.g_dgpA = cv.f(R * 2 * As); w.g_dcpA = cv.f(R * As); w.g_do0 = cv.f(R * Hd); w.g_dq = cv.f(R * A); w.g_do2 = cv.f(R * Hd);
   for (int i = 0; i < hp.dec_prenet_n; ++i) w.g_dz[i] = cv.f(R * hp.dec_prenet[i]);
   w.dpz = cv.f((size_t)B * W2); w.dIn = cv.f((size_t)B * W2);
   if (!dxl) w.g_q = cv.f(R * A);
@@ -777,7 +778,10 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   if (persistent) {
     DbArgs a; memset(&a, 0, sizeof a);
     a.tape = w.tape256; a.tstride = w.tstride; a.tp_p2 = w.pz[1]; a.ld_p2 = Pz; a.tp_e = w.g_e; a.tp_alpha = w.alpha;
-    a.keys = w.keys; a.values = enc_out; a.dmel = dmel;
+    a.keys = w.keys; a.values = enc_out;
+    // d o2 of every step does not depend on the recurrence: ONE GEMM [B n, r M] x [r M, 256] ahead of the loop
+    TRY(run_dgrad(m, st, tp.frame_d, dmel, rM, R, 0, w.g_do2, Hd));
+    a.g_do2 = w.g_do2;
     a.h_att0 = att_init; a.h10 = dec_init ? dec_init[0] : nullptr; a.h20 = dec_init ? dec_init[1] : nullptr;
     a.g_dcp2 = w.g_dcp[1]; a.g_dgp2 = w.g_dgp[1]; a.g_dcp1 = w.g_dcp[0]; a.g_dgp1 = w.g_dgp[0]; a.g_do0 = w.g_do0;
     a.g_dcpA = w.g_dcpA; a.g_dgpA = w.g_dgpA; a.g_dz1 = w.g_dz[0]; a.g_dz2 = w.g_dz[1]; a.g_dq = w.g_dq; a.g_de = w.g_de; a.g_dctx = w.g_dctx;

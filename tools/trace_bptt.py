@@ -21,17 +21,15 @@ out = (C.c_longlong * 128)()
 _lib.check(tr._lib.taco_debug_decoder_trace(mh, 1 | 4, out))
 _lib.check(tr._lib.taco_debug_decoder_trace(mh, 0, None))
 t = np.array(out[:], np.int64).reshape(8, 16)
-names = ["fetch issue + frame projection^T + GRU 2 a", "collect d c_pre 2", "GRU 2 b + collect gate grads", "GRU 2 c / GRU 1 a + collect d c_pre 1",
-         "GRU 1 b + collect gate grads", "GRU 1 c + collect d o0", "concat^T + collect d ctx", "d alpha partials + collect", "normaliser backward + query",
-         "d q partials + collect", "query^T / att GRU a + collect d c_pre", "att GRU b + collect gate grads", "att GRU c + collect d z2",
-         "prenet 2^T + collect d z1", "prenet 1^T (context rows)"]
+names = ["fetch issue + GRU 2 a + collect d c_pre", "GRU 2 b + collect gate grads", "GRU 2 c / GRU 1 a + collect d c_pre", "GRU 1 b + collect gate grads",
+         "GRU 1 c + collect d o0", "concat^T + collect d ctx", "d alpha partials + collect", "normaliser backward + query", "d q partials + collect",
+         "query^T / att GRU a + collect d c_pre", "att GRU b + collect gate grads", "att GRU c + collect d z2", "prenet 2^T + collect d z1",
+         "prenet 1^T (context rows)"]
 d = np.diff(t[:, :15], axis=1).astype(np.float64)
 step = np.median((t[1:, 0] - t[:-1, 0]).astype(np.float64))
 print("B=%d T_in=%d steps=%d: step = %.0f clocks; engine %s" % (B, T_in, T_out // hp.reduction_factor, step, tr.decoder_engine_info()))
-for n_, c in zip(names[1:], np.median(d[1:], axis=0)[0:]):
-    pass
 med = np.median(d[1:], axis=0)
-labels = ["to stamp %d: %s" % (i + 1, names[i]) for i in range(14)]
+labels = ["%2d %s" % (i + 1, names[i]) for i in range(14)]
 for lab, c in zip(labels, med):
     print("  %-70s %6.0f" % (lab, c))
 print("  (clocks of the shader counter; ~2.1-2.3 per ns)")
