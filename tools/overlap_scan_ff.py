@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Does feed-forward work of ANOTHER request run on the CUs while a post-net scan (k_bigru_duo: 2 waves per SIMD, 88 VGPRs, parked half
-of the time) holds them?  Round 2's version of this experiment (tools/scratch/overlap.py) used two arbitrary torch streams, which HIP
+of the time) holds them?  Round 2's version of this experiment (tools/scratch/overlap.py, removed in round 3) used two arbitrary torch streams, which HIP
 may bind to the same hardware queue (then nothing overlaps whatever the kernels are); this one takes streams that were PROBED to run
 concurrently (tacotron._concurrent_streams).
 
