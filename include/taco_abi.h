@@ -300,6 +300,10 @@ int taco_debug_set_overlap(taco_model* m, int on);
  * stage.  mode 2: persistent with write-through (placement-independent) exchanges even when the census finds one group per XCD.
  * rows_per_group: 0 = smallest of 1/2/4/8 that covers the batch with 8 groups; a larger value packs the batch onto fewer XCDs. */
 int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group);
+/* Which engine a forward of this shape WOULD run on -- and, when it is not the persistent whole-chip one, why not (widths, rows, LDS,
+ * compute units of the device, debug switches).  Nothing is launched.  `out` receives a NUL-terminated line (out_len >= 64; truncated
+ * if shorter than the text).  The run-time facts (exchange protocol the census chose) are in taco_debug_decoder_info afterwards. */
+int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual, char* out, int out_len);
 /* after a forward: out16[0] = exchange protocol the last persistent decoder launch used (0 none ran, 1 XCD-local plain stores,
  * 2 write-through), out16[1..8] = workgroups the census saw per XCD, out16[9] = protocol of the persistent BPTT launch when the
  * last decoder backward (training shadow model) used it, else 0, out16[14] = compute units of the device (the whole-chip

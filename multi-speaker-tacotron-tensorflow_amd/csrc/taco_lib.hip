@@ -1976,6 +1976,42 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
   out16[15] = m->dx_pack ? 1 : 0;
   return 0;
 }
+// Which engine a call of this shape would run on, and why not the persistent one when it would not (nothing is launched).
+int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual, char* out, int out_len) {
+  if (!m || !m->finalized || !out || out_len < 64) return fail(TACO_ERR_ARG, "bad argument");
+  std::string s;
+  auto why_common = [&](int rows) -> std::string {
+    if (!m->dx_mode) return "switched off (taco_debug_set_decoder_persist 0)";
+    if (m->cu_count < DX_NGROUP * DX_GROUP) return "the device exposes " + std::to_string(m->cu_count) + " compute units (a partition of an MI355X, or another part): the whole-chip kernels need 256";
+    if (rows > 8 * DX_NGROUP) return std::to_string(rows) + " rows > 64 per launch";
+    return "";
+  };
+  {  // decoder loop
+    std::string why = why_common(B);
+    if (why.empty() && !m->dx_pack) why = "widths differ from the reference's (256-wide attention / decoder cells, prenet 256-128, 2 decoder layers, r * num_mels <= 512)";
+    const int RG = dx_rows_per_group(m, B);
+    if (why.empty() && dx_lds_floats(RG, T_in, m->tp != nullptr) * sizeof(float) > 160 * 1024)
+      why = "T_in = " + std::to_string(T_in) + " does not fit a member's LDS at " + std::to_string(RG) + " rows per group";
+    if (why.empty()) s += "decoder loop: persistent k_decoder_xcd<" + std::to_string(RG) + "> (" + std::string(manual ? "manual alignments" : "computed alignments") + ", " +
+                          std::string(m->dx_mode == 2 ? "write-through exchanges forced" : "XCD-local exchanges when the census finds 32 workgroups per XCD") + ")";
+    else s += "decoder loop: one launch per stage -- " + why;
+  }
+  {  // post-net scan
+    const Cbhg& c = m->post;
+    std::string why = why_common(B);
+    if (why.empty() && m->persist != 1 && m->persist != 8 && m->persist != 9) why = "taco_debug_set_persistent(" + std::to_string(m->persist) + ")";
+    if (why.empty() && (c.rnn != GX_H || !c.gd_pack)) why = "post_rnn_size " + std::to_string(c.rnn) + " != 256";
+    if (why.empty() && T_mel < 2) why = "fewer than 2 frames";
+    int RG = 1;
+    while (RG * DX_NGROUP < B) RG *= 2;
+    if (why.empty()) s += "; post-net scan: persistent " + std::string(m->persist == 1 ? "k_bigru_duo<" : "k_bigru_xcd<") + std::to_string(RG) + ">";
+    else s += "; post-net scan: resident per-row kernels -- " + why;
+  }
+  s += "; encoder scan: k_bigru_res (rows resident per workgroup); feed-forward: ";
+  s += m->bf3 ? "split-bf16 MFMA (k_gemm_bf3 / k_pointwise_chain)" : "exact-fp32 MFMA (k_gemm)";
+  snprintf(out, (size_t)out_len, "%s", s.c_str());
+  return 0;
+}
 int taco_debug_decoder_trace(taco_model* m, int enable, long long* out) {
   if (!m || !m->finalized) return fail(TACO_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(m->device));

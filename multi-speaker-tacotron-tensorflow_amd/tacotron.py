@@ -577,6 +577,15 @@ class Tacotron(object):
         _lib.check(self._lib.taco_debug_decoder_info(self._handle, v))
         return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14])}
 
+    def engine_plan(self, batch, t_in, t_mel=None, manual=False):
+        """One line saying which engine a forward of this shape would run on and, if not the persistent whole-chip kernels, why not
+        (widths, rows per launch, LDS, compute units of the device, debug switches).  Nothing is launched; PlanPool(lanes > 1) additionally
+        switches its lanes to the launch-per-stage engine (two whole-chip kernels cannot share the chip)."""
+        buf = C.create_string_buffer(1024)
+        t_mel = t_mel if t_mel is not None else self._hparams.max_iters * self._hparams.reduction_factor
+        _lib.check(self._lib.taco_model_engine_plan(self._handle, int(batch), int(t_in), int(t_mel), 1 if manual else 0, buf, 1024))
+        return buf.value.decode()
+
     def decoder_trace(self, enable=True, read=False, scan=False):
         """Phase stamps (shader clocks) of group 0 / member 0 of the persistent decoder (scan=True: of the post-net scan, which has
         its own half of the buffer), 8 steps x 16 slots.  Cached plans are dropped whenever the setting changes: a plan captured

@@ -307,3 +307,26 @@ def test_post_net_scan_spread_over_the_chip(B):
             assert maxabs(a, got[(7, tag)][0]) < 2e-5, (name, tag)
         a = got[(1, tag)][0]
         assert maxabs(got[(9, tag)][0], ref) < 1e-4 and maxabs(a, got[(9, tag)][0]) < 2e-5, tag
+
+
+def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
+    """taco_model_engine_plan (Tacotron.engine_plan): the limits of the persistent engine, told to the caller before a call instead of
+    being tripped silently -- and the plan agrees with what a forward then reports."""
+    import torch
+    from util import tiny_hp
+    ohp = O.OracleHParams(max_iters=4)
+    m = build_model(ohp, O.init_weights(ohp, 1, 401))
+    plan = m.engine_plan(32, 128, 512)
+    assert "decoder loop: persistent k_decoder_xcd<4>" in plan and "post-net scan: persistent k_bigru_duo<4>" in plan and "split-bf16" in plan, plan
+    assert "k_decoder_xcd<1>" in m.engine_plan(2, 512)
+    assert "rows > 64" in m.engine_plan(65, 64)
+    assert "does not fit a member's LDS" in m.engine_plan(64, 2000), m.engine_plan(64, 2000)
+    ids, L = O.synthetic_inputs(3, 12, 402)
+    m.run(ids, L)
+    torch.cuda.synchronize()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    m.set_decoder_engine(0)
+    assert "switched off" in m.engine_plan(32, 128)
+    t = build_model(tiny_hp(), O.init_weights(tiny_hp(), 1, 403))
+    plan = t.engine_plan(4, 9)
+    assert "one launch per stage -- widths differ" in plan and "resident per-row kernels" in plan, plan

@@ -9,6 +9,9 @@ timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/b
 for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
+timeout 300 python tools/bench_train.py --exact-gemm 0 > $out/train_step_splitbf16.json 2>> $out/train.err
+timeout 300 python tools/bench_train.py --bptt 0 > $out/train_step_bptt_per_stage.json 2>> $out/train.err
+timeout 300 python tools/trace_bptt.py 2>&1 | grep -v amdgpu.ids > $out/bptt_timeline.txt
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
 # round 3: scan timelines (k_bigru_duo vs k_bigru_xcd), manual / simple decoder modes, feed-forward-under-the-scan experiment, training kernel statistics
 { for p in 1 8; do python tools/trace_bigru.py 32 512 $p; python tools/trace_bigru.py 64 512 $p; python tools/trace_bigru.py 8 4000 $p; done; } 2>&1 | grep -v amdgpu.ids > $out/scan_timeline.txt
