@@ -23,7 +23,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
-# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, profiles/r03_scan_timeline.txt,
+# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, profiles/r03_*_scan_timeline.txt,
 # tools/time_decoder.py, tools/trace_bigru.py; shader clock ~2.16 GHz) and of the matrix pipe (tools/ubench_mfma: 2.08 PFLOP/s bf16
 # dense): what `roofline.latency_floor_ms` is built from.
 HOP_US = 0.5                 # one exchange through the XCD's L2: publish -> every consumer has gathered it (0.44-0.58 measured)
@@ -498,7 +498,7 @@ def main():
                  "frac_of_floor": sum(terms.values()) / (fwd_s * 1e3),
                  "note": "one forward in flight; hop = %.2f us (one exchange through the XCD's L2), chains = dependent VALU/DPP work between "
                          "exchanges (profiles/r02_decoder_timeline.txt); the post-net scan hides its exchanges behind the other direction's "
-                         "phases (k_bigru_duo, profiles/r03_scan_timeline.txt); 0.30 of the HBM streaming roofline would need %.2f ms per forward"
+                         "phases (k_bigru_duo, profiles/r03_*_scan_timeline.txt); 0.30 of the HBM streaming roofline would need %.2f ms per forward"
                          % (HOP_US, abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
