@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void k_dx_fold(const float* __restrict__ Wc, c
 // k_colsum_reduce adds them to out1 / out2 chunk by chunk in a fixed order.
 struct ColArgs { const float* a; const float* b; const float* mu; const float* rstd; float* out1; float* out2;
                  int lda, ldb, M, C, mode, rpb; float* part; };
-__global__ __launch_bounds__(256) void k_colsum(const ColArgs g) {
+__device__ __forceinline__ void colsum_body(const ColArgs& g, int bx, int by) {
   __shared__ float s1[4][64], s2[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const int m0 = blockIdx.y * g.rpb, m1 = min(g.M, m0 + g.rpb);
+  const int c = bx * 64 + cl;
+  const int m0 = by * g.rpb, m1 = min(g.M, m0 + g.rpb);
   float a1 = 0.f, a2 = 0.f;
   if (c < g.C) {
     const float mu = g.mu ? g.mu[c] : 0.f, rs = g.rstd ? g.rstd[c] : 1.f;
@@ -89,13 +89,26 @@ __global__ __launch_bounds__(256) void k_colsum(const ColArgs g) {
     const float t1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
     const float t2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
     if (g.part) {
-      g.part[((size_t)blockIdx.y * 2 + 0) * g.C + c] = t1;
-      g.part[((size_t)blockIdx.y * 2 + 1) * g.C + c] = t2;
+      g.part[((size_t)by * 2 + 0) * g.C + c] = t1;
+      g.part[((size_t)by * 2 + 1) * g.C + c] = t2;
     } else {
       if (g.mode != 1 && g.out1) atomicAdd(g.out1 + c, t1);
       if (g.mode != 0 && g.out2) atomicAdd(g.out2 + c, t2);
     }
   }
+}
+__global__ __launch_bounds__(256) void k_colsum(const ColArgs g) { colsum_body(g, blockIdx.x, blockIdx.y); }
+// several column sums whose operands are all ready (bias / BatchNorm-backward sums of one backward region) as ONE launch; see k_wgrad_bf3_group
+#define COL_MAXP 40
+struct ColGroup { ColArgs p[COL_MAXP]; int start[COL_MAXP + 1]; int n; };
+__global__ __launch_bounds__(256) void k_colsum_group(const ColGroup G) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < G.n && G.start[p + 1] <= b) ++p;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const ColArgs g = G.p[p];
+  const int local = b - G.start[p], gx = (g.C + 63) / 64;
+  colsum_body(g, local % gx, local / gx);
 }
 __global__ void k_colsum_reduce(const float* part, int nchunks, int C, int mode, float* out1, float* out2) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -252,13 +265,13 @@ __device__ __forceinline__ void wgb_split3(const float (&v)[8], bf16x8& hi, bf16
 // NW = waves per workgroup: 4 (128 x 128 tile) or 1 (64 x 64 tile: small matrices with many rows, where a finer tiling buys the
 // workgroups that would otherwise have to come from splitting M -- every M-slice ends in 4096 atomics per wave).
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_wgrad_bf3(const WgArgs g) {
+__device__ __forceinline__ void wgrad_bf3_body(const WgArgs& g, int bx, int by, int bz) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = lane & 31, h = lane >> 5;
   constexpr int TS = NW == 4 ? 128 : 64;
-  const int kb = blockIdx.x * TS + (NW == 4 ? (wave >> 1) * 64 : 0), nb = blockIdx.y * TS + (NW == 4 ? (wave & 1) * 64 : 0);
+  const int kb = bx * TS + (NW == 4 ? (wave >> 1) * 64 : 0), nb = by * TS + (NW == 4 ? (wave & 1) * 64 : 0);
   const int nsplit = (g.M + g.rpb - 1) / g.rpb;
-  const int tap = blockIdx.z / nsplit, sp = blockIdx.z - tap * nsplit;
+  const int tap = bz / nsplit, sp = bz - tap * nsplit;
   const int shift = tap - g.padl;
   const int m0 = sp * g.rpb, m1 = min(g.M, m0 + g.rpb);
   if (kb >= g.K || nb >= g.N) return;
@@ -343,6 +356,24 @@ __global__ __launch_bounds__(64 * NW) void k_wgrad_bf3(const WgArgs g) {
         }
       }
     }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_wgrad_bf3(const WgArgs g) { wgrad_bf3_body<NW>(g, blockIdx.x, blockIdx.y, blockIdx.z); }
+// Several small weight gradients whose operands are all ready, as ONE launch: a 64 x 64-tile problem with a few thousand rows is a
+// handful of one-wave workgroups that mostly wait for their first loads, and a training step has ~100 of them (the decoder's hoisted
+// gradients: 52, of which 32 are the per-row d values products; a conv bank: one per width; a BiGRU: 8).  Workgroup b of the flat grid
+// belongs to problem p with start[p] <= b < start[p + 1] and is block (bx, by, bz) of that problem's own grid.
+#define WG_MAXP 36
+struct WgGroup { WgArgs p[WG_MAXP]; int start[WG_MAXP + 1]; int n; };
+__global__ __launch_bounds__(64) void k_wgrad_bf3_group(const WgGroup G) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < G.n && G.start[p + 1] <= b) ++p;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const WgArgs g = G.p[p];
+  const int local = b - G.start[p], gx = (g.K + 63) / 64, gy = (g.N + 63) / 64;
+  wgrad_bf3_body<1>(g, local % gx, (local / gx) % gy, local / (gx * gy));
 }
 
 // dw[tap][k][n] += sum over the M-slices, slice 0 first (fixed order: run-to-run reproducible)

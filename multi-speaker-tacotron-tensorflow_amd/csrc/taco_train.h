@@ -39,6 +39,7 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
+  size_t n_bf3 = 0; int n_bf3_segs = 0;
   unsigned* d_bf3_idx = nullptr; Bf3Seg* d_bf3_segs = nullptr;   // index list and segment table of the split-bf16 packs (k_bf3_gather)
   float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
@@ -190,6 +191,25 @@ static int build_train_packs(taco_model* m) {
 // (one step per host thread at a time: the library's threading contract).
 struct DetScratch { float* p = nullptr; size_t cap = 0; };
 static thread_local DetScratch g_det;
+// Batching region for small weight gradients (k_wgrad_bf3_group): between wg_begin and wg_end, run_wgrad calls that take the one-wave
+// tile are collected and launched together -- at wg_flush / wg_end, or when the table is full.  The caller flushes before anything
+// overwrites an operand of a collected problem or reads one of their outputs.
+struct WgBatch { WgGroup g; ColGroup c; bool active = false; hipStream_t st = nullptr; };
+static thread_local WgBatch g_wgb;
+static int wg_flush() {      // (column sums of the region ride along: same hazards, same flush points)
+  WgGroup& G = g_wgb.g; ColGroup& Cg = g_wgb.c;
+  if (Cg.n > 0) hipLaunchKernelGGL(k_colsum_group, dim3(Cg.start[Cg.n]), dim3(256), 0, g_wgb.st, Cg);
+  if (G.n > 0) hipLaunchKernelGGL(k_wgrad_bf3_group, dim3(G.start[G.n]), dim3(64), 0, g_wgb.st, G);
+  if (Cg.n > 0 || G.n > 0) HIPCHK(hipGetLastError());
+  G.n = 0; G.start[0] = 0; Cg.n = 0; Cg.start[0] = 0;
+  return 0;
+}
+static void wg_begin(hipStream_t st) { g_wgb.active = true; g_wgb.st = st; g_wgb.g.n = 0; g_wgb.g.start[0] = 0; g_wgb.c.n = 0; g_wgb.c.start[0] = 0; }
+static int wg_end() { const int rc = wg_flush(); g_wgb.active = false; return rc; }
+struct WgRegion {      // RAII: a region ends (and flushes) on every return path
+  explicit WgRegion(hipStream_t st) { wg_begin(st); }
+  ~WgRegion() { if (g_wgb.active) (void)wg_end(); }
+};
 static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, int ldb, const float* mu, const float* rstd,
                       float* out1, float* out2, int M, int C, int mode) {
   ColArgs g; g.a = a; g.b = b; g.mu = mu; g.rstd = rstd; g.out1 = out1; g.out2 = out2; g.lda = lda; g.ldb = ldb; g.M = M; g.C = C;
@@ -199,6 +219,13 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
     g.part = g_det.p;
   }
   const int nchunks = cdiv(M, g.rpb);
+  if (g_wgb.active && !g.part) {      // inside a batching region: joins the group launch (the caller flushes before the sums are read)
+    ColGroup& G = g_wgb.c;
+    G.p[G.n] = g;
+    G.start[G.n + 1] = G.start[G.n] + cdiv(C, 64) * nchunks;
+    if (++G.n == COL_MAXP) return wg_flush();
+    return 0;
+  }
   hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, g);
   if (g.part) hipLaunchKernelGGL(k_colsum_reduce, EWGRID(C), 0, st, (const float*)g.part, nchunks, C, mode, out1, out2);
   HIPCHK(hipGetLastError());
@@ -228,6 +255,13 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
     g.part = g_det.p;
   }
   const int nsplit = cdiv(M, g.rpb);
+  if (g_wgb.active && bf3 && !big && !g.part) {       // small problem inside a batching region: joins the group launch
+    WgGroup& G = g_wgb.g;
+    G.p[G.n] = g;
+    G.start[G.n + 1] = G.start[G.n] + cdiv(K, 64) * cdiv(N, 64) * kw * nsplit;
+    if (++G.n == WG_MAXP) return wg_flush();
+    return 0;
+  }
   if (bf3 && big) hipLaunchKernelGGL((k_wgrad_bf3<4>), dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit), dim3(256), 0, st, g);
   else if (bf3) hipLaunchKernelGGL((k_wgrad_bf3<1>), dim3(cdiv(K, 64), cdiv(N, 64), kw * nsplit), dim3(64), 0, st, g);
   else hipLaunchKernelGGL(k_wgrad, dim3(cdiv(K, 64), cdiv(N, 64), kw * nsplit), dim3(256), 0, st, g);
@@ -480,6 +514,7 @@ static int conv_bn_backward_sums(const TrainCtx& x, const std::string& name, con
   hipStream_t st = x.st;
   TRY(run_colsum(st, a, lda, dy, lddy, mu, rstd, x.g(name + "/beta"), x.g(name + "/gamma"), M, C, 2));
   if (x.t->sync_fn && x.t->sync_world > 1) {
+    TRY(wg_flush());                  // (the sums are copied right here)
     // the gradient buffers keep this rank's own sums (the flat all-reduce after backward averages them like every other gradient)
     HIPCHK(hipMemcpyAsync(sync_scratch + c0, x.g(name + "/beta"), (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(sync_scratch + Ctot + c0, x.g(name + "/gamma"), (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -505,6 +540,7 @@ static int conv_bn_backward_apply(const TrainCtx& x, const std::string& name, co
 static int conv_bn_backward(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
                             const float* rstd, bool relu, float* dz, int lddz, int M, int C, float* sync_scratch) {
   TRY(conv_bn_backward_sums(x, name, a, lda, dy, lddy, mu, rstd, M, C, sync_scratch, 0, C));
+  TRY(wg_flush());                    // (inside a batching region the sums above are still queued)
   conv_bn_backward_exchange(x, sync_scratch, C);
   return conv_bn_backward_apply(x, name, a, lda, dy, lddy, mu, rstd, relu, dz, lddz, M, C, sync_scratch, 0, C);
 }
@@ -547,6 +583,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     HIPCHK(hipGetLastError());
   }
   const float* hlast = w.hx[c.depth];
+  WgRegion wgr(st);          // small weight gradients of this CBHG join group launches; flushed wherever an operand is about to be reused
   for (int dir = 0; dir < 2; ++dir) {
     const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
     const float* dgg = w.dg + dir * 3 * H;          // gates columns (r|u), candidate at +2H
@@ -566,6 +603,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(run_colsum(st, dgg, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/gates/bias"), nullptr, M, 2 * H, 0));
     TRY(run_colsum(st, dgg + 2 * H, 6 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/candidate/bias"), nullptr, M, H, 0));
   }
+  TRY(wg_flush());
   float* dcur = w.d0; float* dalt = w.d1;
   TRY(run_dgrad(m, st, ct.xproj_d, w.dg, 6 * H, M, T, dcur, I));
   // ---- highways ----
@@ -578,6 +616,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(run_colsum(st, w.dcat, 2 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/H/bias"), nullptr, M, H, 0));
     TRY(run_colsum(st, w.dcat + H, 2 * H, nullptr, 0, nullptr, nullptr, x.g(n + "/T/bias"), nullptr, M, H, 0));
     TRY(run_dgrad(m, st, ct.hw_d[i], w.dcat, 2 * H, M, 0, dalt, H, dalt, H));   // += direct path
+    TRY(wg_flush());                                                            // (dcat is the next layer's scratch)
     std::swap(dcur, dalt);
   }
   // ---- dense (post-net) ----
@@ -585,6 +624,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(run_wgrad(st, w.res, nullptr, c.in_dim, dcur, H, x.g(sc + "/dense/kernel"), H, M, 0, c.in_dim, H));
     TRY(run_colsum(st, dcur, H, nullptr, 0, nullptr, nullptr, x.g(sc + "/dense/bias"), nullptr, M, H, 0));
     TRY(run_dgrad(m, st, ct.dense_d, dcur, H, M, 0, dalt, c.in_dim));
+    TRY(wg_flush());
     std::swap(dcur, dalt);
   }
   // dcur = gradient of (proj_last + x (+ before_highway)): keep a copy for the residual path
@@ -601,6 +641,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(run_wgrad(st, xin, nullptr, xd, dalt, N, x.g(n + "/kernel"), N, M, T, xd, N, c.pw, (c.pw - 1) / 2));
     float* dnext = (i == 0) ? w.dbig0 : dcur;
     TRY(run_dgrad(m, st, ct.proj_d[i], dalt, N, M, T, dnext, xd));
+    TRY(wg_flush());                                                            // (dalt is rewritten by the next projection)
     if (i > 0) { /* dnext == dcur already holds the gradient of py[i-1] */ }
   }
   // ---- maxpool + conv bank ----
@@ -611,6 +652,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
     TRY(conv_bn_backward_sums(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, M, c.C, w.stat, c0, KC));
   }
+  TRY(wg_flush());                    // the sums of all widths: one group launch
   conv_bn_backward_exchange(x, w.stat, KC);
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
@@ -851,6 +893,8 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     if (dec_init && dec_init[i])
       TRY(run_wgrad(st, dec_init[i], nullptr, Hd, w.g_dgp[i], n * 2 * Hd, x.g("decoder/gru_" + std::to_string(i + 1) + "/gates/kernel") + (size_t)Hd * 2 * Hd, 2 * Hd, B, 0, Hd, 2 * Hd));
   // ---- weight gradients, hoisted over all steps: rows (b, t) of the [B, n, .] tapes ----
+  wg_begin(st);              // ~50 small products over final tapes: a few group launches (ended before d values is read below)
+  struct WgEnd { ~WgEnd() { if (g_wgb.active) (void)wg_end(); } } wg_end_guard;
   TRY(run_wgrad(st, w.o[L], nullptr, Hd, dmel, rM, x.g("decoder/frame_projection/kernel"), rM, R, 0, Hd, rM));
   TRY(run_colsum(st, dmel, rM, nullptr, 0, nullptr, nullptr, x.g("decoder/frame_projection/bias"), nullptr, R, rM, 0));
   for (int i = 0; i < L; ++i)
@@ -892,6 +936,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
                   w.dvalues + (size_t)b * T_in * D, D, n, 0, T_in, D));
   if (hp.attention_type == 2) { hipLaunchKernelGGL(k_sum_all, dim3(1), dim3(256), 0, st, w.dsb_acc, B, x.g("attention/attention_score_bias")); HIPCHK(hipGetLastError()); }
   TRY(run_wgrad(st, enc_out, nullptr, D, w.dkeys, A, x.g("attention/memory_layer/kernel"), A, B * T_in, 0, D, A));
+  TRY(wg_end());             // d values (the per-row products above) is an operand of the data gradient below
   TRY(run_dgrad(m, st, tp.mem_d, w.dkeys, A, B * T_in, 0, denc, D, w.dvalues, D));
   return 0;
 }

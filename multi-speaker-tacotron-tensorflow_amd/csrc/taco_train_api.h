@@ -30,6 +30,8 @@ int taco_train_create(const taco_hparams* hp, int device, taco_train** out) {
         hipMemcpy(t->d_bf3_segs, sm->bf3_segs.data(), sm->bf3_segs.size() * sizeof(Bf3Seg), hipMemcpyHostToDevice) != hipSuccess) {
       taco_model_destroy(sm); delete t; return fail(TACO_ERR_HIP, "split-bf16 index list allocation failed");
     }
+    t->n_bf3 = sm->bf3_idx.size(); t->n_bf3_segs = (int)sm->bf3_segs.size();
+    std::vector<unsigned>().swap(sm->bf3_idx);          // the host copy (tens of MB) is not needed again
   }
   t->arena_n = sm->arena_n;
   if (hipMalloc((void**)&t->d_map, t->arena_n * sizeof(float)) != hipSuccess ||
@@ -163,7 +165,7 @@ int taco_train_refresh(taco_train* t, void* hip_stream, const float* d_params) {
                      (const float*)t->d_fold, (unsigned)sm->dx_fold_n);
   if (t->d_bf3_idx)                     // the same weights as split-bf16 planes (the map holds zeros there: this runs after the fp32 gather)
     hipLaunchKernelGGL(k_bf3_gather, dim3(2048), dim3(256), 0, (hipStream_t)hip_stream, (const unsigned*)t->d_bf3_idx, (const Bf3Seg*)t->d_bf3_segs,
-                       (int)sm->bf3_segs.size(), d_params, t->sm->darena, sm->bf3_idx.size(), (unsigned)t->NP);
+                       t->n_bf3_segs, d_params, t->sm->darena, t->n_bf3, (unsigned)t->NP);
   if (t->sm->hp.attention_type == 1)    // bah_norm: the pack holds v_hat = g * v / |v| (computed, not copied)
     hipLaunchKernelGGL(k_vnorm_fold, dim3(1), dim3(256), 0, (hipStream_t)hip_stream, d_params + t->poff.at("attention/attention_v"),
                        d_params + t->poff.at("attention/attention_g"), t->sm->darena + (t->sm->att_v - 1), t->sm->hp.attention_size);
