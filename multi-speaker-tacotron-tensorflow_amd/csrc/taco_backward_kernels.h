@@ -48,16 +48,33 @@ __global__ __launch_bounds__(256) void k_bf3_gather(const unsigned* __restrict__
 // The concat projection folded into decoder GRU 1 (taco_model_finalize does it on the host, in double, for inference):
 //   F[z][j] = sum_k C[z][k] * G[k][j],  z = 0 .. Z (row Z: C = the projection's bias), j = 0 .. 3H-1,
 //   G = [gates kernel x rows (2H columns) | candidate kernel x rows (H columns)],  row Z, j < 2H additionally + gates bias[j].
-// One workgroup per row z; fp32 with a fixed summation order.
+// One workgroup per DXF_ROWS rows z (their C rows staged in LDS), thread = column j of each of the three H-wide column blocks; every
+// (z, j) is one fmaf chain over k ascending: fp32 with a fixed summation order.  H = blockDim.x = 256 (the persistent decoder's width).
+#define DXF_ROWS 8
 __global__ __launch_bounds__(256) void k_dx_fold(const float* __restrict__ Wc, const float* __restrict__ bc, const float* __restrict__ gk,
                                                 const float* __restrict__ gb, const float* __restrict__ ck, float* __restrict__ F, int Z, int H) {
-  const int z = blockIdx.x;
-  const float* c = z < Z ? Wc + (size_t)z * H : bc;
-  for (int j = threadIdx.x; j < 3 * H; j += 256) {
-    float acc = 0.f;
-    if (j < 2 * H) { for (int k = 0; k < H; ++k) acc = fmaf(c[k], gk[(size_t)k * 2 * H + j], acc); if (z == Z) acc += gb[j]; }
-    else { for (int k = 0; k < H; ++k) acc = fmaf(c[k], ck[(size_t)k * H + (j - 2 * H)], acc); }
-    F[(size_t)z * 3 * H + j] = acc;
+  __shared__ float cs[DXF_ROWS][256];
+  const int z0 = blockIdx.x * DXF_ROWS, j = threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < DXF_ROWS; ++r) { const int z = z0 + r; cs[r][j] = z < Z ? Wc[(size_t)z * H + j] : (z == Z ? bc[j] : 0.f); }
+  __syncthreads();
+  float acc[DXF_ROWS][3];
+#pragma unroll
+  for (int r = 0; r < DXF_ROWS; ++r) { acc[r][0] = 0.f; acc[r][1] = 0.f; acc[r][2] = 0.f; }
+  for (int k = 0; k < H; ++k) {
+    const float g0 = gk[(size_t)k * 2 * H + j], g1 = gk[(size_t)k * 2 * H + H + j], g2 = ck[(size_t)k * H + j];
+#pragma unroll
+    for (int r = 0; r < DXF_ROWS; ++r) {
+      const float c = cs[r][k];
+      acc[r][0] = fmaf(c, g0, acc[r][0]); acc[r][1] = fmaf(c, g1, acc[r][1]); acc[r][2] = fmaf(c, g2, acc[r][2]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < DXF_ROWS; ++r) {
+    const int z = z0 + r;
+    if (z > Z) continue;
+    float* o = F + (size_t)z * 3 * H;
+    o[j] = acc[r][0] + (z == Z ? gb[j] : 0.f); o[H + j] = acc[r][1] + (z == Z ? gb[H + j] : 0.f); o[2 * H + j] = acc[r][2];
   }
 }
 

@@ -2269,7 +2269,7 @@ int taco_loss_f32(void* hip_stream, const float* d_mel_out, const float* d_mel_t
   const int nbm = std::min(TR_MAXBLK, cdiv(rows * num_mels, TR_NT * 8)), nbl = std::min(TR_MAXBLK, cdiv(rows * num_freq, TR_NT * 8));
   hipLaunchKernelGGL(k_l1_partial, dim3(nbm), dim3(TR_NT), 0, st, d_mel_out, d_mel_tgt, d_loss_coeff, rows, T, num_mels, 0, 0, pm);
   hipLaunchKernelGGL(k_l1_partial, dim3(nbl), dim3(TR_NT), 0, st, d_lin_out, d_lin_tgt, d_loss_coeff, rows, T, num_freq, lo, hi, pl);
-  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, st, pm, nbm, pl, nbl, (double)rows * num_mels, (double)rows * num_freq,
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(TR_NT), 0, st, pm, nbm, pl, nbl, (double)rows * num_mels, (double)rows * num_freq,
                      (double)rows * std::max(hi - lo, 1), prioritize_loss, d_losses);
   HIPCHK(hipGetLastError());
   return 0;

@@ -39,7 +39,7 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
-  size_t n_bf3 = 0; int n_bf3_segs = 0;
+  size_t n_bf3 = 0; int n_bf3_segs = 0; bool bf3_current = false;   // planes regenerated from the current parameters by the last refresh?
   unsigned* d_bf3_idx = nullptr; Bf3Seg* d_bf3_segs = nullptr;   // index list and segment table of the split-bf16 packs (k_bf3_gather)
   float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
@@ -955,6 +955,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   const int n = T_out / r;
   if (n > hp.max_iters) return fail(TACO_ERR_SHAPE, "T_out/r = %d exceeds max_iters %d", n, hp.max_iters);
   TRY(check_common(m, B, T_in));
+  if (m->bf3 && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
   Carver cv(ws, ws_bytes);
   TrainWs w; carve_train(cv, t, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);

@@ -38,12 +38,19 @@ __global__ __launch_bounds__(TR_NT) void k_l1_partial(const float* a, const floa
 }
 
 // losses[0..3] = loss, mel_loss, linear_loss, loss_without_coeff
-__global__ void k_loss_final(const double* pm, int nbm, const double* pl, int nbl, double n_mel, double n_lin, double n_band,
-                             int prioritize, float* losses) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (one workgroup of TR_NT threads: strided partial sums, then a fixed tree -- deterministic; a single thread walking the 2 x 1024 partials
+// one dependent load at a time was 0.2 ms on the step's critical path)
+__global__ __launch_bounds__(TR_NT) void k_loss_final(const double* pm, int nbm, const double* pl, int nbl, double n_mel, double n_lin, double n_band,
+                                                     int prioritize, float* losses) {
+  __shared__ double sm[TR_NT];
+  if (blockIdx.x != 0) return;
   double m0 = 0, m1 = 0, l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-  for (int i = 0; i < nbm; ++i) { m0 += pm[i * 4]; m1 += pm[i * 4 + 1]; }
-  for (int i = 0; i < nbl; ++i) { l0 += pl[i * 4]; l1 += pl[i * 4 + 1]; l2 += pl[i * 4 + 2]; l3 += pl[i * 4 + 3]; }
+  for (int i = threadIdx.x; i < nbm; i += TR_NT) { m0 += pm[i * 4]; m1 += pm[i * 4 + 1]; }
+  for (int i = threadIdx.x; i < nbl; i += TR_NT) { l0 += pl[i * 4]; l1 += pl[i * 4 + 1]; l2 += pl[i * 4 + 2]; l3 += pl[i * 4 + 3]; }
+  m0 = tr_block_sum(m0, sm); __syncthreads(); m1 = tr_block_sum(m1, sm); __syncthreads();
+  l0 = tr_block_sum(l0, sm); __syncthreads(); l1 = tr_block_sum(l1, sm); __syncthreads();
+  l2 = tr_block_sum(l2, sm); __syncthreads(); l3 = tr_block_sum(l3, sm);
+  if (threadIdx.x != 0) return;
   const double mel_loss = m0 / n_mel;
   double loss, lin_loss;
   if (prioritize) {
