@@ -216,7 +216,7 @@ int taco_train_set_exact_wgrad(taco_train* t, int on);
  * linear head) and their data gradients: on = 1 (default) keeps them on the exact-fp32 MFMA (k_gemm); on = 0 runs them on the bf16
  * matrix cores with both operands split in two and three products per tile (k_gemm_bf3, the inference kernels: ~2^-17 per product,
  * fp32 accumulation; the weight planes are re-split on the device from the live parameters by taco_train_refresh, k_bf3_gather) --
- * 13 % off the C4-shard step; gradients then follow the exact engine to ~1e-3 of their norm, individual ReLU / max-pool near-ties
+ * 16 % off the C4-shard step; gradients then follow the exact engine to ~1e-3 of their norm, individual ReLU / max-pool near-ties
  * may resolve differently.  on = 2: forward split-bf16, data gradients exact (A/B hook). */
 int taco_train_set_exact_gemm(taco_train* t, int on);
 /* Back-propagation through the decoder loop (tf.gradients of rnn_wrappers.py:218-341 under train.py:215-219): persistent = 1 (default)

@@ -146,7 +146,7 @@ class Trainer(object):
 
     def set_exact_gemm(self, on=True):
         """True (default): feed-forward and data-gradient GEMMs on the exact-fp32 MFMA.  False: on the split-bf16 matrix-core kernels of
-        inference (k_gemm_bf3; ~2^-17 per product; the weight planes follow the parameters through taco_train_refresh): 13 % off the
+        inference (k_gemm_bf3; ~2^-17 per product; the weight planes follow the parameters through taco_train_refresh): 16 % off the
         C4-shard step, gradients within ~1e-3 of the exact engine's norm.  2: forward split-bf16, data gradients exact (A/B hook)."""
         _lib.check(self._lib.taco_train_set_exact_gemm(self._h, int(on)))
         self.refresh()                 # the split-bf16 planes are (re)generated only while that engine is selected
