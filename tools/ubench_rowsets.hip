@@ -1,0 +1,136 @@
+// ubench_rowsets.hip -- does splitting a group's rows into two software-pipelined sets hide the exchange hops of the persistent decoder?
+// ("two independent row sets ... in k_decoder_xcd".)  The stage of k_decoder_xcd in isolation, built from the
+// kernel's OWN primitives (csrc/taco_decoder_xcd.h: census, dx_pass, dx_reduce, dx_publish, dx_gather): 256 workgroups, one group of 32
+// members per XCD, 10 dependent stages per step, each stage = pass of 2 weight columns over the rows' 256-wide LDS vector -> DPP
+// reduction -> epilogue (sigmoid x tanh) -> publish 8-byte {value, tag} granules -> all-gather into LDS -> barrier.
+//   variant A  one set of RG rows          : compute, publish, gather (the hop is exposed), barrier          -- the decoder today
+//   variant B  two sets of RG/2 rows each  : compute A, publish A | gather B (in flight since the previous half), barrier |
+//              compute B, publish B | gather A, barrier                                                      -- the proposal
+// Same weights in registers for both sets (shared, as proposed), per-set LDS vectors, exchange regions and tags.
+// Prints clocks per stage (shader clock counter of group 0 / member 0) and microseconds per step (HIP events).
+//   hipcc --offload-arch=gfx950 -O3 -I multi-speaker-tacotron-tensorflow_amd/csrc tools/ubench_rowsets.hip -o tools/ubench_rowsets
+#include "taco_decoder_xcd.h"
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+#define UB_NST 10          // dependent stages per step (the decoder has 10 exchanges per step)
+#define UB_LD 512          // LDS floats per row: two alternating 256-wide vectors
+
+struct UbArgs { const float* wpack; unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* clk; float* sink; int steps; };
+
+template <int RG>
+__device__ __forceinline__ void ub_compute(const float (&W)[16], const float* vec, int lane, int wave, int member, dx_gu64* X, unsigned tag, DxRt& rt) {
+  constexpr int RL = DxRL<RG>::value;
+  float acc[2][RG], s[2][RL];
+  dx_zero<2, RG>(acc);
+  dx_pass<0, 2, RG, 16, UB_LD>(W, vec, lane, acc);
+  dx_reduce<2, RG>(acc, s, lane);
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    const float v = dx_sigmoid_fast(s[0][q]) * taco_tanh_fast(s[1][q]);
+    if (epl) dx_publish(X + dx_row<RG>(lane & 3, q) * DX_W + member * 8 + wave, v, tag, rt);
+  }
+}
+
+template <int RG, int SETS>     // RG rows per set
+__global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* st = smem;                                    // [SETS][RG][UB_LD]
+  int* ictl = reinterpret_cast<int*>(st + SETS * RG * UB_LD);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, 0, ictl, tid, 8);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (member >= DX_GROUP) return;
+  float W[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) W[j] = a.wpack[((size_t)member * 16 + j) * DX_NT + tid];
+  for (int i = tid; i < SETS * RG * UB_LD; i += DX_NT) st[i] = 0.01f * (float)(i % 97);
+  __syncthreads();
+  // exchange regions: [set][stage][RG * 256] granules per group
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * SETS * UB_NST * RG * DX_W;
+  const bool tracer = group == 0 && member == 0 && tid == 0;
+  long long t0 = 0;
+  for (int step = 0; step < a.steps; ++step) {
+    if (tracer && step == 8) t0 = (long long)__builtin_readcyclecounter();
+    const unsigned tag = (unsigned)step + 1u;
+    if (SETS == 1) {
+#pragma unroll 1
+      for (int sgi = 0; sgi < UB_NST; ++sgi) {
+        const int rd = (sgi & 1) * 256, wr = 256 - rd;
+        dx_gu64* Xs = X + (size_t)sgi * RG * DX_W;
+        ub_compute<RG>(W, st + rd, lane, wave, member, Xs, tag, rt);
+        dx_gather<RG, DX_W, false, UB_LD>(Xs, tag, st, wr, 0, 0, tid, rt);
+        __syncthreads();
+      }
+    } else {
+      float* stA = st; float* stB = st + RG * UB_LD;
+      dx_gu64* XA = X; dx_gu64* XB = X + (size_t)UB_NST * RG * DX_W;
+#pragma unroll 1
+      for (int sgi = 0; sgi < UB_NST; ++sgi) {
+        const int rd = (sgi & 1) * 256, wr = 256 - rd;
+        const int prev = (sgi + UB_NST - 1) % UB_NST;
+        // set A: stage sgi (its input vector was gathered at the end of the previous iteration)
+        ub_compute<RG>(W, stA + rd, lane, wave, member, XA + (size_t)sgi * RG * DX_W, tag, rt);
+        // set B's vector of the PREVIOUS stage has been in flight since the middle of the previous iteration
+        if (!(step == 0 && sgi == 0))
+          dx_gather<RG, DX_W, false, UB_LD>(XB + (size_t)prev * RG * DX_W, sgi == 0 ? tag - 1u : tag, stB, rd, 0, 0, tid, rt);
+        __syncthreads();
+        ub_compute<RG>(W, stB + rd, lane, wave, member, XB + (size_t)sgi * RG * DX_W, tag, rt);
+        dx_gather<RG, DX_W, false, UB_LD>(XA + (size_t)sgi * RG * DX_W, tag, stA, wr, 0, 0, tid, rt);
+        __syncthreads();
+      }
+    }
+  }
+  if (tracer) { a.clk[0] = (long long)__builtin_readcyclecounter() - t0; }
+  if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (SETS * RG * UB_LD)];
+}
+
+template <int RG, int SETS>
+static int run(const char* name, int steps) {
+  UbArgs a;
+  std::vector<float> hw((size_t)DX_GROUP * 16 * DX_NT);
+  for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.02f * (float)((int)(i * 2654435761u >> 20) % 101 - 50) / 50.f;
+  float* dw; CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+  const size_t xg = (size_t)DX_NGROUP * SETS * UB_NST * RG * DX_W;
+  unsigned long long* xb; CK(hipMalloc(&xb, xg * 8));
+  unsigned *ctl, *err; CK(hipMalloc(&ctl, 256)); CK(hipMalloc(&err, 256));
+  long long* clk; CK(hipMalloc(&clk, 64)); float* sink; CK(hipMalloc(&sink, 256 * 4));
+  a.wpack = dw; a.xbuf = xb; a.ctl = ctl; a.err = err; a.clk = clk; a.sink = sink; a.steps = steps;
+  const size_t lds = std::max((size_t)(SETS * RG * UB_LD + 64) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets<RG, SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float best = 1e30f; long long hclk = 0; unsigned herr[64];
+  for (int rep = 0; rep < 5; ++rep) {
+    CK(hipMemset(xb, 0, xg * 8)); CK(hipMemset(ctl, 0, 256)); CK(hipMemset(err, 0, 256)); CK(hipMemset(clk, 0, 64));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_rowsets<RG, SETS>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipMemcpy(herr, err, 256, hipMemcpyDeviceToHost));
+    if (herr[0]) { printf("%s: device error word %u\n", name, herr[0]); return 1; }
+    if (ms < best) { best = ms; CK(hipMemcpy(&hclk, clk, 8, hipMemcpyDeviceToHost)); }
+  }
+  const double per_stage = (double)hclk / ((double)(steps - 8) * UB_NST * SETS);
+  printf("%-44s %7.2f us per step (%d rows)  %7.0f clocks per step  %6.0f clocks per (set, stage)   protocol %u\n", name, best * 1e3 / steps,
+         RG * SETS, (double)hclk / (steps - 8), per_stage, herr[8]);
+  hipFree(dw); hipFree(xb); hipFree(ctl); hipFree(err); hipFree(clk); hipFree(sink);
+  return 0;
+}
+
+int main() {
+  const int steps = 136;
+  printf("stage of k_decoder_xcd in isolation: 10 exchanges per step, 2 weight columns per wave and stage, 32 members per XCD\n");
+  if (run<4, 1>("one set of 4 rows (C2 today)", steps)) return 1;
+  if (run<2, 2>("two sets of 2 rows, pipelined", steps)) return 1;
+  if (run<2, 1>("one set of 2 rows", steps)) return 1;
+  if (run<8, 1>("one set of 8 rows (64-row pass today)", steps)) return 1;
+  if (run<4, 2>("two sets of 4 rows, pipelined", steps)) return 1;
+  if (run<1, 1>("one set of 1 row", steps)) return 1;
+  return 0;
+}
