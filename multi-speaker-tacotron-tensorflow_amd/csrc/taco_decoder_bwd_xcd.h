@@ -2,14 +2,16 @@
 // rnn_wrappers.py:218-341,367-415, tacotron.py:166-181, helpers.py:35-67) as ONE persistent launch: the mirror of k_decoder_xcd.
 //
 // The launch-per-stage backward is a chain of ~19 dependent launches per decoder step (transposed mat-vecs of k_skinny, the GRU
-// element-wise kernels, k_attention_bwd): 11.9 ms of a 29.5 ms training step at the C4 shard.  Here the step never leaves the chip:
+// element-wise kernels, k_attention_bwd): 11.9 ms of a 29.5 ms training step at the C4 shard (this kernel: 1.7 ms).  Here the step never
+// leaves the chip:
 // same placement (one XCD = one group of 32 members = RG batch rows), same exchange (8-byte {value, tag} granules through the XCD's
 // L2), same pass / reduce / epilogue / publish / gather stages as the forward kernel, with the TRANSPOSED products of BPTT:
 // member m owns column 8m + w of every 256-wide gradient vector, wave w of it keeps the matching ROW of every kernel (its 4-input
 // slice per lane) in VGPRs for the whole launch.  What a step reads from the tape at the owner's (row, column) -- gates,
-// candidates, previous states, prenet outputs -- is loaded one step ahead into registers; the rows it needs whole (dmel, raw scores,
-// alignments) arrive one step ahead straight in LDS.  The state gradients dh2, dh1, dh_att and d ctx never leave the lane that
-// owns their column; d alpha (the monotonic recurrence's carry) lives in LDS on every member of its row.
+// candidates, previous states, prenet outputs, d o2 -- and the rows it needs whole (raw scores, alignments, the processed query) arrive
+// one step ahead straight in LDS (global_load_lds_dword: no registers in flight, nothing waited for on the chain).  The state
+// gradients dh2, dh1, dh_att and d ctx never leave the lane that owns their column; d alpha (the monotonic recurrence's carry) lives
+// in LDS on every member of its row.
 //
 // Per step t = n-1 .. 0 (twelve exchanges):
 //   (do2 = dmel_t . Wf^T: hoisted, one GEMM) GRU 2: d c_pre -> X | d(r*h), d x from Wc^T, gate gradients -> X | d x, dh2 from Wg^T; residual; GRU 1 the same
@@ -84,7 +86,7 @@ struct DbArgs {
   float* d_att_init; float* d_h10; float* d_h20;       // [B, 256] or null
   float* dsb_acc;                                      // [B] or null: d attention_score_bias per row (summed by the host)
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
-  int B, T_in, n, rM, att_type, force_wt;
+  int B, T_in, n, att_type, force_wt;
 };
 
 // K = 512 pass: two 256-halves of the same LD-strided row

@@ -1339,7 +1339,7 @@ static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int 
   a.wpack = AP(m, m->dbx_pack);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
   a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + 2 * DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
-  a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
+  a.B = B; a.T_in = T_in; a.n = n; a.att_type = m->hp.attention_type;
   a.force_wt = m->dx_mode == 2 ? 1 : 0;
   HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));
   const size_t lds = db_lds_floats(RG, T_in) * sizeof(float);
