@@ -185,7 +185,8 @@ int taco_loss_f32(void* hip_stream, const float* d_mel_out, const float* d_mel_t
 float taco_learning_rate(long long global_step, float initial_learning_rate, int decay_learning_rate_mode,
                          int is_randomly_initialized);
 /* clip_by_global_norm + tf.train.AdamOptimizer update (tacotron.py:327-336, TF form of Adam) on flat fp32 buffers.
- * Workspace >= 8 KiB.  d_gnorm_out nullable. */
+ * Workspace >= 8 KiB.  d_gnorm_out nullable.  A non-finite global norm (NaN / inf: a step poisoned after a device fault, or a genuine
+ * overflow) leaves parameters and moments untouched -- where tf.clip_by_global_norm would turn every parameter into NaN. */
 int taco_adam_step_f32(void* hip_stream, float* d_params, const float* d_grads, float* d_m, float* d_v, size_t n,
                        long long global_step, float learning_rate, float beta1, float beta2, float epsilon, float clip_norm,
                        float* d_gnorm_out, void* d_workspace, size_t workspace_bytes);
@@ -253,7 +254,11 @@ int taco_train_set_sync_bn(taco_train* t, taco_sync_sum_fn fn, void* user, int w
  * d_grads (flat, overwritten) = d loss / d parameter; moving statistics get zero.
  * rnn_decoder_test_mode bit 0 (helpers.py:63-64, the test model of train.py:158-166): the decoder is fed its own previous
  * output instead of the target frame; forward/loss only (d_grads must be NULL).  Bit 1: freeze the moving averages even though
- * d_grads is given (a warm-up pass whose update is discarded, e.g. before capturing the step into a graph). */
+ * d_grads is given (a warm-up pass whose update is discarded, e.g. before capturing the step into a graph).
+ * Device faults: if a persistent whole-chip kernel of the step gave up (its bounded spin expired; taco_model_device_errors on
+ * taco_train_model(t) reports and clears the sticky word), d_losses[0..3] and d_grads[0] are set to NaN on the stream: the fault is
+ * visible in the step's own outputs, survives the data-parallel all-reduce, and makes taco_adam_step_f32 skip the update (the
+ * BatchNorm moving averages, which the pass writes itself, may have absorbed that pass's statistics with weight 0.01). */
 int taco_train_forward_backward(taco_train* t, void* hip_stream, float* d_params, float* d_grads, const int32_t* d_inputs,
                                 const int32_t* d_input_lengths, const int32_t* d_speaker_id /* nullable: single speaker */,
                                 const float* d_mel_targets, const float* d_linear_targets,
@@ -300,6 +305,8 @@ int taco_debug_set_overlap(taco_model* m, int on);
  * stage.  mode 2: persistent with write-through (placement-independent) exchanges even when the census finds one group per XCD.
  * rows_per_group: 0 = smallest of 1/2/4/8 that covers the batch with 8 groups; a larger value packs the batch onto fewer XCDs. */
 int taco_debug_set_decoder_persist(taco_model* m, int mode, int rows_per_group);
+/* test hook: set the sticky device error word (as a persistent kernel does when its bounded spin expires) to `value` */
+int taco_debug_raise_device_error(taco_model* m, int value);
 /* Which engine a forward of this shape WOULD run on -- and, when it is not the persistent whole-chip one, why not (widths, rows, LDS,
  * compute units of the device, debug switches).  Nothing is launched.  `out` receives a NUL-terminated line (out_len >= 64; truncated
  * if shorter than the text).  The run-time facts (exchange protocol the census chose) are in taco_debug_decoder_info afterwards. */

@@ -148,6 +148,7 @@ PROTOTYPES = {
     "taco_debug_set_att_split": (_I, [_P, _I]),
     "taco_debug_set_bf3": (_I, [_P, _I, _I]),
     "taco_model_device_errors": (_I, [_P, C.POINTER(_I)]),
+    "taco_debug_raise_device_error": (_I, [_P, _I]),
     "taco_debug_set_decoder_persist": (_I, [_P, _I, _I]),
     "taco_debug_decoder_info": (_I, [_P, C.POINTER(_I)]),
     "taco_model_engine_plan": (_I, [_P, _I, _I, _I, _I, C.c_char_p, _I]),

@@ -1901,6 +1901,15 @@ int taco_model_device_errors(taco_model* m, int* out) {
   return 0;
 }
 
+// test hook: raise the sticky device error word by hand (what a persistent kernel does when its bounded spin expires)
+int taco_debug_raise_device_error(taco_model* m, int value) {
+  if (!m || !m->finalized) return fail(TACO_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->device));
+  const unsigned v = (unsigned)value;
+  HIPCHK(hipMemcpy(m->d_err, &v, sizeof v, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->bf3 = (on & 1) != 0; m->bf3_tn = tile_n;

@@ -63,6 +63,15 @@ __global__ __launch_bounds__(TR_NT) void k_loss_final(const double* pm, int nbm,
   losses[0] = (float)loss; losses[1] = (float)mel_loss; losses[2] = (float)lin_loss; losses[3] = (float)(mel_loss + lin_loss);
 }
 
+// see taco_train_forward_backward: the sticky device error word -> NaN losses and one NaN gradient element
+__global__ void k_train_latch(const unsigned* err, float* losses, float* grads) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && err && err[0] != 0u) {
+    const float nan = __uint_as_float(0x7FC00000u);
+    if (losses) { losses[0] = nan; losses[1] = nan; losses[2] = nan; losses[3] = nan; }
+    if (grads) grads[0] = nan;
+  }
+}
+
 __global__ __launch_bounds__(TR_NT) void k_sumsq_partial(const float* g, size_t n, double* partial) {
   __shared__ double sm[TR_NT];
   double s = 0;
@@ -86,6 +95,10 @@ __global__ __launch_bounds__(TR_NT) void k_adam(float* p, const float* g, float*
   const double gn = sqrt(tr_block_sum(s, sm));
   const float scale = (float)((double)clip / fmax(gn, (double)clip));      // tf.clip_by_global_norm
   if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) *gnorm_out = (float)gn;
+  // a non-finite global norm (a gradient poisoned by k_train_latch after a device fault, or a genuine overflow) skips the update:
+  // parameters and moments stay as they are.  (tf.clip_by_global_norm would turn every parameter into NaN here; nothing can be
+  // learned from such a step either way, and a data-parallel job stays consistent because all ranks see the same reduced norm.)
+  if (!(gn < 1.7976931348623157e308)) return;
   for (size_t i = (size_t)blockIdx.x * TR_NT + threadIdx.x; i < n; i += (size_t)gridDim.x * TR_NT) {
     const float gi = g[i] * scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;

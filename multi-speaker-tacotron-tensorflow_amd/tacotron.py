@@ -599,6 +599,10 @@ class Tacotron(object):
         _lib.check(self._lib.taco_debug_decoder_trace(self._handle, (1 if enable else 0) | (2 if scan else 0), out))
         return np.array(out[:], np.int64).reshape(8, 16) if read else None
 
+    def raise_device_error_for_test(self, value=2):
+        """Test hook: sets the sticky device error word, as a persistent kernel whose bounded spin expired does."""
+        _lib.check(self._lib.taco_debug_raise_device_error(self._handle, int(value)))
+
     def check_device_errors(self):
         """Synchronises and raises if a persistent kernel's bounded spin expired (outputs invalid)."""
         v = C.c_int(0)

@@ -170,6 +170,11 @@ class Trainer(object):
         return {"protocol": int(v[0]), "per_xcd": [int(x) for x in v[1:9]], "has_pack": bool(v[15]), "compute_units": int(v[14]),
                 "bptt_protocol": int(v[9])}       # 0: the last decoder backward was the chain of per-stage launches
 
+    def raise_device_error_for_test(self, value=2):
+        """Test hook: sets the sticky device error word, as a persistent kernel whose bounded spin expired does."""
+        mh = C.c_void_p(self._lib.taco_train_model(self._h))
+        _lib.check(self._lib.taco_debug_raise_device_error(mh, int(value)))
+
     def check_device_errors(self):
         """Synchronises and raises if a persistent kernel of the training forward gave up (outputs and gradients invalid)."""
         mh = C.c_void_p(self._lib.taco_train_model(self._h))

@@ -330,3 +330,31 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     t = build_model(tiny_hp(), O.init_weights(tiny_hp(), 1, 403))
     plan = t.engine_plan(4, 9)
     assert "one launch per stage -- widths differ" in plan and "resident per-row kernels" in plan, plan
+
+
+def test_a_device_fault_is_reported_by_the_forward_that_saw_it():
+    """the sticky device error word, raised by hand here (taco_debug_raise_device_error), comes back in the stop word
+    of the next forward (negative), Tacotron.run and PlanPool.result raise on it and acknowledge it, and the forward after that is
+    clean and equal to the one before the fault."""
+    import torch
+    import taco_amd
+    ohp = O.OracleHParams(max_iters=6)
+    m = build_model(ohp, O.init_weights(ohp, 1, 411))
+    ids, L = O.synthetic_inputs(4, 10, 412)
+    lin0, al0 = m.run(ids, L, honor_stop=False)
+    lin0 = lin0.clone()
+    m.raise_device_error_for_test()
+    with pytest.raises(taco_amd._lib.TacoError):
+        m.run(ids, L, honor_stop=False)
+    lin1, _ = m.run(ids, L, honor_stop=False)            # acknowledged by the failed call: clean again
+    torch.cuda.synchronize()
+    assert torch.equal(lin1, lin0)
+    pool = taco_amd.tacotron.PlanPool(m, 4, 10, lanes=1)
+    t = pool.submit(ids, L); ok = pool.result(t)
+    m.raise_device_error_for_test()
+    t = pool.submit(ids, L)
+    with pytest.raises(taco_amd._lib.TacoError):
+        pool.result(t)
+    t = pool.submit(ids, L); again = pool.result(t)
+    assert torch.equal(again["linear"], ok["linear"])
+    pool.close()

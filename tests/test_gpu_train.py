@@ -704,3 +704,41 @@ def test_split_bf16_training_gemms_track_the_exact_engine(atype, B):
     l2 = tr.forward_backward(ids, L, mt, lt, None, backward=False).cpu().numpy().copy()
     assert step == 1 and abs(l1[0] - l2[0]) < 1e-5 and l1[0] < lf[0]
     tr.close()
+
+
+@pytest.mark.gpu
+def test_a_device_fault_poisons_the_step_and_adam_skips_the_update():
+    """ADVICE r02 (medium), training side: a persistent kernel that gave up must not feed garbage into the optimizer.  The sticky device
+    error word is raised by hand (taco_debug_raise_device_error): the next step's losses and first gradient element are NaN, the
+    update is skipped (parameters and moments bit-identical), check_device_errors() raises and clears, and the step after that trains."""
+    import torch
+    import taco_amd
+    hp = O.OracleHParams(max_iters=8)
+    w = O.init_weights(hp, 1, 111)
+    B, T_in, T_out = 4, 12, 8 * hp.reduction_factor
+    ids, L = O.synthetic_inputs(B, T_in, 112, ragged=True)
+    rs = np.random.RandomState(113)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    tr = taco_amd.Trainer(to_product_hp(hp), w)
+    tr.train_step(ids, L, mt, lt, None)
+    torch.cuda.synchronize()
+    before = tr.params.clone(); m0 = tr.adam.m.clone()
+    tr.raise_device_error_for_test()
+    step, lwc = tr.train_step(ids, L, mt, lt, None)
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(lwc)) and not np.isfinite(float(tr.grads[0]))
+    assert torch.equal(tr.adam.m, m0)
+    now = tr.params
+    for name, shape in tr.spec:        # every trained parameter is untouched (the BatchNorm moving statistics are written by the forward pass itself)
+        if "moving_" in name:
+            continue
+        o, c = tr.offsets[name]
+        assert torch.equal(now[o:o + c], before[o:o + c]), name
+    with pytest.raises(taco_amd._lib.TacoError):
+        tr.check_device_errors()
+    step, lwc = tr.train_step(ids, L, mt, lt, None)       # the word was acknowledged: this one is a normal step again
+    torch.cuda.synchronize()
+    o, c = tr.offsets["linear/kernel"]
+    assert np.isfinite(float(lwc)) and not torch.equal(tr.params[o:o + c], before[o:o + c])
+    tr.check_device_errors()
+    tr.close()
