@@ -54,7 +54,7 @@ __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
   // exchange regions: [set][stage][RG * 256] granules per group
   dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * SETS * UB_NST * RG * DX_W;
   const bool tracer = group == 0 && member == 0 && tid == 0;
-  long long t0 = 0;
+  long long t0 = 0, ph[3] = {0, 0, 0};
   for (int step = 0; step < a.steps; ++step) {
     if (tracer && step == 8) t0 = (long long)__builtin_readcyclecounter();
     const unsigned tag = (unsigned)step + 1u;
@@ -63,9 +63,13 @@ __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
       for (int sgi = 0; sgi < UB_NST; ++sgi) {
         const int rd = (sgi & 1) * 256, wr = 256 - rd;
         dx_gu64* Xs = X + (size_t)sgi * RG * DX_W;
+        const long long c0 = tracer ? (long long)__builtin_readcyclecounter() : 0;
         ub_compute<RG>(W, st + rd, lane, wave, member, Xs, tag, rt);
+        const long long c1 = tracer ? (long long)__builtin_readcyclecounter() : 0;
         dx_gather<RG, DX_W, false, UB_LD>(Xs, tag, st, wr, 0, 0, tid, rt);
+        const long long c2 = tracer ? (long long)__builtin_readcyclecounter() : 0;
         __syncthreads();
+        if (tracer && step >= 8) { ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += (long long)__builtin_readcyclecounter() - c2; }
       }
     } else {
       float* stA = st; float* stB = st + RG * UB_LD;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
       }
     }
   }
-  if (tracer) { a.clk[0] = (long long)__builtin_readcyclecounter() - t0; }
+  if (tracer) { a.clk[0] = (long long)__builtin_readcyclecounter() - t0; a.clk[1] = ph[0]; a.clk[2] = ph[1]; a.clk[3] = ph[2]; }
   if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (SETS * RG * UB_LD)];
 }
 
@@ -104,7 +108,7 @@ static int run(const char* name, int steps) {
   const size_t lds = std::max((size_t)(SETS * RG * UB_LD + 64) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets<RG, SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  float best = 1e30f; long long hclk = 0; unsigned herr[64];
+  float best = 1e30f; long long hclk = 0, hph[4] = {0, 0, 0, 0}; unsigned herr[64];
   for (int rep = 0; rep < 5; ++rep) {
     CK(hipMemset(xb, 0, xg * 8)); CK(hipMemset(ctl, 0, 256)); CK(hipMemset(err, 0, 256)); CK(hipMemset(clk, 0, 64));
     CK(hipDeviceSynchronize());
@@ -114,11 +118,16 @@ static int run(const char* name, int steps) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(herr, err, 256, hipMemcpyDeviceToHost));
     if (herr[0]) { printf("%s: device error word %u\n", name, herr[0]); return 1; }
-    if (ms < best) { best = ms; CK(hipMemcpy(&hclk, clk, 8, hipMemcpyDeviceToHost)); }
+    if (ms < best) { best = ms; CK(hipMemcpy(hph, clk, 32, hipMemcpyDeviceToHost)); hclk = hph[0]; }
   }
   const double per_stage = (double)hclk / ((double)(steps - 8) * UB_NST * SETS);
   printf("%-44s %7.2f us per step (%d rows)  %7.0f clocks per step  %6.0f clocks per (set, stage)   protocol %u\n", name, best * 1e3 / steps,
          RG * SETS, (double)hclk / (steps - 8), per_stage, herr[8]);
+  if (SETS == 1) {
+    const double ns = (double)(steps - 8) * UB_NST;
+    printf("%-44s   of a stage (wave 0 of member 0): pass + reduce + epilogue + publish %5.0f | poll until all granules carry the tag + LDS write %5.0f | barrier %5.0f\n",
+           "", hph[1] / ns, hph[2] / ns, hph[3] / ns);
+  }
   hipFree(dw); hipFree(xb); hipFree(ctl); hipFree(err); hipFree(clk); hipFree(sink);
   return 0;
 }
