@@ -34,6 +34,105 @@ __device__ __forceinline__ void ub_compute(const float (&W)[16], const float* ve
   }
 }
 
+// ---- variant S: 4-byte granules, no tag: "not written yet" is a sentinel bit pattern (a NaN payload no stage produces); two parity
+// copies of every exchange region, the producer of step t re-arms its slot of the other parity while it publishes (every consumer of
+// step t - 1's value has read it by then: nobody reaches stage s of step t before everyone has gathered stage s of step t - 1).
+// Half the bytes per value, and a thread polls its RG/2 values with ONE 8-byte load per pair instead of one per value.
+#define UB_SENT 0xFFFFDEADu
+typedef __attribute__((address_space(1))) unsigned ub_gu32;
+template <int RG>
+__device__ __forceinline__ void ub_compute_s(const float (&W)[16], const float* vec, int lane, int wave, int member, ub_gu32* Xcur, ub_gu32* Xoth, DxRt& rt) {
+  constexpr int RL = DxRL<RG>::value;
+  float acc[2][RG], s[2][RL];
+  dx_zero<2, RG>(acc);
+  dx_pass<0, 2, RG, 16, UB_LD>(W, vec, lane, acc);
+  dx_reduce<2, RG>(acc, s, lane);
+  const bool epl = lane < (RG >= 4 ? 4 : RG);
+#pragma unroll
+  for (int q = 0; q < RL; ++q) {
+    const float v = dx_sigmoid_fast(s[0][q]) * taco_tanh_fast(s[1][q]);
+    if (epl) {
+      const int o = dx_row<RG>(lane & 3, q) * DX_W + member * 8 + wave;
+      if (rt.wt) { __hip_atomic_store(Xcur + o, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(Xoth + o, UB_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      else { __hip_atomic_store(Xcur + o, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); __hip_atomic_store(Xoth + o, UB_SENT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    }
+  }
+}
+template <int RG>
+__device__ __forceinline__ void ub_gather_s(const ub_gu32* X, float* st, int off, int tid, DxRt& rt) {
+  constexpr int NV = RG * DX_W;                 // values per region
+  if (NV >= 2 * DX_NT) {                        // pairs: one 8-byte load per two values
+    constexpr int NP = NV >= 2 * DX_NT ? NV / (2 * DX_NT) : 1;
+    const dx_gu64* P = (const dx_gu64*)X;
+    unsigned long long g[NP];
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) g[u] = __hip_atomic_load(P + tid + u * DX_NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < NP; ++u) ok = ok && ((unsigned)g[u] != UB_SENT) && ((unsigned)(g[u] >> 32) != UB_SENT);
+      if (ok || rt.dead) break;
+      if ((++spins & 1023u) == 0 && spins >= DX_SPIN_LIMIT) { __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rt.dead = true; }
+    }
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = 2 * (tid + u * DX_NT);
+      *reinterpret_cast<float2*>(st + (i / DX_W) * UB_LD + off + (i % DX_W)) = make_float2(__uint_as_float((unsigned)g[u]), __uint_as_float((unsigned)(g[u] >> 32)));
+    }
+  } else {
+    if (tid < NV) {
+      unsigned g; unsigned spins = 0;
+      for (;;) {
+        g = __hip_atomic_load(X + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != UB_SENT || rt.dead) break;
+        if ((++spins & 1023u) == 0 && spins >= DX_SPIN_LIMIT) { __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rt.dead = true; }
+      }
+      st[(tid / DX_W) * UB_LD + off + (tid % DX_W)] = __uint_as_float(g);
+    }
+  }
+}
+template <int RG>
+__global__ __launch_bounds__(DX_NT) void k_rowsets_s(const UbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* st = smem;
+  int* ictl = reinterpret_cast<int*>(st + RG * UB_LD);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, 0, ictl, tid, 8);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (member >= DX_GROUP) return;
+  float W[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) W[j] = a.wpack[((size_t)member * 16 + j) * DX_NT + tid];
+  for (int i = tid; i < RG * UB_LD; i += DX_NT) st[i] = 0.01f * (float)(i % 97);
+  __syncthreads();
+  ub_gu32* X = (ub_gu32*)a.xbuf + (size_t)group * 2 * UB_NST * RG * DX_W;       // [parity][stage][RG * 256]
+  const bool tracer = group == 0 && member == 0 && tid == 0;
+  long long t0 = 0, ph[3] = {0, 0, 0};
+  for (int step = 0; step < a.steps; ++step) {
+    if (tracer && step == 8) t0 = (long long)__builtin_readcyclecounter();
+    const int par = step & 1;
+#pragma unroll 1
+    for (int sgi = 0; sgi < UB_NST; ++sgi) {
+      const int rd = (sgi & 1) * 256, wr = 256 - rd;
+      ub_gu32* Xc = X + ((size_t)par * UB_NST + sgi) * RG * DX_W;
+      ub_gu32* Xo = X + ((size_t)(par ^ 1) * UB_NST + sgi) * RG * DX_W;
+      const long long c0 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      ub_compute_s<RG>(W, st + rd, lane, wave, member, Xc, Xo, rt);
+      const long long c1 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      ub_gather_s<RG>(Xc, st, wr, tid, rt);
+      const long long c2 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      __syncthreads();
+      if (tracer && step >= 8) { ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += (long long)__builtin_readcyclecounter() - c2; }
+    }
+  }
+  if (tracer) { a.clk[0] = (long long)__builtin_readcyclecounter() - t0; a.clk[1] = ph[0]; a.clk[2] = ph[1]; a.clk[3] = ph[2]; }
+  if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (RG * UB_LD)];
+}
+
 template <int RG, int SETS>     // RG rows per set
 __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -94,26 +193,30 @@ __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
   if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (SETS * RG * UB_LD)];
 }
 
-template <int RG, int SETS>
+template <int RG, int SETS, int PROTO = 0>
 static int run(const char* name, int steps) {
   UbArgs a;
   std::vector<float> hw((size_t)DX_GROUP * 16 * DX_NT);
   for (size_t i = 0; i < hw.size(); ++i) hw[i] = 0.02f * (float)((int)(i * 2654435761u >> 20) % 101 - 50) / 50.f;
   float* dw; CK(hipMalloc(&dw, hw.size() * 4)); CK(hipMemcpy(dw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
-  const size_t xg = (size_t)DX_NGROUP * SETS * UB_NST * RG * DX_W;
+  const size_t xg = (size_t)DX_NGROUP * (PROTO ? 1 : SETS) * UB_NST * RG * DX_W;      // 8-byte units (variant S: two parities of 4-byte granules)
   unsigned long long* xb; CK(hipMalloc(&xb, xg * 8));
   unsigned *ctl, *err; CK(hipMalloc(&ctl, 256)); CK(hipMalloc(&err, 256));
   long long* clk; CK(hipMalloc(&clk, 64)); float* sink; CK(hipMalloc(&sink, 256 * 4));
   a.wpack = dw; a.xbuf = xb; a.ctl = ctl; a.err = err; a.clk = clk; a.sink = sink; a.steps = steps;
   const size_t lds = std::max((size_t)(SETS * RG * UB_LD + 64) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets<RG, SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets_s<RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f; long long hclk = 0, hph[4] = {0, 0, 0, 0}; unsigned herr[64];
   for (int rep = 0; rep < 5; ++rep) {
-    CK(hipMemset(xb, 0, xg * 8)); CK(hipMemset(ctl, 0, 256)); CK(hipMemset(err, 0, 256)); CK(hipMemset(clk, 0, 64));
+    if (PROTO) { std::vector<unsigned> fill(xg * 2, UB_SENT); CK(hipMemcpy(xb, fill.data(), xg * 8, hipMemcpyHostToDevice)); }
+    else CK(hipMemset(xb, 0, xg * 8));
+    CK(hipMemset(ctl, 0, 256)); CK(hipMemset(err, 0, 256)); CK(hipMemset(clk, 0, 64));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((k_rowsets<RG, SETS>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
+    if (PROTO) hipLaunchKernelGGL((k_rowsets_s<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
+    else hipLaunchKernelGGL((k_rowsets<RG, SETS>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     CK(hipMemcpy(herr, err, 256, hipMemcpyDeviceToHost));
@@ -141,5 +244,10 @@ int main() {
   if (run<8, 1>("one set of 8 rows (64-row pass today)", steps)) return 1;
   if (run<4, 2>("two sets of 4 rows, pipelined", steps)) return 1;
   if (run<1, 1>("one set of 1 row", steps)) return 1;
+  printf("variant S: 4-byte granules with a sentinel instead of {value, tag}, two parity copies, pairs of values polled by one 8-byte load\n");
+  if (run<4, 1, 1>("S: one set of 4 rows", steps)) return 1;
+  if (run<8, 1, 1>("S: one set of 8 rows", steps)) return 1;
+  if (run<2, 1, 1>("S: one set of 2 rows", steps)) return 1;
+  if (run<1, 1, 1>("S: one set of 1 row", steps)) return 1;
   return 0;
 }
