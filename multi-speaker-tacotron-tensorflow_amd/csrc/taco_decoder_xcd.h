@@ -347,9 +347,54 @@ __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsign
 }
 // all-gather of a published [RG][N] vector into the LDS state vector at column offset `off` (N a power of two);
 // RES: dst2[r][n] = value + res[r][n] as well (ResidualWrapper output, tacotron.py:172)
+// Two ADJACENT granules with one 16-byte request (each 8-byte half is one producer's single 8-byte store; a half that has not landed
+// fails its own tag test and the pair is asked for again).  Used where a thread collects four or more granules per gather (eight rows
+// per group; the 512-wide gate-gradient vectors of the BPTT kernel): measured on the exchange stage in isolation
+// (tools/ubench_rowsets, variant T) 13.96 -> 12.63 us per step at eight rows, and nothing at two granules per thread (C2's decoder).
+typedef unsigned long long dx_u64x2 __attribute__((ext_vector_type(2)));
+template <int NP>
+__device__ __forceinline__ void dx_poll_pairs(const dx_gu64* p0, size_t stride, unsigned tag, float (&v)[2 * NP], DxRt& rt) {
+  dx_u64x2 g[NP];
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const dx_gu64* p = p0 + u * stride;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(p) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < NP; ++u) ok = ok && ((unsigned)(g[u][0] >> 32) == tag) && ((unsigned)(g[u][1] >> 32) == tag);
+    if (ok || rt.dead) break;
+    if ((++spins & 1023u) == 0) {
+      if (spins >= DX_SPIN_LIMIT || __hip_atomic_load(rt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rt.dead = true;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NP; ++u) { v[2 * u] = __uint_as_float((unsigned)g[u][0]); v[2 * u + 1] = __uint_as_float((unsigned)g[u][1]); }
+}
 template <int RG, int N, bool RES, int LD = DXS_LD, int NT = DX_NT>
 __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float* st, int off, int off_res, int off2, int tid, DxRt& rt) {
   constexpr int NI = (RG * N + NT - 1) / NT;
+  if constexpr (NI >= 4 && NI % 2 == 0 && (RG * N) % (2 * NT) == 0 && N % 2 == 0) {
+    constexpr int NP = NI / 2;
+    float v[NI];
+    dx_poll_pairs<NP>(X + 2 * tid, (size_t)2 * NT, tag, v, rt);
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int i = 2 * (u * NT + tid), r = i / N, n = i % N;
+      *reinterpret_cast<float2*>(st + r * LD + off + n) = make_float2(v[2 * u], v[2 * u + 1]);
+      if (RES) {
+        const float2 rs = *reinterpret_cast<const float2*>(st + r * LD + off_res + n);
+        *reinterpret_cast<float2*>(st + r * LD + off2 + n) = make_float2(v[2 * u] + rs.x, v[2 * u + 1] + rs.y);
+      }
+    }
+    return;
+  }
   const bool act = (RG * N >= NT) || tid < RG * N;
   if (act) {
     float v[NI];

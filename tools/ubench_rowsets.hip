@@ -133,6 +133,75 @@ __global__ __launch_bounds__(DX_NT) void k_rowsets_s(const UbArgs a) {
   if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (RG * UB_LD)];
 }
 
+// ---- variant T: the {value, tag} granules as they are, but a thread polls two ADJACENT granules with one 16-byte load (each 8-byte half
+// is written by a single 8-byte store; a half that is not there yet fails its tag test and the pair is requested again)
+typedef unsigned long long ub_u64x2 __attribute__((ext_vector_type(2)));
+template <int RG>
+__device__ __forceinline__ void ub_gather_t(const dx_gu64* X, unsigned tag, float* st, int off, int tid, DxRt& rt) {
+  constexpr int NV = RG * DX_W;
+  static_assert(NV >= 2 * DX_NT, "pairs");
+  constexpr int NP = NV / (2 * DX_NT);
+  ub_u64x2 g[NP];
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const dx_gu64* p = X + 2 * (tid + u * DX_NT);
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(g[u]) : "v"(p) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < NP; ++u) ok = ok && ((unsigned)(g[u][0] >> 32) == tag) && ((unsigned)(g[u][1] >> 32) == tag);
+    if (ok || rt.dead) break;
+    if ((++spins & 1023u) == 0 && spins >= DX_SPIN_LIMIT) { __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); rt.dead = true; }
+  }
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int i = 2 * (tid + u * DX_NT);
+    *reinterpret_cast<float2*>(st + (i / DX_W) * UB_LD + off + (i % DX_W)) = make_float2(__uint_as_float((unsigned)g[u][0]), __uint_as_float((unsigned)g[u][1]));
+  }
+}
+template <int RG>
+__global__ __launch_bounds__(DX_NT) void k_rowsets_t(const UbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* st = smem;
+  int* ictl = reinterpret_cast<int*>(st + RG * UB_LD);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, 0, ictl, tid, 8);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (member >= DX_GROUP) return;
+  float W[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) W[j] = a.wpack[((size_t)member * 16 + j) * DX_NT + tid];
+  for (int i = tid; i < RG * UB_LD; i += DX_NT) st[i] = 0.01f * (float)(i % 97);
+  __syncthreads();
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)group * UB_NST * RG * DX_W;
+  const bool tracer = group == 0 && member == 0 && tid == 0;
+  long long t0 = 0, ph[3] = {0, 0, 0};
+  for (int step = 0; step < a.steps; ++step) {
+    if (tracer && step == 8) t0 = (long long)__builtin_readcyclecounter();
+    const unsigned tag = (unsigned)step + 1u;
+#pragma unroll 1
+    for (int sgi = 0; sgi < UB_NST; ++sgi) {
+      const int rd = (sgi & 1) * 256, wr = 256 - rd;
+      dx_gu64* Xs = X + (size_t)sgi * RG * DX_W;
+      const long long c0 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      ub_compute<RG>(W, st + rd, lane, wave, member, Xs, tag, rt);
+      const long long c1 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      ub_gather_t<RG>(Xs, tag, st, wr, tid, rt);
+      const long long c2 = tracer ? (long long)__builtin_readcyclecounter() : 0;
+      __syncthreads();
+      if (tracer && step >= 8) { ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += (long long)__builtin_readcyclecounter() - c2; }
+    }
+  }
+  if (tracer) { a.clk[0] = (long long)__builtin_readcyclecounter() - t0; a.clk[1] = ph[0]; a.clk[2] = ph[1]; a.clk[3] = ph[2]; }
+  if (tid == 0) a.sink[blockIdx.x] = st[(tid * 7) % (RG * UB_LD)];
+}
+
 template <int RG, int SETS>     // RG rows per set
 __global__ __launch_bounds__(DX_NT) void k_rowsets(const UbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -207,15 +276,17 @@ static int run(const char* name, int steps) {
   const size_t lds = std::max((size_t)(SETS * RG * UB_LD + 64) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets<RG, SETS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets_s<RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if constexpr (RG >= 4) CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rowsets_t<RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e30f; long long hclk = 0, hph[4] = {0, 0, 0, 0}; unsigned herr[64];
   for (int rep = 0; rep < 5; ++rep) {
-    if (PROTO) { std::vector<unsigned> fill(xg * 2, UB_SENT); CK(hipMemcpy(xb, fill.data(), xg * 8, hipMemcpyHostToDevice)); }
+    if (PROTO == 1) { std::vector<unsigned> fill(xg * 2, UB_SENT); CK(hipMemcpy(xb, fill.data(), xg * 8, hipMemcpyHostToDevice)); }
     else CK(hipMemset(xb, 0, xg * 8));
     CK(hipMemset(ctl, 0, 256)); CK(hipMemset(err, 0, 256)); CK(hipMemset(clk, 0, 64));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    if (PROTO) hipLaunchKernelGGL((k_rowsets_s<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
+    if (PROTO == 2) { if constexpr (RG >= 4) hipLaunchKernelGGL((k_rowsets_t<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a); }
+    else if (PROTO) hipLaunchKernelGGL((k_rowsets_s<RG>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
     else hipLaunchKernelGGL((k_rowsets<RG, SETS>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, 0, a);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -249,5 +320,8 @@ int main() {
   if (run<8, 1, 1>("S: one set of 8 rows", steps)) return 1;
   if (run<2, 1, 1>("S: one set of 2 rows", steps)) return 1;
   if (run<1, 1, 1>("S: one set of 1 row", steps)) return 1;
+  printf("variant T: {value, tag} granules as they are, two adjacent granules polled by one 16-byte load\n");
+  if (run<4, 1, 2>("T: one set of 4 rows", steps)) return 1;
+  if (run<8, 1, 2>("T: one set of 8 rows", steps)) return 1;
   return 0;
 }
