@@ -214,11 +214,17 @@ int taco_train_set_deterministic(taco_train* t, int on);
  * exact-fp32 MFMA (k_wgrad, round 1).  Process-wide A/B and test hook. */
 int taco_train_set_exact_wgrad(taco_train* t, int on);
 /* Feed-forward GEMMs of the training step (both CBHGs' conv banks / projections / highways / GRU input projections, encoder prenet,
- * linear head) and their data gradients: on = 1 (default) keeps them on the exact-fp32 MFMA (k_gemm); on = 0 runs them on the bf16
- * matrix cores with both operands split in two and three products per tile (k_gemm_bf3, the inference kernels: ~2^-17 per product,
- * fp32 accumulation; the weight planes are re-split on the device from the live parameters by taco_train_refresh, k_bf3_gather) --
- * 16 % off the C4-shard step; gradients then follow the exact engine to ~1e-3 of their norm, individual ReLU / max-pool near-ties
- * may resolve differently.  on = 2: forward split-bf16, data gradients exact (A/B hook). */
+ * linear head) and their data gradients.  k_gemm = exact-fp32 MFMA; k_gemm_bf3 = the inference kernels: bf16 matrix cores, both
+ * operands split in two, three products per tile (~2^-17 per product, fp32 accumulation), weight planes re-split on the device from
+ * the live parameters by taco_train_refresh (k_bf3_gather).
+ *   on = 3 (default): forward on k_gemm, data gradients on k_gemm_bf3.  The forward -- and with it every ReLU / max-pool decision and
+ *          every BatchNorm statistic -- is exact; a data gradient is linear in dY, and the split costs 4e-6 of the gradient norm
+ *          against the all-exact step (measured; tensor by tensor <= 4e-5 of the tensor's scale).  9 % off the C4-shard step.
+ *   on = 1: everything on k_gemm (rounds 1-2).
+ *   on = 0: everything on k_gemm_bf3: 16 % off the step; the forward's ~1e-5 relative product error is amplified by the BatchNorm
+ *          backward's cancellations to ~1e-3 of the gradient norm and resolves near-ties differently.
+ *   on = 2: forward k_gemm_bf3, data gradients k_gemm (A/B hook).
+ * Call taco_train_refresh after switching (the planes are generated only while an engine that needs them is selected). */
 int taco_train_set_exact_gemm(taco_train* t, int on);
 /* Back-propagation through the decoder loop (tf.gradients of rnn_wrappers.py:218-341 under train.py:215-219): persistent = 1 (default)
  * runs all T_out/r steps as ONE whole-chip launch (k_decoder_bwd_xcd, csrc/taco_decoder_bwd_xcd.h) when the forward ran on the persistent

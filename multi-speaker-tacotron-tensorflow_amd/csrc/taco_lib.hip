@@ -722,6 +722,7 @@ static int pick_cfg(const taco_model* m, int M, int N, int nvar) {
   return 2;
 }
 
+static thread_local int g_gemm_force_bf3 = 0;     // set around a call by run_dgrad (taco_train.h): this GEMM on the split-bf16 kernel although the model's switch is off
 static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, int nvar, bool dual, const GemmCall& c) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
@@ -738,7 +739,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     a.v[i] = m->hvars[layers[i].var_index];
   }
   if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
-  if (m->bf3 && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (every feed-forward layer of inference)
+  if ((m->bf3 || g_gemm_force_bf3) && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (every feed-forward layer of inference)
     // tiles (rows x cols): 1 = 128x64, 2 = 128x128, 3 = 64x256 (one staged 64-row tile feeds 8 MFMA column tiles)
     // measured (tools/time_gemm_layers.py): 64x256 wins when K or N is large (proj_1, linear, GRU projection), 128x64 otherwise
     const int Ktot = L0.kw * L0.cin;

@@ -39,7 +39,7 @@ struct taco_train {
   std::map<std::string, size_t> poff;  // flat offset of every spec tensor
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
-  size_t n_bf3 = 0; int n_bf3_segs = 0; bool bf3_current = false;   // planes regenerated from the current parameters by the last refresh?
+  size_t n_bf3 = 0; int n_bf3_segs = 0; bool want_bf3_planes = false; bool bf3_current = false;   // planes regenerated from the current parameters by the last refresh?
   unsigned* d_bf3_idx = nullptr; Bf3Seg* d_bf3_segs = nullptr;   // index list and segment table of the split-bf16 packs (k_bf3_gather)
   float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
@@ -273,12 +273,14 @@ static void run_embed_bwd(hipStream_t st, const float* dx, const int* ids, float
   if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * E), 0, st, dx, ids, dE, M, E, V);
   else hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)M * E), 0, st, dx, ids, dE, M, E);
 }
+static int g_dgrad_bf3 = 0;       // taco_train_set_exact_gemm(t, 3): forward GEMMs exact fp32, data gradients split-bf16
 static int g_dgrad_exact = 0;     // taco_train_set_exact_gemm(t, 2): data gradients on the exact-fp32 MFMA, forward GEMMs split-bf16 (A/B hook)
 // y = x . W^T style data gradient through k_gemm: out = conv_T(dy) (+ res)
 static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const float* dy, int lddy, int M, int T, float* out, int ldo,
                      const float* res = nullptr, int ldres = 0) {
   GemmCall g; g.x = dy; g.ldx = lddy; g.M = M; g.T = T; g.out = out; g.ldo = ldo; g.res = res; g.ldres = ldres;
   if (g_dgrad_exact) { ConvL E = Ld; E.bh = E.bl = 0; return run_gemm(m, st, &E, 1, false, g); }
+  if (g_dgrad_bf3) { g_gemm_force_bf3 = 1; const int rc = run_gemm(m, st, &Ld, 1, false, g); g_gemm_force_bf3 = 0; return rc; }
   return run_gemm(m, st, &Ld, 1, false, g);
 }
 
@@ -955,7 +957,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   const int n = T_out / r;
   if (n > hp.max_iters) return fail(TACO_ERR_SHAPE, "T_out/r = %d exceeds max_iters %d", n, hp.max_iters);
   TRY(check_common(m, B, T_in));
-  if (m->bf3 && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
+  if ((m->bf3 || g_dgrad_bf3) && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
   Carver cv(ws, ws_bytes);
   TrainWs w; carve_train(cv, t, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);

@@ -145,11 +145,12 @@ class Trainer(object):
             self._graph = None          # a captured step keeps the engine it was captured with
 
     def set_exact_gemm(self, on=True):
-        """True (default): feed-forward and data-gradient GEMMs on the exact-fp32 MFMA.  False: on the split-bf16 matrix-core kernels of
-        inference (k_gemm_bf3; ~2^-17 per product; the weight planes follow the parameters through taco_train_refresh): 16 % off the
-        C4-shard step, gradients within ~1e-3 of the exact engine's norm.  2: forward split-bf16, data gradients exact (A/B hook)."""
+        """Engines of the feed-forward GEMMs and their data gradients (include/taco_abi.h, taco_train_set_exact_gemm).  3 (default):
+        forward on the exact-fp32 MFMA, data gradients on the split-bf16 kernels of inference (4e-6 of the gradient norm against the
+        all-exact step).  True / 1: everything exact.  False / 0: everything split-bf16 (fastest; ~1e-3 of the gradient norm, near-ties of
+        the forward may resolve differently).  2: forward split-bf16, data gradients exact (A/B hook)."""
         _lib.check(self._lib.taco_train_set_exact_gemm(self._h, int(on)))
-        self.refresh()                 # the split-bf16 planes are (re)generated only while that engine is selected
+        self.refresh()                 # the split-bf16 planes are (re)generated only while an engine that needs them is selected
         if getattr(self, "_graph", None) is not None:
             self._graph = None
 

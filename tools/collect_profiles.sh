@@ -10,6 +10,7 @@ for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
 timeout 300 python tools/bench_train.py --exact-gemm 0 > $out/train_step_splitbf16.json 2>> $out/train.err
+timeout 300 python tools/bench_train.py --exact-gemm 1 > $out/train_step_exact.json 2>> $out/train.err
 timeout 300 python tools/bench_train.py --bptt 0 > $out/train_step_bptt_per_stage.json 2>> $out/train.err
 timeout 300 python tools/trace_bptt.py 2>&1 | grep -v amdgpu.ids > $out/bptt_timeline.txt
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
