@@ -7,7 +7,9 @@ from librosa's documented algorithm (0.5/0.6 era, the versions contemporary with
          frame t = y_pad[t*hop : t*hop + n_fft] * window -> rfft
   istft: irfft of every frame * the same window, overlap-added at t*hop, divided by the window sum-square where it exceeds
          tiny, then n_fft/2 trimmed from both ends.
-PARITY UNPINNED: neither librosa nor the reference can run here; only hand checks (round trip, Parseval) pin this file."""
+PARITY: the librosa-free pieces (stft_parameters, denormalize, db_to_amp, the power law, inv_preemphasis) are pinned bit for bit on the
+reference's own functions (tools/make_reference_vectors.py -> tests/golden/audio_vectors.npz, tests/test_reference_vectors.py).  The
+STFT / ISTFT are UNPINNED: librosa cannot run here; only hand checks (round trip, Parseval) hold them."""
 import numpy as np
 
 

@@ -120,3 +120,40 @@ def test_group_logic_equals_enqueue_next_group(fv):
             _same(next(feeder), fv, "group%d_batch%d_" % (gi, bi), ndirs > 1)
         for d in dirs:                            # and it drew exactly the examples the reference drew
             assert next(streams[d], None) is None
+
+
+# ---- audio/__init__.py:118-165 (the NumPy / SciPy part of the spectrogram -> waveform step) ----
+@pytest.fixture(scope="module")
+def av():
+    return np.load(os.path.join(GOLD, "audio_vectors.npz"))
+
+
+def test_audio_hparams_equal_the_reference_effective_values(av):
+    """hparams.py:16-23,27-29,144-145 after the reference's own override chain (its hparams.py was executed to write the vector)."""
+    from taco_amd import hparams as product
+    ref = dict(zip(av["hparams_keys"].tolist(), av["hparams_values"].tolist()))
+    assert ref["sample_rate"] == 24000.0                      # the override of hparams.py:28, not the 20000 of :18
+    for k, v in ref.items():
+        assert float(getattr(product, k)) == v, k
+
+
+def test_audio_oracle_pieces_equal_the_reference_bit_for_bit(av):
+    """oracle/audio_oracle.py restates inv_spectrogram (audio/__init__.py:54-56); its librosa-free pieces are pinned here on what the
+    reference's own functions returned: _stft_parameters, _denormalize, _db_to_amp, the `S ** power` handed to Griffin-Lim, and
+    inv_preemphasis (scipy.signal.lfilter).  The STFT / ISTFT stay restatements of librosa's documented algorithm (unpinned)."""
+    import audio_oracle as AO
+    ref = dict(zip(av["hparams_keys"].tolist(), av["hparams_values"].tolist()))
+    hp = AO.AudioHParams(num_freq=int(ref["num_freq"]), sample_rate=int(ref["sample_rate"]), frame_length_ms=ref["frame_length_ms"],
+                         frame_shift_ms=ref["frame_shift_ms"], preemphasis=ref["preemphasis"], min_level_db=ref["min_level_db"],
+                         ref_level_db=ref["ref_level_db"], power=ref["power"], griffin_lim_iters=int(ref["griffin_lim_iters"]))
+    assert list(hp.stft_parameters()) == av["stft_parameters"].tolist() == [2048, 300, 1200]
+    spec = av["spec"]
+    assert np.array_equal(AO.denormalize(spec, hp), av["denormalize"])
+    S = AO.db_to_amp(AO.denormalize(spec, hp) + hp.ref_level_db)
+    assert np.array_equal(S, av["db_to_amp"])
+    assert np.array_equal(S ** hp.power, av["griffin_lim_input"])
+    # the oracle's inverse pre-emphasis is the recurrence written out; scipy's lfilter is the same recurrence in another order of operations
+    got = AO.inv_preemphasis(av["wave"], hp)
+    assert np.abs(got - av["inv_preemphasis"]).max() < 1e-13
+    # and the forward direction round-trips through the reference's own pair
+    assert np.abs(AO.inv_preemphasis(av["preemphasis"], hp) - av["wave"]).max() < 1e-12

@@ -1,13 +1,18 @@
 #!/usr/bin/env python
-"""Golden vectors produced BY THE REFERENCE for the two parts of SURVEY 8f rank 4 that can run without TensorFlow:
+"""Golden vectors produced BY THE REFERENCE for the parts of SURVEY 8f that can run without TensorFlow / librosa:
 
   * text/korean.py:151-306   normalize() and its stages (dictionary phrases, English words, upper-case spelling, units + numbers)
   * datasets/datafeeder.py:210-243,289-328   _round_up / _prepare_inputs / _prepare_targets / _prepare_batch and the group logic of
     DataFeeder._enqueue_next_group (sort by target length, cut into batches, shuffle the batches, shuffle the rows of a training batch)
+  * audio/__init__.py:118-165 + hparams.py   the spectrogram -> waveform step around Griffin-Lim that is plain NumPy / SciPy: _stft_parameters,
+    _denormalize, _db_to_amp, the `S ** power` the phase reconstruction starts from (inv_spectrogram, :54-56), inv_preemphasis /
+    _preemphasis (scipy.signal.lfilter), _amp_to_db, _normalize -- with the reference's OWN effective hparams (its hparams.py is executed;
+    the stand-in for tf.contrib.training.HParams only stores the values it is given).  _stft / _istft / the mel basis are librosa calls
+    and stay unpinned (oracle/audio_oracle.py restates them).
 
 Run in the BUILD container only (it reads /root/reference; the GPU box has no reference):
 
-    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json and tests/golden/feeder_vectors.npz
+    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz
 
 The reference modules are loaded BY PATH from where they lie; nothing of their source is copied.  Their import lines name packages
 this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `utils` / `text` packages, which pull in TensorFlow and
@@ -15,6 +20,7 @@ librosa).  Those names are satisfied by EMPTY stand-in modules whose functions r
 part in computing a vector -- any stage that would need one (jamo decomposition, nltk sentence splitting inside quotations) is left
 out, and the vectors say so.  tests/test_reference_vectors.py replays the files bit-exactly through korean.py / feeder.py."""
 import importlib
+import importlib.util
 import json
 import os
 import sys
@@ -59,6 +65,59 @@ def load_reference_datafeeder():
     pkg = _stub("refdatasets")
     pkg.__path__ = [os.path.join(REF, "datasets")]
     return importlib.import_module("refdatasets.datafeeder")
+
+
+def load_reference_audio():
+    """audio/__init__.py by path, with the reference's own hparams.py executed for the values.  Stand-ins: `tensorflow` (only
+    tf.contrib.training.HParams, a value holder), `librosa` / `librosa.filters` (refuse to be called)."""
+    class _HP(object):                                   # tf.contrib.training.HParams as far as hparams.py uses it: holds values
+        def __init__(self, **kw):
+            self._v = dict(kw)
+            self.__dict__.update(kw)
+
+        def values(self):
+            return dict(self._v)
+    tf = _stub("tensorflow")
+    tf.contrib = types.SimpleNamespace(training=types.SimpleNamespace(HParams=_HP))
+    lib = _stub("librosa", stft=_refuse("librosa.stft"), istft=_refuse("librosa.istft"))
+    lib.__path__ = []
+    lib.core = types.SimpleNamespace(load=_refuse("librosa.core.load"))
+    _stub("librosa.filters", mel=_refuse("librosa.filters.mel"))
+    sys.modules.pop("hparams", None)
+    spec = importlib.util.spec_from_file_location("hparams", os.path.join(REF, "hparams.py"))
+    hp = importlib.util.module_from_spec(spec); sys.modules["hparams"] = hp; spec.loader.exec_module(hp)
+    sys.modules.pop("audio", None); sys.modules.pop("audio.get_duration", None)
+    spec = importlib.util.spec_from_file_location("refaudio", os.path.join(REF, "audio", "__init__.py"))
+    A = importlib.util.module_from_spec(spec); spec.loader.exec_module(A)
+    return A, hp.hparams
+
+
+def audio_vectors(A, hp):
+    rs = np.random.RandomState(20260927)
+    out = {}
+    keys = ["num_freq", "sample_rate", "frame_length_ms", "frame_shift_ms", "preemphasis", "min_level_db", "ref_level_db", "power",
+            "griffin_lim_iters", "num_mels"]
+    out["hparams_keys"] = np.array(keys)
+    out["hparams_values"] = np.array([float(getattr(hp, k)) for k in keys], np.float64)
+    out["stft_parameters"] = np.array(A._stft_parameters(), np.int64)                       # n_fft, hop_length, win_length
+    spec = rs.uniform(-0.25, 1.25, size=(hp.num_freq, 9))                                   # outside [0, 1] too: _denormalize clips
+    spec[3, :] = [0.0, 1.0, -1.0, 2.0, 0.5, 1e-9, 1 - 1e-9, 0.25, 0.75]
+    out["spec"] = spec
+    out["denormalize"] = A._denormalize(spec)
+    S = A._db_to_amp(A._denormalize(spec) + hp.ref_level_db)
+    out["db_to_amp"] = S
+    out["griffin_lim_input"] = S ** hp.power                                                # what inv_spectrogram hands to _griffin_lim (:55-56)
+    y = rs.randn(777) * 0.1
+    out["wave"] = y
+    out["inv_preemphasis"] = A.inv_preemphasis(y)
+    out["preemphasis"] = A._preemphasis(y)
+    mag = np.abs(rs.randn(hp.num_freq, 5)) * 3.0
+    mag[0, :] = [0.0, 1e-6, 1e-5, 1.0, 1e3]
+    out["mag"] = mag
+    out["amp_to_db"] = A._amp_to_db(mag)
+    out["normalize"] = A._normalize(A._amp_to_db(mag) - hp.ref_level_db)                    # spectrogram() without the STFT (:48-51)
+    out["frames_to_hours"] = np.array([A.frames_to_hours([100, 250, 4000])], np.float64)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -300,6 +359,10 @@ def main():
     F = load_reference_datafeeder()
     fv = feeder_vectors(F)
     np.savez_compressed(os.path.join(GOLD, "feeder_vectors.npz"), **fv)
+    A, ahp = load_reference_audio()
+    av = audio_vectors(A, ahp)
+    np.savez_compressed(os.path.join(GOLD, "audio_vectors.npz"), **av)
+    print("audio: %d arrays, hparams %s" % (len(av), dict(zip(av["hparams_keys"].tolist(), av["hparams_values"].tolist()))))
     print("korean: %d sentences, %d + %d sweep numbers, %d divergences (%d identical); feeder: %d arrays"
           % (len(kv["sentences"]), len(kv["number_sweep"]), len(kv["counted_sweep"]), len(kv["divergences"]),
              sum(d["same"] for d in kv["divergences"]), len(fv)))
