@@ -389,3 +389,20 @@ def test_attention_trim_matches_reference_walk():
         taco_amd._lib.check(lib.taco_attention_trim(stream(), ptr(ad), ptr(sd), N, T_in, n, r, ptr(out)))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy(), want), (case, out.cpu().numpy(), want)
+
+
+def test_attention_trim_kernel_equals_what_the_reference_kept():
+    """The device kernel against the REFERENCE itself: the 120 alignments on which the reference's own plot_graph_and_save_audio ran
+    (tests/golden/trim_vectors.npz, written by tools/make_reference_vectors.py) -> the same number of kept frames, every one."""
+    import os
+    import torch
+    import taco_amd
+    lib = taco_amd._lib.load_library()
+    tv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trim_vectors.npz"))
+    r = int(tv["reduction_factor"][0])
+    for al, (T_in, n), L, want in zip(tv["alignments"], tv["dims"], tv["sequence_len"], tv["spec_end_idx"]):
+        ad = dev(np.ascontiguousarray(al[:T_in, :n][None].astype(np.float32)))
+        sd = dev(np.array([L], np.int32))
+        out = torch.zeros(1, dtype=torch.int32, device="cuda")
+        taco_amd._lib.check(lib.taco_attention_trim(stream(), ptr(ad), ptr(sd), 1, int(T_in), int(n), r, ptr(out)))
+        assert int(out.item()) == int(want), (T_in, n, L, int(out.item()), int(want))

@@ -157,3 +157,16 @@ def test_audio_oracle_pieces_equal_the_reference_bit_for_bit(av):
     assert np.abs(got - av["inv_preemphasis"]).max() < 1e-13
     # and the forward direction round-trips through the reference's own pair
     assert np.abs(AO.inv_preemphasis(av["preemphasis"], hp) - av["wave"]).max() < 1e-12
+
+
+# ---- synthesizer.py:242-262 (attention_trim and end_of_sentence) ----
+def test_attention_trim_walk_equals_what_the_reference_kept():
+    """The reference's own plot_graph_and_save_audio ran on 120 alignments (tools/make_reference_vectors.py: its walk executed as it
+    stands, the array it then hands to inv_spectrogram was recorded).  The oracle's restatement of the walk -- the checker of the device
+    kernel k_attention_trim in tests/test_gpu_ops.py -- returns the same number of frames for every one of them."""
+    import taco_oracle as O
+    tv = np.load(os.path.join(GOLD, "trim_vectors.npz"))
+    r = int(tv["reduction_factor"][0])
+    assert r == 4 and len(tv["spec_end_idx"]) == 120
+    for al, (T_in, n), L, want in zip(tv["alignments"], tv["dims"], tv["sequence_len"], tv["spec_end_idx"]):
+        assert O.attention_trim_end(al[:T_in, :n], int(L), r) == int(want)

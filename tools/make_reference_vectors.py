@@ -9,10 +9,12 @@
     _preemphasis (scipy.signal.lfilter), _amp_to_db, _normalize -- with the reference's OWN effective hparams (its hparams.py is executed;
     the stand-in for tf.contrib.training.HParams only stores the values it is given).  _stft / _istft / the mel basis are librosa calls
     and stay unpinned (oracle/audio_oracle.py restates them).
+  * synthesizer.py:242-262   the `attention_trim and end_of_sentence` walk of plot_graph_and_save_audio, observed through the array it hands
+    to inv_spectrogram (a recording stand-in).
 
 Run in the BUILD container only (it reads /root/reference; the GPU box has no reference):
 
-    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz
+    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz, trim_vectors.npz
 
 The reference modules are loaded BY PATH from where they lie; nothing of their source is copied.  Their import lines name packages
 this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `utils` / `text` packages, which pull in TensorFlow and
@@ -118,6 +120,70 @@ def audio_vectors(A, hp):
     out["normalize"] = A._normalize(A._amp_to_db(mag) - hp.ref_level_db)                    # spectrogram() without the STFT (:48-51)
     out["frames_to_hours"] = np.array([A.frames_to_hours([100, 250, 4000])], np.float64)
     return out
+
+
+def load_reference_synthesizer(record):
+    """synthesizer.py by path, for plot_graph_and_save_audio's `attention_trim and end_of_sentence` walk (:242-262).  Everything the module
+    imports is a stand-in that refuses to be called, except the two calls that FOLLOW the walk: audio.inv_spectrogram, here a recorder
+    of the array the reference hands it (its second dimension is the number of frames the walk kept), and audio.save_audio, a no-op.
+    hparams is the reference's own (reduction_factor)."""
+    load_reference_audio()                                   # leaves the reference's real `hparams` module and the tf / librosa stand-ins in sys.modules
+    def inv_spectrogram(x):
+        record.append(tuple(x.shape))
+        return np.zeros(4)
+    a = _stub("audio", save_audio=lambda *a_, **k: None, inv_spectrogram=inv_spectrogram, inv_preemphasis=_refuse("audio.inv_preemphasis"),
+              inv_spectrogram_tensorflow=_refuse("audio.inv_spectrogram_tensorflow"))
+    a.__path__ = []
+    _stub("models", create_model=_refuse("models.create_model"), get_most_recent_checkpoint=_refuse("models.get_most_recent_checkpoint"))
+    u = _stub("utils", plot=types.SimpleNamespace(plot_alignment=_refuse("plot.plot_alignment")), PARAMS_NAME="params.json",
+              load_json=_refuse("utils.load_json"), load_hparams=_refuse("utils.load_hparams"), add_prefix=_refuse("utils.add_prefix"),
+              add_postfix=_refuse("utils.add_postfix"), get_time=_refuse("utils.get_time"), parallel_run=_refuse("utils.parallel_run"),
+              makedirs=_refuse("utils.makedirs"))
+    u.__path__ = []
+    t = _stub("text", text_to_sequence=_refuse("text.text_to_sequence"), sequence_to_text=_refuse("text.sequence_to_text"))
+    t.__path__ = []
+    _stub("text.korean", tokenize=_refuse("text.korean.tokenize"))
+    spec = importlib.util.spec_from_file_location("refsynthesizer", os.path.join(REF, "synthesizer.py"))
+    S = importlib.util.module_from_spec(spec); spec.loader.exec_module(S)
+    return S
+
+
+def trim_vectors():
+    """Alignments [T_in, n] of single utterances (sharp monotone ramps that reach the end early / late / never, plateaus at the last
+    position, random ones) -> the number of spectrogram frames the reference keeps (spec_end_idx = r * jdx + 3)."""
+    record = []
+    S = load_reference_synthesizer(record)
+    r = int(sys.modules["hparams"].hparams.reduction_factor)
+    rs = np.random.RandomState(77)
+    cases = []
+    for ci in range(120):
+        T_in, n = int(rs.randint(2, 24)), int(rs.randint(1, 40))
+        seq_len = int(rs.randint(1, T_in + 1)) if ci % 3 else T_in
+        kind = ci % 4
+        if kind == 0:                                        # a ramp that reaches the last position and stays
+            speed = rs.uniform(0.3, 2.0)
+            pos = np.minimum((np.arange(n) * speed).astype(int), T_in - 1)
+        elif kind == 1:                                      # reaches the end, then wanders past seq_len - 1 (padding positions)
+            pos = np.minimum(np.arange(n), T_in - 1)
+            pos[n // 2:] = rs.randint(0, T_in, size=n - n // 2)
+        elif kind == 2:                                      # random walk
+            pos = np.clip(np.cumsum(rs.randint(-1, 3, size=n)), 0, T_in - 1)
+        else:
+            pos = rs.randint(0, T_in, size=n)
+        al = rs.uniform(0, 0.05, size=(T_in, n))
+        al[pos, np.arange(n)] += 1.0
+        al /= al.sum(0, keepdims=True)
+        wav = np.zeros((n * r + 16, 8))                      # longer than any spec_end_idx: the slice never clamps
+        del record[:]
+        S.plot_graph_and_save_audio((0, (wav, al, None, "", list(range(seq_len)))), end_of_sentence=True, attention_trim=True)
+        assert len(record) == 1 and record[0][0] == 8
+        cases.append((al.astype(np.float64), seq_len, record[0][1]))
+    Tm, nm = max(c[0].shape[0] for c in cases), max(c[0].shape[1] for c in cases)
+    pad = np.zeros((len(cases), Tm, nm))
+    for i, (al, _, _) in enumerate(cases):
+        pad[i, :al.shape[0], :al.shape[1]] = al
+    return {"alignments": pad, "dims": np.array([c[0].shape for c in cases], np.int64), "sequence_len": np.array([c[1] for c in cases], np.int64),
+            "spec_end_idx": np.array([c[2] for c in cases], np.int64), "reduction_factor": np.array([r], np.int64)}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -363,6 +429,9 @@ def main():
     av = audio_vectors(A, ahp)
     np.savez_compressed(os.path.join(GOLD, "audio_vectors.npz"), **av)
     print("audio: %d arrays, hparams %s" % (len(av), dict(zip(av["hparams_keys"].tolist(), av["hparams_values"].tolist()))))
+    tv = trim_vectors()
+    np.savez_compressed(os.path.join(GOLD, "trim_vectors.npz"), **tv)
+    print("trim: %d alignments, reduction_factor %d, kept frames %d .. %d" % (len(tv["spec_end_idx"]), tv["reduction_factor"][0], tv["spec_end_idx"].min(), tv["spec_end_idx"].max()))
     print("korean: %d sentences, %d + %d sweep numbers, %d divergences (%d identical); feeder: %d arrays"
           % (len(kv["sentences"]), len(kv["number_sweep"]), len(kv["counted_sweep"]), len(kv["divergences"]),
              sum(d["same"] for d in kv["divergences"]), len(fv)))
