@@ -31,6 +31,26 @@ def get_most_recent_checkpoint(checkpoint_dir, checkpoint_step=None):
     return st if os.path.exists(st) or not os.path.exists(st[:-len("safetensors")] + "index") else st[:-len("safetensors")] + "index"
 
 
+def manual_alignments_of(alignments, mode):
+    """The alignments the reference feeds to its second pass (synthesizer.py:171-205) from the first pass's `alignments` [N, T_in, T_dec]:
+    [N, T_dec, T_in] (the layout of the `manual_alignments` placeholder, rnn_wrappers.py:313-317).
+      mode 1 ("argmax one hot", :173-179): zeros, and for every ENCODER position e a one at the decoder step where e was attended most --
+             the reference takes `alignments[idx].argmax(1)`, the argmax over decoder steps, and writes `new[(argmax, range(E))] = 1`; a
+             decoder step can therefore end up with no one at all, or with several.  Reproduced as it stands.
+      mode 3 ("prunning", :189-195): the same ones written into a copy of the transposed alignments instead of into zeros.
+      mode 2 calls np.pow, which does not exist (:181-188): the reference raises AttributeError there; so does this (as an Exception).
+    Pinned on the reference's own code: tests/golden/manual_vectors.npz (tools/make_reference_vectors.py)."""
+    alignments = np.asarray(alignments)
+    if mode == 2:
+        raise Exception("manual_attention_mode 2 is broken in the reference (np.pow, synthesizer.py:181-188)")
+    alignments_T = np.transpose(alignments, [0, 2, 1])                                   # [N, D, E]
+    new_alignments = np.zeros_like(alignments_T) if mode == 1 else alignments_T.copy()
+    for idx in range(len(alignments)):
+        argmax = alignments[idx].argmax(1)                                               # [E]: decoder step of every encoder position
+        new_alignments[idx][(argmax, np.arange(len(argmax)))] = 1
+    return new_alignments
+
+
 class Synthesizer(object):
     # text -> ids ending in EOS (text/__init__.py:23-58): jamo tokeniser of text.py; the reference's Korean number / abbreviation
     # normaliser is not part of it -- assign a callable that includes one if the input needs it
@@ -99,16 +119,7 @@ class Synthesizer(object):
             manual_alignments=manual_alignments, is_manual_attention=manual_alignments is not None)
         linear, alignments = linear.cpu().numpy(), alignments.cpu().numpy()
         if manual_attention_mode > 0:                                                    # :171-205
-            if manual_attention_mode == 2:
-                raise Exception("manual_attention_mode 2 is broken in the reference (np.pow, synthesizer.py:181-188)")
-            alignments_T = np.transpose(alignments, [0, 2, 1])                           # [N, D, E]
-            new_alignments = np.zeros_like(alignments_T) if manual_attention_mode == 1 else alignments_T.copy()
-            for idx in range(len(alignments)):
-                argmax = alignments[idx].argmax(1)
-                # reference indexing (:176-179): new_alignments[idx][(argmax, range(len(argmax)))] = 1 on the
-                # [E-major] transpose; only shape-consistent when T_in == T_dec.  Applied here per decoder step.
-                am = alignments[idx].argmax(0)                                           # [T_dec] -> encoder index
-                new_alignments[idx][(np.arange(len(am)), am)] = 1
+            new_alignments = manual_alignments_of(alignments, manual_attention_mode)
             linear, alignments = self.model.run(
                 inputs=sequences.astype(np.int32), input_lengths=input_lengths, speaker_id=speaker_ids,
                 manual_alignments=new_alignments, is_manual_attention=True)

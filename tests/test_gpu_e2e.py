@@ -260,8 +260,10 @@ def test_synthesizer_surface(tmp_path):
     lin, al = s.synthesize(tokens=ids)
     ref = O.forward(w, ohp, ids, L)
     assert maxabs(lin, ref["linear"]) < 2e-4 and maxabs(al, ref["alignments"]) < 2e-4
-    lin1, al1 = s.synthesize(tokens=ids, manual_attention_mode=1)      # second pass with one-hot alignments
-    assert set(np.unique(al1)) <= {0.0, 1.0} and np.all(al1.sum(1) == 1)
+    lin1, al1 = s.synthesize(tokens=ids, manual_attention_mode=1)      # second pass with the reference's one-hot alignments (synthesizer.py:173-179):
+    from taco_amd.synthesizer import manual_alignments_of            # one decoder step per ENCODER position (pinned on the reference: test_reference_vectors.py)
+    want = np.transpose(manual_alignments_of(al, 1), [0, 2, 1])
+    assert set(np.unique(al1)) <= {0.0, 1.0} and np.all(al1.sum(2) == 1) and np.array_equal(al1, want)
     s.close()
 
 

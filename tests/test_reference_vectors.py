@@ -170,3 +170,23 @@ def test_attention_trim_walk_equals_what_the_reference_kept():
     assert r == 4 and len(tv["spec_end_idx"]) == 120
     for al, (T_in, n), L, want in zip(tv["alignments"], tv["dims"], tv["sequence_len"], tv["spec_end_idx"]):
         assert O.attention_trim_end(al[:T_in, :n], int(L), r) == int(want)
+
+
+# ---- synthesizer.py:171-200 (manual_attention_mode 1 and 3: the alignments of the second pass) ----
+def test_manual_alignments_equal_what_the_reference_feeds_its_second_pass():
+    """The reference's own Synthesizer.synthesize ran on a recording session (tools/make_reference_vectors.py); what it fed as
+    `manual_alignments` to the second pass, for 24 first passes and both working modes, is what manual_alignments_of returns -- including
+    the reference's choice of axis: one hot per ENCODER position at its most-attending decoder step (`alignments[idx].argmax(1)`), so a
+    decoder step may carry no one at all."""
+    from taco_amd.synthesizer import manual_alignments_of
+    mv = np.load(os.path.join(GOLD, "manual_vectors.npz"))
+    some_empty_step = False
+    for fp, m1, m3, (N, E, D) in zip(mv["first_pass"], mv["mode1"], mv["mode3"], mv["dims"]):
+        al = fp[:N, :E, :D]
+        got1, got3 = manual_alignments_of(al, 1), manual_alignments_of(al, 3)
+        assert got1.shape == (N, D, E) and np.array_equal(got1, m1[:N, :D, :E]) and np.array_equal(got3, m3[:N, :D, :E])
+        assert np.all(got1.sum(1) == 1)                       # exactly one decoder step per encoder position ...
+        some_empty_step = some_empty_step or bool(np.any(got1.sum(2) == 0))
+    assert some_empty_step                                    # ... and decoder steps with no position at all do occur
+    with pytest.raises(Exception):
+        manual_alignments_of(mv["first_pass"][0][:1, :2, :2], 2)     # np.pow: the reference raises there too

@@ -11,10 +11,12 @@
     and stay unpinned (oracle/audio_oracle.py restates them).
   * synthesizer.py:242-262   the `attention_trim and end_of_sentence` walk of plot_graph_and_save_audio, observed through the array it hands
     to inv_spectrogram (a recording stand-in).
+  * synthesizer.py:171-200   the manual alignments Synthesizer.synthesize builds for its second pass (manual_attention_mode 1 and 3), observed
+    through the feed of that pass (a recording stand-in for the session).
 
 Run in the BUILD container only (it reads /root/reference; the GPU box has no reference):
 
-    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz, trim_vectors.npz
+    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz, trim_vectors.npz, manual_vectors.npz
 
 The reference modules are loaded BY PATH from where they lie; nothing of their source is copied.  Their import lines name packages
 this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `utils` / `text` packages, which pull in TensorFlow and
@@ -184,6 +186,50 @@ def trim_vectors():
         pad[i, :al.shape[0], :al.shape[1]] = al
     return {"alignments": pad, "dims": np.array([c[0].shape for c in cases], np.int64), "sequence_len": np.array([c[1] for c in cases], np.int64),
             "spec_end_idx": np.array([c[2] for c in cases], np.int64), "reduction_factor": np.array([r], np.int64)}
+
+
+def manual_vectors():
+    """Synthesizer.synthesize(manual_attention_mode = 1 | 3) of the reference (synthesizer.py:69-205) driven on a plain namespace: `self.model`
+    holds placeholder NAMES, `self.sess.run` is a stand-in that returns the seeded first-pass outputs the vector starts from and RECORDS the
+    feed of the second pass -- `feed_dict[manual_alignments]` there is what the reference's own code (:171-200) built from them.  utils.get_time
+    returns a constant and utils.parallel_run (plot + save of the results, after the fact) is a no-op; neither touches the alignments."""
+    record = []
+    S = load_reference_synthesizer(record)
+    S.get_time = lambda: "t"
+    S.parallel_run = lambda fn, items, **k: []
+    rs = np.random.RandomState(4242)
+    out = {"first_pass": [], "dims": [], "mode1": [], "mode3": []}
+    cases = []
+    for ci in range(24):
+        N, E, D = int(rs.randint(1, 4)), int(rs.randint(2, 14)), int(rs.randint(2, 18))
+        al = rs.uniform(0, 1, size=(N, E, D))
+        if ci % 2:                                           # a mostly monotone path on top
+            for b in range(N):
+                pos = np.minimum((np.arange(D) * (E + 1)) // D, E - 1)
+                al[b, pos, np.arange(D)] += 1.5
+        al = (al / al.sum(1, keepdims=True)).astype(np.float32)       # the model's alignments are float32 [N, T_in, T_dec]
+        tokens = np.ones((N, E), np.int64)                   # EOS (= 1) first: input_lengths = argmax(tokens == 1) = 0, unused by modes 1 / 3
+        got = {}
+        for mode in (1, 3):
+            feeds = []
+            class Sess(object):
+                def run(self, fetches, feed_dict=None):
+                    feeds.append(feed_dict)
+                    return np.zeros((N, 4 * D, 8), np.float32), al.copy()
+            me = types.SimpleNamespace(sess=Sess(), model=types.SimpleNamespace(
+                linear_outputs="linear_outputs", alignments="alignments", inputs="inputs", input_lengths="input_lengths",
+                manual_alignments="manual_alignments", is_manual_attention="is_manual_attention", speaker_id="speaker_id"))
+            S.Synthesizer.synthesize(me, tokens=tokens, manual_attention_mode=mode, attention_trim=False)
+            assert len(feeds) == 2 and feeds[1]["is_manual_attention"] is True
+            got[mode] = np.array(feeds[1]["manual_alignments"])
+            assert got[mode].shape == (N, D, E)
+        cases.append((al, got[1], got[3]))
+    Nm = max(c[0].shape[0] for c in cases); Em = max(c[0].shape[1] for c in cases); Dm = max(c[0].shape[2] for c in cases)
+    fp = np.zeros((len(cases), Nm, Em, Dm), np.float32); m1 = np.zeros((len(cases), Nm, Dm, Em), np.float32); m3 = np.zeros_like(m1)
+    for i, (al, a1, a3) in enumerate(cases):
+        N, E, D = al.shape
+        fp[i, :N, :E, :D] = al; m1[i, :N, :D, :E] = a1; m3[i, :N, :D, :E] = a3
+    return {"first_pass": fp, "mode1": m1, "mode3": m3, "dims": np.array([c[0].shape for c in cases], np.int64)}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -432,6 +478,9 @@ def main():
     tv = trim_vectors()
     np.savez_compressed(os.path.join(GOLD, "trim_vectors.npz"), **tv)
     print("trim: %d alignments, reduction_factor %d, kept frames %d .. %d" % (len(tv["spec_end_idx"]), tv["reduction_factor"][0], tv["spec_end_idx"].min(), tv["spec_end_idx"].max()))
+    mv = manual_vectors()
+    np.savez_compressed(os.path.join(GOLD, "manual_vectors.npz"), **mv)
+    print("manual attention: %d first passes, modes 1 and 3" % len(mv["dims"]))
     print("korean: %d sentences, %d + %d sweep numbers, %d divergences (%d identical); feeder: %d arrays"
           % (len(kv["sentences"]), len(kv["number_sweep"]), len(kv["counted_sweep"]), len(kv["divergences"]),
              sum(d["same"] for d in kv["divergences"]), len(fv)))
