@@ -190,3 +190,24 @@ def test_manual_alignments_equal_what_the_reference_feeds_its_second_pass():
     assert some_empty_step                                    # ... and decoder steps with no position at all do occur
     with pytest.raises(Exception):
         manual_alignments_of(mv["first_pass"][0][:1, :2, :2], 2)     # np.pow: the reference raises there too
+
+
+# ---- hparams.py (effective defaults) and utils/__init__.py:110-126 (load_hparams) ----
+def test_every_product_hparam_equals_the_reference_effective_default_and_load_hparams_agrees(tmp_path):
+    """The reference's hparams.py was executed as it stands (override chain :27-29,83-94 included) and its load_hparams applied to four
+    params.json files (unknown keys, a skip list, list-valued keys, an empty file): the product's defaults and its load_hparams give the
+    same values for every key the product carries."""
+    import taco_amd
+    with open(os.path.join(GOLD, "hparams_vectors.json")) as f:
+        hv = json.load(f)
+    prod = taco_amd.hparams.values()
+    assert len(prod) >= 40 and all(k in hv["effective"] for k in prod)
+    assert {k: hv["effective"][k] for k in prod} == prod
+    assert hv["effective"]["reduction_factor"] == 4 and hv["effective"]["post_rnn_size"] == 256 and hv["effective"]["sample_rate"] == 24000
+    for i, case in enumerate(hv["load_cases"]):
+        d = tmp_path / ("case%d" % i)
+        d.mkdir()
+        (d / "params.json").write_text(json.dumps(case["params_json"]))
+        hp = taco_amd.load_hparams(taco_amd.hparams.copy(), str(d), skip_list=case["skip_list"])
+        got = hp.values()
+        assert {k: case["after"][k] for k in got} == got, i

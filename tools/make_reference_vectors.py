@@ -13,10 +13,11 @@
     to inv_spectrogram (a recording stand-in).
   * synthesizer.py:171-200   the manual alignments Synthesizer.synthesize builds for its second pass (manual_attention_mode 1 and 3), observed
     through the feed of that pass (a recording stand-in for the session).
+  * hparams.py (every effective default after its override chain) and utils/__init__.py:110-126 load_hparams.
 
 Run in the BUILD container only (it reads /root/reference; the GPU box has no reference):
 
-    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz, trim_vectors.npz, manual_vectors.npz
+    python tools/make_reference_vectors.py            # writes tests/golden/korean_vectors.json, feeder_vectors.npz, audio_vectors.npz, trim_vectors.npz, manual_vectors.npz, hparams_vectors.json
 
 The reference modules are loaded BY PATH from where they lie; nothing of their source is copied.  Their import lines name packages
 this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `utils` / `text` packages, which pull in TensorFlow and
@@ -230,6 +231,31 @@ def manual_vectors():
         N, E, D = al.shape
         fp[i, :N, :E, :D] = al; m1[i, :N, :D, :E] = a1; m3[i, :N, :D, :E] = a3
     return {"first_pass": fp, "mode1": m1, "mode3": m3, "dims": np.array([c[0].shape for c in cases], np.int64)}
+
+
+def hparams_vectors():
+    """hparams.py executed as it stands (the override chain :27-29,83-94 included) -> every effective default; and utils/__init__.py's
+    load_hparams (:110-126; the module needs no stand-in at all) applied to it for a few params.json files -> the values afterwards."""
+    import tempfile
+    _, hp = load_reference_audio()                           # (re)executes the reference's hparams.py; hp is its `hparams` object
+    sys.modules.pop("utils", None); sys.modules.pop("utils.infolog", None)
+    spec = importlib.util.spec_from_file_location("refutils", os.path.join(REF, "utils", "__init__.py"))
+    U = importlib.util.module_from_spec(spec); spec.loader.exec_module(U)
+    plain = lambda v: v if isinstance(v, (int, float, str, bool, list)) or v is None else str(v)
+    out = {"effective": {k: plain(v) for k, v in sorted(hp.values().items())}, "load_cases": []}
+    cases = [({"reduction_factor": 5, "attention_type": "bah_norm", "not_a_key": 1, "enc_bank_size": 8}, []),
+             ({"model_type": "deepvoice", "speaker_embedding_size": 32, "max_iters": 1000, "dropout_prob": 0.5}, ["dropout_prob"]),
+             ({"post_proj_sizes": [128, 80], "dec_prenet_sizes": [64, 32], "sample_rate": 22050}, ["sample_rate"]),
+             ({}, [])]
+    for js, skip in cases:
+        _, hp_i = load_reference_audio()                     # a fresh copy of the defaults
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "params.json"), "w") as f:
+                json.dump(js, f)
+            U.load_hparams(hp_i, d, skip_list=skip)
+        out["load_cases"].append({"params_json": js, "skip_list": skip,
+                                  "after": {k: plain(getattr(hp_i, k)) for k in sorted(hp.values())}})
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -481,6 +507,10 @@ def main():
     mv = manual_vectors()
     np.savez_compressed(os.path.join(GOLD, "manual_vectors.npz"), **mv)
     print("manual attention: %d first passes, modes 1 and 3" % len(mv["dims"]))
+    hv = hparams_vectors()
+    with open(os.path.join(GOLD, "hparams_vectors.json"), "w") as f:
+        json.dump(hv, f, indent=0, sort_keys=True)
+    print("hparams: %d effective defaults, %d load_hparams cases" % (len(hv["effective"]), len(hv["load_cases"])))
     print("korean: %d sentences, %d + %d sweep numbers, %d divergences (%d identical); feeder: %d arrays"
           % (len(kv["sentences"]), len(kv["number_sweep"]), len(kv["counted_sweep"]), len(kv["divergences"]),
              sum(d["same"] for d in kv["divergences"]), len(fv)))
