@@ -211,3 +211,10 @@ def test_every_product_hparam_equals_the_reference_effective_default_and_load_hp
         hp = taco_amd.load_hparams(taco_amd.hparams.copy(), str(d), skip_list=case["skip_list"])
         got = hp.values()
         assert {k: case["after"][k] for k in got} == got, i
+
+
+def test_symbol_table_equals_the_reference(kv):
+    """text/korean.py:11-21 (= text/symbols.py; id = position, text/__init__.py:11-12): the ids a trained checkpoint's embedding rows mean."""
+    from taco_amd import text as T
+    assert T.symbols == kv["all_symbols"] and len(T.symbols) == 80
+    assert T.PAD == kv["pad"] and T.EOS == kv["eos"] and T.symbols.index(T.PAD) == 0 and T.symbols.index(T.EOS) == 1

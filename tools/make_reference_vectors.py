@@ -386,6 +386,7 @@ def korean_vectors(K):
 
     return {
         "generated_by": "tools/make_reference_vectors.py from /root/reference/text/korean.py (loaded by path; jamo / nltk stand-ins never called)",
+        "all_symbols": K.ALL_SYMBOLS, "pad": K.PAD, "eos": K.EOS,      # text/korean.py:11-21 = text/symbols.py: symbol i of the table has id i (text/__init__.py:11-12)
         "reference_functions": ["normalize :151-164", "normalize_with_dictionary :166-171", "normalize_english :173-182",
                                 "normalize_upper :184-190", "normalize_number :207-214", "number_to_korean :237-306"],
         "not_covered": ["normalize_quote :192-205 (needs nltk.sent_tokenize)", "tokenize :139-147 (needs the jamo package)"],
