@@ -218,3 +218,12 @@ def test_symbol_table_equals_the_reference(kv):
     from taco_amd import text as T
     assert T.symbols == kv["all_symbols"] and len(T.symbols) == 80
     assert T.PAD == kv["pad"] and T.EOS == kv["eos"] and T.symbols.index(T.PAD) == 0 and T.symbols.index(T.EOS) == 1
+
+
+def test_input_lengths_rule_equals_what_the_reference_feeds():
+    """synthesizer.py:120 read from the first feed of the reference's own synthesize(): the position of the FIRST EOS, 0 when there is none."""
+    from taco_amd.hparams import EOS_ID
+    mv = np.load(os.path.join(GOLD, "manual_vectors.npz"))
+    tok = mv["tokens"]
+    assert EOS_ID == 1 and np.array_equal(np.argmax(tok == EOS_ID, 1), mv["input_lengths"]) and mv["input_lengths"].tolist() == [2, 5, 0, 1, 0, 3]
+    assert mv["manual_alignments_fed_when_off"].shape == (1, 1, 1)            # the dummy the placeholder gets when is_manual_attention is False (:128-132)

@@ -230,7 +230,22 @@ def manual_vectors():
     for i, (al, a1, a3) in enumerate(cases):
         N, E, D = al.shape
         fp[i, :N, :E, :D] = al; m1[i, :N, :D, :E] = a1; m3[i, :N, :D, :E] = a3
-    return {"first_pass": fp, "mode1": m1, "mode3": m3, "dims": np.array([c[0].shape for c in cases], np.int64)}
+    # synthesizer.py:120: input_lengths = argmax(tokens == 1) -- read from the FIRST feed of a plain call (EOS in the middle, at the end, at the
+    # start, twice, absent: then 0)
+    tok = np.array([[5, 9, 1, 0, 0, 0], [7, 7, 7, 7, 7, 1], [1, 4, 4, 4, 4, 4], [3, 1, 6, 1, 0, 0], [2, 3, 4, 5, 6, 7], [0, 0, 0, 1, 0, 0]], np.int64)
+    feeds = []
+    class Sess0(object):
+        def run(self, fetches, feed_dict=None):
+            feeds.append(feed_dict)
+            return np.zeros((len(tok), 8, 8), np.float32), np.full((len(tok), tok.shape[1], 2), 0.5, np.float32)
+    me = types.SimpleNamespace(sess=Sess0(), model=types.SimpleNamespace(
+        linear_outputs="linear_outputs", alignments="alignments", inputs="inputs", input_lengths="input_lengths",
+        manual_alignments="manual_alignments", is_manual_attention="is_manual_attention", speaker_id="speaker_id"))
+    S.Synthesizer.synthesize(me, tokens=tok, speaker_ids=[0, 1, 2, 0, 1, 2], attention_trim=False)
+    assert len(feeds) == 1 and feeds[0]["is_manual_attention"] is False
+    return {"first_pass": fp, "mode1": m1, "mode3": m3, "dims": np.array([c[0].shape for c in cases], np.int64),
+            "tokens": tok, "input_lengths": np.asarray(feeds[0]["input_lengths"], np.int64), "speaker_id_fed": np.asarray(feeds[0]["speaker_id"], np.int64),
+            "manual_alignments_fed_when_off": np.asarray(feeds[0]["manual_alignments"], np.float64)}
 
 
 def hparams_vectors():
