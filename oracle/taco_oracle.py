@@ -7,6 +7,10 @@ The reference ships no tests, golden vectors or checkpoints.  This file is there
 restatement of (a) the wiring in the reference's own files (cited per function as
 `file:line`, relative to the reference root) and (b) the published behaviour of the TF 1.4
 ops those lines call (marked TF-sem).  Nothing here was checked against a running TF.
+Pinned on the reference's own code, without TensorFlow: (a) -- the wiring -- by the call trace of the reference's model files
+(tools/trace_reference_graph.py -> tests/golden/graph_trace.json, tests/test_reference_graph.py), and the trim walk and manual
+alignments at the end of this file by reference-run vectors (tests/test_reference_vectors.py).  (b) -- the arithmetic inside TF's
+ops -- is what remains unpinned.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
 module, and only as the checker / reported CPU baseline.  The product path
