@@ -54,7 +54,7 @@ def test_every_layer_of_the_reference_is_a_tensor_of_the_product_with_the_same_s
     import taco_amd
     run = runs[("single", "bah_mon", False, 16)]
     spec = dict(taco_amd.weights.weight_spec(taco_amd.hparams.copy(), 1))
-    to_product = lambda s: s.replace("inference/decoder_step/decoder_prenet/", "decoder/prenet/").replace("inference/", "")
+    to_product = lambda s: s.replace("inference/decoder/output_projection_wrapper/multi_rnn_cell/cell_0/output_projection_wrapper/concat_output_and_attention_wrapper/attention_wrapper/decoder_prenet_wrapper/decoder_prenet/", "decoder/prenet/").replace("inference/", "")
     got = {to_product(n): shp for n, shp in _layers(run)}
     assert got.pop("dense") == (512, 1025) and spec["linear/kernel"] == (512, 1025)          # the linear head: the one unnamed dense of scope `inference`
     assert len(got) == 2 + (16 + 2 + 8) + (8 + 2 + 1 + 8) + 2
@@ -148,7 +148,7 @@ def test_decoder_step_wiring_and_attention_arguments(runs):
         assert {k: v for k, v in aw["kwargs"].items() if v is not None} == {"alignment_history": True, "output_attention": False}
         dd = _ops(run, "tf.contrib.seq2seq.dynamic_decode")[0]
         assert dd["kwargs"]["maximum_iterations"] == run["hparams"]["max_iters"] == 200
-        step = [t for t in tr if t["scope"].startswith("inference/decoder_step")]
+        step = [t for t in tr if t["scope"].startswith("inference/decoder")]
         cat0 = [t for t in step if t["op"] == "tf.concat"][0]     # cell_input_fn: [previous frame | previous context] -> the prenet
         assert [tr[i]["shape"][-1] for i in cat0["in"]] == [80, 256] and cat0["shape"][-1] == 336
         d1 = [t for t in step if t["op"] == "tf.layers.dense"][0]
@@ -186,7 +186,7 @@ def test_training_graph_teacher_forcing_loss_and_optimizer(runs):
     ph = {t["kwargs"]["name"]: t["id"] for t in _ops(run, "tf.placeholder")}
     sl = [t for t in tr if t["op"] == "getitem" and t["in"] == [ph["mel_targets"]] and t["kwargs"]["index"] == ["::", "3::4", "::"]]
     assert len(sl) == 1                                           # helpers.py:44: targets[:, r-1::r, :]
-    step = [t for t in tr if t["scope"].startswith("inference/decoder_step")]
+    step = [t for t in tr if t["scope"].startswith("inference/decoder")]
     nxt = [t for t in step if t["op"] == "getitem" and t["in"][0] == sl[0]["id"]]
     assert len(nxt) == 1 and nxt[0]["kwargs"]["index"][0] == "::" and nxt[0]["kwargs"]["index"][2] == "::"      # next input = targets[:, time, :]
     loss = [t for t in tr if t["scope"] == "loss"]
@@ -231,7 +231,7 @@ def test_multispeaker_wiring(runs):
     assert tr[fw["kwargs"]["initial_state_fw"]["sym"]]["op"] == "tf.split[0]"
     aw = _ops(dv, "new AttentionWrapper")[0]
     assert aw["kwargs"]["initial_cell_state"] == {"sym": spk[2]["id"]}
-    step = [t for t in tr if t["scope"].startswith("inference/decoder_step")]
+    step = [t for t in tr if t["scope"].startswith("inference/decoder")]
     gru = [t for t in step if t["op"] == "GRUCell.call"]
     assert gru[1]["in"][1] == spk[3]["id"] and gru[2]["in"][1] == spk[4]["id"]      # decoder_init_state[idx + 1] = the speaker's vector (tacotron.py:183-197)
     # speaker_embedding_size == 1: per-speaker tables instead of dense layers (tacotron.py:52-66)
@@ -242,7 +242,7 @@ def test_multispeaker_wiring(runs):
     # simple: the embedding is concatenated behind the prenet output, behind [cell output | context] and in front of the post-net output
     sm = runs[("simple", "bah_mon", False, 16)]
     ts = sm["trace"]
-    sstep = [t for t in ts if t["scope"].startswith("inference/decoder_step")]
+    sstep = [t for t in ts if t["scope"].startswith("inference/decoder")]
     sc = [t for t in sstep if t["op"] == "tf.concat" and t["kwargs"].get("name") == "speaker_concat"][0]
     assert [ts[i]["shape"][-1] for i in sc["in"]] == [128, 16]
     cat = [t for t in sstep if t["op"] == "tf.concat" and t["shape"] and t["shape"][-1] == 528][0]
@@ -252,3 +252,57 @@ def test_multispeaker_wiring(runs):
     assert head["op"] == "tf.concat" and [ts[i]["shape"][-1] for i in head["in"]] == [16, 512]
     sspec = dict(taco_amd.weights.weight_spec(taco_amd.hparams.copy(model_type="simple"), 3))
     assert sspec["linear/kernel"] == (528, 1025) and sspec["decoder/concat_projection/kernel"] == (528, 256) and sspec["decoder/attention_gru/gates/kernel"] == (128 + 16 + 256, 512)
+
+
+def _tf_variable_names(run):
+    """The variable names a TensorFlow 1.x graph of this trace has: the reference decides the scopes, the layer names and the order in which
+    the wrappers nest (traced); TensorFlow decides what a layer of each kind calls its variables inside its scope (conv1d/kernel,
+    batch_normalization/gamma, gru_cell/gates/kernel, ...: the documented names, spelled out here)."""
+    out = set()
+    auto = {}
+    atype = run["config"]["attention_type"]
+    for t in run["trace"]:
+        sc, op, kw = t["scope"], t["op"], t["kwargs"]
+        if op == "tf.layers.conv1d":
+            out |= {sc + "/conv1d/kernel", sc + "/conv1d/bias"}
+        elif op == "tf.layers.batch_normalization":
+            out |= {sc + "/batch_normalization/" + v for v in ("gamma", "beta", "moving_mean", "moving_variance")}
+        elif op == "tf.layers.dense":
+            name = kw.get("name")
+            if name is None:
+                n = auto.get(sc, 0)
+                auto[sc] = n + 1
+                name = "dense" if n == 0 else "dense_%d" % n
+            out |= {sc + "/" + name + "/kernel", sc + "/" + name + "/bias"}
+        elif op == "tf.get_variable":
+            out.add((sc + "/" if sc else "") + kw["name"])
+        elif op == "GRUCell.call":
+            out |= {sc + "/" + g + "/" + v for g in ("gates", "candidate") for v in ("kernel", "bias")}
+        elif op == "bidirectional_dynamic_rnn.output_fw":
+            out |= {sc + "/bidirectional_rnn/" + d + "/gru_cell/" + g + "/" + v for d in ("fw", "bw") for g in ("gates", "candidate") for v in ("kernel", "bias")}
+        elif op == "OutputProjectionWrapper.linear":
+            out |= {sc + "/kernel", sc + "/bias"}
+        elif op == "attention.__call__":
+            out |= {sc + "/query_layer/kernel", sc + "/attention_v"}
+            if atype == "bah_mon":
+                out.add(sc + "/attention_score_bias")
+            if atype == "bah_norm":
+                out |= {sc + "/attention_g", sc + "/attention_b"}
+        elif op in ("new BahdanauMonotonicAttention", "new BahdanauAttention"):
+            out.add(sc + "/memory_layer/kernel")
+    return {"model/" + n for n in out}
+
+
+@pytest.mark.parametrize("key,ns", [(("single", "bah_mon", False, 16), 1), (("single", "bah", False, 16), 1), (("single", "bah_norm", False, 16), 1),
+                                    (("deepvoice", "bah_mon", False, 16), 3), (("deepvoice", "bah_mon", False, 1), 3), (("simple", "bah_mon", False, 16), 3)])
+def test_checkpoint_variable_names_follow_the_traced_scopes(runs, key, ns):
+    """f1 (synthesizer.py:66-67, saver.restore): the TensorFlow variable names the importer / exporter use for every tensor
+    (tf_checkpoint.tf_names_for, weights.TF_SCOPE_MAP) are exactly the names the reference's graph has -- scopes, layer names and the nesting
+    of the RNN wrappers taken from the trace of the reference's own code, TensorFlow's per-layer variable names spelled out above."""
+    import taco_amd
+    from taco_amd import tf_checkpoint as T
+    run = runs[key]
+    hp = taco_amd.hparams.copy(model_type=key[0], attention_type=key[1], speaker_embedding_size=key[3])
+    spec = taco_amd.weights.weight_spec(hp, ns)
+    mine = set(T.tf_names_for(spec, key[1]).values())
+    assert mine == _tf_variable_names(run), (sorted(mine - _tf_variable_names(run))[:5], sorted(_tf_variable_names(run) - mine)[:5])

@@ -24,6 +24,7 @@ import importlib.machinery
 import importlib.util
 import json
 import os
+import re
 import sys
 import types
 
@@ -408,7 +409,15 @@ class AdamOptimizer(Recorded):
 
 
 # ---- library classes as dispatchers -------------------------------------------------------------------------------------------
+def snake(name):
+    """TensorFlow's rule for the variable scope a Layer / RNNCell opens around its `call` (base_layer's to_snake_case of the class name)"""
+    s1 = re.sub(r"(.)([A-Z][a-z0-9]+)", r"\1_\2", name)
+    return re.sub(r"([a-z])([A-Z])", r"\1_\2", s1).lower()
+
+
 class RNNCell(Recorded):
+    SCOPED = True           # a cell that defines `call` is run by Layer.__call__ inside a scope named after its class
+
     def __init__(self, name=None, **k):
         self._name = name
         self._base_name = name or type(self).__name__
@@ -418,7 +427,10 @@ class RNNCell(Recorded):
         return self._base_name
 
     def __call__(self, inputs, state, scope=None):
-        return self.call(inputs, state)
+        if not self.SCOPED:
+            return self.call(inputs, state)
+        with scope_cm(snake(type(self).__name__)):
+            return self.call(inputs, state)
 
     def zero_state(self, batch_size, dtype):
         n = self.state_size
@@ -453,8 +465,9 @@ class MultiRNNCell(RNNCell):
 
     def call(self, inputs, state):
         cur, new = inputs, []
-        for c, s in zip(self._cells, state):
-            cur, ns = c(cur, s)
+        for i, (c, s) in enumerate(zip(self._cells, state)):
+            with scope_cm("cell_%d" % i):
+                cur, ns = c(cur, s)
             new.append(ns)
         return cur, tuple(new)
 
@@ -477,6 +490,8 @@ class OutputProjectionWrapper(RNNCell):
 
 
 class ResidualWrapper(RNNCell):
+    SCOPED = False          # TF 1.x's ResidualWrapper overrides __call__ itself: no scope of its own
+
     def __init__(self, cell, **k):
         RNNCell.__init__(self)
         self._cell = cell
@@ -511,7 +526,8 @@ class _Attention(AttentionMechanism):
         return Sym("attention.initial_alignments", (batch_size,), {"mechanism": self._rid}, shape=[None, self.alignments_size])
 
     def __call__(self, query, previous_alignments=None, **k):
-        return Sym("attention.__call__", (query, previous_alignments), dict(mechanism=self._rid, **k), shape=[None, self.alignments_size])
+        with scope_cm(snake(type(self).__name__)):      # the query layer's variables live here
+            return Sym("attention.__call__", (query, previous_alignments), dict(mechanism=self._rid, **k), shape=[None, self.alignments_size])
 
 
 class BahdanauAttention(_Attention):
@@ -547,7 +563,7 @@ class BasicDecoder(Recorded):
 def dynamic_decode(decoder, maximum_iterations=None, **k):
     """records the call and traces ONE step along BasicDecoder's documented structure"""
     Sym("tf.contrib.seq2seq.dynamic_decode", (), dict(maximum_iterations=maximum_iterations, decoder=decoder._rid, **k))
-    with scope_cm("decoder_step"):
+    with scope_cm("decoder"):                      # dynamic_decode's own variable scope
         finished, first_inputs = decoder.helper.initialize()
         time = Sym("time", (), shape=[])
         outputs, state = decoder.cell(first_inputs, decoder.initial_state)
