@@ -227,3 +227,19 @@ def test_input_lengths_rule_equals_what_the_reference_feeds():
     tok = mv["tokens"]
     assert EOS_ID == 1 and np.array_equal(np.argmax(tok == EOS_ID, 1), mv["input_lengths"]) and mv["input_lengths"].tolist() == [2, 5, 0, 1, 0, 3]
     assert mv["manual_alignments_fed_when_off"].shape == (1, 1, 1)            # the dummy the placeholder gets when is_manual_attention is False (:128-132)
+
+
+def test_most_recent_checkpoint_choice_equals_the_reference(tmp_path):
+    """synthesizer.py:289-299 run on four directory listings (numeric, not lexicographic, maximum; an explicit step): the product picks the
+    same checkpoint (it returns the `.index` file of it, which tf_checkpoint.py reads, where the reference returns the prefix)."""
+    from taco_amd.synthesizer import get_most_recent_checkpoint
+    with open(os.path.join(GOLD, "hparams_vectors.json")) as f:
+        cases = json.load(f)["checkpoint_choice"]
+    assert len(cases) == 4
+    for i, c in enumerate(cases):
+        d = tmp_path / ("d%d" % i)
+        d.mkdir()
+        for fn in c["files"]:
+            (d / fn).write_bytes(b"")
+        got = get_most_recent_checkpoint(str(d), checkpoint_step=c["checkpoint_step"])
+        assert os.path.basename(got) == c["chosen"] + ".index", (c, got)

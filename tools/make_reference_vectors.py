@@ -270,6 +270,21 @@ def hparams_vectors():
             U.load_hparams(hp_i, d, skip_list=skip)
         out["load_cases"].append({"params_json": js, "skip_list": skip,
                                   "after": {k: plain(getattr(hp_i, k)) for k in sorted(hp.values())}})
+    # synthesizer.py:289-299 get_most_recent_checkpoint: which step a directory listing selects (the function only globs and parses names)
+    S = load_reference_synthesizer([])
+    out["checkpoint_choice"] = []
+    listings = [(["model.ckpt-100", "model.ckpt-20", "model.ckpt-3000"], None), (["model.ckpt-7", "model.ckpt-70", "model.ckpt-8"], None),
+                (["model.ckpt-5000"], None), (["model.ckpt-100", "model.ckpt-200"], 100)]
+    for stems, step in listings:
+        with tempfile.TemporaryDirectory() as d:
+            files = []
+            for st in stems:
+                for suffix in (".index", ".meta", ".data-00000-of-00001"):
+                    files.append(st + suffix)
+                    open(os.path.join(d, st + suffix), "w").close()
+            open(os.path.join(d, "checkpoint"), "w").close()
+            got = S.get_most_recent_checkpoint(d, checkpoint_step=step)
+            out["checkpoint_choice"].append({"files": sorted(files + ["checkpoint"]), "checkpoint_step": step, "chosen": os.path.basename(got)})
     return out
 
 
