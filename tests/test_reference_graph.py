@@ -21,7 +21,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def runs():
     with open(os.path.join(GOLD, "graph_trace.json")) as f:
         d = json.load(f)
-    return {(r["config"]["model_type"], r["config"]["attention_type"], r["config"]["training"], r["config"]["speaker_embedding_size"]): r for r in d["runs"]}
+    return {(r["config"]["model_type"], r["config"]["attention_type"], r["config"]["training"], r["config"]["speaker_embedding_size"]) +
+            (("priority",) if r["config"].get("prioritize_loss") else ()): r for r in d["runs"]}
 
 
 def _ops(run, op, scope_prefix=None):
@@ -306,3 +307,35 @@ def test_checkpoint_variable_names_follow_the_traced_scopes(runs, key, ns):
     spec = taco_amd.weights.weight_spec(hp, ns)
     mine = set(T.tf_names_for(spec, key[1]).values())
     assert mine == _tf_variable_names(run), (sorted(mine - _tf_variable_names(run))[:5], sorted(_tf_variable_names(run) - mine)[:5])
+
+
+def test_priority_loss_band_and_learning_rate_schedules(runs):
+    """tacotron.py:283-296 with prioritize_loss: the band l1[:, :, lower:upper] and the 0.5 weights; :313-325: both schedules -- the slice
+    bounds and the constants the reference's code produces are the ones the oracle (and through it taco_loss_f32 / taco_learning_rate) use."""
+    import taco_oracle as O
+    run = runs[("single", "bah_mon", True, 16, "priority")]
+    tr = run["trace"]
+    loss = [t for t in tr if t["scope"] == "loss"]
+    band = [t for t in loss if t["op"] == "getitem"][0]
+    F, sr = run["hparams"]["num_freq"], run["hparams"]["sample_rate"]
+    lo, up = int(165 / (sr * 0.5) * F), int(5000 / (sr * 0.5) * F)
+    assert band["kwargs"]["index"] == ["::", "::", "%d:%d:" % (lo, up)] and (lo, up) == (14, 427)
+    assert tr[band["in"][0]]["op"] == "tf.abs"
+    halves = [t for t in loss if t["op"] == "mul" and 0.5 in t["args"]]
+    assert len(halves) == 3                                       # 0.5 * mean(l1 c), 0.5 * mean(l1_priority c), 0.5 * (mean(l1) + mean(l1_priority))
+    # the oracle computes the same band (its loss is the checker of the device kernel)
+    rs = __import__("numpy").random.RandomState(0)
+    a, b = rs.rand(2, 3, F), rs.rand(2, 3, F)
+    got = O.add_loss(rs.rand(2, 3, 80), rs.rand(2, 3, 80), a, b, [1.0, 1.0], prioritize_loss=True, sample_rate=sr)
+    l1 = abs(b - a)
+    assert abs(got["linear_loss"] - 0.5 * (l1.mean() + l1[:, :, lo:up].mean())) < 1e-12
+    # learning rate: mode 1 = initial * exponential_decay(1., step, 3000, 0.95); mode 0 (default run) = initial * w**0.5 * min(step * w**-1.5, step**-0.5)
+    opt = [t for t in tr if t["scope"] == "optimizer"]
+    ed = [t for t in opt if t["op"] == "tf.train.exponential_decay"][0]
+    assert ed["args"][0] == 1.0 and ed["args"][2:] == [3000, 0.95]
+    run0 = runs[("single", "bah_mon", True, 16)]
+    opt0 = [t for t in run0["trace"] if t["scope"] == "optimizer"]
+    mul0 = [t for t in opt0 if t["op"] == "mul" and t["in"] == [[x for x in opt0 if x["op"] == "tf.cast"][0]["id"]]][0]
+    assert abs(mul0["args"][1] - 40000.0 ** -1.5) < 1e-18           # not randomly initialised: warm-up 40000 steps (tacotron.py:316-319)
+    assert abs(O.learning_rate(0, 0.002, 0, False) - 0.002 * 40000.0 ** 0.5 * min(1 * 40000.0 ** -1.5, 1.0)) < 1e-15
+    assert abs(O.learning_rate(2999, 0.002, 1, True) - 0.002 * 0.95) < 1e-12

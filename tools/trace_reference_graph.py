@@ -702,13 +702,15 @@ def load_reference_models():
     return T, hpm.hparams, tf
 
 
-def run_config(model_type, attention_type, num_speakers, training, speaker_embedding_size=None):
+def run_config(model_type, attention_type, num_speakers, training, speaker_embedding_size=None, prioritize_loss=False, decay_mode=0,
+               is_randomly_initialized=False):
     del TRACE[:]
     del SCOPE[:]
     T, hp, tf = load_reference_models()
     hp.model_type, hp.attention_type = model_type, attention_type
     if speaker_embedding_size is not None:
         hp.speaker_embedding_size = speaker_embedding_size
+    hp.prioritize_loss, hp.decay_learning_rate_mode = prioritize_loss, decay_mode
     m = T.Tacotron(hp)
     inputs = tf.placeholder(tf.int32, [None, None], "inputs")
     input_lengths = tf.placeholder(tf.int32, [None], "input_lengths")
@@ -718,12 +720,15 @@ def run_config(model_type, attention_type, num_speakers, training, speaker_embed
         kw = dict(mel_targets=tf.placeholder(tf.float32, [None, None, hp.num_mels], "mel_targets"),
                   linear_targets=tf.placeholder(tf.float32, [None, None, hp.num_freq], "linear_targets"),
                   loss_coeff=tf.placeholder(tf.float32, [None], "loss_coeff"))
+    if training:
+        kw["is_randomly_initialized"] = is_randomly_initialized
     m.initialize(inputs, input_lengths, num_speakers, speaker_id, **kw)
     if training:
         m.add_loss()
         m.add_optimizer(tf.placeholder(tf.int32, [], "global_step"))
     return {"config": dict(model_type=model_type, attention_type=attention_type, num_speakers=num_speakers, training=training,
-                           speaker_embedding_size=hp.speaker_embedding_size),
+                           speaker_embedding_size=hp.speaker_embedding_size, prioritize_loss=prioritize_loss, decay_learning_rate_mode=decay_mode,
+                           is_randomly_initialized=is_randomly_initialized),
             "hparams": {k: v for k, v in hp.values().items() if isinstance(v, (int, float, str, bool, list))},
             "outputs": {"mel_outputs": m.mel_outputs.id, "linear_outputs": m.linear_outputs.id, "alignments": m.alignments.id},
             "trace": [dict(r) for r in TRACE]}
@@ -734,7 +739,8 @@ def main():
         sys.exit("no reference checkout at %s (this script runs in the build container only)" % REF)
     runs = [run_config("single", "bah_mon", 1, False), run_config("single", "bah_mon", 1, True), run_config("single", "bah", 1, False),
             run_config("single", "bah_norm", 1, False), run_config("deepvoice", "bah_mon", 3, False), run_config("deepvoice", "bah_mon", 3, False, 1),
-            run_config("simple", "bah_mon", 3, False)]
+            run_config("simple", "bah_mon", 3, False),
+            run_config("single", "bah_mon", 1, True, prioritize_loss=True, decay_mode=1, is_randomly_initialized=True)]
     os.makedirs(GOLD, exist_ok=True)
     with open(os.path.join(GOLD, "graph_trace.json"), "w") as f:
         json.dump({"generated_by": "tools/trace_reference_graph.py: models/tacotron.py, modules.py, rnn_wrappers.py, helpers.py of /root/reference "
