@@ -22,7 +22,7 @@ def runs():
     with open(os.path.join(GOLD, "graph_trace.json")) as f:
         d = json.load(f)
     return {(r["config"]["model_type"], r["config"]["attention_type"], r["config"]["training"], r["config"]["speaker_embedding_size"]) +
-            (("priority",) if r["config"].get("prioritize_loss") else ()): r for r in d["runs"]}
+            (("priority",) if r["config"].get("prioritize_loss") else ()) + (("test_mode",) if r["config"].get("rnn_decoder_test_mode") else ()): r for r in d["runs"]}
 
 
 def _ops(run, op, scope_prefix=None):
@@ -339,3 +339,17 @@ def test_priority_loss_band_and_learning_rate_schedules(runs):
     assert abs(mul0["args"][1] - 40000.0 ** -1.5) < 1e-18           # not randomly initialised: warm-up 40000 steps (tacotron.py:316-319)
     assert abs(O.learning_rate(0, 0.002, 0, False) - 0.002 * 40000.0 ** 0.5 * min(1 * 40000.0 ** -1.5, 1.0)) < 1e-15
     assert abs(O.learning_rate(2999, 0.002, 1, True) - 0.002 * 0.95) < 1e-12
+
+
+def test_rnn_decoder_test_mode_feeds_back_the_last_frame(runs):
+    """helpers.py:59-66 with rnn_decoder_test_mode (the test model of train.py:158-166): the next input is the step's own last frame,
+    outputs[:, -num_mels:], not the target frame -- while `finished` still counts target steps."""
+    run = runs[("single", "bah_mon", True, 16, "test_mode")]
+    tr = run["trace"]
+    step = [t for t in tr if t["scope"].startswith("inference/decoder")]
+    frame = [t for t in step if t["op"] == "OutputProjectionWrapper.linear"][-1]
+    nxt = [t for t in step if t["op"] == "decoder_step.next_inputs"][0]
+    fed = tr[nxt["in"][0]]
+    assert fed["op"] == "getitem" and fed["in"] == [frame["id"]] and fed["kwargs"]["index"] == ["::", "-80::"]
+    fin = tr[nxt["in"][1]]
+    assert fin["op"] == "greater_equal"

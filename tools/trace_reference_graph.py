@@ -703,7 +703,7 @@ def load_reference_models():
 
 
 def run_config(model_type, attention_type, num_speakers, training, speaker_embedding_size=None, prioritize_loss=False, decay_mode=0,
-               is_randomly_initialized=False):
+               is_randomly_initialized=False, rnn_decoder_test_mode=False):
     del TRACE[:]
     del SCOPE[:]
     T, hp, tf = load_reference_models()
@@ -722,13 +722,14 @@ def run_config(model_type, attention_type, num_speakers, training, speaker_embed
                   loss_coeff=tf.placeholder(tf.float32, [None], "loss_coeff"))
     if training:
         kw["is_randomly_initialized"] = is_randomly_initialized
+        kw["rnn_decoder_test_mode"] = rnn_decoder_test_mode
     m.initialize(inputs, input_lengths, num_speakers, speaker_id, **kw)
     if training:
         m.add_loss()
         m.add_optimizer(tf.placeholder(tf.int32, [], "global_step"))
     return {"config": dict(model_type=model_type, attention_type=attention_type, num_speakers=num_speakers, training=training,
                            speaker_embedding_size=hp.speaker_embedding_size, prioritize_loss=prioritize_loss, decay_learning_rate_mode=decay_mode,
-                           is_randomly_initialized=is_randomly_initialized),
+                           is_randomly_initialized=is_randomly_initialized, rnn_decoder_test_mode=rnn_decoder_test_mode),
             "hparams": {k: v for k, v in hp.values().items() if isinstance(v, (int, float, str, bool, list))},
             "outputs": {"mel_outputs": m.mel_outputs.id, "linear_outputs": m.linear_outputs.id, "alignments": m.alignments.id},
             "trace": [dict(r) for r in TRACE]}
@@ -740,7 +741,8 @@ def main():
     runs = [run_config("single", "bah_mon", 1, False), run_config("single", "bah_mon", 1, True), run_config("single", "bah", 1, False),
             run_config("single", "bah_norm", 1, False), run_config("deepvoice", "bah_mon", 3, False), run_config("deepvoice", "bah_mon", 3, False, 1),
             run_config("simple", "bah_mon", 3, False),
-            run_config("single", "bah_mon", 1, True, prioritize_loss=True, decay_mode=1, is_randomly_initialized=True)]
+            run_config("single", "bah_mon", 1, True, prioritize_loss=True, decay_mode=1, is_randomly_initialized=True),
+            run_config("single", "bah_mon", 1, True, rnn_decoder_test_mode=True)]
     os.makedirs(GOLD, exist_ok=True)
     with open(os.path.join(GOLD, "graph_trace.json"), "w") as f:
         json.dump({"generated_by": "tools/trace_reference_graph.py: models/tacotron.py, modules.py, rnn_wrappers.py, helpers.py of /root/reference "
