@@ -477,9 +477,13 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
 // The persistent BPTT kernel's registers (taco_decoder_bwd_xcd.h, DBR_*): ROWS of the kernels -- wave w of member m holds row 8m + w
 // (128-wide inputs: row 4m + w on waves 0-3) of every matrix a gradient is pulled back through, inputs 4*lane .. 4*lane + 3 per register quad.
 static int dbx_build_pack(taco_model* m) {
-  if (!dx_widths_ok(m) || is_simple(m)) return 0;
+  if (!dx_widths_ok(m)) return 0;
   const taco_hparams& hp = m->hp;
   const int H = DX_W, Mm = hp.num_mels;
+  // 'simple': S speaker rows sit between the prenet rows and the h rows of the attention GRU kernels (and behind [h_att | ctx] in the
+  // concat projection).  The embedding is constant over the loop, so its gradient is a sum over steps of products with those rows --
+  // formed once after the launch from the time-summed pre-activation gradients (decoder_backward); the kernel only skips the rows.
+  const int IA = DX_P2 + (is_simple(m) ? hp.speaker_embedding_size : 0);
   std::vector<float> pack((size_t)DX_GROUP * DB_NREG * DX_NT, 0.f);
   const auto& g2k = T_(m, "decoder/gru_2/gates/kernel").data; const auto& c2k = T_(m, "decoder/gru_2/candidate/kernel").data;
   const auto& g1k = T_(m, "decoder/gru_1/gates/kernel").data; const auto& c1k = T_(m, "decoder/gru_1/candidate/kernel").data;
@@ -504,9 +508,9 @@ static int dbx_build_pack(taco_model* m) {
       row(DBR_G1H, 4, g1k, 2 * H, H + en, 0, 2 * H); row(DBR_G1H + 4, 4, g1k, 2 * H, H + en, 256, 2 * H);
       row(DBR_CCA, 4, cck, H, en, 0, H); row(DBR_CCC, 4, cck, H, H + en, 0, H);
       row(DBR_Q, 4, wq, H, en, 0, H);
-      row(DBR_CAX, 4, ack, H, en2, 0, H); row(DBR_CAH, 4, ack, H, DX_P2 + en, 0, H);
+      row(DBR_CAX, 4, ack, H, en2, 0, H); row(DBR_CAH, 4, ack, H, IA + en, 0, H);
       row(DBR_GAX, 4, agk, 2 * H, en2, 0, 2 * H); row(DBR_GAX + 4, 4, agk, 2 * H, en2, 256, 2 * H);
-      row(DBR_GAH, 4, agk, 2 * H, DX_P2 + en, 0, 2 * H); row(DBR_GAH + 4, 4, agk, 2 * H, DX_P2 + en, 256, 2 * H);
+      row(DBR_GAH, 4, agk, 2 * H, IA + en, 0, 2 * H); row(DBR_GAH + 4, 4, agk, 2 * H, IA + en, 256, 2 * H);
       row(DBR_P2, 2, W2, DX_P2, en, 0, DX_P2);
       row(DBR_P1C, 4, W1, H, Mm + en, 0, H);
     }

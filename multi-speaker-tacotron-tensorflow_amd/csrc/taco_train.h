@@ -816,7 +816,7 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   if (attn_lds > 160 * 1024 || (As % 4) || (D % 4) || (A % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the backward kernel");
   // the whole loop as ONE persistent launch (k_decoder_bwd_xcd, taco_decoder_bwd_xcd.h) when the forward left its tape in that
   // kernel's layout; the launch-per-stage loop below is the general path (other widths, 'simple', more than 64 rows)
-  const bool persistent = x.t->bptt_persistent && w.tape256 && !S && L == 2 && np == 2 && (size_t)DXT_N * w.tstride < (1u << 31) &&
+  const bool persistent = x.t->bptt_persistent && w.tape256 && L == 2 && np == 2 && (size_t)DXT_N * w.tstride < (1u << 31) &&
                           dbx_usable(m, B, T_in);
   x.t->sm->last_bptt = persistent ? 1 : 0;
   if (persistent) {
@@ -832,6 +832,20 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
     a.d_att_init = d_att_init; a.d_h10 = d_dec_init ? d_dec_init[0] : nullptr; a.d_h20 = d_dec_init ? d_dec_init[1] : nullptr;
     a.dsb_acc = w.dsb_acc;
     TRY(dbx_launch(m, st, a, B, T_in, n, w.xbuf, w.dxctl));
+    if (S) {
+      // 'simple': d speaker embedding = sum over steps of [d o0 . Wcc^T]_spk + [d c_pre(att) . Wc^T + d gates(att) . Wg^T]_spk.  Linear in the
+      // pre-activation gradients: sum those over time first, then ONE transposed product each (the per-stage chain adds step by step).
+      hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * Hd), 0, st, (const float*)w.g_do0, w.dht, B, n, Hd);
+      { SkJob j = sk_T(m, tp.concat_T, w.dht, Hd, w.dIn, As + Dc); TRY(run_skinny(st, B, &j, 1)); }
+      hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, dspk, S, w.dIn + As + D, As + Dc, B, S);
+      hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * As), 0, st, (const float*)w.g_dcpA, w.dht, B, n, As);
+      { SkJob j = sk_T(m, tp.att.cT, w.dht, As, w.tmp1, Pz + As); TRY(run_skinny(st, B, &j, 1)); }
+      hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, dspk, S, w.tmp1 + Pl, Pz + As, B, S);
+      hipLaunchKernelGGL(k_time_sum, EWGRID((size_t)B * 2 * As), 0, st, (const float*)w.g_dgpA, w.dpz, B, n, 2 * As);
+      { SkJob j = sk_T(m, tp.att.gT, w.dpz, 2 * As, w.tmp2, Pz + As); TRY(run_skinny(st, B, &j, 1)); }
+      hipLaunchKernelGGL(k_add2d, EWGRID((size_t)B * S), 0, st, dspk, S, w.tmp2 + Pl, Pz + As, B, S);
+      HIPCHK(hipGetLastError());
+    }
   }
   for (int t = n - 1; t >= 0 && !persistent; --t) {
     const size_t oh = (size_t)t * Hd, oa = (size_t)t * As;
