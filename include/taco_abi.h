@@ -228,7 +228,7 @@ int taco_train_set_exact_wgrad(taco_train* t, int on);
 int taco_train_set_exact_gemm(taco_train* t, int on);
 /* Back-propagation through the decoder loop (tf.gradients of rnn_wrappers.py:218-341 under train.py:215-219): persistent = 1 (default)
  * runs all T_out/r steps as ONE whole-chip launch (k_decoder_bwd_xcd, csrc/taco_decoder_bwd_xcd.h) when the forward ran on the persistent
- * decoder (reference widths, tacotron / deepvoice, <= 64 rows, a whole MI355X); 0 keeps the chain of per-stage launches. */
+ * decoder (reference widths, every model type, <= 64 rows, a whole MI355X); 0 keeps the chain of per-stage launches. */
 int taco_train_set_bptt_engine(taco_train* t, int persistent);
 /* Test hook: the post-net BiGRU scan alone -- forward with the gate tape, then backward -- on caller data, ragged lengths and
  * initial states included.  persistent = 1: the whole-chip kernels k_bigru_duo<RG, true> + k_bigru_duo_bwd; 0: k_bigru_res + k_bigru_rows_bwd.
