@@ -570,6 +570,10 @@ def dynamic_decode(decoder, maximum_iterations=None, **k):
         sample_ids = decoder.helper.sample(time=time, outputs=outputs, state=state)
         finished, next_inputs, next_state = decoder.helper.next_inputs(time=time, outputs=outputs, state=state, sample_ids=sample_ids)
         Sym("decoder_step.next_inputs", (next_inputs, finished))
+        # what the loop carries: the symbols of the initial state / first input, and the symbols of this step that replace them in the next one
+        flat = lambda st: [x.id if isinstance(x, Sym) else None for x in nest_flatten(st)]
+        Sym("decoder_step.carry", (), {"initial_state": flat(decoder.initial_state), "next_state": flat(next_state), "first_inputs": first_inputs.id,
+                                       "next_inputs": next_inputs.id, "time": time.id, "outputs": outputs.id})
     n = decoder.cell.output_size
     final_outputs = (Sym("dynamic_decode.rnn_output", (outputs,), shape=[None, None, n]), Sym("dynamic_decode.sample_id", (sample_ids,)))
     return final_outputs, next_state, Sym("dynamic_decode.sequence_lengths", ())
