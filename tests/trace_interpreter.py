@@ -100,7 +100,8 @@ class Interpreter(object):
             return act(y) if act is not None else y
         if op == "tf.layers.batch_normalization":
             c = self.canon(t["scope"] + "/batch_normalization", "gamma")
-            assert kw["training"] is False
+            if kw["training"]:
+                return O.batch_norm_train(A(0), w, c[:-len("/gamma")], self.bn_updates)
             return O.batch_norm_infer(A(0), w, c[:-len("/gamma")])
         if op == "tf.layers.max_pooling1d":
             assert kw["strides"] == 1 and kw["padding"] == "same"
@@ -137,7 +138,24 @@ class Interpreter(object):
             return np.reshape(A(0), shp)
         if op == "tf.transpose":
             return np.transpose(A(0), kw["perm"])
-        if op in ("tf.assert_equal", "attention.batch_size", "time", "decoder_step.next_inputs", "decoder_step.carry", "tf.equal", "tf.reduce_all",
+        if op == "tf.equal":
+            return np.equal(A(0), A(1))
+        if op == "tf.reduce_all":
+            return np.all(A(0), axis=kw.get("axis"))
+        if op == "tf.abs":
+            return np.abs(A(0))
+        if op == "tf.reduce_mean":
+            assert not kw                                   # over every axis
+            return np.mean(A(0))
+        if op == "tf.cast":
+            assert kw["dtype"] == "tf.float32"
+            return float(A(0))
+        if op == "tf.minimum":
+            return min(A(0), A(1))
+        if op == "tf.train.exponential_decay":              # TF-sem: lr * rate ** (step / decay_steps), staircase=False
+            assert not kw
+            return A(0) * A(3) ** (A(1) / A(2))
+        if op in ("tf.assert_equal", "attention.batch_size", "time", "decoder_step.next_inputs", "decoder_step.carry",
                   "dynamic_decode.sample_id", "dynamic_decode.sequence_lengths", "tf.contrib.seq2seq.dynamic_decode"):
             return None
         if op.startswith("new "):
@@ -181,22 +199,33 @@ class Interpreter(object):
         raise NotImplementedError(op)
 
     # ---- the whole graph ----
-    def forward(self, inputs, input_lengths, n_steps, speaker_id=None):
+    def forward(self, inputs, input_lengths, n_steps=None, speaker_id=None, manual_alignments=None, mel_targets=None, linear_targets=None,
+                loss_coeff=None, global_step=None):
+        """n_steps = maximum_iterations (None: the value the reference passes to dynamic_decode).  The decoder loop is dynamic_decode's
+        (TF-sem): run BasicDecoder's step until every row is finished -- the helper's `finished`, OR-ed over the steps -- or the step
+        count reaches maximum_iterations."""
         self.feed = {"inputs": np.asarray(inputs), "input_lengths": np.asarray(input_lengths), "speaker_id": None if speaker_id is None else np.asarray(speaker_id),
-                     "is_manual_attention": False, "manual_alignments": None}
+                     "is_manual_attention": manual_alignments is not None,
+                     "manual_alignments": None if manual_alignments is None else np.asarray(manual_alignments, np.float64),
+                     "mel_targets": mel_targets, "linear_targets": linear_targets, "loss_coeff": loss_coeff, "global_step": global_step}
+        self.bn_updates = {}
         tr = self.tr
-        dd = [t for t in tr if t["op"] == "tf.contrib.seq2seq.dynamic_decode"][0]["id"]
+        ddr = [t for t in tr if t["op"] == "tf.contrib.seq2seq.dynamic_decode"][0]
+        dd = ddr["id"]
+        max_iter = ddr["kwargs"]["maximum_iterations"] if n_steps is None else n_steps
         carry = [t for t in tr if t["op"] == "decoder_step.carry"][0]
         ck = carry["kwargs"]
         out_rec = [t for t in tr if t["op"] == "dynamic_decode.rnn_output"][0]["id"]
         step_ids = list(range(dd + 1, out_rec))
         for t in tr[:dd + 1]:
             self.v[t["id"]] = self.eval(t)
-        # the loop: BasicDecoder's step, n_steps times; the carried symbols take the previous step's values
+        # the loop: BasicDecoder's step; the carried symbols take the previous step's values
         init_ids = [i for i in ck["initial_state"] if i is not None] + [ck["first_inputs"]]
         next_ids = [i for i in ck["next_state"] if i is not None] + [ck["next_inputs"]]
         outs = []
-        for step in range(n_steps):
+        finished = None
+        step = 0
+        while step < max_iter:
             prev = dict(self.v)
             for i in step_ids:
                 t = tr[i]
@@ -206,16 +235,26 @@ class Interpreter(object):
                     self.v[i] = step
                 else:
                     self.v[i] = self.eval(t)
-            if step == 0:           # the carried symbols that were created BEFORE the loop (zero states): from now on they hold the step's results
-                pass
-            for a, b in zip(init_ids, next_ids):
+            for a, b in zip(init_ids, next_ids):     # carried symbols created BEFORE the loop (zero states, state.time)
                 if a <= dd:
                     self.v[a] = self.v[b]
             outs.append(self.v[ck["outputs"]])
+            if finished is None:
+                finished = np.asarray(self.v[ck["initial_finished"]], bool)
+            finished = finished | np.asarray(self.v[ck["finished"]], bool)
+            step += 1
+            if finished.all():
+                break
+        self.n_steps = step
         self.v[out_rec] = np.stack(outs, axis=1)
         for t in tr[out_rec + 1:]:
-            if t["scope"] in ("loss", "optimizer") or (t["op"] == "tf.placeholder" and t["kwargs"]["name"] == "global_step"):
+            if t["op"].startswith("new ") and "Optimizer" in t["op"]:
                 break
             self.v[t["id"]] = self.eval(t)
         o = self.run["outputs"]
-        return {"mel": self.v[o["mel_outputs"]], "linear": self.v[o["linear_outputs"]], "alignments": self.v[o["alignments"]]}
+        res = {"mel": self.v[o["mel_outputs"]], "linear": self.v[o["linear_outputs"]], "alignments": self.v[o["alignments"]], "n_steps": step,
+               "bn_updates": self.bn_updates}
+        for k in ("loss", "mel_loss", "linear_loss", "loss_without_coeff", "learning_rate"):
+            if k in o and self.v.get(o[k]) is not None:
+                res[k] = self.v[o[k]]
+        return res

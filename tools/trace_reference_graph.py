@@ -564,7 +564,7 @@ def dynamic_decode(decoder, maximum_iterations=None, **k):
     """records the call and traces ONE step along BasicDecoder's documented structure"""
     Sym("tf.contrib.seq2seq.dynamic_decode", (), dict(maximum_iterations=maximum_iterations, decoder=decoder._rid, **k))
     with scope_cm("decoder"):                      # dynamic_decode's own variable scope
-        finished, first_inputs = decoder.helper.initialize()
+        finished0, first_inputs = decoder.helper.initialize()
         time = Sym("time", (), shape=[])
         outputs, state = decoder.cell(first_inputs, decoder.initial_state)
         sample_ids = decoder.helper.sample(time=time, outputs=outputs, state=state)
@@ -573,7 +573,8 @@ def dynamic_decode(decoder, maximum_iterations=None, **k):
         # what the loop carries: the symbols of the initial state / first input, and the symbols of this step that replace them in the next one
         flat = lambda st: [x.id if isinstance(x, Sym) else None for x in nest_flatten(st)]
         Sym("decoder_step.carry", (), {"initial_state": flat(decoder.initial_state), "next_state": flat(next_state), "first_inputs": first_inputs.id,
-                                       "next_inputs": next_inputs.id, "time": time.id, "outputs": outputs.id})
+                                       "next_inputs": next_inputs.id, "time": time.id, "outputs": outputs.id,
+                                       "initial_finished": finished0.id, "finished": finished.id})
     n = decoder.cell.output_size
     final_outputs = (Sym("dynamic_decode.rnn_output", (outputs,), shape=[None, None, n]), Sym("dynamic_decode.sample_id", (sample_ids,)))
     return final_outputs, next_state, Sym("dynamic_decode.sequence_lengths", ())
@@ -731,11 +732,15 @@ def run_config(model_type, attention_type, num_speakers, training, speaker_embed
     if training:
         m.add_loss()
         m.add_optimizer(tf.placeholder(tf.int32, [], "global_step"))
+    outs = {"mel_outputs": m.mel_outputs.id, "linear_outputs": m.linear_outputs.id, "alignments": m.alignments.id}
+    if training:
+        for k in ("loss", "mel_loss", "linear_loss", "loss_without_coeff", "learning_rate"):
+            outs[k] = getattr(m, k).id
     return {"config": dict(model_type=model_type, attention_type=attention_type, num_speakers=num_speakers, training=training,
                            speaker_embedding_size=hp.speaker_embedding_size, prioritize_loss=prioritize_loss, decay_learning_rate_mode=decay_mode,
                            is_randomly_initialized=is_randomly_initialized, rnn_decoder_test_mode=rnn_decoder_test_mode),
             "hparams": {k: v for k, v in hp.values().items() if isinstance(v, (int, float, str, bool, list))},
-            "outputs": {"mel_outputs": m.mel_outputs.id, "linear_outputs": m.linear_outputs.id, "alignments": m.alignments.id},
+            "outputs": outs,
             "trace": [dict(r) for r in TRACE]}
 
 
