@@ -199,3 +199,75 @@ def test_tf1_fixture_dumper_prepare_and_compare_stages(tmp_path):
     np.savez(os.path.join(work, "tf1_outputs.npz"), linear=g["linear"] + 0.01, mel=g["mel"], alignments=g["alignments"], tf_version="1.4.0", n_variables=0)
     r = subprocess.run([sys.executable, tool, "compare", fixture, work], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "MISMATCH" in r.stdout
+
+
+def _bundle_messages():
+    """tensorflow/core/protobuf/tensor_bundle.proto + tensor_shape.proto + tensor_slice.proto + versions.proto, declared to Google's own
+    protobuf runtime: an encoder / decoder that shares no code with the hand-written one in tf_checkpoint.py"""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="taco_test_bundle.proto", package="tt", syntax="proto3")
+
+    def msg(parent, name, fields):
+        m = parent.message_type.add(name=name) if hasattr(parent, "message_type") else parent.nested_type.add(name=name)
+        for fname, num, typ, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=typ, label=label)
+            if tname:
+                f.type_name = tname
+        return m
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    shape = msg(fd, "TensorShapeProto", [("dim", 2, F.TYPE_MESSAGE, REP, ".tt.TensorShapeProto.Dim"), ("unknown_rank", 3, F.TYPE_BOOL, OPT, None)])
+    msg(shape, "Dim", [("size", 1, F.TYPE_INT64, OPT, None), ("name", 2, F.TYPE_STRING, OPT, None)])
+    sl = msg(fd, "TensorSliceProto", [("extent", 1, F.TYPE_MESSAGE, REP, ".tt.TensorSliceProto.Extent")])
+    ext = msg(sl, "Extent", [("start", 1, F.TYPE_INT64, OPT, None), ("length", 2, F.TYPE_INT64, OPT, None)])
+    ext.oneof_decl.add(name="has_length")
+    ext.field[1].oneof_index = 0
+    msg(fd, "VersionDef", [("producer", 1, F.TYPE_INT32, OPT, None), ("min_consumer", 2, F.TYPE_INT32, OPT, None), ("bad_consumers", 3, F.TYPE_INT32, REP, None)])
+    msg(fd, "BundleHeaderProto", [("num_shards", 1, F.TYPE_INT32, OPT, None), ("endianness", 2, F.TYPE_INT32, OPT, None),
+                                  ("version", 3, F.TYPE_MESSAGE, OPT, ".tt.VersionDef")])
+    msg(fd, "BundleEntryProto", [("dtype", 1, F.TYPE_INT32, OPT, None), ("shape", 2, F.TYPE_MESSAGE, OPT, ".tt.TensorShapeProto"),
+                                 ("shard_id", 3, F.TYPE_INT32, OPT, None), ("offset", 4, F.TYPE_INT64, OPT, None), ("size", 5, F.TYPE_INT64, OPT, None),
+                                 ("crc32c", 6, F.TYPE_FIXED32, OPT, None), ("slices", 7, F.TYPE_MESSAGE, REP, ".tt.TensorSliceProto")])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = getattr(message_factory, "GetMessageClass", None)
+    mk = (lambda n: get(pool.FindMessageTypeByName("tt." + n))) if get else (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName("tt." + n)))
+    return mk("BundleEntryProto"), mk("BundleHeaderProto")
+
+
+def test_bundle_entries_against_googles_protobuf_runtime(tmp_path):
+    """the hand-written protobuf layer of tf_checkpoint.py == google.protobuf on the published bundle schema, both directions: entries the
+    writer emits parse there field by field, and entries serialised there (incl. field orders / defaults the writer never produces) parse here"""
+    Entry, Header = _bundle_messages()
+    rs = np.random.RandomState(3)
+    for trial in range(200):
+        shape = [int(x) for x in rs.randint(0, 5000, size=rs.randint(0, 5))]
+        shard, off, size, crc = int(rs.randint(0, 4)), int(rs.randint(0, 2 ** 40)), int(rs.randint(0, 2 ** 33)), int(rs.randint(0, 2 ** 32))
+        raw = T._entry_proto(1, shape, shard, off, size, crc)
+        m = Entry.FromString(raw)
+        assert (m.dtype, [d.size for d in m.shape.dim], m.shard_id, m.offset, m.size, m.crc32c) == (1, shape, shard, off, size, crc)
+        assert m.SerializeToString() == raw                  # canonical field order and default elision, byte for byte
+        e = T._parse_entry(m.SerializeToString())
+        assert (e["dtype"], e["shape"], e["shard_id"], e["offset"], e["size"], e["crc32c"], e["sliced"]) == (1, shape, shard, off, size, crc, False)
+    # a partitioned variable's full-tensor entry: slice specs, extents with and without a length
+    slices = [[(0, 3), (0, -1)], [(3, 5), (0, -1)]]
+    raw = T._entry_proto(1, [8, 4], 0, 0, 0, 0, slices=slices)
+    m = Entry.FromString(raw)
+    got = [[(x.start, x.length if x.WhichOneof("has_length") else -1) for x in s.extent] for s in m.slices]
+    assert got == slices and [d.size for d in m.shape.dim] == [8, 4]
+    m2 = Entry(dtype=1)
+    for dsz in (8, 4):
+        m2.shape.dim.add(size=dsz)
+    for ext in slices:
+        s = m2.slices.add()
+        for st, ln in ext:
+            x = s.extent.add(start=st)
+            if ln >= 0:
+                x.length = ln
+    e = T._parse_entry(m2.SerializeToString())
+    assert e["sliced"] and e["slices"] == slices and e["shape"] == [8, 4]
+    # the header the writer puts under the empty key
+    T.write_checkpoint(str(tmp_path / "m.ckpt-1"), {"a": np.arange(6, dtype=np.float32).reshape(2, 3)}, num_shards=1)
+    idx = T.read_index(str(tmp_path / "m.ckpt-1.index"))
+    h = Header.FromString(idx[b""] if b"" in idx else idx[""])
+    assert (h.num_shards, h.endianness, h.version.producer) == (1, 0, 1)
