@@ -9,7 +9,8 @@ from librosa's documented algorithm (0.5/0.6 era, the versions contemporary with
          tiny, then n_fft/2 trimmed from both ends.
 PARITY: the librosa-free pieces (stft_parameters, denormalize, db_to_amp, the power law, inv_preemphasis) are pinned bit for bit on the
 reference's own functions (tools/make_reference_vectors.py -> tests/golden/audio_vectors.npz, tests/test_reference_vectors.py).  The
-STFT / ISTFT are UNPINNED: librosa cannot run here; only hand checks (round trip, Parseval) hold them."""
+STFT / ISTFT are UNPINNED on librosa itself (it cannot run here); they are held against two other implementations of the same documented
+convention -- torch.stft / torch.istft and scipy.signal.stft (tests/test_audio_crosscheck.py) -- and by round trip / Parseval checks."""
 import numpy as np
 
 
