@@ -3,8 +3,10 @@
 Kept: load() / synthesize() / close() names and arguments; token -> input_lengths rule
 (synthesizer.py:120); default speaker id zeros (:43-44); the (linear_outputs, alignments) fetch pair
 (:122-126,166-167); manual-attention second pass for modes 1 and 3 (:171-205; mode 2 is broken in the
-reference: np.pow does not exist).  Out of scope: text normalisation,
-plots, Griffin-Lim, wav I/O -- `synthesize` returns the model outputs as numpy arrays instead."""
+reference: np.pow does not exist); text -> ids with the Korean normaliser (text.py, korean.py); the attention trim
+(:242-262, device kernel) and, with vocode=True, the spectrogram -> waveform step on the GPU (audio.py).
+Out of scope: plots, wav / npy file output, sentence concatenation -- `synthesize` returns the model
+outputs as numpy arrays (and keeps `spec_end_idx` / `wavs` as attributes) instead."""
 import glob
 import os
 import re

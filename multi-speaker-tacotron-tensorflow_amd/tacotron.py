@@ -379,6 +379,7 @@ class Tacotron(object):
     def share_variables_with(self, other):
         """train.py:158-159 builds the test model under reuse=True: same variables as the training model."""
         self._trainer = other._trainer
+        self.device = other.device
         return self
 
     def _train_forward(self):
