@@ -11,7 +11,8 @@
 // host recurrence (so the experiment checks the operand layouts and the split arithmetic as well as the clocks).
 // Prints microseconds per step (HIP events), clocks per step and per part of a step (shader clock of group 0 / member 0 / thread 0).
 //   hipcc --offload-arch=gfx950 -O3 -I multi-speaker-tacotron-tensorflow_amd/csrc tools/ubench_mfma_scan.hip -o tools/ubench_mfma_scan
-// Not yet run on a GPU (written at the end of round 3 without GPU time; the numerics are emulated in tools/sim_split_recurrence.py).
+// Measured (profiles/r03_ubench_mfma_scan.txt): M is row-independent (~900-1000 clocks of compute + publish) but V is 557 at 4 rows and 953 at 8:
+// no gain at the row counts the kernels run.  The numerics (also emulated on the CPU in tools/sim_split_recurrence.py): six products 4e-7, as V.
 #include "taco_decoder_xcd.h"
 #include <cmath>
 #include <cstdio>
