@@ -5,6 +5,7 @@ tag=${1:-vXX}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+[ -x tools/time_stages_native ] && timeout 60 ./tools/time_stages_native > $out/time_stages_native.txt 2>&1     # C ABI only, no Python: seconds
 timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
 for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
