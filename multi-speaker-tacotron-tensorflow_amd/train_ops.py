@@ -75,3 +75,14 @@ def allreduce_gradients(flat_grads):
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
         flat_grads.div_(dist.get_world_size())
     return flat_grads
+
+
+def raise_if_loss_exploded(loss, step):
+    """The guard of the reference's training loop, right after the fetch of the step (train.py:228-230): `loss > 100 or isnan(loss)`
+    raises Exception('Loss Exploded').  `loss` is the step's loss_without_coeff (a device scalar or a float).  A device fault of a
+    persistent kernel poisons the step's losses with NaN (taco_abi.h), so this is also where a caller's loop learns of one."""
+    import math
+    v = float(loss.item() if hasattr(loss, "item") else loss)
+    if v > 100 or math.isnan(v):
+        raise Exception("Loss Exploded")
+    return v

@@ -159,3 +159,16 @@ def test_no_persistent_kernel_uses_scratch():
     names = [n for n, _ in kernels]
     assert any("k_bigru_xcdILi4ELi8" in n for n in names) and any("k_decoder_xcdILi4" in n for n in names)
     assert not bad, bad
+
+
+def test_loss_exploded_guard_is_the_reference_loops():
+    """train.py:228-230: loss > 100 or NaN -> Exception('Loss Exploded'); 100 itself and +-0 pass"""
+    import taco_amd
+    g = taco_amd.train_ops.raise_if_loss_exploded
+    assert g(100.0, 3) == 100.0 and g(0.25, 0) == 0.25
+    for bad in (100.0001, float("nan"), float("inf")):
+        with pytest.raises(Exception, match="Loss Exploded"):
+            g(bad, 1)
+    assert g(float("-inf"), 1) == float("-inf")          # the reference's test lets it through as well
+    import numpy as np
+    assert g(np.float32(1.5), 2) == 1.5
