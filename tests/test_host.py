@@ -172,3 +172,38 @@ def test_loss_exploded_guard_is_the_reference_loops():
     assert g(float("-inf"), 1) == float("-inf")          # the reference's test lets it through as well
     import numpy as np
     assert g(np.float32(1.5), 2) == 1.5
+
+
+def test_open_data_dirs_feeds_batches_from_npz_directories(tmp_path):
+    """feeder.open_data_dirs: the reference's data directories (datafeeder.py:26-121) -> batches of the contract train.py consumes"""
+    import numpy as np
+    import taco_amd
+    from taco_amd import feeder as F
+    rs = np.random.RandomState(0)
+    dirs = []
+    for name, n in (("spk_a", 14), ("spk_b", 11)):
+        d = tmp_path / name
+        d.mkdir()
+        for i in range(n):
+            T, nt = int(rs.randint(10, 40)), int(rs.randint(4, 9))
+            np.savez(str(d / ("u%02d.npz" % i)), tokens=np.r_[rs.randint(2, 80, nt - 1), 1].astype(np.int32),
+                     mel=rs.rand(T, 80).astype(np.float32), linear=rs.rand(T, 1025).astype(np.float32))
+        dirs.append(str(d))
+    hp = taco_amd.hparams.copy(min_iters=3, max_iters=9, min_tokens=5, reduction_factor=4, initial_phase_step=2)
+    lo, hi = F.frame_limits(4, 3, 9)
+    f = F.open_data_dirs(dirs, batch_size=3, hparams=hp, data_type="train", batches_per_group=2, seed=7)
+    for d, src in f.sources.items():          # the filter kept what get_path_dict keeps, minus the test split
+        for p in src.paths:
+            z = np.load(p)
+            assert lo <= z["linear"].shape[0] <= hi and len(z["tokens"]) >= 5
+    seen = 0
+    for _ in range(6):
+        b = next(f)
+        assert b.inputs.shape[0] == 3 and b.mel_targets.shape[1] % 4 == 0 and b.mel_targets.shape[1] > int(max(b.input_lengths) * 0)
+        assert b.mel_targets.shape[2] == 80 and b.linear_targets.shape[2] == 1025 and set(b.speaker_id.tolist()) <= {0, 1}
+        assert np.array_equal(b.input_lengths, (b.inputs != 0).sum(1))          # lengths include the EOS (datafeeder.py:294)
+        assert np.all(b.loss_coeff == 1.0)
+        seen += 1
+    assert f.step == 6 and seen == 6
+    t = F.open_data_dirs(dirs, batch_size=3, hparams=hp, data_type="test", batches_per_group=1, seed=7)
+    assert all(len(s.paths) == 3 for s in t.sources.values())                   # the last batch_size paths of every directory

@@ -111,11 +111,13 @@ def test_group_logic_equals_enqueue_next_group(fv):
     product's GroupFeeder must hand out the same batches in the same order from the same streams and generator seed."""
     for gi, row in enumerate(fv["groups"].tolist()):
         bs, bpg, r, ndirs, step, phase, seed = row[:7]
-        ratios = [x / 1000.0 for x in row[7:7 + ndirs]]
-        dirs = ["a", "b"][:ndirs]
+        ratios = [x / 1000.0 for x in row[7:7 + ndirs]]             # the CONFIGURED data_ratio; which phase applies is the feeder's business
+        greedy = bool(row[9])
+        dirs = [str(d) for d in fv["group%d_dirs" % gi]]
         streams = {d: iter(_examples(fv, "group%d_%s" % (gi, d), int(fv["group%d_%s_count" % (gi, d)]), ndirs > 1)) for d in dirs}
         feeder = F.GroupFeeder({d: (lambda d=d: next(streams[d])) for d in dirs}, bs, r, batches_per_group=bpg,
-                               ratios=dict(zip(dirs, ratios)), seed=seed, training=True)
+                               ratios=dict(zip(dirs, ratios)), seed=seed, training=True, initial_phase_step=phase,
+                               initial_data_greedy=greedy, step=step)
         for bi in range(int(fv["group%d_nbatches" % gi])):
             _same(next(feeder), fv, "group%d_batch%d_" % (gi, bi), ndirs > 1)
         for d in dirs:                            # and it drew exactly the examples the reference drew
@@ -243,3 +245,45 @@ def test_most_recent_checkpoint_choice_equals_the_reference(tmp_path):
             (d / fn).write_bytes(b"")
         got = get_most_recent_checkpoint(str(d), checkpoint_step=c["checkpoint_step"])
         assert os.path.basename(got) == c["chosen"] + ".index", (c, got)
+
+
+def test_npz_source_draws_the_files_the_reference_feeder_draws(tmp_path, fv):
+    """DataFeeder._get_next_example (datafeeder.py:245-287) was driven over real .npz files (cursor starting at the third path, wrap and
+    reshuffle with the feeder's generator, missing paths, the inline frame / token filter under skip_path_filter, the loss_coeff default):
+    NpzSource over the same files, the same path list and the same generator seed returns the same examples in the same order."""
+    nfiles = int(fv["npz_nfiles"])
+    lo, hi, mt = (int(x) for x in fv["npz_limits"])
+    for ci, row in enumerate(fv["npz_cases"]):
+        dtype, skip, seed, ndraw = int(row[0]), bool(row[1]), int(row[2]), int(row[3])
+        missing = [int(x) for x in row[4:] if x >= 0]
+        d = tmp_path / ("case%d" % ci)
+        d.mkdir()
+        paths = []
+        for i in range(nfiles):
+            p = str(d / ("ex%d.npz" % i))
+            if i not in missing:
+                content = {k: fv["npz_file%d_%s" % (i, k)] for k in ("tokens", "mel", "linear")}
+                if "npz_file%d_loss_coeff" % i in fv:
+                    content["loss_coeff"] = fv["npz_file%d_loss_coeff" % i]
+                np.savez(p, **content)
+            paths.append(p)
+        src = F.NpzSource(paths, speaker_id=3, rng=np.random.RandomState(seed), training=dtype == 1, skip_path_filter=skip,
+                          min_n_frame=lo, max_n_frame=hi, min_tokens=mt)
+        want = fv["npz_case%d_draws" % ci]
+        assert len(want) == ndraw
+        for k in range(ndraw):
+            ex = src()
+            got = [int(ex.tokens[0]) - 100, int(round(float(ex.loss_coeff) * 1000)), len(ex.linear), len(ex.mel)]
+            assert got == [int(x) for x in want[k]], (ci, k, got, want[k])
+            assert ex.speaker_id == 3
+        assert not src.skipped
+    # the bookkeeping around it (get_path_dict :41-48,66-71; __init__ :104-121)
+    assert F.frame_limits(4, 30, 200) == (120, 796)
+    items = [("a", 119, 60), ("b", 120, 50), ("c", 796, 49), ("d", 797, 80), ("e", 500, 50)]
+    assert F.filter_items(items, 120, 796, 50) == ["b", "e"]
+    assert F.split_paths(list("abcdef"), "train", 2) == list("abcd") and F.split_paths(list("abcdef"), "test", 2) == list("ef")
+    with pytest.raises(Exception, match="Unkown data_type"):
+        F.split_paths([], "valid", 1)
+    assert F.data_ratios(["x/son", "x/park"]) == {"x/son": 0.5, "x/park": 0.5}
+    r = F.data_ratios(["x/son", "x/park", "x/moon"], main_data=["son"], main_data_greedy_factor=2)
+    assert r == {"x/son": 0.6, "x/park": 0.2, "x/moon": 0.2}

@@ -24,6 +24,7 @@ this image lacks (`jamo`, `tensorflow`, `nltk`, the reference's own `audio` / `u
 librosa).  Those names are satisfied by EMPTY stand-in modules whose functions raise if called (`log` is a no-op): no stand-in takes
 part in computing a vector -- any stage that would need one (jamo decomposition, nltk sentence splitting inside quotations) is left
 out, and the vectors say so.  tests/test_reference_vectors.py replays the files bit-exactly through korean.py / feeder.py."""
+import collections
 import importlib
 import importlib.util
 import json
@@ -481,8 +482,10 @@ def feeder_vectors(F):
             self.feeds.append(feed_dict)
 
     groups = []
-    for gi, (bs, bpg, r, dirs, data_type, step, phase) in enumerate([(4, 3, 4, ["a"], "train", 0, 100), (3, 4, 5, ["a", "b"], "train", 0, 100),
-                                                                     (4, 2, 4, ["a", "b"], "train", 500, 100)]):
+    for gi, (bs, bpg, r, dirs, data_type, step, phase, greedy) in enumerate([(4, 3, 4, ["a"], "train", 0, 100, False), (3, 4, 5, ["a", "b"], "train", 0, 100, False),
+                                                                             (4, 2, 4, ["a", "b"], "train", 500, 100, False),
+                                                                             (4, 2, 4, ["a", "b"], "train", 0, 2, False),         # the phase ends between the two groups
+                                                                             (2, 3, 4, ["a", "krbook_b"], "train", 0, 100, True)]):   # initial_data_greedy: all from "krbook"
         srs = {d: np.random.RandomState(900 + 10 * gi + k) for k, d in enumerate(dirs)}
         drawn = {d: [] for d in dirs}
 
@@ -490,7 +493,7 @@ def feeder_vectors(F):
             ex = make_example(srs[data_dir], 2, 3, len(dirs) > 1, 3, 30)
             drawn[data_dir].append(ex)
             return ex
-        hp = types.SimpleNamespace(reduction_factor=r, initial_data_greedy=False, initial_phase_step=phase)
+        hp = types.SimpleNamespace(reduction_factor=r, initial_data_greedy=greedy, initial_phase_step=phase)
         ratio = {d: w for d, w in zip(dirs, [0.75, 0.25] if len(dirs) == 2 else [1.0])}
         names = ["inputs", "input_lengths", "loss_coeff", "mel_targets", "linear_targets"] + (["speaker_id"] if len(dirs) > 1 else [])
         me = types.SimpleNamespace(batch_size=bs, _hp=hp, static_batches=None, data_dirs=dirs, _step=step, _batches_per_group=bpg,
@@ -511,9 +514,55 @@ def feeder_vectors(F):
             for name in names:
                 out["group%d_batch%d_%s" % (gi, bi, name)] = np.asarray(fd[name])
         out["group%d_nbatches" % gi] = np.int64(len(me._session.feeds))
-        ratios_used = [1.0 / len(dirs)] * len(dirs) if step < phase else [ratio[d] for d in dirs]
-        groups.append([bs, bpg, r, len(dirs), step, phase, 321 + gi] + [int(round(x * 1000)) for x in ratios_used] + [0] * (2 - len(dirs)))
+        groups.append([bs, bpg, r, len(dirs), step, phase, 321 + gi] + [int(round(ratio[d] * 1000)) for d in dirs] + [0] * (2 - len(dirs)) + [int(greedy)])
+        out["group%d_dirs" % gi] = np.array(dirs)
     out["groups"] = np.array(groups, np.int64)
+    return out
+
+
+def npz_source_vectors(F):
+    """DataFeeder._get_next_example (datafeeder.py:245-287) driven on a plain namespace over real .npz files in a temporary directory:
+    which file each draw returns (cursor starting at 2, wrap + reshuffle with the feeder's generator, missing paths skipped, the inline
+    filter under skip_path_filter), the loss_coeff default, the tuple layout.  The files' contents are stored so that the test can
+    rebuild the directory."""
+    import tempfile
+    out = {}
+    rs = np.random.RandomState(777)
+    files = []
+    for i in range(9):
+        n_tok, T = int(rs.randint(3, 12)), int(rs.randint(4, 30))
+        tokens = rs.randint(2, 80, size=n_tok).astype(np.int32)
+        tokens[0] = 100 + i                      # marks the file in what a draw returns
+        d = {"tokens": tokens, "mel": rs.rand(T, 2).astype(np.float32), "linear": rs.rand(T, 3).astype(np.float32)}
+        if i % 3 == 1:
+            d["loss_coeff"] = np.float32(0.5)
+        files.append(d)
+    for i, d in enumerate(files):
+        for k, v in d.items():
+            out["npz_file%d_%s" % (i, k)] = v
+    out["npz_nfiles"] = np.int64(len(files))
+    cases = []
+    for ci, (data_type, skip_filter, seed, ndraw, missing) in enumerate([("train", False, 5, 25, [4]), ("test", False, 6, 14, []),
+                                                                          ("train", True, 7, 30, [0, 7])]):
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for i, d in enumerate(files):
+                pth = os.path.join(td, "ex%d.npz" % i)
+                if i not in missing:
+                    np.savez(pth, **d)
+                paths.append(pth)
+            me = types.SimpleNamespace(path_dict={"dirA": list(paths)}, _offset=collections.defaultdict(lambda: 2), data_type=data_type,
+                                       rng=np.random.RandomState(seed), skip_path_filter=skip_filter, min_n_frame=8, max_n_frame=24, min_tokens=5,
+                                       data_dir_to_id={"dirA": 3})
+            seq = []
+            for _ in range(ndraw):
+                tokens, coeff, mel, lin, did, n = F.DataFeeder._get_next_example(me, "dirA")
+                assert did == 3 and n == len(lin)
+                seq.append([int(tokens[0]) - 100, int(round(float(coeff) * 1000)), int(n), int(mel.shape[0])])
+            out["npz_case%d_draws" % ci] = np.array(seq, np.int64)
+        cases.append([{"train": 1, "test": 2}[data_type], int(skip_filter), seed, ndraw] + missing + [-1] * (2 - len(missing)))
+    out["npz_cases"] = np.array(cases, np.int64)
+    out["npz_limits"] = np.array([8, 24, 5], np.int64)
     return out
 
 
@@ -527,6 +576,7 @@ def main():
         json.dump(kv, f, ensure_ascii=False, indent=0, sort_keys=True)
     F = load_reference_datafeeder()
     fv = feeder_vectors(F)
+    fv.update(npz_source_vectors(F))
     np.savez_compressed(os.path.join(GOLD, "feeder_vectors.npz"), **fv)
     A, ahp = load_reference_audio()
     av = audio_vectors(A, ahp)
