@@ -138,3 +138,19 @@ def test_braced_spans_contribute_nothing_and_pieces_are_cleaned_separately():
     seen = []
     T.text_to_sequence("가{X}나{Y}다", normalizer=lambda s: (seen.append(s), s)[1])
     assert seen == ["가", "나", "다"]
+
+
+def test_hangul_decomposition_is_the_unicode_one_for_every_syllable():
+    """The `jamo` package the reference imports (text/korean.py:5, absent here) decomposes precomposed syllables by the Unicode
+    algorithm; Python's own unicodedata implements the same algorithm as canonical decomposition (NFD) / composition (NFC): all
+    11 172 syllables, both directions, against text.py's arithmetic."""
+    import unicodedata
+    from taco_amd import text as T
+    syll = "".join(chr(c) for c in range(0xAC00, 0xD7A4))
+    assert len(syll) == 11172
+    assert T.hangul_to_jamo(syll) == unicodedata.normalize("NFD", syll)
+    assert T.jamo_to_korean(unicodedata.normalize("NFD", syll)) == syll == unicodedata.normalize("NFC", T.hangul_to_jamo(syll))
+    mixed = "가나 ABC 12, 힣!"
+    assert T.hangul_to_jamo(mixed) == unicodedata.normalize("NFD", mixed)
+    # every jamo a syllable can produce has a symbol: 19 + 21 + 27 of the 80
+    assert set(T.hangul_to_jamo(syll)) == set(T.JAMO_LEADS + T.JAMO_VOWELS + T.JAMO_TAILS)
