@@ -207,3 +207,50 @@ def test_open_data_dirs_feeds_batches_from_npz_directories(tmp_path):
     assert f.step == 6 and seen == 6
     t = F.open_data_dirs(dirs, batch_size=3, hparams=hp, data_type="test", batches_per_group=1, seed=7)
     assert all(len(s.paths) == 3 for s in t.sources.values())                   # the last batch_size paths of every directory
+
+
+def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
+    """Every function of include/taco_abi.h: the ctypes mirror (_lib.PROTOTYPES) has the same number of arguments and the same class of
+    type (pointer / int / float / 64-bit unsigned / 64-bit signed) in every position, and the same class of return type -- so the
+    Python host cannot drift from the C ABI silently (a wrong arity or width is undefined behaviour, not an exception)."""
+    import ctypes as C
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "taco_abi.h")).read(), flags=re.S)
+    header = re.sub(r"//[^\n]*", "", header)
+    decls = re.findall(r"(?:^|[;}\n])\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(taco_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
+    assert len(decls) >= 50
+
+    def klass_c(t):
+        t = " ".join(t.replace("const", " ").split())
+        if "*" in t or t.endswith("_fn"):
+            return "ptr"
+        t = t.strip()
+        return {"int": "int", "int32_t": "int", "float": "float", "size_t": "u64", "long long": "i64", "unsigned long long": "u64",
+                "void": "void", "double": "double"}[t]
+
+    def klass_py(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, (C._Pointer, C._CFuncPtr))):
+            return "ptr"
+        return {C.c_int: "int", C.c_int32: "int", C.c_float: "float", C.c_size_t: "u64", C.c_longlong: "i64", C.c_ulonglong: "u64",
+                C.c_double: "double"}[t]              # (on LP64 ctypes aliases c_size_t / c_ulonglong to c_ulong and c_longlong to c_long)
+
+    seen = set()
+    for ret, name, args in decls:
+        if name.endswith("_fn"):
+            continue
+        seen.add(name)
+        params = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        ctypes_ = []
+        for p in params:
+            p = re.sub(r"\[[^\]]*\]", "*", p)                    # array parameters decay to pointers
+            words = p.replace("*", " * ").split()
+            typ = " ".join(words[:-1]) if (len(words) > 1 and words[-1] != "*" and re.match(r"^[A-Za-z_]\w*$", words[-1])
+                                           and " ".join(words[:-1]).replace("const", "").strip()) else " ".join(words)
+            ctypes_.append(klass_c(typ))
+        restype, argtypes = _lib.PROTOTYPES[name]
+        assert len(argtypes) == len(ctypes_), (name, len(argtypes), len(ctypes_), params)
+        for i, (a, b) in enumerate(zip(argtypes, ctypes_)):
+            assert klass_py(a) == b, (name, i, params[i], a)
+        assert klass_py(restype) == klass_c(ret), (name, ret, restype)
+    assert seen == set(_lib.PROTOTYPES), sorted(seen ^ set(_lib.PROTOTYPES))
