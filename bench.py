@@ -123,7 +123,6 @@ def feedforward_flops(hp, B, T_in, n):
 def feedforward_flops_by_stage(hp, B, T_in, n):
     """feedforward_flops split into the encoder side (prenet, encoder CBHG without its scan, attention memory layer) and the
     post-net side (post CBHG without its scan, linear head); the decoder loop has no feed-forward GEMM."""
-    import copy
     r = hp.reduction_factor
     post_rows = B * n * r
     K, C, pw, rnn = hp.post_bank_size, hp.post_bank_channel_size, hp.post_proj_width, hp.post_rnn_size

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .hparams import hparams as default_hparams, PAD_ID, EOS_ID
+from .hparams import hparams as default_hparams, EOS_ID
 from .weights import random_weights
 
 
