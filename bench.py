@@ -384,16 +384,18 @@ def main():
                 stage_ms[name] = s0.elapsed_time(s1) / 3
             # the feed-forward part of the two CBHG stages alone (the recurrent scan launches skipped: outputs meaningless, timing only)
             model._lib.taco_debug_set_skip_scans(model._handle, 1)
-            for name, fn in (("encoder", lambda: model.encoder(p0.inputs, p0.lengths, spk0)), ("postnet", lambda: model.postnet(mel0, speaker_id=spk0))):
-                fn()
-                s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                s0.record()
-                for _ in range(3):
+            try:
+                for name, fn in (("encoder", lambda: model.encoder(p0.inputs, p0.lengths, spk0)), ("postnet", lambda: model.postnet(mel0, speaker_id=spk0))):
                     fn()
-                s1.record()
-                torch.cuda.synchronize()
-                stage_ms[name + "_ff"] = s0.elapsed_time(s1) / 3
-            model._lib.taco_debug_set_skip_scans(model._handle, 0)
+                    s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s0.record()
+                    for _ in range(3):
+                        fn()
+                    s1.record()
+                    torch.cuda.synchronize()
+                    stage_ms[name + "_ff"] = s0.elapsed_time(s1) / 3
+            finally:            # an exception above must not leave the model with its scans skipped for the companions
+                model._lib.taco_debug_set_skip_scans(model._handle, 0)
         model.check_device_errors()
     finite = all(bool(torch.isfinite(p.mel).all().item() and torch.isfinite(p.linear).all().item()) for p in pool.plans)
 

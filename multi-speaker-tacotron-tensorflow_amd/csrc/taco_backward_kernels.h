@@ -304,10 +304,11 @@ __device__ __forceinline__ void wgrad_bf3_body(const WgArgs& g, int bx, int by, 
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float av[2][8], bv[2][8];
   auto fetch = [&](int mb) {          // this lane's eight rows mb + 8h .. mb + 8h + 7 of both tile pairs
-    // interior block (wave-uniform test on the scalar unit): all 16 rows exist, lie in one batch row and stay inside it after the tap
-    // shift -> sixteen unconditional loads per operand from 32-bit offsets
+    // interior block (wave-uniform test on the scalar unit): all 16 rows exist, lie in ONE batch row before the tap shift (tb + 15 < T:
+    // with a negative shift a block that straddles two batch rows would otherwise pass and read the previous row's tail where the
+    // padding's zeros belong) and stay inside it after the shift -> sixteen unconditional loads per operand from 32-bit offsets
     const int tb = (g.T > 0) ? (mb % g.T) : 0;
-    const bool inner = full && (mb + 16 <= m1) && (g.T <= 0 || (tb + shift >= 0 && tb + 15 + shift < g.T));
+    const bool inner = full && (mb + 16 <= m1) && (g.T <= 0 || (tb + 15 < g.T && tb + shift >= 0 && tb + 15 + shift < g.T));
     if (inner) {
       const unsigned xo = (unsigned)(mb + 8 * h + shift) * (unsigned)g.ldx + (unsigned)(kb + i);
       const unsigned yo = (unsigned)(mb + 8 * h) * (unsigned)g.ldy + (unsigned)(nb + i);

@@ -40,6 +40,7 @@ struct taco_train {
   size_t NP = 0, arena_n = 0;
   float* d_map = nullptr;              // index map of the arena
   size_t n_bf3 = 0; int n_bf3_segs = 0; bool want_bf3_planes = false; bool bf3_current = false;   // planes regenerated from the current parameters by the last refresh?
+  int wgrad_bf3 = 1, dgrad_bf3 = 0, dgrad_exact = 0;   // engine switches of THIS trainer (taco_train_set_exact_wgrad / _gemm); a step installs them in the thread-local g_* the helpers read
   unsigned* d_bf3_idx = nullptr; Bf3Seg* d_bf3_segs = nullptr;   // index list and segment table of the split-bf16 packs (k_bf3_gather)
   float* d_fold = nullptr;             // [Z + 1, 3H] concat projection folded into decoder GRU 1 (k_dx_fold), the index map's second source
   // synchronised BatchNorm over the data-parallel group: the host sums a device vector in place over all ranks
@@ -233,7 +234,7 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
 }
 // 1 (default): weight gradients on the bf16 matrix cores with operands split three ways and six products per tile (k_wgrad_bf3:
 // fp32-grade); 0: exact-fp32 MFMA (k_wgrad).  taco_train_set_exact_wgrad.
-static int g_wgrad_bf3 = 1;
+static thread_local int g_wgrad_bf3 = 1;     // installed from the trainer for the duration of a step (EngineGuard)
 static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
                      int M, int T, int K, int N, int kw = 1, int padl = 0, const int* ygather = nullptr) {
   WgArgs g; g.ygather = ygather; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
@@ -273,8 +274,8 @@ static void run_embed_bwd(hipStream_t st, const float* dx, const int* ids, float
   if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * E), 0, st, dx, ids, dE, M, E, V);
   else hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)M * E), 0, st, dx, ids, dE, M, E);
 }
-static int g_dgrad_bf3 = 0;       // taco_train_set_exact_gemm(t, 3): forward GEMMs exact fp32, data gradients split-bf16
-static int g_dgrad_exact = 0;     // taco_train_set_exact_gemm(t, 2): data gradients on the exact-fp32 MFMA, forward GEMMs split-bf16 (A/B hook)
+static thread_local int g_dgrad_bf3 = 0;       // taco_train_set_exact_gemm(t, 3): forward GEMMs exact fp32, data gradients split-bf16
+static thread_local int g_dgrad_exact = 0;     // taco_train_set_exact_gemm(t, 2): data gradients on the exact-fp32 MFMA, forward GEMMs split-bf16 (A/B hook)
 // y = x . W^T style data gradient through k_gemm: out = conv_T(dy) (+ res)
 static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const float* dy, int lddy, int M, int T, float* out, int ldo,
                      const float* res = nullptr, int ldres = 0) {
@@ -971,6 +972,11 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   const int n = T_out / r;
   if (n > hp.max_iters) return fail(TACO_ERR_SHAPE, "T_out/r = %d exceeds max_iters %d", n, hp.max_iters);
   TRY(check_common(m, B, T_in));
+  struct EngineGuard {  // the GEMM helpers see this trainer's engine switches for the duration of this step only
+    int w, d, e;
+    EngineGuard(const taco_train* t) : w(g_wgrad_bf3), d(g_dgrad_bf3), e(g_dgrad_exact) { g_wgrad_bf3 = t->wgrad_bf3; g_dgrad_bf3 = t->dgrad_bf3; g_dgrad_exact = t->dgrad_exact; }
+    ~EngineGuard() { g_wgrad_bf3 = w; g_dgrad_bf3 = d; g_dgrad_exact = e; }
+  } engine_guard(t);
   if ((m->bf3 || g_dgrad_bf3) && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
   Carver cv(ws, ws_bytes);
   TrainWs w; carve_train(cv, t, B, T_in, n, w);

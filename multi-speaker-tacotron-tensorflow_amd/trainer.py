@@ -98,17 +98,16 @@ class Trainer(object):
             except Exception as e:     # an exception must not unwind through the C frames: it is re-raised after the call returns
                 self._sync_err = e
         self._sync_cb = _lib.SYNC_SUM_FN(_sum)
-        self._sync_group, self._sync_shapes = group, set()
+        self._sync_group = group
         _lib.check(self._lib.taco_train_set_sync_bn(self._h, C.cast(self._sync_cb, C.c_void_p), None, world))
         return True
 
     def _check_sync_shapes(self, B, T_in, T_out):
         """The merge of the per-rank statistics (k_bn_sync_combine) weights every rank equally: it is exact only when every rank
-        normalises the same number of rows.  Checked once per shape with one 4-element MAX all-reduce; unequal shards raise instead
-        of silently producing wrong global statistics."""
-        key = (B, T_in, T_out)
-        if key in self._sync_shapes:
-            return
+        normalises the same number of rows.  Checked on EVERY step with one 4-element MAX all-reduce (a per-rank cache of verified
+        shapes would let one rank skip the collective while its peer issues it -- exactly when the shapes differ -- and pair the
+        peer's shape exchange with this rank's first SyncBN exchange); unequal shards raise on every rank instead of silently
+        producing wrong global statistics."""
         import torch.distributed as dist
         v = torch.tensor([B * T_in, B * T_out, -B * T_in, -B * T_out], dtype=torch.int64, device=self.device)
         dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self._sync_group)
@@ -116,7 +115,6 @@ class Trainer(object):
         if hi_in != -lo_in or hi_out != -lo_out:
             raise _lib.TacoError(_lib.TACO_ERR_SHAPE, "SyncBN needs the same number of rows on every rank: this rank has B*T_in = %d, "
                                  "B*T_out = %d, the group spans %d..%d and %d..%d" % (B * T_in, B * T_out, -lo_in, hi_in, -lo_out, hi_out))
-        self._sync_shapes.add(key)
 
     def set_deterministic(self, on=True):
         """Run-to-run reproducible steps (the reference's single-device step is): every row sum that normally leaves its workgroup

@@ -116,7 +116,7 @@ def main():
                          "gradient_allreduce": allreduce_ms if world > 1 else 0.0},
             "per_rank_ms_per_step": per_rank,
             "engine": {"decoder_loop_and_postnet_scans": "persistent whole-chip kernels with tape (protocol %d)" % engine["protocol"] if args.engine and engine["protocol"] else "one launch per stage",
-                       "decoder_bptt": "one persistent whole-chip launch (k_decoder_bwd_xcd)" if args.engine and args.bptt and engine["protocol"] else "one launch per stage",
+                       "decoder_bptt": "one persistent whole-chip launch (k_decoder_bwd_xcd)" if engine.get("bptt_protocol", 0) else "one launch per stage (per-stage chain)",
                        "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact"}[args.exact_gemm],
                        "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
