@@ -6,6 +6,7 @@
 #include "taco_decoder_xcd.h"
 #include "taco_bigru_xcd.h"
 #include "taco_chain.h"
+#include "taco_front.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
 #include "taco_decoder_bwd_xcd.h"
@@ -105,6 +106,9 @@ struct Cbhg {
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
   size_t gd_pack = 0, gb_pack = 0;                     // k_bigru_duo / k_bigru_duo_bwd: [2 dirs][32 members][12][512]
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
+  // fused front (taco_front.h): per bank width (same order as `bank`) the produce pack [k32 step][16-channel tile][lane][8] (hi, lo)
+  // and its step count; front_kind 0 = not built, 1 = <TN 2, XS 80, CINP 80, KWMAX 8> (post-net), 2 = <TN 1, XS 144, CINP 128, KWMAX 16> (encoder)
+  std::vector<size_t> fr_wh, fr_wl; std::vector<int> fr_ns; int front_kind = 0;
   size_t res_g2p[2] = {0, 0}, res_c1p[2] = {0, 0}; // the same and the candidate h-rows with the columns in k_bigru_resw's thread order
                                                    // (column jb*4 + u = unit jb + 64*u): a thread's four units are 32 / 16 contiguous bytes
 };
@@ -144,6 +148,7 @@ struct taco_model {
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
+  int front = 1;               // conv bank -> max-pool -> proj_1 of a CBHG as one launch (taco_front.h); 0: bank and proj_1 as two k_gemm_bf3 launches
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
   // persistent XCD-local decoder (taco_decoder_xcd.h): per-thread weight pack and the bias vectors its epilogues read
@@ -647,6 +652,39 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
   if (bf3) pack_bf3(m, Wx.data(), 1, I, 6 * H, &X.bh, &X.bl, &X.K16, &X.cin_pad16);
   X.bias = arena_put(m, bx.data(), 6 * H);
   c.xproj = X;
+  // fused front (taco_front.h): inference models only (the training forward needs the bank tensor for its batch statistics)
+  c.front_kind = 0;
+  if (bf3 && !m->tp && maxpool == 2 && pw == 3 && nproj >= 1 && C % FR_CH == 0 && K * (C / FR_CH) <= FR_MAXCH && K <= FR_MAXW) {
+    const int cinp = rup(in_dim, 16), N1 = projs[0];
+    if (cinp == 80 && K <= 8 && N1 <= 256) c.front_kind = 1;
+    else if (cinp == 128 && K <= 16 && N1 <= 128) c.front_kind = 2;
+    if (c.front_kind) {
+      for (const ConvL& L : c.bank) {
+        const HostTensor& kt = T_(m, sc + "/conv_bank/conv1d_" + std::to_string(L.kw) + "/kernel");
+        const int ns = rup(cdiv(L.kw * cinp, 32), 2), nct = C / 16;     // even: the kernel walks the steps in pairs (a padding step has zero weights)
+        std::vector<unsigned short> hi((size_t)ns * nct * 512, 0), lo(hi.size(), 0);
+        for (int st = 0; st < ns; ++st)
+          for (int ct = 0; ct < nct; ++ct)
+            for (int q = 0; q < 4; ++q)
+              for (int i = 0; i < 16; ++i)
+                for (int e = 0; e < 8; ++e) {
+                  const int kk = 32 * st + 8 * q + e, tap = kk / cinp, cc = kk % cinp;
+                  if (tap >= L.kw || cc >= in_dim) continue;
+                  const float w = kt.data[((size_t)tap * in_dim + cc) * C + 16 * ct + i];
+                  const unsigned short hb = bf16_rne_host(w);
+                  unsigned hu = (unsigned)hb << 16; float hf; memcpy(&hf, &hu, 4);
+                  const size_t o = (((size_t)st * nct + ct) * 64 + q * 16 + i) * 8 + e;
+                  hi[o] = hb; lo[o] = bf16_rne_host(w - hf);
+                }
+        auto put = [&](const std::vector<unsigned short>& v) {
+          std::vector<float> f((v.size() + 1) / 2, 0.f);
+          memcpy(f.data(), v.data(), v.size() * sizeof(unsigned short));
+          return arena_put(m, f.data(), f.size());
+        };
+        c.fr_wh.push_back(put(hi)); c.fr_wl.push_back(put(lo)); c.fr_ns.push_back(ns);
+      }
+    }
+  }
 }
 
 static int add_var(taco_model* m, ConvL& L, int coff) {
@@ -1084,6 +1122,71 @@ static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const f
   return 0;
 }
 
+// ---- conv bank -> max-pool -> proj_1 as one launch (taco_front.h) ----
+static bool front_usable(const taco_model* m, const Cbhg& c) {
+  return m->bf3 && m->front && m->force_cfg < 0 && !m->bf3_tn && c.front_kind != 0 && !c.proj.empty() && c.proj[0].bh &&
+         c.proj[0].cin == c.K * c.C && c.proj[0].cin_pad16 == c.K * c.C;
+}
+static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T, const CbhgWs& w) {
+  FrArgs a; memset(&a, 0, sizeof a);
+  const int TN = c.front_kind == 1 ? 2 : 1, cinp = c.front_kind == 1 ? 80 : 128, kwmax = c.front_kind == 1 ? 8 : 16;
+  const ConvL& P1 = c.proj[0];
+  const GemmVar& pv = m->hvars[P1.var_index];
+  a.x = x; a.ldx = c.in_dim; a.B = B; a.T = T; a.Cin = c.in_dim; a.tiles_per_b = cdiv(T, FR_BM);
+  a.ph = pv.bh; a.pl = pv.bl; a.pNT = pv.NT; a.pK16tap = P1.cin_pad16 / 16;
+  a.part = w.bank; a.N1 = P1.N;
+  const int cpw = c.C / FR_CH, nchunks = c.K * cpw, padlmax = (kwmax - 1) / 2;
+  for (int i = 0; i < c.K; ++i) {
+    const ConvL& L = c.bank[i];
+    FrWidth& fw = a.w[i];
+    fw.wh = (const unsigned short*)AP(m, c.fr_wh[i]); fw.wl = (const unsigned short*)AP(m, c.fr_wl[i]);
+    fw.bias = AP(m, L.bias); fw.scale = AP(m, L.bns); fw.shift = AP(m, L.bnb);
+    fw.kw = L.kw; fw.xoff = padlmax - (L.kw - 1) / 2; fw.ns = c.fr_ns[i]; fw.nct = c.C / 16;
+  }
+  // parts: as many as fill the chip (the makespan is rounds of workgroups x the work of one part), at most what the partial-sum
+  // slabs (kept in the bank buffer) and the chunk count allow; chunks go to the least loaded part, heaviest first
+  const int ntiles = B * a.tiles_per_b, ncu = m->cu_count > 0 ? m->cu_count : 256;
+  const int pmax = std::max(1, std::min(std::min(nchunks, FR_MAXP), (c.K * c.C) / P1.N));
+  int P = 1; double best = 1e30;
+  for (int p = 1; p <= pmax; ++p) {
+    const double cost = (double)cdiv(ntiles * p, ncu) * ((double)cdiv(nchunks, p) / nchunks + 0.03);
+    if (cost < best - 1e-9) { best = cost; P = p; }
+  }
+  a.P = P;
+  { std::vector<std::pair<long, int>> order;        // (cost, chunk id = width index * cpw + sub-chunk)
+    for (int i = 0; i < c.K; ++i)
+      for (int j = 0; j < cpw; ++j) order.push_back({432L * c.fr_ns[i] + 4608L * TN, i * cpw + j});
+    std::stable_sort(order.begin(), order.end(), [](const std::pair<long, int>& u, const std::pair<long, int>& v) { return u.first > v.first; });
+    std::vector<long> load(P, 0); std::vector<std::vector<int>> mine(P);
+    for (auto& o : order) {
+      int tgt = 0;
+      for (int p = 1; p < P; ++p) if (load[p] < load[tgt]) tgt = p;
+      load[tgt] += o.first; mine[tgt].push_back(o.second);
+    }
+    int n = 0;
+    for (int p = 0; p < P; ++p) {
+      a.pstart[p] = n;
+      std::sort(mine[p].begin(), mine[p].end());
+      for (int id : mine[p]) {
+        const int i = id / cpw, j = id % cpw;
+        a.ch[n].wi = i; a.ch[n].ct0 = j * (FR_CH / 16); a.ch[n].cg0 = (c.bank[i].kw - 1) * c.C + j * FR_CH; ++n;
+      }
+    }
+    a.pstart[P] = n; }
+  const int xs = c.front_kind == 1 ? 80 : 144, xrows = c.front_kind == 1 ? 16 * FR_NRT + kwmax : FR_PR + kwmax;
+  (void)cinp;
+  const size_t lds = std::max((size_t)2 * xrows * xs * 2 + (size_t)2 * FR_PR * FR_ALD * 2, (size_t)4 * 4 * TN * 16 * 64 * sizeof(float));
+  const dim3 grid(ntiles * P), blk(512);
+  if (c.front_kind == 1) hipLaunchKernelGGL((k_cbhg_front<2, 80, 80, 8>), grid, blk, lds, st, a);      // (> 64 KB of LDS: attribute set at finalize)
+  else hipLaunchKernelGGL((k_cbhg_front<1, 144, 128, 16>), grid, blk, lds, st, a);
+  HIPCHK(hipGetLastError());
+  const size_t MN = (size_t)B * T * P1.N;
+  hipLaunchKernelGGL(k_front_combine, dim3((unsigned)cdiv((int)(MN / 4), 256)), dim3(256), 0, st, (const float*)w.bank, P, MN, P1.N,
+                     AP(m, P1.bias), AP(m, P1.bns), AP(m, P1.bnb), c.proj.size() > 1 ? 1 : 0, w.p[0]);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Feed-forward part of a CBHG (modules.py:27-77) with per-stage watermarks, so it can run chunk by chunk
 // behind a producer of its input frames (the decoder): every stage is advanced as far as the frames
 // available to it allow (a conv needs its right halo; the last chunk gets TF's zero padding).
@@ -1094,6 +1197,11 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
   const int M = B * T;
   auto right = [](int k) { return k - 1 - (k - 1) / 2; };
   auto advance = [&](int win, int reach) { return win >= T ? T : std::max(0, win - reach); };
+  // the whole window at once: bank -> max-pool -> proj_1 as ONE launch, the bank tensor never leaves the CU (taco_front.h)
+  if (avail >= T && pg.w_bank == 0 && pg.w_p[0] == 0 && front_usable(m, c)) {
+    TRY(run_front(m, st, c, x, B, T, w));
+    pg.w_bank = T; pg.w_p[0] = T;
+  }
   // conv bank: all K widths in one launch, written channel-concatenated (modules.py:35-44)
   { const int nw = advance(avail, right(c.K));
     if (nw > pg.w_bank) {
@@ -1850,6 +1958,8 @@ int taco_model_finalize(taco_model* m) {
     v.bh2 = (const unsigned short*)AP(m, (size_t)v.bh2); v.bl2 = (const unsigned short*)AP(m, (size_t)v.bl2);
   }
   // persistent kernels carve up to the full 160 KiB of LDS
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cbhg_front<2, 80, 80, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cbhg_front<1, 144, 128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<256, 64, 24, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<128, 32, 0, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_res<256, 64, 24, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1919,6 +2029,7 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->bf3 = (on & 1) != 0; m->bf3_tn = tile_n;
   m->chain = (on & 4) ? 0 : 1;     // on = 5: split-bf16 GEMMs with one launch per point-wise layer (A/B of taco_chain.h)
+  m->front = (on & 8) ? 0 : 1;     // on = 9: conv bank and proj_1 as two k_gemm_bf3 launches (A/B of taco_front.h)
   return 0;
 }
 

@@ -601,3 +601,48 @@ def test_pointwise_chain_kernel_matches_the_oracle_and_the_per_layer_path(model_
         assert maxabs(post, taps["post"][..., :post.shape[-1]]) < 2e-4 and maxabs(lin, ref["linear"]) < 2e-4, name
     for a, b in zip(got["chain"], got["per-layer"]):
         assert maxabs(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("B,T_in,T_mel,oracle", [(3, 37, 20, True), (2, 130, 280, True), (5, 257, 132, True), (1, 64, 400, True), (9, 128, 129, True),
+                                                 (16, 128, 256, False), (32, 128, 512, False), (43, 100, 384, False), (64, 128, 512, False)])
+def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_mel, oracle):
+    """csrc/taco_front.h: conv bank -> max-pool -> proj_1 of a CBHG as ONE launch (modules.py:35-59; the bank tensor never reaches
+    memory, the contraction of proj_1 is split over parts of the bank's channels and summed in a fixed order).  Reference widths
+    (the kernel exists for the encoder's 16 x 128 over 128 channels and the post-net's 8 x 256 over 80), frame counts below, at and
+    above the 128-frame tile incl. one frame more than a tile, batch sizes that give 1 ... 16 parts, ragged lengths.  Both CBHG
+    stages against the float64 oracle's own stage functions (the large shapes, where NumPy would take minutes, only against the
+    two-launch path: C2 itself is held to the oracle by test_full_size_C2_parity_and_properties), the fused front against bank and
+    proj_1 as two launches, and twice the same call bit for bit (no atomics)."""
+    import torch
+    ohp = O.OracleHParams(max_iters=max(2, T_mel // 4))
+    w = O.init_weights(ohp, 1, 1234)
+    ids, L = O.synthetic_inputs(B, T_in, 77, ragged=True)
+    rs = np.random.RandomState(78)
+    mel = rs.uniform(-0.2, 1.2, (B, T_mel, ohp.num_mels))
+    f64 = lambda a: np.asarray(a, np.float64)
+    if oracle:
+        pre = O.prenet(f64(w["embedding"])[ids], w, "prenet", ohp.enc_prenet_sizes)
+        enc_ref = O.cbhg(pre, L.astype(np.int64), w, "encoder_cbhg", ohp.enc_bank_size, ohp.enc_maxpool_width, ohp.enc_highway_depth, ohp.enc_proj_sizes)
+        post_ref = O.cbhg(f64(mel), None, w, "post_cbhg", ohp.post_bank_size, ohp.post_maxpool_width, ohp.post_highway_depth, ohp.post_proj_sizes)
+        lin_ref = O.dense(post_ref, w, "linear")
+    m = build_model(ohp, w)
+    got = {}
+    for flag, name in ((1, "fused"), (9, "two launches"), (1, "fused again")):      # taco_debug_set_bf3 bit 3: front off
+        m._lib.taco_debug_set_bf3(m._handle, flag, 0)
+        enc = m.encoder(ids, L)
+        lin, post = m.postnet(mel, return_post=True)
+        torch.cuda.synchronize()
+        got[name] = (enc.cpu().numpy(), post.cpu().numpy(), lin.cpu().numpy())
+    m._lib.taco_debug_set_bf3(m._handle, 1, 0)
+    m.check_device_errors()
+    for name, (enc, post, lin) in got.items():
+        if not oracle:
+            break
+        e = (maxabs(enc, enc_ref), maxabs(post, post_ref), maxabs(lin, lin_ref))
+        print("%s: encoder %.2e  post %.2e  linear %.2e" % ((name,) + e))
+        assert e[0] < 1e-4 and e[1] < 2e-4 and e[2] < 2e-4, (name, e)
+    d = [maxabs(a, b) for a, b in zip(got["fused"], got["two launches"])]
+    print("fused vs two launches: encoder %.2e  post %.2e  linear %.2e" % tuple(d))
+    assert max(d) < 3e-5, d
+    for a, b in zip(got["fused"], got["fused again"]):
+        assert np.array_equal(a, b)
