@@ -1,4 +1,4 @@
-"""ctypes binding of libtaco_hip.so (include/taco_abi.h).  There is NO fallback: if the HIP library
+"""ctypes binding of libtaco_hip.so (include/taco_abi.h; the test / timing hooks of include/taco_debug.h).  There is NO fallback: if the HIP library
 is missing or fails to load, importing the compute path raises."""
 import ctypes as C
 import os
@@ -140,6 +140,7 @@ PROTOTYPES = {
     "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
     "taco_debug_set_skip_scans": (_I, [_P, _I]),
+    "taco_debug_set_front": (_I, [_P, _I, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),
     "taco_stop_steps": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -163,7 +164,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("TACO_LIB") or LIB_PATH      # TACO_LIB: an instrumented build (tools/trace_*.py, -DTACO_TRACE)
     if not os.path.exists(p):
         raise ImportError(
             "libtaco_hip.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "

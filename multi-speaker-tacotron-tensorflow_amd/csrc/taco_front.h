@@ -31,6 +31,7 @@
 #define FR_MAXW 16
 #define FR_MAXCH 32
 #define FR_MAXP 16
+#define FR_SMEM_CNT (159 * 1024)   // byte offset of the group-barrier counters in LDS (the kernel always asks for 160 KB)
 
 struct FrWidth {
   const unsigned short* wh; const unsigned short* wl;      // produce pack (pack_front): [k32 step][16-channel tile][lane][8]
@@ -43,14 +44,33 @@ struct FrArgs {
   const unsigned short* ph; const unsigned short* pl;      // proj_1 pack (pack_bf3 layout), NT column tiles, k16 groups per tap
   int pNT, pK16tap;
   float* part; int N1;
+  int prio; int delay;                                               // shader clocks the second K half of every workgroup starts late (0: in phase)
   FrWidth w[FR_MAXW];
   FrChunk ch[FR_MAXCH];
   int pstart[FR_MAXP + 1];
 };
 
+#ifdef TACO_TRACE
+__device__ long long taco_trace_front[64];      // its own slots: the GEMM launches that follow in a stage stamp taco_trace
+#define FTRC(i) do { if (trc) taco_trace_front[i] = clock64(); } while (0)
+#else
+#define FTRC(i) do {} while (0)
+#endif
 // (every pointer these see has been PINned -- address space 1 -- so they compile to global_load, not flat_load)
 __device__ __forceinline__ uint4 fr_ld16(const unsigned short* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ float4 fr_ldf4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// Barrier among the four waves of one K half (one LDS counter per half, never reset: the k-th barrier waits for 4 k arrivals).  The
+// two halves of a workgroup are independent until the final reduction -- produce wave w writes channels 16 w .. 16 w + 15 of the
+// pooled planes and consume waves 4 ks .. 4 ks + 3 read exactly channels 64 ks .. 64 ks + 63 -- and each SIMD hosts one wave of
+// each half, so with the halves half a chunk out of phase the VALU epilogue of one runs under the MFMAs of the other.  A
+// workgroup-wide s_barrier would lock the phases together (measured: 21 % of a chunk with the matrix pipe idle).
+__device__ __forceinline__ void fr_gbar(unsigned* cnt, unsigned target, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // XS = bf16 elements per row of an input plane, CINP = input channels padded to 16.  XS == CINP ("flat", CINP an odd multiple of
 // 16): row r, tap j, channel c is element (r + j) XS + c = r XS + (j CINP + c) -- the (tap, channel) contraction index IS the
@@ -66,8 +86,14 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
   unsigned short* xlo = xhi + XROWS * XS;
   unsigned short* ahi = xlo + XROWS * XS;
   unsigned short* alo = ahi + FR_PR * FR_ALD;
+  unsigned* gcnt = reinterpret_cast<unsigned*>(fr_smem + FR_SMEM_CNT / 2);        // two barrier counters, beyond everything else (fixed offset)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int trci = 3;      // TACO_TRACE slots: 0 entry, 1 staged, from 3 per chunk (produce loop done, other waves done reading, planes written, consume done),
+#ifdef TACO_TRACE    // then K halves met, stored
+  const bool trc = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;
+  FTRC(0);
+#endif
   const int T = a_in.T, P = a_in.P;
   const float* gx = a_in.x; const unsigned short* gph = a_in.ph; const unsigned short* gpl = a_in.pl; float* gpart = a_in.part;
   PIN(gx); PIN(gph); PIN(gpl); PIN(gpart);
@@ -80,25 +106,37 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
   const int b = tile / a_in.tiles_per_b, t0 = (tile - b * a_in.tiles_per_b) * FR_BM;
   const size_t mrow0 = (size_t)b * T;
 
-  // ---- stage the input frames t0 - 1 - PADLMAX ..: fp32 -> (hi, lo) planes, zero outside [0, T) ----
+  // ---- stage the input frames t0 - 1 - PADLMAX ..: fp32 -> (hi, lo) planes, zero outside [0, T); all loads of a thread in flight at once ----
   {
     const float* xb = gx + mrow0 * a_in.ldx;
     const bool vec = (a_in.ldx & 3) == 0 && (a_in.Cin & 3) == 0 && ((reinterpret_cast<uintptr_t>(a_in.x) & 15) == 0);
-    for (int i = tid; i < XROWS * (CINP / 4); i += 512) {
+    constexpr int NST = (XROWS * (CINP / 4) + 511) / 512;
+    float4 f[NST];
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 512 * u;
       const int r = i / (CINP / 4), c = 4 * (i - r * (CINP / 4));
       const int t = t0 - 1 - PADLMAX + r;
-      float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 0 && t < T && c < a_in.Cin) {
+      f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < XROWS && t >= 0 && t < T && c < a_in.Cin) {
         const float* p = xb + (size_t)t * a_in.ldx + c;
-        if (vec) f = fr_ldf4(p);
-        else { f.x = p[0]; if (c + 1 < a_in.Cin) f.y = p[1]; if (c + 2 < a_in.Cin) f.z = p[2]; if (c + 3 < a_in.Cin) f.w = p[3]; }
+        if (vec) f[u] = fr_ldf4(p);
+        else { f[u].x = p[0]; if (c + 1 < a_in.Cin) f[u].y = p[1]; if (c + 2 < a_in.Cin) f[u].z = p[2]; if (c + 3 < a_in.Cin) f[u].w = p[3]; }
       }
-      uint2 h4, l4;
-      taco_split_bf16x4(f, h4, l4);
-      *reinterpret_cast<uint2*>(xhi + r * XS + c) = h4;
-      *reinterpret_cast<uint2*>(xlo + r * XS + c) = l4;
+    }
+#pragma unroll
+    for (int u = 0; u < NST; ++u) {
+      const int i = tid + 512 * u;
+      const int r = i / (CINP / 4), c = 4 * (i - r * (CINP / 4));
+      if (r < XROWS) {
+        uint2 h4, l4;
+        taco_split_bf16x4(f[u], h4, l4);
+        *reinterpret_cast<uint2*>(xhi + r * XS + c) = h4;
+        *reinterpret_cast<uint2*>(xlo + r * XS + c) = l4;
+      }
     }
   }
+  FTRC(1);
   // produce coordinates: frame lane & 15 of a 16-frame tile, k-quarter lane >> 4 (A/B operands of the 16x16x32 MFMA hold k = 8 q .. 8 q + 7)
   const int pc = lane & 15, pq = lane >> 4;
   unsigned vmask = 0, nmask = 0;     // bit rt: frame t0 - 1 + 16 rt + pc lies in [0, T) / has a successor inside the row
@@ -123,7 +161,18 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
       for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
   const int c_begin = a_in.pstart[part], c_end = a_in.pstart[part + 1];
+  if (tid < 2) gcnt[tid] = 0u;
   __syncthreads();
+  unsigned nbar = 0;
+  // the second half starts a few microseconds late (a_in.delay shader clocks): from then on one half's VALU epilogue lies under the
+  // other half's MFMAs instead of next to its epilogue
+  if (ks == 1 && a_in.prio == 1) __builtin_amdgcn_s_setprio(1);        // the younger waves of a SIMD lose the arbitration otherwise: measured,
+  if (ks == 1 && a_in.prio == 2) __builtin_amdgcn_s_setprio(2);        // the second half trails the first by 15 % of the kernel
+  if (ks == 1 && a_in.prio == 3) __builtin_amdgcn_s_setprio(3);
+  if (ks == 1 && a_in.delay > 0) {
+    const long long c0 = clock64();
+    while (clock64() - c0 < a_in.delay) __builtin_amdgcn_s_sleep(8);
+  }
 
   for (int ci = c_begin; ci < c_end; ++ci) {
     const FrChunk ch = a_in.ch[ci];
@@ -144,39 +193,62 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
       const unsigned short* wl = W.wl + ((size_t)ct * 64 + lane) * 8;
       const unsigned short* xbh = xhi + (pcv + W.xoff) * XS + 8 * pqv;
       const unsigned short* xbl = xlo + (pcv + W.xoff) * XS + 8 * pqv;
-      auto pstep = [&](int s, const uint4& wh4, const uint4& wl4) {
-        int xo;
-        if constexpr (FLAT) xo = 32 * s;
-        else { const int kk = 32 * s; const int tap = kk / CINP; xo = tap * XS + (kk - tap * CINP); }
-        const bf16x8 whv = __builtin_bit_cast(bf16x8, wh4), wlv = __builtin_bit_cast(bf16x8, wl4);
+      // Software pipeline over BATCHES of three frame tiles (6 ds_read_b128 -> 9 MFMAs, the three products of a tile three MFMAs
+      // apart): the fragments of batch i + 1 are requested before the MFMAs of batch i are issued, in two register sets that swap
+      // roles, so a wave never waits for the LDS it has just asked (with two waves per SIMD nothing else would fill that gap).
+      // Weight fragments: two sets, one k32 step ahead (the step count is even: pack_front pads it).
+      auto xoff_of = [&](int s) {
+        if constexpr (FLAT) return 32 * s;
+        else { const int kk = 32 * s; const int tap = kk / CINP; return tap * XS + (kk - tap * CINP); }
+      };
+      auto xload = [&](int s, int b, bf16x8 (&xh)[3], bf16x8 (&xl)[3]) {
+        const int xo = xoff_of(s);
 #pragma unroll
-        for (int r3 = 0; r3 < FR_NRT; r3 += 3) {
-          bf16x8 xh[3], xl[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            xh[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xbh + (16 * (r3 + i)) * XS + xo));
-            xl[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xbl + (16 * (r3 + i)) * XS + xo));
-          }
-#pragma unroll
-          for (int i = 0; i < 3; ++i) z[r3 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, xh[i], z[r3 + i], 0, 0, 0);   // small terms first
-#pragma unroll
-          for (int i = 0; i < 3; ++i) z[r3 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, xl[i], z[r3 + i], 0, 0, 0);
-#pragma unroll
-          for (int i = 0; i < 3; ++i) z[r3 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, xh[i], z[r3 + i], 0, 0, 0);
+        for (int i = 0; i < 3; ++i) {
+          xh[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xbh + (16 * (3 * b + i)) * XS + xo));
+          xl[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xbl + (16 * (3 * b + i)) * XS + xo));
         }
       };
-      // weight fragments one step ahead in two register sets that swap roles (the step count is even: pack_front pads it)
+      auto pmma = [&](int b, const uint4& wh4, const uint4& wl4, const bf16x8 (&xh)[3], const bf16x8 (&xl)[3]) {
+        const bf16x8 whv = __builtin_bit_cast(bf16x8, wh4), wlv = __builtin_bit_cast(bf16x8, wl4);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) z[3 * b + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, xh[i], z[3 * b + i], 0, 0, 0);   // small terms first
+#pragma unroll
+        for (int i = 0; i < 3; ++i) z[3 * b + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, xl[i], z[3 * b + i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) z[3 * b + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, xh[i], z[3 * b + i], 0, 0, 0);
+      };
       uint4 p_h = fr_ld16(wh), p_l = fr_ld16(wl), q_h, q_l;
+      bf16x8 xPh[3], xPl[3], xQh[3], xQl[3];
+      xload(0, 0, xPh, xPl);
 #pragma unroll 1
       for (int s = 0; s < W.ns; s += 2) {
-        q_h = fr_ld16(wh + (s + 1) * sstride); q_l = fr_ld16(wl + (s + 1) * sstride);
-        __builtin_amdgcn_sched_barrier(0);
-        pstep(s, p_h, p_l);
-        __builtin_amdgcn_sched_barrier(0);
         const int sn = min(s + 2, W.ns - 1);                       // past the end: fetched again, never used
-        p_h = fr_ld16(wh + sn * sstride); p_l = fr_ld16(wl + sn * sstride);
+        q_h = fr_ld16(wh + (s + 1) * sstride); q_l = fr_ld16(wl + (s + 1) * sstride);
+        xload(s, 1, xQh, xQl);
         __builtin_amdgcn_sched_barrier(0);
-        pstep(s + 1, q_h, q_l);
+        pmma(0, p_h, p_l, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(s, 2, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        pmma(1, p_h, p_l, xQh, xQl);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(s + 1, 0, xQh, xQl);
+        __builtin_amdgcn_sched_barrier(0);
+        pmma(2, p_h, p_l, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        p_h = fr_ld16(wh + sn * sstride); p_l = fr_ld16(wl + sn * sstride);
+        xload(s + 1, 1, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        pmma(0, q_h, q_l, xQh, xQl);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(s + 1, 2, xQh, xQl);
+        __builtin_amdgcn_sched_barrier(0);
+        pmma(1, q_h, q_l, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        xload(sn, 0, xPh, xPl);
+        __builtin_amdgcn_sched_barrier(0);
+        pmma(2, q_h, q_l, xQh, xQl);
         __builtin_amdgcn_sched_barrier(0);
       }
       // bias -> ReLU -> BatchNorm affine, per channel 16 ct + 4 q + reg (C/D map of the 16x16 MFMA: column = lane & 15, row = 4 (lane >> 4) + reg)
@@ -189,18 +261,8 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
         z[rt][3] = fmaxf(z[rt][3] + bi.w, 0.f) * sc.w + sh.w;
       }
     }
-    // first weight fragments of the consume phase, requested before the barriers
-    const int g0 = 4 * ks;
-    const size_t k16base = (size_t)(ch.cg0 >> 4) + g0;
-    auto boff = [&](int u, int tn) {          // step u = (tap j = u >> 2, k16 group g0 + (u & 3)) of this wave's half
-      const size_t k16 = (size_t)(u >> 2) * a_in.pK16tap + k16base + (u & 3);
-      return (((k16 * a_in.pNT + ntc[tn]) * 2 + lhv) * 32 + l31v) * 8;
-    };
-    uint4 pbh[TN], pbl[TN], qbh[TN], qbl[TN];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) { pbh[tn] = fr_ld16(gph + boff(0, tn)); pbl[tn] = fr_ld16(gpl + boff(0, tn)); }
-    __syncthreads();                       // every wave has finished reading the pooled planes of the previous chunk
-    // max-pool with the next frame, zero outside the row, split, store: 4 consecutive channels = 8 bytes per plane
+    // max-pool with the next frame, zero outside the row, split into the two planes -- all in registers, before the barrier
+    uint2 ph4[FR_NRT], pl4[FR_NRT];
 #pragma unroll
     for (int rt = 0; rt < FR_NRT; ++rt) {
       float4 p;
@@ -213,26 +275,46 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
         v = ((vmask >> rt) & 1u) ? v : 0.f;
         (&p.x)[e] = v;
       }
+      taco_split_bf16x4(p, ph4[rt], pl4[rt]);
+      asm volatile("" : "+v"(ph4[rt].x), "+v"(ph4[rt].y), "+v"(pl4[rt].x), "+v"(pl4[rt].y));     // computed HERE, not sunk below the barrier into the guarded stores
+    }
+    // first weight fragments of the consume phase, requested before the barriers
+    const int g0 = 4 * ks;
+    const size_t k16base = (size_t)(ch.cg0 >> 4) + g0;
+    auto boff = [&](int u, int tn) {          // step u = (tap j = u >> 2, k16 group g0 + (u & 3)) of this wave's half
+      const size_t k16 = (size_t)(u >> 2) * a_in.pK16tap + k16base + (u & 3);
+      return (((k16 * a_in.pNT + ntc[tn]) * 2 + lhv) * 32 + l31v) * 8;
+    };
+    uint4 pbh[TN], pbl[TN], qbh[TN], qbl[TN];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) { pbh[tn] = fr_ld16(gph + boff(0, tn)); pbl[tn] = fr_ld16(gpl + boff(0, tn)); }
+    FTRC(trci); ++trci;
+    nbar += 4; fr_gbar(gcnt + ks, nbar, lane);       // the four waves of this half have finished reading the previous chunk's planes
+    FTRC(trci); ++trci;
+    // 4 consecutive channels of one frame = 8 bytes per plane
+#pragma unroll
+    for (int rt = 0; rt < FR_NRT; ++rt) {
       const int fr = 16 * rt + pcv;
-      if (fr < FR_PR) {
-        uint2 h4, l4;
-        taco_split_bf16x4(p, h4, l4);
-        *reinterpret_cast<uint2*>(ahi + fr * FR_ALD + 16 * wave + 4 * pqv) = h4;
-        *reinterpret_cast<uint2*>(alo + fr * FR_ALD + 16 * wave + 4 * pqv) = l4;
+      if (16 * rt + 15 < FR_PR || fr < FR_PR) {       // only the last tile has frames past the planes
+        *reinterpret_cast<uint2*>(ahi + fr * FR_ALD + 16 * wave + 4 * pqv) = ph4[rt];
+        *reinterpret_cast<uint2*>(alo + fr * FR_ALD + 16 * wave + 4 * pqv) = pl4[rt];
       }
     }
-    __syncthreads();
+    nbar += 4; fr_gbar(gcnt + ks, nbar, lane);       // this half's 64 channels of the planes are complete
+    FTRC(trci); ++trci;
     // ================= consume: acc[128 frames][32 TN columns] over this wave's 12 (tap, k16) steps =================
-    auto mma = [&](int u, const uint4 (&bh)[TN], const uint4 (&bl)[TN]) {
+    // the same pipeline: the A fragments (pooled planes) and the weight fragments of step u + 1 are requested before the MFMAs of step u
+    auto aload = [&](int u, bf16x8 (&ah)[4], bf16x8 (&al)[4]) {
       const int j = u >> 2, g = g0 + (u & 3);
       const unsigned short* ph_ = ahi + (l31v + j) * FR_ALD + 16 * g + 8 * lhv;
       const unsigned short* pl_ = alo + (l31v + j) * FR_ALD + 16 * g + 8 * lhv;
-      bf16x8 ah[4], al[4];
 #pragma unroll
       for (int tm = 0; tm < 4; ++tm) {
         ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ph_ + tm * 32 * FR_ALD));
         al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pl_ + tm * 32 * FR_ALD));
       }
+    };
+    auto mma = [&](const bf16x8 (&ah)[4], const bf16x8 (&al)[4], const uint4 (&bh)[TN], const uint4 (&bl)[TN]) {
 #pragma unroll
       for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -245,48 +327,57 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
           }
     };
+    bf16x8 aPh[4], aPl[4], aQh[4], aQl[4];
+    aload(0, aPh, aPl);
 #pragma unroll 1
     for (int u = 0; u < 12; u += 2) {
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) { qbh[tn] = fr_ld16(gph + boff(u + 1, tn)); qbl[tn] = fr_ld16(gpl + boff(u + 1, tn)); }
+      aload(u + 1, aQh, aQl);
       __builtin_amdgcn_sched_barrier(0);
-      mma(u, pbh, pbl);
+      mma(aPh, aPl, pbh, pbl);
       __builtin_amdgcn_sched_barrier(0);
       const int un = (u + 2 < 12) ? u + 2 : u + 1;                 // past the end: fetched again, never used
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) { pbh[tn] = fr_ld16(gph + boff(un, tn)); pbl[tn] = fr_ld16(gpl + boff(un, tn)); }
+      aload(un, aPh, aPl);
       __builtin_amdgcn_sched_barrier(0);
-      mma(u + 1, qbh, qbl);
+      mma(aQh, aQl, qbh, qbl);
       __builtin_amdgcn_sched_barrier(0);
     }
+    FTRC(trci); ++trci;
   }
 
-  // ---- the two K halves meet through LDS (everything staged is dead), then the tile leaves as this part's partial sum ----
+  // ---- the two K halves meet through LDS (everything staged is dead): each half hands the other two of its four row tiles, adds what
+  // it receives, and stores its two row tiles of this part's partial sum -- all eight waves store ----
   __syncthreads();
-  float* red = reinterpret_cast<float*>(fr_smem) + (size_t)wn * (4 * TN * 16 * 64);
-  if (ks == 1) {
+  float* red = reinterpret_cast<float*>(fr_smem) + (size_t)wave * (2 * TN * 16 * 64);
+  const int give0 = ks == 0 ? 2 : 0, keep0 = ks == 0 ? 0 : 2;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[((tm * TN + tn) * 16 + r) * 64 + lane] = acc[tm][tn][r];
-  }
+      for (int r = 0; r < 16; ++r) red[((i * TN + tn) * 16 + r) * 64 + lane] = ks == 0 ? acc[2 + i][tn][r] : acc[i][tn][r];
   __syncthreads();
-  if (ks == 1) return;
+  FTRC(trci); ++trci;
+  (void)give0;
+  const float* got = reinterpret_cast<const float*>(fr_smem) + (size_t)(wave ^ 4) * (2 * TN * 16 * 64);
   float* outp = gpart + ((size_t)part * a_in.B * T + mrow0) * a_in.N1;
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int col = (wn * TN + tn) * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int t = t0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = acc[tm][tn][r] + red[((tm * TN + tn) * 16 + r) * 64 + lane];
+        const int t = t0 + (keep0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float mine = ks == 0 ? acc[i][tn][r] : acc[2 + i][tn][r];
+        const float v = mine + got[((i * TN + tn) * 16 + r) * 64 + lane];
         if (t < T && col < a_in.N1) outp[(size_t)t * a_in.N1 + col] = v;
       }
     }
+  FTRC(trci);
 }
 
 // out[m][n] = act(sum over the parts (fixed order) + bias[n]) * scale[n] + shift[n]   (proj_1's epilogue, modules.py:123-131)

@@ -11,12 +11,14 @@
 #include "taco_backward_kernels.h"
 #include "taco_decoder_bwd_xcd.h"
 #include "../../include/taco_abi.h"
+#include "../../include/taco_debug.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <functional>
 #include <map>
 #include <string>
@@ -148,6 +150,7 @@ struct taco_model {
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
+  int front_prio = 1; int front_delay = 0;      // shader clocks by which the second K half of a k_cbhg_front workgroup starts late (taco_front.h)
   int front = 1;               // conv bank -> max-pool -> proj_1 of a CBHG as one launch (taco_front.h); 0: bank and proj_1 as two k_gemm_bf3 launches
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
@@ -1135,6 +1138,8 @@ static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const f
   a.x = x; a.ldx = c.in_dim; a.B = B; a.T = T; a.Cin = c.in_dim; a.tiles_per_b = cdiv(T, FR_BM);
   a.ph = pv.bh; a.pl = pv.bl; a.pNT = pv.NT; a.pK16tap = P1.cin_pad16 / 16;
   a.part = w.bank; a.N1 = P1.N;
+  a.delay = m->front_delay;
+  a.prio = m->front_prio;
   const int cpw = c.C / FR_CH, nchunks = c.K * cpw, padlmax = (kwmax - 1) / 2;
   for (int i = 0; i < c.K; ++i) {
     const ConvL& L = c.bank[i];
@@ -1175,7 +1180,9 @@ static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const f
     a.pstart[P] = n; }
   const int xs = c.front_kind == 1 ? 80 : 144, xrows = c.front_kind == 1 ? 16 * FR_NRT + kwmax : FR_PR + kwmax;
   (void)cinp;
-  const size_t lds = std::max((size_t)2 * xrows * xs * 2 + (size_t)2 * FR_PR * FR_ALD * 2, (size_t)4 * 4 * TN * 16 * 64 * sizeof(float));
+  if ((size_t)2 * xrows * xs * 2 + (size_t)2 * FR_PR * FR_ALD * 2 > FR_SMEM_CNT || (size_t)8 * 2 * TN * 16 * 64 * sizeof(float) > FR_SMEM_CNT)
+    return fail(TACO_ERR_STATE, "k_cbhg_front: LDS layout does not fit");
+  const size_t lds = 160 * 1024;           // planes + reduction scratch below FR_SMEM_CNT, the two group-barrier counters at it
   const dim3 grid(ntiles * P), blk(512);
   if (c.front_kind == 1) hipLaunchKernelGGL((k_cbhg_front<2, 80, 80, 8>), grid, blk, lds, st, a);      // (> 64 KB of LDS: attribute set at finalize)
   else hipLaunchKernelGGL((k_cbhg_front<1, 144, 128, 16>), grid, blk, lds, st, a);
@@ -2065,6 +2072,7 @@ int taco_debug_set_fuse_prenet(taco_model* m, int on) {
 }
 #ifdef TACO_TRACE
 int taco_debug_read_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
+int taco_debug_read_trace_front(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace_front), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
 #endif
 int taco_debug_set_fuse_concat(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
@@ -2148,6 +2156,11 @@ int taco_debug_decoder_trace(taco_model* m, int enable, long long* out) {
   return 0;
 }
 
+int taco_debug_set_front(taco_model* m, int delay_clocks, int prio) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->front_delay = delay_clocks; m->front_prio = prio;     // k_cbhg_front: start delay and s_setprio level of the second K half (tools/time_front.py)
+  return 0;
+}
 int taco_debug_set_skip_scans(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->skip_scans = on ? 1 : 0;

@@ -16,10 +16,25 @@ from util import tiny_hp, to_product_hp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _headers():
+    """include/taco_abi.h (the drop-in boundary) + include/taco_debug.h (test / timing hooks of this repository)"""
+    return "\n".join(open(os.path.join(ROOT, "include", n)).read() for n in ("taco_abi.h", "taco_debug.h"))
+
+
+def test_the_public_header_carries_no_debug_entry_points():
+    """test hooks do not belong in the ABI a reference maintainer binds."""
+    pub = open(os.path.join(ROOT, "include", "taco_abi.h")).read()
+    names = set(re.findall(r"\b(taco_[a-z0-9_]+)\s*\(", pub))
+    assert not [n for n in names if "debug" in n], sorted(n for n in names if "debug" in n)
+    dbg = open(os.path.join(ROOT, "include", "taco_debug.h")).read()
+    dnames = set(re.findall(r"\b(taco_[a-z0-9_]+)\s*\(", dbg))
+    assert dnames and all("debug" in n for n in dnames), sorted(dnames)
+
+
 def test_library_loads_and_exports_every_header_symbol():
     lib = _lib.load_library()
     assert lib.taco_abi_version() == 1
-    header = open(os.path.join(ROOT, "include", "taco_abi.h")).read()
+    header = _headers()
     declared = set(re.findall(r"\b(taco_[a-z0-9_]+)\s*\(", header))
     declared -= {"taco_model", "taco_plan", "taco_hparams"}
     assert declared, "no declarations parsed"
@@ -210,11 +225,11 @@ def test_open_data_dirs_feeds_batches_from_npz_directories(tmp_path):
 
 
 def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
-    """Every function of include/taco_abi.h: the ctypes mirror (_lib.PROTOTYPES) has the same number of arguments and the same class of
+    """Every function of include/taco_abi.h and include/taco_debug.h: the ctypes mirror (_lib.PROTOTYPES) has the same number of arguments and the same class of
     type (pointer / int / float / 64-bit unsigned / 64-bit signed) in every position, and the same class of return type -- so the
     Python host cannot drift from the C ABI silently (a wrong arity or width is undefined behaviour, not an exception)."""
     import ctypes as C
-    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "taco_abi.h")).read(), flags=re.S)
+    header = re.sub(r"/\*.*?\*/", "", _headers(), flags=re.S)
     header = re.sub(r"//[^\n]*", "", header)
     decls = re.findall(r"(?:^|[;}\n])\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(taco_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S)
     assert len(decls) >= 50

@@ -9,6 +9,7 @@
 #include <string>
 #include <vector>
 #include "taco_abi.h"
+#include "taco_debug.h"      // the timing tools use the A/B switches
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 #define TK(x) do { int r_ = (x); if (r_ != 0) { printf("taco error %d at line %d: %s\n", r_, __LINE__, taco_last_error()); return 1; } } while (0)
