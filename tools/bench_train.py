@@ -7,49 +7,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--t-in", type=int, default=128)
-    ap.add_argument("--t-out", type=int, default=512)
-    ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
-    ap.add_argument("--gpus", type=int, default=1, help="N > 1: this script launches its own N ranks (torch.distributed.run, RCCL, 127.0.0.1)")
-    ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
-    ap.add_argument("--engine", type=int, default=1, help="1: persistent whole-chip kernels for the teacher-forced decoder loop and the post-net scans (default); 0: one launch per stage (rounds 1-2)")
-    ap.add_argument("--bptt", type=int, default=1, help="1: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd; default); 0: the chain of per-stage launches")
-    ap.add_argument("--exact-gemm", type=int, default=3, help="3 (default): forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16")
-    ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
-    ap.add_argument("--deterministic", type=int, default=0, help="1: ordered two-stage sums instead of fp32 atomics (reproducible steps)")
-    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
-                                                           "0: per-rank statistics.  No effect on one GPU")
-    args = ap.parse_args()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        import socket, subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
-        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    if args.selftest_launcher:
-        import torch, taco_amd
-        from taco_amd import dist as D
-        from taco_amd.train_ops import allreduce_gradients
-        rank, _, world = D.env_rank()
-        dist = D.init_process_group("gloo") if world > 1 else None
-        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
-        allreduce_gradients(g)
-        if rank == 0:
-            print(json.dumps({"selftest": "launcher", "world_size": world, "grad_mean_factor": float(g[1])}))
-        if dist is not None:
-            dist.barrier(); dist.destroy_process_group()
-        return
+def measure(args):
+    """One measurement of the train step with the switches of `args` (see main); returns the report dict on rank 0, None elsewhere."""
     import numpy as np, torch, taco_amd
     from taco_amd import dist as D
     rank, local_rank, world = D.env_rank()
     torch.cuda.set_device(local_rank if world > 1 else 0)
-    dist = D.init_process_group("nccl") if world > 1 else None
+    import torch.distributed as tdist
+    own_group = world > 1 and not tdist.is_initialized()
+    dist = D.init_process_group("nccl") if own_group else (tdist if world > 1 else None)
     dev = torch.device("cuda", torch.cuda.current_device())
     hp = taco_amd.hparams.copy(max_iters=max(200, args.t_out // 4))
     tr = taco_amd.Trainer(hp, taco_amd.weights.random_weights(hp, 1, seed=4321), device=str(dev))
@@ -103,8 +69,9 @@ def main():
     tr.check_device_errors()
     per_rank = D.gather_floats(e0.elapsed_time(e1) / args.steps, device=dev if dist is not None else "cpu")
     engine = tr.decoder_engine_info()
+    report = None
     if rank == 0:
-        print(json.dumps({
+        report = ({
             "metric": "train steps/s (C4 shard shapes)", "value": world * args.steps / wall / world, "unit": "steps/s",
             "n_gpus": world, "global_batch": world * B, "ms_per_step": wall / args.steps * 1e3,
             "target_frames_per_s": world * B * T_out * args.steps / wall, "dtype": "f32", "data": "synthetic", "launch": "hipGraph" if args.graph else "eager",
@@ -121,9 +88,79 @@ def main():
                        "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
-            "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9}))
-    if dist is not None:
+            "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9})
+        # FLOP roofline of the step (the dense contractions are MFMA bound).  Forward = the C2-shaped forward's
+        # contractions; backward = one data-gradient and one weight-gradient product per forward product.
+        import importlib.util
+        spec_ = importlib.util.spec_from_file_location("taco_bench", os.path.join(ROOT, "bench.py"))
+        bench = importlib.util.module_from_spec(spec_); spec_.loader.exec_module(bench)
+        n = T_out // hp.reduction_factor
+        fwd = bench.algorithmic_flops(hp, B, T_in, n); ff = bench.feedforward_flops(hp, B, T_in, n)
+        step_s = wall / args.steps
+        total = 3 * fwd * world
+        fgemm = {3: "exact-fp32 MFMA", 1: "exact-fp32 MFMA", 0: "bf16 MFMA x3", 2: "bf16 MFMA x3"}[args.exact_gemm]
+        bf16_issued = ((3 if args.exact_gemm in (0, 2) else 0) + (3 if args.exact_gemm in (0, 3) else 0) + (0 if args.exact_wgrad else 6)) * ff
+        f32_mfma = ((0 if args.exact_gemm in (0, 2) else 1) + (1 if args.exact_gemm in (1, 2) else 0) + (1 if args.exact_wgrad else 0)) * ff
+        report["roofline"] = {
+            "bound": "mfma", "achieved": total / step_s / 1e12, "peak": bench.MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+            "frac": total / step_s / 1e12 / bench.MFMA_F32_PEAK_TF, "traffic": None,
+            "kernel": "whole train step (forward with tape + loss + backward + clip/Adam + pack refresh); algorithmic flops = 3 x the "
+                      "forward's %.1f GFLOP (one data-gradient and one weight-gradient product per forward product) per rank" % (fwd / 1e9),
+            "gflop_per_step_per_rank": 3 * fwd / 1e9,
+            "pipes": {"forward_feed_forward_gemms": fgemm,
+                      "fp32_mfma_gflop": f32_mfma / 1e9, "bf16_mfma_issued_gflop": bf16_issued / 1e9,
+                      "fp32_valu_gflop (scans, decoder loop and their BPTT)": 3 * (fwd - ff) / 1e9,
+                      "lower_bound_ms_at_peaks": (f32_mfma / (bench.MFMA_F32_PEAK_TF * 1e12) + bf16_issued / (bench.MFMA_BF16_PEAK_TF * 1e12)) * 1e3,
+                      "note": "priced against the fp32-MFMA peak because the reference's arithmetic is fp32; the bf16 products are split operands "
+                              "(3 per data-gradient product, 6 per weight-gradient product) that reproduce fp32"}}
+        report["deterministic"] = bool(args.deterministic)
+    tr.close() if hasattr(tr, "close") else None
+    if dist is not None and own_group:
         dist.barrier(); dist.destroy_process_group()
+    return report
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--t-in", type=int, default=128)
+    ap.add_argument("--t-out", type=int, default=512)
+    ap.add_argument("--graph", type=int, default=0, help="1: forward+backward replayed from one hipGraph; 0: eager launches")
+    ap.add_argument("--gpus", type=int, default=1, help="N > 1: this script launches its own N ranks (torch.distributed.run, RCCL, 127.0.0.1)")
+    ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
+    ap.add_argument("--engine", type=int, default=1, help="1: persistent whole-chip kernels for the teacher-forced decoder loop and the post-net scans (default); 0: one launch per stage (rounds 1-2)")
+    ap.add_argument("--bptt", type=int, default=1, help="1: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd; default); 0: the chain of per-stage launches")
+    ap.add_argument("--exact-gemm", type=int, default=3, help="3 (default): forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16")
+    ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
+    ap.add_argument("--deterministic", type=int, default=0, help="1: ordered two-stage sums instead of fp32 atomics (reproducible steps)")
+    ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
+                                                           "0: per-rank statistics.  No effect on one GPU")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket, subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    if args.selftest_launcher:
+        import torch, taco_amd
+        from taco_amd import dist as D
+        from taco_amd.train_ops import allreduce_gradients
+        rank, _, world = D.env_rank()
+        dist = D.init_process_group("gloo") if world > 1 else None
+        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        allreduce_gradients(g)
+        if rank == 0:
+            print(json.dumps({"selftest": "launcher", "world_size": world, "grad_mean_factor": float(g[1])}))
+        if dist is not None:
+            dist.barrier(); dist.destroy_process_group()
+        return
+    rep = measure(args)
+    if rep is not None:
+        print(json.dumps(rep))
 
 
 if __name__ == "__main__":
