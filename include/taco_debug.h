@@ -20,10 +20,12 @@ int taco_debug_set_persistent(taco_model* m, int on);
 /* test hook: on = 1 (default) runs the feed-forward GEMMs of inference on the bf16 matrix cores with 3-term split
  * operands (fp32-grade accuracy, ~1e-5); 0 = exact-fp32 MFMA everywhere.  tile_n: 0 auto, 1 = 128x64, 2 = 128x128,
  * 3 = 64x256 (2x2 waves), 4 = 64x64, 5 = 64x64 with four wave groups splitting K inside the workgroup, 7 = 64x256 by 1x8 waves,
- * 9 = 64x128 by 1x4 waves, 10 = tile 7 with two wave groups splitting K (auto picks 4 / 5 / 7 / 9 / 10).
+ * 9 = 64x128 by 1x4 waves, 10 = tile 7 with two wave groups splitting K, 11 = 128x256 by 1x8 waves (auto picks 4 / 5 / 7 / 9 / 10 / 11).
  * on bit 2 (on = 5): the point-wise tail of a CBHG ([dense ->] highway x depth -> BiGRU input projection; modules.py:72-96) runs as
  * one launch per layer instead of ONE launch with the activations resident on the CU (csrc/taco_chain.h, the default with on = 1).
- * on bit 3 (on = 9): conv bank and proj_1 of a CBHG as two launches instead of the fused front (csrc/taco_front.h). */
+ * on bit 3 (on = 9): conv bank and proj_1 of a CBHG as two launches instead of the fused front (csrc/taco_front.h).
+ * on bit 4 (on = 17): with the fused front, proj_1's epilogue (k_front_combine) and proj_2 as launches of their own instead of the fused
+ * entry of the point-wise chain (csrc/taco_chain.h). */
 int taco_debug_set_bf3(taco_model* m, int on, int tile_n);
 
 /* test hook: > 0 = taco_forward_infer runs the post-net feed-forward stages behind the decoder on a second stream

@@ -23,7 +23,20 @@ struct ChainLayer {
   const float* bias; const float* bias2;
   int type, K16, NT, N, act;       // k16 steps of the layer's K (padded input width / 16), 32-column tiles in the pack, columns
 };
+// Fused entry (the CBHG's second projection in front of the chain, modules.py:55-69): instead of reading its input rows, the workgroup
+// forms them -- proj_1's output from the partial sums of k_cbhg_front (sum over the parts in a fixed order, + bias -> ReLU -> BatchNorm:
+// what k_front_combine did as a launch of its own), then the width-3 projection conv proj_2 (+ bias -> BatchNorm affine, no activation)
+// on the matrix cores, + the residual input (+ the deepvoice per-row vector).  Saves two launches and the round trip of two activations.
+struct ChainEntry {
+  const float* part; int P; size_t MN; int N1;           // partial sums [P][M][N1]
+  const float* b1; const float* s1; const float* h1; int relu1;       // proj_1: bias, BatchNorm scale / shift (nullable), ReLU?
+  const unsigned short* bh; const unsigned short* bl; int NT2, K16tap, N2;   // proj_2 pack (pack_bf3), k16 groups per tap, columns
+  const float* b2; const float* s2; const float* h2;     // proj_2: bias, BatchNorm scale / shift (nullable)
+  const float* res; int ldres;                           // residual rows [M, ldres] (the CBHG's input)
+  const float* rowvec; int ldrv;                         // optional per-batch-row vector [M / T, ldrv]
+};
 struct ChainArgs {
+  ChainEntry e;                    // e.part != null: fused entry (x unused)
   const float* x; int ldx, Cin;    // input rows [M, ldx], Cin columns used
   float* out; int ldo;             // projection output [M, ldo]
   float* y; int ldy;               // optional: the last highway output [M, W] (null: not stored)
@@ -102,6 +115,150 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * CH_BM;
 
+  const int l31_outer = l31, lh_outer = lh;
+  float xreg[TM][16];                          // the lane's slice of the current activation in fp32 (highway carry)
+  bool have_x = false;
+  if (a_in.e.part) {
+    // ---- fused entry: proj_1's epilogue over the partial sums -> planes [CH_BM + 2][N1]; proj_2 (width 3) -> the chain's input ----
+    const ChainEntry E = a_in.e;
+    const float* gpart = E.part; const float* gb1 = E.b1; const float* gs1 = E.s1; const float* gh1 = E.h1;
+    const unsigned short* gbh = E.bh; const unsigned short* gbl = E.bl;
+    const float* gres = E.res; const float* grv = E.rowvec; const float* gb2 = E.b2; const float* gs2 = E.s2; const float* gh2 = E.h2;
+    PIN(gpart); PIN(gb1); PIN(gs1); PIN(gh1); PIN(gbh); PIN(gbl); PIN(gres); PIN(grv); PIN(gb2); PIN(gs2); PIN(gh2);
+    const int LDE = E.N1 + 8;                                              // bf16 per plane row (N1 = 128 / 256: odd multiple of 16 bytes)
+    unsigned short* ehi = ch_smem + 2 * CH_BM * LDSW;                      // behind the chain's own planes
+    unsigned short* elo = ehi + (CH_BM + 2) * LDE;
+    const int nq = E.N1 / 4;
+    constexpr int NSTG = ((CH_BM + 2) * (256 / 4) + 511) / 512;          // float4 per thread at the widest N1
+    {
+      float4 f[NSTG];
+      const float* src[NSTG];
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int i = tid + 512 * u, r = i / nq, c = 4 * (i - r * nq), row = m0 - 1 + r;
+        f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        src[u] = (i < (CH_BM + 2) * nq && row >= 0 && row < a.M) ? gpart + (size_t)row * E.N1 + c : nullptr;
+      }
+      for (int q = 0; q < E.P; ++q) {            // parts in a fixed order; the NSTG loads of a part are in flight together
+        float4 g[NSTG];
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) g[u] = src[u] ? *reinterpret_cast<const float4*>(src[u] + (size_t)q * E.MN) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) { f[u].x += g[u].x; f[u].y += g[u].y; f[u].z += g[u].z; f[u].w += g[u].w; }
+      }
+#pragma unroll
+      for (int u = 0; u < NSTG; ++u) {
+        const int i = tid + 512 * u, r = i / nq, c = 4 * (i - r * nq);
+        if (i >= (CH_BM + 2) * nq) continue;
+        float4 v = f[u];
+        if (src[u]) {
+          const float4 bi = gb1 ? *reinterpret_cast<const float4*>(gb1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 sc = gs1 ? *reinterpret_cast<const float4*>(gs1 + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float4 sh = gh1 ? *reinterpret_cast<const float4*>(gh1 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+          v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+          if (E.relu1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+        }
+        uint2 h4, l4;
+        taco_split_bf16x4(v, h4, l4);
+        *reinterpret_cast<uint2*>(ehi + r * LDE + c) = h4;
+        *reinterpret_cast<uint2*>(elo + r * LDE + c) = l4;
+      }
+    }
+    __syncthreads();
+    // proj_2: wave (wm, wn) owns its TM row tiles x the 32 columns 32 wn .. (waves past the last column tile idle); SAME padding and the
+    // batch-row boundary by masking the A fragment per (row, tap) as k_gemm_bf3 does
+    const int K0 = a_in.L[0].K16 * 16;                                     // columns of the chain's input planes (>= N2, zero padded)
+    const int col = wn * 32 + l31;
+    const bool cin = col < E.N2;
+    // (requested BEFORE the MFMA loop, whose duration hides them; all residual values of the lane are requested before the first is used: left in one loop with the LDS stores, every element
+    // waited for its own load -- 32 memory round trips)
+    float rs[TM][16];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, row = min(m0 + rl, a.M - 1);
+        float v = 0.f;
+        if (cin) {
+          v = gres[(size_t)row * E.ldres + col];
+          if (grv) v += grv[(size_t)(row / a.T) * E.ldrv + col];
+        }
+        rs[tm][r] = v;
+      }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+      for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+    if (wn < E.NT2) {
+      int tloc[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) tloc[tm] = (m0 + (wm * TM + tm) * 32 + l31) % a.T;
+      const int nk = 3 * E.K16tap;                                         // k16 steps: (tap, group)
+      auto boff = [&](int k) { return ((((size_t)k * E.NT2 + wn) * 2 + lh) * 32 + l31) * 8; };
+      // one wave per SIMD is all there is here, so the weight stream is requested a whole block of NB k16 steps ahead (two register
+      // sets that swap roles; nk = 3 N1 / 16 is a multiple of 2 NB): one step ahead left every step waiting ~800 clocks for L2
+      constexpr int NB = W == 256 ? 8 : 6;             // nk = 48 / 24: a multiple of 2 NB either way (the host admits N1 = 256 with W = 256, 128 with 128)
+      uint4 pH[NB], pL[NB], qH[NB], qL[NB];
+      auto loadblk = [&](int k0, uint4 (&H)[NB], uint4 (&Lo)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) { const size_t o = boff(min(k0 + i, nk - 1)); H[i] = *reinterpret_cast<const uint4*>(gbh + o); Lo[i] = *reinterpret_cast<const uint4*>(gbl + o); }
+      };
+      auto mmablk = [&](int k0, const uint4 (&H)[NB], const uint4 (&Lo)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int k = k0 + i, j = k / E.K16tap, g = k - j * E.K16tap;
+          const bf16x8 bh8 = __builtin_bit_cast(bf16x8, H[i]), bl8 = __builtin_bit_cast(bf16x8, Lo[i]);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            const int off = ((wm * TM + tm) * 32 + l31 + j) * LDE + 16 * g + 8 * lh;
+            uint4 xh = *reinterpret_cast<const uint4*>(ehi + off), xl = *reinterpret_cast<const uint4*>(elo + off);
+            const int tt = tloc[tm] + j - 1;
+            const unsigned keep = ((tt >= 0) && (tt < a.T)) ? 0xffffffffu : 0u;
+            xh.x &= keep; xh.y &= keep; xh.z &= keep; xh.w &= keep; xl.x &= keep; xl.y &= keep; xl.z &= keep; xl.w &= keep;
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, xh), al = __builtin_bit_cast(bf16x8, xl);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh8, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl8, acc[tm], 0, 0, 0);
+            acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh8, acc[tm], 0, 0, 0);
+          }
+        }
+      };
+      loadblk(0, pH, pL);
+      for (int k0 = 0; k0 < nk; k0 += 2 * NB) {
+        loadblk(k0 + NB, qH, qL);
+        __builtin_amdgcn_sched_barrier(0);
+        mmablk(k0, pH, pL);
+        __builtin_amdgcn_sched_barrier(0);
+        loadblk(k0 + 2 * NB, pH, pL);
+        __builtin_amdgcn_sched_barrier(0);
+        mmablk(k0 + NB, qH, qL);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // epilogue: + bias -> BatchNorm affine -> + residual (+ per-row vector); the chain's input planes (zero beyond N2) and the carry registers
+    {
+      const float bi = (cin && gb2) ? gb2[col] : 0.f, sc = (cin && gs2) ? gs2[col] : 1.f, sh = (cin && gh2) ? gh2[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(rs[tm][r]));
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const float v = cin ? (acc[tm][r] + bi) * sc + sh + rs[tm][r] : 0.f;
+          xreg[tm][r] = v;
+          if (col < K0) {
+            const unsigned hp = taco_pk_bf16(v, 0.f) & 0xffffu;
+            const unsigned lp = taco_pk_bf16(v - __uint_as_float(hp << 16), 0.f) & 0xffffu;
+            xhi[rl * LDSW + col] = (unsigned short)hp;
+            xlo[rl * LDSW + col] = (unsigned short)lp;
+          }
+        }
+      have_x = true;
+    }
+  } else
   // ---- stage the input rows: fp32 -> (hi, lo) planes, zero padded to the first layer's K ----
   {
     const int K0 = a_in.L[0].K16 * 16;
@@ -120,10 +277,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       *reinterpret_cast<uint2*>(xlo + r * LDSW + c) = l4;
     }
   }
-  const int l31_outer = l31, lh_outer = lh;
   const bool full = m0 + CH_BM <= a.M;         // every row of the tile exists: the stores need no guards (the common case)
-  float xreg[TM][16];                          // the lane's slice of the current activation in fp32 (highway carry)
-  bool have_x = false;
   __syncthreads();
 
   for (int li = 0; li < a.nlayers; ++li) {

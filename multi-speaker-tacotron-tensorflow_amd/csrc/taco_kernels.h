@@ -379,7 +379,7 @@ __device__ long long taco_trace[64];
 // tap x k16 loop over sub-chunk ks, so all groups issue MFMAs at once (KS waves per SIMD hide each other's L2 latency), and the
 // partial accumulators are summed through LDS before the epilogue.
 template <int WM, int WN, int TM, int TN, bool DUAL, int GPI, int KS = 1>
-__global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
+__global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
   constexpr int NTHR = 64 * WM * WN * KS;
   constexpr int SUBSZ = 2 * (WM * TM * 32 + 15) * BF3_LDSW;     // bf16 elements of one sub-chunk tile (hi plane, then lo plane)
   constexpr int KCS = TACO_KC * KS;                              // channels per staging round
@@ -552,7 +552,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && !(DUAL &
     }
     TRC(trci); ++trci;
     const int c0 = cr + ks * TACO_KC;                                                  // this wave group's sub-chunk
-    const int npair = (c0 < v.cin_pad16) ? v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI) : 0;          // even
+    // (a wave whose column tiles all lie past the matrix -- N = 1025 leaves seven of the eight waves of the last column tile without
+    // a column -- takes part in the staging and its barriers only: no weight loads, no MFMAs)
+    const int npair = (c0 < v.cin_pad16 && ntile[0] < v.NT) ? v.kw * ((min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI) : 0;          // even
     for (int pi = 0; pi < npair; pi += 2) {
       // the scheduling barriers keep the loads ahead of the MFMA group they are meant to hide behind (left alone, the
       // scheduler sinks each load to just before its use to save registers)

@@ -150,6 +150,7 @@ struct taco_model {
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
+  int front_entry = 1;         // proj_1's epilogue + proj_2 inside the point-wise chain's entry (taco_chain.h) when the fused front ran
   int front_prio = 1; int front_delay = 0;      // shader clocks by which the second K half of a k_cbhg_front workgroup starts late (taco_front.h)
   int front = 1;               // conv bank -> max-pool -> proj_1 of a CBHG as one launch (taco_front.h); 0: bank and proj_1 as two k_gemm_bf3 launches
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
@@ -800,6 +801,8 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       if (g128 < 384 && !((Ktot >= 1024 || Nmax > 512) && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar >= 192)) tn = (g64 >= 384) ? 4 : 5;
       else if (Nmax <= 128) tn = 9;
       else tn = (!dual && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar <= 320) ? 10 : 7;   // few workgroups: two wave groups split K (16 waves/CU)
+      // (tile 11, 128 x 256 by 1 x 8 waves -- every weight fragment meets four row tiles -- measured SLOWER on the linear head, 116 vs 85 us:
+      // one workgroup of 8 waves per CU and three rounds of workgroups; selectable for A/B only)
     }
     if (dual) {
       if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, true>(st, a, nvar, kw_max, Nmax);
@@ -809,6 +812,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       if (tn == 3) return launch_gemm_bf3<2, 2, 1, 4, true>(st, a, nvar, kw_max, Nmax);
       return tn == 2 ? launch_gemm_bf3<2, 2, 2, 2, true>(st, a, nvar, kw_max, Nmax) : launch_gemm_bf3<2, 2, 2, 1, true>(st, a, nvar, kw_max, Nmax);
     }
+    if (tn == 11) return launch_gemm_bf3<1, 8, 4, 1, false>(st, a, nvar, kw_max, Nmax, 1);      // 128 x 256: every weight fragment meets four row tiles
     if (tn == 10) return launch_gemm_bf3<1, 8, 2, 1, false, 2>(st, a, nvar, kw_max, Nmax);
     if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, false>(st, a, nvar, kw_max, Nmax);
     if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, false>(st, a, nvar, kw_max, Nmax);
@@ -1103,8 +1107,9 @@ static bool chain_fits(const Cbhg& c, int in_dim) {
   return c.xproj.bh && c.xproj.cin == W && c.xproj.N == 6 * W;
 }
 static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int in_dim, int M, int T, const int* lengths,
-                     const CbhgWs& w, const float** ff_out) {
+                     const CbhgWs& w, const float** ff_out, const ChainEntry* entry = nullptr) {
   ChainArgs a; memset(&a, 0, sizeof a);
+  if (entry) a.e = *entry;
   a.x = x; a.ldx = in_dim; a.Cin = in_dim; a.out = w.xproj; a.ldo = 6 * c.rnn; a.rev_len = lengths; a.rev_col0 = 3 * c.rnn;
   a.M = M; a.T = T;
   if (ff_out) { a.y = w.hi0; a.ldy = c.rnn; *ff_out = w.hi0; }
@@ -1118,7 +1123,8 @@ static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const f
   for (int i = 0; i < c.depth; ++i) add(c.hw[i], CH_HIGHWAY);
   add(c.xproj, CH_XPROJ);
   const dim3 grid(cdiv(M, CH_BM)), blk(512);
-  const size_t lds = (size_t)2 * CH_BM * (c.rnn + 8) * sizeof(unsigned short);
+  size_t lds = (size_t)2 * CH_BM * (c.rnn + 8) * sizeof(unsigned short);
+  if (entry) lds += (size_t)2 * (CH_BM + 2) * (entry->N1 + 8) * sizeof(unsigned short);      // planes of proj_1's output (+ 1 frame each side)
   if (c.rnn == 256) hipLaunchKernelGGL((k_pointwise_chain<256>), grid, blk, lds, st, a);
   else hipLaunchKernelGGL((k_pointwise_chain<128>), grid, blk, lds, st, a);
   HIPCHK(hipGetLastError());
@@ -1130,7 +1136,7 @@ static bool front_usable(const taco_model* m, const Cbhg& c) {
   return m->bf3 && m->front && m->force_cfg < 0 && !m->bf3_tn && c.front_kind != 0 && !c.proj.empty() && c.proj[0].bh &&
          c.proj[0].cin == c.K * c.C && c.proj[0].cin_pad16 == c.K * c.C;
 }
-static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T, const CbhgWs& w) {
+static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T, const CbhgWs& w, bool combine, int* P_out) {
   FrArgs a; memset(&a, 0, sizeof a);
   const int TN = c.front_kind == 1 ? 2 : 1, cinp = c.front_kind == 1 ? 80 : 128, kwmax = c.front_kind == 1 ? 8 : 16;
   const ConvL& P1 = c.proj[0];
@@ -1187,6 +1193,8 @@ static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const f
   if (c.front_kind == 1) hipLaunchKernelGGL((k_cbhg_front<2, 80, 80, 8>), grid, blk, lds, st, a);      // (> 64 KB of LDS: attribute set at finalize)
   else hipLaunchKernelGGL((k_cbhg_front<1, 144, 128, 16>), grid, blk, lds, st, a);
   HIPCHK(hipGetLastError());
+  if (P_out) *P_out = P;
+  if (!combine) return 0;                  // the chain kernel's fused entry sums the parts itself (taco_chain.h)
   const size_t MN = (size_t)B * T * P1.N;
   hipLaunchKernelGGL(k_front_combine, dim3((unsigned)cdiv((int)(MN / 4), 256)), dim3(256), 0, st, (const float*)w.bank, P, MN, P1.N,
                      AP(m, P1.bias), AP(m, P1.bns), AP(m, P1.bnb), c.proj.size() > 1 ? 1 : 0, w.p[0]);
@@ -1205,9 +1213,17 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
   auto right = [](int k) { return k - 1 - (k - 1) / 2; };
   auto advance = [&](int win, int reach) { return win >= T ? T : std::max(0, win - reach); };
   // the whole window at once: bank -> max-pool -> proj_1 as ONE launch, the bank tensor never leaves the CU (taco_front.h)
+  // ... and with it proj_1's epilogue and proj_2 (+ residual) move into the entry of the point-wise chain: front + chain = the whole
+  // feed-forward part of a CBHG in two launches
+  bool entry = false; int parts = 1;
   if (avail >= T && pg.w_bank == 0 && pg.w_p[0] == 0 && front_usable(m, c)) {
-    TRY(run_front(m, st, c, x, B, T, w));
+    const bool chain_next = m->chain && c.proj.size() == 2 && chain_fits(c, c.proj[1].N);
+    const ConvL& P2 = c.proj.back();
+    entry = chain_next && m->front_entry && P2.bh && P2.kw == 3 && P2.cin == c.proj[0].N && P2.cin_pad16 == c.proj[0].N &&
+            c.proj[0].N == c.rnn && (c.rnn == 128 || c.rnn == 256) && P2.N <= c.rnn && c.in_dim == P2.N;     // (k16 steps of proj_2: 3 rnn / 16 = a multiple of the entry's block pairs)
+    TRY(run_front(m, st, c, x, B, T, w, !entry, &parts));
     pg.w_bank = T; pg.w_p[0] = T;
+    if (entry) pg.w_p[1] = T;
   }
   // conv bank: all K widths in one launch, written channel-concatenated (modules.py:35-44)
   { const int nw = advance(avail, right(c.K));
@@ -1242,9 +1258,20 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
   // point-wise chain: optional dense (modules.py:72-73), highway x depth (:76-77), hoisted BiGRU input projection
   const int wlast = pg.w_p[c.proj.size() - 1];
   const int t0 = pg.w_pt, tl = wlast - pg.w_pt;
+  if (entry && !(m->chain && t0 == 0 && tl == T && chain_fits(c, curd))) return fail(TACO_ERR_STATE, "fused chain entry planned but the chain kernel does not apply");
   if (m->bf3 && m->chain && m->force_cfg < 0 && !m->bf3_tn && t0 == 0 && tl == T && chain_fits(c, curd)) {
     // the whole tail as ONE launch, activations resident on the CU from layer to layer (taco_chain.h)
-    TRY(run_chain(m, st, c, cur, curd, M, T, lengths, w, ff_out));
+    ChainEntry E; memset(&E, 0, sizeof E);
+    if (entry) {
+      const ConvL& P1 = c.proj[0]; const ConvL& P2 = c.proj[1];
+      const GemmVar& v2 = m->hvars[P2.var_index];
+      E.part = w.bank; E.P = parts; E.MN = (size_t)M * P1.N; E.N1 = P1.N;
+      E.b1 = AP(m, P1.bias); E.s1 = AP(m, P1.bns); E.h1 = AP(m, P1.bnb); E.relu1 = 1;
+      E.bh = v2.bh; E.bl = v2.bl; E.NT2 = v2.NT; E.K16tap = P2.cin_pad16 / 16; E.N2 = P2.N;
+      E.b2 = AP(m, P2.bias); E.s2 = AP(m, P2.bns); E.h2 = AP(m, P2.bnb);
+      E.res = x; E.ldres = c.in_dim; E.rowvec = before_highway; E.ldrv = c.in_dim;
+    }
+    TRY(run_chain(m, st, c, cur, curd, M, T, lengths, w, ff_out, entry ? &E : nullptr));
     pg.w_pt = wlast;
     return 0;
   }
@@ -1980,6 +2007,7 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2037,6 +2065,7 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   m->bf3 = (on & 1) != 0; m->bf3_tn = tile_n;
   m->chain = (on & 4) ? 0 : 1;     // on = 5: split-bf16 GEMMs with one launch per point-wise layer (A/B of taco_chain.h)
   m->front = (on & 8) ? 0 : 1;     // on = 9: conv bank and proj_1 as two k_gemm_bf3 launches (A/B of taco_front.h)
+  m->front_entry = (on & 16) ? 0 : 1;   // on = 17: fused front, but k_front_combine and proj_2 as launches of their own (A/B of the chain's fused entry)
   return 0;
 }
 

@@ -627,7 +627,9 @@ def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_
         lin_ref = O.dense(post_ref, w, "linear")
     m = build_model(ohp, w)
     got = {}
-    for flag, name in ((1, "fused"), (9, "two launches"), (1, "fused again")):      # taco_debug_set_bf3 bit 3: front off
+    # taco_debug_set_bf3 bit 3: front off; bit 4: fused front, but proj_1's epilogue and proj_2 as launches of their own instead of the
+    # point-wise chain's fused entry (csrc/taco_chain.h)
+    for flag, name in ((1, "fused"), (17, "fused front, separate proj_2"), (9, "two launches"), (1, "fused again")):
         m._lib.taco_debug_set_bf3(m._handle, flag, 0)
         enc = m.encoder(ids, L)
         lin, post = m.postnet(mel, return_post=True)
@@ -641,9 +643,10 @@ def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_
         e = (maxabs(enc, enc_ref), maxabs(post, post_ref), maxabs(lin, lin_ref))
         print("%s: encoder %.2e  post %.2e  linear %.2e" % ((name,) + e))
         assert e[0] < 1e-4 and e[1] < 2e-4 and e[2] < 2e-4, (name, e)
-    d = [maxabs(a, b) for a, b in zip(got["fused"], got["two launches"])]
-    print("fused vs two launches: encoder %.2e  post %.2e  linear %.2e" % tuple(d))
-    assert max(d) < 3e-5, d
+    for other in ("two launches", "fused front, separate proj_2"):
+        d = [maxabs(a, b) for a, b in zip(got["fused"], got[other])]
+        print("fused vs %s: encoder %.2e  post %.2e  linear %.2e" % ((other,) + tuple(d)))
+        assert max(d) < 3e-5, (other, d)
     for a, b in zip(got["fused"], got["fused again"]):
         assert np.array_equal(a, b)
 

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_x, nx * 4)); CK(hipMalloc(&d_o, no * 4));
   { std::vector<float> h(nx); for (auto& v : h) v = urand() - 0.5f; CK(hipMemcpy(d_x, h.data(), nx * 4, hipMemcpyHostToDevice)); }
   printf("feed-forward layers of C2 through the op-level C ABI, %d timed calls each (us | TF-eq)\n", reps);
-  const int tiles[] = {1, 3, 4, 5, 7, 9, 10};
+  const int tiles[] = {1, 3, 4, 5, 7, 9, 10, 11};
   printf("%-36s %8s | %-15s | %-15s |", "layer", "GFLOP", "exact fp32", "split-bf16 auto");
   for (int tn : tiles) printf(" tile %-2d        |", tn);
   printf("\n");
