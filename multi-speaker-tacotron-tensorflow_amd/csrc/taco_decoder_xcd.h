@@ -539,7 +539,8 @@ __global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const i
     if (tracer && t < DX_TRACE_STEPS) a.trace[t * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
 
-template <int RG, bool TAPE = false>
+// MAN: the manual-attention instantiation (a.manual != null); the plain one carries none of its branches, loads or address selects
+template <int RG, bool TAPE = false, bool MAN = false>
 __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   extern __shared__ __attribute__((aligned(16))) float dx_smem[];
   DxArgs a = a_in;
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     rbl[i] = v;
   }
   const float sbias = (a.att_type == 2 && a.score_bias) ? a.score_bias[0] : 0.f;
-  const bool man = a.manual != nullptr;
+  constexpr bool man = MAN;
   const unsigned mrow_lds = (unsigned)(size_t)(dx_lds_float*)mrow;
   const unsigned tfb_lds = (unsigned)(size_t)(dx_lds_float*)tfb;
   if (TAPE) for (int i = tid; i < RG * DX_W; i += DX_NT) tfb[i] = 0.f;
@@ -721,6 +722,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     // loop invariant, and hoisted out of the loop it occupies (and spills) dozens of registers next to the resident weights
     int tid = tid_outer, lane = lane_outer;
     asm volatile("" : "+v"(tid), "+v"(lane));
+    int erow[RL];                  // (recomputed from the opaque lane: addresses derived from it -- mel / stop-flag / tape rows -- stay out of the hoisted set)
+#pragma unroll
+    for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
     DX_STAMP(0);
     if (man) {   // this step's manual alignments of the member's row -> LDS (consumed three exchanges from now)
       const float* src = a.manual + ((size_t)min(brow, a.B - 1) * a.n + t) * T;
@@ -813,9 +817,12 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       DX_STAMP(4);
       {  // partial scores over the member's channel block (A.9): a quad of lanes per encoder position, CH channels per lane
         const int jl = lane >> 2, cp = lane & 3;
-        float qreg[CH], vreg[CH];
+        constexpr bool QV_REG = CH < 16;     // (16 channels per lane = eight rows per group: the 32 registers are not there; read per use)
+        float qreg[QV_REG ? CH : 1], vreg[QV_REG ? CH : 1];
+        if constexpr (QV_REG) {
 #pragma unroll
-        for (int c = 0; c < CH; ++c) { qreg[c] = qv[cp * CH + c]; vreg[c] = vv[cp * CH + c]; }
+          for (int c = 0; c < CH; ++c) { qreg[c] = qv[cp * CH + c]; vreg[c] = vv[cp * CH + c]; }
+        }
         for (int j0 = 0; j0 < psn; j0 += 16 * DX_NW) {
           const int j = j0 + wave * 16 + jl;
           const int jc = j < psn ? j : psn - 1;
@@ -824,19 +831,30 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
           for (int c = 0; c < CH; c += 4) {
             const float4 k4 = *reinterpret_cast<const float4*>(kp + c);
-            e += vreg[c] * taco_tanh_fast(k4.x + qreg[c]) + vreg[c + 1] * taco_tanh_fast(k4.y + qreg[c + 1]) +
-                 vreg[c + 2] * taco_tanh_fast(k4.z + qreg[c + 2]) + vreg[c + 3] * taco_tanh_fast(k4.w + qreg[c + 3]);
+            if constexpr (QV_REG) {
+              e += vreg[c] * taco_tanh_fast(k4.x + qreg[c]) + vreg[c + 1] * taco_tanh_fast(k4.y + qreg[c + 1]) +
+                   vreg[c + 2] * taco_tanh_fast(k4.z + qreg[c + 2]) + vreg[c + 3] * taco_tanh_fast(k4.w + qreg[c + 3]);
+            } else {
+              const float4 q4 = *reinterpret_cast<const float4*>(qv + cp * CH + c), v4 = *reinterpret_cast<const float4*>(vv + cp * CH + c);
+              e += v4.x * taco_tanh_fast(k4.x + q4.x) + v4.y * taco_tanh_fast(k4.y + q4.y) +
+                   v4.z * taco_tanh_fast(k4.z + q4.z) + v4.w * taco_tanh_fast(k4.w + q4.w);
+            }
           }
           e = dx_quadsum(e);
           if (cp == 0 && j < psn) dx_publish(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
         }
       }
     }
-    // ahead of its turn: GRU 1 (concat projection folded in): h1 rows of the gates, then the h_att rows of r, u, candidate-x, o0
+    // ahead of its turn: GRU 1 (concat projection folded in): h1 rows of the gates, then the h_att rows of r, u, candidate-x, o0.
+    // With eight rows per group the 32 accumulators would have to live across the whole attention phase next to 138 resident weights:
+    // there they are formed after the context has arrived instead (two more passes on the critical path, no spilled registers).
+    constexpr bool G1_AHEAD = RG < 8;
     float g1a[4][RG];
     dx_zero<4, RG>(g1a);
-    dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
-    dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+    if (G1_AHEAD) {
+      dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
+      dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+    }
     int aoff = 0;                  // the step's alignments are sc[aoff + j]: computed (sc itself) or manual (mrow, a region of the same LDS array)
     if (!man) {
       {  // gather the row's partial scores and sum them over the Pc channel blocks (fixed order)
@@ -903,6 +921,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     // ================= concat projection folded into residual GRU 1 (rnn_wrappers.py:405-415; tacotron.py:166-172) =================
     {
       float s[4][RL];
+      if (!G1_AHEAD) {
+        dx_zero<4, RG>(g1a);
+        dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
+        dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+      }
       dx_pass<DXR_G1B, 4, RG>(W, st + DXS_CTX, lane, g1a);
       dx_reduce<4, RG>(g1a, s, lane);
       DX_STAMP(12);
@@ -940,9 +963,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     }
 #pragma unroll
     for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H2 + en];
-    float g2a[3][RG];          // GRU 2: r, u, candidate-x; the h2 rows run ahead of GRU 1's output
+    float g2a[3][RG];          // GRU 2: r, u, candidate-x; the h2 rows run ahead of GRU 1's output (not at eight rows per group: registers)
     dx_zero<3, RG>(g2a);
-    dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
+    if (G1_AHEAD) dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
     dx_gather<RG, DX_W, false>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
     dx_gather<RG, DX_W, false>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
     __syncthreads();
@@ -950,6 +973,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     // ================= residual GRU 2 =================
     {
       float s[3][RL];
+      if (!G1_AHEAD) dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
       dx_pass<DXR_G2X, 3, RG>(W, st + DXS_OUT1, lane, g2a);
       dx_reduce<3, RG>(g2a, s, lane);
 #pragma unroll
@@ -980,7 +1004,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     // ahead of its turn: next step's prenet layer 1, context rows
     float p1a[1][RG];
     dx_zero<1, RG>(p1a);
-    dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, p1a);
+    if (G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, p1a);
     dx_gather<RG, DX_W, true>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
     __syncthreads();
     DX_STAMP(10);
@@ -991,6 +1015,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       dx_zero<3, RG>(fa);
 #pragma unroll
       for (int r = 0; r < RG; ++r) fa[2][r] = p1a[0][r];
+      if (!G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
       dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[2][RG]>(fa));
       // prenet layer 1 of the next step: from this step's own output (frame projection folded into the registers), or -- teacher
       // forcing -- from the teacher's frame (raw kernel rows in the same registers, zero beyond num_mels)

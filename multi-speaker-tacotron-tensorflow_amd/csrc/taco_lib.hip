@@ -1422,7 +1422,10 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
 }
 template <int RG, bool TAPE>
 static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
-  hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
+  if constexpr (!TAPE) {
+    if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, true>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
+  }
+  hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE, false>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2019,6 +2022,10 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   m->events.resize(192);
   for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
