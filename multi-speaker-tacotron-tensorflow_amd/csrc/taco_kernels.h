@@ -1588,6 +1588,89 @@ __device__ __forceinline__ float taco_tanh_fast(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// k_bigru_quad : the H = 128 scan (encoder BiGRU, modules.py:82-96; A.6, A.7) with the K split kept inside a QUAD of lanes.
+// One workgroup = one (direction, batch row) chain, recurrent weights resident in registers as in k_bigru_res -- but thread
+// (unit j = 16 wave + lane / 4, K-slice q = lane & 3) keeps the four slices of a unit in four ADJACENT lanes: the partial sums
+// meet by two quad_perm DPP adds instead of a round trip through LDS and a barrier, every lane of the quad then holds the unit's
+// pre-activation and state (h stays in a register), and a step has two workgroup barriers (r*h visible, h visible) instead of four.
+// The transcendentals are the exp2 / rcp forms of the persistent kernels, the step's x-projection values are requested two steps
+// ahead (registers), the state vectors are padded so the four K-slices of a broadcast read fall on different banks.
+// Measured at C2 (B = 32, T = 128): k_bigru_res 0.93 us per step.
+__device__ __forceinline__ float taco_quadsum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float taco_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__global__ __launch_bounds__(512) void k_bigru_quad(const BigruSArgs a_in) {
+  constexpr int H = 128, KS = 32, SP = 36;          // K-slice q of the state lives at floats [q * SP, q * SP + 32)
+  __shared__ __attribute__((aligned(16))) float hs[4 * SP];
+  __shared__ __attribute__((aligned(16))) float xs[4 * SP];
+  BigruSArgs a = a_in;
+  PIN(a.xproj); PIN(a.g2_0); PIN(a.g2_1); PIN(a.c1_0); PIN(a.c1_1); PIN(a.h0); PIN(a.lengths); PIN(a.out); PIN(a.B); PIN(a.T);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = lane & 3, j = wave * 16 + (lane >> 2), k0 = q * KS;
+  const int d = blockIdx.x / a.B, b = blockIdx.x - d * a.B;
+  const int T = a.T;
+  const float2* G2 = d ? a.g2_1 : a.g2_0;
+  const float* C1 = d ? a.c1_1 : a.c1_0;
+  float2 wg[KS]; float wc[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i) { wg[i] = G2[(size_t)(k0 + i) * H + j]; wc[i] = C1[(size_t)(k0 + i) * H + j]; }
+  const int L = a.lengths ? a.lengths[b] : T;
+  float hj = a.h0 ? a.h0[(size_t)b * 2 * H + d * H + j] : 0.f;
+  const int pos = (j >> 5) * SP + (j & 31);        // where unit j sits in the padded state vectors
+  if (q == 0) hs[pos] = hj;
+  const float* xp = a.xproj + (size_t)b * T * 6 * H + d * 3 * H + j;
+  float* op = a.out + (size_t)b * T * 2 * H + d * H + j;
+  float xa[3], xb[3];
+  auto xload = [&](int s, float (&x)[3]) {
+    const float* p = xp + (size_t)min(s, T - 1) * 6 * H;       // (past the end: fetched again, never used)
+    x[0] = p[0]; x[1] = p[H]; x[2] = p[2 * H];
+  };
+  xload(0, xa); xload(1, xb);
+  __syncthreads();
+  auto step = [&](int s, const float (&x)[3]) {
+    // ---- gates: r, u of unit j over K-slice q, summed over the quad ----
+    taco_f32x2 g2 = {0.f, 0.f}, g3 = {0.f, 0.f};       // (r, u) partial sums: one v_pk_fma_f32 per state element, two independent chains
+#pragma unroll
+    for (int i = 0; i < KS; i += 4) {
+      const float4 h4 = *reinterpret_cast<const float4*>(&hs[q * SP + i]);
+      g2 = __builtin_elementwise_fma((taco_f32x2){h4.x, h4.x}, (taco_f32x2){wg[i].x, wg[i].y}, g2);
+      g3 = __builtin_elementwise_fma((taco_f32x2){h4.y, h4.y}, (taco_f32x2){wg[i + 1].x, wg[i + 1].y}, g3);
+      g2 = __builtin_elementwise_fma((taco_f32x2){h4.z, h4.z}, (taco_f32x2){wg[i + 2].x, wg[i + 2].y}, g2);
+      g3 = __builtin_elementwise_fma((taco_f32x2){h4.w, h4.w}, (taco_f32x2){wg[i + 3].x, wg[i + 3].y}, g3);
+    }
+    const float ar = taco_quadsum(g2.x + g3.x), au = taco_quadsum(g2.y + g3.y);
+    const float r = taco_sigmoid_fast(ar + x[0]), u = taco_sigmoid_fast(au + x[1]);
+    if (q == 0) xs[pos] = r * hj;
+    __syncthreads();
+    // ---- candidate ----
+    taco_f32x2 c2 = {0.f, 0.f}, c3 = {0.f, 0.f};       // even / odd K elements in two chains, summed at the end
+#pragma unroll
+    for (int i = 0; i < KS; i += 4) {
+      const float4 x4 = *reinterpret_cast<const float4*>(&xs[q * SP + i]);
+      c2 = __builtin_elementwise_fma((taco_f32x2){x4.x, x4.y}, (taco_f32x2){wc[i], wc[i + 1]}, c2);
+      c3 = __builtin_elementwise_fma((taco_f32x2){x4.z, x4.w}, (taco_f32x2){wc[i + 2], wc[i + 3]}, c3);
+    }
+    const float ac = taco_quadsum((c2.x + c2.y) + (c3.x + c3.y));
+    const float c = taco_tanh_fast(ac + x[2]);
+    const float hn = u * hj + (1.f - u) * c;
+    const bool active = s < L;                          // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+    const int t = (d && active) ? (L - 1 - s) : s;
+    if (active) hj = hn;
+    if (q == 0) { hs[pos] = hj; op[(size_t)t * 2 * H] = active ? hn : 0.f; }
+    __syncthreads();
+  };
+  int s = 0;
+#pragma unroll 1
+  for (; s + 1 < T; s += 2) {
+    step(s, xa); xload(s + 2, xa);
+    step(s + 1, xb); xload(s + 3, xb);
+  }
+  if (s < T) step(s, xa);
+}
+
 // One workgroup (8 waves) per batch row.  Everything a step needs from HBM/L2 -- the row's keys
 // [T_in, A] and values [T_in, D] -- is requested up front in two bursts (scores burst; values burst
 // before the serial normaliser), so a step costs ~one memory round trip plus the tanh/exp math.

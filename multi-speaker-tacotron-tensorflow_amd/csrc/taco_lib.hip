@@ -1054,6 +1054,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T;
     const dim3 grid(2 * B);
     if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, false>), grid, dim3(512), bigru_res_lds(256, 24, 1), st, a);
+    else if (m->persist == 1) hipLaunchKernelGGL(k_bigru_quad, grid, dim3(512), 0, st, a);       // quad-local K split: two barriers per step (persist 3: k_bigru_res)
     else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, false>), grid, dim3(512), bigru_res_lds(128, 0, 1), st, a);
     HIPCHK(hipGetLastError());
     return 0;
