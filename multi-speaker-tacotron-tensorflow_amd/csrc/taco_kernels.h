@@ -2048,7 +2048,9 @@ __global__ __launch_bounds__(64 * ATS_NW) void k_att_context(const AttnArgs a_in
 // stop rule of helpers.py:29 + TF dynamic_decode: a row is finished once a step's r*num_mels outputs are
 // all exactly 0; the loop ends after the first step at which every row is finished.
 // nz [n_steps, B] : 1 if row b emitted any non-zero at step t.
-__global__ __launch_bounds__(256) void k_stop_step(const int* nz, int B, int n_steps, int* stop) {
+// errw (nullable): the sticky device error word of the persistent kernels; when it is set the stop word becomes its negative (the
+// forward's own error latch, see latch_errors() in taco_lib.hip) -- the whole forward ends in this one launch
+__global__ __launch_bounds__(256) void k_stop_step(const int* nz, int B, int n_steps, int* stop, const unsigned* errw = nullptr) {
   // all loads independent (a per-row serial walk with an early exit was a chain of n_steps dependent cache misses: 34 us at C2)
   __shared__ int first[1024];     // first all-zero step of the rows of one chunk
   __shared__ int worst;
@@ -2068,7 +2070,10 @@ __global__ __launch_bounds__(256) void k_stop_step(const int* nz, int B, int n_s
     if (w) atomicMax(&worst, w);
     __syncthreads();
   }
-  if (tid == 0) *stop = min(worst + 1, n_steps);
+  if (tid == 0) {
+    const unsigned e = errw ? errw[0] : 0u;
+    *stop = e ? -(int)e : min(worst + 1, n_steps);
+  }
 }
 
 // see latch_errors() in taco_lib.hip

@@ -46,6 +46,19 @@ __global__ __launch_bounds__(256) void k_zero_fill(uint32_t* __restrict__ p, siz
   for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
   for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
 }
+// several regions in ONE launch (a forward clears the decoder's exchange buffers, the stop flags and the post-net scan's exchange
+// buffers up front: three fill launches and their graph edges less); every region 4-byte aligned and sized
+struct ZeroRegions { uint32_t* p[4]; unsigned long long nw[4]; };
+__global__ void k_zero_fill_multi(const ZeroRegions z) {
+  uint32_t* p = z.p[blockIdx.y];
+  const size_t nw = z.nw[blockIdx.y];
+  const size_t n16 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : nw / 4;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
+}
+static thread_local bool g_precleared = false;   // set by forward_enqueue around its stages: their own clears have been done by the one launch
 static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
   if (!bytes) return hipSuccess;
   if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, st);
@@ -966,7 +979,7 @@ static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
   a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
   int RG = 1;
   while (RG * DX_NGROUP < B) RG *= 2;
-  HIPCHK(zero_async(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
+  if (!g_precleared) HIPCHK(zero_async(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
   const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
   if (gsave) {
@@ -1458,7 +1471,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.mels = m->hp.num_mels;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
-  HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
+  if (!g_precleared) HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
   const size_t lds = dx_lds_floats(RG, T_in, tape != nullptr) * sizeof(float);
   if (tape) {
     switch (RG) {
@@ -1528,7 +1541,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   const int Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
   const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
   const int dbgw = As + D + L * Hd;
-  HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
+  if (!g_precleared) HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
     // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
     // vectors); the launch-per-stage loop below is the general path
@@ -1694,14 +1707,29 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   FullWs w;
   carve_full(cv, m, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);
-  TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
   const int r = m->hp.reduction_factor, T_mel = n * r;
   const int CH = m->overlap > 16 ? m->overlap : 16;   // decoder steps per post-net chunk
   if (!m->overlap || (size_t)(n / CH + 4) > m->events.size()) {
-    TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, stop, nullptr, w.dec, true, &w.enc.spk));
+    // every word a persistent kernel polls and the stop flags, cleared by ONE launch in front of the forward; the stop rule and the
+    // error latch are ONE launch behind it (16 graph nodes at C2; 20 in round 3)
+    ZeroRegions z; memset(&z, 0, sizeof z);
+    z.p[0] = (uint32_t*)w.dec.xbuf; z.nw[0] = ((size_t)((char*)w.dec.dxctl - (char*)w.dec.xbuf) + 256) / 4;
+    z.p[1] = (uint32_t*)w.dec.nz; z.nw[1] = (size_t)n * B;
+    z.p[2] = (uint32_t*)w.post.cb.gxbuf; z.nw[2] = ((size_t)((char*)w.post.cb.gxctl - (char*)w.post.cb.gxbuf) + 256) / 4;
+    z.p[3] = (uint32_t*)w.enc.cb.gxbuf; z.nw[3] = ((size_t)((char*)w.enc.cb.gxctl - (char*)w.enc.cb.gxbuf) + 256) / 4;     // (an encoder of width 256 scans on k_bigru_duo too)
+    hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
+    HIPCHK(hipGetLastError());
+    struct Guard { Guard() { g_precleared = true; } ~Guard() { g_precleared = false; } } guard;
+    TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
+    TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, nullptr, nullptr, w.dec, true, &w.enc.spk));
     TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
-    return latch_errors(m, st, stop);
+    if (stop) {
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, (const int*)w.dec.nz, B, n, stop, (const unsigned*)m->d_err);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
   }
+  TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
   // The decoder loop is a chain of tiny dependent launches that occupies < 1/5 of the CUs; the post-net's
   // feed-forward stages (conv bank, projections, highways, hoisted GRU projection: ~1.3 ms of fp32 MFMA work @C2)
   // need only frames that already exist plus a conv halo.  They run on a second stream, one chunk of CH steps

@@ -20,6 +20,12 @@ timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.er
 timeout 300 python tools/time_manual.py 2>&1 | grep -v amdgpu.ids > $out/time_manual.txt
 timeout 300 python tools/overlap_scan_ff.py 2>&1 | grep -v amdgpu.ids > $out/overlap_scan_ff.txt
 timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $out/time_stages.txt
+# round 4: the fused CBHG front (k_cbhg_front): feed-forward time of both stages with the front on / off and per start delay / priority, phase
+# timeline of one workgroup (needs the -DTACO_TRACE build next to the library), per-layer timings, the C4 line of bench.py
+timeout 300 python tools/time_front.py 2>&1 | grep -v amdgpu.ids > $out/time_front.txt
+[ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_front.py 2>&1 | grep -v amdgpu.ids > $out/front_timeline.txt
+[ -x tools/time_layers_native ] && timeout 120 ./tools/time_layers_native 20 > $out/time_layers_native.txt 2>&1
+timeout 600 python bench.py --workload C4 --steps 10 --warmup 2 > $out/bench_C4.json 2>> $out/bench_C2.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/tks -o tks --output-format csv -- python tools/bench_train.py --steps 4 --warmup 1 > $out/tks.log 2>&1
 cp $out/tks/*kernel_stats.csv $out/train_kernel_stats.csv 2>/dev/null; rm -rf $out/tks
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
