@@ -217,7 +217,7 @@ def train_step_report(steps, warmup, **switches):
     """BASELINE.json configs[3] (C4), one shard: the train.py step (train.py:215-219: forward with tape, loss, backward, clip + Adam) at
     B=32, T_in=128, T_out=512 per GPU, timed by tools/bench_train.py's measure() (ms per step, phase split, engine flags, FLOP roofline)."""
     import argparse as _ap
-    ns = _ap.Namespace(steps=steps, warmup=warmup, batch=32, t_in=128, t_out=512, graph=0, engine=1, bptt=1, exact_gemm=3, exact_wgrad=0,
+    ns = _ap.Namespace(steps=steps, warmup=warmup, batch=32, t_in=128, t_out=512, graph=0, engine=1, bptt=1, exact_gemm=4, exact_wgrad=0,
                        deterministic=0, sync_bn=0)
     for k, v in switches.items():
         setattr(ns, k, v)
@@ -261,7 +261,7 @@ def train_step_line(args):
     out = {"metric": "target mel-frames/sec through one train step (forward + backward + update)", "value": rep["target_frames_per_s"],
            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 storage and accumulation; forward GEMMs exact-fp32 MFMA, data / weight gradients on split-bf16 MFMA (3 / 6 products, fp32-grade)",
+           "dtype": "f32 storage and accumulation; forward GEMMs and weight gradients on split-bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients split in two (3 products); recurrent parts exact fp32",
            "data": "synthetic", "world_size_seen": rep["world_size_seen"],
            "config": {"workload": rep["config"]["workload"], "global_batch": world * B, "parallelism": rep["config"]["parallelism"],
                       "launch": rep["launch"]},

@@ -217,13 +217,16 @@ int taco_train_set_exact_wgrad(taco_train* t, int on);
  * linear head) and their data gradients.  k_gemm = exact-fp32 MFMA; k_gemm_bf3 = the inference kernels: bf16 matrix cores, both
  * operands split in two, three products per tile (~2^-17 per product, fp32 accumulation), weight planes re-split on the device from
  * the live parameters by taco_train_refresh (k_bf3_gather).
- *   on = 3 (default): forward on k_gemm, data gradients on k_gemm_bf3.  The forward -- and with it every ReLU / max-pool decision and
+ *   on = 3 (the default of rounds 2-3): forward on k_gemm, data gradients on k_gemm_bf3.  The forward -- and with it every ReLU / max-pool decision and
  *          every BatchNorm statistic -- is exact; a data gradient is linear in dY, and the split costs 4e-6 of the gradient norm
  *          against the all-exact step (measured; tensor by tensor <= 4e-5 of the tensor's scale).  9 % off the C4-shard step.
  *   on = 1: everything on k_gemm (rounds 1-2).
  *   on = 0: everything on k_gemm_bf3: 16 % off the step; the forward's ~1e-5 relative product error is amplified by the BatchNorm
  *          backward's cancellations to ~1e-3 of the gradient norm and resolves near-ties differently.
  *   on = 2: forward k_gemm_bf3, data gradients k_gemm (A/B hook).
+ *   on = 4 (default since round 4): forward on the SIX-product instantiation of k_gemm_bf3 (every operand split three ways, hi + lo + l3 = 24 mantissa bits;
+ *          l3*hi, hi*l3, lo*lo, lo*hi, hi*lo, hi*hi accumulated in fp32: 2^-24 per product, fp32-grade, as k_wgrad_bf3), data
+ *          gradients as in mode 3: the forward leaves the fp32-input MFMA (1/16 of the bf16 rate) without touching its decisions.
  * Call taco_train_refresh after switching (the planes are generated only while an engine that needs them is selected). */
 int taco_train_set_exact_gemm(taco_train* t, int on);
 /* Back-propagation through the decoder loop (tf.gradients of rnn_wrappers.py:218-341 under train.py:215-219): persistent = 1 (default)

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_pack_gather(const float* __restrict__ m
 // The split-bf16 packs of the training model (k_gemm_bf3 operands) from the live parameters: element e of the concatenated index
 // list belongs to the segment s with segs[s].start <= e < start + count and becomes hi = bf16(w), lo = bf16(w - hi) at position
 // e - start of the segment's two arrays (the same split pack_bf3 does on the host for inference).
-struct Bf3Seg { unsigned start, count; unsigned long long hi, lo; };   // [start, start + count) of the index list -> bf16 arrays at arena float offsets hi / lo
+struct Bf3Seg { unsigned start, count; unsigned long long hi, lo, l3; };   // [start, start + count) of the index list -> bf16 arrays at arena float offsets hi / lo / l3 (third plane: bf16(w - hi - lo))
 __device__ __forceinline__ unsigned short bf16_rne_dev(float f) {
   const unsigned u = __float_as_uint(f);
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_bf3_gather(const unsigned* __restrict__
     const size_t k = e - sg.start;
     reinterpret_cast<unsigned short*>(arena + sg.hi)[k] = hb;
     reinterpret_cast<unsigned short*>(arena + sg.lo)[k] = lb;
+    reinterpret_cast<unsigned short*>(arena + sg.l3)[k] = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16) - __uint_as_float((unsigned)lb << 16));
   }
 }
 // The concat projection folded into decoder GRU 1 (taco_model_finalize does it on the host, in double, for inference):

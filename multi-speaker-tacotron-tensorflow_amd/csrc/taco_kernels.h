@@ -84,6 +84,8 @@ struct GemmVar {
   // split-bf16 packs (k_gemm_bf3): hi/lo bf16 halves of the same weights, fragment-native for 32x32x16 MFMA
   const unsigned short* bh; const unsigned short* bl; const unsigned short* bh2; const unsigned short* bl2;
   int K16, cin_pad16;     // k16 groups per n-tile = kw*cin_pad16/16
+  // third planes (training shadow model only): l3 = bf16(w - hi - lo), the operand of the six-product (fp32-grade) instantiation X6
+  const unsigned short* bl3; const unsigned short* bl3_2;
 };
 
 struct GemmArgs {
@@ -378,10 +380,14 @@ __device__ long long taco_trace[64];
 // workgroup.  Every staging round brings in KS consecutive 64-channel sub-chunks (one LDS tile each); group ks runs the same
 // tap x k16 loop over sub-chunk ks, so all groups issue MFMAs at once (KS waves per SIMD hide each other's L2 latency), and the
 // partial accumulators are summed through LDS before the epilogue.
-template <int WM, int WN, int TM, int TN, bool DUAL, int GPI, int KS = 1>
-__global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
+// X6: every operand split THREE ways (hi, lo, l3 = bf16(x - hi - lo): 24 mantissa bits) and six products per k16 group -- l3*hi, hi*l3,
+// lo*lo, lo*hi, hi*lo, hi*hi, as k_wgrad_bf3 -- i.e. fp32-grade products on the bf16 pipe (2^-24 per product instead of 2^-16): the
+// forward GEMMs of the TRAINING step, whose ReLU / max-pool decisions must not differ from fp32's (taco_train_set_exact_gemm mode 4).
+template <int WM, int WN, int TM, int TN, bool DUAL, int GPI, int KS = 1, bool X6 = false>
+__global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 && !X6 && !(DUAL && TM * TN >= 4)) ? 2 : 1) void k_gemm_bf3(const GemmArgs a_in) {
   constexpr int NTHR = 64 * WM * WN * KS;
-  constexpr int SUBSZ = 2 * (WM * TM * 32 + 15) * BF3_LDSW;     // bf16 elements of one sub-chunk tile (hi plane, then lo plane)
+  constexpr int NPL = X6 ? 3 : 2;                                  // planes of a staged tile
+  constexpr int SUBSZ = NPL * (WM * TM * 32 + 15) * BF3_LDSW;     // bf16 elements of one sub-chunk tile (hi plane, then lo plane[, then l3])
   constexpr int KCS = TACO_KC * KS;                              // channels per staging round
 #ifdef TACO_TRACE
   const bool trc = (blockIdx.x == gridDim.x / 2) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
   PIN(a.ldx); PIN(a.M); PIN(a.T); PIN(a.Cin); PIN(a.mpw); PIN(a.act); PIN(a.ldres); PIN(a.ldrv); PIN(a.ldo); PIN(a.vec_ok);
   PIN(a.rev_col0); PIN(a.t_begin); PIN(a.t_len); PIN(a.tiles_per_b);
   GemmVar v = a_in.v[blockIdx.z];
-  PIN(v.bias); PIN(v.bias2); PIN(v.bn_scale); PIN(v.bn_shift); PIN(v.bh); PIN(v.bl); PIN(v.bh2); PIN(v.bl2);
+  PIN(v.bias); PIN(v.bias2); PIN(v.bn_scale); PIN(v.bn_shift); PIN(v.bh); PIN(v.bl); PIN(v.bh2); PIN(v.bl2); PIN(v.bl3); PIN(v.bl3_2);
   PIN(v.kw); PIN(v.padl); PIN(v.NT); PIN(v.N); PIN(v.coff); PIN(v.K16); PIN(v.cin_pad16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -415,6 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
   unsigned short* tall = reinterpret_cast<unsigned short*>(smem);
   unsigned short* thi = tall + (size_t)ks * SUBSZ;                 // this wave group's tile
   unsigned short* tlo = thi + (size_t)(BM + 15) * BF3_LDSW;
+  unsigned short* tl3 = tlo + (size_t)(BM + 15) * BF3_LDSW;       // (X6 only)
 
   int tloc[TM];
 #pragma unroll
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) ntc[tn] = min(ntile[tn], v.NT - 1);
   auto load_grp = [&](int c0, int pi, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
-                      uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+                      uint4 (&ul2)[GPI][DUAL ? TN : 1], uint4 (&u3)[GPI][X6 ? TN : 1], uint4 (&u32)[GPI][(X6 && DUAL) ? TN : 1]) {
     const int gpc = (min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI;      // groups per tap in this chunk
     const int j = pi / gpc, g0 = GPI * (pi - j * gpc);
 #pragma unroll
@@ -475,25 +482,26 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
         const size_t off = ((((size_t)k16 * v.NT + ntc[tn]) * 2 + lh) * 32 + l31) * 8;
         uh[h][tn] = *reinterpret_cast<const uint4*>(v.bh + off); ul[h][tn] = *reinterpret_cast<const uint4*>(v.bl + off);
         if constexpr (DUAL) { uh2[h][tn] = *reinterpret_cast<const uint4*>(v.bh2 + off); ul2[h][tn] = *reinterpret_cast<const uint4*>(v.bl2 + off); }
+        if constexpr (X6) { u3[h][tn] = *reinterpret_cast<const uint4*>(v.bl3 + off); if constexpr (DUAL) u32[h][tn] = *reinterpret_cast<const uint4*>(v.bl3_2 + off); }
       }
     }
   };
   // the group after (c0, pi): next one of this chunk, first one of the next chunk, or (end of K) this one again
   auto load_next = [&](int c0, int pi, int npair, uint4 (&uh)[GPI][TN], uint4 (&ul)[GPI][TN], uint4 (&uh2)[GPI][DUAL ? TN : 1],
-                       uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+                       uint4 (&ul2)[GPI][DUAL ? TN : 1], uint4 (&u3)[GPI][X6 ? TN : 1], uint4 (&u32)[GPI][(X6 && DUAL) ? TN : 1]) {
     int nc0 = c0, npi = pi + 1;
     if (npi == npair) { nc0 = c0 + KCS; npi = 0; }
     if (nc0 >= v.cin_pad16) { nc0 = c0; npi = pi; }
-    load_grp(nc0, npi, uh, ul, uh2, ul2);
+    load_grp(nc0, npi, uh, ul, uh2, ul2, u3, u32);
   };
   auto mma_grp = [&](int c0, int pi, const uint4 (&uh)[GPI][TN], const uint4 (&ul)[GPI][TN], const uint4 (&uh2)[GPI][DUAL ? TN : 1],
-                     const uint4 (&ul2)[GPI][DUAL ? TN : 1]) {
+                     const uint4 (&ul2)[GPI][DUAL ? TN : 1], const uint4 (&u3)[GPI][X6 ? TN : 1], const uint4 (&u32)[GPI][(X6 && DUAL) ? TN : 1]) {
     const int gpc = (min(TACO_KC, v.cin_pad16 - c0) >> 4) / GPI;
     const int j = pi / gpc, g0 = GPI * (pi - j * gpc);
 #pragma unroll
     for (int h = 0; h < GPI; ++h) {
       const int g = g0 + h;
-      bf16x8 ah[TM], al[TM];
+      bf16x8 ah[TM], al[TM], a3[X6 ? TM : 1];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         const int srow = (wm * TM + tm) * 32 + l31 + j;
@@ -503,28 +511,44 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
         const unsigned keep = ((tt >= 0) && (tt < a.T)) ? 0xffffffffu : 0u;
         xh.x &= keep; xh.y &= keep; xh.z &= keep; xh.w &= keep; xl.x &= keep; xl.y &= keep; xl.z &= keep; xl.w &= keep;
         ah[tm] = __builtin_bit_cast(bf16x8, xh); al[tm] = __builtin_bit_cast(bf16x8, xl);
+        if constexpr (X6) {
+          uint4 x3 = *reinterpret_cast<const uint4*>(tl3 + off);
+          x3.x &= keep; x3.y &= keep; x3.z &= keep; x3.w &= keep;
+          a3[tm] = __builtin_bit_cast(bf16x8, x3);
+        }
       }
       // term-major order: the TM*TN independent accumulators sit between two MFMAs on the same accumulator
+      constexpr int NTERM = X6 ? 6 : 3;
 #pragma unroll
-      for (int term = 0; term < 3; ++term)
+      for (int term = 0; term < NTERM; ++term)
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
             const bf16x8 bh = __builtin_bit_cast(bf16x8, uh[h][tn]), bl = __builtin_bit_cast(bf16x8, ul[h][tn]);
-            const bf16x8 aa = (term == 0) ? al[tm] : ah[tm];          // small terms first: al*bh, ah*bl, ah*bh
-            const bf16x8 bb = (term == 1) ? bl : bh;
+            bf16x8 aa, bb;
+            if constexpr (X6) {      // small terms first: a3*bh, ah*b3, al*bl, al*bh, ah*bl, ah*bh
+              const bf16x8 b3 = __builtin_bit_cast(bf16x8, u3[h][tn]);
+              aa = (term == 0) ? a3[tm] : (term == 2 || term == 3) ? al[tm] : ah[tm];
+              bb = (term == 1) ? b3 : (term == 2 || term == 4) ? bl : bh;
+            } else {                 // al*bh, ah*bl, ah*bh
+              aa = (term == 0) ? al[tm] : ah[tm];
+              bb = (term == 1) ? bl : bh;
+            }
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb, acc[tm][tn], 0, 0, 0);
             if constexpr (DUAL) {
               const bf16x8 bh2 = __builtin_bit_cast(bf16x8, uh2[h][tn]), bl2 = __builtin_bit_cast(bf16x8, ul2[h][tn]);
-              acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, (term == 1) ? bl2 : bh2, acc2[tm][tn], 0, 0, 0);
+              bf16x8 bb2;
+              if constexpr (X6) { const bf16x8 b32 = __builtin_bit_cast(bf16x8, u32[h][tn]); bb2 = (term == 1) ? b32 : (term == 2 || term == 4) ? bl2 : bh2; }
+              else bb2 = (term == 1) ? bl2 : bh2;
+              acc2[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aa, bb2, acc2[tm][tn], 0, 0, 0);
             }
           }
     }
   };
-  uint4 pbh[GPI][TN], pbl[GPI][TN], pbh2[GPI][DUAL ? TN : 1], pbl2[GPI][DUAL ? TN : 1];     // set P
-  uint4 qbh[GPI][TN], qbl[GPI][TN], qbh2[GPI][DUAL ? TN : 1], qbl2[GPI][DUAL ? TN : 1];     // set Q
-  load_grp((ks * TACO_KC < v.cin_pad16) ? ks * TACO_KC : 0, 0, pbh, pbl, pbh2, pbl2);
+  uint4 pbh[GPI][TN], pbl[GPI][TN], pbh2[GPI][DUAL ? TN : 1], pbl2[GPI][DUAL ? TN : 1], pb3[GPI][X6 ? TN : 1], pb32[GPI][(X6 && DUAL) ? TN : 1];     // set P
+  uint4 qbh[GPI][TN], qbl[GPI][TN], qbh2[GPI][DUAL ? TN : 1], qbl2[GPI][DUAL ? TN : 1], qb3[GPI][X6 ? TN : 1], qb32[GPI][(X6 && DUAL) ? TN : 1];     // set Q
+  load_grp((ks * TACO_KC < v.cin_pad16) ? ks * TACO_KC : 0, 0, pbh, pbl, pbh2, pbl2, pb3, pb32);
   int trci = 3;
   TRC(2);
   for (int cr = 0; cr < v.cin_pad16; cr += KCS) {
@@ -540,6 +564,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
         const int off = (cq / (TACO_KC / 4)) * SUBSZ + (idx / (KCS / 4)) * BF3_LDSW + 4 * (cq % (TACO_KC / 4));
         *reinterpret_cast<uint2*>(tall + off) = h4;
         *reinterpret_cast<uint2*>(tall + off + (BM + 15) * BF3_LDSW) = l4;
+        if constexpr (X6) {       // third plane: what hi + lo leave of x
+          const float4 f = pre[u];
+          uint2 t4;
+          t4.x = taco_pk_bf16(f.x - __uint_as_float(h4.x << 16) - __uint_as_float(l4.x << 16),
+                              f.y - __uint_as_float(h4.x & 0xffff0000u) - __uint_as_float(l4.x & 0xffff0000u));
+          t4.y = taco_pk_bf16(f.z - __uint_as_float(h4.y << 16) - __uint_as_float(l4.y << 16),
+                              f.w - __uint_as_float(h4.y & 0xffff0000u) - __uint_as_float(l4.y & 0xffff0000u));
+          *reinterpret_cast<uint2*>(tall + off + 2 * (BM + 15) * BF3_LDSW) = t4;
+        }
       }
     }
     __syncthreads();
@@ -558,13 +591,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS, (KS == 1 && GPI == 1 && TM < 4 &
     for (int pi = 0; pi < npair; pi += 2) {
       // the scheduling barriers keep the loads ahead of the MFMA group they are meant to hide behind (left alone, the
       // scheduler sinks each load to just before its use to save registers)
-      load_next(c0, pi, npair, qbh, qbl, qbh2, qbl2);
+      load_next(c0, pi, npair, qbh, qbl, qbh2, qbl2, qb3, qb32);
       __builtin_amdgcn_sched_barrier(0);
-      mma_grp(c0, pi, pbh, pbl, pbh2, pbl2);
+      mma_grp(c0, pi, pbh, pbl, pbh2, pbl2, pb3, pb32);
       __builtin_amdgcn_sched_barrier(0);
-      load_next(c0, pi + 1, npair, pbh, pbl, pbh2, pbl2);
+      load_next(c0, pi + 1, npair, pbh, pbl, pbh2, pbl2, pb3, pb32);
       __builtin_amdgcn_sched_barrier(0);
-      mma_grp(c0, pi + 1, qbh, qbl, qbh2, qbl2);
+      mma_grp(c0, pi + 1, qbh, qbl, qbh2, qbl2, qb3, qb32);
       __builtin_amdgcn_sched_barrier(0);
     }
   }

@@ -98,6 +98,7 @@ struct ConvL {  // a k_gemm layer (conv1d+BN, dense, highway, hoisted GRU input 
   int kw = 1, cin = 0, cin_pad = 0, N = 0;
   size_t wp = 0, wp2 = 0, bias = 0, bias2 = 0, bns = 0, bnb = 0;  // arena offsets (+1; 0 = absent)
   size_t bh = 0, bl = 0, bh2 = 0, bl2 = 0;                          // split-bf16 packs (k_gemm_bf3), 0 = not built
+  size_t bl3 = 0, bl3_2 = 0;                                       // third planes (training shadow model: the six-product instantiation)
   int K16 = 0, cin_pad16 = 0;
   int var_index = -1;                                              // index into the device GemmVar array
 };
@@ -161,6 +162,7 @@ struct taco_model {
   unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
   int persist = 1;             // use the persistent BiGRU kernel when it fits
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
+  int bf3x6 = 0;               // training shadow model: feed-forward GEMMs on the six-product (fp32-grade) split-bf16 instantiation
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
   int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
   int front_entry = 1;         // proj_1's epilogue + proj_2 inside the point-wise chain's entry (taco_chain.h) when the fused front ran
@@ -304,7 +306,7 @@ static unsigned short bf16_rne_host(float x) {
   unsigned u; memcpy(&u, &x, 4);
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
-static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size_t* hi_out, size_t* lo_out, int* K16_out, int* cp16_out) {
+static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size_t* hi_out, size_t* lo_out, int* K16_out, int* cp16_out, size_t* l3_out = nullptr) {
   const int cp16 = rup(cin, 32), K16 = kw * cp16 / 16, NT = cdiv(N, 32);   // multiple of 32: k_gemm_bf3 walks k16 groups in pairs
   std::vector<unsigned short> hi((size_t)NT * K16 * 2 * 32 * 8, 0), lo(hi.size(), 0);
   std::vector<unsigned> idx(m->tp ? hi.size() : 0, 0u);
@@ -331,7 +333,10 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
   };
   *hi_out = put(hi); *lo_out = put(lo); *K16_out = K16; *cp16_out = cp16;
   if (m->tp) {
-    m->bf3_segs.push_back(Bf3Seg{(unsigned)m->bf3_idx.size(), (unsigned)idx.size(), (unsigned long long)(*hi_out - 1), (unsigned long long)(*lo_out - 1)});
+    // third plane (zeros here: k_bf3_gather fills all three from the live parameters): the operand of the six-product instantiation
+    const size_t l3 = put(std::vector<unsigned short>(hi.size(), 0));
+    if (l3_out) *l3_out = l3;
+    m->bf3_segs.push_back(Bf3Seg{(unsigned)m->bf3_idx.size(), (unsigned)idx.size(), (unsigned long long)(*hi_out - 1), (unsigned long long)(*lo_out - 1), (unsigned long long)(l3 - 1)});
     m->bf3_idx.insert(m->bf3_idx.end(), idx.begin(), idx.end());
   }
 }
@@ -364,7 +369,7 @@ static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has
   else { L.kw = 1; L.cin = (int)k.shape[0]; L.N = (int)k.shape[1]; }
   int Kq, NT;
   L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
-  if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16);
+  if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16, &L.bl3);
   if (has_bias) L.bias = arena_put(m, T_(m, name + "/bias").data.data(), L.N);
   if (bn) {  // BatchNorm inference folded to y*scale + shift (A.2; epsilon 1e-3 = tf.layers default)
     const auto& g = T_(m, name + "/gamma").data; const auto& b = T_(m, name + "/beta").data;
@@ -567,7 +572,7 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
     const std::string n = sc + "/highway_" + std::to_string(i + 1);
     ConvL L = make_conv(m, n + "/H", false, true, bf3);
     ConvL Tt = make_conv(m, n + "/T", false, true, bf3);
-    L.wp2 = Tt.wp; L.bias2 = Tt.bias; L.bh2 = Tt.bh; L.bl2 = Tt.bl;
+    L.wp2 = Tt.wp; L.bias2 = Tt.bias; L.bh2 = Tt.bh; L.bl2 = Tt.bl; L.bl3_2 = Tt.bl3;
     c.hw.push_back(L);
     m->convs[n] = L;
   }
@@ -666,7 +671,7 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
   X.wp = pack_w32(m, Wx.data(), 1, I, 6 * H, &X.cin_pad, &Kq, &NT);
-  if (bf3) pack_bf3(m, Wx.data(), 1, I, 6 * H, &X.bh, &X.bl, &X.K16, &X.cin_pad16);
+  if (bf3) pack_bf3(m, Wx.data(), 1, I, 6 * H, &X.bh, &X.bl, &X.K16, &X.cin_pad16, &X.bl3);
   X.bias = arena_put(m, bx.data(), 6 * H);
   c.xproj = X;
   // fused front (taco_front.h): inference models only (the training forward needs the bank tensor for its batch statistics)
@@ -711,6 +716,7 @@ static int add_var(taco_model* m, ConvL& L, int coff) {
   v.wp = (const float*)L.wp; v.wp2 = (const float*)L.wp2; v.bias = (const float*)L.bias; v.bias2 = (const float*)L.bias2;
   v.bn_scale = (const float*)L.bns; v.bn_shift = (const float*)L.bnb;
   v.bh = (const unsigned short*)L.bh; v.bl = (const unsigned short*)L.bl; v.bh2 = (const unsigned short*)L.bh2; v.bl2 = (const unsigned short*)L.bl2;
+  v.bl3 = (const unsigned short*)L.bl3; v.bl3_2 = (const unsigned short*)L.bl3_2;
   v.K16 = L.K16; v.cin_pad16 = L.cin_pad16;
   v.kw = L.kw; v.padl = (L.kw - 1) / 2; v.Kq = L.kw * L.cin_pad / 4; v.NT = cdiv(L.N, 32); v.N = L.N; v.coff = coff;
   L.var_index = (int)m->hvars.size();
@@ -746,10 +752,10 @@ static int launch_gemm_cfg(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   return 0;
 }
 
-template <int WM, int WN, int TM, int TN, bool DUAL, int KS = 1>
+template <int WM, int WN, int TM, int TN, bool DUAL, int KS = 1, bool X6 = false>
 static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_max, int Nmax, int gpi = 0) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  size_t lds = (size_t)KS * 2 * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
+  size_t lds = (size_t)KS * (X6 ? 3 : 2) * (BM + 15) * BF3_LDSW * sizeof(unsigned short);
   if (KS > 1) lds = std::max(lds, (size_t)(KS - 1) * WM * WN * TM * TN * 16 * 64 * (DUAL ? 2 : 1) * sizeof(float));   // split-K reduction
   GemmArgs aa = a;
   int gx = cdiv(a.M, BM);
@@ -758,8 +764,13 @@ static int launch_gemm_bf3(hipStream_t st, const GemmArgs& a, int nvar, int kw_m
   dim3 grid(gx, cdiv(Nmax, BN), nvar);
   if constexpr (KS > 1) {
     static bool attr_set = false;      // > 64 KB of dynamic LDS has to be asked for once per kernel
-    if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
-    hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS>), grid, dim3(64 * WM * WN * KS), lds, st, aa);
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS, X6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, KS, X6>), grid, dim3(64 * WM * WN * KS), lds, st, aa);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if constexpr (X6) {      // six products per k16 group: one prefetch depth only
+    hipLaunchKernelGGL((k_gemm_bf3<WM, WN, TM, TN, DUAL, 1, 1, true>), grid, dim3(64 * WM * WN), lds, st, aa);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -798,7 +809,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     a.v[i] = m->hvars[layers[i].var_index];
   }
   if (nvar > 16) return fail(TACO_ERR_UNSUPPORTED, "conv bank wider than 16 is not supported");
-  if ((m->bf3 || g_gemm_force_bf3) && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (every feed-forward layer of inference)
+  if ((m->bf3 || m->bf3x6 || g_gemm_force_bf3) && m->force_cfg < 0 && L0.bh) {   // split-bf16 path (every feed-forward layer of inference)
     // tiles (rows x cols): 1 = 128x64, 2 = 128x128, 3 = 64x256 (one staged 64-row tile feeds 8 MFMA column tiles)
     // measured (tools/time_gemm_layers.py): 64x256 wins when K or N is large (proj_1, linear, GRU projection), 128x64 otherwise
     const int Ktot = L0.kw * L0.cin;
@@ -816,6 +827,21 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       else tn = (!dual && (long)cdiv(Meff, 64) * cdiv(Nmax, 256) * nvar <= 320) ? 10 : 7;   // few workgroups: two wave groups split K (16 waves/CU)
       // (tile 11, 128 x 256 by 1 x 8 waves -- every weight fragment meets four row tiles -- measured SLOWER on the linear head, 116 vs 85 us:
       // one workgroup of 8 waves per CU and three rounds of workgroups; selectable for A/B only)
+    }
+    // six-product (fp32-grade) instantiations: the training forward (taco_train_set_exact_gemm mode 4); the tiles the heuristic picks
+    bool x6 = m->bf3x6 && !g_gemm_force_bf3;
+    for (int i = 0; i < nvar; ++i) x6 = x6 && a.v[i].bl3 && (!dual || a.v[i].bl3_2);
+    if (x6) {
+      if (tn == 10) tn = 7;
+      if (dual) {
+        if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, true, 1, true>(st, a, nvar, kw_max, Nmax);
+        if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, true, 1, true>(st, a, nvar, kw_max, Nmax);
+        return launch_gemm_bf3<2, 2, 1, 1, true, 1, true>(st, a, nvar, kw_max, Nmax);      // (the four-wave-group tile would spill with two accumulator sets and three planes)
+      }
+      if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, false, 1, true>(st, a, nvar, kw_max, Nmax);
+      if (tn == 9) return launch_gemm_bf3<1, 4, 2, 1, false, 1, true>(st, a, nvar, kw_max, Nmax);
+      if (tn == 5) return launch_gemm_bf3<2, 2, 1, 1, false, 4, true>(st, a, nvar, kw_max, Nmax);
+      return launch_gemm_bf3<2, 2, 1, 1, false, 1, true>(st, a, nvar, kw_max, Nmax);
     }
     if (dual) {
       if (tn == 7) return launch_gemm_bf3<1, 8, 2, 1, true>(st, a, nvar, kw_max, Nmax);
@@ -2022,6 +2048,7 @@ int taco_model_finalize(taco_model* m) {
     v.bn_scale = AP(m, (size_t)v.bn_scale); v.bn_shift = AP(m, (size_t)v.bn_shift);
     v.bh = (const unsigned short*)AP(m, (size_t)v.bh); v.bl = (const unsigned short*)AP(m, (size_t)v.bl);
     v.bh2 = (const unsigned short*)AP(m, (size_t)v.bh2); v.bl2 = (const unsigned short*)AP(m, (size_t)v.bl2);
+    v.bl3 = (const unsigned short*)AP(m, (size_t)v.bl3); v.bl3_2 = (const unsigned short*)AP(m, (size_t)v.bl3_2);
   }
   // persistent kernels carve up to the full 160 KiB of LDS
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cbhg_front<2, 80, 80, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

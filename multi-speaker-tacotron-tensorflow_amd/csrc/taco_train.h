@@ -977,7 +977,7 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     EngineGuard(const taco_train* t) : w(g_wgrad_bf3), d(g_dgrad_bf3), e(g_dgrad_exact) { g_wgrad_bf3 = t->wgrad_bf3; g_dgrad_bf3 = t->dgrad_bf3; g_dgrad_exact = t->dgrad_exact; }
     ~EngineGuard() { g_wgrad_bf3 = w; g_dgrad_bf3 = d; g_dgrad_exact = e; }
   } engine_guard(t);
-  if ((m->bf3 || g_dgrad_bf3) && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
+  if ((m->bf3 || m->bf3x6 || g_dgrad_bf3) && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
   Carver cv(ws, ws_bytes);
   TrainWs w; carve_train(cv, t, B, T_in, n, w);
   if (!cv.ok()) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", cv.off, ws_bytes);

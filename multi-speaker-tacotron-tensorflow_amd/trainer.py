@@ -143,10 +143,11 @@ class Trainer(object):
             self._graph = None          # a captured step keeps the engine it was captured with
 
     def set_exact_gemm(self, on=True):
-        """Engines of the feed-forward GEMMs and their data gradients (include/taco_abi.h, taco_train_set_exact_gemm).  3 (default):
+        """Engines of the feed-forward GEMMs and their data gradients (include/taco_abi.h, taco_train_set_exact_gemm).  4 (default): see below.  3 (the default of rounds 2-3):
         forward on the exact-fp32 MFMA, data gradients on the split-bf16 kernels of inference (4e-6 of the gradient norm against the
         all-exact step).  True / 1: everything exact.  False / 0: everything split-bf16 (fastest; ~1e-3 of the gradient norm, near-ties of
-        the forward may resolve differently).  2: forward split-bf16, data gradients exact (A/B hook)."""
+        the forward may resolve differently).  2: forward split-bf16, data gradients exact (A/B hook).  4: forward on the six-product
+        split (operands split three ways, fp32-grade products on the bf16 matrix cores), data gradients as in 3."""
         _lib.check(self._lib.taco_train_set_exact_gemm(self._h, int(on)))
         self.refresh()                 # the split-bf16 planes are (re)generated only while an engine that needs them is selected
         if getattr(self, "_graph", None) is not None:

@@ -24,7 +24,7 @@ def measure(args):
         tr.set_decoder_engine(args.engine)
     if not args.bptt:
         tr.set_bptt_engine(False)
-    if args.exact_gemm != 3:
+    if args.exact_gemm != 4:
         tr.set_exact_gemm(args.exact_gemm)
     if args.exact_wgrad:
         tr.set_exact_wgrad(True)
@@ -84,7 +84,7 @@ def measure(args):
             "per_rank_ms_per_step": per_rank,
             "engine": {"decoder_loop_and_postnet_scans": "persistent whole-chip kernels with tape (protocol %d)" % engine["protocol"] if args.engine and engine["protocol"] else "one launch per stage",
                        "decoder_bptt": "one persistent whole-chip launch (k_decoder_bwd_xcd)" if engine.get("bptt_protocol", 0) else "one launch per stage (per-stage chain)",
-                       "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact"}[args.exact_gemm],
+                       "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact", 4: "forward bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients bf16 MFMA with operands split in two (3 products)"}[args.exact_gemm],
                        "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
@@ -98,9 +98,9 @@ def measure(args):
         fwd = bench.algorithmic_flops(hp, B, T_in, n); ff = bench.feedforward_flops(hp, B, T_in, n)
         step_s = wall / args.steps
         total = 3 * fwd * world
-        fgemm = {3: "exact-fp32 MFMA", 1: "exact-fp32 MFMA", 0: "bf16 MFMA x3", 2: "bf16 MFMA x3"}[args.exact_gemm]
-        bf16_issued = ((3 if args.exact_gemm in (0, 2) else 0) + (3 if args.exact_gemm in (0, 3) else 0) + (0 if args.exact_wgrad else 6)) * ff
-        f32_mfma = ((0 if args.exact_gemm in (0, 2) else 1) + (1 if args.exact_gemm in (1, 2) else 0) + (1 if args.exact_wgrad else 0)) * ff
+        fgemm = {3: "exact-fp32 MFMA", 1: "exact-fp32 MFMA", 0: "bf16 MFMA x3", 2: "bf16 MFMA x3", 4: "bf16 MFMA x6 (fp32-grade)"}[args.exact_gemm]
+        bf16_issued = ((3 if args.exact_gemm in (0, 2) else 6 if args.exact_gemm == 4 else 0) + (3 if args.exact_gemm in (0, 3, 4) else 0) + (0 if args.exact_wgrad else 6)) * ff
+        f32_mfma = ((0 if args.exact_gemm in (0, 2, 4) else 1) + (1 if args.exact_gemm in (1, 2) else 0) + (1 if args.exact_wgrad else 0)) * ff
         report["roofline"] = {
             "bound": "mfma", "achieved": total / step_s / 1e12, "peak": bench.MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": total / step_s / 1e12 / bench.MFMA_F32_PEAK_TF, "traffic": None,
@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--selftest-launcher", action="store_true", help="CPU test hook: launcher + gloo rendezvous + the flat all-reduce only")
     ap.add_argument("--engine", type=int, default=1, help="1: persistent whole-chip kernels for the teacher-forced decoder loop and the post-net scans (default); 0: one launch per stage (rounds 1-2)")
     ap.add_argument("--bptt", type=int, default=1, help="1: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd; default); 0: the chain of per-stage launches")
-    ap.add_argument("--exact-gemm", type=int, default=3, help="3 (default): forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16")
+    ap.add_argument("--exact-gemm", type=int, default=4, help="4 (default): forward on the six-product split (fp32-grade), data gradients split-bf16; 3: forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16; 4: forward on the six-product split (fp32-grade), data gradients split-bf16")
     ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
     ap.add_argument("--deterministic", type=int, default=0, help="1: ordered two-stage sums instead of fp32 atomics (reproducible steps)")
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "

@@ -3,7 +3,7 @@
 // iterate-on-a-kernel loop.  Random-init parameters in the flat buffer, targets ~U[0,1], HIP events on the stream used.
 //   hipcc -O2 -I include tools/time_train_native.cpp -L multi-speaker-tacotron-tensorflow_amd/csrc -ltaco_hip \
 //         -Wl,-rpath,'$ORIGIN/../multi-speaker-tacotron-tensorflow_amd/csrc' -o tools/time_train_native
-//   ./tools/time_train_native [B=32] [T_in=128] [T_out=512] [reps=8] [exact_gemm=3] [bptt_persistent=1]
+//   ./tools/time_train_native [B=32] [T_in=128] [T_out=512] [reps=8] [exact_gemm=4] [bptt_persistent=1]
 // Prints ms per step and per part (forward only; forward + backward; clip + Adam; refresh) and the losses of the last step.
 // NOT YET RUN ON A GPU (written at the end of round 3 after the GPU budget was spent).
 #include "native_model.h"
