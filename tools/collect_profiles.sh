@@ -23,6 +23,7 @@ timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $ou
 # round 4: the fused CBHG front (k_cbhg_front): feed-forward time of both stages with the front on / off and per start delay / priority, phase
 # timeline of one workgroup (needs the -DTACO_TRACE build next to the library), per-layer timings, the C4 line of bench.py
 timeout 300 python tools/time_front.py 2>&1 | grep -v amdgpu.ids > $out/time_front.txt
+timeout 300 python tools/time_decoder.py C2:8 2>&1 | grep -v amdgpu.ids > $out/decoder_timeline.txt       # per-phase clocks of one decoder step; 64-row pass at eight rows per group
 [ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_front.py 2>&1 | grep -v amdgpu.ids > $out/front_timeline.txt
 [ -x tools/time_layers_native ] && timeout 120 ./tools/time_layers_native 20 > $out/time_layers_native.txt 2>&1
 timeout 600 python bench.py --workload C4 --steps 10 --warmup 2 > $out/bench_C4.json 2>> $out/bench_C2.err
