@@ -591,7 +591,7 @@ def main():
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3), the attention memory layer on exact-fp32 MFMA; recurrent / decoder mat-vecs exact fp32",
+            "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3), the attention memory layer as 6-term split-bf16 MFMA (operands split three ways: fp32-grade); recurrent / decoder mat-vecs exact fp32",
             "data": "synthetic", "world_size_seen": world,
             "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
                                    % (args.workload, B, T_in, n * r, r, mt),

@@ -99,6 +99,7 @@ struct ConvL {  // a k_gemm layer (conv1d+BN, dense, highway, hoisted GRU input 
   size_t wp = 0, wp2 = 0, bias = 0, bias2 = 0, bns = 0, bnb = 0;  // arena offsets (+1; 0 = absent)
   size_t bh = 0, bl = 0, bh2 = 0, bl2 = 0;                          // split-bf16 packs (k_gemm_bf3), 0 = not built
   size_t bl3 = 0, bl3_2 = 0;                                       // third planes (training shadow model: the six-product instantiation)
+  bool x6 = false;                                                 // inference: run this layer on the six-product (fp32-grade) instantiation (its third plane is built)
   int K16 = 0, cin_pad16 = 0;
   int var_index = -1;                                              // index into the device GemmVar array
 };
@@ -310,6 +311,8 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
   const int cp16 = rup(cin, 32), K16 = kw * cp16 / 16, NT = cdiv(N, 32);   // multiple of 32: k_gemm_bf3 walks k16 groups in pairs
   std::vector<unsigned short> hi((size_t)NT * K16 * 2 * 32 * 8, 0), lo(hi.size(), 0);
   std::vector<unsigned> idx(m->tp ? hi.size() : 0, 0u);
+  const bool want_l3 = l3_out && !m->tp && *l3_out == (size_t)1;     // inference model, caller asks (*l3_out preset to 1) for the third plane too
+  std::vector<unsigned short> l3v(want_l3 ? hi.size() : 0, 0);
   for (int nt = 0; nt < NT; ++nt)
     for (int k16 = 0; k16 < K16; ++k16)
       for (int h = 0; h < 2; ++h)
@@ -324,6 +327,7 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
               unsigned hu = (unsigned)hb << 16; float hf; memcpy(&hf, &hu, 4);
               const size_t o = ((((size_t)k16 * NT + nt) * 2 + h) * 32 + j) * 8 + e;   // k16-major: see the layout note in taco_kernels.h
               hi[o] = hb; lo[o] = bf16_rne_host(w - hf);
+              if (want_l3) { unsigned lu = (unsigned)lo[o] << 16; float lf; memcpy(&lf, &lu, 4); l3v[o] = bf16_rne_host(w - hf - lf); }
             }
           }
   auto put = [&](const std::vector<unsigned short>& v) {
@@ -332,6 +336,8 @@ static void pack_bf3(taco_model* m, const float* W, int kw, int cin, int N, size
     return arena_put(m, f.data(), f.size());
   };
   *hi_out = put(hi); *lo_out = put(lo); *K16_out = K16; *cp16_out = cp16;
+  if (want_l3) *l3_out = put(l3v);
+  else if (l3_out && !m->tp) *l3_out = 0;
   if (m->tp) {
     // third plane (zeros here: k_bf3_gather fills all three from the live parameters): the operand of the six-product instantiation
     const size_t l3 = put(std::vector<unsigned short>(hi.size(), 0));
@@ -362,13 +368,14 @@ static SkW pack_w16(taco_model* m, const float* W, int ldw, int r0, int K, int c
 
 static const HostTensor& T_(taco_model* m, const std::string& n) { return m->raw[n]; }
 
-static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has_bias = true, bool bf3 = false) {
+static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has_bias = true, bool bf3 = false, bool x6 = false) {
   const HostTensor& k = T_(m, name + "/kernel");
   ConvL L;
   if (k.shape.size() == 3) { L.kw = (int)k.shape[0]; L.cin = (int)k.shape[1]; L.N = (int)k.shape[2]; }
   else { L.kw = 1; L.cin = (int)k.shape[0]; L.N = (int)k.shape[1]; }
   int Kq, NT;
   L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
+  if (x6) { L.bl3 = 1; L.x6 = true; }        // (preset 1 = "build the third plane in an inference model too")
   if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16, &L.bl3);
   if (has_bias) L.bias = arena_put(m, T_(m, name + "/bias").data.data(), L.N);
   if (bn) {  // BatchNorm inference folded to y*scale + shift (A.2; epsilon 1e-3 = tf.layers default)
@@ -829,7 +836,7 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       // one workgroup of 8 waves per CU and three rounds of workgroups; selectable for A/B only)
     }
     // six-product (fp32-grade) instantiations: the training forward (taco_train_set_exact_gemm mode 4); the tiles the heuristic picks
-    bool x6 = m->bf3x6 && !g_gemm_force_bf3;
+    bool x6 = (m->bf3x6 && !g_gemm_force_bf3) || (m->bf3 && L0.x6);
     for (int i = 0; i < nvar; ++i) x6 = x6 && a.v[i].bl3 && (!dual || a.v[i].bl3_2);
     if (x6) {
       if (tn == 10) tn = 7;
@@ -1868,8 +1875,9 @@ int taco_model_finalize(taco_model* m) {
   }
   make_cbhg(m, m->enc, "encoder_cbhg", hp.enc_prenet[hp.enc_prenet_n - 1], hp.enc_bank_size, hp.enc_bank_channels,
             hp.enc_maxpool, hp.enc_highway_depth, hp.enc_rnn_size, hp.enc_proj, hp.enc_proj_n, hp.enc_proj_width, true);
-  // exact fp32 (no split-bf16 pack): the keys feed the alignment argmax, the one output held to "bit-identical" (costs ~35 us per C2 forward)
-  m->memory_layer = make_conv(m, "attention/memory_layer", false, false, false);
+  // fp32-grade: the keys feed the alignment argmax, the one output held to "bit-identical".  Rounds 1-3: the exact-fp32 MFMA (k_gemm, +35 us per
+  // C2 forward over the three-product split); round 4: the SIX-product split (operands split three ways, 2^-24 per product) on the bf16 pipe
+  m->memory_layer = make_conv(m, "attention/memory_layer", false, false, true, true);
   make_cbhg(m, m->post, "post_cbhg", hp.num_mels, hp.post_bank_size, hp.post_bank_channels, hp.post_maxpool,
             hp.post_highway_depth, hp.post_rnn_size, hp.post_proj, hp.post_proj_n, hp.post_proj_width, true);
   if (hp.num_speakers > 1 && hp.model_type == 1) {
