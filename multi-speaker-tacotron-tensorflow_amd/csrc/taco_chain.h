@@ -16,6 +16,13 @@
 #include "taco_kernels.h"
 
 #define CH_MAXL 8
+#ifndef CH_PF256
+#define CH_PF256 2       // register sets of weight fragments per wave (ch_mma_loop), W = 256 / W = 128.  Measured at C2 (round 4): 2, 3, 4 and 5 sets give the
+                         // same time to 1 % -- the two waves of a SIMD cover each other's L2 latency -- so the smallest ring stays
+#endif
+#ifndef CH_PF128
+#define CH_PF128 2
+#endif
 #define CH_BM 64
 enum { CH_DENSE = 0, CH_HIGHWAY = 1, CH_XPROJ = 2 };
 struct ChainLayer {
@@ -48,7 +55,7 @@ struct ChainArgs {
 // one layer's K loop for the wave's TM row tiles and one 32-column tile (DUAL: two products that share the A fragments -- the H and
 // T matrices of a highway layer at the same column tile, or two column tiles nt, nt2 of one matrix): weight fragments (hi, lo) one
 // k16 step ahead in two register sets that swap roles (K16 is even: pack_bf3 pads K to a multiple of 32)
-template <int TM, int LDSW, bool DUAL>
+template <int TM, int LDSW, bool DUAL, int CH_PF>
 __device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned short* bhA, const unsigned short* blA, int nt,
                                             const unsigned short* bhB, const unsigned short* blB, int nt2,
                                             const unsigned short* xhi, const unsigned short* xlo, int row0,
@@ -86,6 +93,7 @@ __device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned shor
       for (int tm = 0; tm < TM; ++tm) acc2[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh2, acc2[tm], 0, 0, 0);
     }
   };
+  if constexpr (CH_PF == 2) {
   loadb(0, ph, pl, ph2, pl2);
   for (int g = 0; g < K16; g += 2) {
     loadb(g + 1, qh, ql, qh2, ql2);
@@ -97,11 +105,37 @@ __device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned shor
     mma(g + 1, qh, ql, qh2, ql2);
     __builtin_amdgcn_sched_barrier(0);
   }
+  } else {
+  // a ring of CH_PF register sets: the fragments of step g + CH_PF - 1 are requested before step g is multiplied.  One step ahead
+  // (round 3) left every k16 step waiting for L2: a workgroup had 32 KB in flight, and a CU's share of the L2 stream at that depth
+  // is ~27 GB/s -- a quarter of what it reaches with 8 loads per lane outstanding (MI355X_MICROARCH.md, hand-off payload row)
+  uint4 rh[CH_PF], rl[CH_PF], rh2[CH_PF], rl2[CH_PF];
+#pragma unroll
+  for (int i = 0; i < CH_PF; ++i) rh2[i] = rl2[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < CH_PF - 1; ++i) loadb(i, rh[i], rl[i], rh2[i], rl2[i]);
+  for (int g = 0; g < K16; g += CH_PF) {
+#pragma unroll
+    for (int i = 0; i < CH_PF; ++i) {
+      loadb(g + i + CH_PF - 1, rh[(i + CH_PF - 1) % CH_PF], rl[(i + CH_PF - 1) % CH_PF], rh2[(i + CH_PF - 1) % CH_PF], rl2[(i + CH_PF - 1) % CH_PF]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + i < K16) mma(g + i, rh[i], rl[i], rh2[i], rl2[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  }
 }
 
+#ifdef TACO_TRACE
+__device__ long long taco_trace_chain[64];      // slots: 0 entry, 1 partial sums in planes, 2 proj_2 products done, 3 entry epilogue done, 4 first barrier; then per layer:
+#define CTRC(i) do { if (trc && (i) < 64) taco_trace_chain[i] = clock64(); } while (0)      // products done, epilogue done, planes free, planes written
+#else
+#define CTRC(i) do {} while (0)
+#endif
 template <int W>
 __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   constexpr int WN = W / 32, WM = 8 / WN, TM = CH_BM / 32 / WM;      // W = 256: 1 x 8 waves of 64 x 32; W = 128: 2 x 4 waves of 32 x 32
+  constexpr int PF = W == 256 ? CH_PF256 : CH_PF128;
   constexpr int LDSW = W + 8;                                          // bf16 elements per plane row: (W + 8) * 2 bytes = odd multiple of 16
   extern __shared__ __attribute__((aligned(16))) unsigned short ch_smem[];
   unsigned short* xhi = ch_smem;
@@ -114,6 +148,11 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * CH_BM;
+#ifdef TACO_TRACE
+  const bool trc = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;
+  int trci = 5;
+  CTRC(0);
+#endif
 
   const int l31_outer = l31, lh_outer = lh;
   float xreg[TM][16];                          // the lane's slice of the current activation in fp32 (highway carry)
@@ -165,6 +204,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         *reinterpret_cast<uint2*>(elo + r * LDE + c) = l4;
       }
     }
+    CTRC(1);
     __syncthreads();
     // proj_2: wave (wm, wn) owns its TM row tiles x the 32 columns 32 wn .. (waves past the last column tile idle); SAME padding and the
     // batch-row boundary by masking the A fragment per (row, tap) as k_gemm_bf3 does
@@ -235,6 +275,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    CTRC(2);
     // epilogue: + bias -> BatchNorm affine -> + residual (+ per-row vector); the chain's input planes (zero beyond N2) and the carry registers
     {
       const float bi = (cin && gb2) ? gb2[col] : 0.f, sc = (cin && gs2) ? gs2[col] : 1.f, sh = (cin && gh2) ? gh2[col] : 0.f;
@@ -258,6 +299,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         }
       have_x = true;
     }
+    CTRC(3);
   } else
   // ---- stage the input rows: fp32 -> (hi, lo) planes, zero padded to the first layer's K ----
   {
@@ -279,6 +321,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   }
   const bool full = m0 + CH_BM <= a.M;         // every row of the tile exists: the stores need no guards (the common case)
   __syncthreads();
+  CTRC(4);
 
   for (int li = 0; li < a.nlayers; ++li) {
     const ChainLayer L = a_in.L[li];
@@ -306,11 +349,13 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
             for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = acc[tm][r] + bia;
           }
         } else {                               // the backward direction's columns go to the time-reversed row of the batch row
+          int lhs = lh;                        // (opaque per call: the 32 reversed row indices are formed here, not kept -- and spilled -- across the column groups)
+          asm volatile("" : "+v"(lhs));
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const int row = m0 + rloc(tm, r);
+              const int row = m0 + (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhs;
               int orow = row;
               if (rev) {
                 const int bb = a.T >= CH_BM ? bb0 + (row >= (bb0 + 1) * a.T ? 1 : 0) : row / a.T;
@@ -327,9 +372,15 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
-        ch_mma_loop<TM, LDSW, true>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+#ifdef TACO_TRACE
+        CTRC(trci); ++trci;
+#endif
         store_group(ng, acc);
         if (ng + 1 < ngroups) store_group(ng + 1, acc2);
+#ifdef TACO_TRACE
+        CTRC(trci); ++trci;
+#endif
       }
       continue;
     }
@@ -350,7 +401,10 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       const float bia = L.bias ? L.bias[col] : 0.f;
       if (dual) {
         const float bia2 = L.bias2 ? L.bias2[col] : 0.f;
-        ch_mma_loop<TM, LDSW, true>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+#ifdef TACO_TRACE
+        CTRC(trci); ++trci;
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -360,7 +414,10 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
             xreg[tm][r] = Hh * Tg + xreg[tm][r] * (1.f - Tg);
           }
       } else {
-        ch_mma_loop<TM, LDSW, false>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+#ifdef TACO_TRACE
+        CTRC(trci); ++trci;
+#endif
         const bool relu = L.act == ACT_RELU;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -378,7 +435,13 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
           if (row < a.M) a.y[(size_t)row * a.ldy + col] = xreg[tm][r];
         }
     }
+#ifdef TACO_TRACE
+    CTRC(trci); ++trci;
+#endif
     __syncthreads();                            // every wave has read the planes of this layer
+#ifdef TACO_TRACE
+    CTRC(trci); ++trci;
+#endif
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -390,5 +453,8 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         xlo[rloc(tm, r) * LDSW + col] = (unsigned short)lp;
       }
     __syncthreads();
+#ifdef TACO_TRACE
+    CTRC(trci); ++trci;
+#endif
   }
 }

@@ -1,0 +1,254 @@
+// taco_head.h -- a wide dense layer over many rows as a ROW SWEEP: the linear head (tacotron.py:226-235; SURVEY 8a row a17:
+// [B*T, 512] x [512, num_freq = 1025] at every output frame), split-bf16 arithmetic of k_gemm_bf3 (three products, same packs).
+//
+// k_gemm_bf3 tiles the output 64 x 256: five column blocks at N = 1025, the fifth for ONE column; every workgroup stages its 64 input
+// rows again (eight 64-channel rounds, two barriers each, nothing in flight while the tile is converted) and 1280 workgroups take
+// five turns on the chip: 91 us at C2, 27 % of the bf16 pipe.  Here a workgroup owns 64 rows for ALL columns:
+//   * the rows are staged ONCE -- fp32 -> (hi, lo) bf16 planes [64][K + 8] in LDS, one barrier in the whole kernel;
+//   * wave w sweeps the column-tile pairs w, w + 8, ... (64 x 64 outputs per pass, K / 16 steps of 12 MFMAs); its weight fragments
+//     come straight from the layer's pack in L2 through a ring of HD_PF register sets that runs on across the passes, so the stream
+//     never restarts; the stores of a pass drain behind the products of the next one;
+//   * the columns past the last full tile (ONE at N = 1025) are dot products on the vector ALU from the same planes (hi + lo as fp32,
+//     fp32 weights): a 33rd MFMA tile would hand one wave a third pass while seven idle.
+#pragma once
+#include "taco_kernels.h"
+
+#define HD_BM 64
+#define HD_KMAX 512      // widest input (the planes of 64 rows x 512 inputs take 133 KB of LDS)
+#define HD_PF 2          // register sets of weight fragments per wave: the fragments of step g + 1 are requested before step g is multiplied (two waves per SIMD cover each other; deeper rings measured the same in k_pointwise_chain and cost registers the interleaved stores need)
+struct HeadArgs {
+  const float* x; int ldx;                                     // input rows [M, ldx], K columns used (K % 64 == 0, K <= HD_KMAX)
+  const unsigned short* bh; const unsigned short* bl;          // split-bf16 pack of the layer (pack_bf3)
+  int NT, K16;                                                 // 32-column tiles in the pack, k16 steps (K / 16)
+  const float* bias;                                           // [N] or null
+  const float* wtail; int ntail;                               // the last N % 32 columns as fp32 rows [ntail][K] (ntail <= 4), or null / 0
+  const float* rowvec; int ldrv, T;                            // optional per-batch-row vector [M / T, ldrv] added to every row of its batch row
+  float* out; int ldo;                                         // [M, ldo]
+  int M, K, N;
+};
+
+#ifdef TACO_TRACE
+__device__ long long taco_trace_head[16];       // 0 entry, 1 rows staged, then per pass (products done, stores issued), last: tail columns done
+#define HTRC(i) do { if (trc && (i) < 16) taco_trace_head[i] = clock64(); } while (0)
+#else
+#define HTRC(i) do {} while (0)
+#endif
+template <int KK>          // the layer's input width K (256 or 512): the product loop is unrolled over its K / 16 steps
+__global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short hd_smem[];
+  const float* gx = a_in.x; const unsigned short* gbh = a_in.bh; const unsigned short* gbl = a_in.bl; const float* gbias = a_in.bias;
+  const float* gwt = a_in.wtail; const float* grv = a_in.rowvec; float* gout = a_in.out;
+  PIN(gx); PIN(gbh); PIN(gbl); PIN(gbias); PIN(gwt); PIN(grv); PIN(gout);
+  constexpr int K = KK, K16 = KK / 16;
+  const int NT = a_in.NT, N = a_in.N, M = a_in.M, ldo = a_in.ldo;
+  constexpr int LDSW = K + 8;                                      // bf16 per plane row: (K + 8) * 2 bytes = an odd multiple of 16 (K % 16 == 0)
+  unsigned short* xhi = hd_smem;
+  unsigned short* xlo = hd_smem + HD_BM * LDSW;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * HD_BM;
+#ifdef TACO_TRACE
+  const bool trc = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;
+  int trci = 2;
+  HTRC(0);
+#endif
+
+  // ---- the workgroup's rows: fp32 -> planes, once ----
+  {
+    constexpr int nq = K / 4;                                      // float4 per row
+    constexpr int NS = HD_BM * (K / 4) / 512;                  // float4 per thread
+    float4 f[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {                             // all requests first
+      const int i = tid + 512 * u, r = i / nq, c = 4 * (i - r * nq);
+      f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < HD_BM * nq && m0 + r < M) f[u] = *reinterpret_cast<const float4*>(gx + (size_t)(m0 + r) * a_in.ldx + c);
+    }
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      const int i = tid + 512 * u, r = i / nq, c = 4 * (i - r * nq);
+      if (i >= HD_BM * nq) continue;
+      uint2 h4, l4;
+      taco_split_bf16x4(f[u], h4, l4);
+      *reinterpret_cast<uint2*>(xhi + r * LDSW + c) = h4;
+      *reinterpret_cast<uint2*>(xlo + r * LDSW + c) = l4;
+    }
+  }
+  // the wave's share of the sweep: column-tile pairs wave, wave + 8, ... of the full tiles
+  const int NTF = N / 32, npair = (NTF + 1) / 2;
+  const int mypass = wave < npair ? (npair - 1 - wave) / 8 + 1 : 0;
+  const int nsteps = mypass * K16;
+  auto bofs = [&](int s) {                                     // flat step (pass, k16) -> element offset of the lane's fragment of the pair's first tile
+    const int sc = min(s, nsteps - 1), p = sc / K16, g = sc - p * K16, t0 = 2 * (wave + 8 * p);
+    return ((((size_t)g * NT + t0) * 2 + lh) * 32 + l31) * 8;
+  };
+  uint4 rh[HD_PF][2], rl[HD_PF][2];
+  auto loadb = [&](int s, uint4 (&h)[2], uint4 (&l)[2]) {
+    const size_t o = bofs(s);
+    const int sc = min(s, nsteps - 1), t1 = 2 * (wave + 8 * (sc / K16)) + 1;
+    const size_t o1 = o + (t1 < NT ? 512 : 0);                 // (the second tile of the last pair may not exist: its products are never stored)
+    h[0] = *reinterpret_cast<const uint4*>(gbh + o); l[0] = *reinterpret_cast<const uint4*>(gbl + o);
+    h[1] = *reinterpret_cast<const uint4*>(gbh + o1); l[1] = *reinterpret_cast<const uint4*>(gbl + o1);
+  };
+  if (mypass > 0) {
+#pragma unroll
+    for (int i = 0; i < HD_PF - 1; ++i) loadb(i, rh[i], rl[i]);     // in flight across the staging barrier
+  }
+  __syncthreads();
+  HTRC(1);
+
+  f32x16 acc[2][2];
+  const unsigned short* abh = xhi;                             // the lane's fragment rows in the two planes (set per pass from opaque lane coordinates:
+  const unsigned short* abl = xlo;                             // everything else of an A-fragment address is an immediate offset)
+  auto mma = [&](int g, const uint4 (&h)[2], const uint4 (&l)[2]) {
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abh + tm * 32 * LDSW + 16 * g));
+      al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abl + tm * 32 * LDSW + 16 * g));
+    }
+    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, h[0]), bl0 = __builtin_bit_cast(bf16x8, l[0]);
+    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, h[1]), bl1 = __builtin_bit_cast(bf16x8, l[1]);
+    // small terms first; the four independent accumulators sit between two MFMAs on the same one
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh0, acc[tm][0], 0, 0, 0);
+      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh1, acc[tm][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl0, acc[tm][0], 0, 0, 0);
+      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl1, acc[tm][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh0, acc[tm][0], 0, 0, 0);
+      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh1, acc[tm][1], 0, 0, 0);
+    }
+  };
+  // The stores of a pass are issued INSIDE the product loop of the next one (64 per lane: two per k16 step at K = 512), from a copy of its
+  // accumulators: left behind the loop, every wave of the chip stores at once and the matrix pipe idles for a third of the kernel
+  // (measured: 21 K clocks of stores behind 35 K clocks of products, twice).  Only the last pass's stores stay exposed.  Workgroups with
+  // rows past M, and the per-batch-row vector of model type 'simple', take the plain order (guards / an index division per element).
+  const bool inter = (m0 + HD_BM <= M) && !grv;
+  f32x16 accP[2][2];
+  float pbia[2] = {0.f, 0.f};
+  bool pv[2] = {false, false};
+  float* pbase = gout;                                        // previous pass: element (row m0 + 4 * (lane >> 5), first column of the pair + (lane & 31))
+  constexpr int SPS = 64 / K16;                                // stores of the previous pass per k16 step
+  auto store_prev = [&](int idx) {                             // idx (compile-time after unrolling): tn | tm | register
+    const int tn = idx >> 5, tm = (idx >> 4) & 1, r = idx & 15;
+    if (pv[tn]) pbase[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldo + tn * 32] = accP[tm][tn][r] + pbia[tn];
+  };
+  for (int p = 0; p < mypass; ++p) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn)
+        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+    const int s0 = p * K16;
+    {
+      int l31a = l31, lha = lh;
+      asm volatile("" : "+v"(l31a), "+v"(lha));
+      abh = xhi + l31a * LDSW + 8 * lha; abl = xlo + l31a * LDSW + 8 * lha;
+    }
+    if (p > 0 && inter) {
+#pragma unroll
+      for (int g = 0; g < K16; g += HD_PF) {                   // K16 % HD_PF == 0: the ring stays aligned across the passes
+#pragma unroll
+        for (int i = 0; i < HD_PF; ++i) {
+          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
+#pragma unroll
+          for (int u = 0; u < SPS; ++u) store_prev((g + i) * SPS + u);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(g + i, rh[i], rl[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      for (int g = 0; g < K16; g += HD_PF) {
+#pragma unroll
+        for (int i = 0; i < HD_PF; ++i) {
+          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(g + i, rh[i], rl[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#ifdef TACO_TRACE
+    HTRC(trci); ++trci;
+#endif
+    const int t0 = 2 * (wave + 8 * p);
+    int l31e = l31, lhe = lh;                                  // (opaque per pass: the output addresses are formed here, not kept across the sweep)
+    asm volatile("" : "+v"(l31e), "+v"(lhe));
+    if (inter && p + 1 < mypass) {                             // hand the tile to the next pass's loop
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = (t0 + tn) * 32 + l31e;
+        pv[tn] = t0 + tn < NTF;
+        pbia[tn] = (gbias && pv[tn]) ? gbias[col] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) accP[tm][tn] = acc[tm][tn];
+      }
+      pbase = gout + (size_t)(m0 + 4 * lhe) * ldo + t0 * 32 + l31e;
+      continue;
+    }
+    // + bias (+ the batch row's vector) -> the output rows
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) {
+      if (t0 + tn >= NTF) continue;
+      const int col = (t0 + tn) * 32 + l31e;
+      const float bia = gbias ? gbias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhe;
+          if (row < M) {
+            float v = acc[tm][tn][r] + bia;
+            if (grv) v += grv[(size_t)(row / a_in.T) * a_in.ldrv + col];
+            gout[(size_t)row * ldo + col] = v;
+          }
+        }
+    }
+#ifdef TACO_TRACE
+    HTRC(trci); ++trci;
+#endif
+  }
+#ifdef TACO_TRACE
+  HTRC(trci); ++trci;
+#endif
+  // ---- the columns behind the last full tile: eight lanes per row, K / 8 inputs per lane, fp32 ----
+  if (a_in.ntail > 0) {
+    const int r = wave * 8 + (lane >> 3), kn = K / 8, k0 = (lane & 7) * kn, row = m0 + r;
+    for (int t = 0; t < a_in.ntail; ++t) {
+      const float* wt = gwt + (size_t)t * K + k0;
+      float s = 0.f;
+      for (int kk = 0; kk < kn; kk += 8) {
+        const uint4 h = *reinterpret_cast<const uint4*>(xhi + r * LDSW + k0 + kk), l = *reinterpret_cast<const uint4*>(xlo + r * LDSW + k0 + kk);
+        const float4 w0 = *reinterpret_cast<const float4*>(wt + kk), w1 = *reinterpret_cast<const float4*>(wt + kk + 4);
+        s = fmaf(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), w0.x, s);
+        s = fmaf(__uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u), w0.y, s);
+        s = fmaf(__uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), w0.z, s);
+        s = fmaf(__uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u), w0.w, s);
+        s = fmaf(__uint_as_float(h.z << 16) + __uint_as_float(l.z << 16), w1.x, s);
+        s = fmaf(__uint_as_float(h.z & 0xffff0000u) + __uint_as_float(l.z & 0xffff0000u), w1.y, s);
+        s = fmaf(__uint_as_float(h.w << 16) + __uint_as_float(l.w << 16), w1.z, s);
+        s = fmaf(__uint_as_float(h.w & 0xffff0000u) + __uint_as_float(l.w & 0xffff0000u), w1.w, s);
+      }
+      s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+      s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+      s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xF, 0xF, false));     // row_half_mirror: the other quad of the eight
+      const int col = N - a_in.ntail + t;
+      if ((lane & 7) == 0 && row < M) {
+        float v = s + (gbias ? gbias[col] : 0.f);
+        if (grv) v += grv[(size_t)(row / a_in.T) * a_in.ldrv + col];
+        gout[(size_t)row * ldo + col] = v;
+      }
+    }
+  }
+#ifdef TACO_TRACE
+  HTRC(trci);
+#endif
+}

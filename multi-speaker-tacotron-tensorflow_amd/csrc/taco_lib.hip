@@ -7,6 +7,7 @@
 #include "taco_bigru_xcd.h"
 #include "taco_chain.h"
 #include "taco_front.h"
+#include "taco_head.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
 #include "taco_decoder_bwd_xcd.h"
@@ -101,6 +102,7 @@ struct ConvL {  // a k_gemm layer (conv1d+BN, dense, highway, hoisted GRU input 
   size_t bl3 = 0, bl3_2 = 0;                                       // third planes (training shadow model: the six-product instantiation)
   bool x6 = false;                                                 // inference: run this layer on the six-product (fp32-grade) instantiation (its third plane is built)
   int K16 = 0, cin_pad16 = 0;
+  size_t wtail = 0; int ntail = 0;                                 // the last N % 32 (<= 4) columns as fp32 rows [ntail][cin]: the vector-ALU tail of k_head_sweep (taco_head.h)
   int var_index = -1;                                              // index into the device GemmVar array
 };
 struct SkW {  // a k_skinny weight
@@ -168,6 +170,7 @@ struct taco_model {
   int chain = 1;               // point-wise tail of a CBHG as one launch (taco_chain.h); 0: one launch per layer
   int front_entry = 1;         // proj_1's epilogue + proj_2 inside the point-wise chain's entry (taco_chain.h) when the fused front ran
   int front_prio = 1; int front_delay = 0;      // shader clocks by which the second K half of a k_cbhg_front workgroup starts late (taco_front.h)
+  int head_sweep = 1;          // wide dense layers over many rows (the linear head) as a row sweep (taco_head.h); 0: k_gemm_bf3 tiles
   int front = 1;               // conv bank -> max-pool -> proj_1 of a CBHG as one launch (taco_front.h); 0: bank and proj_1 as two k_gemm_bf3 launches
   int overlap = 0;             // >0: run the post-net feed-forward stages behind the decoder on a second stream, chunks of
                                // max(overlap,16) steps.  Measured SLOWER on MI355X (13.2 -> 14.4-17 ms @C2): off by default
@@ -377,6 +380,13 @@ static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has
   L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
   if (x6) { L.bl3 = 1; L.x6 = true; }        // (preset 1 = "build the third plane in an inference model too")
   if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16, &L.bl3);
+  if (bf3 && L.kw == 1 && L.N >= 512 && L.N % 32 > 0 && L.N % 32 <= 4 && (L.cin == 256 || L.cin == 512)) {
+    L.ntail = L.N % 32;
+    std::vector<float> wt((size_t)L.ntail * L.cin);
+    for (int t = 0; t < L.ntail; ++t)
+      for (int kk = 0; kk < L.cin; ++kk) wt[(size_t)t * L.cin + kk] = k.data[(size_t)kk * L.N + (L.N - L.ntail + t)];
+    L.wtail = arena_put(m, wt.data(), wt.size());
+  }
   if (has_bias) L.bias = arena_put(m, T_(m, name + "/bias").data.data(), L.N);
   if (bn) {  // BatchNorm inference folded to y*scale + shift (A.2; epsilon 1e-3 = tf.layers default)
     const auto& g = T_(m, name + "/gamma").data; const auto& b = T_(m, name + "/beta").data;
@@ -826,6 +836,21 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
     // tile 9: 64x128 by 1x4): every wave streams its OWN weight columns and all of them share the staged activation tile, so no
     // weight fragment is fetched twice by a workgroup (the 2x2 arrangements of tiles 1-3 fetch each one twice through a 16 KB L1
     // that cannot hold them: measured 20-30 % slower on every large layer, tools/time_gemm_layers.py).
+    // a wide dense layer over many rows (the linear head): every workgroup keeps its 64 rows for ALL columns (taco_head.h)
+    bool x6 = (m->bf3x6 && !g_gemm_force_bf3) || (m->bf3 && L0.x6);
+    if (m->head_sweep && !m->bf3_tn && !x6 && nvar == 1 && !dual && L0.kw == 1 && c.mpw <= 1 && !c.gather && !c.res && !c.rev_len && c.rev_col0 < 0 &&
+        c.t_len == 0 && !c.aux0 && !c.aux1 && c.act == ACT_NONE && !L0.bns && a.vec_ok && (L0.cin == 256 || L0.cin == 512) && L0.N >= 512 &&
+        L0.N % 32 == L0.ntail && (L0.ntail == 0 || L0.wtail) && c.M >= 256 && (long)c.M * c.ldo < (1L << 30)) {
+      HeadArgs h;
+      memset(&h, 0, sizeof h);
+      h.x = c.x; h.ldx = c.ldx; h.bh = a.v[0].bh; h.bl = a.v[0].bl; h.NT = a.v[0].NT; h.K16 = L0.cin / 16; h.bias = a.v[0].bias;
+      h.wtail = L0.wtail ? AP(m, L0.wtail) : nullptr; h.ntail = L0.ntail; h.rowvec = c.rowvec; h.ldrv = c.ldrv; h.T = a.T;
+      h.out = c.out; h.ldo = c.ldo; h.M = c.M; h.K = L0.cin; h.N = L0.N;
+      if (L0.cin == 512) hipLaunchKernelGGL(k_head_sweep<512>, dim3(cdiv(c.M, HD_BM)), dim3(512), (size_t)2 * HD_BM * (512 + 8) * sizeof(unsigned short), st, h);
+      else hipLaunchKernelGGL(k_head_sweep<256>, dim3(cdiv(c.M, HD_BM)), dim3(512), (size_t)2 * HD_BM * (256 + 8) * sizeof(unsigned short), st, h);
+      HIPCHK(hipGetLastError());
+      return 0;
+    }
     int tn = m->bf3_tn;
     if (!tn) {
       const long g128 = (long)cdiv(Meff, 128) * cdiv(Nmax, 64) * nvar, g64 = (long)cdiv(Meff, 64) * cdiv(Nmax, 64) * nvar;
@@ -836,7 +861,6 @@ static int run_gemm(const taco_model* m, hipStream_t st, const ConvL* layers, in
       // one workgroup of 8 waves per CU and three rounds of workgroups; selectable for A/B only)
     }
     // six-product (fp32-grade) instantiations: the training forward (taco_train_set_exact_gemm mode 4); the tiles the heuristic picks
-    bool x6 = (m->bf3x6 && !g_gemm_force_bf3) || (m->bf3 && L0.x6);
     for (int i = 0; i < nvar; ++i) x6 = x6 && a.v[i].bl3 && (!dual || a.v[i].bl3_2);
     if (x6) {
       if (tn == 10) tn = 7;
@@ -2074,6 +2098,8 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_xcd<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2137,6 +2163,7 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   m->chain = (on & 4) ? 0 : 1;     // on = 5: split-bf16 GEMMs with one launch per point-wise layer (A/B of taco_chain.h)
   m->front = (on & 8) ? 0 : 1;     // on = 9: conv bank and proj_1 as two k_gemm_bf3 launches (A/B of taco_front.h)
   m->front_entry = (on & 16) ? 0 : 1;   // on = 17: fused front, but k_front_combine and proj_2 as launches of their own (A/B of the chain's fused entry)
+  m->head_sweep = (on & 32) ? 0 : 1;    // on = 33: the linear head on k_gemm_bf3's 64 x 256 tiles (A/B of taco_head.h)
   return 0;
 }
 
@@ -2173,6 +2200,8 @@ int taco_debug_set_fuse_prenet(taco_model* m, int on) {
 #ifdef TACO_TRACE
 int taco_debug_read_trace(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
 int taco_debug_read_trace_front(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace_front), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
+int taco_debug_read_trace_head(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace_head), 16 * sizeof(long long)) == hipSuccess ? 0 : -1; }
+int taco_debug_read_trace_chain(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(taco_trace_chain), 64 * sizeof(long long)) == hipSuccess ? 0 : -1; }
 #endif
 int taco_debug_set_fuse_concat(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");

@@ -610,7 +610,8 @@ def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_
     memory, the contraction of proj_1 is split over parts of the bank's channels and summed in a fixed order).  Reference widths
     (the kernel exists for the encoder's 16 x 128 over 128 channels and the post-net's 8 x 256 over 80), frame counts below, at and
     above the 128-frame tile incl. one frame more than a tile, batch sizes that give 1 ... 16 parts, ragged lengths.  Both CBHG
-    stages against the float64 oracle's own stage functions (the large shapes, where NumPy would take minutes, only against the
+    stages and the linear head behind them (csrc/taco_head.h: row sweep with a vector-ALU tail column, row counts that are not multiples
+    of its 64-row tile) against the float64 oracle's own stage functions (the large shapes, where NumPy would take minutes, only against the
     two-launch path: C2 itself is held to the oracle by test_full_size_C2_parity_and_properties), the fused front against bank and
     proj_1 as two launches, and twice the same call bit for bit (no atomics)."""
     import torch
@@ -629,7 +630,8 @@ def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_
     got = {}
     # taco_debug_set_bf3 bit 3: front off; bit 4: fused front, but proj_1's epilogue and proj_2 as launches of their own instead of the
     # point-wise chain's fused entry (csrc/taco_chain.h)
-    for flag, name in ((1, "fused"), (17, "fused front, separate proj_2"), (9, "two launches"), (1, "fused again")):
+    # bit 5: the linear head on k_gemm_bf3's 64 x 256 tiles instead of the row sweep (csrc/taco_head.h; runs from 256 rows on)
+    for flag, name in ((1, "fused"), (17, "fused front, separate proj_2"), (9, "two launches"), (33, "linear head on GEMM tiles"), (1, "fused again")):
         m._lib.taco_debug_set_bf3(m._handle, flag, 0)
         enc = m.encoder(ids, L)
         lin, post = m.postnet(mel, return_post=True)
@@ -643,7 +645,7 @@ def test_fused_cbhg_front_matches_the_oracle_and_the_two_launch_path(B, T_in, T_
         e = (maxabs(enc, enc_ref), maxabs(post, post_ref), maxabs(lin, lin_ref))
         print("%s: encoder %.2e  post %.2e  linear %.2e" % ((name,) + e))
         assert e[0] < 1e-4 and e[1] < 2e-4 and e[2] < 2e-4, (name, e)
-    for other in ("two launches", "fused front, separate proj_2"):
+    for other in ("two launches", "fused front, separate proj_2", "linear head on GEMM tiles"):
         d = [maxabs(a, b) for a, b in zip(got["fused"], got[other])]
         print("fused vs %s: encoder %.2e  post %.2e  linear %.2e" % ((other,) + tuple(d)))
         assert max(d) < 3e-5, (other, d)
