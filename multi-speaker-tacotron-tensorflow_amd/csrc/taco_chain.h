@@ -16,9 +16,15 @@
 #include "taco_kernels.h"
 
 #define CH_MAXL 8
+// Register sets of weight fragments per wave (ch_mma_loop), W = 256 / W = 128.  What bounds the product loops, measured at C2 in round 4
+// (tools/trace_chain.py on ablated builds): a k16 step of a highway layer takes ~1040 ticks for ~650 of matrix work.  Rings 2, 3, 4, 5 deep,
+// the activation fragments requested a step ahead of their MFMAs, four or eight independent accumulator chains per cluster: no change.
+// Every step re-reading the FIRST step's weight fragments (L1 hits, same instruction stream): 16.2 K -> 10.5 K ticks per layer.  So the loops
+// are bound by the stream of weight fragments out of L2: 32 CUs of an XCD x 32 KB per step = 1 MB per step through an L2 that returns ~1 KB
+// per clock -- bandwidth, not latency.  Rows per workgroup set that ratio (every workgroup streams all 3.6 MB of the stage's weights): 128-row
+// tiles would halve the stream but leave half the CUs idle at M = 16384 and double the matrix time per CU, which is the larger term.
 #ifndef CH_PF256
-#define CH_PF256 2       // register sets of weight fragments per wave (ch_mma_loop), W = 256 / W = 128.  Measured at C2 (round 4): 2, 3, 4 and 5 sets give the
-                         // same time to 1 % -- the two waves of a SIMD cover each other's L2 latency -- so the smallest ring stays
+#define CH_PF256 2
 #endif
 #ifndef CH_PF128
 #define CH_PF128 2
@@ -230,19 +236,26 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
       for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
-    if (wn < E.NT2) {
+    // W = 256 (one row of eight waves): N2 = 80 columns are three column tiles -- alone, three waves would run the whole contraction on
+    // three SIMDs, one wave each, while five wait (31 K of the workgroup's 220 K clocks at C2).  The contraction is cut in two K halves
+    // instead: waves NT2 .. 2 NT2 - 1 take the second half of the k16 steps of column tile wn - NT2 and hand their partial tile over
+    // through LDS (the chain's own planes are not written yet)
+    const int KSPL = (WM == 1 && 2 * E.NT2 <= WN) ? 2 : 1;
+    const bool mact = wn < E.NT2 * KSPL;
+    const int ect = mact ? wn % E.NT2 : 0, kp = mact ? wn / E.NT2 : 0;
+    if (mact) {
       int tloc[TM];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) tloc[tm] = (m0 + (wm * TM + tm) * 32 + l31) % a.T;
-      const int nk = 3 * E.K16tap;                                         // k16 steps: (tap, group)
-      auto boff = [&](int k) { return ((((size_t)k * E.NT2 + wn) * 2 + lh) * 32 + l31) * 8; };
-      // one wave per SIMD is all there is here, so the weight stream is requested a whole block of NB k16 steps ahead (two register
-      // sets that swap roles; nk = 3 N1 / 16 is a multiple of 2 NB): one step ahead left every step waiting ~800 clocks for L2
-      constexpr int NB = W == 256 ? 8 : 6;             // nk = 48 / 24: a multiple of 2 NB either way (the host admits N1 = 256 with W = 256, 128 with 128)
+      const int nk = (3 * E.K16tap) / KSPL, kbeg = kp * nk, kend = kbeg + nk;      // k16 steps (tap, group) of this wave
+      auto boff = [&](int k) { return ((((size_t)k * E.NT2 + ect) * 2 + lh) * 32 + l31) * 8; };
+      // few waves per SIMD here, so the weight stream is requested a whole block of NB k16 steps ahead (two register
+      // sets that swap roles; nk = 3 N1 / 16 [/ 2] is a multiple of 2 NB): one step ahead left every step waiting ~800 clocks for L2
+      constexpr int NB = 6;                            // nk = 48, 24 (K halves) or 24: a multiple of 2 NB (the host admits N1 = 256 with W = 256, 128 with 128)
       uint4 pH[NB], pL[NB], qH[NB], qL[NB];
       auto loadblk = [&](int k0, uint4 (&H)[NB], uint4 (&Lo)[NB]) {
 #pragma unroll
-        for (int i = 0; i < NB; ++i) { const size_t o = boff(min(k0 + i, nk - 1)); H[i] = *reinterpret_cast<const uint4*>(gbh + o); Lo[i] = *reinterpret_cast<const uint4*>(gbl + o); }
+        for (int i = 0; i < NB; ++i) { const size_t o = boff(min(k0 + i, kend - 1)); H[i] = *reinterpret_cast<const uint4*>(gbh + o); Lo[i] = *reinterpret_cast<const uint4*>(gbl + o); }
       };
       auto mmablk = [&](int k0, const uint4 (&H)[NB], const uint4 (&Lo)[NB]) {
 #pragma unroll
@@ -263,8 +276,8 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
           }
         }
       };
-      loadblk(0, pH, pL);
-      for (int k0 = 0; k0 < nk; k0 += 2 * NB) {
+      loadblk(kbeg, pH, pL);
+      for (int k0 = kbeg; k0 < kend; k0 += 2 * NB) {
         loadblk(k0 + NB, qH, qL);
         __builtin_amdgcn_sched_barrier(0);
         mmablk(k0, pH, pL);
@@ -274,6 +287,27 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         mmablk(k0 + NB, qH, qL);
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
+    if (KSPL == 2) {                                   // the second K half's partial tile -> the first half's wave (fixed order: bit-reproducible)
+      float* red = reinterpret_cast<float*>(ch_smem);
+      if (mact && kp == 1) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((ect * TM + tm) * 16 + r) * 64 + lane] = acc[tm][r];
+      }
+      __syncthreads();
+      if (mact && kp == 0) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tm][r] += red[((ect * TM + tm) * 16 + r) * 64 + lane];
+      } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+      }
+      __syncthreads();                                 // ... before the epilogue below writes the planes over the partial tiles
     }
     CTRC(2);
     // epilogue: + bias -> BatchNorm affine -> + residual (+ per-row vector); the chain's input planes (zero beyond N2) and the carry registers
@@ -366,13 +400,18 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
             }
         }
       };
-      for (int ng = 0; ng < ngroups; ng += 2) {            // two column groups per pass share the A fragments
+      // two column groups per pass share the A fragments; an odd group left over (6H = 3 W at W = 256: the backward direction's last
+      // columns, whose time-reversed stores are the slow ones) goes FIRST, so that its stores drain behind the products of the pass after it
+      const int npass = (ngroups + 1) / 2, odd = ngroups & 1;
+      for (int ps = 0; ps < npass; ++ps) {
+        const int ng = (odd && ps == 0) ? ngroups - 1 : 2 * (ps - odd);
         const int nt = min(ng * WN + wn, L.NT - 1), nt2 = min((ng + 1) * WN + wn, L.NT - 1);   // tiles past the pack are clamped, never stored
         f32x16 acc[TM], acc2[TM];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
-        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);     // the odd group: one matrix
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif
