@@ -34,6 +34,9 @@
 //   * Model type 'simple' (rnn_wrappers.py:372-376, 408-413): the speaker embedding is one more input segment of the attention GRU and
 //     of the concat projection; it is constant over the loop, so its products with those rows are formed once per launch by a
 //     small kernel (k_dx_rowbias) and enter the epilogues as per-(row, column) biases.
+//   * Other presets of hparams.py:71-117 (round 4): the attention width (attention_size: keys, query layer, attention_v) is the template
+//     parameter AW -- 128 / 256 / 512 --, and a third decoder prenet layer (dec_prenet_sizes [256, 128, 64]) the parameter PD = 3: one more
+//     stage (64 columns, two per member) whose output feeds the attention GRU's 64 input rows (one per lane).  Inference only.
 //   * Training forward (TAPE instantiation; helpers.py:35-67, train.py:215-219): the frame fed to the next step's prenet comes from
 //     the teacher buffer (fetched straight into LDS one step ahead of its use) instead of the step's own output, and every value the
 //     backward pass needs (gates, candidates, r*h, states, the concat projection, the processed query, raw scores, alignments,
@@ -50,6 +53,7 @@ typedef __attribute__((address_space(1))) unsigned dx_gu32;
 #define DX_NGROUP 8          // groups (XCDs)
 #define DX_W 256             // attention_state_size = dec_rnn_size = attention_size = 2*enc_rnn_size = dec_prenet[0]
 #define DX_P2 128            // dec_prenet[1]
+#define DX_P3 64             // dec_prenet[2] (PD = 3: presets with a third prenet layer)
 #define DX_SPIN_LIMIT (1u << 21)
 #ifndef DX_POLL_SLEEP
 #define DX_POLL_SLEEP 0          // s_sleep units (64 clocks) between two polls of a stale granule
@@ -64,6 +68,7 @@ enum {
   DXR_P2 = 0,     // prenet layer 2: p1 -> column 4m + w (waves 0-3)                                   1 col
   DXR_AGH = 4,    // attention GRU gates, h rows: h_att -> r, u                                        2 cols
   DXR_AGX = 12,   // attention GRU, x rows (128): p2 -> r, u, candidate-x                              3 cols x 2 regs
+                  // (PD = 3: x rows (64): p3 -> r, u, candidate-x, 3 cols x 1 reg; then prenet layer 3: p2 -> column 2m + w (waves 0-1), 1 col x 2 regs)
   DXR_AC = 18,    // attention GRU candidate, h rows: r*h -> c                                         1 col
   DXR_G1H = 22,   // decoder GRU 1 gates, h rows: h1 -> r, u                                           2 cols
   DXR_G1A = 30,   // GRU 1 with the concat projection folded in, h_att rows: -> r, u, candidate-x, o0  4 cols
@@ -83,7 +88,7 @@ enum { DXS_P2 = 0, DXS_HATT = 128, DXS_CTX = 384, DXS_OUT2 = 640, DXS_T = 896, D
        DXS_LD = 1920 };
 // own-column bias table in LDS: bl[slot][wave]
 enum { DXB_P1 = 0, DXB_P2, DXB_AR, DXB_AU, DXB_AC, DXB_G1R, DXB_G1U, DXB_G1X, DXB_O0, DXB_G1C, DXB_G2R, DXB_G2U, DXB_G2C, DXB_F0, DXB_F1,
-       DXB_N };
+       DXB_P3, DXB_N };
 // per-row bias slots (model type 'simple'): the speaker embedding's product with the speaker rows of the attention GRU (r, u,
 // candidate-x) and of the folded GRU 1 (r, u, candidate-x, o0); rowbias[b][slot][256]
 enum { DXRB_AR = 0, DXRB_AU, DXRB_AX, DXRB_G1R, DXRB_G1U, DXRB_G1X, DXRB_O0, DXRB_N };
@@ -93,20 +98,21 @@ enum { DXT_P1 = 0, DXT_HA, DXT_RA, DXT_UA, DXT_CA, DXT_RHA, DXT_Q, DXT_O0, DXT_R
        DXT_R2, DXT_U2, DXT_C2, DXT_RH2, DXT_H2, DXT_O2, DXT_N };
 
 // exchange buffers of one group, in granules, for RG rows (the host sizes the buffer with RG = 8)
-struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, total; };
+struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, p3, total; };
 __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
   DxX x; int o = 0;
   x.p1 = o; o += RG * DX_W;  x.p2 = o; o += RG * DX_P2; x.rha = o; o += RG * DX_W; x.ha = o; o += RG * DX_W;
   x.sc = o; o += DX_GROUP * T_in;                         // partial scores: [row][member of the row][position]
   x.ctx = o; o += RG * DX_W; x.rh1 = o; o += RG * DX_W; x.h1 = o; o += RG * DX_W; x.o1 = o; o += RG * DX_W;
   x.rh2 = o; o += RG * DX_W; x.h2 = o; o += RG * DX_W;
+  x.p3 = o; o += RG * DX_P3;                              // (PD = 3 only)
   x.total = o;
   return x;
 }
 // LDS floats of a member (host mirror of the carve in the kernel)
-__host__ __device__ inline size_t dx_lds_floats(int RG, int T_in, bool teacher = false) {
+__host__ __device__ inline size_t dx_lds_floats(int RG, int T_in, bool teacher = false, int AW = DX_W) {
   const int Pr = DX_GROUP / RG, DC = DX_W / Pr, Tpad = (T_in + 3) & ~3;
-  const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = DX_W / Pc, TS = (T_in + Pp - 1) / Pp;
+  const int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc, DS = AW / Pc, TS = (T_in + Pp - 1) / Pp;
   size_t n = 0;
   n += (size_t)RG * DXS_LD;           // state
   n += (size_t)TS * DS;               // keys: position block x score-channel block
@@ -122,12 +128,13 @@ __host__ __device__ inline size_t dx_lds_floats(int RG, int T_in, bool teacher =
   return n;
 }
 __host__ __device__ inline int dx_score_blocks(int RG) { const int Pr = DX_GROUP / RG; return Pr < 8 ? Pr : 8; }   // channel blocks per row
-__host__ __device__ inline int dx_q_regs(int RG) { return (DX_W / dx_score_blocks(RG)) / 2; }   // 4 per query column, DS/8 columns per wave
+__host__ __device__ inline int dx_q_regs(int RG, int AW = DX_W) { return (AW / dx_score_blocks(RG)) / 2; }   // 4 per query column, DS/8 columns per wave
 
 struct DxArgs {
   const float* wpack;                                  // [32 members][DX_NREG][DX_NT]
   const float* qpack;                                  // [32 members][dx_q_regs(RG)][DX_NT]   (layout depends on RG)
   const float* b_p1_0; const float* b_p1c; const float* b_p2;      // prenet biases: layer 1 raw (step 0), composite (steps >= 1), layer 2
+  const float* b_p3;                                   // layer 3 (PD = 3)
   const float* b_ag; const float* b_ac;                // attention GRU: gates [2H] (r|u), candidate [H]
   const float* b_g1f;                                  // folded GRU 1: [4H] = gates (r|u) | candidate-x | o0
   const float* b_g1c; const float* b_g2g; const float* b_g2c;
@@ -207,6 +214,16 @@ __device__ __forceinline__ void dx_pass2(const float (&W)[DX_NREG], const float*
       acc[c][r] = fmaf(W[REG0 + 2 * c + 0], xv.x, acc[c][r]);
       acc[c][r] = fmaf(W[REG0 + 2 * c + 1], xv.y, acc[c][r]);
     }
+  }
+}
+// the 64-wide pass (PD = 3: attention GRU x rows): 1 input per lane
+template <int REG0, int NCOLS, int RG>
+__device__ __forceinline__ void dx_pass1(const float (&W)[DX_NREG], const float* x, int lane, float (&acc)[NCOLS][RG]) {
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float xv = x[r * DXS_LD + lane];
+#pragma unroll
+    for (int c = 0; c < NCOLS; ++c) acc[c][r] = fmaf(W[REG0 + c], xv, acc[c][r]);
   }
 }
 template <int NCOLS, int RG>
@@ -540,8 +557,10 @@ __global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const i
   } while (0)
 
 // MAN: the manual-attention instantiation (a.manual != null); the plain one carries none of its branches, loads or address selects
-template <int RG, bool TAPE = false, bool MAN = false>
+// AW: attention_size (128 / 256 / 512); PD: decoder prenet layers (2: [256, 128]; 3: [256, 128, 64])
+template <int RG, bool TAPE = false, bool MAN = false, int AW = DX_W, int PD = 2>
 __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
+  static_assert((AW == DX_W && PD == 2) || !TAPE, "the training forward exists at the reference widths only");
   extern __shared__ __attribute__((aligned(16))) float dx_smem[];
   DxArgs a = a_in;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -551,7 +570,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   // score phase: the Pr members of a row form Pc channel blocks x Pp position blocks (the partial scores a member has to collect
   // grow with Pc * T_in, its own work with T_in / Pp * 256 / Pc)
   constexpr int Pc = Pr < 8 ? Pr : 8, Pp = Pr / Pc;
-  constexpr int DS = DX_W / Pc;              // score channels per member (32; 64 at RG = 8)
+  constexpr int DS = AW / Pc;                // score channels per member (AW = 256: 32; 64 at RG = 8)
+  static_assert(DS >= 8 && DS <= 64, "query columns per wave / the qv, vv, bq slots");
   constexpr int QC = DS / 8;                 // query columns per wave
   constexpr int QR = 4 * QC;                 // query-layer registers per thread
   constexpr int CH = DS / 4;                 // channels per lane in the score phase (a quad of lanes covers a position)
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   for (int i = tid; i < TS * (DS / 4); i += DX_NT) {
     const int j = i / (DS / 4), d4 = i % (DS / 4);
     float4 k4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (brow < a.B && j < psn) k4 = *reinterpret_cast<const float4*>(a.keys + ((size_t)brow * T + ps0 + j) * DX_W + cb * DS + 4 * d4);
+    if (brow < a.B && j < psn) k4 = *reinterpret_cast<const float4*>(a.keys + ((size_t)brow * T + ps0 + j) * AW + cb * DS + 4 * d4);
     *reinterpret_cast<float4*>(Kc + (size_t)j * DS + 4 * d4) = k4;
   }
   for (int i = tid; i < T * (DC / 4); i += DX_NT) {
@@ -660,6 +680,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       case DXB_G2C: v = a.b_g2c[n8]; break;
       case DXB_F0: if (w < NCF && member * NCF + w < a.rM) v = a.b_f[member * NCF + w]; break;
       case DXB_F1: if (w + 8 < NCF && member * NCF + w + 8 < a.rM) v = a.b_f[member * NCF + w + 8]; break;
+      case DXB_P3: if (PD == 3 && w < 2) v = a.b_p3[member * 2 + w]; break;
       default: break;
     }
     bl[tid] = v;
@@ -758,11 +779,28 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     dx_pass<DXR_AGH, 2, RG>(W, st + DXS_HATT, lane, reinterpret_cast<float (&)[2][RG]>(aga));
     dx_gather<RG, DX_P2, false>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
     __syncthreads();
+    if constexpr (PD == 3) {
+      // ================= prenet layer 3 (64 columns, two per member); its output takes the OUT2 slot, dead until the end of the step =================
+      if (wave < 2) {
+        float acc[1][RG], s[1][RL];
+        dx_zero<1, RG>(acc);
+        dx_pass2<DXR_AGX + 3, 1, RG>(W, st + DXS_P2, lane, acc);
+        dx_reduce<1, RG>(acc, s, lane);
+        if (epl) {
+#pragma unroll
+          for (int q = 0; q < RL; ++q)
+            dx_publish(X + xl.p3 + erow[q] * DX_P3 + member * 2 + wave, fmaxf(s[0][q] + bl[DXB_P3 * DX_NW + wave], 0.f), tag, rt);
+        }
+      }
+      dx_gather<RG, DX_P3, false>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
+      __syncthreads();
+    }
     DX_STAMP(1);
     // ================= attention GRUCell (tacotron.py:127-130; A.6): gates, then candidate =================
     {
       float s[3][RL];
-      dx_pass2<DXR_AGX, 3, RG>(W, st + DXS_P2, lane, aga);
+      if constexpr (PD == 3) dx_pass1<DXR_AGX, 3, RG>(W, st + DXS_OUT2, lane, aga);
+      else dx_pass2<DXR_AGX, 3, RG>(W, st + DXS_P2, lane, aga);
       dx_reduce<3, RG>(aga, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {

@@ -181,7 +181,7 @@ struct taco_model {
   std::vector<unsigned> bf3_idx; std::vector<Bf3Seg> bf3_segs;
   int last_bptt = 0;           // the last decoder backward ran as the persistent launch (taco_debug_decoder_info out16[9])
   size_t dbx_pack = 0;         // training shadow model: the persistent BPTT kernel's rows (dbx_build_pack)
-  size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
+  size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_p3 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
   int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
   int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
@@ -421,11 +421,21 @@ static GruDec make_grudec(taco_model* m, const std::string& name, int I, int H) 
 static bool is_simple(const taco_model* m);
 
 // ---- persistent XCD-local decoder: per-thread weight packs (mirror of the pass mapping in taco_decoder_xcd.h) ----
+// The persistent decoder exists for 256-wide cells and memory, two decoder layers, and the attention widths / prenet depths of the presets of
+// hparams.py:71-117: attention_size 128 / 256 / 512, dec_prenet_sizes [256, 128] or [256, 128, 64].
+static int dx_prenet_depth(const taco_model* m) {
+  const taco_hparams& hp = m->hp;
+  if (hp.dec_prenet_n == 2 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2) return 2;
+  if (hp.dec_prenet_n == 3 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2 && hp.dec_prenet[2] == DX_P3) return 3;
+  return 0;
+}
+static bool dx_reference_widths(const taco_model* m) { return m->hp.attention_size == DX_W && dx_prenet_depth(m) == 2; }
 static bool dx_widths_ok(const taco_model* m) {
   const taco_hparams& hp = m->hp;
-  return hp.attention_state_size == DX_W && hp.dec_rnn_size == DX_W && hp.attention_size == DX_W && 2 * hp.enc_rnn_size == DX_W &&
-         hp.dec_prenet_n == 2 && hp.dec_prenet[0] == DX_W && hp.dec_prenet[1] == DX_P2 && hp.dec_layer_num == 2 &&
-         hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP;
+  const bool aw = hp.attention_size == 128 || hp.attention_size == 256 || hp.attention_size == 512;
+  return hp.attention_state_size == DX_W && hp.dec_rnn_size == DX_W && aw && 2 * hp.enc_rnn_size == DX_W && dx_prenet_depth(m) != 0 &&
+         hp.dec_layer_num == 2 && hp.num_mels * hp.reduction_factor <= 16 * DX_GROUP &&
+         (dx_reference_widths(m) || !m->tp);       // the training forward / BPTT kernels: reference widths only
 }
 // one weight column of a pass: registers reg0 .. reg0+kw-1 of every thread = W[row0 + kw*lane + e][col(wave)]  (col < 0: none)
 template <class ColFn>
@@ -445,7 +455,8 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   const taco_hparams& hp = m->hp;
   const int H = DX_W, rM = hp.num_mels * hp.reduction_factor, NCF = cdiv(rM, DX_GROUP);
   const int S = is_simple(m) ? hp.speaker_embedding_size : 0;     // 'simple': S speaker rows behind the prenet output / behind [h_att | ctx]
-  const int IA = DX_P2 + S, Z = 2 * H + S;                        // first h row of the attention GRU kernels / of the folded GRU 1 matrix
+  const int PD = dx_prenet_depth(m), AW = hp.attention_size;
+  const int IA = (PD == 3 ? DX_P3 : DX_P2) + S, Z = 2 * H + S;    // first h row of the attention GRU kernels / of the folded GRU 1 matrix
   std::vector<float> pack((size_t)DX_GROUP * DX_NREG * DX_NT, 0.f);
   const auto& W2 = T_(m, "decoder/prenet/dense_2/kernel").data;
   const auto& agk = T_(m, "decoder/attention_gru/gates/kernel").data; const auto& ack = T_(m, "decoder/attention_gru/candidate/kernel").data;
@@ -462,7 +473,12 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
     auto put = [&](int reg0, int kw, const float* W, int ldw, int row0, auto col) { dx_fill_col(pack, DX_NREG, mem, reg0, kw, W, ldw, row0, col); };
     put(DXR_P2, 4, W2.data(), DX_P2, 0, c4);
     put(DXR_AGH, 4, agk.data(), 2 * H, IA, c8); put(DXR_AGH + 4, 4, agk.data(), 2 * H, IA, cu);                  // h rows
-    put(DXR_AGX, 2, agk.data(), 2 * H, 0, c8); put(DXR_AGX + 2, 2, agk.data(), 2 * H, 0, cu); put(DXR_AGX + 4, 2, ack.data(), H, 0, c8);
+    if (PD == 3) {      // 64 input rows, one per lane: r, u, candidate-x in one register each; behind them prenet layer 3 (p2 -> column 2m + w, waves 0-1)
+      put(DXR_AGX, 1, agk.data(), 2 * H, 0, c8); put(DXR_AGX + 1, 1, agk.data(), 2 * H, 0, cu); put(DXR_AGX + 2, 1, ack.data(), H, 0, c8);
+      put(DXR_AGX + 3, 2, T_(m, "decoder/prenet/dense_3/kernel").data.data(), DX_P3, 0, [&](int w) { return w < 2 ? mem * 2 + w : -1; });
+    } else {
+      put(DXR_AGX, 2, agk.data(), 2 * H, 0, c8); put(DXR_AGX + 2, 2, agk.data(), 2 * H, 0, cu); put(DXR_AGX + 4, 2, ack.data(), H, 0, c8);
+    }
     put(DXR_AC, 4, ack.data(), H, IA, c8);
     auto fx = [&](int w) { return 2 * H + mem * 8 + w; };
     auto fo = [&](int w) { return 3 * H + mem * 8 + w; };
@@ -485,8 +501,9 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
     for (int k = 0; k < S; ++k)
       for (int n = 0; n < H; ++n) {
         float* o = &sw[(size_t)k * DXRB_N * H + n];
-        o[DXRB_AR * H] = agk[(size_t)(DX_P2 + k) * 2 * H + n]; o[DXRB_AU * H] = agk[(size_t)(DX_P2 + k) * 2 * H + H + n];
-        o[DXRB_AX * H] = ack[(size_t)(DX_P2 + k) * H + n];
+        const int px = IA - S;                                      // prenet output rows in front of the speaker rows
+        o[DXRB_AR * H] = agk[(size_t)(px + k) * 2 * H + n]; o[DXRB_AU * H] = agk[(size_t)(px + k) * 2 * H + H + n];
+        o[DXRB_AX * H] = ack[(size_t)(px + k) * H + n];
         const float* wf = &Wf[(size_t)(2 * H + k) * 4 * H];
         o[DXRB_G1R * H] = wf[n]; o[DXRB_G1U * H] = wf[H + n]; o[DXRB_G1X * H] = wf[2 * H + n]; o[DXRB_O0 * H] = wf[3 * H + n];
       }
@@ -495,12 +512,13 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   // query layer: slot s of a row (s = member % Pr) scores channel block s % Pc and holds columns (s % Pc)*DS + w*QC + i of it; one pack
   // per rows-per-group
   for (int q = 0; q < 4; ++q) {
-    const int RG = 1 << q, Pr = DX_GROUP / RG, Pc = dx_score_blocks(RG), DS = DX_W / Pc, QC = DS / 8, QR = dx_q_regs(RG);
+    const int RG = 1 << q, Pr = DX_GROUP / RG, Pc = dx_score_blocks(RG), DS = AW / Pc, QC = DS / 8, QR = dx_q_regs(RG, AW);
+    if (DS < 8 || DS > 64) continue;                                // (no instantiation: attention_size 128 below / 512 above 4 rows per group)
     std::vector<float> qp((size_t)DX_GROUP * QR * DX_NT, 0.f);
     for (int mem = 0; mem < DX_GROUP; ++mem)
       for (int i = 0; i < QC; ++i) {
         const int cb = (mem % Pr) % Pc;
-        dx_fill_col(qp, QR, mem, 4 * i, 4, wq.data(), H, 0, [&](int w) { return cb * DS + w * QC + i; });
+        dx_fill_col(qp, QR, mem, 4 * i, 4, wq.data(), AW, 0, [&](int w) { return cb * DS + w * QC + i; });
       }
     m->dx_qpack[q] = arena_put(m, qp.data(), qp.size());
   }
@@ -508,6 +526,7 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
   m->dx_b_p1_0 = putv(T_(m, "decoder/prenet/dense_1/bias").data);
   m->dx_b_p1c = putv(bc);
   m->dx_b_p2 = putv(T_(m, "decoder/prenet/dense_2/bias").data);
+  if (PD == 3) m->dx_b_p3 = putv(T_(m, "decoder/prenet/dense_3/bias").data);
   m->dx_b_ag = putv(T_(m, "decoder/attention_gru/gates/bias").data);
   m->dx_b_ac = putv(T_(m, "decoder/attention_gru/candidate/bias").data);
   m->dx_b_g1f = putv(bf);
@@ -1441,8 +1460,11 @@ static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, 
 }
 
 static int dx_rows_per_group(const taco_model* m, int B) {
-  if (m->dx_rows == 1 || m->dx_rows == 2 || m->dx_rows == 4 || m->dx_rows == 8) { if (m->dx_rows * DX_NGROUP >= B) return m->dx_rows; }
-  int RG = 1;
+  // the other presets (attention_size 128 / 512, three prenet layers) are instantiated for 4 and 8 rows per group only: smaller batches run
+  // as padded groups of 4 (a step costs the same there: its time is the chain of exchanges, not the rows)
+  const int lo = dx_reference_widths(m) ? 1 : 4;
+  if (m->dx_rows == 1 || m->dx_rows == 2 || m->dx_rows == 4 || m->dx_rows == 8) { if (m->dx_rows * DX_NGROUP >= B && m->dx_rows >= lo) return m->dx_rows; }
+  int RG = lo;
   while (RG < 8 && RG * DX_NGROUP < B) RG *= 2;
   return RG;
 }
@@ -1489,14 +1511,15 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
   // training shadow model's pack has them (taco_model_finalize)
   if (!m->dx_mode || !m->dx_pack || (teacher && !m->tp) || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
   const int RG = dx_rows_per_group(m, B);
-  return dx_lds_floats(RG, T_in, m->tp != nullptr) * sizeof(float) <= 160 * 1024;
+  if (m->hp.attention_size == 512 && RG > 4) return false;        // 128 score channels per member: no instantiation (query registers, the q / v slots)
+  return dx_lds_floats(RG, T_in, m->tp != nullptr, m->hp.attention_size) * sizeof(float) <= 160 * 1024;
 }
-template <int RG, bool TAPE>
+template <int RG, bool TAPE, int AW = DX_W, int PD = 2>
 static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
   if constexpr (!TAPE) {
-    if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, true>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
+    if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, true, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
   }
-  hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE, false>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
+  hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE, false, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1517,7 +1540,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   }
   a.wpack = AP(m, m->dx_pack);
   a.qpack = AP(m, m->dx_qpack[RG == 1 ? 0 : RG == 2 ? 1 : RG == 4 ? 2 : 3]);
-  a.b_p1_0 = AP(m, m->dx_b_p1_0); a.b_p1c = AP(m, m->dx_b_p1c); a.b_p2 = AP(m, m->dx_b_p2); a.b_ag = AP(m, m->dx_b_ag); a.b_ac = AP(m, m->dx_b_ac);
+  a.b_p1_0 = AP(m, m->dx_b_p1_0); a.b_p1c = AP(m, m->dx_b_p1c); a.b_p2 = AP(m, m->dx_b_p2); a.b_p3 = AP(m, m->dx_b_p3); a.b_ag = AP(m, m->dx_b_ag); a.b_ac = AP(m, m->dx_b_ac);
   a.b_g1f = AP(m, m->dx_b_g1f); a.b_g1c = AP(m, m->dx_b_g1c); a.b_g2g = AP(m, m->dx_b_g2g); a.b_g2c = AP(m, m->dx_b_g2c);
   a.b_f = AP(m, m->dx_b_f);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
@@ -1529,7 +1552,17 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
   if (!g_precleared) HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
-  const size_t lds = dx_lds_floats(RG, T_in, tape != nullptr) * sizeof(float);
+  const size_t lds = dx_lds_floats(RG, T_in, tape != nullptr, m->hp.attention_size) * sizeof(float);
+  if (!dx_reference_widths(m)) {      // the presets of hparams.py:71-117 that the reference ships switched off: (attention_size, prenet layers)
+    const int aw = m->hp.attention_size, pd = dx_prenet_depth(m);
+    if (tape) return fail(TACO_ERR_UNSUPPORTED, "the persistent training forward exists at the reference widths only");
+    if (aw == 128 && pd == 2) return RG == 4 ? dx_launch_rg<4, false, 128, 2>(st, a, lds) : dx_launch_rg<8, false, 128, 2>(st, a, lds);      // "Single Speaker"
+    if (aw == 256 && pd == 3) return RG == 4 ? dx_launch_rg<4, false, 256, 3>(st, a, lds) : dx_launch_rg<8, false, 256, 3>(st, a, lds);      // "Single Speaker with generalization"
+    if (aw == 512 && pd == 3 && RG == 4) return dx_launch_rg<4, false, 512, 3>(st, a, lds);                                                   // "Deep Voice 2" (the first, disabled block)
+    if (aw == 128 && pd == 3) return RG == 4 ? dx_launch_rg<4, false, 128, 3>(st, a, lds) : dx_launch_rg<8, false, 128, 3>(st, a, lds);
+    if (aw == 512 && pd == 2 && RG == 4) return dx_launch_rg<4, false, 512, 2>(st, a, lds);
+    return fail(TACO_ERR_STATE, "no persistent decoder instantiation for attention_size %d, %d prenet layers, %d rows per group", aw, pd, RG);
+  }
   if (tape) {
     switch (RG) {
       case 1: return dx_launch_rg<1, true>(st, a, lds);
@@ -2116,6 +2149,11 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define DX_ATTR(RG, AW, PD) \
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, false, false, AW, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, false, true, AW, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  DX_ATTR(4, 128, 2) DX_ATTR(8, 128, 2) DX_ATTR(4, 256, 3) DX_ATTR(8, 256, 3) DX_ATTR(4, 512, 3) DX_ATTR(4, 128, 3) DX_ATTR(8, 128, 3) DX_ATTR(4, 512, 2)
+#undef DX_ATTR
   HIPCHK(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
   m->events.resize(192);
   for (auto& e : m->events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2250,11 +2288,13 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
   };
   {  // decoder loop
     std::string why = why_common(B);
-    if (why.empty() && !m->dx_pack) why = "widths differ from the reference's (256-wide attention / decoder cells, prenet 256-128, 2 decoder layers, r * num_mels <= 512)";
+    if (why.empty() && !m->dx_pack) why = "widths outside the presets (256-wide decoder cells and memory, attention_size 128 / 256 / 512, prenet 256-128[-64], 2 decoder layers, r * num_mels <= 512)";
     const int RG = dx_rows_per_group(m, B);
-    if (why.empty() && dx_lds_floats(RG, T_in, m->tp != nullptr) * sizeof(float) > 160 * 1024)
+    if (why.empty() && m->hp.attention_size == 512 && RG > 4) why = "attention_size 512 with more than 32 rows (no instantiation at 8 rows per group)";
+    if (why.empty() && dx_lds_floats(RG, T_in, m->tp != nullptr, m->hp.attention_size) * sizeof(float) > 160 * 1024)
       why = "T_in = " + std::to_string(T_in) + " does not fit a member's LDS at " + std::to_string(RG) + " rows per group";
-    if (why.empty()) s += "decoder loop: persistent k_decoder_xcd<" + std::to_string(RG) + "> (" + std::string(manual ? "manual alignments" : "computed alignments") + ", " +
+    if (why.empty()) s += "decoder loop: persistent k_decoder_xcd<" + std::to_string(RG) + (dx_reference_widths(m) ? std::string("") : ", attention " + std::to_string(m->hp.attention_size) + ", " +
+                          std::to_string(dx_prenet_depth(m)) + " prenet layers") + "> (" + std::string(manual ? "manual alignments" : "computed alignments") + ", " +
                           std::string(m->dx_mode == 2 ? "write-through exchanges forced" : "XCD-local exchanges when the census finds 32 workgroups per XCD") + ")";
     else s += "decoder loop: one launch per stage -- " + why;
   }
@@ -2269,7 +2309,8 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
     if (why.empty()) s += "; post-net scan: persistent " + std::string(m->persist == 1 ? "k_bigru_duo<" : "k_bigru_xcd<") + std::to_string(RG) + ">";
     else s += "; post-net scan: resident per-row kernels -- " + why;
   }
-  s += "; encoder scan: k_bigru_res (rows resident per workgroup); feed-forward: ";
+  s += m->enc.rnn == 128 && m->persist == 1 ? "; encoder scan: k_bigru_quad (a row and direction per workgroup, K split inside a quad of lanes); feed-forward: "
+                                            : "; encoder scan: k_bigru_res (rows resident per workgroup); feed-forward: ";
   s += m->bf3 ? "split-bf16 MFMA (k_gemm_bf3 / k_pointwise_chain)" : "exact-fp32 MFMA (k_gemm)";
   snprintf(out, (size_t)out_len, "%s", s.c_str());
   return 0;

@@ -160,6 +160,62 @@ def test_simple_multispeaker_on_the_persistent_decoder(atype, B):
     m.check_device_errors()
 
 
+PRESETS = {   # hparams.py:71-117: the blocks the reference ships switched off (`if False` / `elif False`); decoder-side fields
+    "single_speaker": dict(attention_size=128),
+    "single_speaker_generalization": dict(attention_size=256, dec_prenet_sizes=[256, 128, 64]),
+    "deep_voice_2_first_block": dict(attention_size=512, dec_prenet_sizes=[256, 128, 64]),
+    "attention_128_three_prenet_layers": dict(attention_size=128, dec_prenet_sizes=[256, 128, 64]),
+    "attention_512_two_prenet_layers": dict(attention_size=512),
+}
+
+
+@pytest.mark.parametrize("B", [5, 32, 40])
+@pytest.mark.parametrize("atype", ["bah_mon", "bah_norm"])
+@pytest.mark.parametrize("preset", sorted(PRESETS))
+def test_other_presets_on_the_persistent_decoder(preset, atype, B):
+    """The other presets of hparams.py:71-117 (attention_size 128 / 512, a third decoder prenet layer of 64) are template parameters
+    of k_decoder_xcd: every state of every step against the float64 oracle, at 4 rows per group (B <= 32; smaller batches are padded
+    groups) and 8 (B = 40; attention_size 512 has no instantiation there and must say so in engine_plan and fall back)."""
+    n = 5
+    ohp = O.OracleHParams(max_iters=n, attention_type=atype, **PRESETS[preset])
+    w = O.init_weights(ohp, 1, 341)
+    ids, L = O.synthetic_inputs(B, 37, 342 + B, ragged=True)
+    m, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, n)
+    plan = m.engine_plan(B, 37)
+    if ohp.attention_size == 512 and B > 32:
+        assert info["protocol"] == 0 and "one launch per stage" in plan and "attention_size 512" in plan, (info, plan)
+    else:
+        assert info["has_pack"] and info["protocol"] in (1, 2), (info, plan)
+        assert "persistent k_decoder_xcd<%d, attention %d, %d prenet layers>" % (4 if B <= 32 else 8, ohp.attention_size, len(ohp.dec_prenet_sizes)) in plan, plan
+
+
+@pytest.mark.parametrize("preset,model_type", [("single_speaker", "simple"), ("deep_voice_2_first_block", "simple"), ("single_speaker_generalization", "deepvoice")])
+def test_other_presets_multi_speaker_manual_attention_and_end_to_end(preset, model_type):
+    """... with the multi-speaker model types ('simple': the speaker rows of the attention GRU sit behind a 64-row prenet output
+    there), with manual alignments (the MAN instantiations), and the whole forward end to end (the feed-forward stages of these
+    presets -- other conv-bank / post-net widths -- run the general kernels)."""
+    import torch
+    ns, n, B, T_in = 3, 5, 6, 29
+    ohp = O.OracleHParams(max_iters=n, model_type=model_type, **PRESETS[preset])
+    w = O.init_weights(ohp, ns, 351)
+    ids, L = O.synthetic_inputs(B, T_in, 352, ragged=True)
+    spk = (np.arange(B) % ns).astype(np.int32)
+    m, info, _, taps = _decoder_vs_oracle(ohp, w, ids, L, n, spk=spk, ns=ns)
+    assert info["has_pack"] and info["protocol"] in (1, 2), info
+    man = np.random.RandomState(353).dirichlet(np.ones(T_in), (B, n))
+    refm = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, manual_alignments=man, honor_stop=False)
+    mel, al, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk, manual_alignments=man)
+    torch.cuda.synchronize()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    assert maxabs(mel.cpu().numpy(), refm["mel"]) < 2e-4 and maxabs(al.cpu().numpy(), refm["alignments"]) < 2e-4
+    lin, al = m.run(inputs=ids, input_lengths=L, speaker_id=spk)
+    torch.cuda.synchronize()
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns)
+    k = ref["mel"].shape[1]
+    assert maxabs(m.mel_outputs.cpu().numpy()[:, :k], ref["mel"]) < 2e-4 and maxabs(lin.cpu().numpy()[:, :k], ref["linear"]) < 2e-4
+    m.check_device_errors()
+
+
 def test_teacher_forcing_still_runs_the_launch_engine():
     """teacher-forced frames (helpers.py:35-67; the training forward) are not a mode of the persistent decoder: same results from
     the launch-per-stage loop as before."""
@@ -329,7 +385,7 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     assert "switched off" in m.engine_plan(32, 128)
     t = build_model(tiny_hp(), O.init_weights(tiny_hp(), 1, 403))
     plan = t.engine_plan(4, 9)
-    assert "one launch per stage -- widths differ" in plan and "resident per-row kernels" in plan, plan
+    assert "one launch per stage -- widths outside the presets" in plan and "resident per-row kernels" in plan, plan
 
 
 def test_a_device_fault_is_reported_by_the_forward_that_saw_it():
