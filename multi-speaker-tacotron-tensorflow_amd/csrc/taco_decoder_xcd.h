@@ -98,7 +98,7 @@ enum { DXT_P1 = 0, DXT_HA, DXT_RA, DXT_UA, DXT_CA, DXT_RHA, DXT_Q, DXT_O0, DXT_R
        DXT_R2, DXT_U2, DXT_C2, DXT_RH2, DXT_H2, DXT_O2, DXT_N };
 
 // exchange buffers of one group, in granules, for RG rows (the host sizes the buffer with RG = 8)
-struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, p3, total; };
+struct DxX { int p1, p2, rha, ha, sc, ctx, rh1, h1, o1, rh2, h2, p3, fb, total; };
 __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
   DxX x; int o = 0;
   x.p1 = o; o += RG * DX_W;  x.p2 = o; o += RG * DX_P2; x.rha = o; o += RG * DX_W; x.ha = o; o += RG * DX_W;
@@ -106,6 +106,7 @@ __host__ __device__ inline DxX dx_xlayout(int RG, int T_in) {
   x.ctx = o; o += RG * DX_W; x.rh1 = o; o += RG * DX_W; x.h1 = o; o += RG * DX_W; x.o1 = o; o += RG * DX_W;
   x.rh2 = o; o += RG * DX_W; x.h2 = o; o += RG * DX_W;
   x.p3 = o; o += RG * DX_P3;                              // (PD = 3 only)
+  x.fb = o; o += RG * DX_P2;                              // the step's last frame (TAPE with own_fb: rnn_decoder_test_mode), num_mels <= 128
   x.total = o;
   return x;
 }
@@ -146,6 +147,8 @@ struct DxArgs {
   const float* rowbias;                                // [B, DXRB_N, 256] ('simple') or null
   // TAPE instantiation only (training forward):
   const float* teacher;                                // [B, n, mels]: frame t feeds the prenet of step t + 1 (helpers.py:44,66)
+  int own_fb;                                          // rnn_decoder_test_mode (helpers.py:63-64; the test model of train.py:158-166): no teacher, the prenet of step t + 1 reads the
+                                                       // LAST of the r frames step t emitted -- with the raw prenet rows of the teacher-form pack, so the frame is exchanged first
   float* tape; size_t tstride;                         // 256-wide per-step arrays: slot s, row (b, t) at tape + s*tstride + (b*n + t)*256
   float* tp_p2; float* tp_ctx; int ld_p2, ld_ctx;      // prenet output [B, n, ld_p2], context [B, n, ld_ctx] (wider rows: 'simple' parks the speaker embedding behind them)
   float* tp_e; float* tp_alpha;                        // raw scores [B, n, T_in]; alignments [B, n + 1, T_in] (slot t + 1 = step t)
@@ -1048,7 +1051,61 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     DX_STAMP(10);
     // ================= prenet layer 1 of step t+1 (composite: frame projection folded in, helpers.py:31) and the frame
     // projection of step t (tacotron.py:178-179), straight into the mel buffer =================
-    {
+    auto store_frame = [&](int q, float y0, float y1, bool share) {      // the lane's two frame-projection columns of row erow[q]: mel buffer, stop rule, (own_fb) the exchange
+      const int b = row0 + erow[q];
+      const int n0 = member * NCF + wave, n1 = n0 + 8;
+      const bool v0 = wave < NCF && n0 < a.rM, v1 = wave + 8 < NCF && n1 < a.rM;
+      if (b < a.B) {
+        float* mrow = a.mel + (size_t)b * a.n * a.rM + (size_t)t * a.rM;
+        bool nzf = false;
+        if (v0) { mrow[n0] = y0; nzf = nzf || (y0 != 0.f); }
+        if (v1) { mrow[n1] = y1; nzf = nzf || (y1 != 0.f); }
+        if (nzf) a.nz[(size_t)t * a.B + b] = 1;                            // stop rule helpers.py:29
+      }
+      if (share) {                                                         // last of the r frames -> every member's copy of the next prenet input
+        const int f0 = a.rM - a.mels;
+        if (v0 && n0 >= f0) dx_publish(X + xl.fb + erow[q] * DX_P2 + (n0 - f0), y0, tag, rt);
+        if (v1 && n1 >= f0) dx_publish(X + xl.fb + erow[q] * DX_P2 + (n1 - f0), y1, tag, rt);
+      }
+    };
+    if (TAPE && a.own_fb) {
+      // rnn_decoder_test_mode: the frame first (its own stage and exchange), then the prenet layer over it
+      {
+        float fa[2][RG], s[2][RL];
+        dx_zero<2, RG>(fa);
+        dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, fa);
+        dx_reduce<2, RG>(fa, s, lane);
+        if (epl) {
+#pragma unroll
+          for (int q = 0; q < RL; ++q) store_frame(q, s[0][q] + bl[DXB_F0 * DX_NW + wave], s[1][q] + bl[DXB_F1 * DX_NW + wave], t + 1 < a.n);
+        }
+      }
+      if (t + 1 < a.n) {
+        for (int i = tid; i < RG * a.mels; i += DX_NT) {
+          const int r = i / a.mels, j = i - r * a.mels;
+          float v[1];
+          dx_poll<1>(X + xl.fb + r * DX_P2 + j, 0, tag, v, rt);
+          tfb[r * DX_W + j] = v[0];
+        }
+      }
+      __syncthreads();
+      {
+        float pa[1][RG], s[1][RL];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) pa[0][r] = p1a[0][r];
+        if (!G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, pa);
+        dx_pass<DXR_P1O, 1, RG, DX_NREG, DX_W>(W, tfb, lane, pa);
+        dx_reduce<1, RG>(pa, s, lane);
+        if (epl && t + 1 < a.n) {
+#pragma unroll
+          for (int q = 0; q < RL; ++q) {
+            const float p1v = fmaxf(s[0][q] + bl[DXB_P1 * DX_NW + wave], 0.f);
+            dx_publish(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
+            if (tval[q]) a.tape[(unsigned)DXT_P1 * tstr + trow[q] + (unsigned)(t + 1) * DX_W] = p1v;
+          }
+        }
+      }
+    } else {
       float fa[3][RG], s[3][RL];
       dx_zero<3, RG>(fa);
 #pragma unroll
@@ -1068,16 +1125,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
             dx_publish(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
             if (TAPE && tval[q]) a.tape[(unsigned)DXT_P1 * tstr + trow[q] + (unsigned)(t + 1) * DX_W] = p1v;
           }
-          const int b = row0 + erow[q];
-          if (b < a.B) {
-            const float y0 = s[0][q] + bl[DXB_F0 * DX_NW + wave], y1 = s[1][q] + bl[DXB_F1 * DX_NW + wave];
-            const int n0 = member * NCF + wave, n1 = n0 + 8;
-            float* mrow = a.mel + (size_t)b * a.n * a.rM + (size_t)t * a.rM;
-            bool nzf = false;
-            if (wave < NCF && n0 < a.rM) { mrow[n0] = y0; nzf = nzf || (y0 != 0.f); }
-            if (wave + 8 < NCF && n1 < a.rM) { mrow[n1] = y1; nzf = nzf || (y1 != 0.f); }
-            if (nzf) a.nz[(size_t)t * a.B + b] = 1;                            // stop rule helpers.py:29
-          }
+          store_frame(q, s[0][q] + bl[DXB_F0 * DX_NW + wave], s[1][q] + bl[DXB_F1 * DX_NW + wave], false);
         }
       }
     }

@@ -2307,6 +2307,7 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
     int RG = 1;
     while (RG * DX_NGROUP < B) RG *= 2;
     if (why.empty()) s += "; post-net scan: persistent " + std::string(m->persist == 1 ? "k_bigru_duo<" : "k_bigru_xcd<") + std::to_string(RG) + ">";
+    else if (c.rnn == 128 && m->persist == 1) s += "; post-net scan: k_bigru_quad (post_rnn_size 128: a row and direction per workgroup, its weights resident, no exchange between workgroups)";
     else s += "; post-net scan: resident per-row kernels -- " + why;
   }
   s += m->enc.rnn == 128 && m->persist == 1 ? "; encoder scan: k_bigru_quad (a row and direction per workgroup, K split inside a quad of lanes); feed-forward: "

@@ -707,10 +707,11 @@ static int decoder_forward_train(const TrainCtx& x, const float* enc_out, int B,
     hipLaunchKernelGGL(k_tile_rows, EWGRID((size_t)B * n * S), 0, st, spk_emb, w.pz[np - 1], Pz, Pl, B, n, S);
     HIPCHK(hipGetLastError());
   }
-  if (!feed_back && w.tape256 && hp.dec_layer_num == 2 && (size_t)DXT_N * w.tstride < (1u << 31) && dx_usable(m, B, T_in, nullptr, teach)) {
-    // the whole teacher-forced loop as ONE persistent launch that also writes the tape (k_decoder_xcd<RG, true>, taco_decoder_xcd.h)
+  if (w.tape256 && hp.dec_layer_num == 2 && hp.num_mels <= DX_P2 && (size_t)DXT_N * w.tstride < (1u << 31) && dx_usable(m, B, T_in, nullptr, teach)) {
+    // the whole teacher-forced loop as ONE persistent launch that also writes the tape (k_decoder_xcd<RG, true>, taco_decoder_xcd.h);
+    // rnn_decoder_test_mode (feed_back): the same launch, the step's own last frame exchanged in place of the teacher's
     DxArgs ta; memset(&ta, 0, sizeof ta);
-    ta.teacher = teach; ta.tape = w.tape256; ta.tstride = w.tstride; ta.tp_p2 = w.pz[np - 1]; ta.ld_p2 = Pz; ta.tp_ctx = w.ctx; ta.ld_ctx = Dc;
+    ta.teacher = feed_back ? nullptr : teach; ta.own_fb = feed_back ? 1 : 0; ta.tape = w.tape256; ta.tstride = w.tstride; ta.tp_p2 = w.pz[np - 1]; ta.ld_p2 = Pz; ta.tp_ctx = w.ctx; ta.ld_ctx = Dc;
     ta.tp_e = w.g_e; ta.tp_alpha = w.alpha;
     return dx_launch(m, st, enc_out, nullptr, spk_emb, B, T_in, n, nullptr, mel, align_hist, nullptr, 0, w.keys, w.nz, w.xbuf, w.dxctl, w.rowbias,
                      att_init, dec_init ? dec_init[0] : nullptr, dec_init ? dec_init[1] : nullptr, &ta);

@@ -137,7 +137,8 @@ class Trainer(object):
     def set_decoder_engine(self, mode=1):
         """1 (default): at the reference widths the teacher-forced decoder loop and the post-net scan of the forward run as the
         persistent whole-chip kernels of inference with tape outputs (csrc/taco_decoder_xcd.h, taco_bigru_xcd.h); 0: one launch per
-        stage everywhere (round 1's engine; also what other widths, more than 64 rows and rnn_decoder_test_mode use)."""
+        stage everywhere (round 1's engine; also what other widths and more than 64 rows use).  rnn_decoder_test_mode is a mode of the
+        persistent kernel since round 4 (the step's own last frame is exchanged in place of the teacher's)."""
         mh = C.c_void_p(self._lib.taco_train_model(self._h))
         _lib.check(self._lib.taco_debug_set_decoder_persist(mh, int(mode), 0))
         if getattr(self, "_graph", None) is not None:

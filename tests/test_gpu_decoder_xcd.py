@@ -160,10 +160,11 @@ def test_simple_multispeaker_on_the_persistent_decoder(atype, B):
     m.check_device_errors()
 
 
-PRESETS = {   # hparams.py:71-117: the blocks the reference ships switched off (`if False` / `elif False`); decoder-side fields
-    "single_speaker": dict(attention_size=128),
-    "single_speaker_generalization": dict(attention_size=256, dec_prenet_sizes=[256, 128, 64]),
-    "deep_voice_2_first_block": dict(attention_size=512, dec_prenet_sizes=[256, 128, 64]),
+PRESETS = {   # hparams.py:71-117: the blocks the reference ships switched off (`if False` / `elif False`), field by field
+    "single_speaker": dict(attention_size=128, post_bank_channel_size=128, post_rnn_size=128),
+    "single_speaker_generalization": dict(attention_size=256, dec_prenet_sizes=[256, 128, 64], post_bank_channel_size=128, post_rnn_size=128),
+    "deep_voice_2_first_block": dict(attention_size=512, dec_prenet_sizes=[256, 128, 64], post_bank_channel_size=512, post_rnn_size=256),
+    # (the two remaining combinations of the decoder-side fields)
     "attention_128_three_prenet_layers": dict(attention_size=128, dec_prenet_sizes=[256, 128, 64]),
     "attention_512_two_prenet_layers": dict(attention_size=512),
 }
@@ -195,7 +196,7 @@ def test_other_presets_multi_speaker_manual_attention_and_end_to_end(preset, mod
     there), with manual alignments (the MAN instantiations), and the whole forward end to end (the feed-forward stages of these
     presets -- other conv-bank / post-net widths -- run the general kernels)."""
     import torch
-    ns, n, B, T_in = 3, 5, 6, 29
+    ns, n, B, T_in = 3, 11, 6, 29          # 6 x 44 = 264 output frames: from 256 rows on the linear head is the row sweep (csrc/taco_head.h; K = 256 at post_rnn_size 128)
     ohp = O.OracleHParams(max_iters=n, model_type=model_type, **PRESETS[preset])
     w = O.init_weights(ohp, ns, 351)
     ids, L = O.synthetic_inputs(B, T_in, 352, ragged=True)

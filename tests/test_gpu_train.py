@@ -408,6 +408,46 @@ def test_simple_multispeaker_training_gradients(ses, atype):
     tr.close()
 
 
+@pytest.mark.parametrize("model_type,atype,B,r", [("single", "bah_mon", 9, 4), ("simple", "bah", 5, 5), ("deepvoice", "bah_norm", 3, 4), ("single", "bah_mon", 37, 4)])
+def test_rnn_decoder_test_mode_on_the_persistent_kernel(model_type, atype, B, r):
+    """rnn_decoder_test_mode (helpers.py:63-64; the test model of train.py:158-166, run every test_interval): the decoder is fed the LAST
+    of the r frames it just emitted.  At the reference widths that is a mode of the TAPE instantiation of k_decoder_xcd (the frame is
+    exchanged between the group's members, then the prenet layer reads it with the raw kernel rows of the teacher-form pack): outputs and
+    loss against the float64 oracle's fed-back forward, rows per group 2 / 1 / 1 / 8, and against the launch-per-stage loop."""
+    import torch
+    import taco_amd
+    ns = 1 if model_type == "single" else 3
+    n = 7
+    hp = O.OracleHParams(max_iters=n, model_type=model_type, attention_type=atype, reduction_factor=r)
+    w = O.init_weights(hp, ns, 91)
+    T_in, T_out = 19, n * r
+    ids, L = O.synthetic_inputs(B, T_in, 92, ragged=True)
+    rs = np.random.RandomState(93)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    co = rs.uniform(0.5, 1.5, size=B)
+    spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
+    fb = O.forward(w, hp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, honor_stop=False, training=True)
+    tr = taco_amd.Trainer(to_product_hp(hp), w, num_speakers=ns)
+    got = {}
+    for mode in (1, 0):
+        tr.set_decoder_engine(mode)
+        losses = tr.forward_backward(ids, L, mt, lt, co, backward=False, keep_outputs=True, rnn_decoder_test_mode=True, speaker_id=spk)
+        torch.cuda.synchronize()
+        tr.check_device_errors()
+        info = tr.decoder_engine_info()
+        assert mode == 0 or info["protocol"] in (1, 2), (mode, info)      # (the word keeps the last persistent launch's answer when the launch-per-stage loop runs)
+        got[mode] = (tr.mel_outputs.cpu().numpy(), tr.linear_outputs.cpu().numpy(), tr.alignments.cpu().numpy(), float(losses[0]))
+        assert maxabs(got[mode][0], fb["mel"]) < 1e-4 and maxabs(got[mode][1], fb["linear"]) < 2e-4 and maxabs(got[mode][2], fb["alignments"]) < 1e-4, mode
+        assert abs(got[mode][3] - O.add_loss(fb["mel"], mt, fb["linear"], lt, co)["loss"]) < 2e-5
+    assert maxabs(got[1][0], got[0][0]) < 2e-5 and maxabs(got[1][2], got[0][2]) < 2e-5
+    # and the teacher-forced step right after it on the same trainer (the teacher buffer of the kernel's LDS was the fed-back frame's)
+    ref = O.forward(w, hp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, honor_stop=False, teacher_frames=mt[:, r - 1::r], training=True)
+    tr.set_decoder_engine(1)
+    tr.forward_backward(ids, L, mt, lt, co, backward=False, keep_outputs=True, speaker_id=spk)
+    torch.cuda.synchronize()
+    assert maxabs(tr.mel_outputs.cpu().numpy(), ref["mel"]) < 1e-4
+
+
 @pytest.mark.parametrize("model_type,atype,B", [("single", "bah_mon", 9), ("deepvoice", "bah", 3), ("simple", "bah_norm", 5), ("single", "bah_mon", 33),
                                                 ("deepvoice", "bah_mon", 20), ("single", "bah_norm", 18)])
 def test_training_forward_on_the_persistent_kernels(model_type, atype, B):
