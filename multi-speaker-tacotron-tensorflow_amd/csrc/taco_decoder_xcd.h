@@ -147,6 +147,8 @@ struct DxArgs {
   const float* rowbias;                                // [B, DXRB_N, 256] ('simple') or null
   // TAPE instantiation only (training forward):
   const float* teacher;                                // [B, n, mels]: frame t feeds the prenet of step t + 1 (helpers.py:44,66)
+  const float* p1o_raw;                                // [32 members][4][DX_NT] or null: the raw frame rows of prenet layer 1 for the registers DXR_P1O .. + 3 of a pack built in
+                                                       // composite form (teacher-forced decoding on an inference model); the layer's bias is then b_p1_0 at every step
   int own_fb;                                          // rnn_decoder_test_mode (helpers.py:63-64; the test model of train.py:158-166): no teacher, the prenet of step t + 1 reads the
                                                        // LAST of the r frames step t emitted -- with the raw prenet rows of the teacher-form pack, so the frame is exchanged first
   float* tape; size_t tstride;                         // 256-wide per-step arrays: slot s, row (b, t) at tape + s*tstride + (b*n + t)*256
@@ -625,6 +627,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
     for (int j = 0; j < DX_NREG; ++j) W[j] = wp[(size_t)j * DX_NT];
   }
+  if (TAPE && a.p1o_raw) {
+    const float* wp = a.p1o_raw + ((size_t)member * 4) * DX_NT + tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) W[DXR_P1O + j] = wp[(size_t)j * DX_NT];
+  }
   float WQ[QR];     // query layer: columns cb*DS + wave*QC + i, inputs 4*lane..4*lane+3
   {
     const float* wp = a.qpack + ((size_t)member * QR) * DX_NT + tid;
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     const int e = tid / DX_NW, w = tid % DX_NW, n8 = member * 8 + w;
     float v = 0.f;
     switch (e) {
-      case DXB_P1: v = a.b_p1c[n8]; break;
+      case DXB_P1: v = (TAPE && a.p1o_raw) ? a.b_p1_0[n8] : a.b_p1c[n8]; break;
       case DXB_P2: if (w < 4) v = a.b_p2[member * 4 + w]; break;
       case DXB_AR: v = a.b_ag[n8]; break;
       case DXB_AU: v = a.b_ag[DX_W + n8]; break;

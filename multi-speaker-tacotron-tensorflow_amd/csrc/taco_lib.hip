@@ -181,7 +181,7 @@ struct taco_model {
   std::vector<unsigned> bf3_idx; std::vector<Bf3Seg> bf3_segs;
   int last_bptt = 0;           // the last decoder backward ran as the persistent launch (taco_debug_decoder_info out16[9])
   size_t dbx_pack = 0;         // training shadow model: the persistent BPTT kernel's rows (dbx_build_pack)
-  size_t dx_pack = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_p3 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
+  size_t dx_pack = 0, dx_p1o_raw = 0, dx_qpack[4] = {0, 0, 0, 0}, dx_b_p1_0 = 0, dx_b_p1c = 0, dx_b_p2 = 0, dx_b_p3 = 0, dx_b_ag = 0, dx_b_ac = 0, dx_b_g1f = 0,
          dx_b_g1c = 0, dx_b_g2g = 0, dx_b_g2c = 0, dx_b_f = 0;
   int cu_count = 0;            // compute units of the device (the whole-chip persistent kernels need one workgroup per CU on 256 CUs)
   int dx_mode = 1;             // 0: launch-per-stage decoder; 1: persistent decoder when the configuration fits; 2: same, write-through exchanges
@@ -496,6 +496,15 @@ static int dx_build_pack(taco_model* m, const std::vector<float>& Wc, const std:
     put(DXR_F, 4, fk.data(), rM, 0, f0); put(DXR_F + 4, 4, fk.data(), rM, 0, f1);
   }
   m->dx_pack = arena_put(m, pack.data(), pack.size());
+  if (!m->tp && dx_reference_widths(m)) {
+    // teacher-forced decoding on an inference model (taco_decoder_forward with teacher frames): the TAPE instantiation reads the teacher's
+    // frame with the RAW frame rows of prenet layer 1 where this pack holds the frame-projection composite -- four registers per thread
+    const auto& W1 = T_(m, "decoder/prenet/dense_1/kernel").data;
+    std::vector<float> raw((size_t)DX_W * DX_W, 0.f), alt((size_t)DX_GROUP * 4 * DX_NT, 0.f);
+    for (int k = 0; k < hp.num_mels; ++k) for (int q = 0; q < DX_W; ++q) raw[(size_t)k * DX_W + q] = W1[(size_t)k * DX_W + q];
+    for (int mem = 0; mem < DX_GROUP; ++mem) dx_fill_col(alt, 4, mem, 0, 4, raw.data(), DX_W, 0, [&](int w) { return mem * 8 + w; });
+    m->dx_p1o_raw = arena_put(m, alt.data(), alt.size());
+  }
   if (S) {   // speaker rows: [k][slot][n], slots in DXRB_* order
     std::vector<float> sw((size_t)S * DXRB_N * H);
     for (int k = 0; k < S; ++k)
@@ -1509,10 +1518,13 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
   (void)manual;   // manual alignments are a mode of the persistent kernel (the score phases are skipped)
   // teacher forcing needs the raw prenet rows in the registers where inference keeps the frame-projection composite: only the
   // training shadow model's pack has them (taco_model_finalize)
-  if (!m->dx_mode || !m->dx_pack || (teacher && !m->tp) || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
+  if (!m->dx_mode || !m->dx_pack || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
+  // teacher forcing: the TAPE instantiation -- the training shadow model (pack in teacher form), or an inference model at the reference widths
+  // (raw frame rows of prenet layer 1 kept beside the composite pack); not together with manual alignments
+  if (teacher && !(m->tp || (m->dx_p1o_raw && !manual && m->hp.num_mels <= DX_P2))) return false;
   const int RG = dx_rows_per_group(m, B);
   if (m->hp.attention_size == 512 && RG > 4) return false;        // 128 score channels per member: no instantiation (query registers, the q / v slots)
-  return dx_lds_floats(RG, T_in, m->tp != nullptr, m->hp.attention_size) * sizeof(float) <= 160 * 1024;
+  return dx_lds_floats(RG, T_in, m->tp != nullptr || teacher != nullptr, m->hp.attention_size) * sizeof(float) <= 160 * 1024;
 }
 template <int RG, bool TAPE, int AW = DX_W, int PD = 2>
 static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
@@ -1635,8 +1647,10 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
     // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
     // vectors); the launch-per-stage loop below is the general path
+    DxArgs ta; memset(&ta, 0, sizeof ta);
+    if (teacher) { ta.teacher = teacher; ta.p1o_raw = m->tp ? nullptr : AP(m, m->dx_p1o_raw); }     // teacher-forced: the TAPE instantiation without a tape
     TRY(dx_launch(m, st, enc_out, speaker_id, nullptr, B, T_in, n, manual, mel, align_out, dbg, dbgw, w.keys, w.nz, w.xbuf, w.dxctl, w.rowbias,
-                  dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr));
+                  dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr, teacher ? &ta : nullptr));
     if (stop_step) {
       hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
       HIPCHK(hipGetLastError());

@@ -217,20 +217,42 @@ def test_other_presets_multi_speaker_manual_attention_and_end_to_end(preset, mod
     m.check_device_errors()
 
 
-def test_teacher_forcing_still_runs_the_launch_engine():
-    """teacher-forced frames (helpers.py:35-67; the training forward) are not a mode of the persistent decoder: same results from
-    the launch-per-stage loop as before."""
+@pytest.mark.parametrize("model_type,B,atype", [("single", 2, "bah_mon"), ("deepvoice", 19, "bah"), ("simple", 40, "bah_norm")])
+def test_teacher_forced_decoding_on_the_persistent_decoder(model_type, B, atype):
+    """Teacher-forced frames on an INFERENCE model (helpers.py:35-67 outside the trainer): the TAPE instantiation of k_decoder_xcd
+    without a tape, its four prenet-layer-1 frame registers loaded with the raw kernel rows that the model keeps beside its composite
+    pack.  Every state of every step against the oracle (rows per group 1 / 4 / 8), and against the launch-per-stage loop."""
     import torch
-    ohp = O.OracleHParams(max_iters=4)
-    w = O.init_weights(ohp, 1, 321)
-    ids, L = O.synthetic_inputs(2, 16, 322)
-    frames = np.random.RandomState(5).rand(2, 4, ohp.num_mels)
+    ns, n = (1 if model_type == "single" else 3), 6
+    ohp = O.OracleHParams(max_iters=n, model_type=model_type, attention_type=atype)
+    w = O.init_weights(ohp, ns, 321)
+    ids, L = O.synthetic_inputs(B, 16, 322, ragged=True)
+    spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
+    frames = np.random.RandomState(5).rand(B, n, ohp.num_mels)
     taps = {}
-    ref = O.forward(w, ohp, ids, L, n_steps=4, teacher_frames=frames, taps=taps)
-    m = build_model(ohp, w)
-    mel, al, _, _ = m.decoder(taps["encoder"], 4, teacher_frames=frames)
+    ref = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, teacher_frames=frames, taps=taps, honor_stop=False)
+    m = build_model(ohp, w, num_speakers=ns)
+    mel, al, _, dbg = m.decoder(taps["encoder"], n, speaker_id=spk, teacher_frames=frames, debug=True)
     torch.cuda.synchronize()
-    assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4
+    m.check_device_errors()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    dbg = dbg.cpu().numpy()
+    As, D, H = ohp.attention_state_size, 2 * ohp.enc_rnn_size, ohp.dec_rnn_size
+    for t, st in enumerate(taps["steps"]):
+        assert maxabs(dbg[t, :, :As], st["h_att"]) < 2e-4 and maxabs(dbg[t, :, As:As + D], st["ctx"]) < 2e-4, t
+        for i, h in enumerate(st["h"]):
+            assert maxabs(dbg[t, :, As + D + i * H:As + D + (i + 1) * H], h) < 2e-4, (t, i)
+    assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4 and maxabs(al.cpu().numpy(), ref["alignments"]) < 2e-4
+    m.set_decoder_engine(0)
+    mel0, al0, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk, teacher_frames=frames)
+    torch.cuda.synchronize()
+    assert maxabs(mel0.cpu().numpy(), mel.cpu().numpy()) < 2e-5 and maxabs(al0.cpu().numpy(), al.cpu().numpy()) < 2e-5
+    # the same model without teacher frames afterwards: the composite registers are back
+    m.set_decoder_engine(1)
+    free = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, honor_stop=False)
+    mel1, _, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk)
+    torch.cuda.synchronize()
+    assert maxabs(mel1.cpu().numpy(), free["mel"]) < 2e-4
 
 
 def test_C5_real_widths_against_the_oracle():
