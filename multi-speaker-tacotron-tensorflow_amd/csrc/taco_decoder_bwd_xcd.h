@@ -342,6 +342,15 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     const int buf = (n - 1 - t) & 1;
     int tid = tid_outer, lane = lane_outer;
     asm volatile("" : "+v"(tid), "+v"(lane));
+    // (the owner's rows, their validity and tape offsets are formed again from the opaque lane: derived before the loop, the 64-bit
+    // addresses of the eleven gradient tapes x the lane's rows are loop invariants -- 22 pointers at eight rows per group -- and spill)
+    int erow[RL]; bool ev[RL]; unsigned trow[RL];
+#pragma unroll
+    for (int q = 0; q < RL; ++q) {
+      erow[q] = dx_row<RG>(lane & 3, q);
+      ev[q] = (lane < (RG >= 4 ? 4 : RG)) && (row0 + erow[q] < a.B);
+      trow[q] = (unsigned)min(row0 + erow[q], a.B - 1) * (unsigned)n;
+    }
     DB_STAMP(0);
     if (t > 0) { fetch_own(t - 1, buf ^ 1); fetch_rows(t - 1, buf ^ 1); }
     const float* ow = own + (buf * DX_NW + wave) * 128;

@@ -7,9 +7,9 @@ touches sits in registers or LDS; a value the compiler demotes to scratch turns 
 issue).  csrc/build.sh compiles with -Rpass-analysis=kernel-resource-usage and keeps the remarks in csrc/kernel_resources.txt;
 this script reads them and fails when
 
-  * any instantiation of k_bigru_xcd, k_bigru_duo, k_pointwise_chain or k_cbhg_front has ScratchSize > 0, or
-  * any instantiation of k_decoder_xcd / k_decoder_bwd_xcd has, except the 8-rows-per-group BPTT kernel, whose 256-VGPR budget is known
-    to spill (<= 196 bytes per lane today; it fails if that grows).
+any instantiation of k_bigru_xcd, k_bigru_duo, k_pointwise_chain, k_cbhg_front, k_head_sweep, k_decoder_xcd or k_decoder_bwd_xcd has
+ScratchSize > 0 (no allowances since round 4: the last one, the 8-rows-per-group BPTT kernel's 196 bytes, went when the owner rows' tape
+offsets became per-step values instead of 22 hoisted pointers).
 
     python tools/check_kernel_resources.py [remarks file]        # exit status 1 on a violation; prints a table either way"""
 import os
@@ -18,11 +18,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
-PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front")  # k_bigru_duo also matches k_bigru_duo_bwd
-# k_decoder_xcd<RG, TAPE, MAN>: bytes per lane (round 2: 144; +24 with the per-row-bias path; the manual-attention path is its own instantiation since round 4)
-# (round 4: the forward decoder's eight-rows-per-group instantiations are at 0 -- their run-ahead accumulators are formed in place and
-# the score phase reads q / v per use; what is left is the BPTT kernel's)
-ALLOWED_SCRATCH = {"_Z17k_decoder_bwd_xcdILi8EEv6DbArgs": 196}
+PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front", "k_head_sweep")  # k_bigru_duo also matches k_bigru_duo_bwd
+ALLOWED_SCRATCH = {}      # (mangled name -> bytes per lane; empty since round 4)
 
 
 def parse(path):
