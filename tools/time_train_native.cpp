@@ -5,12 +5,12 @@
 //         -Wl,-rpath,'$ORIGIN/../multi-speaker-tacotron-tensorflow_amd/csrc' -o tools/time_train_native
 //   ./tools/time_train_native [B=32] [T_in=128] [T_out=512] [reps=8] [exact_gemm=4] [bptt_persistent=1]
 // Prints ms per step and per part (forward only; forward + backward; clip + Adam; refresh) and the losses of the last step.
-// NOT YET RUN ON A GPU (written at the end of round 3 after the GPU budget was spent).
+// First run: round 4 (profiles/r04_v4_time_train_native.txt).
 #include "native_model.h"
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 32, T_in = argc > 2 ? atoi(argv[2]) : 128, T_out = argc > 3 ? atoi(argv[3]) : 512;
-  const int reps = argc > 4 ? atoi(argv[4]) : 8, gemm = argc > 5 ? atoi(argv[5]) : 3, bptt = argc > 6 ? atoi(argv[6]) : 1;
+  const int reps = argc > 4 ? atoi(argv[4]) : 8, gemm = argc > 5 ? atoi(argv[5]) : 4, bptt = argc > 6 ? atoi(argv[6]) : 1;
   taco_hparams hp;
   native_hparams(200, hp);
   CK(hipSetDevice(0));

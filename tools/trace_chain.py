@@ -13,7 +13,7 @@ ids = torch.randint(2, 80, (B, T_in), dtype=torch.int32, device="cuda"); ids[:, 
 lens = torch.full((B,), T_in - 1, dtype=torch.int32, device="cuda")
 mel = torch.rand(B, T_mel, hp.num_mels, device="cuda")
 L.taco_debug_set_skip_scans(m._handle, 1)
-def show(name, fn, hidden):
+def show(name, fn, hidden, passes):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     buf = (C.c_longlong * 64)()
@@ -26,9 +26,10 @@ def show(name, fn, hidden):
         print("  layer %d: products %6d | epilogue %5d | wait for the other waves %5d | planes + barrier %5d" % (
             li, rel[k] - rel[k - 1], rel[k + 1] - rel[k], rel[k + 2] - rel[k + 1], rel[k + 3] - rel[k + 2]))
         k += 4
-    while k + 1 < 64 and rel[k + 1] > rel[k] > 0:
+    npass = 0
+    while k + 1 < 64 and rel[k + 1] > rel[k] > rel[k - 1] and rel[k] - rel[k - 1] < 10 ** 7 and npass < passes:      # (later slots may hold another launch's stamps)
         print("  projection pass: products %6d | stores %5d" % (rel[k] - rel[k - 1], rel[k + 1] - rel[k]))
-        k += 2
+        k += 2; npass += 1
     print("  total %d clocks" % rel[k - 1])
 def show_head():
     L.taco_debug_read_trace_head.restype = C.c_int
@@ -41,8 +42,8 @@ def show_head():
     # pass's product loop: the last one), tail columns done
     print("linear head (k_head_sweep): stamps (clocks since entry) %s; total %d" % (" ".join(str(int(v - t[0])) for v in t[1:n]), int(t[n - 1] - t[0])))
 try:
-    show("post-net", lambda: m.postnet(mel), 5)
+    show("post-net", lambda: m.postnet(mel), 5, 2)      # 6H = 768 columns at W = 256: an odd group alone, then a pair
     show_head()
-    show("encoder", lambda: m.encoder(ids, lens), 4)
+    show("encoder", lambda: m.encoder(ids, lens), 4, 3)           # 768 columns at W = 128: three pairs
 finally:
     L.taco_debug_set_skip_scans(m._handle, 0)
