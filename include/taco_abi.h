@@ -206,9 +206,10 @@ void taco_train_destroy(taco_train* t);
 taco_model* taco_train_model(taco_train* t);
 /* Deterministic reductions: on = 1 makes every sum over rows that normally leaves its workgroup through fp32 atomics (weight
  * gradients, bias and BatchNorm sums, embedding gradients, d attention_v) a two-stage sum in a fixed order, so that a step is
- * run-to-run reproducible, as the reference's single-device step is (train.py:215-219).  Costs 192 MB more workspace
- * (taco_train_workspace_bytes reflects it: query it again) and, today, a third of the step (20.1 instead of 14.8 ms at the C4 shard: the small
- * problems leave their group launches in this mode).  Default 0. */
+ * run-to-run reproducible TO THE BIT, as the reference's single-device step is (train.py:215-219).  Costs 192 MB of workspace
+ * (taco_train_workspace_bytes reflects it: query it again) and 6.6 % of the step (15.85 instead of 14.87 ms at the C4 shard, round 4: the small
+ * problems stay in their group launches, their per-slice partials are added up by two more group launches).  Default 1 since round 4
+ * (rounds 1-3: 0); on = 0 selects the atomics. */
 int taco_train_set_deterministic(taco_train* t, int on);
 /* Weight gradients: on = 0 (default) computes dW = X^T . dY on the bf16 matrix cores with operands split three ways (24 bits) and
  * six products per tile, fp32 accumulation (k_wgrad_bf3: fp32-grade, ~2^-24 per product); on = 1 keeps them on the

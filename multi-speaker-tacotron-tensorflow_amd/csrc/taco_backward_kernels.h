@@ -137,6 +137,23 @@ __global__ void k_colsum_reduce(const float* part, int nchunks, int C, int mode,
   if (mode != 0 && out2) out2[c] += t2;
 }
 
+// the ordered sums of several column-sum problems of a group launch (deterministic mode) as ONE launch
+struct ColRed { const float* part; float* out1; float* out2; int nchunks, C, mode; };
+struct ColRedGroup { ColRed p[COL_MAXP]; int start[COL_MAXP + 1]; int n; };
+__global__ __launch_bounds__(256) void k_colsum_reduce_group(const ColRedGroup G) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < G.n && G.start[p + 1] <= b) ++p;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const ColRed g = G.p[p];
+  const int c = (b - G.start[p]) * 256 + threadIdx.x;
+  if (c >= g.C) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int k = 0; k < g.nchunks; ++k) { t1 += g.part[((size_t)k * 2 + 0) * g.C + c]; t2 += g.part[((size_t)k * 2 + 1) * g.C + c]; }
+  if (g.mode != 1 && g.out1) g.out1[c] += t1;
+  if (g.mode != 0 && g.out2) g.out2[c] += t2;
+}
+
 // BatchNorm (training): mu = S1/M; second pass gives S2 = sum (a-mu)^2; rstd = 1/sqrt(S2/M + eps) (biased variance);
 // moving <- moving*momentum + batch*(1-momentum), written straight into the flat parameter buffer (UPDATE_OPS, tacotron.py:334)
 __global__ void k_bn_mean(const float* S1, float* mu, int C, float invM) {
@@ -403,6 +420,24 @@ __global__ void k_wgrad_reduce(const float* part, int nsplit, int kw, int K, int
   for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * per + i];
   const int n = (int)(i % N); const size_t tk = i / N;      // tk = tap * K + k
   dw[tk * lddw + n] += s;
+}
+
+// the ordered sums of the problems of a group launch (deterministic mode) as ONE launch: block b of the flat grid belongs to problem p
+// with start[p] <= b < start[p + 1] and sums 256 elements of its weight gradient over the M-slices, slice 0 first
+struct WgRed { const float* part; float* dw; int nsplit, kw, K, N, lddw; };
+struct WgRedGroup { WgRed p[WG_MAXP]; int start[WG_MAXP + 1]; int n; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce_group(const WgRedGroup G) {
+  const int b = blockIdx.x;
+  int p = 0;
+  while (p + 1 < G.n && G.start[p + 1] <= b) ++p;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const WgRed g = G.p[p];
+  const size_t i = (size_t)(b - G.start[p]) * 256 + threadIdx.x, per = (size_t)g.kw * g.K * g.N;
+  if (i >= per) return;
+  float s = 0.f;
+  for (int sp = 0; sp < g.nsplit; ++sp) s += g.part[(size_t)sp * per + i];
+  const int n = (int)(i % g.N); const size_t tk = i / g.N;
+  g.dw[tk * g.lddw + n] += s;
 }
 
 // ---- small element-wise pieces ----

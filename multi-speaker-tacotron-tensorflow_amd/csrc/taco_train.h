@@ -49,7 +49,7 @@ struct taco_train {
   void* sync_user = nullptr;
   int sync_world = 1;
   int bptt_persistent = 1;             // taco_train_set_bptt_engine: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd) where it fits
-  int deterministic = 0;               // taco_train_set_deterministic: ordered two-stage sums instead of fp32 atomics (needs DET_SCRATCH_FLOATS of workspace)
+  int deterministic = 1;               // taco_train_set_deterministic: ordered two-stage sums (default since round 4) or fp32 atomics; the former needs DET_SCRATCH_FLOATS of workspace
 };
 #define DET_SCRATCH_FLOATS ((size_t)48 << 20)      // 192 MB: e.g. 30 M-slices of the largest weight gradient (post-net proj_1, 3 x 2048 x 256)
 
@@ -195,17 +195,26 @@ static thread_local DetScratch g_det;
 // Batching region for small weight gradients (k_wgrad_bf3_group): between wg_begin and wg_end, run_wgrad calls that take the one-wave
 // tile are collected and launched together -- at wg_flush / wg_end, or when the table is full.  The caller flushes before anything
 // overwrites an operand of a collected problem or reads one of their outputs.
-struct WgBatch { WgGroup g; ColGroup c; bool active = false; hipStream_t st = nullptr; };
+// Deterministic mode: the collected problems write per-slice partials into consecutive regions of the deterministic scratch (det_used: the
+// cursor; a problem that does not fit flushes the region first) and two more group launches add the slices up in a fixed order.  (Problems
+// launched on their own in between use the scratch from its start: everything is stream ordered, the group's kernels run at the flush.)
+struct WgBatch { WgGroup g; ColGroup c; WgRedGroup r; ColRedGroup cr; size_t det_used = 0; bool active = false; hipStream_t st = nullptr; };
 static thread_local WgBatch g_wgb;
 static int wg_flush() {      // (column sums of the region ride along: same hazards, same flush points)
   WgGroup& G = g_wgb.g; ColGroup& Cg = g_wgb.c;
   if (Cg.n > 0) hipLaunchKernelGGL(k_colsum_group, dim3(Cg.start[Cg.n]), dim3(256), 0, g_wgb.st, Cg);
   if (G.n > 0) hipLaunchKernelGGL(k_wgrad_bf3_group, dim3(G.start[G.n]), dim3(64), 0, g_wgb.st, G);
+  if (g_wgb.cr.n > 0) hipLaunchKernelGGL(k_colsum_reduce_group, dim3(g_wgb.cr.start[g_wgb.cr.n]), dim3(256), 0, g_wgb.st, g_wgb.cr);
+  if (g_wgb.r.n > 0) hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(g_wgb.r.start[g_wgb.r.n]), dim3(256), 0, g_wgb.st, g_wgb.r);
   if (Cg.n > 0 || G.n > 0) HIPCHK(hipGetLastError());
   G.n = 0; G.start[0] = 0; Cg.n = 0; Cg.start[0] = 0;
+  g_wgb.r.n = 0; g_wgb.r.start[0] = 0; g_wgb.cr.n = 0; g_wgb.cr.start[0] = 0; g_wgb.det_used = 0;
   return 0;
 }
-static void wg_begin(hipStream_t st) { g_wgb.active = true; g_wgb.st = st; g_wgb.g.n = 0; g_wgb.g.start[0] = 0; g_wgb.c.n = 0; g_wgb.c.start[0] = 0; }
+static void wg_begin(hipStream_t st) {
+  g_wgb.active = true; g_wgb.st = st; g_wgb.g.n = 0; g_wgb.g.start[0] = 0; g_wgb.c.n = 0; g_wgb.c.start[0] = 0;
+  g_wgb.r.n = 0; g_wgb.r.start[0] = 0; g_wgb.cr.n = 0; g_wgb.cr.start[0] = 0; g_wgb.det_used = 0;
+}
 static int wg_end() { const int rc = wg_flush(); g_wgb.active = false; return rc; }
 struct WgRegion {      // RAII: a region ends (and flushes) on every return path
   explicit WgRegion(hipStream_t st) { wg_begin(st); }
@@ -220,7 +229,20 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
     g.part = g_det.p;
   }
   const int nchunks = cdiv(M, g.rpb);
-  if (g_wgb.active && !g.part) {      // inside a batching region: joins the group launch (the caller flushes before the sums are read)
+  if (g_wgb.active) {      // inside a batching region: joins the group launch (the caller flushes before the sums are read)
+    if (g.part) {          // deterministic: its own region of the scratch, summed by the group's reduce launch
+      const size_t need = (size_t)nchunks * 2 * C;
+      // (two problems of one reduce launch must not add into the same vector: their read-modify-writes would race, where the atomics
+      // of the other mode simply accumulate -- e.g. the five speaker projections of model type deepvoice sum into one embedding gradient)
+      bool clash = false;
+      for (int i = 0; i < g_wgb.cr.n; ++i)
+        clash = clash || (out1 && (g_wgb.cr.p[i].out1 == out1 || g_wgb.cr.p[i].out2 == out1)) || (out2 && (g_wgb.cr.p[i].out1 == out2 || g_wgb.cr.p[i].out2 == out2));
+      if (clash || g_wgb.det_used + need > g_det.cap) TRY(wg_flush());
+      g.part = g_det.p + g_wgb.det_used; g_wgb.det_used += need;
+      ColRedGroup& R = g_wgb.cr;
+      R.p[R.n].part = g.part; R.p[R.n].out1 = out1; R.p[R.n].out2 = out2; R.p[R.n].nchunks = nchunks; R.p[R.n].C = C; R.p[R.n].mode = mode;
+      R.start[R.n + 1] = R.start[R.n] + cdiv(C, 256); ++R.n;
+    }
     ColGroup& G = g_wgb.c;
     G.p[G.n] = g;
     G.start[G.n + 1] = G.start[G.n] + cdiv(C, 64) * nchunks;
@@ -256,7 +278,17 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
     g.part = g_det.p;
   }
   const int nsplit = cdiv(M, g.rpb);
-  if (g_wgb.active && bf3 && !big && !g.part) {       // small problem inside a batching region: joins the group launch
+  if (g_wgb.active && bf3 && !big) {       // small problem inside a batching region: joins the group launch
+    if (g.part) {                          // deterministic: its own region of the scratch, summed by the group's reduce launch
+      const size_t need = (size_t)nsplit * kw * K * N;
+      bool clash = false;                  // (same rule as for the column sums: one writer per output per reduce launch)
+      for (int i = 0; i < g_wgb.r.n; ++i) clash = clash || g_wgb.r.p[i].dw == dw;
+      if (clash || g_wgb.det_used + need > g_det.cap) TRY(wg_flush());
+      g.part = g_det.p + g_wgb.det_used; g_wgb.det_used += need;
+      WgRedGroup& R = g_wgb.r;
+      R.p[R.n].part = g.part; R.p[R.n].dw = dw; R.p[R.n].nsplit = nsplit; R.p[R.n].kw = kw; R.p[R.n].K = K; R.p[R.n].N = N; R.p[R.n].lddw = lddw;
+      R.start[R.n + 1] = R.start[R.n] + cdiv(kw * K * N, 256); ++R.n;
+    }
     WgGroup& G = g_wgb.g;
     G.p[G.n] = g;
     G.start[G.n + 1] = G.start[G.n] + cdiv(K, 64) * cdiv(N, 64) * kw * nsplit;

@@ -28,8 +28,7 @@ def measure(args):
         tr.set_exact_gemm(args.exact_gemm)
     if args.exact_wgrad:
         tr.set_exact_wgrad(True)
-    if args.deterministic:
-        tr.set_deterministic(True)
+    tr.set_deterministic(bool(args.deterministic))
     rs = np.random.RandomState(77 + rank)
     B, T_in, T_out = args.batch, args.t_in, args.t_out
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32); ids[:, -1] = 1
@@ -134,7 +133,7 @@ def main():
     ap.add_argument("--bptt", type=int, default=1, help="1: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd; default); 0: the chain of per-stage launches")
     ap.add_argument("--exact-gemm", type=int, default=4, help="4 (default): forward on the six-product split (fp32-grade), data gradients split-bf16; 3: forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16; 4: forward on the six-product split (fp32-grade), data gradients split-bf16")
     ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
-    ap.add_argument("--deterministic", type=int, default=0, help="1: ordered two-stage sums instead of fp32 atomics (reproducible steps)")
+    ap.add_argument("--deterministic", type=int, default=1, help="1 (the library's default): ordered two-stage sums, bit-reproducible steps; 0: fp32 atomics")
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
                                                            "0: per-rank statistics.  No effect on one GPU")
     args = ap.parse_args()

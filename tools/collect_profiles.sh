@@ -10,6 +10,7 @@ timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/b
 for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
+timeout 300 python tools/bench_train.py --deterministic 0 > $out/train_step_atomics.json 2>> $out/train.err      # fp32 atomics instead of the ordered sums (the default since round 4)
 timeout 300 python tools/bench_train.py --exact-gemm 0 > $out/train_step_splitbf16.json 2>> $out/train.err
 timeout 300 python tools/bench_train.py --exact-gemm 1 > $out/train_step_exact.json 2>> $out/train.err
 timeout 300 python tools/bench_train.py --bptt 0 > $out/train_step_bptt_per_stage.json 2>> $out/train.err
