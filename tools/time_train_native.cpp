@@ -5,7 +5,7 @@
 //         -Wl,-rpath,'$ORIGIN/../multi-speaker-tacotron-tensorflow_amd/csrc' -o tools/time_train_native
 //   ./tools/time_train_native [B=32] [T_in=128] [T_out=512] [reps=8] [exact_gemm=4] [bptt_persistent=1]
 // Prints ms per step and per part (forward only; forward + backward; clip + Adam; refresh) and the losses of the last step.
-// First run: round 4 (profiles/r04_v4_time_train_native.txt).
+// First run: round 4 (profiles/r04_v5_time_train_native.txt).
 #include "native_model.h"
 
 int main(int argc, char** argv) {
