@@ -23,16 +23,53 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measu
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0 # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md)
 
-# Measured building blocks of the two sequential loops (profiles/r02_decoder_timeline.txt, profiles/r03_*_scan_timeline.txt,
-# tools/time_decoder.py, tools/trace_bigru.py; shader clock ~2.16 GHz) and of the matrix pipe (tools/ubench_mfma: 2.08 PFLOP/s bf16
-# dense): what `roofline.latency_floor_ms` is built from.
-HOP_US = 0.5                 # one exchange through the XCD's L2: publish -> every consumer has gathered it (0.44-0.58 measured)
-DEC_HOPS, DEC_CHAIN_US = 10, 6.5    # per decoder step: exchanges, and the dependent instruction chains between them (11.7 - 10 x 0.5, rounded down)
-# per post-net scan step of k_bigru_duo (4668 clocks): the two directions hide each other's exchanges; what is left is four
-# compute phases (800 + 804 + 692 + 740 clocks) and four collect + barrier points (368 + 328 + 308 + 256)
-SCAN_PHASES_US, SCAN_SYNC_US = 1.40, 0.58
-ENC_SCAN_STEP_US = 0.93             # encoder scan (k_bigru_res, one CU per chain, no exchange)
 MFMA_BF16_MEASURED_TF = 2080.0      # tools/ubench_mfma on this part; a 3-term split product costs three bf16 MFMAs
+
+
+def floor_constants():
+    """The measured building blocks `roofline.latency_floor_ms` is built from, READ from the newest committed profile files of the two
+    sequential loops (tools/time_decoder.py --json -> r*_decoder_timeline.json, tools/trace_bigru.py --json -> r*_scan_timeline.json,
+    rocprofv3 kernel statistics -> r*_c2_kernel_stats*.csv) -- never constants carried over from an earlier round.
+    Returns the numbers and the file each came from; a missing or unreadable file leaves its terms None and the floor says so."""
+    import glob
+    import re
+    prof = os.path.join(ROOT, "profiles")
+
+    def newest(pat):
+        fs = glob.glob(os.path.join(prof, pat))
+        key = lambda f: (int((re.findall(r"^r(\d+)_", os.path.basename(f)) or ["0"])[0]), os.path.getmtime(f))
+        return sorted(fs, key=key)[-1] if fs else None
+    c = {"sources": {}, "hop_us": None, "dec_step_us": None, "dec_chain_us": None, "dec_hops": 10, "scan_phases_us": None,
+         "scan_sync_us": None, "scan_kernel": None, "enc_scan_ns": None}
+    f = newest("r*decoder_timeline.json")
+    try:
+        rec = json.load(open(f))["C2"]["persistent"]
+        tl, sp = rec["timeline_us"], rec["gates_stage_split_us"]
+        c["dec_step_us"], c["hop_us"] = float(sum(tl.values())), float(sp["gather(poll)"])
+        c["dec_chain_us"] = c["dec_step_us"] - c["dec_hops"] * c["hop_us"]
+        c["sources"]["decoder"] = os.path.basename(f)
+    except Exception:
+        pass
+    f = newest("r*scan_timeline.json")
+    try:
+        rec = [r for r in json.load(open(f)) if r["B"] == 32 and r["T"] == 512 and r["persist"] == 1][0]
+        ph = rec["phases_clocks"]
+        c["scan_phases_us"] = sum(v for k, v in ph.items() if "collect" not in k) / rec["clocks_per_us"]
+        c["scan_sync_us"] = sum(v for k, v in ph.items() if "collect" in k) / rec["clocks_per_us"]
+        c["scan_kernel"] = rec["kernel"]
+        c["sources"]["scan"] = os.path.basename(f)
+    except Exception:
+        pass
+    f = newest("r*c2_kernel_stats*.csv")
+    try:
+        import csv
+        q = [r for r in csv.DictReader(open(f)) if "k_bigru_quad" in r["Name"]][0]
+        c["enc_scan_ns"] = float(q["AverageNs"])
+        c["sources"]["encoder_scan"] = os.path.basename(f)
+    except Exception:
+        pass
+    return c
+
 
 WORKLOADS = {  # SURVEY section 8 config names: (B, T_in, r, n_steps, num_speakers, model_type)
     "C1": (1, 64, 5, 200, 1, "single"),
@@ -152,56 +189,58 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def cpu_baseline(name, seed):
-    """SURVEY 8(d) / BASELINE.md section 3: the CPU restatement (oracle/taco_oracle.py, float32 NumPy/OpenBLAS -- not TF1) timed on
-    this host (i) with ONE intra-op thread, mirroring the reference session's intra_op_parallelism_threads=1 (synthesizer.py:58-61),
-    and (ii) with all cores; 3 warm-up + 10 timed runs each, median.  Bounded sample: a row slice of the workload at its full
-    T_in / T_mel (rows are independent at inference, cost is linear in rows), sized to ~10-20 s of CPU work per arm."""
+def cpu_baseline(name, seed, budget_s=20.0):
+    """SURVEY 8(d) / BASELINE.md section 3: the fp32 PyTorch-CPU, eager, op-for-op restatement of the TF1 inference graph
+    (oracle/taco_torch_cpu.py -- not TF1; held to the NumPy oracle by tests/test_oracle.py) timed on this host over the FULL batch of the
+    workload, (i) with torch.set_num_threads(1), mirroring the reference session's intra_op_parallelism_threads=1 (synthesizer.py:58-61),
+    and (ii) with all host threads.  Protocol: 3 warm-up + 10 timed runs, median -- cut to what fits `budget_s` seconds per arm (never fewer
+    than 1 warm-up + 3 timed; the counts used are in the record), so that the default bench run stays within minutes: one C2 forward
+    is seconds of CPU work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
+    import torch
     import taco_oracle as O
-    from threadpoolctl import threadpool_limits, threadpool_info
+    import taco_torch_cpu as TT
     B, T_in, r, n, ns, mt = WORKLOADS[name]
     ohp = O.OracleHParams(max_iters=n, reduction_factor=r, model_type=mt)
-    w = {k: np.asarray(v, np.float32) for k, v in O.init_weights(ohp, ns, seed).items()}
+    w = O.init_weights(ohp, ns, seed)
     ids, L = O.synthetic_inputs(B, T_in, seed)
     spk = (np.arange(B) % ns).astype(np.int32) if ns > 1 else None
-    ncores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    model = TT.TorchCpuTacotron(w, ohp, ns)
+    ncores = int(os.cpu_count() or 1)
+    nthreads0 = torch.get_num_threads()
 
-    def arm(threads, rows):
-        rows = min(rows, B)
-        sl = slice(0, rows)
-        run = lambda: O.forward(w, ohp, ids[sl], L[sl], speaker_id=None if spk is None else spk[sl], num_speakers=ns,
-                                dtype=np.float32, honor_stop=False)
-        with threadpool_limits(limits=threads):
-            ts = []
-            for i in range(13):
-                t0 = time.perf_counter()
-                run()
-                dt = time.perf_counter() - t0
-                if i >= 3:
-                    ts.append(dt)
-                if i == 0 and dt > 4.0:        # slow host: shorten the arm (still >= 1 warm-up + 3 timed)
-                    reps_left = 3
-                    ts = []
-                    for _ in range(reps_left):
-                        t0 = time.perf_counter()
-                        run()
-                        ts.append(time.perf_counter() - t0)
-                    break
+    def arm(threads):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        model.forward(ids, L, spk)
+        first = time.perf_counter() - t0
+        timed = int(max(3, min(10, (budget_s - first) // max(first, 1e-3))))
+        warm = 3 if timed == 10 else 1
+        for _ in range(warm - 1):
+            model.forward(ids, L, spk)
+        ts = []
+        for _ in range(timed):
+            t0 = time.perf_counter()
+            model.forward(ids, L, spk)
+            ts.append(time.perf_counter() - t0)
         med = float(np.median(ts))
-        return {"value": rows * n * r / med, "unit": "mel-frames/s", "threads": int(threads), "rows": int(rows), "timed_runs": len(ts),
+        return {"value": B * n * r / med, "unit": "mel-frames/s", "threads": int(threads), "rows": int(B), "warmup_runs": warm, "timed_runs": timed,
                 "median_s": med}
-    one = arm(1, max(1, B // 16))
-    allc = arm(ncores, max(1, B // 4))
-    return {"value": allc["value"], "unit": "mel-frames/s", "cores": int(ncores), "kind": "port",
-            "kind_detail": "CPU restatement (NumPy oracle, float32), NOT TF1; timed on a ROW SLICE of the workload and extrapolated per row "
-                           "(rows are independent at inference) -- not the full-batch 3 + 10 run protocol of SURVEY 8d, which would take minutes",
-            "sample": "oracle/taco_oracle.py in float32 (NumPy/OpenBLAS; a CPU restatement, not TF1) on a row slice of %s at full "
-                      "T_in=%d / T_mel=%d: all %d threads on %d rows (median of %d runs, %.2f s each) -> value; one thread "
-                      "(synthesizer.py:58-61 intra_op=1) on %d rows (median of %d, %.2f s each) -> single_thread"
-                      % (name, T_in, n * r, ncores, allc["rows"], allc["timed_runs"], allc["median_s"], one["rows"], one["timed_runs"],
-                         one["median_s"]),
+    try:
+        one = arm(1)
+        allc = arm(ncores)
+    finally:
+        torch.set_num_threads(nthreads0)
+    best = allc if allc["value"] >= one["value"] else one
+    return {"value": best["value"], "unit": "mel-frames/s", "cores": int(best["threads"]), "host_cores": ncores, "kind": "port",
+            "kind_detail": "fp32 PyTorch-CPU eager op-for-op restatement of the TF1 graph (oracle/taco_torch_cpu.py), NOT TF1; full batch; the "
+                           "better of the one-thread and the all-threads arm is `value` (a decoder step is a chain of small ops: more threads "
+                           "mostly add synchronisation)",
+            "sample": "oracle/taco_torch_cpu.py (torch %s, float32) on the FULL %s batch (B=%d, T_in=%d, T_mel=%d): one thread "
+                      "(synthesizer.py:58-61 intra_op=1) %d warm-up + %d timed runs, median %.2f s per forward; all %d host threads %d + %d runs, "
+                      "median %.2f s" % (torch.__version__.split("+")[0], name, B, T_in, n * r, one["warmup_runs"], one["timed_runs"], one["median_s"],
+                                         ncores, allc["warmup_runs"], allc["timed_runs"], allc["median_s"]),
             "single_thread": one, "all_cores": allc}
 
 
@@ -293,6 +332,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="weak (default): every GPU runs the workload's batch (B rows per GPU, global batch N*B); strong: the workload's batch is "
+                         "the GLOBAL batch, split into B/N rows per GPU (SURVEY 8e asks for both; the loop is latency bound, so strong scaling is poor by construction)")
     ap.add_argument("--overlap", type=int, default=None, help="debug: 0 = no decoder/post-net overlap, N>1 = chunk of N decoder steps")
     ap.add_argument("--eager", action="store_true", help="enqueue kernels directly instead of replaying the hipGraph plan")
     ap.add_argument("--lanes", type=int, default=1,
@@ -349,6 +391,11 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     B, T_in, r, n, ns, mt = WORKLOADS[args.workload]
+    B_global = B * world if args.scaling == "weak" else B
+    if args.scaling == "strong":
+        if B % world:
+            sys.exit("--scaling strong: the workload's batch of %d rows does not split over %d GPUs" % (B, world))
+        B = B // world                                                           # rows of THIS rank; the global batch stays the workload's
     hp = taco_amd.hparams.copy(max_iters=n, reduction_factor=r, model_type=mt)
     model = taco_amd.create_model(hp)
     seed = 1234 + sorted(WORKLOADS).index(args.workload)
@@ -359,7 +406,7 @@ def main():
     if args.decoder_engine != 1:
         model.set_decoder_engine(args.decoder_engine)
     rs = np.random.RandomState(seed + 100 * rank)
-    ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)
+    ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)                   # (strong scaling: every rank draws its own B/N rows)
     ids[:, T_in - 1] = 1                                                       # fixed-length batches
     lengths = taco_amd.input_lengths_from_tokens(ids)
     lanes = max(1, args.lanes)
@@ -510,7 +557,25 @@ def main():
         t_exact = timed_pool(p2, lanes, ksteps)
         companions["exact_fp32"] = {"mel_frames_per_s": B * n * r / t_exact, "forwards_in_flight": lanes, "forward_ms": t_exact * 1e3,
                                     "arithmetic": "every contraction on exact-fp32 MFMA / VALU (taco_debug_set_bf3 off)"}
+        out_exact = (p2.plans[0].mel.clone(), p2.plans[0].linear.clone())
         p2.close()
+        model.check_device_errors()
+        # (ii-b) fp32-GRADE products on the bf16 pipe: every feed-forward layer on the six-product instantiation of k_gemm_bf3 (operands
+        # split three ways, 24 mantissa bits; one launch per layer -- the fused front / chain / head kernels are three-product kernels)
+        model._lib.taco_debug_set_bf3(model._handle, 65, 0)
+        model._plans.clear()
+        p6 = model.plan_pool(B, T_in, n, lanes=lanes, coalesce=1)
+        fill(p6, 1)
+        t_x6 = timed_pool(p6, lanes, ksteps)
+        d = lambda a, b: float((a - b).abs().max().item())
+        out_def = (pool.plans[0].mel, pool.plans[0].linear)
+        companions["fp32_grade_x6"] = {
+            "mel_frames_per_s": B * n * r / t_x6, "forwards_in_flight": lanes, "forward_ms": t_x6 * 1e3,
+            "arithmetic": "every feed-forward contraction as SIX bf16 MFMA products of operands split three ways (k_gemm_bf3<..., X6>, taco_debug_set_bf3 65): "
+                          "fp32-grade (2^-24) products on the bf16 pipe; scans and decoder loop exact fp32 as in the headline",
+            "max_abs_vs_exact_fp32": {"mel": d(p6.plans[0].mel, out_exact[0]), "linear": d(p6.plans[0].linear, out_exact[1])},
+            "headline_max_abs_vs_exact_fp32": {"mel": d(out_def[0], out_exact[0]), "linear": d(out_def[1], out_exact[1])}}
+        p6.close()
         model.check_device_errors()
         model._lib.taco_debug_set_bf3(model._handle, 1, 0)
         # (iii) two requests of B rows riding through one pass (PlanPool coalesce = 2)
@@ -544,7 +609,7 @@ def main():
             except Exception as e:      # the inference line must not die with the companion
                 companions["train_step_c4_shard"] = {"error": repr(e)}
     if rank == 0:
-        frames = world * B * n * r * args.steps
+        frames = B_global * n * r * args.steps
         spec = taco_amd.weights.weight_spec(hp, ns)
         abytes, per_step = algorithmic_bytes(spec, hp, B, T_in, n)
         flops = algorithmic_flops(hp, B, T_in, n)
@@ -569,33 +634,40 @@ def main():
                 e["binding_roofline"] = "mfma (bf16, 3 MFMAs per fp32 product) for the feed-forward part; the scan is latency bound"
             stages[k] = e
         T_mel = n * r
-        terms = {
-            "decoder_hops": n * DEC_HOPS * HOP_US * 1e-3, "decoder_chains": n * DEC_CHAIN_US * 1e-3,
-            "postnet_scan_phases": T_mel * SCAN_PHASES_US * 1e-3, "postnet_scan_collects_and_barriers": T_mel * SCAN_SYNC_US * 1e-3,
-            "encoder_scan": T_in * ENC_SCAN_STEP_US * 1e-3,
-            "feed_forward_at_measured_mfma_ceiling": 3 * ff_flops / (MFMA_BF16_MEASURED_TF * 1e12) * 1e3,
-        }
-        hw = {k: terms[k] for k in ("decoder_hops", "feed_forward_at_measured_mfma_ceiling")}
+        fc = floor_constants() if args.workload in ("C2", "C3") else {"sources": {}}
+        have = lambda *ks: all(fc.get(k) is not None for k in ks)
+        terms = {"feed_forward_at_measured_mfma_ceiling": 3 * ff_flops / (MFMA_BF16_MEASURED_TF * 1e12) * 1e3}
+        if have("hop_us", "dec_chain_us"):
+            terms["decoder_hops"] = n * fc["dec_hops"] * fc["hop_us"] * 1e-3
+            terms["decoder_chains"] = n * fc["dec_chain_us"] * 1e-3
+        if have("scan_phases_us", "scan_sync_us"):
+            terms["postnet_scan_phases"] = T_mel * fc["scan_phases_us"] * 1e-3
+            terms["postnet_scan_collects_and_barriers"] = T_mel * fc["scan_sync_us"] * 1e-3
+        if have("enc_scan_ns"):
+            terms["encoder_scan"] = fc["enc_scan_ns"] * 1e-6
+        hw = {k: terms[k] for k in ("decoder_hops", "feed_forward_at_measured_mfma_ceiling") if k in terms}
         design = {k: v for k, v in terms.items() if k not in hw}
+        missing = [k for k in ("decoder", "scan", "encoder_scan") if k not in fc["sources"]]
         floor = {"hardware_terms": hw, "hardware_total": sum(hw.values()),
                  "design_terms": design, "design_total": sum(design.values()),
                  "total": sum(terms.values()), "measured_forward_ms": fwd_s * 1e3,
-                 "note": "one forward in flight.  hardware_terms are bounds no rewrite of THIS decomposition avoids: the decoder's ten dependent "
-                         "exchanges per step at the measured L2 hand-off time (hop = %.2f us; MI355X_MICROARCH.md gives 0.8 idle) and the feed-forward "
-                         "products at the measured matrix-pipe ceiling.  design_terms are this build's own dependent-instruction time (decoder chains "
-                         "between exchanges, the scan's phases, collects and barriers, the encoder scan) -- MEASURED time of these kernels "
-                         "(profiles/r02_decoder_timeline.txt, profiles/r03_*_scan_timeline.txt), a description and a work-list, not a floor.  "
-                         "0.30 of the HBM streaming roofline would need %.2f ms per forward"
-                         % (HOP_US, abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
+                 "sources": fc["sources"], "terms_without_a_profile": missing,
+                 "note": "one forward in flight; C2 geometry.  hardware_terms are bounds no rewrite of THIS decomposition avoids: the decoder's ten dependent "
+                         "exchanges per step at the measured L2 hand-off time (the gather of a gates stage in the decoder timeline%s; MI355X_MICROARCH.md "
+                         "gives 0.8 us idle) and the feed-forward products at the measured matrix-pipe ceiling.  design_terms are this build's own "
+                         "dependent-instruction time (decoder chains between exchanges, the scan's phases, collects and barriers, the encoder scan) -- MEASURED "
+                         "time of these kernels, read from the profile files named in `sources` (newest round first), a description and a work-list, "
+                         "not a floor.  0.30 of the HBM streaming roofline would need %.2f ms per forward"
+                         % ((": %.2f us" % fc["hop_us"]) if have("hop_us") else "", abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32 storage and accumulation; feed-forward GEMMs as 3-term split-bf16 MFMA (bf16x3), the attention memory layer as 6-term split-bf16 MFMA (operands split three ways: fp32-grade); recurrent / decoder mat-vecs exact fp32",
             "data": "synthetic", "world_size_seen": world,
             "config": {"workload": "%s: batched inference B=%d/GPU, T_in=%d, T_mel=%d, r=%d, %s, attention bah_mon"
                                    % (args.workload, B, T_in, n * r, r, mt),
-                       "global_batch": world * B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
+                       "global_batch": B_global, "rows_per_gpu": B, "parallelism": "batch-sharded replicas x%d, no collective" % world,
                        "arithmetic": "fp32 storage and accumulation; feed-forward GEMMs (both CBHGs, linear head) as 3-term split-bf16 MFMA, BiGRU scans and the decoder loop in exact fp32 (max err vs float64 oracle 3.4e-6)",
                        "decoder_engine": "launch per stage" if pool.engine != "persistent" else
                                          {1: "persistent XCD-local (csrc/taco_decoder_xcd.h)", 2: "persistent, write-through exchanges"}[args.decoder_engine],
@@ -643,9 +715,12 @@ def main():
                 out["roofline"]["traffic_source"] = "none: no committed PMC profile matches this build of the kernels (hash %s)" % here
         except Exception:
             pass
-        if "exact_fp32" in companions:      # the same roofline fraction for the exact-arithmetic run, beside the headline's
+        if "exact_fp32" in companions:      # the same roofline fraction for the exact-arithmetic runs, beside the headline's
             companions["exact_fp32"]["roofline_frac"] = abytes / (companions["exact_fp32"]["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["frac_exact_fp32"] = companions["exact_fp32"]["roofline_frac"]
+        if "fp32_grade_x6" in companions:
+            companions["fp32_grade_x6"]["roofline_frac"] = abytes / (companions["fp32_grade_x6"]["forward_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["frac_fp32_grade_x6"] = companions["fp32_grade_x6"]["roofline_frac"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, seed)
         print(json.dumps(out))

@@ -165,6 +165,9 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("TACO_LIB") or LIB_PATH      # TACO_LIB: an instrumented build (tools/trace_*.py, -DTACO_TRACE)
+    if path is None and os.environ.get("TACO_LIB") and os.path.abspath(p) != os.path.abspath(LIB_PATH):
+        import warnings
+        warnings.warn("TACO_LIB overrides the library: loading %s instead of %s" % (p, LIB_PATH), RuntimeWarning, stacklevel=2)
     if not os.path.exists(p):
         raise ImportError(
             "libtaco_hip.so not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()' "

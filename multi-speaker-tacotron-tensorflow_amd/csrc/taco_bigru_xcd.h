@@ -484,6 +484,227 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_oct<UPW, TAPE> (round 5): ONE batch row per cluster of 32 / UPW CUs -- UPW = 4: four clusters of 8 CUs per XCD, 32 rows (C2);
+// UPW = 2: two clusters of 16, 16 rows; UPW = 1: one cluster of 32 (k_bigru_duo<1>'s geometry).
+//
+// k_bigru_duo gives a group of 32 CUs RG rows: a member owns 8 units x RG rows, a gather collects RG x 256 granules from 31 peers, a
+// pass reads RG rows from LDS and the epilogue lanes run RG / 4 ... sigmoid chains one behind the other.  Its one-row geometry (C5)
+// steps in 3456 clocks against 4672 at four rows (profiles/r04_v5_scan_timeline.txt).  Here every cluster has that geometry: a member
+// owns 8 UPW units of both directions of ONE row -- the same 24 UPW / 96 weight registers per thread and the same FMAs per lane as RG =
+// UPW rows of 8 units --, a gather is 256 granules from 32 / UPW - 1 peers (one per thread of HALF the workgroup: waves 0-3 collect the
+// forward direction's vectors, waves 4-7 the backward direction's), a pass is one ds_read_b128 per lane, and length masking is a scalar
+// test.  Wave w owns units 8 UPW m + UPW w + i: the wave reduction deals them to the lanes -- unit i's totals end up on lanes
+// i * 64 / UPW ... -- so its first log2(UPW) levels are HALVING levels on permlane swaps (the partner gets the half it keeps; no
+// selects, no DPP) and the epilogue is one sigmoid / tanh chain per lane whatever UPW is; every lane of a unit keeps the unit's state
+// in a register, the first one publishes.  The step is k_bigru_duo's: the two directions pipelined against each other, polls requested a
+// compute phase ahead.
+// ------------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t go_ring_floats(int UPW) { return (size_t)2 * 2 * GX_BLK * 3 * 8 * UPW; }      // [slot][dir][step][gate][8 UPW units]
+__host__ __device__ inline size_t go_lds_floats(int UPW) { return go_ring_floats(UPW) + (size_t)4 * GX_H + 64; }
+__host__ __device__ inline size_t go_xbuf_granules() { return (size_t)DX_NGROUP * 4 * 4 * GX_H; }            // <= 32 clusters x [dir][r*h | h'] x H
+
+template <int UPW, int NG>
+__device__ __forceinline__ void go_reduce(const float (&v)[UPW * NG], float (&out)[NG]) {
+  float t[NG];
+  if constexpr (UPW == 4) {
+    float h[2 * NG];       // lanes 0-31: units 0, 1; lanes 32-63: units 2, 3
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j * NG + g]), __float_as_uint(v[(j + 2) * NG + g]), false, false);
+        h[j * NG + g] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {      // even rows of 16 lanes: units 0 | 2, odd rows: units 1 | 3 -> row i = unit i
+      auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[g]), __float_as_uint(h[NG + g]), false, false);
+      t[g] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+  } else if constexpr (UPW == 2) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {      // lanes 0-31: unit 0; lanes 32-63: unit 1
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[g]), __float_as_uint(v[NG + g]), false, false);
+      t[g] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t[g] = dx_xrow16(t[g]);
+  } else {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t[g] = dx_xrow16(dx_xrow32(v[g]));
+  }
+  // the 16 lanes of a row: quad, then the two mirrors (every lane of a quad holds the quad's sum by then)
+#pragma unroll
+  for (int g = 0; g < NG; ++g) t[g] += DX_DPP0(t[g], 0xB1);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) t[g] += DX_DPP0(t[g], 0x4E);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) t[g] += DX_DPP0(t[g], 0x141);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) out[g] = t[g] + DX_DPP0(t[g], 0x140);
+}
+
+template <int UPW, bool TAPE = false>
+__global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  constexpr int NT = 512, H = GX_H, MB = DX_GROUP / UPW, UPM = 8 * UPW, NREG = 24 * UPW, LPU = 64 / UPW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SLOT = 2 * GX_BLK * 3 * UPM;      // floats of one ring slot (both directions)
+  float* xq = gx_smem;                            // ring first: its LDS addresses go through M0
+  float* hs = xq + 2 * SLOT;                      // [2 dirs][H] states
+  float* xs = hs + 2 * H;                         // [2 dirs][H] r * h
+  int* ictl = reinterpret_cast<int*>(xs + 2 * H);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
+  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  // the workgroups of an XCD are dealt round-robin to its UPW clusters
+  const int row = place * UPW + (slot % UPW), member = slot / UPW;
+  if (row >= a.B || member >= MB) return;
+  const int T = a.T;
+  const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
+  const bool tracer = a.trace && row == 0 && member == 0 && tid == 0;
+
+  float W[NREG];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float* wp = a.wpack + (((size_t)d * MB + member) * (NREG / 2)) * NT + tid;
+#pragma unroll
+    for (int j = 0; j < NREG / 2; ++j) W[(NREG / 2) * d + j] = wp[(size_t)j * NT];
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)row * 4 * H;       // [dir][r*h : H | h' : H]
+  for (int i = tid; i < 2 * H; i += NT) {
+    hs[i] = a.h0 ? a.h0[(size_t)row * 2 * H + i] : 0.f;
+    xs[i] = 0.f;
+  }
+  // x-part blocks of both directions: item i = (dir, step j, gate g, quarter c) -> one float4 of the member's 8 UPW units
+  constexpr int QPG = UPM / 4, NIT = 2 * GX_BLK * 3 * QPG, NLD = (NIT + NT - 1) / NT;
+  static_assert(NIT % 64 == 0, "a wave's 64 items are all inside the block or all outside");
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  auto blk_fetch = [&](int s0, int ring) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      if (u * NT + wave * 64 < NIT) {            // wave-uniform
+        const int i = u * NT + tid;
+        const int c = i % QPG, g = (i / QPG) % 3, j = (i / (3 * QPG)) % GX_BLK, d = i / (3 * QPG * GX_BLK);
+        const int sx = min(s0 + j, T - 1);
+        const float* src = a.xproj + ((size_t)row * T + sx) * 6 * H + d * 3 * H + g * H + member * UPM + 4 * c;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * SLOT + 4 * (u * NT + wave * 64)) * 4u);
+        gx_load_lds16(src, dst);
+      }
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(GX_BLK, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // the lane's unit: i = lane / LPU of the wave's UPW; the first lane of the unit publishes and stores
+  const int ui_outer = lane / LPU;
+  float x0[2][3], hv[2], gv[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) { hv[d] = hs[d * H + member * UPM + wave * UPW + ui_outer]; gv[d] = 0.f; }
+  unsigned long long pre = 0ull;          // the granule of a gather in flight across the current compute phase
+
+  const int tid_outer = tid, lane_outer = lane;
+  for (int s = 0; s < T; ++s) {
+    const unsigned tag = (unsigned)s + 1u;
+    int tid = tid_outer, lane = lane_outer;                 // opaque per-iteration copies: see taco_decoder_xcd.h
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int ui = lane / LPU, unit = member * UPM + wave * UPW + ui;
+    const bool pub = (lane & (LPU - 1)) == 0;
+    const bool active = s < L;                              // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+    GD_STAMP(0);
+    const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
+    if (sb == 0 && s > 0) blk_fetch(s + GX_BLK, ring ^ 1);
+    // gathers: direction D's vectors are collected by waves 4D .. 4D+3, one granule per thread
+    auto request = [&](const dx_gu64* Xv, int D) {
+      if ((wave >> 2) == D) pre = __hip_atomic_load(Xv + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto collect = [&](const dx_gu64* Xv, unsigned tg, float* dst, int D) {
+      if ((wave >> 2) == D) {
+        float v[1];
+        if ((unsigned)(pre >> 32) == tg) v[0] = __uint_as_float((unsigned)pre);
+        else dx_poll<1>(Xv + (tid & 255), 0, tg, v, rt);       // a producer was late: the ordinary bounded poll
+        dst[tid & 255] = v[0];
+      }
+    };
+    auto gates = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) x0[D][g] = xq[(size_t)ring * SLOT + ((size_t)(D * GX_BLK + sb) * 3 + g) * UPM + wave * UPW + ui];
+      float acc[2 * UPW][1], v[2 * UPW], sm[2];
+      dx_zero<2 * UPW, 1>(acc);
+      dx_pass<(NREG / 2) * D, 2 * UPW, 1, NREG, GX_H>(W, hs + D * H, lane, acc);
+#pragma unroll
+      for (int c = 0; c < 2 * UPW; ++c) v[c] = acc[c][0];
+      go_reduce<UPW, 2>(v, sm);
+      const float rr = dx_sigmoid_fast(sm[0] + x0[D][0]);
+      gv[D] = dx_sigmoid_fast(sm[1] + x0[D][1]);
+      float rh = rr * hv[D];
+      if (TAPE && pub && active) {      // gates of the active steps at their true time (modules.py:82-96 / A.7), for the backward scan
+        float* gs = a.gsave + ((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + unit;
+        gs[0] = rr; gs[H] = gv[D];
+      }
+      asm volatile("" : "+v"(pre), "+v"(rh));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
+      if (pub) dx_publish(X + (size_t)D * 2 * H + unit, rh, tag, rt);
+    };
+    auto cand = [&](auto Dc) {
+      constexpr int D = decltype(Dc)::value;
+      float acc[UPW][1], v[UPW], sm[1];
+      dx_zero<UPW, 1>(acc);
+      dx_pass<(NREG / 2) * D + 8 * UPW, UPW, 1, NREG, GX_H>(W, xs + D * H, lane, acc);
+#pragma unroll
+      for (int c = 0; c < UPW; ++c) v[c] = acc[c][0];
+      go_reduce<UPW, 1>(v, sm);
+      const float cc = taco_tanh_fast(sm[0] + x0[D][2]);
+      float blend = gv[D] * hv[D] + (1.f - gv[D]) * cc;
+      DX_PIN(blend);
+      float nv = active ? blend : hv[D];
+      if (TAPE && pub && active) a.gsave[((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + 2 * H + unit] = cc;
+      asm volatile("" : "+v"(pre), "+v"(nv));
+      if (pub) {
+        dx_publish(X + (size_t)(D * 2 + 1) * H + unit, nv, tag, rt);
+        const int t = (D && active) ? (L - 1 - s) : s;
+        a.out[((size_t)row * T + t) * 2 * H + D * H + unit] = active ? nv : 0.f;
+      }
+      hv[D] = nv;
+    };
+    using F = std::integral_constant<int, 0>;
+    using Bk = std::integral_constant<int, 1>;
+    const dx_gu64* X_rhF = X;                  const dx_gu64* X_hF = X + (size_t)H;
+    const dx_gu64* X_rhB = X + (size_t)2 * H;  const dx_gu64* X_hB = X + (size_t)3 * H;
+    // (the load for h'(B) of the previous step was requested at the end of that step)
+    gates(F{});
+    GD_STAMP(1);
+    if (s > 0) collect(X_hB, tag - 1u, hs + H, 1);
+    __syncthreads();
+    GD_STAMP(2);
+    request(X_rhF, 0);
+    gates(Bk{});
+    GD_STAMP(3);
+    collect(X_rhF, tag, xs, 0);
+    __syncthreads();
+    GD_STAMP(4);
+    request(X_rhB, 1);
+    cand(F{});
+    GD_STAMP(5);
+    collect(X_rhB, tag, xs + H, 1);
+    __syncthreads();
+    GD_STAMP(6);
+    request(X_hF, 0);
+    cand(Bk{});
+    GD_STAMP(7);
+    collect(X_hF, tag, hs, 0);
+    if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
+    __syncthreads();
+    GD_STAMP(8);
+    request(X_hB, 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // k_bigru_duo_bwd<RG>: the backward scan of the same BiGRU (BPTT through modules.py:82-96 / TF GRUCell, A.6/A.7) on k_bigru_duo's
 // machinery: both directions of RG rows on one group of 32 CUs, the two directions software-pipelined against each other, polls
 // issued early.  It replaces k_bigru_rows_bwd (one workgroup per (direction, row pair), the transposed recurrent kernels streamed

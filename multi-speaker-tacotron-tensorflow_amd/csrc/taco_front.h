@@ -378,6 +378,9 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
       }
     }
   FTRC(trci);
+#ifdef TACO_TRACE
+  if (trc) taco_trace_front[2] = trci;      // index of the last stamp THIS launch wrote (a workgroup of another launch may have had more chunks: stale slots beyond it)
+#endif
 }
 
 // out[m][n] = act(sum over the parts (fixed order) + bias[n]) * scale[n] + shift[n]   (proj_1's epilogue, modules.py:123-131)

@@ -59,7 +59,17 @@ __global__ void k_zero_fill_multi(const ZeroRegions z) {
   for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
   for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
 }
-static thread_local bool g_precleared = false;   // set by forward_enqueue around its stages: their own clears have been done by the one launch
+// Regions a caller up the stack has already cleared on this stream (forward_enqueue: ONE fill launch for every word the persistent kernels of a
+// forward poll).  A stage clears its polled words through clear_polled(): skipped only when exactly that region -- same start, at least as many
+// bytes -- is registered, so a stage whose region changes (or a new stage) clears itself instead of trusting a list kept elsewhere.
+struct ClearedSet { const void* p[8]; size_t n[8]; int cnt; };
+static thread_local ClearedSet g_cleared = {};
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+static hipError_t clear_polled(void* p, size_t bytes, hipStream_t st) {
+  for (int i = 0; i < g_cleared.cnt; ++i)
+    if (g_cleared.p[i] == p && g_cleared.n[i] >= bytes) return hipSuccess;
+  return zero_async(p, bytes, st);
+}
 static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
   if (!bytes) return hipSuccess;
   if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return hipMemsetAsync(p, 0, bytes, st);
@@ -124,6 +134,7 @@ struct Cbhg {
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
   size_t gd_pack = 0, gb_pack = 0;                     // k_bigru_duo / k_bigru_duo_bwd: [2 dirs][32 members][12][512]
+  size_t go_pack[3] = {0, 0, 0};                       // k_bigru_oct<UPW>, UPW = 1, 2, 4: [2 dirs][32 / UPW members][12 UPW][512]
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   // fused front (taco_front.h): per bank width (same order as `bank`) the produce pack [k32 step][16-channel tile][lane][8] (hi, lo)
   // and its step count; front_kind 0 = not built, 1 = <TN 2, XS 80, CINP 80, KWMAX 8> (post-net), 2 = <TN 1, XS 144, CINP 128, KWMAX 16> (encoder)
@@ -378,7 +389,8 @@ static ConvL make_conv(taco_model* m, const std::string& name, bool bn, bool has
   else { L.kw = 1; L.cin = (int)k.shape[0]; L.N = (int)k.shape[1]; }
   int Kq, NT;
   L.wp = pack_w32(m, k.data.data(), L.kw, L.cin, L.N, &L.cin_pad, &Kq, &NT);
-  if (x6) { L.bl3 = 1; L.x6 = true; }        // (preset 1 = "build the third plane in an inference model too")
+  if (bf3 && !m->tp) L.bl3 = 1;              // (preset 1 = "build the third plane in an inference model too": every layer can run the six-product instantiation, taco_debug_set_bf3 bit 64)
+  if (x6) L.x6 = true;                       // ... and this one does by default
   if (bf3) pack_bf3(m, k.data.data(), L.kw, L.cin, L.N, &L.bh, &L.bl, &L.K16, &L.cin_pad16, &L.bl3);
   if (bf3 && L.kw == 1 && L.N >= 512 && L.N % 32 > 0 && L.N % 32 <= 4 && (L.cin == 256 || L.cin == 512)) {
     L.ntail = L.N % 32;
@@ -694,6 +706,31 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
         }
     }
     c.gd_pack = arena_put(m, gp.data(), gp.size());
+    // k_bigru_oct<UPW>: member mem of a cluster of 32 / UPW, wave w owns units 8 UPW mem + UPW w + i of BOTH directions; lane l holds h rows
+    // 4l..4l+3 of the columns r_0, u_0, r_1, u_1, ... (registers 8i + 4g + e) and then of the candidates c_i (8 UPW + 4i + e)
+    for (int lg = 0; lg < 3; ++lg) {
+      const int UPW = 1 << lg, MB = DX_GROUP / UPW, NR = 12 * UPW;
+      std::vector<float> op((size_t)2 * MB * NR * 512, 0.f);
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+        const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
+        for (int mem = 0; mem < MB; ++mem)
+          for (int tid = 0; tid < 512; ++tid) {
+            const int w = tid >> 6, l = tid & 63;
+            float* base = &op[(((size_t)dir * MB + mem) * NR) * 512 + tid];
+            for (int i = 0; i < UPW; ++i) {
+              const int u = mem * 8 * UPW + w * UPW + i;
+              for (int e = 0; e < 4; ++e) {
+                const size_t kr = (size_t)(I + 4 * l + e);
+                base[(size_t)(8 * i + e) * 512] = gk[kr * 2 * H + u];
+                base[(size_t)(8 * i + 4 + e) * 512] = gk[kr * 2 * H + H + u];
+                base[(size_t)(8 * UPW + 4 * i + e) * 512] = ck[kr * H + u];
+              }
+            }
+          }
+      }
+      c.go_pack[lg] = arena_put(m, op.data(), op.size());
+    }
     if (m->tp) {   // k_bigru_duo_bwd (training only): ROWS of the recurrent kernels -- unit u's row of Wc_h, then of Wg_h (r half, u half)
       std::vector<float> bp((size_t)2 * GD_MEMBERS * 12 * 512, 0.f);
       for (int dir = 0; dir < 2; ++dir) {
@@ -716,6 +753,7 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
   int Kq, NT;
   X.wp = pack_w32(m, Wx.data(), 1, I, 6 * H, &X.cin_pad, &Kq, &NT);
+  if (bf3 && !m->tp) X.bl3 = 1;
   if (bf3) pack_bf3(m, Wx.data(), 1, I, 6 * H, &X.bh, &X.bl, &X.K16, &X.cin_pad16, &X.bl3);
   X.bias = arena_put(m, bx.data(), 6 * H);
   c.xproj = X;
@@ -723,8 +761,10 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
   c.front_kind = 0;
   if (bf3 && !m->tp && maxpool == 2 && pw == 3 && nproj >= 1 && C % FR_CH == 0 && K * (C / FR_CH) <= FR_MAXCH && K <= FR_MAXW) {
     const int cinp = rup(in_dim, 16), N1 = projs[0];
-    if (cinp == 80 && K <= 8 && N1 <= 256) c.front_kind = 1;
-    else if (cinp == 128 && K <= 16 && N1 <= 128) c.front_kind = 2;
+    // (N1 % 32: k_front_combine and the chain's fused entry read the partial sums, bias and BatchNorm operands as float4 at n = i % N1 and
+    // consume them in 32-column tiles -- a custom first projection size such as 250 takes the two-launch path)
+    if (cinp == 80 && K <= 8 && N1 <= 256 && N1 % 32 == 0) c.front_kind = 1;
+    else if (cinp == 128 && K <= 16 && N1 <= 128 && N1 % 32 == 0) c.front_kind = 2;
     if (c.front_kind) {
       for (const ConvL& L : c.bank) {
         const HostTensor& kt = T_(m, sc + "/conv_bank/conv1d_" + std::to_string(L.kw) + "/kernel");
@@ -1053,7 +1093,7 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 
 // k_bigru_duo (taco_bigru_xcd.h) usable for this scan?  (H = 256, a whole MI355X, at most 64 rows)
 static bool duo_usable(const taco_model* m, const Cbhg& c, int B, int T) {
-  return m->persist == 1 && m->dx_mode && c.gd_pack && c.rnn == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256;
+  return (m->persist == 1 || m->persist == 10 || m->persist == 11) && m->dx_mode && c.gd_pack && c.rnn == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256;
 }
 // both directions of RG rows on one group of 32 CUs, software-pipelined against each other; gsave != null: the TAPE instantiation
 static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* xproj, const int* lengths, const float* init_state,
@@ -1064,7 +1104,7 @@ static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
   a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
   int RG = 1;
   while (RG * DX_NGROUP < B) RG *= 2;
-  if (!g_precleared) HIPCHK(zero_async(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
+  HIPCHK(clear_polled(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
   const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
   if (gsave) {
@@ -1085,6 +1125,39 @@ static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
   HIPCHK(hipGetLastError());
   return 0;
 }
+// k_bigru_oct: one row per cluster of 32 / UPW CUs (UPW = 4: up to 32 rows, 2: 16, 1: 8).  persist 1 (default): from 9 rows on -- up to eight
+// rows k_bigru_duo<1> IS the one-row geometry on 32 CUs --; persist 10: wherever it fits (A/B); persist 11: never (round 4's k_bigru_duo)
+static int oct_upw(const taco_model* m, const Cbhg& c, int B, int T) {
+  if (!(m->persist == 1 || m->persist == 10) || !m->dx_mode || !c.go_pack[0] || c.rnn != GX_H || B > 32 || T < 2 || m->cu_count < 256) return 0;
+  if (B > 16) return 4;
+  if (B > 8) return 2;
+  return m->persist == 10 ? 1 : 0;
+}
+static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UPW, int B, int T, const float* xproj, const int* lengths, const float* init_state,
+                      float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
+  GdArgs a; memset(&a, 0, sizeof a);
+  a.wpack = AP(m, c.go_pack[UPW == 4 ? 2 : UPW == 2 ? 1 : 0]); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
+  a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
+  a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+  HIPCHK(clear_polled(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
+  const size_t lds = std::max(go_lds_floats(UPW) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+  const dim3 grid(DX_NGROUP * DX_GROUP), blk(512);
+  if (gsave) {
+    switch (UPW) {
+      case 1: hipLaunchKernelGGL((k_bigru_oct<1, true>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_oct<2, true>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_oct<4, true>), grid, blk, lds, st, a); break;
+    }
+  } else {
+    switch (UPW) {
+      case 1: hipLaunchKernelGGL((k_bigru_oct<1, false>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_oct<2, false>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_oct<4, false>), grid, blk, lds, st, a); break;
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 
 // BiGRU (modules.py:82-96 -> TF bidirectional_dynamic_rnn, A.7): hoisted x.[Wg_x|Wc_x]+b for both
 // directions as one GEMM, then T sequential steps of two launches (gates; candidate+update), both
@@ -1093,6 +1166,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
                       const int* lengths, const float* init_state, float* out, const CbhgWs& w) {
   const int H = c.rnn;
   if (m->skip_scans) return 0;
+  if (const int upw = oct_upw(m, c, B, T)) return oct_launch(m, st, c, upw, B, T, w.xproj, lengths, init_state, out, nullptr, w.gxbuf, w.gxctl);
   if (duo_usable(m, c, B, T)) return duo_launch(m, st, c, B, T, w.xproj, lengths, init_state, out, nullptr, w.gxbuf, w.gxctl);
   if ((m->persist == 8 || m->persist == 9) && m->dx_mode && c.gx_pack[0] && H == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256) {
     // the 2B chains spread over the whole chip, recurrent weights stationary in registers (taco_bigru_xcd.h): 256 workgroups of 8
@@ -1232,7 +1306,7 @@ static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const f
 
 // ---- conv bank -> max-pool -> proj_1 as one launch (taco_front.h) ----
 static bool front_usable(const taco_model* m, const Cbhg& c) {
-  return m->bf3 && m->front && m->force_cfg < 0 && !m->bf3_tn && c.front_kind != 0 && !c.proj.empty() && c.proj[0].bh &&
+  return m->bf3 && !m->bf3x6 && m->front && m->force_cfg < 0 && !m->bf3_tn && c.front_kind != 0 && !c.proj.empty() && c.proj[0].bh &&
          c.proj[0].cin == c.K * c.C && c.proj[0].cin_pad16 == c.K * c.C;
 }
 static int run_front(const taco_model* m, hipStream_t st, const Cbhg& c, const float* x, int B, int T, const CbhgWs& w, bool combine, int* P_out) {
@@ -1358,7 +1432,7 @@ static int cbhg_ff_advance(const taco_model* m, hipStream_t st, const Cbhg& c, c
   const int wlast = pg.w_p[c.proj.size() - 1];
   const int t0 = pg.w_pt, tl = wlast - pg.w_pt;
   if (entry && !(m->chain && t0 == 0 && tl == T && chain_fits(c, curd))) return fail(TACO_ERR_STATE, "fused chain entry planned but the chain kernel does not apply");
-  if (m->bf3 && m->chain && m->force_cfg < 0 && !m->bf3_tn && t0 == 0 && tl == T && chain_fits(c, curd)) {
+  if (m->bf3 && !m->bf3x6 && m->chain && m->force_cfg < 0 && !m->bf3_tn && t0 == 0 && tl == T && chain_fits(c, curd)) {
     // the whole tail as ONE launch, activations resident on the CU from layer to layer (taco_chain.h)
     ChainEntry E; memset(&E, 0, sizeof E);
     if (entry) {
@@ -1563,7 +1637,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.mels = m->hp.num_mels;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
   // every polled word starts from zero on every launch (tags are step numbers, the census counts arrivals)
-  if (!g_precleared) HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
+  HIPCHK(clear_polled(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));   // carved back to back: one fill launch
   const size_t lds = dx_lds_floats(RG, T_in, tape != nullptr, m->hp.attention_size) * sizeof(float);
   if (!dx_reference_widths(m)) {      // the presets of hparams.py:71-117 that the reference ships switched off: (attention_size, prenet layers)
     const int aw = m->hp.attention_size, pd = dx_prenet_depth(m);
@@ -1643,7 +1717,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
   const int Ilast = hp.dec_prenet[np - 1], ldz = Ilast + S;
   const int ldY = n * rM;   // mel buffer viewed as Y [B, n, r*num_mels] (tacotron.py:213-214 is a pure reshape)
   const int dbgw = As + D + L * Hd;
-  if (!g_precleared) HIPCHK(zero_async(w.nz, (size_t)n * B * sizeof(int), st));
+  HIPCHK(clear_polled(w.nz, (size_t)n * B * sizeof(int), st));
   if (dx_usable(m, B, T_in, manual, teacher) && !after_step) {
     // the whole loop as ONE persistent launch (taco_decoder_xcd.h), which builds its initial state itself (zeros or the deepvoice
     // vectors); the launch-per-stage loop below is the general path
@@ -1823,7 +1897,10 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
     z.p[3] = (uint32_t*)w.enc.cb.gxbuf; z.nw[3] = ((size_t)((char*)w.enc.cb.gxctl - (char*)w.enc.cb.gxbuf) + 256) / 4;     // (an encoder of width 256 scans on k_bigru_duo too)
     hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
     HIPCHK(hipGetLastError());
-    struct Guard { Guard() { g_precleared = true; } ~Guard() { g_precleared = false; } } guard;
+    struct Guard {
+      explicit Guard(const ZeroRegions& z) { g_cleared.cnt = 0; for (int i = 0; i < 4; ++i) if (z.p[i]) { g_cleared.p[g_cleared.cnt] = z.p[i]; g_cleared.n[g_cleared.cnt++] = z.nw[i] * 4; } }
+      ~Guard() { g_cleared.cnt = 0; }
+    } guard(z);
     TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
     TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, nullptr, nullptr, w.dec, true, &w.enc.spk));
     TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
@@ -2216,6 +2293,9 @@ int taco_debug_set_bf3(taco_model* m, int on, int tile_n) {
   m->front = (on & 8) ? 0 : 1;     // on = 9: conv bank and proj_1 as two k_gemm_bf3 launches (A/B of taco_front.h)
   m->front_entry = (on & 16) ? 0 : 1;   // on = 17: fused front, but k_front_combine and proj_2 as launches of their own (A/B of the chain's fused entry)
   m->head_sweep = (on & 32) ? 0 : 1;    // on = 33: the linear head on k_gemm_bf3's 64 x 256 tiles (A/B of taco_head.h)
+  // on = 65: EVERY feed-forward layer on the six-product instantiation of k_gemm_bf3 (operands split three ways: fp32-grade products on the bf16
+  // pipe), one launch per layer -- the fused front / chain / head kernels are three-product kernels and stay out of this mode
+  if (!m->tp) m->bf3x6 = (on & 64) ? 1 : 0;
   return 0;
 }
 
@@ -2315,12 +2395,14 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
   {  // post-net scan
     const Cbhg& c = m->post;
     std::string why = why_common(B);
-    if (why.empty() && m->persist != 1 && m->persist != 8 && m->persist != 9) why = "taco_debug_set_persistent(" + std::to_string(m->persist) + ")";
+    if (why.empty() && m->persist != 1 && m->persist != 8 && m->persist != 9 && m->persist != 10 && m->persist != 11) why = "taco_debug_set_persistent(" + std::to_string(m->persist) + ")";
     if (why.empty() && (c.rnn != GX_H || !c.gd_pack)) why = "post_rnn_size " + std::to_string(c.rnn) + " != 256";
     if (why.empty() && T_mel < 2) why = "fewer than 2 frames";
     int RG = 1;
     while (RG * DX_NGROUP < B) RG *= 2;
-    if (why.empty()) s += "; post-net scan: persistent " + std::string(m->persist == 1 ? "k_bigru_duo<" : "k_bigru_xcd<") + std::to_string(RG) + ">";
+    const int upw = why.empty() ? oct_upw(m, c, B, T_mel) : 0;
+    if (upw) s += "; post-net scan: persistent k_bigru_oct<" + std::to_string(upw) + "> (one row per cluster of " + std::to_string(DX_GROUP / upw) + " CUs)";
+    else if (why.empty()) s += "; post-net scan: persistent " + std::string(m->persist == 8 || m->persist == 9 ? "k_bigru_xcd<" : "k_bigru_duo<") + std::to_string(RG) + ">";
     else if (c.rnn == 128 && m->persist == 1) s += "; post-net scan: k_bigru_quad (post_rnn_size 128: a row and direction per workgroup, its weights resident, no exchange between workgroups)";
     else s += "; post-net scan: resident per-row kernels -- " + why;
   }

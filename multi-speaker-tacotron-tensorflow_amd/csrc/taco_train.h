@@ -519,7 +519,9 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
   HIPCHK(zero_async(w.gsave, (size_t)M * 6 * H * sizeof(float), st));
-  if (duo_usable(m, c, B, T))     // the whole-chip scan of inference with the gate tape (k_bigru_duo<RG, true>)
+  if (const int upw = oct_upw(m, c, B, T))     // the whole-chip scans of inference with the gate tape (k_bigru_oct<UPW, true> / k_bigru_duo<RG, true>)
+    return oct_launch(m, st, c, upw, B, T, w.xproj, lengths, init_state, w.out, w.gsave, w.gxbuf, w.gxctl);
+  if (duo_usable(m, c, B, T))
     return duo_launch(m, st, c, B, T, w.xproj, lengths, init_state, w.out, w.gsave, w.gxbuf, w.gxctl);
   if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res), gates saved for the backward scan
     BigruSArgs a; memset(&a, 0, sizeof a);

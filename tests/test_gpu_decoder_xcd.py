@@ -342,13 +342,14 @@ def test_C3_full_length_128_steps_on_8_of_the_32_rows():
     m.check_device_errors()
 
 
-@pytest.mark.parametrize("B", [1, 7, 32, 64])
+@pytest.mark.parametrize("B", [1, 7, 9, 16, 17, 32, 64])
 def test_post_net_scan_spread_over_the_chip(B):
-    """The whole-chip scans of csrc/taco_bigru_xcd.h at H = 256: k_bigru_duo (the default: 8 groups of 32 CUs, BOTH directions of
-    ceil(B/8) rows each, the two directions software-pipelined against each other with early-issued polls) and k_bigru_xcd (round
-    2: 16 groups of 16 CUs, one direction each; persist 8, and its two-workgroups-per-CU geometry, persist 9).  Against the oracle's
-    bidirectional GRU (modules.py:82-96, A.6/A.7) with ragged lengths (incl. 0 and T) and an initial state, against the
-    one-CU-per-chain kernel they replace, and bit-repeatable."""
+    """The whole-chip scans of csrc/taco_bigru_xcd.h at H = 256: k_bigru_oct (round 5, the default from 9 to 32 rows: ONE row per cluster
+    of 8 / 16 CUs, both directions pipelined against each other; persist 10 forces it for every B <= 32, i.e. also its 32-CU geometry),
+    k_bigru_duo (persist 11; the default up to 8 and above 32 rows: 8 groups of 32 CUs, BOTH directions of ceil(B/8) rows each) and
+    k_bigru_xcd (round 2: 16 groups of 16 CUs, one direction each; persist 8, and its two-workgroups-per-CU geometry, persist 9).
+    Against the oracle's bidirectional GRU (modules.py:82-96, A.6/A.7) with ragged lengths (incl. 0 and T) and an initial state,
+    against the one-CU-per-chain kernel they replace, and bit-repeatable."""
     import ctypes as C
     import torch
     import taco_amd
@@ -367,7 +368,8 @@ def test_post_net_scan_spread_over_the_chip(B):
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
     got = {}
-    for persist in (1, 1, 8, 8, 9, 7):  # 1: k_bigru_duo (default); 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU; 7: one CU per chain
+    # 1: the default; 10: k_bigru_oct wherever it fits; 11: k_bigru_duo; 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU; 7: one CU per chain
+    for persist in (1, 1, 10, 10, 11, 11, 8, 8, 9, 7):
         m._lib.taco_debug_set_persistent(m._handle, persist)
         for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
             out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
@@ -379,13 +381,56 @@ def test_post_net_scan_spread_over_the_chip(B):
     v = (C.c_int * 16)()
     taco_amd._lib.check(m._lib.taco_debug_decoder_info(m._handle, v))
     for tag, ref in (("plain", O.bidirectional_gru(x, None, w, "post_cbhg/bigru")), ("ragged", O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init))):
-        for persist, name in ((1, "k_bigru_duo"), (8, "k_bigru_xcd")):
+        for persist, name in ((1, "the default scan"), (10, "k_bigru_oct"), (11, "k_bigru_duo"), (8, "k_bigru_xcd")):
             a, b = got[(persist, tag)]
             assert np.array_equal(a, b), "%s is not bit-repeatable (%s)" % (name, tag)
             assert maxabs(a, ref) < 1e-4, (name, tag)
             assert maxabs(a, got[(7, tag)][0]) < 2e-5, (name, tag)
         a = got[(1, tag)][0]
         assert maxabs(got[(9, tag)][0], ref) < 1e-4 and maxabs(a, got[(9, tag)][0]) < 2e-5, tag
+        # which kernel the default is: k_bigru_oct from 9 to 32 rows (bit-identical to persist 10), k_bigru_duo otherwise (persist 11)
+        assert np.array_equal(a, got[(10 if 8 < B <= 32 else 11, tag)][0]), tag
+
+
+@pytest.mark.parametrize("B,T", [(5, 300), (32, 128), (3, 1000)])
+def test_encoder_scan_fast_transcendentals_against_libm_and_the_oracle(B, T):
+    """the encoder scan (H = 128) runs k_bigru_quad, whose sigmoid / tanh are rcp / exp2 approximations, where k_bigru_res
+    (persist 3) calls libm's expf / tanhf; its outputs are the attention keys and values, i.e. they feed the alignment argmax.  Held here
+    directly: k_bigru_quad vs k_bigru_res vs the float64 oracle over LONG ragged inputs (the error of a contractive recurrence does not
+    grow with T: the budget is a few ulp of the state, 2e-6 absolute on |h| < 1) and an initial state, bit-repeatable."""
+    import torch
+    import taco_amd
+    from util import dev, ptr, stream
+    ohp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(ohp, 1, 51)
+    m = build_model(ohp, w)
+    rs = np.random.RandomState(52 + B)
+    H = ohp.enc_rnn_size
+    x = rs.randn(B, T, H) * 0.7
+    lens = rs.randint(T // 2, T + 1, size=B).astype(np.int32); lens[0] = T
+    if B > 1:
+        lens[1] = 0
+    init = rs.randn(B, 2 * H) * 0.5
+    xd, ld, idv = dev(x, torch.float32), dev(lens), dev(init, torch.float32)
+    n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
+    ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
+    got = {}
+    for persist in (1, 1, 3):
+        m._lib.taco_debug_set_persistent(m._handle, persist)
+        out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
+        taco_amd._lib.check(m._lib.taco_bigru_f32(m._handle, stream(), b"encoder_cbhg", ptr(xd), ptr(ld), ptr(idv), B, T, ptr(out), ptr(ws), n))
+        torch.cuda.synchronize()
+        got.setdefault(persist, []).append(out.cpu().numpy())
+    m._lib.taco_debug_set_persistent(m._handle, 1)
+    ref = O.bidirectional_gru(x, lens, w, "encoder_cbhg/bigru", init)
+    quad, res = got[1][0], got[3][0]
+    assert np.array_equal(quad, got[1][1]), "k_bigru_quad is not bit-repeatable"
+    e_q, e_r, d = maxabs(quad, ref), maxabs(res, ref), maxabs(quad, res)
+    print("encoder scan, B=%d T=%d: k_bigru_quad vs oracle %.2e, k_bigru_res (libm) vs oracle %.2e, quad vs res %.2e" % (B, T, e_q, e_r, d))
+    assert e_q < 5e-6 and e_r < 5e-6 and d < 5e-6
+    # the error does not accumulate along the recurrence: the last quarter of the longest row is no worse than the first
+    L0 = int(lens[0])
+    assert maxabs(quad[0, 3 * L0 // 4:L0], ref[0, 3 * L0 // 4:L0]) < 5e-6
 
 
 def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
@@ -396,7 +441,7 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     ohp = O.OracleHParams(max_iters=4)
     m = build_model(ohp, O.init_weights(ohp, 1, 401))
     plan = m.engine_plan(32, 128, 512)
-    assert "decoder loop: persistent k_decoder_xcd<4>" in plan and "post-net scan: persistent k_bigru_duo<4>" in plan and "split-bf16" in plan, plan
+    assert "decoder loop: persistent k_decoder_xcd<4>" in plan and "post-net scan: persistent k_bigru_oct<4>" in plan and "split-bf16" in plan, plan
     assert "k_decoder_xcd<1>" in m.engine_plan(2, 512)
     assert "rows > 64" in m.engine_plan(65, 64)
     assert "does not fit a member's LDS" in m.engine_plan(64, 2000), m.engine_plan(64, 2000)

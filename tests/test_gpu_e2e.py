@@ -295,6 +295,19 @@ def test_full_size_C2_parity_and_properties():
     ref = O.forward(w, ohp, ids, L)
     assert hip[0].shape == (32, 512, 80) and hip[1].shape == (32, 512, 1025) and hip[2].shape == (32, 128, 128)
     _check(hip, ref, tol=1e-3)
+    # the three arithmetic levels of the bench line against the same oracle run: bf16 x 3 (default, above), every feed-forward layer on the
+    # six-product split (operands split three ways: fp32-grade products on the bf16 pipe; taco_debug_set_bf3 65) and every contraction exact fp32
+    errs = {"bf16x3": [maxabs(hip[0], ref["mel"]), maxabs(hip[1], ref["linear"])]}
+    for name, mode in (("bf16x6", 65), ("exact fp32", 0)):
+        m._lib.taco_debug_set_bf3(m._handle, mode, 0)
+        m._plans.clear()
+        got = _run(m, ids, L)
+        _check(got, ref, tol=1e-3)
+        errs[name] = [maxabs(got[0], ref["mel"]), maxabs(got[1], ref["linear"])]
+    m._lib.taco_debug_set_bf3(m._handle, 1, 0)
+    print("C2 max |err| vs the float64 oracle (mel, linear):", {k: ["%.2e" % x for x in v] for k, v in errs.items()})
+    # the six-product split is fp32-grade: as close to the oracle as the exact-fp32 engine (both ~1e-6: fp32 rounding of the recurrences), never worse than the default
+    assert errs["bf16x6"][0] <= max(2 * errs["exact fp32"][0], 5e-6) and errs["bf16x6"][1] <= max(2 * errs["exact fp32"][1], 5e-6)
 
 
 def test_the_one_excused_tie_at_C2_is_a_tie_in_exact_fp32_too():

@@ -167,3 +167,20 @@ def test_golden_fixture_pins_the_oracle():
     assert np.abs(out["mel"] - g["mel"]).max() < 1e-9
     assert np.abs(out["linear"] - g["linear"]).max() < 1e-9
     assert np.abs(out["alignments"] - g["alignments"]).max() < 1e-9
+
+
+@pytest.mark.parametrize("mt,ns,at", [("single", 1, "bah_mon"), ("deepvoice", 3, "bah"), ("simple", 2, "bah_norm")])
+def test_torch_cpu_restatement_equals_the_numpy_oracle(mt, ns, at):
+    """oracle/taco_torch_cpu.py (the fp32 torch-CPU op-for-op restatement SURVEY 8(d) names as the CPU baseline; timed by bench.py's
+    cpu_baseline leg) is the same function as the NumPy oracle: 1e-12 in float64, 1e-5 in float32, ragged lengths, every model type."""
+    import taco_torch_cpu as TT
+    hp = O.OracleHParams(max_iters=5, model_type=mt, attention_type=at)
+    w = O.init_weights(hp, ns, 7)
+    ids, L = O.synthetic_inputs(3, 11, 8, ragged=True)
+    spk = (np.arange(3) % ns).astype(np.int32) if ns > 1 else None
+    ref = O.forward(w, hp, ids, L, speaker_id=spk, num_speakers=ns, honor_stop=False)
+    got = TT.TorchCpuTacotron(w, hp, ns, dtype=torch.float64).forward(ids, L, spk)
+    g32 = TT.TorchCpuTacotron(w, hp, ns).forward(ids, L, spk)
+    for k in ("mel", "linear", "alignments"):
+        assert np.abs(got[k] - ref[k]).max() < 1e-12, k
+        assert np.abs(g32[k] - ref[k]).max() < 1e-5, k

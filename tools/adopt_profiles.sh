@@ -14,6 +14,7 @@ cp $o/train_step.json profiles/${rnd}_train_step_c4shard_${ver}.json
 cp $o/griffin_lim.json profiles/${rnd}_griffin_lim_c2shape_${ver}.json
 for f in train_step_atomics train_step_splitbf16 train_step_exact train_step_bptt_per_stage; do [ -f $o/$f.json ] && cp $o/$f.json profiles/${rnd}_${f}_${ver}.json; done
 for f in scan_timeline time_manual overlap_scan_ff time_stages bptt_timeline time_front front_timeline decoder_timeline time_layers_native time_stages_native time_train_native chain_timeline; do [ -f $o/$f.txt ] && cp $o/$f.txt profiles/${rnd}_${ver}_$f.txt; done
+for f in scan_timeline decoder_timeline; do [ -f $o/$f.json ] && cp $o/$f.json profiles/${rnd}_${ver}_$f.json; done      # bench.py's latency_floor_ms reads these
 [ -f $o/bench_C4.json ] && cp $o/bench_C4.json profiles/${rnd}_bench_${ver}_C4.json
 [ -f $o/train_kernel_stats.csv ] && cp $o/train_kernel_stats.csv profiles/${rnd}_train_kernel_stats_${ver}.csv
 ls profiles | grep "${rnd}_.*${ver}"

@@ -7,7 +7,7 @@ touches sits in registers or LDS; a value the compiler demotes to scratch turns 
 issue).  csrc/build.sh compiles with -Rpass-analysis=kernel-resource-usage and keeps the remarks in csrc/kernel_resources.txt;
 this script reads them and fails when
 
-any instantiation of k_bigru_xcd, k_bigru_duo, k_pointwise_chain, k_cbhg_front, k_head_sweep, k_decoder_xcd or k_decoder_bwd_xcd has
+any instantiation of k_bigru_xcd, k_bigru_duo, k_bigru_oct, k_pointwise_chain, k_cbhg_front, k_head_sweep, k_decoder_xcd or k_decoder_bwd_xcd has
 ScratchSize > 0 (no allowances since round 4: the last one, the 8-rows-per-group BPTT kernel's 196 bytes, went when the owner rows' tape
 offsets became per-step values instead of 22 hoisted pointers).
 
@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
-PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front", "k_head_sweep")  # k_bigru_duo also matches k_bigru_duo_bwd
+PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_bigru_oct", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front", "k_head_sweep")  # k_bigru_duo also matches k_bigru_duo_bwd
 ALLOWED_SCRATCH = {}      # (mangled name -> bytes per lane; empty since round 4)
 
 

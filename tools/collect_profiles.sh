@@ -17,14 +17,15 @@ timeout 300 python tools/bench_train.py --bptt 0 > $out/train_step_bptt_per_stag
 timeout 300 python tools/trace_bptt.py 2>&1 | grep -v amdgpu.ids > $out/bptt_timeline.txt
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
 # round 3: scan timelines (k_bigru_duo vs k_bigru_xcd), manual / simple decoder modes, feed-forward-under-the-scan experiment, training kernel statistics
-{ for p in 1 8; do python tools/trace_bigru.py 32 512 $p; python tools/trace_bigru.py 64 512 $p; python tools/trace_bigru.py 8 4000 $p; done; } 2>&1 | grep -v amdgpu.ids > $out/scan_timeline.txt
+rm -f $out/scan_timeline.json
+{ for p in 1 10 11 8; do python tools/trace_bigru.py 32 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 16 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 64 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 8 4000 $p --json $out/scan_timeline.json; done; } 2>&1 | grep -v amdgpu.ids > $out/scan_timeline.txt
 timeout 300 python tools/time_manual.py 2>&1 | grep -v amdgpu.ids > $out/time_manual.txt
 timeout 300 python tools/overlap_scan_ff.py 2>&1 | grep -v amdgpu.ids > $out/overlap_scan_ff.txt
 timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $out/time_stages.txt
 # round 4: the fused CBHG front (k_cbhg_front): feed-forward time of both stages with the front on / off and per start delay / priority, phase
 # timeline of one workgroup (needs the -DTACO_TRACE build next to the library), per-layer timings, the C4 line of bench.py
 timeout 300 python tools/time_front.py 2>&1 | grep -v amdgpu.ids > $out/time_front.txt
-timeout 300 python tools/time_decoder.py C2:8 2>&1 | grep -v amdgpu.ids > $out/decoder_timeline.txt       # per-phase clocks of one decoder step; 64-row pass at eight rows per group
+timeout 300 python tools/time_decoder.py C2:8 --json $out/decoder_timeline.json 2>&1 | grep -v amdgpu.ids > $out/decoder_timeline.txt       # per-phase clocks of one decoder step; 64-row pass at eight rows per group
 [ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_front.py 2>&1 | grep -v amdgpu.ids > $out/front_timeline.txt
 [ -x tools/time_layers_native ] && timeout 120 ./tools/time_layers_native 20 > $out/time_layers_native.txt 2>&1
 [ -x tools/time_train_native ] && timeout 120 ./tools/time_train_native > $out/time_train_native.txt 2>&1      # one C4-shard training step through the C ABI, no Python

@@ -81,6 +81,7 @@ def main():
                 print("   timeline (median of steps 1-7, us; clock ~%.0f MHz): " % clk_per_us +
                       "  ".join("%s %.2f" % (p, c / clk_per_us) for p, c in zip(PHASES, med)), flush=True)
                 sm = np.median(sub[1:], axis=0) / clk_per_us
+                rec[label]["gates_stage_split_us"] = dict(zip(("pass+reduce", "epilogue+publish", "gather(poll)", "barrier"), (float(x) for x in sm)))
                 print("   GRU1 gates stage split: pass+reduce %.2f  epilogue+publish %.2f  gather(poll) %.2f  barrier %.2f" % tuple(sm), flush=True)
         res[name] = rec
         model.close()

@@ -19,13 +19,15 @@ def show(name, fn):
     buf = (C.c_longlong * 64)()
     assert L.taco_debug_read_trace_front(buf) == 0
     t = np.array(buf[:64], dtype=np.int64)
+    last = int(t[2])                       # index of the last stamp this launch wrote: slots beyond it are another launch's
     rel = t - t[0]
-    print(name, "staged", rel[1])
+    print(name, "staged", rel[1], "(%d chunks in the traced workgroup)" % ((last - 4) // 4))
     k = 3
-    while k + 3 < 64 and rel[k] > 0 and rel[k + 3] > rel[k]:
+    while k + 3 < last - 1:
         print("  chunk: produce loop %6d | wait for the other waves %5d | pool + planes %5d | consume %6d" % (
             rel[k] - (rel[k - 1] if k > 3 else rel[1]), rel[k + 1] - rel[k], rel[k + 2] - rel[k + 1], rel[k + 3] - rel[k + 2]))
         k += 4
+    assert k == last - 1, (k, last)
     print("  K halves met +%d, stored +%d, total %d clocks" % (rel[k] - rel[k - 1], rel[k + 1] - rel[k], rel[k + 1]))
 show("post-net", lambda: m.postnet(mel))
 show("encoder", lambda: m.encoder(ids, lens))
