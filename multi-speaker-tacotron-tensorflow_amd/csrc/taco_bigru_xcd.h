@@ -543,10 +543,20 @@ __device__ __forceinline__ void go_reduce(const float (&v)[UPW * NG], float (&ou
   for (int g = 0; g < NG; ++g) out[g] = t[g] + DX_DPP0(t[g], 0x140);
 }
 
-template <int UPW, bool TAPE = false>
-__global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
-  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
-  GdArgs a = a_in;
+// WT: the census found the fallback placement -- write-through exchanges (decided once per launch: the loop carries no protocol branch);
+// TRACE: shader-clock stamps of row 0 / member 0 (tools/trace_bigru.py); the production instantiation has none of their branches.
+#define GO_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if constexpr (TRACE) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
+  } while (0)
+template <bool WT>
+__device__ __forceinline__ void go_publish(dx_gu64* p, float v, unsigned tag) {
+  const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if constexpr (WT) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);                  // sc0: stays in this XCD's L2
+}
+template <int UPW, bool TAPE, bool WT, bool TRACE>
+__device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int place, int slot, DxRt rt) {
   constexpr int NT = 512, H = GX_H, MB = DX_GROUP / UPW, UPM = 8 * UPW, NREG = 24 * UPW, LPU = 64 / UPW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -554,17 +564,12 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
   float* xq = gx_smem;                            // ring first: its LDS addresses go through M0
   float* hs = xq + 2 * SLOT;                      // [2 dirs][H] states
   float* xs = hs + 2 * H;                         // [2 dirs][H] r * h
-  int* ictl = reinterpret_cast<int*>(xs + 2 * H);
-  dx_gu32* errw = (dx_gu32*)a.err;
-  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
-  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
-  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
   // the workgroups of an XCD are dealt round-robin to its UPW clusters
   const int row = place * UPW + (slot % UPW), member = slot / UPW;
   if (row >= a.B || member >= MB) return;
   const int T = a.T;
   const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
-  const bool tracer = a.trace && row == 0 && member == 0 && tid == 0;
+  const bool tracer = TRACE && a.trace && row == 0 && member == 0 && tid == 0;
 
   float W[NREG];
 #pragma unroll
@@ -605,7 +610,10 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
   float x0[2][3], hv[2], gv[2];
 #pragma unroll
   for (int d = 0; d < 2; ++d) { hv[d] = hs[d * H + member * UPM + wave * UPW + ui_outer]; gv[d] = 0.f; }
-  unsigned long long pre = 0ull;          // the granule of a gather in flight across the current compute phase
+  // the granule of a gather in flight across the current compute phase, asked for twice: at the start of the phase (`pre`: a fast producer's value
+  // is back long before it is needed) and again behind the phase's products (`pre2`: a request that reaches the L2 ~250 clocks later finds the value of
+  // a producer that published late; it is back by the time the phase's reduction and epilogue are done).  256 threads x 8 bytes each: nothing.
+  unsigned long long pre = 0ull, pre2 = 0ull;
 
   const int tid_outer = tid, lane_outer = lane;
   for (int s = 0; s < T; ++s) {
@@ -615,30 +623,46 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
     const int ui = lane / LPU, unit = member * UPM + wave * UPW + ui;
     const bool pub = (lane & (LPU - 1)) == 0;
     const bool active = s < L;                              // A.7: row active iff s < L; forward t = s, backward t = L-1-s
-    GD_STAMP(0);
+    GO_STAMP(0);
     const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
     if (sb == 0 && s > 0) blk_fetch(s + GX_BLK, ring ^ 1);
     // gathers: direction D's vectors are collected by waves 4D .. 4D+3, one granule per thread
     auto request = [&](const dx_gu64* Xv, int D) {
       if ((wave >> 2) == D) pre = __hip_atomic_load(Xv + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    auto request2 = [&](const dx_gu64* Xv, int D) {
+      if ((wave >> 2) == D) pre2 = __hip_atomic_load(Xv + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
     auto collect = [&](const dx_gu64* Xv, unsigned tg, float* dst, int D) {
       if ((wave >> 2) == D) {
         float v[1];
-        if ((unsigned)(pre >> 32) == tg) v[0] = __uint_as_float((unsigned)pre);
+        if ((unsigned)(pre2 >> 32) == tg) v[0] = __uint_as_float((unsigned)pre2);
+        else if ((unsigned)(pre >> 32) == tg) v[0] = __uint_as_float((unsigned)pre);
         else dx_poll<1>(Xv + (tid & 255), 0, tg, v, rt);       // a producer was late: the ordinary bounded poll
         dst[tid & 255] = v[0];
       }
     };
-    auto gates = [&](auto Dc) {
+    // a phase: D = its direction; (Xn, Dn) = the gather in flight across it (null: none)
+    auto gates = [&](auto Dc, const dx_gu64* Xn, int Dn) {
       constexpr int D = decltype(Dc)::value;
+      constexpr int R0 = (NREG / 2) * D;
 #pragma unroll
       for (int g = 0; g < 3; ++g) x0[D][g] = xq[(size_t)ring * SLOT + ((size_t)(D * GX_BLK + sb) * 3 + g) * UPM + wave * UPW + ui];
-      float acc[2 * UPW][1], v[2 * UPW], sm[2];
-      dx_zero<2 * UPW, 1>(acc);
-      dx_pass<(NREG / 2) * D, 2 * UPW, 1, NREG, GX_H>(W, hs + D * H, lane, acc);
+      // (r_i, u_i) of unit i in one v_pk_fma_f32 per input: registers R0 + 8i + e (r) and R0 + 8i + 4 + e (u), the state value broadcast
+      const float4 hx = *reinterpret_cast<const float4*>(hs + D * H + 4 * lane);
+      taco_f32x2 acc[UPW];
 #pragma unroll
-      for (int c = 0; c < 2 * UPW; ++c) v[c] = acc[c][0];
+      for (int i = 0; i < UPW; ++i) acc[i] = (taco_f32x2){W[R0 + 8 * i] * hx.x, W[R0 + 8 * i + 4] * hx.x};
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.y, hx.y}, (taco_f32x2){W[R0 + 8 * i + 1], W[R0 + 8 * i + 5]}, acc[i]);
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
+      if (Xn) request2(Xn, Dn);
+      float v[2 * UPW], sm[2];
+#pragma unroll
+      for (int i = 0; i < UPW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
       go_reduce<UPW, 2>(v, sm);
       const float rr = dx_sigmoid_fast(sm[0] + x0[D][0]);
       gv[D] = dx_sigmoid_fast(sm[1] + x0[D][1]);
@@ -647,25 +671,41 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
         float* gs = a.gsave + ((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + unit;
         gs[0] = rr; gs[H] = gv[D];
       }
-      asm volatile("" : "+v"(pre), "+v"(rh));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
-      if (pub) dx_publish(X + (size_t)D * 2 * H + unit, rh, tag, rt);
+      asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(rh));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
+      if (pub) go_publish<WT>(X + (size_t)D * 2 * H + unit, rh, tag);
     };
-    auto cand = [&](auto Dc) {
+    auto cand = [&](auto Dc, const dx_gu64* Xn, int Dn) {
       constexpr int D = decltype(Dc)::value;
-      float acc[UPW][1], v[UPW], sm[1];
-      dx_zero<UPW, 1>(acc);
-      dx_pass<(NREG / 2) * D + 8 * UPW, UPW, 1, NREG, GX_H>(W, xs + D * H, lane, acc);
+      constexpr int R0 = (NREG / 2) * D + 8 * UPW;
+      const float4 hx = *reinterpret_cast<const float4*>(xs + D * H + 4 * lane);
+      float v[UPW], sm[1];
+      if constexpr (UPW >= 2) {        // candidates of units (i, i + 1) in one v_pk_fma_f32 per input
+        taco_f32x2 acc[UPW / 2];
 #pragma unroll
-      for (int c = 0; c < UPW; ++c) v[c] = acc[c][0];
+        for (int i = 0; i < UPW / 2; ++i) acc[i] = (taco_f32x2){W[R0 + 8 * i] * hx.x, W[R0 + 8 * i + 4] * hx.x};
+#pragma unroll
+        for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.y, hx.y}, (taco_f32x2){W[R0 + 8 * i + 1], W[R0 + 8 * i + 5]}, acc[i]);
+#pragma unroll
+        for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
+#pragma unroll
+        for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
+#pragma unroll
+        for (int i = 0; i < UPW / 2; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
+      } else {                         // one unit: even / odd inputs in the two halves
+        taco_f32x2 acc = (taco_f32x2){W[R0] * hx.x, W[R0 + 1] * hx.y};
+        acc = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.w}, (taco_f32x2){W[R0 + 2], W[R0 + 3]}, acc);
+        v[0] = acc.x + acc.y;
+      }
+      if (Xn) request2(Xn, Dn);
       go_reduce<UPW, 1>(v, sm);
       const float cc = taco_tanh_fast(sm[0] + x0[D][2]);
       float blend = gv[D] * hv[D] + (1.f - gv[D]) * cc;
       DX_PIN(blend);
       float nv = active ? blend : hv[D];
       if (TAPE && pub && active) a.gsave[((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + 2 * H + unit] = cc;
-      asm volatile("" : "+v"(pre), "+v"(nv));
+      asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(nv));
       if (pub) {
-        dx_publish(X + (size_t)(D * 2 + 1) * H + unit, nv, tag, rt);
+        go_publish<WT>(X + (size_t)(D * 2 + 1) * H + unit, nv, tag);
         const int t = (D && active) ? (L - 1 - s) : s;
         a.out[((size_t)row * T + t) * 2 * H + D * H + unit] = active ? nv : 0.f;
       }
@@ -676,32 +716,46 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
     const dx_gu64* X_rhF = X;                  const dx_gu64* X_hF = X + (size_t)H;
     const dx_gu64* X_rhB = X + (size_t)2 * H;  const dx_gu64* X_hB = X + (size_t)3 * H;
     // (the load for h'(B) of the previous step was requested at the end of that step)
-    gates(F{});
-    GD_STAMP(1);
+    gates(F{}, s > 0 ? X_hB : nullptr, 1);
+    GO_STAMP(1);
     if (s > 0) collect(X_hB, tag - 1u, hs + H, 1);
     __syncthreads();
-    GD_STAMP(2);
+    GO_STAMP(2);
     request(X_rhF, 0);
-    gates(Bk{});
-    GD_STAMP(3);
+    gates(Bk{}, X_rhF, 0);
+    GO_STAMP(3);
     collect(X_rhF, tag, xs, 0);
     __syncthreads();
-    GD_STAMP(4);
+    GO_STAMP(4);
     request(X_rhB, 1);
-    cand(F{});
-    GD_STAMP(5);
+    cand(F{}, X_rhB, 1);
+    GO_STAMP(5);
     collect(X_rhB, tag, xs + H, 1);
     __syncthreads();
-    GD_STAMP(6);
+    GO_STAMP(6);
     request(X_hF, 0);
-    cand(Bk{});
-    GD_STAMP(7);
+    cand(Bk{}, X_hF, 0);
+    GO_STAMP(7);
     collect(X_hF, tag, hs, 0);
     if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
     __syncthreads();
-    GD_STAMP(8);
+    GO_STAMP(8);
     request(X_hB, 1);
   }
+}
+
+template <int UPW, bool TAPE = false, bool TRACE = false>
+__global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  const int tid = threadIdx.x;
+  int* ictl = reinterpret_cast<int*>(gx_smem + go_ring_floats(UPW) + 4 * GX_H);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
+  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) go_body<UPW, TAPE, true, TRACE>(a, gx_smem, place, slot, rt);
+  else go_body<UPW, TAPE, false, TRACE>(a, gx_smem, place, slot, rt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

@@ -1137,12 +1137,18 @@ static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UP
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
   GdArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.go_pack[UPW == 4 ? 2 : UPW == 2 ? 1 : 0]); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
-  a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
+  a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace && !gsave) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
   a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
   HIPCHK(clear_polled(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
   const size_t lds = std::max(go_lds_floats(UPW) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   const dim3 grid(DX_NGROUP * DX_GROUP), blk(512);
-  if (gsave) {
+  if (a.trace) {          // the stamped instantiation (tools/trace_bigru.py): inference only
+    switch (UPW) {
+      case 1: hipLaunchKernelGGL((k_bigru_oct<1, false, true>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_oct<2, false, true>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_oct<4, false, true>), grid, blk, lds, st, a); break;
+    }
+  } else if (gsave) {
     switch (UPW) {
       case 1: hipLaunchKernelGGL((k_bigru_oct<1, true>), grid, blk, lds, st, a); break;
       case 2: hipLaunchKernelGGL((k_bigru_oct<2, true>), grid, blk, lds, st, a); break;
