@@ -514,14 +514,24 @@ __global__ void k_embed_bwd(const float* dx, const int* ids, float* dE, int M, i
   const int m = (int)(i / E), c = (int)(i % E);
   atomicAdd(dE + (size_t)ids[m] * E + c, dx[i]);
 }
-// deterministic variant: one thread per (table row v, column c) walks the rows in order
+// deterministic variant: one WAVE per (table row v, 64 columns) walks the rows in order -- the ids come 64 at a time (one coalesced load and a
+// ballot), only the matching rows are visited: the same summation order as one thread per element walking all M rows (round 4: 240 us per
+// step at the C4 shard), without its M dependent id loads per thread
 __global__ void k_embed_bwd_det(const float* dx, const int* ids, float* dE, int M, int E, int V) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)V * E) return;
-  const int v = (int)(i / E), c = (int)(i % E);
+  const int wave = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int ncb = (E + 63) / 64, v = wave / ncb, c = (wave % ncb) * 64 + lane;
+  if (v >= V) return;
   float s = 0.f;
-  for (int m = 0; m < M; ++m) if (ids[m] == v) s += dx[(size_t)m * E + c];
-  dE[i] += s;
+  for (int m0 = 0; m0 < M; m0 += 64) {
+    const int id = (m0 + lane < M) ? ids[m0 + lane] : -1;
+    unsigned long long mask = __ballot(id == v);
+    while (mask) {
+      const int j = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      if (c < E) s += dx[(size_t)(m0 + j) * E + c];
+    }
+  }
+  if (c < E) dE[(size_t)v * E + c] += s;
 }
 // y = softsign(z) = z / (1 + |z|)  =>  dz = dy * (1 - |y|)^2   (deepvoice speaker layers, tacotron.py:68-79)
 __global__ void k_softsign_bwd(const float* dy, const float* y, float* dz, int n) {

@@ -547,8 +547,14 @@ __device__ __forceinline__ void go_reduce(const float (&v)[UPW * NG], float (&ou
 // TRACE: shader-clock stamps of row 0 / member 0 (tools/trace_bigru.py); the production instantiation has none of their branches.
 #define GO_STAMP(slot)                                                                                            \
   do {                                                                                                            \
-    if constexpr (TRACE) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
+    if constexpr (TRACE || GO_DYN) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
   } while (0)
+#ifndef GO_REQ2
+#define GO_REQ2 1          // A/B (tools/scratch): 0 = no second, mid-phase request
+#endif
+#ifndef GO_DYN
+#define GO_DYN 0           // A/B: 1 = the protocol test of every publish and the tracer test of every stamp at run time, as in k_bigru_duo / k_decoder_xcd
+#endif
 template <bool WT>
 __device__ __forceinline__ void go_publish(dx_gu64* p, float v, unsigned tag) {
   const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
@@ -569,7 +575,7 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
   if (row >= a.B || member >= MB) return;
   const int T = a.T;
   const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
-  const bool tracer = TRACE && a.trace && row == 0 && member == 0 && tid == 0;
+  const bool tracer = (TRACE || GO_DYN) && a.trace && row == 0 && member == 0 && tid == 0;
 
   float W[NREG];
 #pragma unroll
@@ -659,7 +665,7 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
       for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
 #pragma unroll
       for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
-      if (Xn) request2(Xn, Dn);
+      if (GO_REQ2 && Xn) request2(Xn, Dn);
       float v[2 * UPW], sm[2];
 #pragma unroll
       for (int i = 0; i < UPW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
@@ -667,12 +673,12 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
       const float rr = dx_sigmoid_fast(sm[0] + x0[D][0]);
       gv[D] = dx_sigmoid_fast(sm[1] + x0[D][1]);
       float rh = rr * hv[D];
-      if (TAPE && pub && active) {      // gates of the active steps at their true time (modules.py:82-96 / A.7), for the backward scan
+      asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(rh));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
+      if (pub) { if (GO_DYN) dx_publish(X + (size_t)D * 2 * H + unit, rh, tag, rt); else go_publish<WT>(X + (size_t)D * 2 * H + unit, rh, tag); }
+      if (TAPE && pub && active) {      // gates of the active steps at their true time (modules.py:82-96 / A.7), for the backward scan -- BEHIND the publish: the exchange is the critical path
         float* gs = a.gsave + ((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + unit;
         gs[0] = rr; gs[H] = gv[D];
       }
-      asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(rh));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
-      if (pub) go_publish<WT>(X + (size_t)D * 2 * H + unit, rh, tag);
     };
     auto cand = [&](auto Dc, const dx_gu64* Xn, int Dn) {
       constexpr int D = decltype(Dc)::value;
@@ -696,18 +702,18 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
         acc = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.w}, (taco_f32x2){W[R0 + 2], W[R0 + 3]}, acc);
         v[0] = acc.x + acc.y;
       }
-      if (Xn) request2(Xn, Dn);
+      if (GO_REQ2 && Xn) request2(Xn, Dn);
       go_reduce<UPW, 1>(v, sm);
       const float cc = taco_tanh_fast(sm[0] + x0[D][2]);
       float blend = gv[D] * hv[D] + (1.f - gv[D]) * cc;
       DX_PIN(blend);
       float nv = active ? blend : hv[D];
-      if (TAPE && pub && active) a.gsave[((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + 2 * H + unit] = cc;
       asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(nv));
       if (pub) {
-        go_publish<WT>(X + (size_t)(D * 2 + 1) * H + unit, nv, tag);
+        if (GO_DYN) dx_publish(X + (size_t)(D * 2 + 1) * H + unit, nv, tag, rt); else go_publish<WT>(X + (size_t)(D * 2 + 1) * H + unit, nv, tag);
         const int t = (D && active) ? (L - 1 - s) : s;
         a.out[((size_t)row * T + t) * 2 * H + D * H + unit] = active ? nv : 0.f;
+        if (TAPE && active) a.gsave[((size_t)row * T + t) * 6 * H + D * 3 * H + 2 * H + unit] = cc;
       }
       hv[D] = nv;
     };

@@ -304,7 +304,7 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
   return 0;
 }
 static void run_embed_bwd(hipStream_t st, const float* dx, const int* ids, float* dE, int M, int E, int V) {
-  if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * E), 0, st, dx, ids, dE, M, E, V);
+  if (g_det.p) hipLaunchKernelGGL(k_embed_bwd_det, EWGRID((size_t)V * ((E + 63) / 64) * 64), 0, st, dx, ids, dE, M, E, V);      // one wave per (table row, 64 columns)
   else hipLaunchKernelGGL(k_embed_bwd, EWGRID((size_t)M * E), 0, st, dx, ids, dE, M, E);
 }
 static thread_local int g_dgrad_bf3 = 0;       // taco_train_set_exact_gemm(t, 3): forward GEMMs exact fp32, data gradients split-bf16
