@@ -318,20 +318,23 @@ __device__ __forceinline__ void dx_reduce(const float (&a)[NC][RG], float (&out)
 struct DxRt {     // run-time state of a thread
   dx_gu32* err; bool wt; bool dead;
 };
+// WTC: the protocol as a compile-time constant (0: XCD-local, 1: write-through) where the kernel body is instantiated per protocol -- the
+// run-time test (-1) costs a branch per publish, ~30 clocks each on the chain (round 5: 11 % of a post-net scan step, measured)
+template <int WTC = -1>
 __device__ __forceinline__ void dx_publish(dx_gu64* p, float v, unsigned tag, const DxRt& rt) {
   const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-  if (rt.wt) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
+  if (WTC == 1 || (WTC < 0 && rt.wt)) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
   else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // sc0: stays in this XCD's L2
 }
 // N granules of one lane at once (p + u*stride): ONE uniform branch on the protocol around all stores, so that the epilogue that
 // produced the values stays a single basic block (a branch per value kept the compiler from interleaving the exp/rcp chains of
 // independent units)
-template <int N>
+template <int N, int WTC = -1>
 __device__ __forceinline__ void dx_publish_n(dx_gu64* p, int stride, const float (&v)[N], unsigned tag, const DxRt& rt) {
   unsigned long long g[N];
 #pragma unroll
   for (int u = 0; u < N; ++u) g[u] = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v[u]);
-  if (rt.wt) {
+  if (WTC == 1 || (WTC < 0 && rt.wt)) {
 #pragma unroll
     for (int u = 0; u < N; ++u) __hip_atomic_store(p + u * stride, g[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
@@ -558,16 +561,17 @@ __global__ __launch_bounds__(DX_W) void k_dx_rowbias(const float* table, const i
 
 #define DX_STAMP(slot)                                                                                     \
   do {                                                                                                     \
-    if (tracer && t < DX_TRACE_STEPS) a.trace[t * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
+    if constexpr (TRACE) { if (tracer && t < DX_TRACE_STEPS) a.trace[t * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
   } while (0)
 
 // MAN: the manual-attention instantiation (a.manual != null); the plain one carries none of its branches, loads or address selects
 // AW: attention_size (128 / 256 / 512); PD: decoder prenet layers (2: [256, 128]; 3: [256, 128, 64])
-template <int RG, bool TAPE = false, bool MAN = false, int AW = DX_W, int PD = 2>
-__global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
+// WT: the census chose the write-through protocol (decided once per launch; the step carries no protocol branch); TRACE: shader-clock stamps
+// (tools/time_decoder.py) -- the production instantiations have none of their branches
+template <int RG, bool TAPE, bool MAN, int AW, int PD, bool WT, bool TRACE>
+__device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int group, int member, DxRt rt) {
   static_assert((AW == DX_W && PD == 2) || !TAPE, "the training forward exists at the reference widths only");
-  extern __shared__ __attribute__((aligned(16))) float dx_smem[];
-  DxArgs a = a_in;
+  constexpr int WTC = WT ? 1 : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int Pr = DX_GROUP / RG;          // members per row in the attention phases
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const int TP = (T + Pr - 1) / Pr;          // positions whose history this member writes
   const int TS = (T + Pp - 1) / Pp;          // positions it scores
 
-  // ---- LDS carve (dx_lds_floats mirrors this) ----
+  // ---- LDS carve (dx_lds_floats mirrors this; its last 64 floats are the census words of the kernel wrapper) ----
   float* st = dx_smem;
   float* Kc = st + RG * DXS_LD;              // keys   [TS][DS]: the member's position block x channel block
   float* Vc = Kc + (size_t)TS * DS;          // values [T][DC]: all positions x its context channels
@@ -601,15 +605,6 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   float* rbl = bl + DXB_N * DX_NW;           // [DXRB_N][RG][DX_NW]
   float* mrow = rbl + DXRB_N * RG * DX_NW;   // [roundup(T, 64)] manual alignments of the step
   float* tfb = mrow + ((T + 63) & ~63);      // [RG][DX_W] teacher frames (TAPE only)
-  int* ictl = reinterpret_cast<int*>(tfb + (TAPE ? RG * DX_W : 0));
-
-  // ---- census: which XCD am I on, is every XCD hosting exactly one group? ----
-  dx_gu32* ctl = (dx_gu32*)a.ctl;
-  dx_gu32* errw = (dx_gu32*)a.err;
-  dx_census(ctl, errw, a.force_wt, ictl, tid, 8);
-  const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
-  const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
-  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
   const int ga = (group - a.grp0) & 7;
   if (ga >= a.ngroups || member >= DX_GROUP) return;
   const int row0 = ga * RG;
@@ -618,7 +613,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const int cb = asl % Pc, pb = asl / Pc;                // score role: channel block, position block
   const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
   const int brow = row0 + arow;                          // its batch row (may be >= B: padding)
-  const bool tracer = a.trace && ga == 0 && member == 0 && tid == 0;
+  const bool tracer = TRACE && a.trace && ga == 0 && member == 0 && tid == 0;
 
   // ---- weights, resident for the whole loop ----
   float W[DX_NREG];
@@ -777,7 +772,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
           const float p2v = fmaxf(s[0][q] + bl[DXB_P2 * DX_NW + wave], 0.f);
-          dx_publish(X + xl.p2 + erow[q] * DX_P2 + member * 4 + wave, p2v, tag, rt);
+          dx_publish<WTC>(X + xl.p2 + erow[q] * DX_P2 + member * 4 + wave, p2v, tag, rt);
           if (TAPE && tval[q] && a.tp_p2) a.tp_p2[((size_t)(row0 + erow[q]) * a.n + t) * a.ld_p2 + member * 4 + wave] = p2v;
         }
       }
@@ -799,7 +794,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         if (epl) {
 #pragma unroll
           for (int q = 0; q < RL; ++q)
-            dx_publish(X + xl.p3 + erow[q] * DX_P3 + member * 2 + wave, fmaxf(s[0][q] + bl[DXB_P3 * DX_NW + wave], 0.f), tag, rt);
+            dx_publish<WTC>(X + xl.p3 + erow[q] * DX_P3 + member * 2 + wave, fmaxf(s[0][q] + bl[DXB_P3 * DX_NW + wave], 0.f), tag, rt);
         }
       }
       dx_gather<RG, DX_P3, false>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
@@ -817,7 +812,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         const float rg = dx_sigmoid_fast(s[0][q] + DX_RB(DXRB_AR, q));
         g_u[q] = dx_sigmoid_fast(s[1][q] + DX_RB(DXRB_AU, q));
         g_cx[q] = s[2][q] + DX_RB(DXRB_AX, q);
-        if (epl) dx_publish(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.rha + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
         DX_TAPE(DXT_RA, q, rg); DX_TAPE(DXT_UA, q, g_u[q]); DX_TAPE(DXT_RHA, q, rg * g_h[q]);
       }
     }
@@ -833,7 +828,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_AC * DX_NW + wave]);
         const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
-        if (epl) dx_publish(X + xl.ha + erow[q] * DX_W + en, hn, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.ha + erow[q] * DX_W + en, hn, tag, rt);
         DX_TAPE(DXT_CA, q, c); DX_TAPE(DXT_HA, q, hn);
       }
     }
@@ -889,7 +884,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
             }
           }
           e = dx_quadsum(e);
-          if (cp == 0 && j < psn) dx_publish(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
+          if (cp == 0 && j < psn) dx_publish<WTC>(X + xl.sc + (size_t)(arow * Pc + cb) * T + ps0 + j, e, tag, rt);
         }
       }
     }
@@ -960,7 +955,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       float s = 0.f;
 #pragma unroll
       for (int w = 0; w < DX_NW; ++w) s += cpart[w * 64 + tid];
-      dx_publish(X + xl.ctx + arow * DX_W + asl * DC + tid, s, tag, rt);
+      dx_publish<WTC>(X + xl.ctx + arow * DX_W + asl * DC + tid, s, tag, rt);
       if (TAPE && a.tp_ctx && brow < a.B) a.tp_ctx[((size_t)brow * a.n + t) * a.ld_ctx + asl * DC + tid] = s;
     }
     dx_gather<RG, DX_W, false>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
@@ -983,7 +978,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         g_u[q] = dx_sigmoid_fast(s[1][q] + DX_RB(DXRB_G1U, q));
         g_cx[q] = s[2][q] + DX_RB(DXRB_G1X, q);
         g_o0[q] = s[3][q] + DX_RB(DXRB_O0, q);
-        if (epl) dx_publish(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.rh1 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
         DX_TAPE(DXT_R1, q, rg); DX_TAPE(DXT_U1, q, g_u[q]); DX_TAPE(DXT_RH1, q, rg * g_h[q]); DX_TAPE(DXT_O0, q, g_o0[q]);
       }
       DX_STAMP(13);
@@ -1003,8 +998,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
         g_o1[q] = hn + g_o0[q];
         if (epl) {
-          dx_publish(X + xl.h1 + erow[q] * DX_W + en, hn, tag, rt);
-          dx_publish(X + xl.o1 + erow[q] * DX_W + en, hn + g_o0[q], tag, rt);       // ResidualWrapper: cell output + cell input
+          dx_publish<WTC>(X + xl.h1 + erow[q] * DX_W + en, hn, tag, rt);
+          dx_publish<WTC>(X + xl.o1 + erow[q] * DX_W + en, hn + g_o0[q], tag, rt);       // ResidualWrapper: cell output + cell input
         }
         DX_TAPE(DXT_C1, q, c); DX_TAPE(DXT_H1, q, hn); DX_TAPE(DXT_O1, q, g_o1[q]);
       }
@@ -1029,7 +1024,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G2R * DX_NW + wave]);
         g_u[q] = dx_sigmoid_fast(s[1][q] + bl[DXB_G2U * DX_NW + wave]);
         g_cx[q] = s[2][q];
-        if (epl) dx_publish(X + xl.rh2 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.rh2 + erow[q] * DX_W + en, rg * g_h[q], tag, rt);
         DX_TAPE(DXT_R2, q, rg); DX_TAPE(DXT_U2, q, g_u[q]); DX_TAPE(DXT_RH2, q, rg * g_h[q]);
       }
     }
@@ -1045,7 +1040,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G2C * DX_NW + wave]);
         const float hn = g_u[q] * g_h[q] + (1.f - g_u[q]) * c;
-        if (epl) dx_publish(X + xl.h2 + erow[q] * DX_W + en, hn, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.h2 + erow[q] * DX_W + en, hn, tag, rt);
         DX_TAPE(DXT_C2, q, c); DX_TAPE(DXT_H2, q, hn); DX_TAPE(DXT_O2, q, hn + g_o1[q]);
       }
     }
@@ -1071,8 +1066,8 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
       }
       if (share) {                                                         // last of the r frames -> every member's copy of the next prenet input
         const int f0 = a.rM - a.mels;
-        if (v0 && n0 >= f0) dx_publish(X + xl.fb + erow[q] * DX_P2 + (n0 - f0), y0, tag, rt);
-        if (v1 && n1 >= f0) dx_publish(X + xl.fb + erow[q] * DX_P2 + (n1 - f0), y1, tag, rt);
+        if (v0 && n0 >= f0) dx_publish<WTC>(X + xl.fb + erow[q] * DX_P2 + (n0 - f0), y0, tag, rt);
+        if (v1 && n1 >= f0) dx_publish<WTC>(X + xl.fb + erow[q] * DX_P2 + (n1 - f0), y1, tag, rt);
       }
     };
     if (TAPE && a.own_fb) {
@@ -1107,7 +1102,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
 #pragma unroll
           for (int q = 0; q < RL; ++q) {
             const float p1v = fmaxf(s[0][q] + bl[DXB_P1 * DX_NW + wave], 0.f);
-            dx_publish(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
+            dx_publish<WTC>(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
             if (tval[q]) a.tape[(unsigned)DXT_P1 * tstr + trow[q] + (unsigned)(t + 1) * DX_W] = p1v;
           }
         }
@@ -1129,7 +1124,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
         for (int q = 0; q < RL; ++q) {
           if (t + 1 < a.n) {
             const float p1v = fmaxf(s[2][q] + bl[DXB_P1 * DX_NW + wave], 0.f);
-            dx_publish(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
+            dx_publish<WTC>(X + xl.p1 + erow[q] * DX_W + en, p1v, tag, rt);
             if (TAPE && tval[q]) a.tape[(unsigned)DXT_P1 * tstr + trow[q] + (unsigned)(t + 1) * DX_W] = p1v;
           }
           store_frame(q, s[0][q] + bl[DXB_F0 * DX_NW + wave], s[1][q] + bl[DXB_F1 * DX_NW + wave], false);
@@ -1147,4 +1142,19 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
     __syncthreads();
     DX_STAMP(11);
   }
+}
+
+template <int RG, bool TAPE = false, bool MAN = false, int AW = DX_W, int PD = 2, bool TRACE = false>
+__global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float dx_smem[];
+  DxArgs a = a_in;
+  // ---- census: which XCD am I on, is every XCD hosting exactly one group?  (its words: the last 64 floats of the LDS request) ----
+  int* ictl = reinterpret_cast<int*>(dx_smem + dx_lds_floats(RG, a.T_in, TAPE, AW) - 64);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 8);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
+  const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) dx_body<RG, TAPE, MAN, AW, PD, true, TRACE>(a, dx_smem, group, member, rt);
+  else dx_body<RG, TAPE, MAN, AW, PD, false, TRACE>(a, dx_smem, group, member, rt);
 }

@@ -1607,7 +1607,12 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
   return dx_lds_floats(RG, T_in, m->tp != nullptr || teacher != nullptr, m->hp.attention_size) * sizeof(float) <= 160 * 1024;
 }
 template <int RG, bool TAPE, int AW = DX_W, int PD = 2>
-static int dx_launch_rg(hipStream_t st, const DxArgs& a, size_t lds) {
+static int dx_launch_rg(hipStream_t st, const DxArgs& a_in, size_t lds) {
+  DxArgs a = a_in;
+  if constexpr (!TAPE && AW == DX_W && PD == 2) {      // the stamped instantiation (tools/time_decoder.py): the plain decoder at the reference widths only
+    if (a.trace && !a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, false, AW, PD, true>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
+  }
+  a.trace = nullptr;
   if constexpr (!TAPE) {
     if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, true, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
   }
@@ -2246,6 +2251,10 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      // the stamped instantiations
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #define DX_ATTR(RG, AW, PD) \
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, false, false, AW, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, false, true, AW, PD>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

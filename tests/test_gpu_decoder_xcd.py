@@ -397,7 +397,8 @@ def test_encoder_scan_fast_transcendentals_against_libm_and_the_oracle(B, T):
     """the encoder scan (H = 128) runs k_bigru_quad, whose sigmoid / tanh are rcp / exp2 approximations, where k_bigru_res
     (persist 3) calls libm's expf / tanhf; its outputs are the attention keys and values, i.e. they feed the alignment argmax.  Held here
     directly: k_bigru_quad vs k_bigru_res vs the float64 oracle over LONG ragged inputs (the error of a contractive recurrence does not
-    grow with T: the budget is a few ulp of the state, 2e-6 absolute on |h| < 1) and an initial state, bit-repeatable."""
+    grow with T; measured on MI355X: both kernels sit 5.9e-6 from float64 at T = 300 -- fp32 rounding of the recurrence itself -- and 2.4e-7 from EACH
+    OTHER: the budget for the approximations is 2e-6 absolute on |h| < 1) and an initial state, bit-repeatable."""
     import torch
     import taco_amd
     from util import dev, ptr, stream
@@ -427,10 +428,10 @@ def test_encoder_scan_fast_transcendentals_against_libm_and_the_oracle(B, T):
     assert np.array_equal(quad, got[1][1]), "k_bigru_quad is not bit-repeatable"
     e_q, e_r, d = maxabs(quad, ref), maxabs(res, ref), maxabs(quad, res)
     print("encoder scan, B=%d T=%d: k_bigru_quad vs oracle %.2e, k_bigru_res (libm) vs oracle %.2e, quad vs res %.2e" % (B, T, e_q, e_r, d))
-    assert e_q < 5e-6 and e_r < 5e-6 and d < 5e-6
+    assert e_q < 3e-5 and e_r < 3e-5 and d < 2e-6
     # the error does not accumulate along the recurrence: the last quarter of the longest row is no worse than the first
     L0 = int(lens[0])
-    assert maxabs(quad[0, 3 * L0 // 4:L0], ref[0, 3 * L0 // 4:L0]) < 5e-6
+    assert maxabs(quad[0, 3 * L0 // 4:L0], ref[0, 3 * L0 // 4:L0]) < 3e-5 and maxabs(quad[0, 3 * L0 // 4:L0], res[0, 3 * L0 // 4:L0]) < 2e-6
 
 
 def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
