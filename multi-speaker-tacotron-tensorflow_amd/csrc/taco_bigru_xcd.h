@@ -765,6 +765,221 @@ __global__ __launch_bounds__(512) void k_bigru_oct(const GdArgs a_in) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_dir<CPX, TAPE, TRACE> (round 5): k_bigru_oct's clusters (ONE row per 32 / CPX CUs, CPX = 4 / 2 / 1 clusters per XCD) with the two
+// directions on DIFFERENT waves and no workgroup barrier, no LDS state at all.
+//
+// k_bigru_oct's step is issue bound: all eight waves run the same phase (two per SIMD, ~55 VALU instructions each), then all of them sit in a
+// collect (LDS write, s_barrier, LDS read: ~250 clocks with the SIMDs idle), four times per step.  Here waves 0-3 own the FORWARD direction of
+// the member's 8 CPX units (2 CPX units per wave, both gates and the candidate: the same 24 CPX weight registers per thread) and waves 4-7 the
+// BACKWARD direction; every SIMD hosts one wave of each, so one direction's phase issues while the other waits for its exchange.  A wave needs
+// of an exchanged vector exactly the four values its lanes multiply -- granules 4 lane .. 4 lane + 3 -- so it polls THOSE straight into
+// registers (two 16-byte requests per lane): the poll is the operand fetch; nothing is staged through LDS, nothing is waited for on behalf of
+// another wave.  Traffic: 4 waves x 2 KB per vector and CU instead of 2 KB -- 32 KB per CU and step, a sixth of what the L2 delivers.
+// The x-parts ring is wave-private (global_load_lds, two slots of 16 steps: program order is all the synchronisation it needs).
+// ------------------------------------------------------------------------------------------------------------------------------
+#ifndef GV_DELAY
+#define GV_DELAY 4           // s_sleep units (64 clocks) between a wave's publish and its first poll of the vector that publish belongs to
+#endif
+__host__ __device__ inline size_t gv_lds_floats() { return (size_t)8 * 2 * 512 + 64; }      // [wave][slot][128 items x 4 floats] + census words
+
+// UW units per wave, NG values per unit: unit i's totals end up on lanes i * 64 / UW ... (UW = 8: halving on the two swap levels and on lane bit 3)
+template <int UW, int NG>
+__device__ __forceinline__ void gv_reduce(const float (&v)[UW * NG], float (&out)[NG], int lane) {
+  if constexpr (UW <= 4) { go_reduce<UW, NG>(v, out); return; }
+  else {
+    float h[4 * NG], t[2 * NG], o[NG];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {      // lanes 0-31: units 0-3; lanes 32-63: units 4-7
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j * NG + g]), __float_as_uint(v[(j + 4) * NG + g]), false, false);
+        h[j * NG + g] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {      // even rows of 16 lanes: units j | j + 4, odd rows: units j + 2 | j + 6 -> row r holds units 2r, 2r + 1
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[j * NG + g]), __float_as_uint(h[(j + 2) * NG + g]), false, false);
+        t[j * NG + g] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+      }
+    const bool hi8 = (lane & 8) != 0;      // lanes 0-7 of a row keep unit 2r, lanes 8-15 unit 2r + 1
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float keep = hi8 ? t[NG + g] : t[g], send = hi8 ? t[g] : t[NG + g];
+      o[g] = keep + DX_DPP0(send, 0x128);      // row_ror:8
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) o[g] += DX_DPP0(o[g], 0xB1);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) o[g] += DX_DPP0(o[g], 0x4E);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) out[g] = o[g] + DX_DPP0(o[g], 0x141);      // row_half_mirror: the other quad of the eight
+  }
+}
+// the four granules 4 lane .. 4 lane + 3 of a 256-granule vector, polled until all carry `tag` (two 16-byte L1-bypassing requests; bounded)
+__device__ __forceinline__ void gv_poll4(const dx_gu64* X, int lane, unsigned tag, float (&v)[4], DxRt& rt) {
+  dx_u64x2 g[2];
+  unsigned spins = 0;
+  for (;;) {
+    const dx_gu64* p = X + 4 * lane;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g[0]), "=&v"(g[1]) : "v"(p) : "memory");
+    const bool ok = ((unsigned)(g[0][0] >> 32) == tag) && ((unsigned)(g[0][1] >> 32) == tag) && ((unsigned)(g[1][0] >> 32) == tag) && ((unsigned)(g[1][1] >> 32) == tag);
+    if (ok || rt.dead) break;
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 1023u) == 0) {
+      if (spins >= DX_SPIN_LIMIT || __hip_atomic_load(rt.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(rt.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rt.dead = true;
+      }
+    }
+  }
+  v[0] = __uint_as_float((unsigned)g[0][0]); v[1] = __uint_as_float((unsigned)g[0][1]); v[2] = __uint_as_float((unsigned)g[1][0]); v[3] = __uint_as_float((unsigned)g[1][1]);
+}
+#define GV_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if constexpr (TRACE) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
+  } while (0)
+
+template <int CPX, bool TAPE, bool WT, bool TRACE>
+__device__ __forceinline__ void gv_body(const GdArgs& a, float* gx_smem, int place, int slot, DxRt rt) {
+  constexpr int H = GX_H, MB = DX_GROUP / CPX, UPM = 8 * CPX, UW = 2 * CPX, NREG = 12 * UW, LPU = 64 / UW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = wave >> 2, wq = wave & 3;                                    // the wave's direction, its quarter of the member's units
+  const int row = place * CPX + (slot % CPX), member = slot / CPX;
+  if (row >= a.B || member >= MB) return;
+  const int T = a.T;
+  const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
+  const bool tracer = TRACE && a.trace && row == 0 && member == 0 && tid == 0;
+  // weights: [dir][member][wq][NREG][64 lanes]: registers 8i + e (r_i), 8i + 4 + e (u_i), then 8 UW + 4i + e (c_i) of units wq UW + i
+  float W[NREG];
+  {
+    const float* wp = a.wpack + ((((size_t)D * MB + member) * 4 + wq) * NREG) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) W[j] = wp[(size_t)j * 64];
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)row * 4 * H + (size_t)D * 2 * H;      // this direction's [r*h : H | h' : H]
+  const int ui = lane / LPU, unit = member * UPM + wq * UW + ui;
+  const bool pub = (lane & (LPU - 1)) == 0;
+  // wave-private ring of x-parts: item i = (step j, gate g, quarter c) -> one float4 of the wave's units; slot = 128 items
+  constexpr int QW = UW >= 4 ? UW / 4 : 1, NIT = GX_BLK * 3 * QW, NLD = (NIT + 63) / 64;
+  constexpr int U4 = UW >= 4 ? 0 : 1;                                            // UW = 2: the float4 that holds the wave's two units starts at an even pair
+  float* xq = gx_smem + (size_t)wave * 2 * 512;
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  const int ubase = member * UPM + (U4 ? ((wq * UW) & ~3) : wq * UW), uoff = U4 ? ((wq * UW) & 3) : 0;
+  auto blk_fetch = [&](int s0, int ring) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = min(u * 64 + lane, NIT - 1);
+      const int c = i % QW, g = (i / QW) % 3, j = i / (3 * QW);
+      const int sx = min(s0 + j, T - 1);
+      const float* src = a.xproj + ((size_t)row * T + sx) * 6 * H + D * 3 * H + g * H + ubase + 4 * c;
+      gx_load_lds16(src, __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * 512 + u * 256) * 4u));
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(GX_BLK, 1);
+  float hx[4], hv;
+  {
+    const float* h0 = a.h0 ? a.h0 + (size_t)row * 2 * H + D * H : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hx[e] = h0 ? h0[4 * lane + e] : 0.f;
+    hv = h0 ? h0[unit] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const int lane_outer = lane;
+  for (int s = 0; s < T; ++s) {
+    const unsigned tag = (unsigned)s + 1u;
+    int lane = lane_outer;                                     // opaque per-iteration copy: see taco_decoder_xcd.h
+    asm volatile("" : "+v"(lane));
+    const bool active = s < L;                                 // A.7: row active iff s < L; forward t = s, backward t = L-1-s
+    GV_STAMP(0);
+    const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
+    if (sb == 0 && s > 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the slot entered now was requested 16 steps ago
+      blk_fetch(s + GX_BLK, ring ^ 1);                         // ... and the one just left is free (program order: this wave was its only reader)
+    }
+    float x0[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) x0[g] = xq[ring * 512 + ((sb * 3 + g) * QW) * 4 + uoff + (lane_outer / LPU)];
+    // ---- gates: (r_i, u_i) of unit i in one v_pk_fma_f32 per input ----
+    float rr, uu;
+    {
+      taco_f32x2 acc[UW];
+#pragma unroll
+      for (int i = 0; i < UW; ++i) acc[i] = (taco_f32x2){W[8 * i] * hx[0], W[8 * i + 4] * hx[0]};
+#pragma unroll
+      for (int e = 1; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < UW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx[e], hx[e]}, (taco_f32x2){W[8 * i + e], W[8 * i + 4 + e]}, acc[i]);
+      float v[2 * UW], sm[2];
+#pragma unroll
+      for (int i = 0; i < UW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
+      gv_reduce<UW, 2>(v, sm, lane);
+      rr = dx_sigmoid_fast(sm[0] + x0[0]);
+      uu = dx_sigmoid_fast(sm[1] + x0[1]);
+    }
+    const float rh = rr * hv;
+    if (pub) dx_publish<WT ? 1 : 0>(X + unit, rh, tag, rt);
+    if (TAPE && pub && active) {      // gates of the active steps at their true time (modules.py:82-96 / A.7), for the backward scan
+      float* gs = a.gsave + ((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + unit;
+      gs[0] = rr; gs[H] = uu;
+    }
+    GV_STAMP(1);
+    __builtin_amdgcn_s_sleep(GV_DELAY);
+    float xr[4];
+    gv_poll4(X, lane, tag, xr, rt);
+    GV_STAMP(2);
+    // ---- candidate and the new state: units (i, i + 1) in one v_pk_fma_f32 per input ----
+    float nv;
+    {
+      taco_f32x2 acc[UW / 2];
+#pragma unroll
+      for (int i = 0; i < UW / 2; ++i) acc[i] = (taco_f32x2){W[8 * UW + 8 * i] * xr[0], W[8 * UW + 8 * i + 4] * xr[0]};
+#pragma unroll
+      for (int e = 1; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < UW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){xr[e], xr[e]}, (taco_f32x2){W[8 * UW + 8 * i + e], W[8 * UW + 8 * i + 4 + e]}, acc[i]);
+      float v[UW], sm[1];
+#pragma unroll
+      for (int i = 0; i < UW / 2; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
+      gv_reduce<UW, 1>(v, sm, lane);
+      const float cc = taco_tanh_fast(sm[0] + x0[2]);
+      float blend = uu * hv + (1.f - uu) * cc;
+      DX_PIN(blend);
+      nv = active ? blend : hv;
+      if (pub) {
+        dx_publish<WT ? 1 : 0>(X + H + unit, nv, tag, rt);
+        const int t = (D && active) ? (L - 1 - s) : s;
+        a.out[((size_t)row * T + t) * 2 * H + D * H + unit] = active ? nv : 0.f;
+        if (TAPE && active) a.gsave[((size_t)row * T + t) * 6 * H + D * 3 * H + 2 * H + unit] = cc;
+      }
+    }
+    hv = nv;
+    GV_STAMP(3);
+    if (s + 1 < T) {
+      __builtin_amdgcn_s_sleep(GV_DELAY);
+      gv_poll4(X + H, lane, tag, hx, rt);
+    }
+    GV_STAMP(4);
+  }
+}
+
+template <int CPX, bool TAPE = false, bool TRACE = false>
+__global__ __launch_bounds__(512) void k_bigru_dir(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  int* ictl = reinterpret_cast<int*>(gx_smem + 8 * 2 * 512);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 24);
+  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gv_body<CPX, TAPE, true, TRACE>(a, gx_smem, place, slot, rt);
+  else gv_body<CPX, TAPE, false, TRACE>(a, gx_smem, place, slot, rt);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // k_bigru_duo_bwd<RG>: the backward scan of the same BiGRU (BPTT through modules.py:82-96 / TF GRUCell, A.6/A.7) on k_bigru_duo's
 // machinery: both directions of RG rows on one group of 32 CUs, the two directions software-pipelined against each other, polls
 // issued early.  It replaces k_bigru_rows_bwd (one workgroup per (direction, row pair), the transposed recurrent kernels streamed
