@@ -315,6 +315,187 @@ __device__ __forceinline__ void dx_reduce(const float (&a)[NC][RG], float (&out)
     for (int q = 0; q < RL; ++q) out[c][q] = dx_xrow32(d[c][q]);
 }
 
+// ---- round 5: the step's VALU diet (the passes and reductions of k_decoder_xcd are issue bound: two waves per SIMD, ~130 instructions
+// each per gates stage) ----
+#ifndef DX_DIET
+#define DX_DIET 1            // A/B: 0 = the scalar passes and the select-based reduction of rounds 2-4
+#endif
+// Column PAIRS in one v_pk_fma_f32 per input: the input broadcast to both halves (op_sel), the two columns' weights of that input side by
+// side.  The resident weights ARE register pairs (taco_f32x2 WP[DX_NREG / 2], loaded once in the order the passes consume them; an array of
+// scalars left the pairing to the allocator, which parked 40 of them in scratch): pair k of a pass that starts at register REG0 is
+// WP[REG0 / 2 + ...] -- every DXR_* base is even and every pass owns an even number of registers.  Accumulators of paired columns are pairs
+// from the start; single columns stay scalar (pairing their even / odd inputs costs the adds it saves).
+//   single column (4 registers r0..r3):             WP[k] = (r0, r1), WP[k + 1] = (r2, r3)
+//   two columns (8 registers, c0: +e, c1: +4+e):    WP[k + e] = (c0_e, c1_e)
+//   AGX, 3 columns x 2 inputs (PD = 2):             WP[6] = (c0_0, c1_0), WP[7] = (c0_1, c1_1), WP[8] = (c2_0, c2_1)
+//   AGX, 3 columns x 1 input + prenet 3 (PD = 3):   WP[6] = (c0, c1), WP[7] = (c2, p3_0), WP[8] = (p3_1, -)
+#define DX_NWP (DX_NREG / 2)
+__host__ __device__ constexpr int dxw_two(int base, int r, int h) { return base + (r - base) / 2 + 4 * h; }      // pair e of a two-column block: (base + e, base + 4 + e)
+__host__ __device__ constexpr int dxw_src(int k, int h, int PD) {      // pack register that half h of pair k holds
+  const int r = 2 * k;
+  if (r >= DXR_AGH && r < DXR_AGX) return dxw_two(DXR_AGH, r, h);
+  if (r >= DXR_AGX && r < DXR_AC) return PD == 3 ? r + h : (r < DXR_AGX + 4 ? DXR_AGX + (r - DXR_AGX) / 2 + 2 * h : r + h);
+  if (r >= DXR_G1H && r < DXR_G1A) return dxw_two(DXR_G1H, r, h);
+  if (r >= DXR_G1A && r < DXR_G1C) return dxw_two(DXR_G1A + 8 * ((r - DXR_G1A) / 8), r, h);      // G1A, G1B: two two-column blocks each
+  if (r >= DXR_G2H && r < DXR_G2X) return dxw_two(DXR_G2H, r, h);
+  if (r >= DXR_G2X && r < DXR_G2X + 8) return dxw_two(DXR_G2X, r, h);
+  if (r >= DXR_F) return dxw_two(DXR_F, r, h);
+  return r + h;                                                         // single columns: P2, AC, G1C, the third column of G2X, G2C, P1C, P1O
+}
+#define DXQ_FMA(acc, xs, wp) \
+  do { if (DX_DIET) acc = __builtin_elementwise_fma((taco_f32x2){xs, xs}, wp, acc); else { acc.x = fmaf((wp).x, xs, acc.x); acc.y = fmaf((wp).y, xs, acc.y); } } while (0)
+template <int RG>
+__device__ __forceinline__ void dxq_zero(taco_f32x2 (&acc)[RG]) {
+#pragma unroll
+  for (int r = 0; r < RG; ++r) acc[r] = (taco_f32x2){0.f, 0.f};
+}
+// one column over a 256-wide input
+template <int REG0, int RG, int LD = DXS_LD>
+__device__ __forceinline__ void dxw_single(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, float (&acc)[1][RG]) {
+  constexpr int k = REG0 / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
+    acc[0][r] = fmaf(WP[k].x, xv.x, acc[0][r]); acc[0][r] = fmaf(WP[k].y, xv.y, acc[0][r]);
+    acc[0][r] = fmaf(WP[k + 1].x, xv.z, acc[0][r]); acc[0][r] = fmaf(WP[k + 1].y, xv.w, acc[0][r]);
+  }
+}
+// two columns over a 256-wide input
+template <int REG0, int RG, int LD = DXS_LD>
+__device__ __forceinline__ void dxw_pair(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, taco_f32x2 (&acc)[RG]) {
+  constexpr int k = REG0 / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
+    DXQ_FMA(acc[r], xv.x, WP[k]); DXQ_FMA(acc[r], xv.y, WP[k + 1]); DXQ_FMA(acc[r], xv.z, WP[k + 2]); DXQ_FMA(acc[r], xv.w, WP[k + 3]);
+  }
+}
+// four columns = two pairs, one read of the input
+template <int REG0, int RG, int LD = DXS_LD>
+__device__ __forceinline__ void dxw_quad(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, taco_f32x2 (&p0)[RG], taco_f32x2 (&p1)[RG]) {
+  constexpr int k = REG0 / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
+    DXQ_FMA(p0[r], xv.x, WP[k]); DXQ_FMA(p1[r], xv.x, WP[k + 4]);
+    DXQ_FMA(p0[r], xv.y, WP[k + 1]); DXQ_FMA(p1[r], xv.y, WP[k + 5]);
+    DXQ_FMA(p0[r], xv.z, WP[k + 2]); DXQ_FMA(p1[r], xv.z, WP[k + 6]);
+    DXQ_FMA(p0[r], xv.w, WP[k + 3]); DXQ_FMA(p1[r], xv.w, WP[k + 7]);
+  }
+}
+// a pair (REGP ..) and a single column (REGS ..) over the same 256-wide input
+template <int REGP, int REGS, int RG, int LD = DXS_LD>
+__device__ __forceinline__ void dxw_pair_single(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, taco_f32x2 (&p)[RG], float (&sg)[1][RG]) {
+  constexpr int k = REGP / 2, ks = REGS / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float4 xv = *reinterpret_cast<const float4*>(x + r * LD + 4 * lane);
+    DXQ_FMA(p[r], xv.x, WP[k]); sg[0][r] = fmaf(WP[ks].x, xv.x, sg[0][r]);
+    DXQ_FMA(p[r], xv.y, WP[k + 1]); sg[0][r] = fmaf(WP[ks].y, xv.y, sg[0][r]);
+    DXQ_FMA(p[r], xv.z, WP[k + 2]); sg[0][r] = fmaf(WP[ks + 1].x, xv.z, sg[0][r]);
+    DXQ_FMA(p[r], xv.w, WP[k + 3]); sg[0][r] = fmaf(WP[ks + 1].y, xv.w, sg[0][r]);
+  }
+}
+// attention GRU x rows, PD = 2: the 128-wide input (two inputs per lane), pair (r, u) and the candidate-x column
+template <int RG>
+__device__ __forceinline__ void dxw_agx2(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, taco_f32x2 (&p)[RG], float (&sg)[1][RG]) {
+  constexpr int k = DXR_AGX / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float2 xv = *reinterpret_cast<const float2*>(x + r * DXS_LD + 2 * lane);
+    DXQ_FMA(p[r], xv.x, WP[k]); sg[0][r] = fmaf(WP[k + 2].x, xv.x, sg[0][r]);
+    DXQ_FMA(p[r], xv.y, WP[k + 1]); sg[0][r] = fmaf(WP[k + 2].y, xv.y, sg[0][r]);
+  }
+}
+// ... PD = 3: the 64-wide input (one input per lane)
+template <int RG>
+__device__ __forceinline__ void dxw_agx1(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, taco_f32x2 (&p)[RG], float (&sg)[1][RG]) {
+  constexpr int k = DXR_AGX / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float xv = x[r * DXS_LD + lane];
+    DXQ_FMA(p[r], xv, WP[k]); sg[0][r] = fmaf(WP[k + 1].x, xv, sg[0][r]);
+  }
+}
+// prenet layer 3 (PD = 3): one column over the 128-wide prenet-2 output, registers DXR_AGX + 3, + 4
+template <int RG>
+__device__ __forceinline__ void dxw_p3(const taco_f32x2 (&WP)[DX_NWP], const float* x, int lane, float (&acc)[1][RG]) {
+  constexpr int k = DXR_AGX / 2;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const float2 xv = *reinterpret_cast<const float2*>(x + r * DXS_LD + 2 * lane);
+    acc[0][r] = fmaf(WP[k + 1].y, xv.x, acc[0][r]); acc[0][r] = fmaf(WP[k + 2].x, xv.y, acc[0][r]);
+  }
+}
+// Wave reduction of NC columns x RG rows with the ROWS dealt to the lanes by permlane swaps: a swap hands the partner the half of the rows
+// it keeps and one add finishes the level -- no selects, no DPP on the two halving levels --, then four DPP adds inside the row of 16 lanes.
+// Row(s) of a lane: dxs_row; every lane of a 16-lane row ends with the totals, its first lane (dxs_epl) publishes.  10 instructions per
+// column at four rows (dx_reduce: 15).
+template <int RG>
+__device__ __forceinline__ int dxs_row(int lane, int q) {
+  if (!DX_DIET) return dx_row<RG>(lane & 3, q);
+  if (RG >= 8) return ((lane >> 4) & 1) * (RG / 4) + (lane >> 5) * (RG / 2) + q;
+  if (RG == 4) return lane >> 4;
+  if (RG == 2) return lane >> 5;
+  return 0;
+}
+template <int RG>
+__device__ __forceinline__ bool dxs_epl(int lane) {
+  if (!DX_DIET) return lane < (RG >= 4 ? 4 : RG);
+  return RG >= 4 ? (lane & 15) == 0 : RG == 2 ? (lane & 31) == 0 : lane == 0;
+}
+template <int NC, int RG>
+__device__ __forceinline__ void dxs_reduce(const float (&a)[NC][RG], float (&out)[NC][DxRL<RG>::value], int lane) {
+  if constexpr (!DX_DIET) { dx_reduce<NC, RG>(a, out, lane); return; }
+  else {
+    constexpr int RL = DxRL<RG>::value;
+    float d[NC][RL];
+    if constexpr (RG >= 4) {
+      constexpr int Hh = RG / 2, Q = RG / 4;
+      float b[NC][Hh];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int p = 0; p < Hh; ++p) {        // lanes 0-31 keep rows 0 .. RG/2-1, lanes 32-63 rows RG/2 ..
+          auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c][p]), __float_as_uint(a[c][Hh + p]), false, false);
+          b[c][p] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {         // even rows of 16 lanes keep the first half of those, odd rows the second
+          auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(b[c][q]), __float_as_uint(b[c][Q + q]), false, false);
+          d[c][q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+    } else if constexpr (RG == 2) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[c][0]), __float_as_uint(a[c][1]), false, false);
+        d[c][0] = dx_xrow16(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) d[c][0] = dx_xrow16(dx_xrow32(a[c][0]));
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < RL; ++q) d[c][q] += DX_DPP0(d[c][q], 0xB1);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < RL; ++q) d[c][q] += DX_DPP0(d[c][q], 0x4E);      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < RL; ++q) d[c][q] += DX_DPP0(d[c][q], 0x141);     // row_half_mirror
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int q = 0; q < RL; ++q) out[c][q] = d[c][q] + DX_DPP0(d[c][q], 0x140);      // row_mirror
+  }
+}
+
 struct DxRt {     // run-time state of a thread
   dx_gu32* err; bool wt; bool dead;
 };
@@ -616,22 +797,24 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
   const bool tracer = TRACE && a.trace && ga == 0 && member == 0 && tid == 0;
 
   // ---- weights, resident for the whole loop ----
-  float W[DX_NREG];
+  taco_f32x2 WP[DX_NWP];      // register pairs in the order the passes consume them (dxw_src)
   {
     const float* wp = a.wpack + ((size_t)member * DX_NREG) * DX_NT + tid;
 #pragma unroll
-    for (int j = 0; j < DX_NREG; ++j) W[j] = wp[(size_t)j * DX_NT];
+    for (int k = 0; k < DX_NWP; ++k) WP[k] = (taco_f32x2){wp[(size_t)dxw_src(k, 0, PD) * DX_NT], wp[(size_t)dxw_src(k, 1, PD) * DX_NT]};
   }
   if (TAPE && a.p1o_raw) {
     const float* wp = a.p1o_raw + ((size_t)member * 4) * DX_NT + tid;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) W[DXR_P1O + j] = wp[(size_t)j * DX_NT];
+    WP[DXR_P1O / 2] = (taco_f32x2){wp[0], wp[(size_t)DX_NT]};
+    WP[DXR_P1O / 2 + 1] = (taco_f32x2){wp[(size_t)2 * DX_NT], wp[(size_t)3 * DX_NT]};
   }
-  float WQ[QR];     // query layer: columns cb*DS + wave*QC + i, inputs 4*lane..4*lane+3
+  taco_f32x2 WQP[QR / 2];     // query layer: columns cb*DS + wave*QC + i, inputs 4*lane..4*lane+3; pair 4j + e = columns (2j, 2j + 1), input e
   {
     const float* wp = a.qpack + ((size_t)member * QR) * DX_NT + tid;
 #pragma unroll
-    for (int j = 0; j < QR; ++j) WQ[j] = wp[(size_t)j * DX_NT];
+    for (int j = 0; j < QC / 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) WQP[4 * j + e] = (taco_f32x2){wp[(size_t)(8 * j + e) * DX_NT], wp[(size_t)(8 * j + 4 + e) * DX_NT]};
   }
   const DxX xl = dx_xlayout(RG, T);
   dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)ga * xl.total;
@@ -714,11 +897,11 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
 
   // epilogue role: the lanes of quad 0 own the outputs (rows dx_row(lane, q), column 8*member + wave) of every 256-wide stage
   constexpr int RL = DxRL<RG>::value;
-  const bool epl = lane < (RG >= 4 ? 4 : RG);
+  const bool epl = dxs_epl<RG>(lane);
   const int en = member * 8 + wave;
   int erow[RL];
 #pragma unroll
-  for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
+  for (int q = 0; q < RL; ++q) erow[q] = dxs_row<RG>(lane, q);
 #define DX_RB(slot, q) rbl[((slot) * RG + erow[q]) * DX_NW + wave]
   float g_u[RL], g_cx[RL], g_h[RL], g_o0[RL];            // live between the two stages of a GRU cell
   // tape (TAPE): the lane that owns (row, column) of a stage writes it; trow = float offset of step 0 of the lane's row in a [B, n, 256] array
@@ -750,7 +933,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     asm volatile("" : "+v"(tid), "+v"(lane));
     int erow[RL];                  // (recomputed from the opaque lane: addresses derived from it -- mel / stop-flag / tape rows -- stay out of the hoisted set)
 #pragma unroll
-    for (int q = 0; q < RL; ++q) erow[q] = dx_row<RG>(lane & 3, q);
+    for (int q = 0; q < RL; ++q) erow[q] = dxs_row<RG>(lane, q);
     DX_STAMP(0);
     if (man) {   // this step's manual alignments of the member's row -> LDS (consumed three exchanges from now)
       const float* src = a.manual + ((size_t)min(brow, a.B - 1) * a.n + t) * T;
@@ -766,8 +949,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     if (wave < 4) {
       float acc[1][RG], s[1][RL];
       dx_zero<1, RG>(acc);
-      dx_pass<DXR_P2, 1, RG>(W, st + DXS_T, lane, acc);
-      dx_reduce<1, RG>(acc, s, lane);
+      dxw_single<DXR_P2, RG>(WP, st + DXS_T, lane, acc);
+      dxs_reduce<1, RG>(acc, s, lane);
       if (epl) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
@@ -779,9 +962,11 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     }
 #pragma unroll
     for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_HATT + en];
-    float aga[3][RG];          // attention GRU: r, u, candidate-x; the h rows run ahead of the prenet output
-    dx_zero<3, RG>(aga);
-    dx_pass<DXR_AGH, 2, RG>(W, st + DXS_HATT, lane, reinterpret_cast<float (&)[2][RG]>(aga));
+    taco_f32x2 ag01[RG];       // attention GRU: (r, u) as a pair, candidate-x; the h rows run ahead of the prenet output
+    float ag2[1][RG];
+    dxq_zero<RG>(ag01);
+    dx_zero<1, RG>(ag2);
+    dxw_pair<DXR_AGH, RG>(WP, st + DXS_HATT, lane, ag01);
     dx_gather<RG, DX_P2, false>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
     __syncthreads();
     if constexpr (PD == 3) {
@@ -789,8 +974,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       if (wave < 2) {
         float acc[1][RG], s[1][RL];
         dx_zero<1, RG>(acc);
-        dx_pass2<DXR_AGX + 3, 1, RG>(W, st + DXS_P2, lane, acc);
-        dx_reduce<1, RG>(acc, s, lane);
+        dxw_p3<RG>(WP, st + DXS_P2, lane, acc);
+        dxs_reduce<1, RG>(acc, s, lane);
         if (epl) {
 #pragma unroll
           for (int q = 0; q < RL; ++q)
@@ -804,9 +989,12 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     // ================= attention GRUCell (tacotron.py:127-130; A.6): gates, then candidate =================
     {
       float s[3][RL];
-      if constexpr (PD == 3) dx_pass1<DXR_AGX, 3, RG>(W, st + DXS_OUT2, lane, aga);
-      else dx_pass2<DXR_AGX, 3, RG>(W, st + DXS_P2, lane, aga);
-      dx_reduce<3, RG>(aga, s, lane);
+      if constexpr (PD == 3) dxw_agx1<RG>(WP, st + DXS_OUT2, lane, ag01, ag2);
+      else dxw_agx2<RG>(WP, st + DXS_P2, lane, ag01, ag2);
+      float aga[3][RG];
+#pragma unroll
+      for (int r = 0; r < RG; ++r) { aga[0][r] = ag01[r].x; aga[1][r] = ag01[r].y; aga[2][r] = ag2[0][r]; }
+      dxs_reduce<3, RG>(aga, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float rg = dx_sigmoid_fast(s[0][q] + DX_RB(DXRB_AR, q));
@@ -822,8 +1010,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     {
       float acc[1][RG], s[1][RL];
       dx_zero<1, RG>(acc);
-      dx_pass<DXR_AC, 1, RG>(W, st + DXS_T, lane, acc);
-      dx_reduce<1, RG>(acc, s, lane);
+      dxw_single<DXR_AC, RG>(WP, st + DXS_T, lane, acc);
+      dxs_reduce<1, RG>(acc, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_AC * DX_NW + wave]);
@@ -842,13 +1030,14 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       {  // query for the member's own score channels of its row: columns cb*DS + wave*QC + i
         const float4 xv = *reinterpret_cast<const float4*>(st + arow * DXS_LD + DXS_HATT + 4 * lane);
         float qa[QC][1], qs[QC][1];
+        static_assert(QC % 2 == 0, "query columns in pairs");
 #pragma unroll
-        for (int i = 0; i < QC; ++i) {
-          float q = WQ[4 * i] * xv.x;
-          q = fmaf(WQ[4 * i + 1], xv.y, q); q = fmaf(WQ[4 * i + 2], xv.z, q); q = fmaf(WQ[4 * i + 3], xv.w, q);
-          qa[i][0] = q;
+        for (int i = 0; i < QC; i += 2) {        // columns (i, i + 1) in one v_pk_fma_f32 per input
+          taco_f32x2 q2 = {0.f, 0.f};
+          DXQ_FMA(q2, xv.x, WQP[2 * i + 0]); DXQ_FMA(q2, xv.y, WQP[2 * i + 1]); DXQ_FMA(q2, xv.z, WQP[2 * i + 2]); DXQ_FMA(q2, xv.w, WQP[2 * i + 3]);
+          qa[i][0] = q2.x; qa[i + 1][0] = q2.y;
         }
-        dx_reduce<QC, 1>(qa, qs, lane);
+        dxs_reduce<QC, 1>(qa, qs, lane);
         float qme = qs[0][0];
 #pragma unroll
         for (int i = 1; i < QC; ++i) qme = (lane >= i) ? qs[i][0] : qme;
@@ -892,11 +1081,11 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     // With eight rows per group the 32 accumulators would have to live across the whole attention phase next to 138 resident weights:
     // there they are formed after the context has arrived instead (two more passes on the critical path, no spilled registers).
     constexpr bool G1_AHEAD = RG < 8;
-    float g1a[4][RG];
-    dx_zero<4, RG>(g1a);
+    taco_f32x2 g1p0[RG], g1p1[RG];      // (r, u) and (candidate-x, o0)
+    dxq_zero<RG>(g1p0); dxq_zero<RG>(g1p1);
     if (G1_AHEAD) {
-      dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
-      dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+      dxw_pair<DXR_G1H, RG>(WP, st + DXS_H1, lane, g1p0);
+      dxw_quad<DXR_G1A, RG>(WP, st + DXS_HATT, lane, g1p0, g1p1);
     }
     int aoff = 0;                  // the step's alignments are sc[aoff + j]: computed (sc itself) or manual (mrow, a region of the same LDS array)
     if (!man) {
@@ -965,12 +1154,15 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     {
       float s[4][RL];
       if (!G1_AHEAD) {
-        dx_zero<4, RG>(g1a);
-        dx_pass<DXR_G1H, 2, RG>(W, st + DXS_H1, lane, reinterpret_cast<float (&)[2][RG]>(g1a));
-        dx_pass<DXR_G1A, 4, RG>(W, st + DXS_HATT, lane, g1a);
+        dxq_zero<RG>(g1p0); dxq_zero<RG>(g1p1);
+        dxw_pair<DXR_G1H, RG>(WP, st + DXS_H1, lane, g1p0);
+        dxw_quad<DXR_G1A, RG>(WP, st + DXS_HATT, lane, g1p0, g1p1);
       }
-      dx_pass<DXR_G1B, 4, RG>(W, st + DXS_CTX, lane, g1a);
-      dx_reduce<4, RG>(g1a, s, lane);
+      dxw_quad<DXR_G1B, RG>(WP, st + DXS_CTX, lane, g1p0, g1p1);
+      float g1a[4][RG];
+#pragma unroll
+      for (int r = 0; r < RG; ++r) { g1a[0][r] = g1p0[r].x; g1a[1][r] = g1p0[r].y; g1a[2][r] = g1p1[r].x; g1a[3][r] = g1p1[r].y; }
+      dxs_reduce<4, RG>(g1a, s, lane);
       DX_STAMP(12);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
@@ -990,8 +1182,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     {
       float acc[1][RG], s[1][RL];
       dx_zero<1, RG>(acc);
-      dx_pass<DXR_G1C, 1, RG>(W, st + DXS_T, lane, acc);
-      dx_reduce<1, RG>(acc, s, lane);
+      dxw_single<DXR_G1C, RG>(WP, st + DXS_T, lane, acc);
+      dxs_reduce<1, RG>(acc, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G1C * DX_NW + wave]);
@@ -1006,9 +1198,11 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     }
 #pragma unroll
     for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H2 + en];
-    float g2a[3][RG];          // GRU 2: r, u, candidate-x; the h2 rows run ahead of GRU 1's output (not at eight rows per group: registers)
-    dx_zero<3, RG>(g2a);
-    if (G1_AHEAD) dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
+    taco_f32x2 g2p[RG];        // GRU 2: (r, u) as a pair, candidate-x; the h2 rows run ahead of GRU 1's output (not at eight rows per group: registers)
+    float g2c[1][RG];
+    dxq_zero<RG>(g2p);
+    dx_zero<1, RG>(g2c);
+    if (G1_AHEAD) dxw_pair<DXR_G2H, RG>(WP, st + DXS_H2, lane, g2p);
     dx_gather<RG, DX_W, false>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
     dx_gather<RG, DX_W, false>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
     __syncthreads();
@@ -1016,9 +1210,12 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     // ================= residual GRU 2 =================
     {
       float s[3][RL];
-      if (!G1_AHEAD) dx_pass<DXR_G2H, 2, RG>(W, st + DXS_H2, lane, reinterpret_cast<float (&)[2][RG]>(g2a));
-      dx_pass<DXR_G2X, 3, RG>(W, st + DXS_OUT1, lane, g2a);
-      dx_reduce<3, RG>(g2a, s, lane);
+      if (!G1_AHEAD) dxw_pair<DXR_G2H, RG>(WP, st + DXS_H2, lane, g2p);
+      dxw_pair_single<DXR_G2X, DXR_G2X + 8, RG>(WP, st + DXS_OUT1, lane, g2p, g2c);
+      float g2a[3][RG];
+#pragma unroll
+      for (int r = 0; r < RG; ++r) { g2a[0][r] = g2p[r].x; g2a[1][r] = g2p[r].y; g2a[2][r] = g2c[0][r]; }
+      dxs_reduce<3, RG>(g2a, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float rg = dx_sigmoid_fast(s[0][q] + bl[DXB_G2R * DX_NW + wave]);
@@ -1034,8 +1231,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     {
       float acc[1][RG], s[1][RL];
       dx_zero<1, RG>(acc);
-      dx_pass<DXR_G2C, 1, RG>(W, st + DXS_T, lane, acc);
-      dx_reduce<1, RG>(acc, s, lane);
+      dxw_single<DXR_G2C, RG>(WP, st + DXS_T, lane, acc);
+      dxs_reduce<1, RG>(acc, s, lane);
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float c = taco_tanh_fast(g_cx[q] + s[0][q] + bl[DXB_G2C * DX_NW + wave]);
@@ -1047,7 +1244,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     // ahead of its turn: next step's prenet layer 1, context rows
     float p1a[1][RG];
     dx_zero<1, RG>(p1a);
-    if (G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, p1a);
+    if (G1_AHEAD) dxw_single<DXR_P1C, RG>(WP, st + DXS_CTX, lane, p1a);
     dx_gather<RG, DX_W, true>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
     __syncthreads();
     DX_STAMP(10);
@@ -1073,10 +1270,13 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     if (TAPE && a.own_fb) {
       // rnn_decoder_test_mode: the frame first (its own stage and exchange), then the prenet layer over it
       {
+        taco_f32x2 fp[RG];
         float fa[2][RG], s[2][RL];
-        dx_zero<2, RG>(fa);
-        dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, fa);
-        dx_reduce<2, RG>(fa, s, lane);
+        dxq_zero<RG>(fp);
+        dxw_pair<DXR_F, RG>(WP, st + DXS_OUT2, lane, fp);
+#pragma unroll
+        for (int r = 0; r < RG; ++r) { fa[0][r] = fp[r].x; fa[1][r] = fp[r].y; }
+        dxs_reduce<2, RG>(fa, s, lane);
         if (epl) {
 #pragma unroll
           for (int q = 0; q < RL; ++q) store_frame(q, s[0][q] + bl[DXB_F0 * DX_NW + wave], s[1][q] + bl[DXB_F1 * DX_NW + wave], t + 1 < a.n);
@@ -1095,9 +1295,9 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         float pa[1][RG], s[1][RL];
 #pragma unroll
         for (int r = 0; r < RG; ++r) pa[0][r] = p1a[0][r];
-        if (!G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, pa);
-        dx_pass<DXR_P1O, 1, RG, DX_NREG, DX_W>(W, tfb, lane, pa);
-        dx_reduce<1, RG>(pa, s, lane);
+        if (!G1_AHEAD) dxw_single<DXR_P1C, RG>(WP, st + DXS_CTX, lane, pa);
+        dxw_single<DXR_P1O, RG, DX_W>(WP, tfb, lane, pa);
+        dxs_reduce<1, RG>(pa, s, lane);
         if (epl && t + 1 < a.n) {
 #pragma unroll
           for (int q = 0; q < RL; ++q) {
@@ -1108,17 +1308,19 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         }
       }
     } else {
-      float fa[3][RG], s[3][RL];
-      dx_zero<3, RG>(fa);
+      taco_f32x2 fp[RG];       // the frame projection's two columns as a pair
+      float f2[1][RG], fa[3][RG], s[3][RL];
+      dxq_zero<RG>(fp);
 #pragma unroll
-      for (int r = 0; r < RG; ++r) fa[2][r] = p1a[0][r];
-      if (!G1_AHEAD) dx_pass<DXR_P1C, 1, RG>(W, st + DXS_CTX, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
-      dx_pass<DXR_F, 2, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[2][RG]>(fa));
+      for (int r = 0; r < RG; ++r) f2[0][r] = p1a[0][r];
+      if (!G1_AHEAD) dxw_single<DXR_P1C, RG>(WP, st + DXS_CTX, lane, f2);
       // prenet layer 1 of the next step: from this step's own output (frame projection folded into the registers), or -- teacher
       // forcing -- from the teacher's frame (raw kernel rows in the same registers, zero beyond num_mels)
-      if (TAPE) dx_pass<DXR_P1O, 1, RG, DX_NREG, DX_W>(W, tfb, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
-      else dx_pass<DXR_P1O, 1, RG>(W, st + DXS_OUT2, lane, reinterpret_cast<float (&)[1][RG]>(fa[2]));
-      dx_reduce<3, RG>(fa, s, lane);
+      if (TAPE) { dxw_pair<DXR_F, RG>(WP, st + DXS_OUT2, lane, fp); dxw_single<DXR_P1O, RG, DX_W>(WP, tfb, lane, f2); }
+      else dxw_pair_single<DXR_F, DXR_P1O, RG>(WP, st + DXS_OUT2, lane, fp, f2);
+#pragma unroll
+      for (int r = 0; r < RG; ++r) { fa[0][r] = fp[r].x; fa[1][r] = fp[r].y; fa[2][r] = f2[0][r]; }
+      dxs_reduce<3, RG>(fa, s, lane);
       if (epl) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {

@@ -260,12 +260,19 @@ def test_gradients_at_full_reference_widths(B, T_in, T_out):
     assert worst[0][0] < tol, worst[:5]
     # the relaxed bound above must not hide what this parametrisation exists for.  The conv taps' gradients -- every
     # [k, cin, cout] kernel of both CBHGs, the tensors the batch-row-boundary bug moved by 2-6 % -- are sums over all B * T frames: one
-    # flipped L1 sign or one near-tie moves them by ~1 / (B T) of their scale, so they keep a TIGHT bound (1e-2: a fifth of the relaxed one, below the bug's 2-6 %) whatever `flips` is, for
-    # both weight-gradient kernels (the exact-fp32 one below).
-    conv_taps = lambda rep: [x for x in rep if ("/conv_bank/" in x[1] or "/proj_" in x[1]) and x[1].endswith("/kernel")]
-    assert len(conv_taps(worst)) == 16 + 8 + 4
-    print("conv-tap gradients vs float64 autograd, worst three:", conv_taps(worst)[:3])
-    assert conv_taps(worst)[0][0] < 1e-2, conv_taps(worst)[:5]      # (measured: 3.4e-3 with one flipped sign at B * T_out = 300; the boundary bug: 2e-2 .. 6e-2)
+    # flipped L1 sign or one near-tie moves a few ELEMENTS of them (the max-norm measure above sees that: up to 1e-2 of a small tensor's
+    # scale, measured), not the tensor: in the Frobenius norm they keep the TIGHT bound whatever `flips` is, for both weight-gradient
+    # kernels (the exact-fp32 one below).
+    def conv_taps(got_):
+        rep = []
+        for k, v in g.items():
+            if ("/conv_bank/" in k or "/proj_" in k) and k.endswith("/kernel"):
+                rep.append((float(np.linalg.norm(got_[k] - v)) / max(float(np.linalg.norm(v)), 1e-3 * gn), k))
+        return sorted(rep, reverse=True)
+    ct = conv_taps(tr.grad_dict())
+    assert len(ct) == 16 + 8 + 4
+    print("conv-tap gradients vs float64 autograd (Frobenius, relative), worst three:", ct[:3])
+    assert ct[0][0] < 3e-3, ct[:5]
     # the weight gradients above came from the split-bf16 matrix-core kernel (k_wgrad_bf3, the default); the exact-fp32 MFMA kernel
     # (k_wgrad) must give the same gradients to the split's ~1e-5
     got = tr.grad_dict()
@@ -280,7 +287,7 @@ def test_gradients_at_full_reference_widths(B, T_in, T_out):
     d = max(maxabs(got[k], exact[k]) / max(float(np.abs(exact[k]).max()), 1e-3 * gn) for k in exact)
     print("weight gradients: split-bf16 vs float64 autograd %.2e, exact fp32 vs autograd %.2e, split vs exact %.2e (relative, per tensor, worst)" % (worst[0][0], worst_x[0][0], d))
     assert worst_x[0][0] < tol and d < 1e-3
-    assert conv_taps(worst_x)[0][0] < 1e-2, conv_taps(worst_x)[:5]
+    assert conv_taps(exact)[0][0] < 3e-3, conv_taps(exact)[:5]
     tr.close()
 
 
