@@ -304,15 +304,16 @@ struct GdArgs {
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T, force_wt;
 };
-#define GD_STAMP(slot)                                                                                            \
+#define GDT_STAMP(slot)                                                                                           \
   do {                                                                                                            \
-    if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
+    if constexpr (TRACE) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
   } while (0)
 
-template <int RG, bool TAPE = false>
-__global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
-  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
-  GdArgs a = a_in;
+// (WT / TRACE: the protocol and the stamps as template parameters of the body, as in k_bigru_oct: no protocol branch per publish, no stamp
+// branches in the production instantiations)
+template <int RG, bool TAPE, bool WT, bool TRACE>
+__device__ __forceinline__ void gd_body(const GdArgs& a, float* gx_smem, int group, int member, DxRt rt) {
+  constexpr int WTC = WT ? 1 : 0;
   constexpr int NT = 512, H = GX_H, RL = DxRL<RG>::value;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -320,15 +321,10 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
   float* xq = gx_smem;                            // ring first: its LDS addresses go through M0
   float* hs = xq + 2 * SLOT;                      // [2 dirs][RG][H] states
   float* xs = hs + 2 * RG * H;                    // [2 dirs][RG][H] r * h
-  int* ictl = reinterpret_cast<int*>(xs + 2 * RG * H);
-  dx_gu32* errw = (dx_gu32*)a.err;
-  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
-  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
-  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
   const int row0 = group * RG;
   if (row0 >= a.B || member >= GD_MEMBERS) return;
   const int T = a.T;
-  const bool tracer = a.trace && group == 0 && member == 0 && tid == 0;
+  const bool tracer = TRACE && a.trace && group == 0 && member == 0 && tid == 0;
 
   float W[GD_NREG];
 #pragma unroll
@@ -387,7 +383,7 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
     const unsigned tag = (unsigned)s + 1u;
     int tid = tid_outer, lane = lane_outer;                 // opaque per-iteration copies: see taco_decoder_xcd.h
     asm volatile("" : "+v"(tid), "+v"(lane));
-    GD_STAMP(0);
+    GDT_STAMP(0);
     const int sb = s & (GX_BLK - 1), ring = (s / GX_BLK) & 1;
     if (sb == 0 && s > 0) blk_fetch(s + GX_BLK, ring ^ 1);
     // one lambda per phase kind; D is a compile-time direction
@@ -418,7 +414,7 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
       gd_landed<RG, NT>(pre, rh[RL - 1][0]);
       if (epl) {
 #pragma unroll
-        for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)D * 2 * RG * H + erow[q] * H + u0, 1, rh[q], tag, rt);
+        for (int q = 0; q < RL; ++q) dx_publish_n<1, WTC>(X + (size_t)D * 2 * RG * H + erow[q] * H + u0, 1, rh[q], tag, rt);
       }
     };
     auto cand = [&](auto Dc) {
@@ -441,7 +437,7 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
       gd_landed<RG, NT>(pre, nv[RL - 1][0]);
       if (epl) {
 #pragma unroll
-        for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)(D * 2 + 1) * RG * H + erow[q] * H + u0, 1, nv[q], tag, rt);
+        for (int q = 0; q < RL; ++q) dx_publish_n<1, WTC>(X + (size_t)(D * 2 + 1) * RG * H + erow[q] * H + u0, 1, nv[q], tag, rt);
       }
 #pragma unroll
       for (int q = 0; q < RL; ++q)
@@ -456,31 +452,44 @@ __global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
     const dx_gu64* X_rhB = X + (size_t)2 * RG * H;  const dx_gu64* X_hB = X + (size_t)3 * RG * H;
     // (the loads for h'(B) of the previous step were requested at the end of that step)
     gates(F{});
-    GD_STAMP(1);
+    GDT_STAMP(1);
     if (s > 0) gd_collect<RG, NT>(X_hB, tag - 1u, hs + RG * H, tid, pre, rt);
     __syncthreads();
-    GD_STAMP(2);
+    GDT_STAMP(2);
     gd_request<RG, NT>(X_rhF, tid, pre);
     gates(Bk{});
-    GD_STAMP(3);
+    GDT_STAMP(3);
     gd_collect<RG, NT>(X_rhF, tag, xs, tid, pre, rt);
     __syncthreads();
-    GD_STAMP(4);
+    GDT_STAMP(4);
     gd_request<RG, NT>(X_rhB, tid, pre);
     cand(F{});
-    GD_STAMP(5);
+    GDT_STAMP(5);
     gd_collect<RG, NT>(X_rhB, tag, xs + RG * H, tid, pre, rt);
     __syncthreads();
-    GD_STAMP(6);
+    GDT_STAMP(6);
     gd_request<RG, NT>(X_hF, tid, pre);
     cand(Bk{});
-    GD_STAMP(7);
+    GDT_STAMP(7);
     gd_collect<RG, NT>(X_hF, tag, hs, tid, pre, rt);
     if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
     __syncthreads();
-    GD_STAMP(8);
+    GDT_STAMP(8);
     gd_request<RG, NT>(X_hB, tid, pre);
   }
+}
+
+template <int RG, bool TAPE = false, bool TRACE = false>
+__global__ __launch_bounds__(512) void k_bigru_duo(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  int* ictl = reinterpret_cast<int*>(gx_smem + gd_lds_floats(RG) - 64);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 24);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gd_body<RG, TAPE, true, TRACE>(a, gx_smem, group, member, rt);
+  else gd_body<RG, TAPE, false, TRACE>(a, gx_smem, group, member, rt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -1047,10 +1056,9 @@ struct GbArgs {
   int B, T, force_wt;
 };
 
-template <int RG>
-__global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
-  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
-  GbArgs a = a_in;
+template <int RG, bool WT>
+__device__ __forceinline__ void gb_body(const GbArgs& a, float* gx_smem, int group, int member, DxRt rt) {
+  constexpr int WTC = WT ? 1 : 0;
   constexpr int NT = 512, H = GX_H, RL = DxRL<RG>::value;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1058,11 +1066,6 @@ __global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
   float* xq = gx_smem;                                    // ring first (M0-addressed)
   float* v1 = xq + 2 * SLOT;                              // [2 dirs][RG][H]   d c_pre
   float* v2 = v1 + 2 * RG * H;                            // [2 dirs][RG][2H]  d r_pre | d u_pre
-  int* ictl = reinterpret_cast<int*>(v2 + 2 * RG * 2 * H);
-  dx_gu32* errw = (dx_gu32*)a.err;
-  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 24);
-  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
-  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
   const int row0 = group * RG;
   if (row0 >= a.B || member >= GD_MEMBERS) return;
   const int T = a.T;
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
         gb_landed<RG, 2 * H, NT>(pre2, dcp[RL - 1][0]);    // wait for it HERE, ahead of the publish stores (see gd_landed)
         if (epl) {
 #pragma unroll
-          for (int q = 0; q < RL; ++q) dx_publish_n<1>(X + (size_t)D * RG * 3 * H + erow[q] * H + u0, 1, dcp[q], tag, rt);
+          for (int q = 0; q < RL; ++q) dx_publish_n<1, WTC>(X + (size_t)D * RG * 3 * H + erow[q] * H + u0, 1, dcp[q], tag, rt);
         }
       }
     };
@@ -1217,8 +1220,8 @@ __global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
       if (epl) {
 #pragma unroll
         for (int q = 0; q < RL; ++q) {
-          dx_publish_n<1>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + u0, 1, gr[q], tag, rt);
-          dx_publish_n<1>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + H + u0, 1, gu[q], tag, rt);
+          dx_publish_n<1, WTC>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + u0, 1, gr[q], tag, rt);
+          dx_publish_n<1, WTC>(X + (size_t)D * RG * 3 * H + RG * H + erow[q] * 2 * H + H + u0, 1, gu[q], tag, rt);
         }
       }
     };
@@ -1246,4 +1249,17 @@ __global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
     __syncthreads();
     gb_request<RG, 2 * H, NT>(Xg1, tid, pre2);
   }
+}
+
+template <int RG>
+__global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GbArgs a = a_in;
+  int* ictl = reinterpret_cast<int*>(gx_smem + gb_lds_floats(RG) - 64);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 24);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]), member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gb_body<RG, true>(a, gx_smem, group, member, rt);
+  else gb_body<RG, false>(a, gx_smem, group, member, rt);
 }

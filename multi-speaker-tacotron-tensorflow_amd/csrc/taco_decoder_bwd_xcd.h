@@ -189,10 +189,11 @@ __device__ __forceinline__ float db_normalise_bwd(const float* er, const float* 
   return dx_allsum(dsb);
 }
 
-template <int RG>
-__global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
-  extern __shared__ __attribute__((aligned(16))) float dx_smem[];
-  const DbArgs& a = a_in;
+// WT: the census chose the write-through protocol (decided once per launch: the step carries no protocol branch); TRACE: shader-clock stamps
+// (tools/trace_bptt.py) -- the production instantiation has none of their branches (round 5: ~30 clocks per publish / stamp on the chain)
+template <int RG, bool WT, bool TRACE>
+__device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int group, int member, DxRt rt) {
+  constexpr int WTC = WT ? 1 : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int Pr = DX_GROUP / RG, DC = DX_W / Pr;
@@ -212,13 +213,6 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   float* qv = dac + Tpad; float* vv = qv + 64; float* bq = vv + 64;
   float* qraw = bq + 64;                      // [2][64] processed query of the member's channels (tape), one step ahead
   float* cpart = qraw + 128;                  // [DX_NW][64]
-  int* ictl = reinterpret_cast<int*>(cpart + DX_NW * 64);
-
-  dx_gu32* errw = (dx_gu32*)a.err;
-  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, tid, 40);
-  const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
-  const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
-  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
   if (member >= DX_GROUP) return;
   const int row0 = group * RG;
   if (row0 >= a.B) return;
@@ -227,11 +221,11 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
   const int brow = row0 + arow;
   const int browc = min(brow, a.B - 1);
-  const bool tracer = a.trace && group == 0 && member == 0 && tid == 0;
+  const bool tracer = TRACE && a.trace && group == 0 && member == 0 && tid == 0;
 #define DB_STAMP(slot)                                                                                                   \
   do {                                                                                                                   \
     const int ks_ = n - 1 - t - 8;         /* steps 8 .. 15 of the launch: past the start-up transients */                \
-    if (tracer && ks_ >= 0 && ks_ < DX_TRACE_STEPS) a.trace[ks_ * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); \
+    if constexpr (TRACE) { if (tracer && ks_ >= 0 && ks_ < DX_TRACE_STEPS) a.trace[ks_ * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
   } while (0)
 
   float W[DB_NREG];
@@ -371,7 +365,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         const float dcp = g * (1.f - OWN(OW_U2, q)) * (1.f - OWN(OW_C2, q) * OWN(OW_C2, q));
         dgu[q] = g * ((z2 ? 0.f : OWN(OW_H2P, q)) - OWN(OW_C2, q)) * OWN(OW_U2, q) * (1.f - OWN(OW_U2, q));
         dht[q] = g;
-        if (epl) dx_publish(X + xl.dcp2 + erow[q] * 256 + en, dcp, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.dcp2 + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcp2, 256, q, en, dcp); DB_OUT(a.g_dgp2, 512, q, 256 + en, dgu[q]);
       }
     }
@@ -391,7 +385,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         const float drh = s[1][q];                                                                           \
         const float dgr = drh * (HP) * (RR) * (1.f - (RR));                                                  \
         DHP[q] = dht[q] * (UU) + drh * (RR);                                                                 \
-        if (epl) { dx_publish(X + (XG) + erow[q] * 512 + en, dgr, tag, rt); dx_publish(X + (XG) + erow[q] * 512 + 256 + en, dgu[q], tag, rt); } \
+        if (epl) { dx_publish<WTC>(X + (XG) + erow[q] * 512 + en, dgr, tag, rt); dx_publish<WTC>(X + (XG) + erow[q] * 512 + 256 + en, dgu[q], tag, rt); } \
         DB_OUT(GOUT, 512, q, en, dgr);                                                                       \
       }                                                                                                      \
     }
@@ -416,7 +410,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         const float dcp = g * (1.f - OWN(OW_U1, q)) * (1.f - OWN(OW_C1, q) * OWN(OW_C1, q));
         dgu[q] = g * ((z1 ? 0.f : OWN(OW_H1P, q)) - OWN(OW_C1, q)) * OWN(OW_U1, q) * (1.f - OWN(OW_U1, q));
         dht[q] = g;
-        if (epl) dx_publish(X + xl.dcp1 + erow[q] * 256 + en, dcp, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.dcp1 + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcp1, 256, q, en, dcp); DB_OUT(a.g_dgp1, 512, q, 256 + en, dgu[q]);
       }
     }
@@ -439,7 +433,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         dh1[q] = dhp[q] + s[1][q];
         const float do0 = tx[q] + s[0][q] + do_[q];              // d o0 = d x of GRU 1 + residual (o1 = h1 + o0)
-        if (epl) dx_publish(X + xl.do0 + erow[q] * 256 + en, do0, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.do0 + erow[q] * 256 + en, do0, tag, rt);
         DB_OUT(a.g_do0, 256, q, en, do0);
       }
     }
@@ -458,7 +452,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
       for (int q = 0; q < RL; ++q) {
         dIn_hA[q] = s[0][q];
         const float dc = dctxc[q] + s[1][q];                     // total gradient of context(t)
-        if (epl) dx_publish(X + xl.dctx + erow[q] * 256 + en, dc, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.dctx + erow[q] * 256 + en, dc, tag, rt);
         DB_OUT(a.g_dctx, 256, q, en, dc);
       }
     }
@@ -475,7 +469,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
           const float4 v4 = *reinterpret_cast<const float4*>(Vc + (size_t)j * DC + c);
           s += v4.x * dcx[c] + v4.y * dcx[c + 1] + v4.z * dcx[c + 2] + v4.w * dcx[c + 3];
         }
-        dx_publish(X + xl.da + (size_t)(arow * Pr + asl) * T + j, s, tag, rt);
+        dx_publish<WTC>(X + xl.da + (size_t)(arow * Pr + asl) * T + j, s, tag, rt);
       }
     }
     {  // gather the row's partials (fixed order) + the carried d alpha
@@ -577,7 +571,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         float tot = 0.f;
 #pragma unroll
         for (int k = 0; k < NPC; ++k) tot += cpart[k * DS + tid];
-        dx_publish(X + xl.dq + (size_t)(arow * Pp + pb) * 256 + cb * DS + tid, tot * vv[tid], tag, rt);
+        dx_publish<WTC>(X + xl.dq + (size_t)(arow * Pp + pb) * 256 + cb * DS + tid, tot * vv[tid], tag, rt);
       }
     }
     {  // gather d q of every row: sum over the Pp position blocks
@@ -611,7 +605,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         const float dcp = g * (1.f - OWN(OW_UA, q)) * (1.f - OWN(OW_CA, q) * OWN(OW_CA, q));
         dgu[q] = g * ((zA ? 0.f : OWN(OW_HAP, q)) - OWN(OW_CA, q)) * OWN(OW_UA, q) * (1.f - OWN(OW_UA, q));
         dht[q] = g;
-        if (epl) dx_publish(X + xl.dcpa + erow[q] * 256 + en, dcp, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.dcpa + erow[q] * 256 + en, dcp, tag, rt);
         DB_OUT(a.g_dcpA, 256, q, en, dcp); DB_OUT(a.g_dgpA, 512, q, 256 + en, dgu[q]);
       }
     }
@@ -635,7 +629,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
         dhA[q] = dhp[q] + s[1][q];
         if (wave < 4) {
           const float dz2 = (OWN(OW_P2, q) > 0.f) ? tx[q] + s[0][q] : 0.f;
-          if (epl) dx_publish(X + xl.dz2 + erow[q] * 128 + en2, dz2, tag, rt);
+          if (epl) dx_publish<WTC>(X + xl.dz2 + erow[q] * 128 + en2, dz2, tag, rt);
           DB_OUT(a.g_dz2, 128, q, en2, dz2);
         }
       }
@@ -656,7 +650,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
 #pragma unroll
       for (int q = 0; q < RL; ++q) {
         const float dz1 = (OWN(OW_P1, q) > 0.f) ? s[0][q] : 0.f;
-        if (epl) dx_publish(X + xl.dz1 + erow[q] * 256 + en, dz1, tag, rt);
+        if (epl) dx_publish<WTC>(X + xl.dz1 + erow[q] * 256 + en, dz1, tag, rt);
         DB_OUT(a.g_dz1, 256, q, en, dz1);
       }
     }
@@ -692,4 +686,18 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
     }
   }
   if (a.dsb_acc && asl == 0 && tid == 0 && brow < a.B) a.dsb_acc[brow] = dsb_row;
+}
+
+template <int RG, bool TRACE = false>
+__global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float dx_smem[];
+  const DbArgs& a = a_in;
+  int* ictl = reinterpret_cast<int*>(dx_smem + db_lds_floats(RG, a.T_in) - 64);      // census words: the last 64 floats of the LDS request
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 40);
+  const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
+  const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) db_body<RG, true, TRACE>(a, dx_smem, group, member, rt);
+  else db_body<RG, false, TRACE>(a, dx_smem, group, member, rt);
 }

@@ -1130,7 +1130,15 @@ static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
   HIPCHK(clear_polled(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
   const size_t lds = std::max(gd_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
-  if (gsave) {
+  if (gsave) a.trace = nullptr;
+  if (a.trace) {          // the stamped instantiations (tools/trace_bigru.py): inference only
+    switch (RG) {
+      case 1: hipLaunchKernelGGL((k_bigru_duo<1, false, true>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((k_bigru_duo<2, false, true>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((k_bigru_duo<4, false, true>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_bigru_duo<8, false, true>), grid, blk, lds, st, a); break;
+    }
+  } else if (gsave) {
     switch (RG) {
       case 1: hipLaunchKernelGGL((k_bigru_duo<1, true>), grid, blk, lds, st, a); break;
       case 2: hipLaunchKernelGGL((k_bigru_duo<2, true>), grid, blk, lds, st, a); break;
@@ -1742,6 +1750,12 @@ static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int 
   HIPCHK(zero_async(xbuf, (size_t)((char*)dxctl - (char*)xbuf) + 256, st));
   const size_t lds = db_lds_floats(RG, T_in) * sizeof(float);
   const dim3 grid(DX_NGROUP * DX_GROUP), blk(DX_NT);
+  if (a.trace && RG == 4) {      // the stamped instantiation (tools/trace_bptt.py): the C4 shard's geometry only
+    hipLaunchKernelGGL((k_decoder_bwd_xcd<4, true>), grid, blk, lds, st, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  a.trace = nullptr;
   switch (RG) {
     case 1: hipLaunchKernelGGL((k_decoder_bwd_xcd<1>), grid, blk, lds, st, a); break;
     case 2: hipLaunchKernelGGL((k_decoder_bwd_xcd<2>), grid, blk, lds, st, a); break;
