@@ -989,6 +989,251 @@ __global__ __launch_bounds__(512) void k_bigru_dir(const GdArgs a_in) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_ks<TAPE, TRACE> (round 5): ONE exchange per direction and step instead of two.
+//
+// k_bigru_oct sits on the bound of its decomposition: per direction a step is gates -> exchange r*h -> candidate -> exchange h', and an
+// exchange (publish -> the L2 -> every consumer has seen the last producer's granule) is ~900 clocks however little is computed around it.
+// The second exchange exists because the candidate's product (r*h) . Wc_h is split by COLUMNS: every member needs the whole r*h.  Split by
+// ROWS it needs none: a member knows r_k h_k of its own 32 units k the moment its gates are done, so it forms, for ALL 256 candidate columns
+// j, the partial sum over its own k -- the rows of Wc_h of its units: 32 x 256 weights, as many as the 256 x 32 column block they replace --
+// and publishes the 256 partials next to the update gates u of its units.  Every member then collects the 8 partial vectors and the u vector
+// of its cluster (2304 granules: nine per thread of one half of the workgroup) and finishes ALL 256 units itself, redundantly and bit-
+// identically (c_j = tanh(xc_j + the partials in member order), h'_j = u_j h_j + (1 - u_j) c_j): it holds the whole new state without a
+// second exchange.  A step of a direction is
+//     G  gates of the own units (as k_bigru_oct)          -> r*h of the own units to LDS, u published
+//     P  partial candidate sums for all columns            -> published          [exchange, hidden behind the other direction's E + G + P]
+//     E  every unit's candidate and new state              -> the state vector in LDS; the owner of a unit stores the output
+// with the two directions half a step apart.  The granules of a step go to buffer (step & 1): a member can overwrite a buffer only after
+// every member has published into the other one, i.e. after every member has read this one.  One row per cluster of 8 CUs (17 to 32 rows).
+// ------------------------------------------------------------------------------------------------------------------------------
+#define GK_MB 8                       // members per cluster
+#define GK_UPM 32                     // units per member
+#define GK_BLK 8                      // steps per block of prefetched x-parts (both rings together stay below 48 KB: LDS-direct loads address through M0)
+__host__ __device__ inline size_t gk_xbuf_granules() { return (size_t)32 * 2 * 2 * 9 * GX_H; }      // rows x dir x buffer x (8 partial vectors + u) x H
+__host__ __device__ inline size_t gk_lds_floats() {
+  return (size_t)2 * 2 * GK_BLK * 2 * GK_UPM      // x-parts of the own units' gates [slot][dir][step][r | u][32]
+       + (size_t)2 * 2 * GK_BLK * GX_H            // x-parts of every unit's candidate [slot][dir][step][256]
+       + (size_t)2 * GX_H + 2 * GK_UPM + 64;      // states [dir][256], r*h of the own units [dir][32], census words
+}
+#define GK_STAMP(slot)                                                                                            \
+  do {                                                                                                            \
+    if constexpr (TRACE) { if (tracer && s >= 8 && s < 8 + DX_TRACE_STEPS) a.trace[(s - 8) * DX_TRACE_SLOTS + (slot)] = (long long)__builtin_readcyclecounter(); } \
+  } while (0)
+
+template <bool TAPE, bool WT, bool TRACE>
+__device__ __forceinline__ void gk_body(const GdArgs& a, float* gx_smem, int place, int slot, DxRt rt) {
+  constexpr int NT = 512, H = GX_H, UPW = 4, WTC = WT ? 1 : 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SG = 2 * GK_BLK * 2 * GK_UPM, SC = 2 * GK_BLK * H;      // floats of one ring slot: gates part, candidate part
+  float* xg = gx_smem;                            // rings first: their LDS addresses go through M0
+  float* xc = xg + 2 * SG;
+  float* hs = xc + 2 * SC;                        // [2 dirs][H]
+  float* rhs = hs + 2 * H;                        // [2 dirs][32]
+  const int row = place * 4 + (slot & 3), member = slot >> 2;
+  if (row >= a.B || member >= GK_MB) return;
+  const int T = a.T;
+  const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
+  const bool tracer = TRACE && a.trace && row == 0 && member == 0 && tid == 0;
+  // gates: wave w owns units 32 member + 4w + i of both directions (registers 8i + e: r_i, 8i + 4 + e: u_i, inputs 4 lane + e) -- as pairs (r_i, u_i);
+  // candidate ROWS: thread (wave, lane) owns column j = 32 wave + (lane & 31) for the units 32 member + 16 (lane >> 5) + kk, kk < 16 -- pairs (kk, kk + 1)
+  taco_f32x2 WG[2][16], WC[2][8];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float* wp = a.wpack + (((size_t)member * 2 + d) * 48) * NT + tid;
+#pragma unroll
+    for (int i = 0; i < UPW; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) WG[d][4 * i + e] = (taco_f32x2){wp[(size_t)(8 * i + e) * NT], wp[(size_t)(8 * i + 4 + e) * NT]};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) WC[d][kk] = (taco_f32x2){wp[(size_t)(32 + 2 * kk) * NT], wp[(size_t)(33 + 2 * kk) * NT]};
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)row * 2 * 2 * 9 * H;       // [dir][buffer][8 partial vectors | u][H]
+  for (int i = tid; i < 2 * H; i += NT) hs[i] = a.h0 ? a.h0[(size_t)row * 2 * H + i] : 0.f;
+  // x-part blocks: gates of the own units: item i = (dir, step j, gate g, quarter c of 8); candidates of all units: item i = (dir, step j, quarter c of 64)
+  constexpr int NIG = 2 * GK_BLK * 2 * 8, NIC = 2 * GK_BLK * 64;      // 256, 1024 float4 items per block
+  static_assert(NIG % 64 == 0 && NIC % NT == 0, "whole waves");
+  const unsigned xg_lds = (unsigned)(size_t)(gx_lds_float*)xg, xc_lds = (unsigned)(size_t)(gx_lds_float*)xc;
+  auto blk_fetch = [&](int s0, int ring) {
+    if (wave * 64 < NIG) {                                                        // wave-uniform
+      const int i = tid;
+      const int c = i & 7, g = (i >> 3) & 1, j = (i >> 4) % GK_BLK, d = i / (16 * GK_BLK);
+      const int sx = min(s0 + j, T - 1);
+      const float* src = a.xproj + ((size_t)row * T + sx) * 6 * H + d * 3 * H + g * H + member * GK_UPM + 4 * c;
+      gx_load_lds16(src, __builtin_amdgcn_readfirstlane(xg_lds + (unsigned)(ring * SG + 4 * (wave * 64)) * 4u));
+    }
+#pragma unroll
+    for (int u = 0; u < NIC / NT; ++u) {
+      const int i = u * NT + tid;
+      const int c = i & 63, j = (i >> 6) % GK_BLK, d = i / (64 * GK_BLK);
+      const int sx = min(s0 + j, T - 1);
+      const float* src = a.xproj + ((size_t)row * T + sx) * 6 * H + d * 3 * H + 2 * H + 4 * c;
+      gx_load_lds16(src, __builtin_amdgcn_readfirstlane(xc_lds + (unsigned)(ring * SC + 4 * (u * NT + wave * 64)) * 4u));
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(GK_BLK, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int tid_outer = tid, lane_outer = lane;
+  float uu[2] = {0.f, 0.f};
+  unsigned long long pq[9], pq2[9];      // the nine granules of a collect in flight, asked for twice (k_bigru_oct: pre / pre2)
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { pq[i] = 0ull; pq2[i] = 0ull; }
+
+  // G: the gates of the own units of direction D at step s
+  auto gates = [&](auto Dc, int s, int lane, const dx_gu64* Xreq, bool req) {
+    constexpr int D = decltype(Dc)::value;
+    const int sb = s & (GK_BLK - 1), ring = (s / GK_BLK) & 1, ui = lane >> 4, ul = wave * UPW + ui;
+    const float x0r = xg[ring * SG + ((D * GK_BLK + sb) * 2 + 0) * GK_UPM + ul], x0u = xg[ring * SG + ((D * GK_BLK + sb) * 2 + 1) * GK_UPM + ul];
+    const float hk = hs[D * H + member * GK_UPM + ul];
+    const float4 hx = *reinterpret_cast<const float4*>(hs + D * H + 4 * lane);
+    taco_f32x2 acc[UPW];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) acc[i] = WG[D][4 * i] * (taco_f32x2){hx.x, hx.x};
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.y, hx.y}, WG[D][4 * i + 1], acc[i]);
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, WG[D][4 * i + 2], acc[i]);
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, WG[D][4 * i + 3], acc[i]);
+    if (req && (wave >> 2) != D) {            // second request of the OTHER direction's collect (its waves: the ones that do not own this phase's)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pq2[i] = __hip_atomic_load(Xreq + (size_t)i * H + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float v[2 * UPW], sm[2];
+#pragma unroll
+    for (int i = 0; i < UPW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
+    go_reduce<UPW, 2>(v, sm);
+    const float rr = dx_sigmoid_fast(sm[0] + x0r);
+    uu[D] = dx_sigmoid_fast(sm[1] + x0u);
+    if ((lane & 15) == 0) {
+      rhs[D * GK_UPM + ul] = rr * hk;
+      dx_publish<WTC>(X + (size_t)((D * 2 + (s & 1)) * 9 + 8) * H + member * GK_UPM + ul, uu[D], (unsigned)s + 1u, rt);
+      if (TAPE && s < L) {
+        float* gs = a.gsave + ((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + member * GK_UPM + ul;
+        gs[0] = rr; gs[H] = uu[D];
+      }
+    }
+  };
+  // P: partial candidate sums of direction D over the own units, for all 256 columns
+  auto partial = [&](auto Dc, int s, int lane) {
+    constexpr int D = decltype(Dc)::value;
+    const float* rp = rhs + D * GK_UPM + 16 * (lane >> 5);
+    taco_f32x2 acc = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 r4 = *reinterpret_cast<const float4*>(rp + 4 * q);
+      acc = __builtin_elementwise_fma((taco_f32x2){r4.x, r4.y}, WC[D][2 * q], acc);
+      acc = __builtin_elementwise_fma((taco_f32x2){r4.z, r4.w}, WC[D][2 * q + 1], acc);
+    }
+    const float h2 = acc.x + acc.y;
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(h2), __float_as_uint(h2), false, false);
+    float tot = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    // the collect in flight across this phase has landed: wait for it HERE, ahead of the publish stores (see gd_landed)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "+v"(pq[i]), "+v"(pq2[i]), "+v"(tot));
+    if (lane < 32) dx_publish<WTC>(X + (size_t)((D * 2 + (s & 1)) * 9 + member) * H + 32 * wave + lane, tot, (unsigned)s + 1u, rt);
+  };
+  // the collect of direction D's granules of step s: requested ...
+  auto request = [&](int D, int s, int tid) {
+    if ((wave >> 2) == D) {
+      const dx_gu64* Xv = X + (size_t)((D * 2 + (s & 1)) * 9) * H + (tid & 255);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pq[i] = __hip_atomic_load(Xv + (size_t)i * H, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  // ... and used (E): every unit's candidate and new state, by the waves 4D .. 4D+3 (one unit per thread)
+  auto finish = [&](auto Dc, int s, int tid) {
+    constexpr int D = decltype(Dc)::value;
+    if ((wave >> 2) == D) {
+      const int j = tid & 255;
+      const unsigned tg = (unsigned)s + 1u;
+      const dx_gu64* Xv = X + (size_t)((D * 2 + (s & 1)) * 9) * H + j;
+      float pv[9];
+      bool ok2 = true, ok1 = true;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { ok2 = ok2 && ((unsigned)(pq2[i] >> 32) == tg); ok1 = ok1 && ((unsigned)(pq[i] >> 32) == tg); }
+      if (ok2) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pv[i] = __uint_as_float((unsigned)pq2[i]);
+      } else if (ok1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pv[i] = __uint_as_float((unsigned)pq[i]);
+      } else {
+        dx_poll<9>(Xv, (size_t)H, tg, pv, rt);       // a producer was late: the ordinary bounded poll
+      }
+      const int sb = s & (GK_BLK - 1), ring = (s / GK_BLK) & 1;
+      float cpre = xc[ring * SC + (D * GK_BLK + sb) * H + j];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) cpre += pv[m];      // member order: every member forms the same sum
+      const float cc = taco_tanh_fast(cpre), u = pv[8], hj = hs[D * H + j];
+      float blend = u * hj + (1.f - u) * cc;
+      DX_PIN(blend);
+      const bool active = s < L;
+      const float nv = active ? blend : hj;
+      hs[D * H + j] = nv;
+      if ((j >> 5) == member) {                        // the unit's owner
+        const int t = (D && active) ? (L - 1 - s) : s;
+        a.out[((size_t)row * T + t) * 2 * H + D * H + j] = active ? nv : 0.f;
+        if (TAPE && active) a.gsave[((size_t)row * T + t) * 6 * H + D * 3 * H + 2 * H + j] = cc;
+      }
+    }
+  };
+  using F = std::integral_constant<int, 0>;
+  using Bk = std::integral_constant<int, 1>;
+  for (int s = 0; s < T; ++s) {
+    int tid = tid_outer, lane = lane_outer;                 // opaque per-iteration copies: see taco_decoder_xcd.h
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    GK_STAMP(0);
+    const int sb = s & (GK_BLK - 1), ring = (s / GK_BLK) & 1;
+    // (B's granules of step s - 1 were requested at the end of the previous iteration)
+    gates(F{}, s, lane, X + (size_t)((2 + ((s - 1) & 1)) * 9) * H, s > 0);
+    __syncthreads();                                        // r*h of the own units (F) visible
+    GK_STAMP(1);
+    partial(F{}, s, lane);
+    GK_STAMP(2);
+    if (s > 0) finish(Bk{}, s - 1, tid);
+    __syncthreads();                                        // the new state (B) visible
+    GK_STAMP(3);
+    // the block after next goes into the slot whose last reader -- finish(B, s - 1) just now: the candidate x-parts of step s - 1 -- is done
+    if (sb == 0 && s > 0) blk_fetch(s + GK_BLK, ring ^ 1);
+    request(0, s, tid);
+    gates(Bk{}, s, lane, X + (size_t)((0 + (s & 1)) * 9) * H, true);
+    __syncthreads();
+    GK_STAMP(4);
+    partial(Bk{}, s, lane);
+    GK_STAMP(5);
+    finish(F{}, s, tid);
+    if (sb == GK_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
+    __syncthreads();                                        // the new state (F) visible
+    GK_STAMP(6);
+    request(1, s, tid);
+  }
+  {   // the backward direction's last step
+    int tid = tid_outer;
+    asm volatile("" : "+v"(tid));
+#pragma unroll
+    for (int i = 0; i < 9; ++i) pq2[i] = 0ull;
+    finish(Bk{}, T - 1, tid);
+  }
+}
+
+template <bool TAPE = false, bool TRACE = false>
+__global__ __launch_bounds__(512) void k_bigru_ks(const GdArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GdArgs a = a_in;
+  int* ictl = reinterpret_cast<int*>(gx_smem + gk_lds_floats() - 64);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 24);
+  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gk_body<TAPE, true, TRACE>(a, gx_smem, place, slot, rt);
+  else gk_body<TAPE, false, TRACE>(a, gx_smem, place, slot, rt);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // k_bigru_duo_bwd<RG>: the backward scan of the same BiGRU (BPTT through modules.py:82-96 / TF GRUCell, A.6/A.7) on k_bigru_duo's
 // machinery: both directions of RG rows on one group of 32 CUs, the two directions software-pipelined against each other, polls
 // issued early.  It replaces k_bigru_rows_bwd (one workgroup per (direction, row pair), the transposed recurrent kernels streamed
