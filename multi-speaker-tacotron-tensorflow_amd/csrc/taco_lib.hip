@@ -135,8 +135,6 @@ struct Cbhg {
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
   size_t gd_pack = 0, gb_pack = 0;                     // k_bigru_duo / k_bigru_duo_bwd: [2 dirs][32 members][12][512]
   size_t go_pack[3] = {0, 0, 0};                       // k_bigru_oct<UPW>, UPW = 1, 2, 4: [2 dirs][32 / UPW members][12 UPW][512]
-  size_t gv_pack[3] = {0, 0, 0};                       // k_bigru_dir<CPX>, CPX = 1, 2, 4: [2 dirs][32 / CPX members][4 waves][24 CPX][64]
-  size_t gk_pack = 0;                                  // k_bigru_ks: [8 members][2 dirs][48][512]: gate columns of the member's units, then the candidate kernel's ROWS of its units
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   // fused front (taco_front.h): per bank width (same order as `bank`) the produce pack [k32 step][16-channel tile][lane][8] (hi, lo)
   // and its step count; front_kind 0 = not built, 1 = <TN 2, XS 80, CINP 80, KWMAX 8> (post-net), 2 = <TN 1, XS 144, CINP 128, KWMAX 16> (encoder)
@@ -732,52 +730,6 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
           }
       }
       c.go_pack[lg] = arena_put(m, op.data(), op.size());
-      // k_bigru_dir<CPX>: wave (dir, wq) of member mem owns units 8 CPX mem + 2 CPX wq + i of ONE direction; registers 8i + 4g + e, then 16 CPX + 4i + e
-      const int CPX = UPW, UW = 2 * CPX, NRV = 12 * UW;
-      std::vector<float> vp((size_t)2 * MB * 4 * NRV * 64, 0.f);
-      for (int dir = 0; dir < 2; ++dir) {
-        const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
-        const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
-        for (int mem = 0; mem < MB; ++mem)
-          for (int wq = 0; wq < 4; ++wq)
-            for (int l = 0; l < 64; ++l) {
-              float* base = &vp[((((size_t)dir * MB + mem) * 4 + wq) * NRV) * 64 + l];
-              for (int i = 0; i < UW; ++i) {
-                const int u = mem * 8 * CPX + wq * UW + i;
-                for (int e = 0; e < 4; ++e) {
-                  const size_t kr = (size_t)(I + 4 * l + e);
-                  base[(size_t)(8 * i + e) * 64] = gk[kr * 2 * H + u];
-                  base[(size_t)(8 * i + 4 + e) * 64] = gk[kr * 2 * H + H + u];
-                  base[(size_t)(8 * UW + 4 * i + e) * 64] = ck[kr * H + u];
-                }
-              }
-            }
-      }
-      c.gv_pack[lg] = arena_put(m, vp.data(), vp.size());
-    }
-    {  // k_bigru_ks: gates as k_bigru_oct<4> (registers 8i + e: r_i, 8i + 4 + e: u_i of unit 32 mem + 4w + i, input 4l + e); then for thread (w, l) the
-       // candidate kernel's entries (row 32 mem + 16 (l >> 5) + kk, column 32 w + (l & 31)), kk < 16: the ROWS of the member's own units
-      std::vector<float> kp((size_t)GK_MB * 2 * 48 * 512, 0.f);
-      for (int mem = 0; mem < GK_MB; ++mem)
-        for (int dir = 0; dir < 2; ++dir) {
-          const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
-          const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
-          for (int tid = 0; tid < 512; ++tid) {
-            const int w = tid >> 6, l = tid & 63;
-            float* base = &kp[(((size_t)mem * 2 + dir) * 48) * 512 + tid];
-            for (int i = 0; i < 4; ++i) {
-              const int u = mem * GK_UPM + 4 * w + i;
-              for (int e = 0; e < 4; ++e) {
-                const size_t kr = (size_t)(I + 4 * l + e);
-                base[(size_t)(8 * i + e) * 512] = gk[kr * 2 * H + u];
-                base[(size_t)(8 * i + 4 + e) * 512] = gk[kr * 2 * H + H + u];
-              }
-            }
-            for (int kk = 0; kk < 16; ++kk)
-              base[(size_t)(32 + kk) * 512] = ck[(size_t)(I + mem * GK_UPM + 16 * (l >> 5) + kk) * H + 32 * w + (l & 31)];
-          }
-        }
-      c.gk_pack = arena_put(m, kp.data(), kp.size());
     }
     if (m->tp) {   // k_bigru_duo_bwd (training only): ROWS of the recurrent kernels -- unit u's row of Wc_h, then of Wg_h (r half, u half)
       std::vector<float> bp((size_t)2 * GD_MEMBERS * 12 * 512, 0.f);
@@ -1117,8 +1069,7 @@ static void carve_cbhg(Carver& cv, const Cbhg& c, int B, int T, CbhgWs& w) {
   w.hi0 = cv.f(M * c.rnn); w.hi1 = cv.f(M * c.rnn);
   w.xproj = cv.f(M * 6 * c.rnn);
   w.h = cv.f((size_t)2 * B * c.rnn); w.rh = cv.f((size_t)2 * B * c.rnn); w.u = cv.f((size_t)2 * B * c.rnn);
-  // k_bigru_xcd exchange granules (16 groups x 8 rows = 32 groups x 4 rows); k_bigru_ks: 32 rows x 2 directions x 2 buffers x 9 vectors
-  w.gxbuf_bytes = std::max(gx_xbuf_granules(16, 8), c.rnn == GX_H ? gk_xbuf_granules() : (size_t)0) * sizeof(unsigned long long);
+  w.gxbuf_bytes = gx_xbuf_granules(16, 8) * sizeof(unsigned long long);  // k_bigru_xcd exchange granules (16 groups x 8 rows = 32 groups x 4 rows; k_bigru_duo / k_bigru_oct need no more)
   w.gxbuf = (unsigned long long*)cv.raw(w.gxbuf_bytes);
   w.gxctl = (unsigned*)cv.raw(256);
 }
@@ -1142,7 +1093,7 @@ static size_t bigru_res_lds(int H, int KL, int R) {
 
 // k_bigru_duo (taco_bigru_xcd.h) usable for this scan?  (H = 256, a whole MI355X, at most 64 rows)
 static bool duo_usable(const taco_model* m, const Cbhg& c, int B, int T) {
-  return (m->persist == 1 || (m->persist >= 10 && m->persist <= 14)) && m->dx_mode && c.gd_pack && c.rnn == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256;
+  return (m->persist == 1 || m->persist == 10 || m->persist == 11) && m->dx_mode && c.gd_pack && c.rnn == GX_H && B <= 64 && T >= 2 && m->cu_count >= 256;
 }
 // both directions of RG rows on one group of 32 CUs, software-pipelined against each other; gsave != null: the TAPE instantiation
 static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* xproj, const int* lengths, const float* init_state,
@@ -1185,10 +1136,10 @@ static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
 // k_bigru_oct: one row per cluster of 32 / UPW CUs (UPW = 4: up to 32 rows, 2: 16, 1: 8).  persist 1 (default): from 9 rows on -- up to eight
 // rows k_bigru_duo<1> IS the one-row geometry on 32 CUs --; persist 10: wherever it fits (A/B); persist 11: never (round 4's k_bigru_duo)
 static int oct_upw(const taco_model* m, const Cbhg& c, int B, int T) {
-  if (!(m->persist == 1 || m->persist == 10 || m->persist == 12 || m->persist == 13 || m->persist == 14) || !m->dx_mode || !c.go_pack[0] || c.rnn != GX_H || B > 32 || T < 2 || m->cu_count < 256) return 0;
+  if (!(m->persist == 1 || m->persist == 10) || !m->dx_mode || !c.go_pack[0] || c.rnn != GX_H || B > 32 || T < 2 || m->cu_count < 256) return 0;
   if (B > 16) return 4;
   if (B > 8) return 2;
-  return (m->persist == 10 || m->persist == 13) ? 1 : 0;
+  return m->persist == 10 ? 1 : 0;
 }
 static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UPW, int B, int T, const float* xproj, const int* lengths, const float* init_state,
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
@@ -1199,38 +1150,6 @@ static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UP
   HIPCHK(clear_polled(gxbuf, (size_t)((char*)gxctl - (char*)gxbuf) + 256, st));
   const size_t lds = std::max(go_lds_floats(UPW) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
   const dim3 grid(DX_NGROUP * DX_GROUP), blk(512);
-  if (m->persist == 14 && UPW == 4 && !gsave) {      // k_bigru_ks: the candidate split by ROWS -- one exchange per direction and step (17 to 32 rows)
-    a.wpack = AP(m, c.gk_pack);
-    const size_t ldsk = std::max(gk_lds_floats() * sizeof(float), (size_t)96 * 1024);
-    if (a.trace) hipLaunchKernelGGL((k_bigru_ks<false, true>), grid, blk, ldsk, st, a);
-    else hipLaunchKernelGGL((k_bigru_ks<false, false>), grid, blk, ldsk, st, a);
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
-  if (m->persist == 12 || m->persist == 13) {      // k_bigru_dir: the directions on different waves, no barrier, operands polled straight into registers
-    a.wpack = AP(m, c.gv_pack[UPW == 4 ? 2 : UPW == 2 ? 1 : 0]);
-    if (a.trace) {
-      switch (UPW) {
-        case 1: hipLaunchKernelGGL((k_bigru_dir<1, false, true>), grid, blk, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_bigru_dir<2, false, true>), grid, blk, lds, st, a); break;
-        default: hipLaunchKernelGGL((k_bigru_dir<4, false, true>), grid, blk, lds, st, a); break;
-      }
-    } else if (gsave) {
-      switch (UPW) {
-        case 1: hipLaunchKernelGGL((k_bigru_dir<1, true>), grid, blk, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_bigru_dir<2, true>), grid, blk, lds, st, a); break;
-        default: hipLaunchKernelGGL((k_bigru_dir<4, true>), grid, blk, lds, st, a); break;
-      }
-    } else {
-      switch (UPW) {
-        case 1: hipLaunchKernelGGL((k_bigru_dir<1, false>), grid, blk, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((k_bigru_dir<2, false>), grid, blk, lds, st, a); break;
-        default: hipLaunchKernelGGL((k_bigru_dir<4, false>), grid, blk, lds, st, a); break;
-      }
-    }
-    HIPCHK(hipGetLastError());
-    return 0;
-  }
   if (a.trace) {          // the stamped instantiation (tools/trace_bigru.py): inference only
     switch (UPW) {
       case 1: hipLaunchKernelGGL((k_bigru_oct<1, false, true>), grid, blk, lds, st, a); break;
@@ -2505,7 +2424,7 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
   {  // post-net scan
     const Cbhg& c = m->post;
     std::string why = why_common(B);
-    if (why.empty() && m->persist != 1 && m->persist != 8 && m->persist != 9 && !(m->persist >= 10 && m->persist <= 14)) why = "taco_debug_set_persistent(" + std::to_string(m->persist) + ")";
+    if (why.empty() && m->persist != 1 && m->persist != 8 && m->persist != 9 && m->persist != 10 && m->persist != 11) why = "taco_debug_set_persistent(" + std::to_string(m->persist) + ")";
     if (why.empty() && (c.rnn != GX_H || !c.gd_pack)) why = "post_rnn_size " + std::to_string(c.rnn) + " != 256";
     if (why.empty() && T_mel < 2) why = "fewer than 2 frames";
     int RG = 1;

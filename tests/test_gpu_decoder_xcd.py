@@ -368,8 +368,8 @@ def test_post_net_scan_spread_over_the_chip(B):
     n = int(m._lib.taco_stage_workspace_bytes(m._handle, B, T))
     ws = torch.empty((n,), dtype=torch.uint8, device="cuda")
     got = {}
-    # 1: the default; 10: k_bigru_oct wherever it fits; 11: k_bigru_duo; 13: k_bigru_dir wherever it fits (the directions on different waves, no barrier, operands polled into registers); 14: k_bigru_ks from 17 to 32 rows (the candidate split by rows: one exchange per direction and step); 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU; 7: one CU per chain
-    for persist in (1, 1, 10, 10, 11, 11, 13, 13, 14, 14, 8, 8, 9, 7):
+    # 1: the default; 10: k_bigru_oct wherever it fits; 11: k_bigru_duo; 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU; 7: one CU per chain
+    for persist in (1, 1, 10, 10, 11, 11, 8, 8, 9, 7):
         m._lib.taco_debug_set_persistent(m._handle, persist)
         for tag, (lp, ip) in (("plain", (ptr(None), ptr(None))), ("ragged", (ptr(ld), ptr(idv)))):
             out = torch.full((B, T, 2 * H), float("nan"), device="cuda")
@@ -381,7 +381,7 @@ def test_post_net_scan_spread_over_the_chip(B):
     v = (C.c_int * 16)()
     taco_amd._lib.check(m._lib.taco_debug_decoder_info(m._handle, v))
     for tag, ref in (("plain", O.bidirectional_gru(x, None, w, "post_cbhg/bigru")), ("ragged", O.bidirectional_gru(x, lens, w, "post_cbhg/bigru", init))):
-        for persist, name in ((1, "the default scan"), (10, "k_bigru_oct"), (11, "k_bigru_duo"), (13, "k_bigru_dir"), (14, "k_bigru_ks"), (8, "k_bigru_xcd")):
+        for persist, name in ((1, "the default scan"), (10, "k_bigru_oct"), (11, "k_bigru_duo"), (8, "k_bigru_xcd")):
             a, b = got[(persist, tag)]
             assert np.array_equal(a, b), "%s is not bit-repeatable (%s)" % (name, tag)
             assert maxabs(a, ref) < 1e-4, (name, tag)

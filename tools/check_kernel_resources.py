@@ -18,7 +18,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEFAULT = os.path.join(ROOT, "multi-speaker-tacotron-tensorflow_amd", "csrc", "kernel_resources.txt")
-PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_bigru_oct", "k_bigru_dir", "k_bigru_ks", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front", "k_head_sweep")  # k_bigru_duo also matches k_bigru_duo_bwd
+PERSISTENT = ("k_bigru_xcd", "k_bigru_duo", "k_bigru_oct", "k_decoder_xcd", "k_decoder_bwd_xcd", "k_pointwise_chain", "k_cbhg_front", "k_head_sweep")  # k_bigru_duo also matches k_bigru_duo_bwd
 ALLOWED_SCRATCH = {}      # (mangled name -> bytes per lane; empty since round 4)
 
 

@@ -10,7 +10,7 @@ if "--json" in argv:
     i = argv.index("--json"); jpath = argv[i + 1]; del argv[i:i + 2]
 B = int(argv[0]) if len(argv) > 0 else 32
 T = int(argv[1]) if len(argv) > 1 else 512
-# 1: the default (k_bigru_oct from 9 to 32 rows, else k_bigru_duo); 10: k_bigru_oct wherever it fits; 11: k_bigru_duo; 12 / 13: k_bigru_dir from 9 rows / wherever it fits; 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU
+# 1: the default (k_bigru_oct from 9 to 32 rows, else k_bigru_duo); 10: k_bigru_oct wherever it fits; 11: k_bigru_duo; 8: k_bigru_xcd, one 8-wave workgroup per CU; 9: two 4-wave workgroups per CU
 PERSIST = int(argv[2]) if len(argv) > 2 else 1
 hp = taco_amd.hparams.copy(max_iters=128)
 m = taco_amd.create_model(hp); m.initialize(None, None, 1, None)
@@ -42,13 +42,7 @@ m.decoder_trace(True)
 fn(); torch.cuda.synchronize()
 tr = m.decoder_trace(True, read=True, scan=True); m.decoder_trace(False)
 m.check_device_errors()
-if PERSIST == 14 and 16 < B <= 32:      # k_bigru_ks: one exchange per direction and step
-    names = ["gates F + barrier", "partials F (+publish)", "finish B + barrier", "request + gates B + barrier", "partials B (+publish)", "finish F + barrier"]
-    d = np.diff(tr[:, :7], axis=1).astype(np.float64)
-elif PERSIST in (12, 13):      # k_bigru_dir: the stamps of one FORWARD-direction wave (no barriers: the waits are its own polls)
-    names = ["gates (+publish)", "sleep + poll r*h", "cand (+publish, store)", "sleep + poll h'"]
-    d = np.diff(tr[:, :5], axis=1).astype(np.float64)
-elif PERSIST in (1, 10, 11, 14):
+if PERSIST in (1, 10, 11):
     names = ["gates F (+publish)", "collect h'(B) + barrier", "request + gates B (+publish)", "collect r*h(F) + barrier", "request + cand F (+publish, store)",
              "collect r*h(B) + barrier", "request + cand B (+publish, store)", "collect h'(F) + barrier"]
     d = np.diff(tr[:, :9], axis=1).astype(np.float64)
@@ -58,8 +52,8 @@ else:
 step = float(np.median((tr[1:, 0] - tr[:-1, 0]).astype(np.float64)))
 scan_us = us - us_gemm
 cpu = step * T / scan_us if scan_us > 0 else 0.0
-oct_ = PERSIST in (1, 10, 12, 13, 14) and B <= 32 and (B > 8 or PERSIST in (10, 13))
-kernel = "k_bigru_ks" if (PERSIST == 14 and 16 < B <= 32) else (("k_bigru_dir<%d>" if PERSIST in (12, 13) else "k_bigru_oct<%d>") % (4 if B > 16 else 2 if B > 8 else 1)) if oct_ else ("k_bigru_duo<%d>" % max(1, 1 << int(np.ceil(np.log2(max(1, (B + 7) // 8)))))) if PERSIST in (1, 10, 11, 12, 13, 14) else "k_bigru_xcd"
+oct_ = PERSIST in (1, 10) and B <= 32 and (B > 8 or PERSIST == 10)
+kernel = ("k_bigru_oct<%d>" % (4 if B > 16 else 2 if B > 8 else 1)) if oct_ else ("k_bigru_duo<%d>" % max(1, 1 << int(np.ceil(np.log2(max(1, (B + 7) // 8)))))) if PERSIST in (1, 10, 11) else "k_bigru_xcd"
 print("B=%d T=%d persist %d kernel %s: %.1f us total (input projection %.1f + scan %.1f = %.3f us per step), step = %.0f clocks, %.0f clocks per us"
       % (B, T, PERSIST, kernel, us, us_gemm, scan_us, scan_us / T, step, cpu))
 med = np.median(d[1:], axis=0)
