@@ -1751,7 +1751,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     TRY(dx_launch(m, st, enc_out, speaker_id, nullptr, B, T_in, n, manual, mel, align_out, dbg, dbgw, w.keys, w.nz, w.xbuf, w.dxctl, w.rowbias,
                   dv ? spk->vec[2] : nullptr, dv ? spk->vec[3] : nullptr, dv ? spk->vec[4] : nullptr, teacher ? &ta : nullptr));
     if (stop_step) {
-      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(1024), 0, st, w.nz, B, n, stop_step);
       HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1835,7 +1835,7 @@ static int decoder_forward(const taco_model* m, hipStream_t st, const float* enc
     }
   }
   if (stop_step) {
-    hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, w.nz, B, n, stop_step);
+    hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(1024), 0, st, w.nz, B, n, stop_step);
     HIPCHK(hipGetLastError());
   }
   return 0;
@@ -1930,7 +1930,7 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
     TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, nullptr, nullptr, w.dec, true, &w.enc.spk));
     TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
     if (stop) {
-      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(256), 0, st, (const int*)w.dec.nz, B, n, stop, (const unsigned*)m->d_err);
+      hipLaunchKernelGGL(k_stop_step, dim3(1), dim3(1024), 0, st, (const int*)w.dec.nz, B, n, stop, (const unsigned*)m->d_err);
       HIPCHK(hipGetLastError());
     }
     return 0;

@@ -7,7 +7,8 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 [ -x tools/time_stages_native ] && timeout 60 ./tools/time_stages_native > $out/time_stages_native.txt 2>&1     # C ABI only, no Python: seconds
 timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
-for w in C1 C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
+timeout 300 python bench.py --workload C1 --steps 12 --warmup 3 > $out/bench_C1.json 2>> $out/bench_C2.err      # (with its CPU baseline: one utterance is cheap)
+for w in C3 C5; do timeout 300 python bench.py --no-cpu-baseline --workload $w --steps 12 --warmup 3 > $out/bench_$w.json 2>> $out/bench_C2.err; done
 timeout 300 python bench.py --no-cpu-baseline --coalesce 2 --steps 24 --warmup 4 > $out/bench_C2_coalesce2.json 2>> $out/bench_C2.err
 timeout 300 python tools/bench_train.py > $out/train_step.json 2> $out/train.err
 timeout 300 python tools/bench_train.py --deterministic 0 > $out/train_step_atomics.json 2>> $out/train.err      # fp32 atomics instead of the ordered sums (the default since round 4)
@@ -18,7 +19,8 @@ timeout 300 python tools/trace_bptt.py 2>&1 | grep -v amdgpu.ids > $out/bptt_tim
 timeout 300 python tools/bench_audio.py > $out/griffin_lim.json 2> $out/audio.err
 # round 3: scan timelines (k_bigru_duo vs k_bigru_xcd), manual / simple decoder modes, feed-forward-under-the-scan experiment, training kernel statistics
 rm -f $out/scan_timeline.json
-{ for p in 1 10 11 8; do python tools/trace_bigru.py 32 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 16 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 64 512 $p --json $out/scan_timeline.json; python tools/trace_bigru.py 8 4000 $p --json $out/scan_timeline.json; done; } 2>&1 | grep -v amdgpu.ids > $out/scan_timeline.txt
+# round 5: k_bigru_oct (persist 1 from 9 to 32 rows; 10: wherever it fits) vs k_bigru_duo (11) vs k_bigru_xcd (8); --json feeds bench.py's latency_floor_ms
+{ for sh in "32 512 1" "16 512 1" "64 512 1" "8 4000 1" "32 512 11" "16 512 11" "8 4000 10" "32 512 8"; do python tools/trace_bigru.py $sh --json $out/scan_timeline.json; done; } 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|warnings.warn" > $out/scan_timeline.txt
 timeout 300 python tools/time_manual.py 2>&1 | grep -v amdgpu.ids > $out/time_manual.txt
 timeout 300 python tools/overlap_scan_ff.py 2>&1 | grep -v amdgpu.ids > $out/overlap_scan_ff.txt
 timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $out/time_stages.txt
