@@ -1,7 +1,13 @@
 #!/bin/bash
-# round 5, GPU call H: k_bigru_ks (one exchange per direction and step) vs k_bigru_oct
-out=gpurun_out/r05_h; mkdir -p $out
+# round 5: the two bench lines whose CPU baseline ran into the collection's time limit (all host threads on small ops), re-run with the bounded arms
+out=gpurun_out/r05_v1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest -x -q -m gpu "tests/test_gpu_decoder_xcd.py::test_post_net_scan_spread_over_the_chip" -s > $out/pytest_h.txt 2>&1; echo "pytest rc=$?" >> $out/pytest_h.txt
-{ for p in 1 14; do python tools/trace_bigru.py 32 512 $p; python tools/trace_bigru.py 32 512 $p; done; python tools/trace_bigru.py 20 512 14; } 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|warnings.warn" > $out/scan_timeline.txt
-grep -E "passed|failed|rc=|Error|assert|rror" $out/pytest_h.txt | tail; cat $out/scan_timeline.txt
+nproc
+timeout 900 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
+timeout 600 python bench.py --workload C1 --steps 12 --warmup 3 > $out/bench_C1.json 2>> $out/bench_C2.err
+python - <<'PY'
+import json
+for f in ("bench_C2","bench_C1"):
+    d=json.load(open("gpurun_out/r05_v1/%s.json"%f)); print(f, d["value"], d["ms_per_step"], d["roofline"]["frac"]); print(json.dumps(d["cpu_baseline"])[:900])
+d=json.load(open("gpurun_out/r05_v1/bench_C2.json")); print(d["roofline"]["latency_floor_ms"]); print({k:(v.get("forward_ms"), v.get("mel_frames_per_s"), v.get("ms_per_step")) for k,v in d["companions"].items()})
+PY
