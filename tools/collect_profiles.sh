@@ -28,10 +28,10 @@ timeout 300 python tools/time_stages.py C2 32 64 2>&1 | grep -v amdgpu.ids > $ou
 # timeline of one workgroup (needs the -DTACO_TRACE build next to the library), per-layer timings, the C4 line of bench.py
 timeout 300 python tools/time_front.py 2>&1 | grep -v amdgpu.ids > $out/time_front.txt
 timeout 300 python tools/time_decoder.py C2:8 --json $out/decoder_timeline.json 2>&1 | grep -v amdgpu.ids > $out/decoder_timeline.txt       # per-phase clocks of one decoder step; 64-row pass at eight rows per group
-[ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_front.py 2>&1 | grep -v amdgpu.ids > $out/front_timeline.txt
+[ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_front.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|load_library()" > $out/front_timeline.txt
 [ -x tools/time_layers_native ] && timeout 120 ./tools/time_layers_native 20 > $out/time_layers_native.txt 2>&1
 [ -x tools/time_train_native ] && timeout 120 ./tools/time_train_native > $out/time_train_native.txt 2>&1      # one C4-shard training step through the C ABI, no Python
-[ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_chain.py 2>&1 | grep -v amdgpu.ids > $out/chain_timeline.txt
+[ -f multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so ] && TACO_LIB=$GRAFT_REPO_ROOT/multi-speaker-tacotron-tensorflow_amd/csrc/libtaco_hip_trace.so timeout 200 python tools/trace_chain.py 2>&1 | grep -v "amdgpu.ids\|RuntimeWarning\|load_library()" > $out/chain_timeline.txt
 timeout 600 python bench.py --workload C4 --steps 10 --warmup 2 > $out/bench_C4.json 2>> $out/bench_C2.err
 timeout 400 rocprofv3 --kernel-trace --stats -d $out/tks -o tks --output-format csv -- python tools/bench_train.py --steps 4 --warmup 1 > $out/tks.log 2>&1
 cp $out/tks/*kernel_stats.csv $out/train_kernel_stats.csv 2>/dev/null; rm -rf $out/tks

@@ -26,16 +26,22 @@ def main():
     fk = f.groupby(f.Kernel_Name.str.slice(0, 46)).Counter_Value.sum() / nfwd_f
     wk = w.groupby(w.Kernel_Name.str.slice(0, 46)).Counter_Value.sum() / nfwd_w
     calls = f.groupby(f.Kernel_Name.str.slice(0, 46)).size() / nfwd_f
-    fetch_kb, write_kb = float(fk.sum()), float(wk.sum())
+    # the forward's own kernels only: torch's elementwise / reduce kernels (bench.py's isfinite checks) and the runtime's copy / fill kernels
+    # run in the same process but are not part of a forward
+    own = lambda k: not (k.startswith("void at::native") or k.startswith("__amd_rocclr"))
+    fetch_kb, write_kb = float(sum(v for k, v in fk.items() if own(k))), float(sum(v for k, v in wk.items() if own(k)))
+    other_kb = float(sum(2 * v for k, v in fk.items() if not own(k)) + sum(v for k, v in wk.items() if not own(k)))
     rec = {"workload": "C2", "kernel_source_hash": source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), %d forwards averaged" % nfwd_f,
            "fetch_size_reported_bytes": fetch_kb * 1024, "fetch_size_corrected_bytes": 2 * fetch_kb * 1024, "write_size_bytes": write_kb * 1024,
            "traffic_bytes_per_forward": 2 * fetch_kb * 1024 + write_kb * 1024,
+           "excluded_not_part_of_a_forward_bytes": other_kb * 1024,
            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of a wide coalesced stream); counters are L2<->fabric "
                    "requests, Infinity-Cache hits included; WRITE_SIZE uncalibrated"}
     json.dump(rec, open(outp + ".json", "w"), indent=1)
     with open(outp + ".txt", "w") as fh:
         fh.write("rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2), bench.py C2 --lanes 1, per forward (%d forwards averaged), KB as reported\n" % nfwd_f)
-        fh.write("total: FETCH_SIZE %.1f MB reported -> %.1f MB corrected (x2, gfx950); WRITE_SIZE %.1f MB\n" % (fetch_kb / 1024, 2 * fetch_kb / 1024, write_kb / 1024))
+        fh.write("total of the forward's own kernels (torch's and the runtime's kernels of the same process excluded: %.1f MB): FETCH_SIZE %.1f MiB reported -> %.1f MiB corrected (x2, gfx950); WRITE_SIZE %.1f MiB; traffic = %.3f GB (10^9 bytes) per forward\n"
+                 % (other_kb * 1024 / 1e6, fetch_kb / 1024, 2 * fetch_kb / 1024, write_kb / 1024, (2 * fetch_kb + write_kb) * 1024 / 1e9))
         for k in fk.sort_values(ascending=False).index:
             fh.write("%-48s calls/fwd %6.0f  fetch %10.1f KB/fwd  write %10.1f KB/fwd\n" % (k, calls.get(k, 0), fk[k], wk.get(k, 0.0)))
     print(json.dumps(rec))
