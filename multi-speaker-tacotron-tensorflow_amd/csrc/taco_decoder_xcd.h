@@ -158,6 +158,7 @@ struct DxArgs {
   float* mel; float* hist; int* nz; float* dbg;
   unsigned long long* xbuf; unsigned* ctl; unsigned* err; long long* trace;
   int B, T_in, n, rM, att_type, grp0, ngroups, force_wt, dbgw;
+  int trc_member, trc_tid;                             // TRACE instantiation: the (member, thread) of group 0 that stamps (default 0, 0; TACO_TRACE_MEMBER / TACO_TRACE_TID)
 };
 
 #define DX_DPP0(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, false))
@@ -794,7 +795,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
   const int cb = asl % Pc, pb = asl / Pc;                // score role: channel block, position block
   const int ps0 = pb * TS, psn = max(0, min(T - ps0, TS));
   const int brow = row0 + arow;                          // its batch row (may be >= B: padding)
-  const bool tracer = TRACE && a.trace && ga == 0 && member == 0 && tid == 0;
+  const bool tracer = TRACE && a.trace && ga == 0 && member == a.trc_member && tid == a.trc_tid;
 
   // ---- weights, resident for the whole loop ----
   taco_f32x2 WP[DX_NWP];      // register pairs in the order the passes consume them (dxw_src)

@@ -1652,6 +1652,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   a.keys = keys; a.values = enc_out; a.h_att0 = h_att0; a.h10 = h10; a.h20 = h20;
   a.mel = mel; a.hist = align_out; a.nz = nz; a.dbg = dbg; a.dbgw = dbgw;
   a.xbuf = xbuf; a.ctl = dxctl; a.err = m->d_err; a.trace = m->trace_on ? m->d_trace : nullptr;
+  if (a.trace) { const char* e = getenv("TACO_TRACE_MEMBER"); a.trc_member = e ? atoi(e) : 0; e = getenv("TACO_TRACE_TID"); a.trc_tid = e ? atoi(e) : 0; }
   a.B = B; a.T_in = T_in; a.n = n; a.rM = m->hp.num_mels * m->hp.reduction_factor; a.att_type = m->hp.attention_type;
   a.mels = m->hp.num_mels;
   a.grp0 = 0; a.ngroups = cdiv(B, RG); a.force_wt = m->dx_mode == 2 ? 1 : 0;
