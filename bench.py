@@ -386,7 +386,10 @@ def main():
         if dist is not None:
             dist.barrier()
         if rank == 0:
-            print(json.dumps({"selftest": "launcher", "world_size": world, "n_gpus": args.gpus, "max_over_ranks": t}))
+            Bw = WORKLOADS[args.workload][0]
+            rows = Bw // world if args.scaling == "strong" else Bw        # the sharding rule of the timed path (below)
+            print(json.dumps({"selftest": "launcher", "world_size": world, "n_gpus": args.gpus, "max_over_ranks": t, "scaling": args.scaling,
+                              "rows_per_gpu": rows, "global_batch": rows * world}))
         if dist is not None:
             dist.destroy_process_group()
         return

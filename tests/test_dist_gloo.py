@@ -102,6 +102,23 @@ def test_bench_spawns_its_own_ranks():
     assert rec["world_size"] == 2 and rec["n_gpus"] == 2 and rec["max_over_ranks"] == 2.0
 
 
+def test_bench_strong_and_weak_scaling_shard_the_batch_as_survey_8e_says():
+    """SURVEY 8e asks for both: weak (per-GPU batch held at the workload's 32 rows: global batch N x 32) and strong (the workload's batch is the
+    GLOBAL batch, split over the ranks).  The launcher self-test reports the sharding rule of the timed path for two ranks."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for scaling, rows, glob in (("weak", 32, 64), ("strong", 16, 32)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", scaling, "--selftest-launcher"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert rec["world_size"] == 2 and rec["scaling"] == scaling and rec["rows_per_gpu"] == rows and rec["global_batch"] == glob, rec
+
+
 def test_bench_single_process_selftest():
     import json
     import subprocess
