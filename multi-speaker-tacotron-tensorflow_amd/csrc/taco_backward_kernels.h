@@ -10,17 +10,23 @@
 // map[i] = 1 + flat index of the parameter that pack element i copies (the host packers run once over
 // index-valued tensors); anything else = zero padding / unused.
 // Indices NP + 1 .. NP + NF address a second source F (computed values: the GRU-1 fold of the persistent decoder, k_dx_fold).
+__device__ __forceinline__ float pack_pick(float v, const float* __restrict__ P, unsigned NP, const float* __restrict__ F, unsigned NF) {
+  float o = 0.f;
+  if (v >= 1.f && v <= (float)(NP + NF)) {
+    const unsigned iv = (unsigned)v;
+    if ((float)iv == v) o = iv <= NP ? P[iv - 1] : F[iv - NP - 1];
+  }
+  return o;
+}
 __global__ __launch_bounds__(256) void k_pack_gather(const float* __restrict__ map, const float* __restrict__ P,
                                                     float* __restrict__ arena, size_t n, unsigned NP, const float* __restrict__ F, unsigned NF) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float v = map[i];
-    float o = 0.f;
-    if (v >= 1.f && v <= (float)(NP + NF)) {
-      const unsigned iv = (unsigned)v;
-      if ((float)iv == v) o = iv <= NP ? P[iv - 1] : F[iv - NP - 1];
-    }
-    arena[i] = o;
+  // four pack elements per thread: the map is read and the arena written 16 bytes at a time (both hipMalloc'ed), the gathers are scalar
+  const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += stride) {
+    const float4 v = *reinterpret_cast<const float4*>(map + 4 * q);
+    *reinterpret_cast<float4*>(arena + 4 * q) = make_float4(pack_pick(v.x, P, NP, F, NF), pack_pick(v.y, P, NP, F, NF), pack_pick(v.z, P, NP, F, NF), pack_pick(v.w, P, NP, F, NF));
   }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const size_t i = 4 * n4 + threadIdx.x; arena[i] = pack_pick(map[i], P, NP, F, NF); }
 }
 // The split-bf16 packs of the training model (k_gemm_bf3 operands) from the live parameters: element e of the concatenated index
 // list belongs to the segment s with segs[s].start <= e < start + count and becomes hi = bf16(w), lo = bf16(w - hi) at position
@@ -30,20 +36,52 @@ __device__ __forceinline__ unsigned short bf16_rne_dev(float f) {
   const unsigned u = __float_as_uint(f);
   return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
+__device__ __forceinline__ void bf3_split(float w, unsigned short& hb, unsigned short& lb, unsigned short& tb) {
+  hb = bf16_rne_dev(w);
+  lb = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16));
+  tb = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16) - __uint_as_float((unsigned)lb << 16));
+}
 __global__ __launch_bounds__(256) void k_bf3_gather(const unsigned* __restrict__ idx, const Bf3Seg* __restrict__ segs, int nseg, const float* __restrict__ P,
                                                    float* __restrict__ arena, size_t n, unsigned NP) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
-    int lo = 0, hi = nseg - 1;
+  // eight elements per thread: ONE segment search, two 16-byte index loads and three 16-byte stores where the eight lie in one segment at a
+  // multiple of 8 from its start and the segment's arrays are 16-byte aligned (the packs' fragments are 8 bf16 wide); element by element otherwise
+  auto seg_of = [&](size_t e) { int lo = 0, hi = nseg - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((size_t)segs[mid].start <= e) lo = mid; else hi = mid - 1; }
-    const Bf3Seg sg = segs[lo];
-    const unsigned i = idx[e];
-    const float w = (i >= 1u && i <= NP) ? P[i - 1] : 0.f;
-    const unsigned short hb = bf16_rne_dev(w);
-    const unsigned short lb = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16));
-    const size_t k = e - sg.start;
-    reinterpret_cast<unsigned short*>(arena + sg.hi)[k] = hb;
-    reinterpret_cast<unsigned short*>(arena + sg.lo)[k] = lb;
-    reinterpret_cast<unsigned short*>(arena + sg.l3)[k] = bf16_rne_dev(w - __uint_as_float((unsigned)hb << 16) - __uint_as_float((unsigned)lb << 16));
+    return lo; };
+  const size_t n8 = (n + 7) >> 3, stride = (size_t)gridDim.x * 256;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n8; q += stride) {
+    const size_t e0 = 8 * q;
+    const Bf3Seg sg = segs[seg_of(e0)];
+    const size_t k = e0 - sg.start;
+    if (e0 + 8 <= n && k + 8 <= (size_t)sg.count && (k & 7) == 0 && ((sg.hi | sg.lo | sg.l3) & 3) == 0) {
+      const uint4 i0 = *reinterpret_cast<const uint4*>(idx + e0), i1 = *reinterpret_cast<const uint4*>(idx + e0 + 4);
+      const unsigned ii[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = (ii[u] >= 1u && ii[u] <= NP) ? P[ii[u] - 1] : 0.f;
+      unsigned hh[4], ll[4], tt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        unsigned short h0, l0, t0, h1, l1, t1;
+        bf3_split(w[2 * u], h0, l0, t0); bf3_split(w[2 * u + 1], h1, l1, t1);
+        hh[u] = (unsigned)h0 | ((unsigned)h1 << 16); ll[u] = (unsigned)l0 | ((unsigned)l1 << 16); tt[u] = (unsigned)t0 | ((unsigned)t1 << 16);
+      }
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(arena + sg.hi) + k) = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(arena + sg.lo) + k) = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+      *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(arena + sg.l3) + k) = make_uint4(tt[0], tt[1], tt[2], tt[3]);
+      continue;
+    }
+    for (size_t e = e0; e < e0 + 8 && e < n; ++e) {
+      const Bf3Seg s1 = segs[seg_of(e)];
+      const unsigned i = idx[e];
+      const float w = (i >= 1u && i <= NP) ? P[i - 1] : 0.f;
+      unsigned short hb, lb, tb;
+      bf3_split(w, hb, lb, tb);
+      const size_t k1 = e - s1.start;
+      reinterpret_cast<unsigned short*>(arena + s1.hi)[k1] = hb;
+      reinterpret_cast<unsigned short*>(arena + s1.lo)[k1] = lb;
+      reinterpret_cast<unsigned short*>(arena + s1.l3)[k1] = tb;
+    }
   }
 }
 // The concat projection folded into decoder GRU 1 (taco_model_finalize does it on the host, in double, for inference):
@@ -87,25 +125,70 @@ __global__ __launch_bounds__(256) void k_dx_fold(const float* __restrict__ Wc, c
 struct ColArgs { const float* a; const float* b; const float* mu; const float* rstd; float* out1; float* out2;
                  int lda, ldb, M, C, mode, rpb; float* part; };
 __device__ __forceinline__ void colsum_body(const ColArgs& g, int bx, int by) {
-  __shared__ float s1[4][64], s2[4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = bx * 64 + cl;
-  const int m0 = by * g.rpb, m1 = min(g.M, m0 + g.rpb);
-  float a1 = 0.f, a2 = 0.f;
-  if (c < g.C) {
-    const float mu = g.mu ? g.mu[c] : 0.f, rs = g.rstd ? g.rstd[c] : 1.f;
-    for (int m = m0 + rl; m < m1; m += 4) {
-      const float av = g.a[(size_t)m * g.lda + c];
-      if (g.mode == 0) a1 += av;
-      else if (g.mode == 1) { const float d = av - mu; a2 += d * d; }
-      else { const float bv = g.b[(size_t)m * g.ldb + c]; a1 += bv; a2 += bv * (av - mu) * rs; }
+  // 64 columns x rpb rows per workgroup.  Where the rows allow 16-byte loads (strides and C multiples of 4, aligned bases) a thread owns
+  // FOUR columns and every 16th row (a wave reads four 256-byte row segments per instruction, four rows in flight per thread);
+  // otherwise (the linear head's 1025 columns) one column and every 4th row.  Either way a column's rows are added in an order that
+  // depends on the shapes only: per-thread partial sums, then the row lanes in ascending order (fixed order: bit-reproducible).
+  __shared__ float s1[16][64], s2[16][64];
+  const int m0 = by * g.rpb, m1 = min(g.M, m0 + g.rpb), c0 = bx * 64;
+  const bool vec = (g.C & 3) == 0 && (g.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(g.a) & 15) == 0 &&
+                   (g.mode != 2 || ((g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.b) & 15) == 0));
+  int nl;
+  if (vec) {
+    nl = 16;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4, c = c0 + 4 * cq;
+    float4 a1 = make_float4(0.f, 0.f, 0.f, 0.f), a2 = a1;
+    if (c < g.C) {
+      const float* pa = g.a + (size_t)(m0 + rl) * g.lda + c;
+      const size_t sa = (size_t)16 * g.lda;
+      const int n = m1 - m0 - rl > 0 ? (m1 - m0 - rl + 15) >> 4 : 0;
+      if (g.mode == 0) {
+#pragma unroll 4
+        for (int k = 0; k < n; ++k) { const float4 v = *reinterpret_cast<const float4*>(pa + k * sa); a1.x += v.x; a1.y += v.y; a1.z += v.z; a1.w += v.w; }
+      } else {
+        const float4 mu = g.mu ? make_float4(g.mu[c], g.mu[c + 1], g.mu[c + 2], g.mu[c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);      // (per-column vectors may sit anywhere in the flat parameter buffer)
+        if (g.mode == 1) {
+#pragma unroll 4
+          for (int k = 0; k < n; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(pa + k * sa);
+            const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+            a2.x += dx * dx; a2.y += dy * dy; a2.z += dz * dz; a2.w += dw * dw;
+          }
+        } else {
+          const float4 rs = g.rstd ? make_float4(g.rstd[c], g.rstd[c + 1], g.rstd[c + 2], g.rstd[c + 3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+          const float* pb = g.b + (size_t)(m0 + rl) * g.ldb + c;
+          const size_t sb = (size_t)16 * g.ldb;
+#pragma unroll 4
+          for (int k = 0; k < n; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(pa + k * sa), w = *reinterpret_cast<const float4*>(pb + k * sb);
+            a1.x += w.x; a1.y += w.y; a1.z += w.z; a1.w += w.w;
+            a2.x += w.x * (v.x - mu.x) * rs.x; a2.y += w.y * (v.y - mu.y) * rs.y; a2.z += w.z * (v.z - mu.z) * rs.z; a2.w += w.w * (v.w - mu.w) * rs.w;
+          }
+        }
+      }
     }
+    *reinterpret_cast<float4*>(&s1[rl][4 * cq]) = a1; *reinterpret_cast<float4*>(&s2[rl][4 * cq]) = a2;
+  } else {
+    nl = 4;
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6, c = c0 + cl;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < g.C) {
+      const float mu = g.mu ? g.mu[c] : 0.f, rs = g.rstd ? g.rstd[c] : 1.f;
+#pragma unroll 8
+      for (int m = m0 + rl; m < m1; m += 4) {
+        const float av = g.a[(size_t)m * g.lda + c];
+        if (g.mode == 0) a1 += av;
+        else if (g.mode == 1) { const float d = av - mu; a2 += d * d; }
+        else { const float bv = g.b[(size_t)m * g.ldb + c]; a1 += bv; a2 += bv * (av - mu) * rs; }
+      }
+    }
+    s1[rl][cl] = a1; s2[rl][cl] = a2;
   }
-  s1[rl][cl] = a1; s2[rl][cl] = a2;
   __syncthreads();
-  if (rl == 0 && c < g.C) {
-    const float t1 = s1[0][cl] + s1[1][cl] + s1[2][cl] + s1[3][cl];
-    const float t2 = s2[0][cl] + s2[1][cl] + s2[2][cl] + s2[3][cl];
+  const int cl = threadIdx.x, c = c0 + cl;
+  if (cl < 64 && c < g.C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int r = 0; r < nl; ++r) { t1 += s1[r][cl]; t2 += s2[r][cl]; }
     if (g.part) {
       g.part[((size_t)by * 2 + 0) * g.C + c] = t1;
       g.part[((size_t)by * 2 + 1) * g.C + c] = t2;
@@ -132,6 +215,7 @@ __global__ void k_colsum_reduce(const float* part, int nchunks, int C, int mode,
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
   for (int k = 0; k < nchunks; ++k) { t1 += part[((size_t)k * 2 + 0) * C + c]; t2 += part[((size_t)k * 2 + 1) * C + c]; }
   if (mode != 1 && out1) out1[c] += t1;
   if (mode != 0 && out2) out2[c] += t2;
@@ -149,6 +233,7 @@ __global__ __launch_bounds__(256) void k_colsum_reduce_group(const ColRedGroup G
   const int c = (b - G.start[p]) * 256 + threadIdx.x;
   if (c >= g.C) return;
   float t1 = 0.f, t2 = 0.f;
+#pragma unroll 8
   for (int k = 0; k < g.nchunks; ++k) { t1 += g.part[((size_t)k * 2 + 0) * g.C + c]; t2 += g.part[((size_t)k * 2 + 1) * g.C + c]; }
   if (g.mode != 1 && g.out1) g.out1[c] += t1;
   if (g.mode != 0 && g.out2) g.out2[c] += t2;
@@ -196,6 +281,69 @@ __global__ void k_bn_apply(const float* a, int lda, const float* mu, const float
   if (i >= (size_t)M * C) return;
   const int m = (int)(i / C), c = (int)(i % C);
   y[(size_t)m * ldy + c] = (a[(size_t)m * lda + c] - mu[c]) * rstd[c] * gamma[c] + beta[c];
+}
+// Four columns per thread (16-byte loads and stores; C, the strides and the bases multiples of 4 floats -- the launchers in taco_train.h check
+// that and fall back to the one-element kernels): same expressions per element, no 64-bit index division.
+#define V4_INDEX(M, C) const unsigned C4_ = (unsigned)(C) >> 2, i_ = blockIdx.x * 256u + threadIdx.x; if (i_ >= (unsigned)(M) * C4_) return; \
+                       const unsigned m = i_ / C4_, c = 4u * (i_ - m * C4_)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ldp4(const float* p) { return make_float4(p[0], p[1], p[2], p[3]); }      // per-column vectors: any alignment (flat parameter buffer, no padding)
+__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__global__ __launch_bounds__(256) void k_bn_apply_v4(const float* a, int lda, const float* mu, const float* rstd, const float* gamma, const float* beta,
+                                                    float* y, int ldy, int M, int C) {
+  V4_INDEX(M, C);
+  const float4 av = ld4(a + (size_t)m * lda + c), mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(gamma + c), bv = ldp4(beta + c);
+  st4(y + (size_t)m * ldy + c, make_float4((av.x - mv.x) * rv.x * gv.x + bv.x, (av.y - mv.y) * rv.y * gv.y + bv.y,
+                                           (av.z - mv.z) * rv.z * gv.z + bv.z, (av.w - mv.w) * rv.w * gv.w + bv.w));
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_v4(const float* a, int lda, const float* dy, int ldy, const float* mu, const float* rstd, const float* gamma,
+                                                  const float* sdy, const float* sdyxh, int relu, float* dz, int ldz, int M, int C, float invM) {
+  V4_INDEX(M, C);
+  const float4 av = ld4(a + (size_t)m * lda + c), dv = ld4(dy + (size_t)m * ldy + c), mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(gamma + c),
+               s1 = ldp4(sdy + c), s2 = ldp4(sdyxh + c);
+  auto one = [&](float a_, float d_, float m_, float r_, float g_, float p_, float q_) {
+    const float ah = (a_ - m_) * r_;
+    const float da = g_ * r_ * (d_ - p_ * invM - ah * q_ * invM);
+    return (relu && !(a_ > 0.f)) ? 0.f : da;
+  };
+  st4(dz + (size_t)m * ldz + c, make_float4(one(av.x, dv.x, mv.x, rv.x, gv.x, s1.x, s2.x), one(av.y, dv.y, mv.y, rv.y, gv.y, s1.y, s2.y),
+                                            one(av.z, dv.z, mv.z, rv.z, gv.z, s1.z, s2.z), one(av.w, dv.w, mv.w, rv.w, gv.w, s1.w, s2.w)));
+}
+// The BatchNorm layers of a conv bank (one per width: column block k of a [M, K*Cw] matrix, modules.py:35-44) as ONE launch: the layers' own vectors
+// come through a pointer table (they are separate tensors of the flat parameter / gradient buffers), everything else is indexed by the full column.
+#define BNB_MAXK 16
+struct BnBank { const float* gamma[BNB_MAXK]; const float* beta[BNB_MAXK]; const float* sdy[BNB_MAXK]; const float* sdyxh[BNB_MAXK];
+                float* mov_mean[BNB_MAXK]; float* mov_var[BNB_MAXK]; int Cw; };
+__global__ __launch_bounds__(256) void k_bn_apply_bank_v4(const float* a, int lda, const float* mu, const float* rstd, const BnBank nb, float* y, int ldy, int M, int C) {
+  V4_INDEX(M, C);
+  const unsigned k = c / (unsigned)nb.Cw, cl = c - k * nb.Cw;
+  const float4 av = ld4(a + (size_t)m * lda + c), mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(nb.gamma[k] + cl), bv = ldp4(nb.beta[k] + cl);
+  st4(y + (size_t)m * ldy + c, make_float4((av.x - mv.x) * rv.x * gv.x + bv.x, (av.y - mv.y) * rv.y * gv.y + bv.y,
+                                           (av.z - mv.z) * rv.z * gv.z + bv.z, (av.w - mv.w) * rv.w * gv.w + bv.w));
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_bank_v4(const float* a, int lda, const float* dy, int ldy, const float* mu, const float* rstd, const BnBank nb,
+                                                       int relu, float* dz, int ldz, int M, int C, float invM) {
+  V4_INDEX(M, C);
+  const unsigned k = c / (unsigned)nb.Cw, cl = c - k * nb.Cw;
+  const float4 av = ld4(a + (size_t)m * lda + c), dv = ld4(dy + (size_t)m * ldy + c), mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(nb.gamma[k] + cl),
+               s1 = ldp4(nb.sdy[k] + cl), s2 = ldp4(nb.sdyxh[k] + cl);
+  auto one = [&](float a_, float d_, float m_, float r_, float g_, float p_, float q_) {
+    const float ah = (a_ - m_) * r_;
+    const float da = g_ * r_ * (d_ - p_ * invM - ah * q_ * invM);
+    return (relu && !(a_ > 0.f)) ? 0.f : da;
+  };
+  st4(dz + (size_t)m * ldz + c, make_float4(one(av.x, dv.x, mv.x, rv.x, gv.x, s1.x, s2.x), one(av.y, dv.y, mv.y, rv.y, gv.y, s1.y, s2.y),
+                                            one(av.z, dv.z, mv.z, rv.z, gv.z, s1.z, s2.z), one(av.w, dv.w, mv.w, rv.w, gv.w, s1.w, s2.w)));
+}
+__global__ void k_bn_finalize_bank(const float* mu, const float* S2, float* rstd, const BnBank nb, int C, float invM, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int k = c / nb.Cw, cl = c - k * nb.Cw;
+  const float var = S2[c] * invM;
+  rstd[c] = 1.0f / sqrtf(var + eps);
+  if (nb.mov_mean[k]) nb.mov_mean[k][cl] = nb.mov_mean[k][cl] * momentum + mu[c] * (1.f - momentum);
+  if (nb.mov_var[k]) nb.mov_var[k][cl] = nb.mov_var[k][cl] * momentum + var * (1.f - momentum);
 }
 // dz = [a > 0 if relu] * gamma*rstd * (dy - mean(dy) - ahat*mean(dy*ahat));  sdy = sum dy (= d beta), sdyxh = sum dy*ahat (= d gamma)
 __global__ void k_bn_bwd(const float* a, int lda, const float* dy, int ldy, const float* mu, const float* rstd, const float* gamma,
@@ -468,7 +616,53 @@ __global__ void k_maxpool_bwd(const float* x, const float* dp, float* dx, int M,
   }
   dx[i] = acc;
 }
+__global__ __launch_bounds__(256) void k_maxpool_fwd_v4(const float* x, float* y, int M, int T, int C, int w) {
+  V4_INDEX(M, C);
+  const int t = (int)(m % (unsigned)T), pl = (w - 1) >> 1;
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int j = 0; j < w; ++j) {
+    const int tt = t - pl + j;
+    if (tt < 0 || tt >= T) continue;
+    const float4 v = ld4(x + (size_t)((int)m - pl + j) * C + c);
+    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+  }
+  st4(y + (size_t)m * C + c, best);
+}
+__global__ __launch_bounds__(256) void k_maxpool_bwd_v4(const float* x, const float* dp, float* dx, int M, int T, int C, int w) {
+  V4_INDEX(M, C);
+  const int t = (int)(m % (unsigned)T), pl = (w - 1) >> 1;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int tp = t - (w - 1 - pl); tp <= t + pl; ++tp) {      // output positions whose window contains t
+    if (tp < 0 || tp >= T) continue;
+    int ax = -1, ay = -1, az = -1, aw = -1;
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int j = 0; j < w; ++j) {
+      const int tt = tp - pl + j;
+      if (tt < 0 || tt >= T) continue;
+      const float4 v = ld4(x + (size_t)((int)m + tt - t) * C + c);
+      if (v.x > best.x) { best.x = v.x; ax = tt; }
+      if (v.y > best.y) { best.y = v.y; ay = tt; }
+      if (v.z > best.z) { best.z = v.z; az = tt; }
+      if (v.w > best.w) { best.w = v.w; aw = tt; }
+    }
+    const float4 d = ld4(dp + (size_t)((int)m + tp - t) * C + c);
+    if (ax == t) acc.x += d.x;
+    if (ay == t) acc.y += d.y;
+    if (az == t) acc.z += d.z;
+    if (aw == t) acc.w += d.w;
+  }
+  st4(dx + (size_t)m * C + c, acc);
+}
 // highway y = H*T + x*(1-T): dcat = [dH_pre | dT_pre] (input of the transposed GEMM), dxd = direct path dy*(1-T)
+__global__ __launch_bounds__(256) void k_highway_bwd_v4(const float* dy, const float* x, const float* H, const float* Tg, float* dcat, float* dxd, int M, int D) {
+  V4_INDEX(M, D);
+  const size_t i = (size_t)m * D + c;
+  const float4 g = ld4(dy + i), h = ld4(H + i), tg = ld4(Tg + i), xv = ld4(x + i);
+  st4(dcat + (size_t)m * 2 * D + c, make_float4((h.x > 0.f) ? g.x * tg.x : 0.f, (h.y > 0.f) ? g.y * tg.y : 0.f, (h.z > 0.f) ? g.z * tg.z : 0.f, (h.w > 0.f) ? g.w * tg.w : 0.f));
+  st4(dcat + (size_t)m * 2 * D + D + c, make_float4(g.x * (h.x - xv.x) * tg.x * (1.f - tg.x), g.y * (h.y - xv.y) * tg.y * (1.f - tg.y),
+                                                    g.z * (h.z - xv.z) * tg.z * (1.f - tg.z), g.w * (h.w - xv.w) * tg.w * (1.f - tg.w)));
+  st4(dxd + i, make_float4(g.x * (1.f - tg.x), g.y * (1.f - tg.y), g.z * (1.f - tg.z), g.w * (1.f - tg.w)));
+}
 __global__ void k_highway_bwd(const float* dy, const float* x, const float* H, const float* Tg, float* dcat, float* dxd, int M, int D) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)M * D) return;
@@ -977,6 +1171,7 @@ __global__ void k_rows_reduce(const float* part, int nrows, int C, float* out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
+#pragma unroll 8
   for (int r = 0; r < nrows; ++r) s += part[(size_t)r * C + c];
   out[c] += s;
 }

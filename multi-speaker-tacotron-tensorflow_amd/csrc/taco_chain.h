@@ -29,6 +29,9 @@
 #ifndef CH_PF128
 #define CH_PF128 2
 #endif
+#ifndef CH_ROT
+#define CH_ROT 0
+#endif
 #define CH_BM 64
 enum { CH_DENSE = 0, CH_HIGHWAY = 1, CH_XPROJ = 2 };
 struct ChainLayer {
@@ -65,8 +68,11 @@ template <int TM, int LDSW, bool DUAL, int CH_PF>
 __device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned short* bhA, const unsigned short* blA, int nt,
                                             const unsigned short* bhB, const unsigned short* blB, int nt2,
                                             const unsigned short* xhi, const unsigned short* xlo, int row0,
-                                            int l31, int lh, f32x16 (&acc)[TM], f32x16 (&acc2)[TM]) {
-  auto boff = [&](int g, int t) { return ((((size_t)min(g, K16 - 1) * NT + t) * 2 + lh) * 32 + l31) * 8; };
+                                            int l31, int lh, f32x16 (&acc)[TM], f32x16 (&acc2)[TM], int rot = 0) {
+  // rot: the workgroup's first k16 step (CH_ROT): the CUs of an XCD walk the layer's K in the same order but from different starts, so
+  // that at any moment they ask the L2 for DIFFERENT 8 KB slices of the pack instead of all 32 for the same one
+  auto kstep = [&](int g) { const int gg = min(g, K16 - 1) + rot; return gg >= K16 ? gg - K16 : gg; };
+  auto boff = [&](int g, int t) { return ((((size_t)kstep(g) * NT + t) * 2 + lh) * 32 + l31) * 8; };
   uint4 ph, pl, ph2, pl2, qh, ql, qh2, ql2;
   ph2 = pl2 = qh2 = ql2 = make_uint4(0, 0, 0, 0);
   auto loadb = [&](int g, uint4& h, uint4& l, uint4& h2, uint4& l2) {
@@ -79,7 +85,7 @@ __device__ __forceinline__ void ch_mma_loop(int K16, int NT, const unsigned shor
     bf16x8 ah[TM], al[TM];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
-      const int off = (row0 + tm * 32 + l31) * LDSW + 16 * g + 8 * lh;
+      const int off = (row0 + tm * 32 + l31) * LDSW + 16 * kstep(g) + 8 * lh;
       ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xhi + off));
       al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xlo + off));
     }
@@ -410,8 +416,8 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
-        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
-        else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);     // the odd group: one matrix
+        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
+        else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);     // the odd group: one matrix
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif
@@ -440,7 +446,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       const float bia = L.bias ? L.bias[col] : 0.f;
       if (dual) {
         const float bia2 = L.bias2 ? L.bias2[col] : 0.f;
-        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
             xreg[tm][r] = Hh * Tg + xreg[tm][r] * (1.f - Tg);
           }
       } else {
-        ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2);
+        ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif

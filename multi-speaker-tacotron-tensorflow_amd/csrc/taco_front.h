@@ -21,6 +21,9 @@
 // adds the parts in a fixed order and applies proj_1's own bias -> ReLU -> BatchNorm.  No atomics: bit-reproducible.
 // Neither phase needs per-fragment padding masks: a tile never crosses a batch row, and what lies outside the row is zero in LDS.
 #pragma once
+#ifndef FR_ROT
+#define FR_ROT 0
+#endif
 #include "taco_kernels.h"
 
 #define FR_BM 128          // frames of proj_1 output per workgroup
@@ -174,7 +177,11 @@ __global__ __launch_bounds__(512) void k_cbhg_front(const FrArgs a_in) {
     while (clock64() - c0 < a_in.delay) __builtin_amdgcn_s_sleep(8);
   }
 
-  for (int ci = c_begin; ci < c_end; ++ci) {
+  // FR_ROT: the workgroups of an XCD (one part: the same chunks) start at different chunks, so that they do not all ask the L2 for
+  // the same weight slices at the same moment; a workgroup's summation order over its chunks is fixed by its id (bit-reproducible)
+  const int nchunks = c_end - c_begin, crot = FR_ROT ? (int)(blockIdx.x >> 3) % max(nchunks, 1) : 0;
+  for (int cj = 0; cj < nchunks; ++cj) {
+    const int ci = c_begin + (cj + crot >= nchunks ? cj + crot - nchunks : cj + crot);
     const FrChunk ch = a_in.ch[ci];
     FrWidth W = a_in.w[ch.wi];
     PIN(W.wh); PIN(W.wl); PIN(W.bias); PIN(W.scale); PIN(W.shift);

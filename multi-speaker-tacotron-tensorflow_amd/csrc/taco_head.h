@@ -13,6 +13,9 @@
 #pragma once
 #include "taco_kernels.h"
 
+#ifndef HD_ROT
+#define HD_ROT 0
+#endif
 #define HD_BM 64
 #define HD_KMAX 512      // widest input (the planes of 64 rows x 512 inputs take 133 KB of LDS)
 #define HD_PF 2          // register sets of weight fragments per wave: the fragments of step g + 1 are requested before step g is multiplied (two waves per SIMD cover each other; deeper rings measured the same in k_pointwise_chain and cost registers the interleaved stores need)
@@ -78,14 +81,17 @@ __global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
   const int NTF = N / 32, npair = (NTF + 1) / 2;
   const int mypass = wave < npair ? (npair - 1 - wave) / 8 + 1 : 0;
   const int nsteps = mypass * K16;
+  // HD_ROT: the workgroups of an XCD start their sweep at different passes (the L2 is asked for different column tiles at a time)
+  const int prot = HD_ROT ? (int)(blockIdx.x >> 3) % max(mypass, 1) : 0;
+  auto pass_of = [&](int p) { const int q = p + prot; return q >= mypass ? q - mypass : q; };
   auto bofs = [&](int s) {                                     // flat step (pass, k16) -> element offset of the lane's fragment of the pair's first tile
-    const int sc = min(s, nsteps - 1), p = sc / K16, g = sc - p * K16, t0 = 2 * (wave + 8 * p);
+    const int sc = min(s, nsteps - 1), p = sc / K16, g = sc - p * K16, t0 = 2 * (wave + 8 * pass_of(p));
     return ((((size_t)g * NT + t0) * 2 + lh) * 32 + l31) * 8;
   };
   uint4 rh[HD_PF][2], rl[HD_PF][2];
   auto loadb = [&](int s, uint4 (&h)[2], uint4 (&l)[2]) {
     const size_t o = bofs(s);
-    const int sc = min(s, nsteps - 1), t1 = 2 * (wave + 8 * (sc / K16)) + 1;
+    const int sc = min(s, nsteps - 1), t1 = 2 * (wave + 8 * pass_of(sc / K16)) + 1;
     const size_t o1 = o + (t1 < NT ? 512 : 0);                 // (the second tile of the last pair may not exist: its products are never stored)
     h[0] = *reinterpret_cast<const uint4*>(gbh + o); l[0] = *reinterpret_cast<const uint4*>(gbl + o);
     h[1] = *reinterpret_cast<const uint4*>(gbh + o1); l[1] = *reinterpret_cast<const uint4*>(gbl + o1);
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
 #ifdef TACO_TRACE
     HTRC(trci); ++trci;
 #endif
-    const int t0 = 2 * (wave + 8 * p);
+    const int t0 = 2 * (wave + 8 * pass_of(p));
     int l31e = l31, lhe = lh;                                  // (opaque per pass: the output addresses are formed here, not kept across the sweep)
     asm volatile("" : "+v"(l31e), "+v"(lhe));
     if (inter && p + 1 < mypass) {                             // hand the tile to the next pass's loop

@@ -185,6 +185,7 @@ static int build_train_packs(taco_model* m) {
 // launch helpers
 // ---------------------------------------------------------------------------------------------------------------
 #define EWGRID(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256)
+static inline bool al16h(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }      // may a matrix be read four columns at a time (the _v4 kernels)
 // Deterministic reductions (taco_train_set_deterministic): the sums over rows that normally leave their workgroups through fp32
 // atomics (weight gradients, bias / BatchNorm sums, embedding gradients, d attention_v) are written as per-slice partials into this
 // scratch and added up in a fixed order by a second launch -- the step becomes run-to-run reproducible, as the reference's
@@ -466,6 +467,18 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
       hipLaunchKernelGGL(k_bn_sync_combine, EWGRID(cols[i]), 0, st, pack, (const float*)x.p(names[i] + "/moving_mean"), mu, scratch + C, C, c0, cols[i],
                          (float)M, (float)x.t->sync_world);
   }
+  bool even = nnames > 1 && nnames <= BNB_MAXK;
+  for (int i = 1; i < nnames; ++i) even = even && cols[i] == cols[0];
+  if (even) {                          // the layers of a conv bank: one launch for all of them
+    BnBank nb; memset(&nb, 0, sizeof nb); nb.Cw = cols[0];
+    for (int i = 0; i < nnames; ++i) {
+      nb.mov_mean[i] = x.update_moving ? x.p(names[i] + "/moving_mean") : (float*)nullptr;
+      nb.mov_var[i] = x.update_moving ? x.p(names[i] + "/moving_variance") : (float*)nullptr;
+    }
+    hipLaunchKernelGGL(k_bn_finalize_bank, EWGRID(C), 0, st, mu, scratch + C, rstd, nb, C, invM, 1e-3f, 0.99f);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   int c0 = 0;
   for (int i = 0; i < nnames; ++i) {   // one BatchNorm layer per column block (conv bank) or the whole matrix
     // forward-only passes (loss fetches, the test model, a capture warm-up) leave the moving statistics alone, as the reference does
@@ -487,12 +500,18 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
     // column block k-1 of the concatenation belongs to conv1d_k (modules.py:35-44)
     for (int k = 1; k <= c.K; ++k) { names.push_back(sc + "/conv_bank/conv1d_" + std::to_string(k)); cols.push_back(c.C); }
     TRY(bn_stats(x, w.bank_a, KC, M, KC, w.bank_mu, w.bank_rs, w.stat, names.data(), cols.data(), c.K));
+    if (c.K <= BNB_MAXK && (c.C & 3) == 0 && al16h(w.bank_a) && al16h(w.bank_y)) {      // all widths in one launch, four columns per thread
+      BnBank nb; memset(&nb, 0, sizeof nb); nb.Cw = c.C;
+      for (int k = 1; k <= c.K; ++k) { nb.gamma[k - 1] = x.p(names[k - 1] + "/gamma"); nb.beta[k - 1] = x.p(names[k - 1] + "/beta"); }
+      hipLaunchKernelGGL(k_bn_apply_bank_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_a, KC, (const float*)w.bank_mu, (const float*)w.bank_rs, nb, w.bank_y, KC, M, KC);
+    } else
     for (int k = 1; k <= c.K; ++k) {
       const int c0 = (k - 1) * c.C;
       hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * c.C), 0, st, w.bank_a + c0, KC, w.bank_mu + c0, w.bank_rs + c0,
                          x.p(names[k - 1] + "/gamma"), x.p(names[k - 1] + "/beta"), w.bank_y + c0, KC, M, c.C);
     } }
-  hipLaunchKernelGGL(k_maxpool_fwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.pool, M, T, KC, c.maxpool);
+  if ((KC & 3) == 0 && al16h(w.bank_y) && al16h(w.pool)) hipLaunchKernelGGL(k_maxpool_fwd_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_y, w.pool, M, T, KC, c.maxpool);
+  else hipLaunchKernelGGL(k_maxpool_fwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.pool, M, T, KC, c.maxpool);
   HIPCHK(hipGetLastError());
   const float* cur = w.pool; int curd = KC;
   for (int i = 0; i < c.nproj; ++i) {
@@ -501,7 +520,9 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
     GemmCall p; p.x = cur; p.ldx = curd; p.M = M; p.T = T; p.act = (i + 1 == c.nproj) ? ACT_NONE : ACT_RELU; p.out = w.pa[i]; p.ldo = N;
     TRY(run_gemm(m, st, &ct.proj_f[i], 1, false, p));
     TRY(bn_stats(x, w.pa[i], N, M, N, w.pmu[i], w.prs[i], w.stat, &n, &N, 1));
-    hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * N), 0, st, w.pa[i], N, w.pmu[i], w.prs[i], x.p(n + "/gamma"), x.p(n + "/beta"), w.py[i], N, M, N);
+    if ((N & 3) == 0 && al16h(w.pa[i]) && al16h(w.py[i]))
+      hipLaunchKernelGGL(k_bn_apply_v4, EWGRID((size_t)M * N / 4), 0, st, (const float*)w.pa[i], N, (const float*)w.pmu[i], (const float*)w.prs[i], (const float*)x.p(n + "/gamma"), (const float*)x.p(n + "/beta"), w.py[i], N, M, N);
+    else hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * N), 0, st, w.pa[i], N, w.pmu[i], w.prs[i], x.p(n + "/gamma"), x.p(n + "/beta"), w.py[i], N, M, N);
     cur = w.py[i]; curd = N;
   }
   // residual (modules.py:62-69)
@@ -563,12 +584,18 @@ static void conv_bn_backward_exchange(const TrainCtx& x, float* sync_scratch, in
   if (x.t->sync_fn && x.t->sync_world > 1) x.t->sync_fn(x.t->sync_user, sync_scratch, 2 * Ctot);
 }
 static int conv_bn_backward_apply(const TrainCtx& x, const std::string& name, const float* a, int lda, const float* dy, int lddy, const float* mu,
-                                  const float* rstd, bool relu, float* dz, int lddz, int M, int C, const float* sync_scratch, int c0, int Ctot) {
+                                  const float* rstd, bool relu, float* dz, int lddz, int M, int C, const float* sync_scratch, int c0, int Ctot,
+                                  bool dz_done = false) {      // dz_done: the caller formed dz for all layers of a bank in one launch (bank_bn_bwd)
   hipStream_t st = x.st;
   const bool sync = x.t->sync_fn && x.t->sync_world > 1;
   const float* sdy = sync ? sync_scratch + c0 : x.g(name + "/beta");
   const float* sdyxh = sync ? sync_scratch + Ctot + c0 : x.g(name + "/gamma");
   const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
+  if (dz_done) {}
+  else if ((C & 3) == 0 && (lda & 3) == 0 && (lddy & 3) == 0 && (lddz & 3) == 0 && al16h(a) && al16h(dy) && al16h(dz))
+    hipLaunchKernelGGL(k_bn_bwd_v4, EWGRID((size_t)M * C / 4), 0, st, a, lda, dy, lddy, mu, rstd, (const float*)x.p(name + "/gamma"), sdy,
+                       sdyxh, relu ? 1 : 0, dz, lddz, M, C, invM);
+  else
   hipLaunchKernelGGL(k_bn_bwd, EWGRID((size_t)M * C), 0, st, a, lda, dy, lddy, mu, rstd, x.p(name + "/gamma"), sdy,
                      sdyxh, relu ? 1 : 0, dz, lddz, M, C, invM);
   TRY(run_colsum(st, dz, lddz, nullptr, 0, nullptr, nullptr, x.g(name + "/bias"), nullptr, M, C, 0));
@@ -647,7 +674,9 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   // ---- highways ----
   for (int i = c.depth - 1; i >= 0; --i) {
     const std::string n = sc + "/highway_" + std::to_string(i + 1);
-    hipLaunchKernelGGL(k_highway_bwd, EWGRID((size_t)M * H), 0, st, dcur, w.hx[i], w.hH[i], w.hT[i], w.dcat, dalt, M, H);
+    if ((H & 3) == 0 && al16h(dcur) && al16h(w.hx[i]) && al16h(w.hH[i]) && al16h(w.hT[i]) && al16h(w.dcat) && al16h(dalt))
+      hipLaunchKernelGGL(k_highway_bwd_v4, EWGRID((size_t)M * H / 4), 0, st, (const float*)dcur, (const float*)w.hx[i], (const float*)w.hH[i], (const float*)w.hT[i], w.dcat, dalt, M, H);
+    else hipLaunchKernelGGL(k_highway_bwd, EWGRID((size_t)M * H), 0, st, dcur, w.hx[i], w.hH[i], w.hT[i], w.dcat, dalt, M, H);
     HIPCHK(hipGetLastError());
     TRY(run_wgrad(st, w.hx[i], nullptr, H, w.dcat, 2 * H, x.g(n + "/H/kernel"), H, M, 0, H, H));
     TRY(run_wgrad(st, w.hx[i], nullptr, H, w.dcat + H, 2 * H, x.g(n + "/T/kernel"), H, M, 0, H, H));
@@ -683,7 +712,8 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     if (i > 0) { /* dnext == dcur already holds the gradient of py[i-1] */ }
   }
   // ---- maxpool + conv bank ----
-  hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
+  if ((KC & 3) == 0 && al16h(w.bank_y) && al16h(w.dbig0) && al16h(w.dbig1)) hipLaunchKernelGGL(k_maxpool_bwd_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_y, (const float*)w.dbig0, w.dbig1, M, T, KC, c.maxpool);
+  else hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
   HIPCHK(hipGetLastError());
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {     // the bank's BatchNorm sums of all widths, then one exchange for all of them
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
@@ -692,10 +722,32 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   }
   TRY(wg_flush());                    // the sums of all widths: one group launch
   conv_bn_backward_exchange(x, w.stat, KC);
+  // dz of ALL widths in one launch (their BatchNorm sums are complete: the flush above); the layers' own vectors through a pointer table
+  bool bank_dz = false;
+  if ((int)c.bank.size() == c.K && c.K <= BNB_MAXK && (c.C & 3) == 0 && al16h(w.bank_a) && al16h(w.dbig0) && al16h(w.dbig1)) {
+    const bool sync = x.t->sync_fn && x.t->sync_world > 1;
+    BnBank nb; memset(&nb, 0, sizeof nb); nb.Cw = c.C;
+    bool all = true;
+    for (size_t bi = 0; bi < c.bank.size(); ++bi) {
+      const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
+      if (k < 1 || k > c.K || nb.gamma[k - 1]) { all = false; break; }
+      const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
+      nb.gamma[k - 1] = x.p(n + "/gamma");
+      nb.sdy[k - 1] = sync ? w.stat + c0 : x.g(n + "/beta");
+      nb.sdyxh[k - 1] = sync ? w.stat + KC + c0 : x.g(n + "/gamma");
+    }
+    if (all) {
+      const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
+      hipLaunchKernelGGL(k_bn_bwd_bank_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_a, KC, (const float*)w.dbig1, KC, (const float*)w.bank_mu, (const float*)w.bank_rs, nb, 1,
+                         w.dbig0, KC, M, KC, invM);
+      HIPCHK(hipGetLastError());
+      bank_dz = true;
+    }
+  }
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
-    TRY(conv_bn_backward_apply(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat, c0, KC));
+    TRY(conv_bn_backward_apply(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat, c0, KC, bank_dz));
     TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
     TRY(run_dgrad(m, st, ct.bank_d[bi], w.dbig0 + c0, KC, M, T, din, c.in_dim, din, c.in_dim));   // accumulates onto the residual path
   }
