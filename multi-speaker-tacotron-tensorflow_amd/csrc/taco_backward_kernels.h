@@ -217,8 +217,9 @@ __global__ void k_colsum_reduce(const float* part, int nchunks, int C, int mode,
   float t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
   for (int k = 0; k < nchunks; ++k) { t1 += part[((size_t)k * 2 + 0) * C + c]; t2 += part[((size_t)k * 2 + 1) * C + c]; }
-  if (mode != 1 && out1) out1[c] += t1;
-  if (mode != 0 && out2) out2[c] += t2;
+  const int md = mode & 3;             // bit 3 of mode: the sums REPLACE out1 / out2 (no zero fill in front: BatchNorm statistics)
+  if (md != 1 && out1) out1[c] = (mode & 8) ? t1 : out1[c] + t1;
+  if (md != 0 && out2) out2[c] = (mode & 8) ? t2 : out2[c] + t2;
 }
 
 // the ordered sums of several column-sum problems of a group launch (deterministic mode) as ONE launch
@@ -235,8 +236,9 @@ __global__ __launch_bounds__(256) void k_colsum_reduce_group(const ColRedGroup G
   float t1 = 0.f, t2 = 0.f;
 #pragma unroll 8
   for (int k = 0; k < g.nchunks; ++k) { t1 += g.part[((size_t)k * 2 + 0) * g.C + c]; t2 += g.part[((size_t)k * 2 + 1) * g.C + c]; }
-  if (g.mode != 1 && g.out1) g.out1[c] += t1;
-  if (g.mode != 0 && g.out2) g.out2[c] += t2;
+  const int md = g.mode & 3;
+  if (md != 1 && g.out1) g.out1[c] = (g.mode & 8) ? t1 : g.out1[c] + t1;
+  if (md != 0 && g.out2) g.out2[c] = (g.mode & 8) ? t2 : g.out2[c] + t2;
 }
 
 // BatchNorm (training): mu = S1/M; second pass gives S2 = sum (a-mu)^2; rstd = 1/sqrt(S2/M + eps) (biased variance);

@@ -30,7 +30,7 @@
 #define CH_PF128 2
 #endif
 #ifndef CH_ROT
-#define CH_ROT 0
+#define CH_ROT 1
 #endif
 #define CH_BM 64
 enum { CH_DENSE = 0, CH_HIGHWAY = 1, CH_XPROJ = 2 };
@@ -54,10 +54,14 @@ struct ChainEntry {
 struct ChainArgs {
   ChainEntry e;                    // e.part != null: fused entry (x unused)
   const float* x; int ldx, Cin;    // input rows [M, ldx], Cin columns used
+  const int* gather;               // optional: row m of the input is x[gather[m]] (the embedding lookup in front of the encoder prenet, tacotron.py:38-39)
   float* out; int ldo;             // projection output [M, ldo]
   float* y; int ldy;               // optional: the last highway output [M, W] (null: not stored)
   const int* rev_len; int rev_col0;
   int M, T, nlayers;
+  // riders: with ntiles > 0 the workgroups ntiles .. gridDim.x - 1 own no tile; they clear up to four regions of 32-bit words (the words the
+  // persistent kernels of the same forward poll: a launch of its own otherwise -- the encoder prenet's chain leaves three quarters of the CUs free)
+  int ntiles; unsigned* zp[4]; unsigned long long znw[4];
   ChainLayer L[CH_MAXL];
 };
 
@@ -159,9 +163,22 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  if (a_in.ntiles > 0 && (int)blockIdx.x >= a_in.ntiles) {
+    const size_t i0 = (size_t)((int)blockIdx.x - a_in.ntiles) * 512 + tid, stride = (size_t)((int)gridDim.x - a_in.ntiles) * 512;
+    for (int rg = 0; rg < 4; ++rg) {
+      unsigned* p = a_in.zp[rg];
+      const size_t nw = a_in.znw[rg];
+      if (!p || !nw) continue;
+      const size_t n16 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : nw / 4;
+      uint4* q = reinterpret_cast<uint4*>(p);
+      for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
+    }
+    return;
+  }
   const int m0 = blockIdx.x * CH_BM;
 #ifdef TACO_TRACE
-  const bool trc = (blockIdx.x == gridDim.x / 2) && threadIdx.x == 0;
+  const bool trc = (blockIdx.x == (a_in.ntiles > 0 ? a_in.ntiles : gridDim.x) / 2) && threadIdx.x == 0;
   int trci = 5;
   CTRC(0);
 #endif
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
       const int row = m0 + r;
       if (row < a.M && c < a.Cin) {
-        const float* p = a.x + (size_t)row * a.ldx + c;
+        const float* p = a.x + (size_t)(a_in.gather ? a_in.gather[row] : row) * a.ldx + c;
         if (c + 3 < a.Cin && (a.ldx & 3) == 0) f = *reinterpret_cast<const float4*>(p);
         else { f.x = p[0]; if (c + 1 < a.Cin) f.y = p[1]; if (c + 2 < a.Cin) f.z = p[2]; if (c + 3 < a.Cin) f.w = p[3]; }
       }
@@ -381,12 +398,13 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         if (ocol >= L.N) return;
         const float bia = L.bias ? L.bias[ocol] : 0.f;
         const bool rev = a.rev_col0 >= 0 && ocol >= a.rev_col0;
+        const float floor_ = L.act == ACT_RELU ? 0.f : -INFINITY;      // (a chain that ends in a ReLU layer: the encoder prenet)
         if (full && !rev) {
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm) {
             float* po = a.out + (size_t)(m0 + rloc(tm, 0)) * a.ldo + ocol;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = acc[tm][r] + bia;
+            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = fmaxf(acc[tm][r] + bia, floor_);
           }
         } else {                               // the backward direction's columns go to the time-reversed row of the batch row
           int lhs = lh;                        // (opaque per call: the 32 reversed row indices are formed here, not kept -- and spilled -- across the column groups)
@@ -402,7 +420,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
                 const int tt = row - bb * a.T, Lb = a.rev_len ? a.rev_len[min(bb, (a.M - 1) / a.T)] : a.T;
                 orow = tt < Lb ? bb * a.T + (Lb - 1 - tt) : row;
               }
-              if (row < a.M) a.out[(size_t)orow * a.ldo + ocol] = acc[tm][r] + bia;
+              if (row < a.M) a.out[(size_t)orow * a.ldo + ocol] = fmaxf(acc[tm][r] + bia, floor_);
             }
         }
       };

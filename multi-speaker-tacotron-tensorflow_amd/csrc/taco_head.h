@@ -14,11 +14,13 @@
 #include "taco_kernels.h"
 
 #ifndef HD_ROT
-#define HD_ROT 0
+#define HD_ROT 1
 #endif
 #define HD_BM 64
 #define HD_KMAX 512      // widest input (the planes of 64 rows x 512 inputs take 133 KB of LDS)
-#define HD_PF 2          // register sets of weight fragments per wave: the fragments of step g + 1 are requested before step g is multiplied (two waves per SIMD cover each other; deeper rings measured the same in k_pointwise_chain and cost registers the interleaved stores need)
+#ifndef HD_PF
+#define HD_PF 4          // register sets of weight fragments per wave: the fragments of step g + HD_PF - 1 are requested before step g is multiplied (a step is 6 MFMAs = ~200 clocks of the wave's own matrix work: three steps ahead cover an L2 round trip under load)
+#endif
 struct HeadArgs {
   const float* x; int ldx;                                     // input rows [M, ldx], K columns used (K % 64 == 0, K <= HD_KMAX)
   const unsigned short* bh; const unsigned short* bl;          // split-bf16 pack of the layer (pack_bf3)
@@ -77,24 +79,22 @@ __global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
       *reinterpret_cast<uint2*>(xlo + r * LDSW + c) = l4;
     }
   }
-  // the wave's share of the sweep: column-tile pairs wave, wave + 8, ... of the full tiles
+  // the wave's share of the sweep: column-tile pairs wave, wave + 8, ... of the full tiles, ONE 32-column tile at a time
   const int NTF = N / 32, npair = (NTF + 1) / 2;
   const int mypass = wave < npair ? (npair - 1 - wave) / 8 + 1 : 0;
-  const int nsteps = mypass * K16;
-  // HD_ROT: the workgroups of an XCD start their sweep at different passes (the L2 is asked for different column tiles at a time)
+  const int ntile = 2 * mypass, nsteps = ntile * K16;
+  // HD_ROT: the workgroups of an XCD start their sweep at different passes (the L2 is asked for different column tiles at a time:
+  // 75 -> 64 us at C2, profiles/r05_*)
   const int prot = HD_ROT ? (int)(blockIdx.x >> 3) % max(mypass, 1) : 0;
-  auto pass_of = [&](int p) { const int q = p + prot; return q >= mypass ? q - mypass : q; };
-  auto bofs = [&](int s) {                                     // flat step (pass, k16) -> element offset of the lane's fragment of the pair's first tile
-    const int sc = min(s, nsteps - 1), p = sc / K16, g = sc - p * K16, t0 = 2 * (wave + 8 * pass_of(p));
-    return ((((size_t)g * NT + t0) * 2 + lh) * 32 + l31) * 8;
+  auto tile_of = [&](int q) { int pp = (q >> 1) + prot; pp = pp >= mypass ? pp - mypass : pp; return 2 * (wave + 8 * pp) + (q & 1); };
+  auto bofs = [&](int s) {                                     // flat step (tile, k16) -> element offset of the lane's fragment
+    const int sc = min(s, nsteps - 1), q = sc / K16, g = sc - q * K16, t = min(tile_of(q), NT - 1);      // (the second tile of the last pair may not exist: its products are never stored)
+    return ((((size_t)g * NT + t) * 2 + lh) * 32 + l31) * 8;
   };
-  uint4 rh[HD_PF][2], rl[HD_PF][2];
-  auto loadb = [&](int s, uint4 (&h)[2], uint4 (&l)[2]) {
+  uint4 rh[HD_PF], rl[HD_PF];
+  auto loadb = [&](int s, uint4& h, uint4& l) {
     const size_t o = bofs(s);
-    const int sc = min(s, nsteps - 1), t1 = 2 * (wave + 8 * pass_of(sc / K16)) + 1;
-    const size_t o1 = o + (t1 < NT ? 512 : 0);                 // (the second tile of the last pair may not exist: its products are never stored)
-    h[0] = *reinterpret_cast<const uint4*>(gbh + o); l[0] = *reinterpret_cast<const uint4*>(gbl + o);
-    h[1] = *reinterpret_cast<const uint4*>(gbh + o1); l[1] = *reinterpret_cast<const uint4*>(gbl + o1);
+    h = *reinterpret_cast<const uint4*>(gbh + o); l = *reinterpret_cast<const uint4*>(gbl + o);
   };
   if (mypass > 0) {
 #pragma unroll
@@ -102,129 +102,6 @@ __global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
   }
   __syncthreads();
   HTRC(1);
-
-  f32x16 acc[2][2];
-  const unsigned short* abh = xhi;                             // the lane's fragment rows in the two planes (set per pass from opaque lane coordinates:
-  const unsigned short* abl = xlo;                             // everything else of an A-fragment address is an immediate offset)
-  auto mma = [&](int g, const uint4 (&h)[2], const uint4 (&l)[2]) {
-    bf16x8 ah[2], al[2];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abh + tm * 32 * LDSW + 16 * g));
-      al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abl + tm * 32 * LDSW + 16 * g));
-    }
-    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, h[0]), bl0 = __builtin_bit_cast(bf16x8, l[0]);
-    const bf16x8 bh1 = __builtin_bit_cast(bf16x8, h[1]), bl1 = __builtin_bit_cast(bf16x8, l[1]);
-    // small terms first; the four independent accumulators sit between two MFMAs on the same one
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh0, acc[tm][0], 0, 0, 0);
-      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh1, acc[tm][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl0, acc[tm][0], 0, 0, 0);
-      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl1, acc[tm][1], 0, 0, 0);
-    }
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      acc[tm][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh0, acc[tm][0], 0, 0, 0);
-      acc[tm][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh1, acc[tm][1], 0, 0, 0);
-    }
-  };
-  // The stores of a pass are issued INSIDE the product loop of the next one (64 per lane: two per k16 step at K = 512), from a copy of its
-  // accumulators: left behind the loop, every wave of the chip stores at once and the matrix pipe idles for a third of the kernel
-  // (measured: 21 K clocks of stores behind 35 K clocks of products, twice).  Only the last pass's stores stay exposed.  Workgroups with
-  // rows past M, and the per-batch-row vector of model type 'simple', take the plain order (guards / an index division per element).
-  const bool inter = (m0 + HD_BM <= M) && !grv;
-  f32x16 accP[2][2];
-  float pbia[2] = {0.f, 0.f};
-  bool pv[2] = {false, false};
-  float* pbase = gout;                                        // previous pass: element (row m0 + 4 * (lane >> 5), first column of the pair + (lane & 31))
-  constexpr int SPS = 64 / K16;                                // stores of the previous pass per k16 step
-  auto store_prev = [&](int idx) {                             // idx (compile-time after unrolling): tn | tm | register
-    const int tn = idx >> 5, tm = (idx >> 4) & 1, r = idx & 15;
-    if (pv[tn]) pbase[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldo + tn * 32] = accP[tm][tn][r] + pbia[tn];
-  };
-  for (int p = 0; p < mypass; ++p) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
-        for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
-    const int s0 = p * K16;
-    {
-      int l31a = l31, lha = lh;
-      asm volatile("" : "+v"(l31a), "+v"(lha));
-      abh = xhi + l31a * LDSW + 8 * lha; abl = xlo + l31a * LDSW + 8 * lha;
-    }
-    if (p > 0 && inter) {
-#pragma unroll
-      for (int g = 0; g < K16; g += HD_PF) {                   // K16 % HD_PF == 0: the ring stays aligned across the passes
-#pragma unroll
-        for (int i = 0; i < HD_PF; ++i) {
-          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
-#pragma unroll
-          for (int u = 0; u < SPS; ++u) store_prev((g + i) * SPS + u);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(g + i, rh[i], rl[i]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-      for (int g = 0; g < K16; g += HD_PF) {
-#pragma unroll
-        for (int i = 0; i < HD_PF; ++i) {
-          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(g + i, rh[i], rl[i]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    }
-#ifdef TACO_TRACE
-    HTRC(trci); ++trci;
-#endif
-    const int t0 = 2 * (wave + 8 * pass_of(p));
-    int l31e = l31, lhe = lh;                                  // (opaque per pass: the output addresses are formed here, not kept across the sweep)
-    asm volatile("" : "+v"(l31e), "+v"(lhe));
-    if (inter && p + 1 < mypass) {                             // hand the tile to the next pass's loop
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int col = (t0 + tn) * 32 + l31e;
-        pv[tn] = t0 + tn < NTF;
-        pbia[tn] = (gbias && pv[tn]) ? gbias[col] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) accP[tm][tn] = acc[tm][tn];
-      }
-      pbase = gout + (size_t)(m0 + 4 * lhe) * ldo + t0 * 32 + l31e;
-      continue;
-    }
-    // + bias (+ the batch row's vector) -> the output rows
-#pragma unroll
-    for (int tn = 0; tn < 2; ++tn) {
-      if (t0 + tn >= NTF) continue;
-      const int col = (t0 + tn) * 32 + l31e;
-      const float bia = gbias ? gbias[col] : 0.f;
-#pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhe;
-          if (row < M) {
-            float v = acc[tm][tn][r] + bia;
-            if (grv) v += grv[(size_t)(row / a_in.T) * a_in.ldrv + col];
-            gout[(size_t)row * ldo + col] = v;
-          }
-        }
-    }
-#ifdef TACO_TRACE
-    HTRC(trci); ++trci;
-#endif
-  }
-#ifdef TACO_TRACE
-  HTRC(trci); ++trci;
-#endif
   // ---- the columns behind the last full tile: eight lanes per row, K / 8 inputs per lane, fp32 ----
   if (a_in.ntail > 0) {
     const int r = wave * 8 + (lane >> 3), kn = K / 8, k0 = (lane & 7) * kn, row = m0 + r;
@@ -252,6 +129,109 @@ __global__ __launch_bounds__(512) void k_head_sweep(const HeadArgs a_in) {
         if (grv) v += grv[(size_t)(row / a_in.T) * a_in.ldrv + col];
         gout[(size_t)row * ldo + col] = v;
       }
+    }
+  }
+
+  f32x16 acc[2];
+  const unsigned short* abh = xhi;                             // the lane's fragment rows in the two planes (set per tile from opaque lane coordinates:
+  const unsigned short* abl = xlo;                             // everything else of an A-fragment address is an immediate offset)
+  auto mma = [&](int g, const uint4& h, const uint4& l) {
+    bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      ah[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abh + tm * 32 * LDSW + 16 * g));
+      al[tm] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(abl + tm * 32 * LDSW + 16 * g));
+    }
+    const bf16x8 bh0 = __builtin_bit_cast(bf16x8, h), bl0 = __builtin_bit_cast(bf16x8, l);
+    // small terms first; the two independent accumulators alternate
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh0, acc[tm], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl0, acc[tm], 0, 0, 0);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh0, acc[tm], 0, 0, 0);
+  };
+  // The stores of a tile are issued INSIDE the product loop of the next one (32 per lane: one per k16 step at K = 512), from a copy of its
+  // accumulators: left behind the loop, every wave of the chip stores at once and the matrix pipe idles (round 4, with 64 x 64 outputs per
+  // pass: 21 K clocks of stores behind 35 K clocks of products, twice; with the pair as the unit the LAST pair's 35 K clocks stayed exposed
+  // -- a quarter of the kernel -- so the unit is now one 32-column tile: a wave re-reads its A fragments for the second tile of a pair
+  // (LDS has the bandwidth) and only a quarter of its stores are left over at the end).  Workgroups with rows past M, and the
+  // per-batch-row vector of model type 'simple', take the plain order (guards / an index division per element).
+  const bool inter = (m0 + HD_BM <= M) && !grv;
+  f32x16 accP[2];
+  float pbia = 0.f;
+  bool pv = false;
+  float* pbase = gout;                                        // previous tile: element (row m0 + 4 * (lane >> 5), column 32 t + (lane & 31))
+  constexpr int SPS = 32 / K16;                                // stores of the previous tile per k16 step
+  static_assert(K16 <= 32 && 32 % K16 == 0, "the previous tile's 32 stores spread evenly over the k16 steps");
+  auto store_prev = [&](int idx) {                             // idx (compile-time after unrolling): tm | register
+    const int tm = (idx >> 4) & 1, r = idx & 15;
+    if (pv) pbase[(size_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * ldo] = accP[tm][r] + pbia;
+  };
+  for (int q = 0; q < ntile; ++q) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+      for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+    const int s0 = q * K16;
+    {
+      int l31a = l31, lha = lh;
+      asm volatile("" : "+v"(l31a), "+v"(lha));
+      abh = xhi + l31a * LDSW + 8 * lha; abl = xlo + l31a * LDSW + 8 * lha;
+    }
+    if (q > 0 && inter) {
+#pragma unroll
+      for (int g = 0; g < K16; g += HD_PF) {                   // K16 % HD_PF == 0: the ring stays aligned across the tiles
+#pragma unroll
+        for (int i = 0; i < HD_PF; ++i) {
+          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
+#pragma unroll
+          for (int u = 0; u < SPS; ++u) store_prev((g + i) * SPS + u);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(g + i, rh[i], rl[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      for (int g = 0; g < K16; g += HD_PF) {
+#pragma unroll
+        for (int i = 0; i < HD_PF; ++i) {
+          loadb(s0 + g + i + HD_PF - 1, rh[(i + HD_PF - 1) % HD_PF], rl[(i + HD_PF - 1) % HD_PF]);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(g + i, rh[i], rl[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+#ifdef TACO_TRACE
+    HTRC(trci); ++trci;
+#endif
+    const int t = tile_of(q);
+    int l31e = l31, lhe = lh;                                  // (opaque per tile: the output addresses are formed here, not kept across the sweep)
+    asm volatile("" : "+v"(l31e), "+v"(lhe));
+    if (inter && q + 1 < ntile) {                              // hand the tile to the next tile's loop
+      const int col = t * 32 + l31e;
+      pv = t < NTF;
+      pbia = (gbias && pv) ? gbias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) accP[tm] = acc[tm];
+      pbase = gout + (size_t)(m0 + 4 * lhe) * ldo + t * 32 + l31e;
+      continue;
+    }
+    // + bias (+ the batch row's vector) -> the output rows
+    if (t < NTF) {
+      const int col = t * 32 + l31e;
+      const float bia = gbias ? gbias[col] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhe;
+          if (row < M) {
+            float v = acc[tm][r] + bia;
+            if (grv) v += grv[(size_t)(row / a_in.T) * a_in.ldrv + col];
+            gout[(size_t)row * ldo + col] = v;
+          }
+        }
     }
   }
 #ifdef TACO_TRACE

@@ -59,6 +59,18 @@ __global__ void k_zero_fill_multi(const ZeroRegions z) {
   for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
   for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
 }
+// up to ZM_MAX regions in one launch (the backward pass clears a dozen small accumulators in a row)
+#define ZM_MAX 12
+struct ZeroMany { uint32_t* p[ZM_MAX]; unsigned long long nw[ZM_MAX]; };
+__global__ void k_zero_fill_many(const ZeroMany z) {
+  uint32_t* p = z.p[blockIdx.y];
+  const size_t nw = z.nw[blockIdx.y];
+  const size_t n16 = (reinterpret_cast<uintptr_t>(p) & 15) ? 0 : nw / 4;
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  uint4* q = reinterpret_cast<uint4*>(p);
+  for (size_t i = i0; i < n16; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = n16 * 4 + i0; i < nw; i += stride) p[i] = 0u;
+}
 // Regions a caller up the stack has already cleared on this stream (forward_enqueue: ONE fill launch for every word the persistent kernels of a
 // forward poll).  A stage clears its polled words through clear_polled(): skipped only when exactly that region -- same start, at least as many
 // bytes -- is registered, so a stage whose region changes (or a new stage) clears itself instead of trusting a list kept elsewhere.
@@ -80,6 +92,26 @@ static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
   hipLaunchKernelGGL(k_zero_fill, dim3(blocks), dim3(256), 0, st, static_cast<uint32_t*>(p), n16, nw);
   return hipGetLastError();
 }
+
+// collects zero fills that follow one another on a stream and issues them as one launch (run() -- also from the destructor's caller)
+struct ZeroBatch {
+  ZeroMany z; int n = 0; size_t big = 0; hipStream_t st;
+  explicit ZeroBatch(hipStream_t s) : st(s) { memset(&z, 0, sizeof z); }
+  hipError_t add(void* p, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return zero_async(p, bytes, st);
+    if (n == ZM_MAX) { hipError_t e = run(); if (e != hipSuccess) return e; }
+    z.p[n] = static_cast<uint32_t*>(p); z.nw[n] = bytes / 4; big = std::max(big, bytes / 16); ++n;
+    return hipSuccess;
+  }
+  hipError_t run() {
+    if (!n) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((big + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(k_zero_fill_many, dim3(blocks, n), dim3(256), 0, st, z);
+    n = 0; big = 0; memset(&z, 0, sizeof z);
+    return hipGetLastError();
+  }
+};
 
 #define HIPCHK(expr)                                                                        \
   do {                                                                                      \
@@ -1540,12 +1572,51 @@ static void carve_enc(Carver& cv, const taco_model* m, int B, int T, EncWs& w) {
   carve_cbhg(cv, m->enc, B, T, w.cb);
   carve_spk(cv, m, B, w.spk);
 }
+// The encoder prenet (modules.py:18-25: two dense + ReLU layers over the looked-up embeddings) as ONE launch of the point-wise chain kernel
+// (taco_chain.h): gathered rows -> planes, a 256-wide ReLU layer, and the second layer as the chain's last link (stored straight to the
+// prenet output).  Two k_gemm_bf3 launches of 11 us each at C2 otherwise -- a 64-row tile of 4096 rows leaves them latency-bound.
+static bool prenet_chain_fits(const taco_model* m) {
+  const taco_hparams& hp = m->hp;
+  if (!(m->bf3 && !m->bf3x6 && m->chain && m->force_cfg < 0 && !m->bf3_tn) || hp.enc_prenet_n != 2) return false;
+  const ConvL& a = m->enc_prenet[0]; const ConvL& b = m->enc_prenet[1];
+  return a.bh && b.bh && a.kw == 1 && b.kw == 1 && a.N == 256 && a.cin == hp.embedding_size && a.cin_pad16 <= 256 && (hp.embedding_size & 3) == 0 &&
+         b.cin == 256 && b.N == hp.enc_prenet[1] && a.var_index >= 0 && b.var_index >= 0;
+}
+static thread_local const ZeroRegions* g_zero_rider = nullptr;      // forward_enqueue -> run_prenet_chain: the forward's up-front clears ride in the prenet launch
+static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids, int M, float* out) {
+  const taco_hparams& hp = m->hp;
+  ChainArgs a; memset(&a, 0, sizeof a);
+  a.x = AP(m, m->emb); a.ldx = hp.embedding_size; a.Cin = hp.embedding_size; a.gather = ids;
+  a.out = out; a.ldo = hp.enc_prenet[1]; a.rev_len = nullptr; a.rev_col0 = -1; a.M = M; a.T = M;
+  const int types[2] = {CH_DENSE, CH_XPROJ};
+  for (int i = 0; i < 2; ++i) {
+    const GemmVar& v = m->hvars[m->enc_prenet[i].var_index];
+    ChainLayer& l = a.L[a.nlayers++];
+    l.bh = v.bh; l.bl = v.bl; l.bh2 = v.bh2; l.bl2 = v.bl2; l.bias = v.bias; l.bias2 = v.bias2;
+    l.type = types[i]; l.K16 = v.K16; l.NT = v.NT; l.N = v.N; l.act = ACT_RELU;
+  }
+  int nwg = cdiv(M, CH_BM);
+  if (g_zero_rider) {
+    a.ntiles = nwg;
+    for (int i = 0; i < 4; ++i) { a.zp[i] = g_zero_rider->p[i]; a.znw[i] = g_zero_rider->nw[i]; }
+    nwg += std::min(192, std::max(16, 256 - nwg));
+    g_zero_rider = nullptr;
+  }
+  hipLaunchKernelGGL((k_pointwise_chain<256>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
 static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, const int* lengths, const int* speaker_id,
                            int B, int T, float* enc_out, const EncWs& w, bool spk_done) {
   const taco_hparams& hp = m->hp;
   const int M = B * T;
   if (is_deepvoice(m) && !spk_done) TRY(spk_forward(m, st, speaker_id, B, w.spk));
   const float* cur = AP(m, m->emb); int curd = hp.embedding_size;
+  if (prenet_chain_fits(m)) {
+    TRY(run_prenet_chain(m, st, ids, M, w.pre[1]));
+    return cbhg_forward(m, st, m->enc, w.pre[1], B, T, lengths, is_deepvoice(m) ? w.spk.vec[0] : nullptr,
+                        is_deepvoice(m) ? w.spk.vec[1] : nullptr, enc_out, w.cb);
+  }
   for (int i = 0; i < hp.enc_prenet_n; ++i) {  // embedding_lookup fused as a row gather (tacotron.py:38-39)
     GemmCall g; g.x = cur; g.ldx = curd; g.gather = (i == 0) ? ids : nullptr; g.M = M; g.act = ACT_RELU;
     g.out = w.pre[i]; g.ldo = hp.enc_prenet[i];
@@ -1921,8 +1992,13 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
     z.p[1] = (uint32_t*)w.dec.nz; z.nw[1] = (size_t)n * B;
     z.p[2] = (uint32_t*)w.post.cb.gxbuf; z.nw[2] = ((size_t)((char*)w.post.cb.gxctl - (char*)w.post.cb.gxbuf) + 256) / 4;
     z.p[3] = (uint32_t*)w.enc.cb.gxbuf; z.nw[3] = ((size_t)((char*)w.enc.cb.gxctl - (char*)w.enc.cb.gxbuf) + 256) / 4;     // (an encoder of width 256 scans on k_bigru_duo too)
-    hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
-    HIPCHK(hipGetLastError());
+    // (they ride in the encoder prenet's launch where that is the chain kernel -- the first launch of the forward, with CUs to spare)
+    struct Rider { ~Rider() { g_zero_rider = nullptr; } } rider;
+    if (prenet_chain_fits(m)) g_zero_rider = &z;
+    else {
+      hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
+      HIPCHK(hipGetLastError());
+    }
     struct Guard {
       explicit Guard(const ZeroRegions& z) { g_cleared.cnt = 0; for (int i = 0; i < 4; ++i) if (z.p[i]) { g_cleared.p[g_cleared.cnt] = z.p[i]; g_cleared.n[g_cleared.cnt++] = z.nw[i] * 4; } }
       ~Guard() { g_cleared.cnt = 0; }

@@ -222,7 +222,8 @@ struct WgRegion {      // RAII: a region ends (and flushes) on every return path
   ~WgRegion() { if (g_wgb.active) (void)wg_end(); }
 };
 static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, int ldb, const float* mu, const float* rstd,
-                      float* out1, float* out2, int M, int C, int mode) {
+                      float* out1, float* out2, int M, int C, int mode, bool assign = false) {
+  // assign (deterministic mode only -- the caller zero-fills otherwise): the ordered sums replace out1 / out2 instead of being added to them
   ColArgs g; g.a = a; g.b = b; g.mu = mu; g.rstd = rstd; g.out1 = out1; g.out2 = out2; g.lda = lda; g.ldb = ldb; g.M = M; g.C = C;
   g.mode = mode; g.rpb = 256; g.part = nullptr;
   if (g_det.p) {
@@ -241,7 +242,7 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
       if (clash || g_wgb.det_used + need > g_det.cap) TRY(wg_flush());
       g.part = g_det.p + g_wgb.det_used; g_wgb.det_used += need;
       ColRedGroup& R = g_wgb.cr;
-      R.p[R.n].part = g.part; R.p[R.n].out1 = out1; R.p[R.n].out2 = out2; R.p[R.n].nchunks = nchunks; R.p[R.n].C = C; R.p[R.n].mode = mode;
+      R.p[R.n].part = g.part; R.p[R.n].out1 = out1; R.p[R.n].out2 = out2; R.p[R.n].nchunks = nchunks; R.p[R.n].C = C; R.p[R.n].mode = mode | (assign ? 8 : 0);
       R.start[R.n + 1] = R.start[R.n] + cdiv(C, 256); ++R.n;
     }
     ColGroup& G = g_wgb.c;
@@ -251,7 +252,7 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
     return 0;
   }
   hipLaunchKernelGGL(k_colsum, dim3(cdiv(C, 64), nchunks), dim3(256), 0, st, g);
-  if (g.part) hipLaunchKernelGGL(k_colsum_reduce, EWGRID(C), 0, st, (const float*)g.part, nchunks, C, mode, out1, out2);
+  if (g.part) hipLaunchKernelGGL(k_colsum_reduce, EWGRID(C), 0, st, (const float*)g.part, nchunks, C, mode | (assign ? 8 : 0), out1, out2);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -452,10 +453,11 @@ static int bn_stats(const TrainCtx& x, const float* a, int lda, int M, int C, fl
   // the whole batch computes (modules.py:131) -- merged from the ranks' own (mean, centred sum) pairs
   const bool sync = x.t->sync_fn && x.t->sync_world > 1;
   const float invM = 1.0f / ((float)M * (sync ? x.t->sync_world : 1));
-  HIPCHK(zero_async(scratch, (size_t)2 * C * sizeof(float), st));
-  TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0));
+  const bool det = g_det.p != nullptr;      // the ordered sums replace the scratch; the atomics of the other mode need it cleared
+  if (!det) HIPCHK(zero_async(scratch, (size_t)2 * C * sizeof(float), st));
+  TRY(run_colsum(st, a, lda, nullptr, 0, nullptr, nullptr, scratch, nullptr, M, C, 0, det));
   hipLaunchKernelGGL(k_bn_mean, EWGRID(C), 0, st, scratch, mu, C, 1.0f / (float)M);
-  TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1));
+  TRY(run_colsum(st, a, lda, nullptr, 0, mu, nullptr, nullptr, scratch + C, M, C, 1, det));
   if (sync) {
     // ONE exchange per layer (the layer's columns, or all widths of a conv bank at once): rank means, centred sums, squared means
     // (means are exchanged as offsets from the layer's moving mean, which every rank holds identically: k_bn_sync_pack)
@@ -617,16 +619,22 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   const taco_model* m = x.t->sm; hipStream_t st = x.st;
   const int M = B * T, KC = c.K * c.C, H = c.rnn, I = c.rnn;
   // ---- BiGRU ----
-  HIPCHK(zero_async(w.dg, (size_t)M * 6 * H * sizeof(float), st));
-  HIPCHK(zero_async(w.rh, (size_t)M * 2 * H * sizeof(float), st));
-  if (duo_usable(m, c, B, T) && c.gb_pack) {
+  // (the backward scans write the steps inside a row's length only; k_bigru_duo_bwd without lengths -- the post-net -- writes every element)
+  const bool duo_bwd = duo_usable(m, c, B, T) && c.gb_pack;
+  ZeroBatch zb(st);
+  if (!(duo_bwd && !lengths)) {
+    HIPCHK(zb.add(w.dg, (size_t)M * 6 * H * sizeof(float)));
+    HIPCHK(zb.add(w.rh, (size_t)M * 2 * H * sizeof(float)));
+  }
+  if (duo_bwd) HIPCHK(zb.add(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256));
+  HIPCHK(zb.run());
+  if (duo_bwd) {
     // both directions of RG rows per group of 32 CUs, the directions software-pipelined against each other (k_bigru_duo_bwd)
     GbArgs a; memset(&a, 0, sizeof a);
     a.wpack = AP(m, c.gb_pack); a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.h0 = h0; a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.dh0 = dh0;
     a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
     int RG = 1;
     while (RG * DX_NGROUP < B) RG *= 2;
-    HIPCHK(zero_async(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256, st));
     const size_t lds = std::max(gb_lds_floats(RG) * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
     const dim3 grid(DX_NGROUP * GD_MEMBERS), blk(512);
     switch (RG) {
@@ -893,14 +901,16 @@ static int decoder_backward(const TrainCtx& x, const float* enc_out, int B, int 
   const int ldal = (n + 1) * T_in, R = B * n;
   const int S = simple_S(m), Dc = D + S, Pz = Pl + S;
   if (S && !dspk) return fail(TACO_ERR_ARG, "speaker-embedding gradient buffer missing");
-  HIPCHK(zero_async(w.dkeys, (size_t)B * T_in * A * sizeof(float), st));
-  HIPCHK(zero_async(w.dvalues, (size_t)B * T_in * D * sizeof(float), st));
-  HIPCHK(zero_async(w.dv_acc, (size_t)B * A * sizeof(float), st));
-  HIPCHK(zero_async(w.dsb_acc, (size_t)B * sizeof(float), st));
-  HIPCHK(zero_async(w.dalpha, (size_t)B * T_in * sizeof(float), st));
-  HIPCHK(zero_async(w.dctx, (size_t)B * D * sizeof(float), st));
-  HIPCHK(zero_async(w.dhA, (size_t)B * As * sizeof(float), st));
-  for (int i = 0; i < L; ++i) HIPCHK(zero_async(w.dh[i], (size_t)B * Hd * sizeof(float), st));
+  { ZeroBatch zb(st);               // the loop's accumulators: one fill launch
+    HIPCHK(zb.add(w.dkeys, (size_t)B * T_in * A * sizeof(float)));
+    HIPCHK(zb.add(w.dvalues, (size_t)B * T_in * D * sizeof(float)));
+    HIPCHK(zb.add(w.dv_acc, (size_t)B * A * sizeof(float)));
+    HIPCHK(zb.add(w.dsb_acc, (size_t)B * sizeof(float)));
+    HIPCHK(zb.add(w.dalpha, (size_t)B * T_in * sizeof(float)));
+    HIPCHK(zb.add(w.dctx, (size_t)B * D * sizeof(float)));
+    HIPCHK(zb.add(w.dhA, (size_t)B * As * sizeof(float)));
+    for (int i = 0; i < L; ++i) HIPCHK(zb.add(w.dh[i], (size_t)B * Hd * sizeof(float)));
+    HIPCHK(zb.run()); }
   const size_t attn_lds = (size_t)(2 * ((A + 3) & ~3) + ((D + 3) & ~3) + 5 * ((T_in + 3) & ~3) + ATB_NW * 256) * sizeof(float);
   if (attn_lds > 160 * 1024 || (As % 4) || (D % 4) || (A % 4)) return fail(TACO_ERR_UNSUPPORTED, "attention sizes not supported by the backward kernel");
   // the whole loop as ONE persistent launch (k_decoder_bwd_xcd, taco_decoder_bwd_xcd.h) when the forward left its tape in that
