@@ -567,9 +567,10 @@ __global__ void k_wgrad_reduce(const float* part, int nsplit, int kw, int K, int
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)kw * K * N;
   if (i >= per) return;
   float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * per + i];
-  const int n = (int)(i % N); const size_t tk = i / N;      // tk = tap * K + k
-  dw[tk * lddw + n] += s;
+#pragma unroll 8
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * per + i];        // (independent loads, eight in flight; the adds keep their order)
+  const unsigned tk = (unsigned)i / (unsigned)N, n = (unsigned)i - tk * (unsigned)N;      // tk = tap * K + k   (per < 2^32)
+  dw[(size_t)tk * lddw + n] += s;
 }
 
 // the ordered sums of the problems of a group launch (deterministic mode) as ONE launch: block b of the flat grid belongs to problem p
@@ -585,9 +586,10 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_group(const WgRedGroup G) 
   const size_t i = (size_t)(b - G.start[p]) * 256 + threadIdx.x, per = (size_t)g.kw * g.K * g.N;
   if (i >= per) return;
   float s = 0.f;
+#pragma unroll 8
   for (int sp = 0; sp < g.nsplit; ++sp) s += g.part[(size_t)sp * per + i];
-  const int n = (int)(i % g.N); const size_t tk = i / g.N;
-  g.dw[tk * g.lddw + n] += s;
+  const unsigned tk = (unsigned)i / (unsigned)g.N, n = (unsigned)i - tk * (unsigned)g.N;
+  g.dw[(size_t)tk * g.lddw + n] += s;
 }
 
 // ---- small element-wise pieces ----

@@ -1602,7 +1602,7 @@ static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids,
     nwg += std::min(192, std::max(16, 256 - nwg));
     g_zero_rider = nullptr;
   }
-  hipLaunchKernelGGL((k_pointwise_chain<256>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
+  hipLaunchKernelGGL((k_pointwise_chain<256, 6>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2324,6 +2324,7 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
