@@ -1048,3 +1048,229 @@ __global__ __launch_bounds__(512) void k_bigru_duo_bwd(const GbArgs a_in) {
   if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gb_body<RG, true>(a, gx_smem, group, member, rt);
   else gb_body<RG, false>(a, gx_smem, group, member, rt);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// k_bigru_oct_bwd: the backward scan on k_bigru_oct's geometry (round 5) -- ONE row per cluster of 8 CUs (four clusters per XCD),
+// a member owns 32 units of both directions, wave w the units 32 m + 4 w + i.  The recurrences, the exchanges (d c_pre, then the 2H
+// gate gradients, per direction and step), the tape ring and the outputs are k_bigru_duo_bwd's (above); what changes is what made
+// the forward scan faster: a gather is 256 / 512 granules from 7 peers with one granule per thread, a pass is one or two
+// ds_read_b128 per lane, the four units of a wave are dealt to the lanes by permlane swaps (one epilogue chain per lane), the
+// products are packed (v_pk_fma_f32: two units of one input vector in phase B; the r and u halves of one unit in phase CA), every
+// gather is requested twice (at the start of the phase it is in flight across and again behind the phase's products), and length
+// masking is a scalar test.  Weight pack: [2 dirs][8 members][48][512] -- registers 8 p + 4 j + e: row of Wc_h of unit 2 p + j
+// (p = 0, 1), 16 + 8 i + e / 16 + 8 i + 4 + e: rows of Wg_h (r half / u half) of unit i, inputs 4 lane + e.
+// ------------------------------------------------------------------------------------------------------------------------------
+#define GOB_UPW 4
+#define GOB_UPM 32
+__host__ __device__ inline size_t gob_ring_floats() { return (size_t)2 * 2 * GX_BLK * GB_ARR * GOB_UPM; }      // [slot][dir][step][array][32 units]
+__host__ __device__ inline size_t gob_lds_floats() { return gob_ring_floats() + (size_t)2 * GX_H + (size_t)2 * 2 * GX_H + 64; }
+
+template <bool WT>
+__device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int place, int slot, DxRt rt) {
+  constexpr int NT = 512, H = GX_H, UPW = GOB_UPW, MB = DX_GROUP / UPW, UPM = GOB_UPM, NREG = 96, LPU = 64 / UPW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int SLOT = 2 * GX_BLK * GB_ARR * UPM;         // floats of one ring slot (both directions)
+  float* xq = gx_smem;                                    // ring first (M0-addressed)
+  float* v1 = xq + 2 * SLOT;                              // [2 dirs][H]   d c_pre
+  float* v2 = v1 + 2 * H;                                 // [2 dirs][r half : H | u half : H]  gate gradients
+  const int row = place * UPW + (slot % UPW), member = slot / UPW;
+  if (row >= a.B || member >= MB) return;
+  const int T = a.T;
+  const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
+
+  float W[NREG];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const float* wp = a.wpack + (((size_t)d * MB + member) * (NREG / 2)) * NT + tid;
+#pragma unroll
+    for (int j = 0; j < NREG / 2; ++j) W[(NREG / 2) * d + j] = wp[(size_t)j * NT];
+  }
+  dx_gu64* X = (dx_gu64*)a.xbuf + (size_t)row * 2 * 3 * H;      // [dir][d c_pre : H | d r_pre : H | d u_pre : H]
+  for (int i = tid; i < 2 * H; i += NT) v1[i] = 0.f;
+  for (int i = tid; i < 4 * H; i += NT) v2[i] = 0.f;
+  // ring blocks: block b covers steps s = T-1-16b .. T-16-16b; item i = (dir, j, array, c) -> one float4 of the member's 32 units
+  constexpr int QPA = UPM / 4, NIT = 2 * GX_BLK * GB_ARR * QPA, NLD = (NIT + NT - 1) / NT;
+  static_assert(NIT % 64 == 0, "a wave's 64 items are all inside the block or all outside");
+  const unsigned xq_lds = (unsigned)(size_t)(gx_lds_float*)xq;
+  auto blk_fetch = [&](int blk, int ring) {
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      if (u * NT + wave * 64 < NIT) {            // wave-uniform
+        const int i = u * NT + tid;
+        const int c = i % QPA, ar = (i / QPA) % GB_ARR, j = (i / (QPA * GB_ARR)) % GX_BLK, d = i / (QPA * GB_ARR * GX_BLK);
+        const int s = max(T - 1 - GX_BLK * blk - j, 0);
+        const int sc = min(s, max(L - 1, 0));                                   // inactive steps: any valid row (the values are not used)
+        const int t = d ? (L - 1 - sc) : sc, tp = min(max(d ? t + 1 : t - 1, 0), T - 1);
+        const float* src;
+        if (ar == 0) src = a.dout + ((size_t)row * T + t) * 2 * H + d * H;
+        else if (ar == 4) src = a.out + ((size_t)row * T + tp) * 2 * H + d * H;
+        else src = a.gsave + ((size_t)row * T + t) * 6 * H + d * 3 * H + (ar - 1) * H;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(xq_lds + (unsigned)(ring * SLOT + 4 * (u * NT + wave * 64)) * 4u);
+        gx_load_lds16(src + member * UPM + 4 * c, dst);
+      }
+    }
+  };
+  blk_fetch(0, 0);
+  blk_fetch(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  float keep[2] = {0.f, 0.f}, hpv[2] = {0.f, 0.f}, rgv[2] = {0.f, 0.f}, dguv[2] = {0.f, 0.f};
+  bool actd[2] = {false, false};
+  unsigned long long pre = 0ull, pre2 = 0ull;      // the granule of the gather in flight across the current phase, asked for twice (see go_body)
+
+  const int tid_outer = tid, lane_outer = lane;
+  for (int k = 0; k <= T; ++k) {                 // k == T: only the trailing dh of step s = 0 (the initial-state gradient)
+    const int s = T - 1 - k;
+    const unsigned tag = (unsigned)k + 1u;
+    int tid = tid_outer, lane = lane_outer;
+    asm volatile("" : "+v"(tid), "+v"(lane));
+    const int ui = lane / LPU, unit = member * UPM + wave * UPW + ui;
+    const bool pub = (lane & (LPU - 1)) == 0;
+    const bool active = k < T && s < L;
+    const int sb = k & (GX_BLK - 1), ring = (k / GX_BLK) & 1;
+    if (sb == 0 && k > 0 && k < T) blk_fetch(k / GX_BLK + 1, ring ^ 1);
+    // gathers: n granules (256: by the four waves 4 D .. 4 D + 3; 512: by all), one per thread
+    auto mine = [&](int n, int D) { return n == 512 || (wave >> 2) == D; };
+    auto request = [&](const dx_gu64* Xv, int n, int D) {
+      if (mine(n, D)) pre = __hip_atomic_load(Xv + (tid & (n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto request2 = [&](const dx_gu64* Xv, int n, int D) {
+      if (mine(n, D)) pre2 = __hip_atomic_load(Xv + (tid & (n - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto collect = [&](const dx_gu64* Xv, unsigned tg, float* dst, int n, int D) {
+      if (mine(n, D)) {
+        float v[1];
+        if ((unsigned)(pre2 >> 32) == tg) v[0] = __uint_as_float((unsigned)pre2);
+        else if ((unsigned)(pre >> 32) == tg) v[0] = __uint_as_float((unsigned)pre);
+        else dx_poll<1>(Xv + (tid & (n - 1)), 0, tg, v, rt);       // a producer was late: the ordinary bounded poll
+        dst[tid & (n - 1)] = v[0];
+      }
+    };
+    // phase CA(D): finish step s+1 (dh of the previous step from the gathered gate gradients), start step s; (Xn, nn, Dn): the gather in flight
+    auto phase_ca = [&](auto Dc, const dx_gu64* Xn, int nn, int Dn) {
+      constexpr int D = decltype(Dc)::value;
+      constexpr int R0 = (NREG / 2) * D + 16;
+      float dhg = 0.f;
+      if (k > 0) {
+        const float4 gr = *reinterpret_cast<const float4*>(v2 + D * 2 * H + 4 * lane);
+        const float4 gu = *reinterpret_cast<const float4*>(v2 + D * 2 * H + H + 4 * lane);
+        taco_f32x2 acc[UPW];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = (taco_f32x2){W[R0 + 8 * i] * gr.x, W[R0 + 8 * i + 4] * gu.x};
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.y, gu.y}, (taco_f32x2){W[R0 + 8 * i + 1], W[R0 + 8 * i + 5]}, acc[i]);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.z, gu.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.w, gu.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
+        if (Xn) request2(Xn, nn, Dn);
+        float v[UPW], sm[1];
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) v[i] = acc[i].x + acc[i].y;
+        go_reduce<UPW, 1>(v, sm);
+        dhg = sm[0];
+      }
+      const float dh = actd[D] ? keep[D] + dhg : keep[D];          // actd = the previous step's
+      keep[D] = dh; dguv[D] = 0.f;
+      float dcp = 0.f;
+      if (k < T) {
+        actd[D] = active;
+        const float* rq = xq + (size_t)ring * SLOT + ((size_t)(D * GX_BLK + sb) * GB_ARR) * UPM + wave * UPW + ui;
+        const float dout = rq[0], r = rq[UPM], u = rq[2 * UPM], c = rq[3 * UPM];
+        float hprev = rq[4 * UPM];
+        if (active && s == 0) hprev = a.h0 ? a.h0[(size_t)row * 2 * H + D * H + unit] : 0.f;   // the step that started from the initial state
+        float rhp = 0.f;
+        if (active) {
+          const float g = dh + dout;
+          dcp = g * (1.f - u) * (1.f - c * c);
+          dguv[D] = g * (hprev - c) * u * (1.f - u);
+          keep[D] = g * u;
+          hpv[D] = hprev; rgv[D] = r; rhp = r * hprev;
+        }
+        asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(dcp));      // the gather in flight has landed: wait for it HERE, ahead of the publish store (see gd_landed)
+        if (pub) {
+          go_publish<WT>(X + (size_t)D * 3 * H + unit, dcp, tag);
+          if (active) {                                            // (behind the publish: the exchange is the critical path)
+            const size_t rowt = (size_t)row * T + (D ? L - 1 - s : s);
+            a.rh[rowt * 2 * H + D * H + unit] = rhp;
+            float* dq = a.dg + rowt * 6 * H + D * 3 * H + unit;
+            dq[H] = dguv[D]; dq[2 * H] = dcp;
+          }
+        }
+      } else {
+        actd[D] = false;
+        if (a.dh0 && pub) a.dh0[(size_t)row * 2 * H + D * H + unit] = dh;
+      }
+    };
+    // phase B(D): d(r*h) from the gathered d c_pre -> d r_pre, publish both gate gradients
+    auto phase_b = [&](auto Dc, const dx_gu64* Xn, int nn, int Dn) {
+      constexpr int D = decltype(Dc)::value;
+      constexpr int R0 = (NREG / 2) * D;
+      const float4 hx = *reinterpret_cast<const float4*>(v1 + D * H + 4 * lane);
+      taco_f32x2 acc[UPW / 2];
+#pragma unroll
+      for (int i = 0; i < UPW / 2; ++i) acc[i] = (taco_f32x2){W[R0 + 8 * i] * hx.x, W[R0 + 8 * i + 4] * hx.x};
+#pragma unroll
+      for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.y, hx.y}, (taco_f32x2){W[R0 + 8 * i + 1], W[R0 + 8 * i + 5]}, acc[i]);
+#pragma unroll
+      for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
+#pragma unroll
+      for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
+      if (Xn) request2(Xn, nn, Dn);
+      float v[UPW], sm[1];
+#pragma unroll
+      for (int i = 0; i < UPW / 2; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
+      go_reduce<UPW, 1>(v, sm);
+      float dgr = 0.f;
+      if (actd[D]) {
+        const float drh = sm[0];
+        dgr = drh * hpv[D] * rgv[D] * (1.f - rgv[D]);
+        keep[D] += drh * rgv[D];
+      }
+      float gu = dguv[D];
+      asm volatile("" : "+v"(pre), "+v"(pre2), "+v"(dgr), "+v"(gu));
+      if (pub) {
+        go_publish<WT>(X + (size_t)D * 3 * H + H + unit, dgr, tag);
+        go_publish<WT>(X + (size_t)D * 3 * H + 2 * H + unit, gu, tag);
+        if (actd[D]) a.dg[((size_t)row * T + (D ? L - 1 - s : s)) * 6 * H + D * 3 * H + unit] = dgr;
+      }
+    };
+    using F = std::integral_constant<int, 0>;
+    using Bk = std::integral_constant<int, 1>;
+    const dx_gu64* Xc0 = X;                          const dx_gu64* Xg0 = X + (size_t)H;
+    const dx_gu64* Xc1 = X + (size_t)3 * H;          const dx_gu64* Xg1 = X + (size_t)3 * H + H;
+    // (the gate gradients of F of the previous step were collected at the end of the previous iteration; B's are in flight)
+    phase_ca(F{}, k > 0 ? Xg1 : nullptr, 512, 1);
+    if (k > 0) collect(Xg1, tag - 1u, v2 + 2 * H, 512, 1);
+    __syncthreads();
+    if (k == T) { phase_ca(Bk{}, nullptr, 512, 1); break; }
+    request(Xc0, 256, 0);
+    phase_ca(Bk{}, Xc0, 256, 0);
+    collect(Xc0, tag, v1, 256, 0);
+    __syncthreads();
+    request(Xc1, 256, 1);
+    phase_b(F{}, Xc1, 256, 1);
+    collect(Xc1, tag, v1 + H, 256, 1);
+    __syncthreads();
+    request(Xg0, 512, 0);
+    phase_b(Bk{}, Xg0, 512, 0);
+    collect(Xg0, tag, v2, 512, 0);
+    if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    request(Xg1, 512, 1);
+  }
+}
+
+__global__ __launch_bounds__(512) void k_bigru_oct_bwd(const GbArgs a_in) {
+  extern __shared__ __attribute__((aligned(16))) float gx_smem[];
+  GbArgs a = a_in;
+  int* ictl = reinterpret_cast<int*>(gx_smem + gob_lds_floats() - 64);
+  dx_gu32* errw = (dx_gu32*)a.err;
+  dx_census((dx_gu32*)a.ctl, errw, a.force_wt, ictl, threadIdx.x, 24);
+  const int place = __builtin_amdgcn_readfirstlane(ictl[0]), slot = __builtin_amdgcn_readfirstlane(ictl[1]);
+  DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+  if (__builtin_amdgcn_readfirstlane((int)rt.wt)) gob_body<true>(a, gx_smem, place, slot, rt);
+  else gob_body<false>(a, gx_smem, place, slot, rt);
+}

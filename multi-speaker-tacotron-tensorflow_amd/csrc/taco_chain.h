@@ -148,14 +148,14 @@ __device__ long long taco_trace_chain[64];      // slots: 0 entry, 1 partial sum
 #else
 #define CTRC(i) do {} while (0)
 #endif
-// PFX: register sets of weight fragments (0: CH_PF256 / CH_PF128).  The CBHG chains are paced by the L2's bandwidth (above) and gain nothing from a
-// deeper ring; the encoder prenet's chain runs on 64 workgroups (4096 rows), nobody competes for the L2, and every k16 step of 6 MFMAs waited for
-// the ROUND TRIP of the fragments asked for one step earlier: six sets there (17.6 -> see profiles/r05_*)
-template <int W, int PFX = 0>
+// (Round 5: the ring depth was tried again where only 64 workgroups run -- the encoder prenet's chain and the encoder's own, 4096 rows: six sets
+// instead of two made the prenet chain 17.6 -> 22.9 us and the encoder chain 61 -> 71 us (four sets: 63).  A deeper ring issues its last sets'
+// requests again past the end of every short K loop; the loops are paced by the bytes a CU can pull from L2 (~26-31 B per clock and CU
+// measured, all CUs streaming), not by the round trip, so more requests in flight only add bytes.  profiles/r05_*.)
+template <int W>
 __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
   constexpr int WN = W / 32, WM = 8 / WN, TM = CH_BM / 32 / WM;      // W = 256: 1 x 8 waves of 64 x 32; W = 128: 2 x 4 waves of 32 x 32
-  constexpr int PF = PFX ? PFX : (W == 256 ? CH_PF256 : CH_PF128);
-  constexpr int PFD = W == 256 ? CH_PF256 : CH_PF128;                  // two-matrix loops (16 registers per set) keep the default depth
+  constexpr int PF = W == 256 ? CH_PF256 : CH_PF128;
   constexpr int LDSW = W + 8;                                          // bf16 elements per plane row: (W + 8) * 2 bytes = odd multiple of 16
   extern __shared__ __attribute__((aligned(16))) unsigned short ch_smem[];
   unsigned short* xhi = ch_smem;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
-        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PFD>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
+        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
         else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);     // the odd group: one matrix
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       const float bia = L.bias ? L.bias[col] : 0.f;
       if (dual) {
         const float bia2 = L.bias2 ? L.bias2[col] : 0.f;
-        ch_mma_loop<TM, LDSW, true, PFD>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
+        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif

@@ -166,6 +166,7 @@ struct Cbhg {
   size_t raw_gh[2] = {0, 0}, raw_ch[2] = {0, 0};   // h-rows of the GRU kernels in TF layout (row-parallel scan)
   size_t res_g2[2] = {0, 0};                       // h-rows of gates/kernel as (r, u) pairs per unit: [H][H][2] (k_bigru_res)
   size_t gd_pack = 0, gb_pack = 0;                     // k_bigru_duo / k_bigru_duo_bwd: [2 dirs][32 members][12][512]
+  size_t gob_pack = 0;                                 // k_bigru_oct_bwd (training): [2 dirs][8 members][48][512]
   size_t go_pack[3] = {0, 0, 0};                       // k_bigru_oct<UPW>, UPW = 1, 2, 4: [2 dirs][32 / UPW members][12 UPW][512]
   size_t gx_pack[2] = {0, 0}, gx_pack4[2] = {0, 0};   // per-thread weight packs of k_bigru_xcd (8-wave and 4-wave workgroups), H = 256 only
   // fused front (taco_front.h): per bank width (same order as `bank`) the produce pack [k32 step][16-channel tile][lane][8] (hi, lo)
@@ -780,6 +781,27 @@ static void make_cbhg(taco_model* m, Cbhg& c, const std::string& sc, int in_dim,
           }
       }
       c.gb_pack = arena_put(m, bp.data(), bp.size());
+      // k_bigru_oct_bwd: member mem of a cluster of 8, wave w owns units 32 mem + 4 w + i; lane l holds inputs 4l..4l+3 of the unit's ROWS: registers
+      // 8 p + 4 j + e = Wc_h row of unit 2 p + j (p = 0, 1); 16 + 8 i + e / 16 + 8 i + 4 + e = Wg_h row of unit i, r half / u half
+      std::vector<float> ob((size_t)2 * (DX_GROUP / GOB_UPW) * 48 * 512, 0.f);
+      for (int dir = 0; dir < 2; ++dir) {
+        const std::string n = sc + "/bigru/" + (dir ? "bw" : "fw");
+        const auto& gk = T_(m, n + "/gates/kernel").data; const auto& ck = T_(m, n + "/candidate/kernel").data;
+        for (int mem = 0; mem < DX_GROUP / GOB_UPW; ++mem)
+          for (int tid = 0; tid < 512; ++tid) {
+            const int w = tid >> 6, l = tid & 63;
+            float* base = &ob[(((size_t)dir * (DX_GROUP / GOB_UPW) + mem) * 48) * 512 + tid];
+            for (int i = 0; i < GOB_UPW; ++i) {
+              const int u = mem * GOB_UPM + w * GOB_UPW + i;
+              for (int e = 0; e < 4; ++e) {
+                base[(size_t)(8 * (i >> 1) + 4 * (i & 1) + e) * 512] = ck[(size_t)(I + u) * H + 4 * l + e];
+                base[(size_t)(16 + 8 * i + e) * 512] = gk[(size_t)(I + u) * 2 * H + 4 * l + e];
+                base[(size_t)(16 + 8 * i + 4 + e) * 512] = gk[(size_t)(I + u) * 2 * H + H + 4 * l + e];
+              }
+            }
+          }
+      }
+      c.gob_pack = arena_put(m, ob.data(), ob.size());
     }
   }
   ConvL X; X.kw = 1; X.cin = I; X.N = 6 * H;
@@ -1172,6 +1194,18 @@ static int oct_upw(const taco_model* m, const Cbhg& c, int B, int T) {
   if (B > 16) return 4;
   if (B > 8) return 2;
   return m->persist == 10 ? 1 : 0;
+}
+// the backward scan on the same geometry (k_bigru_oct_bwd; four units per wave: up to 32 rows), where the forward scan runs on k_bigru_oct
+static bool oct_bwd_usable(const taco_model* m, const Cbhg& c, int B, int T) { return c.gob_pack && oct_upw(m, c, B, T) != 0; }
+static int oct_bwd_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* dout, const float* out, const float* gsave,
+                          const float* h0, const int* lengths, float* dg, float* rh, float* dh0, unsigned long long* gxbuf, unsigned* gxctl) {
+  GbArgs a; memset(&a, 0, sizeof a);
+  a.wpack = AP(m, c.gob_pack); a.dout = dout; a.out = out; a.gsave = gsave; a.h0 = h0; a.lengths = lengths; a.dg = dg; a.rh = rh; a.dh0 = dh0;
+  a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
+  const size_t lds = std::max(gob_lds_floats() * sizeof(float), (size_t)96 * 1024);      // one workgroup per CU
+  hipLaunchKernelGGL(k_bigru_oct_bwd, dim3(DX_NGROUP * DX_GROUP), dim3(512), lds, st, a);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UPW, int B, int T, const float* xproj, const int* lengths, const float* init_state,
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
@@ -1602,7 +1636,7 @@ static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids,
     nwg += std::min(192, std::max(16, 256 - nwg));
     g_zero_rider = nullptr;
   }
-  hipLaunchKernelGGL((k_pointwise_chain<256, 6>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
+  hipLaunchKernelGGL((k_pointwise_chain<256>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -2324,7 +2358,6 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_bigru_rows<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_head_sweep<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointwise_chain<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

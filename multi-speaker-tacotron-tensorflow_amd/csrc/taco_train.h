@@ -628,7 +628,10 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
   }
   if (duo_bwd) HIPCHK(zb.add(w.gxbuf, (size_t)((char*)w.gxctl - (char*)w.gxbuf) + 256));
   HIPCHK(zb.run());
-  if (duo_bwd) {
+  if (duo_bwd && oct_bwd_usable(m, c, B, T)) {
+    // one row per cluster of 8 CUs, as the forward scan of these shapes (k_bigru_oct_bwd)
+    TRY(oct_bwd_launch(m, st, c, B, T, dout, w.out, w.gsave, h0, lengths, w.dg, w.rh, dh0, w.gxbuf, w.gxctl));
+  } else if (duo_bwd) {
     // both directions of RG rows per group of 32 CUs, the directions software-pipelined against each other (k_bigru_duo_bwd)
     GbArgs a; memset(&a, 0, sizeof a);
     a.wpack = AP(m, c.gb_pack); a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.h0 = h0; a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.dh0 = dh0;
