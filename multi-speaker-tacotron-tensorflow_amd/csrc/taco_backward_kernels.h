@@ -940,6 +940,100 @@ __global__ __launch_bounds__(RP_NT) void k_bigru_rows_bwd(const BigruBArgs a_in)
   if (a.dh0 && brow) a.dh0[(size_t)b * 2 * H + d * H + n] = dh[o];
 }
 
+// ---- the same backward scan with the recurrent kernels RESIDENT in registers (round 5; H = 128: the encoder) ----
+// k_bigru_rows_bwd streams both transposed kernels from L2 in every step and reads the step's tape values at the moment it needs them:
+// 3.5 us per step at the C4 shard (0.45 ms per training step for 128 steps).  Here one workgroup of 4 H threads owns one (direction,
+// row): thread (n, q) keeps the quarter q of unit n's ROWS of Wc_h and Wg_h (r half, u half) -- 3 H / 4 = 96 registers, the interleaved
+// float4 chunks q, q + 4, ... so that the four lanes of a unit read 64 consecutive bytes of LDS --, a product is H / 4 FMAs and two DPP
+// adds inside the quad, the d c_pre / gate-gradient vectors alternate between two LDS copies (two barriers per step), and the tape
+// values of step s - 1 are requested while step s is computed.  Same recurrences, outputs and masking as k_bigru_rows_bwd.
+struct BigruQArgs {
+  const float* dout; const float* out; const float* gsave;      // as BigruBArgs
+  const float* gh0; const float* gh1;     // h-rows of gates/kernel     [H, 2H] (TF layout), forward / backward direction
+  const float* ch0; const float* ch1;     // h-rows of candidate/kernel [H, H]
+  const int* lengths; float* dg; float* rh; const float* h0; float* dh0;
+  int B, T;
+};
+template <int H>
+__global__ __launch_bounds__(4 * H) void k_bigru_resb(const BigruQArgs a) {
+  static_assert(H % 16 == 0 && 4 * H <= 1024, "four lanes per unit, float4 chunks dealt round the quad");
+  constexpr int NC = H / 16;               // float4 chunks per lane and vector
+  __shared__ __attribute__((aligned(16))) float v1[2][H], v2[2][2 * H];
+  const int tid = threadIdx.x, n = tid >> 2, q = tid & 3;
+  const int d = blockIdx.x / a.B, b = blockIdx.x - d * a.B;
+  const int T = a.T, L = a.lengths ? a.lengths[b] : T;
+  const float* gh = d ? a.gh1 : a.gh0; const float* ch = d ? a.ch1 : a.ch0;
+  float wc[H / 4], wr[H / 4], wu[H / 4];
+#pragma unroll
+  for (int m = 0; m < NC; ++m) {
+    const int j = 4 * (q + 4 * m);
+    const float4 x = *reinterpret_cast<const float4*>(ch + (size_t)n * H + j);
+    const float4 y = *reinterpret_cast<const float4*>(gh + (size_t)n * 2 * H + j);
+    const float4 z = *reinterpret_cast<const float4*>(gh + (size_t)n * 2 * H + H + j);
+    wc[4 * m] = x.x; wc[4 * m + 1] = x.y; wc[4 * m + 2] = x.z; wc[4 * m + 3] = x.w;
+    wr[4 * m] = y.x; wr[4 * m + 1] = y.y; wr[4 * m + 2] = y.z; wr[4 * m + 3] = y.w;
+    wu[4 * m] = z.x; wu[4 * m + 1] = z.y; wu[4 * m + 2] = z.z; wu[4 * m + 3] = z.w;
+  }
+  auto quad_sum = [](float x) {
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));      // quad_perm [1,0,3,2]
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xF, 0xF, false));      // quad_perm [2,3,0,1]
+    return x;
+  };
+  struct Tape { float dout, r, u, c, hp; };
+  auto fetch = [&](int s) {                 // the tape values of step s (0 <= s < L) at their true time
+    Tape p;
+    const int t = d ? (L - 1 - s) : s, tp = d ? t + 1 : t - 1;
+    const size_t row = (size_t)b * T + t;
+    p.dout = a.dout[row * 2 * H + d * H + n];
+    const float* gs = a.gsave + row * 6 * H + d * 3 * H + n;
+    p.r = gs[0]; p.u = gs[H]; p.c = gs[2 * H];
+    p.hp = (s > 0) ? a.out[((size_t)b * T + tp) * 2 * H + d * H + n] : (a.h0 ? a.h0[(size_t)b * 2 * H + d * H + n] : 0.f);
+    return p;
+  };
+  float dh = 0.f;
+  Tape nx = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (L > 0) nx = fetch(L - 1);
+  for (int s = L - 1; s >= 0; --s) {
+    const int p = s & 1;
+    const Tape cur = nx;
+    if (s > 0) nx = fetch(s - 1);           // in flight across this step
+    const float g = dh + cur.dout;
+    const float dcp = g * (1.f - cur.u) * (1.f - cur.c * cur.c);
+    const float dgu = g * (cur.hp - cur.c) * cur.u * (1.f - cur.u);
+    float keep = g * cur.u;
+    if (q == 0) { v1[p][n] = dcp; v2[p][H + n] = dgu; }
+    __syncthreads();
+    float acc = 0.f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      const float4 x = *reinterpret_cast<const float4*>(&v1[p][4 * (q + 4 * m)]);
+      acc = fmaf(x.x, wc[4 * m], acc); acc = fmaf(x.y, wc[4 * m + 1], acc); acc = fmaf(x.z, wc[4 * m + 2], acc); acc = fmaf(x.w, wc[4 * m + 3], acc);
+    }
+    const float drh = quad_sum(acc);
+    const float dgr = drh * cur.hp * cur.r * (1.f - cur.r);
+    keep += drh * cur.r;
+    if (q == 0) v2[p][n] = dgr;
+    __syncthreads();
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < NC; ++m) {
+      const float4 x = *reinterpret_cast<const float4*>(&v2[p][4 * (q + 4 * m)]);
+      const float4 y = *reinterpret_cast<const float4*>(&v2[p][H + 4 * (q + 4 * m)]);
+      a0 = fmaf(x.x, wr[4 * m], a0); a0 = fmaf(x.y, wr[4 * m + 1], a0); a0 = fmaf(x.z, wr[4 * m + 2], a0); a0 = fmaf(x.w, wr[4 * m + 3], a0);
+      a1 = fmaf(y.x, wu[4 * m], a1); a1 = fmaf(y.y, wu[4 * m + 1], a1); a1 = fmaf(y.z, wu[4 * m + 2], a1); a1 = fmaf(y.w, wu[4 * m + 3], a1);
+    }
+    dh = keep + quad_sum(a0 + a1);
+    if (q == 0) {
+      const int t = d ? (L - 1 - s) : s;
+      const size_t row = (size_t)b * T + t;
+      a.rh[row * 2 * H + d * H + n] = cur.r * cur.hp;
+      float* o = a.dg + row * 6 * H + d * 3 * H + n;
+      o[0] = dgr; o[H] = dgu; o[2 * H] = dcp;
+    }
+  }
+  if (a.dh0 && q == 0) a.dh0[(size_t)b * 2 * H + d * H + n] = dh;
+}
+
 // inclusive wave64 SUFFIX sum (lane l gets sum over lanes >= l); never formed as total - prefix, which cancels
 // catastrophically when the tail is many orders of magnitude below the head (it is: the tail carries cumprod(1-p))
 __device__ __forceinline__ float wave_rscan(float x, int lane) {

@@ -48,6 +48,7 @@ struct taco_train {
   void (*sync_fn)(void* user, float* d_vec, int n) = nullptr;
   void* sync_user = nullptr;
   int sync_world = 1;
+  int resident_bwd_scan = 1;           // the encoder's backward scan with the recurrent kernels in registers (k_bigru_resb); 0 (with taco_train_set_bptt_engine(t, 0)): k_bigru_rows_bwd
   int bptt_persistent = 1;             // taco_train_set_bptt_engine: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd) where it fits
   int deterministic = 1;               // taco_train_set_deterministic: ordered two-stage sums (default since round 4) or fp32 atomics; the former needs DET_SCRATCH_FLOATS of workspace
 };
@@ -646,6 +647,13 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
       case 4: hipLaunchKernelGGL((k_bigru_duo_bwd<4>), grid, blk, lds, st, a); break;
       default: hipLaunchKernelGGL((k_bigru_duo_bwd<8>), grid, blk, lds, st, a); break;
     }
+    HIPCHK(hipGetLastError());
+  } else if (H == 128 && x.t->resident_bwd_scan) {
+    // recurrent kernels resident in registers, one workgroup per (direction, row) (k_bigru_resb): the encoder at the reference width
+    BigruQArgs a; memset(&a, 0, sizeof a);
+    a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.gh0 = AP(m, c.raw_gh[0]); a.gh1 = AP(m, c.raw_gh[1]); a.ch0 = AP(m, c.raw_ch[0]); a.ch1 = AP(m, c.raw_ch[1]);
+    a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.h0 = h0; a.dh0 = dh0; a.B = B; a.T = T;
+    hipLaunchKernelGGL(k_bigru_resb<128>, dim3(2 * B), dim3(512), 0, st, a);
     HIPCHK(hipGetLastError());
   } else {
     int R = (B >= 2 && 2 * H <= RP_NT) ? 2 : 1;
