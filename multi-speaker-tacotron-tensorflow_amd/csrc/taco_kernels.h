@@ -1635,6 +1635,8 @@ __device__ __forceinline__ float taco_quadsum(float v) {
   return v;
 }
 __device__ __forceinline__ float taco_sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+// TAPE: the training forward -- the gates r, u and the candidate c of the active steps at their true time (a.gsave [B*T, 6H]), for the backward scan
+template <bool TAPE = false>
 __global__ __launch_bounds__(512) void k_bigru_quad(const BigruSArgs a_in) {
   constexpr int H = 128, KS = 32, SP = 36;          // K-slice q of the state lives at floats [q * SP, q * SP + 32)
   __shared__ __attribute__((aligned(16))) float hs[4 * SP];
@@ -1693,6 +1695,7 @@ __global__ __launch_bounds__(512) void k_bigru_quad(const BigruSArgs a_in) {
     const int t = (d && active) ? (L - 1 - s) : s;
     if (active) hj = hn;
     if (q == 0) { hs[pos] = hj; op[(size_t)t * 2 * H] = active ? hn : 0.f; }
+    if (TAPE && q == 0 && active) { float* gs = a.gsave + ((size_t)b * T + t) * 6 * H + d * 3 * H + j; gs[0] = r; gs[H] = u; gs[2 * H] = c; }
     __syncthreads();
   };
   int s = 0;

@@ -1306,7 +1306,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.h0 = init_state; a.lengths = lengths; a.out = out; a.B = B; a.T = T;
     const dim3 grid(2 * B);
     if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, false>), grid, dim3(512), bigru_res_lds(256, 24, 1), st, a);
-    else if (m->persist == 1) hipLaunchKernelGGL(k_bigru_quad, grid, dim3(512), 0, st, a);       // quad-local K split: two barriers per step (persist 3: k_bigru_res)
+    else if (m->persist == 1) hipLaunchKernelGGL(k_bigru_quad<false>, grid, dim3(512), 0, st, a);       // quad-local K split: two barriers per step (persist 3: k_bigru_res)
     else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, false>), grid, dim3(512), bigru_res_lds(128, 0, 1), st, a);
     HIPCHK(hipGetLastError());
     return 0;
@@ -2549,6 +2549,14 @@ int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual
   s += m->enc.rnn == 128 && m->persist == 1 ? "; encoder scan: k_bigru_quad (a row and direction per workgroup, K split inside a quad of lanes); feed-forward: "
                                             : "; encoder scan: k_bigru_res (rows resident per workgroup); feed-forward: ";
   s += m->bf3 ? "split-bf16 MFMA (k_gemm_bf3 / k_pointwise_chain)" : "exact-fp32 MFMA (k_gemm)";
+  if (!m->tp) s += prenet_chain_fits(m) ? "; encoder prenet: one k_pointwise_chain launch (embedding rows gathered, both layers; the forward's zero fills ride in it)"
+                                        : "; encoder prenet: one GEMM launch per layer";
+  else {        // the training step's backward scans (taco_train.h: cbhg_backward)
+    const Cbhg& c = m->post;
+    s += std::string("; backward scans: post-net ") + (duo_usable(m, c, B, T_mel) && c.gb_pack ? (oct_bwd_usable(m, c, B, T_mel) ? "k_bigru_oct_bwd (one row per cluster of 8 CUs)" : "k_bigru_duo_bwd")
+                                                                                                : "k_bigru_rows_bwd") +
+         ", encoder " + (m->enc.rnn == 128 ? "k_bigru_resb (recurrent kernels in registers)" : "k_bigru_rows_bwd");
+  }
   snprintf(out, (size_t)out_len, "%s", s.c_str());
   return 0;
 }

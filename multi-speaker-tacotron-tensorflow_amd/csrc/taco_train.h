@@ -542,17 +542,18 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
   const int H = c.rnn;
   { GemmCall xp; xp.x = w.hx[c.depth]; xp.ldx = H; xp.M = M; xp.T = T; xp.out = w.xproj; xp.ldo = 6 * H; xp.rev_len = lengths; xp.rev_col0 = 3 * H;
     TRY(run_gemm(m, st, &c.xproj, 1, false, xp)); }
-  HIPCHK(zero_async(w.gsave, (size_t)M * 6 * H * sizeof(float), st));
+  if (lengths) HIPCHK(zero_async(w.gsave, (size_t)M * 6 * H * sizeof(float), st));      // (without lengths -- the post-net -- every step of every row is active and written)
   if (const int upw = oct_upw(m, c, B, T))     // the whole-chip scans of inference with the gate tape (k_bigru_oct<UPW, true> / k_bigru_duo<RG, true>)
     return oct_launch(m, st, c, upw, B, T, w.xproj, lengths, init_state, w.out, w.gsave, w.gxbuf, w.gxctl);
   if (duo_usable(m, c, B, T))
     return duo_launch(m, st, c, B, T, w.xproj, lengths, init_state, w.out, w.gsave, w.gxbuf, w.gxctl);
-  if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res), gates saved for the backward scan
+  if (H == 256 || H == 128) {     // recurrent weights resident on the CU (k_bigru_res; H = 128: k_bigru_quad, as inference runs it), gates saved for the backward scan
     BigruSArgs a; memset(&a, 0, sizeof a);
     a.xproj = w.xproj; a.g2_0 = (const float2*)AP(m, c.res_g2[0]); a.g2_1 = (const float2*)AP(m, c.res_g2[1]);
     a.c1_0 = AP(m, c.raw_ch[0]); a.c1_1 = AP(m, c.raw_ch[1]); a.lengths = lengths; a.out = w.out; a.gsave = w.gsave; a.B = B; a.T = T;
     a.h0 = init_state;
     if (H == 256) hipLaunchKernelGGL((k_bigru_res<256, 64, 24, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(256, 24, 1), st, a);
+    else if (m->persist == 1 && x.t->resident_bwd_scan) hipLaunchKernelGGL(k_bigru_quad<true>, dim3(2 * B), dim3(512), 0, st, a);      // (the A/B engine keeps k_bigru_res)
     else hipLaunchKernelGGL((k_bigru_res<128, 32, 0, 1, true>), dim3(2 * B), dim3(512), bigru_res_lds(128, 0, 1), st, a);
   } else {
     int R = 0; size_t lds = 0;

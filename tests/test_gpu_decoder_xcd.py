@@ -443,6 +443,7 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     m = build_model(ohp, O.init_weights(ohp, 1, 401))
     plan = m.engine_plan(32, 128, 512)
     assert "decoder loop: persistent k_decoder_xcd<4>" in plan and "post-net scan: persistent k_bigru_oct<4>" in plan and "split-bf16" in plan, plan
+    assert "encoder prenet: one k_pointwise_chain launch" in plan, plan            # round 5: gather + both layers + the forward's zero fills in one launch
     assert "k_decoder_xcd<1>" in m.engine_plan(2, 512)
     assert "rows > 64" in m.engine_plan(65, 64)
     assert "does not fit a member's LDS" in m.engine_plan(64, 2000), m.engine_plan(64, 2000)
@@ -455,6 +456,7 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     t = build_model(tiny_hp(), O.init_weights(tiny_hp(), 1, 403))
     plan = t.engine_plan(4, 9)
     assert "one launch per stage -- widths outside the presets" in plan and "resident per-row kernels" in plan, plan
+    assert "encoder prenet: one GEMM launch per layer" in plan, plan
 
 
 def test_a_device_fault_is_reported_by_the_forward_that_saw_it():

@@ -84,6 +84,8 @@ def measure(args):
             "engine": {"decoder_loop_and_postnet_scans": "persistent whole-chip kernels with tape (protocol %d)" % engine["protocol"] if args.engine and engine["protocol"] else "one launch per stage",
                        "decoder_bptt": "one persistent whole-chip launch (k_decoder_bwd_xcd)" if engine.get("bptt_protocol", 0) else "one launch per stage (per-stage chain)",
                        "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact", 4: "forward bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients bf16 MFMA with operands split in two (3 products)"}[args.exact_gemm],
+                       "backward_scans": ("post-net: k_bigru_oct_bwd (one row per cluster of 8 CUs) from 9 to 32 rows, else k_bigru_duo_bwd; encoder: k_bigru_resb (recurrent kernels in registers)"
+                                          if args.engine and engine["protocol"] and args.bptt else "k_bigru_rows_bwd (round 1's kernel: A/B engine)"),
                        "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
