@@ -1,6 +1,6 @@
 #!/bin/bash
-out=gpurun_out/r05_final; mkdir -p $out
+out=gpurun_out/r05_sq; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee $out/pytest_gpu.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee -a $out/pytest_gpu.txt
-timeout 200 python bench.py --no-cpu-baseline --no-companions --steps 20 --warmup 4 > $out/bench_C2_quick.json 2> $out/bench.err; grep -o '"ms_per_step": [0-9.]*' $out/bench_C2_quick.json | head -1; grep -o '"traffic": [0-9.a-z]*' $out/bench_C2_quick.json | head -1
+timeout 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $out/pmc_sq -o sq --output-format csv -- python tools/bench_train.py --steps 2 --warmup 1 > $out/pmc_sq.log 2>&1
+python tools/pmc_sq.py $out/pmc_sq $out/train_pmc_sq.txt "python tools/bench_train.py --steps 2 --warmup 1 (C4 shard; 5 forwards, 4 backward passes)" 30 | tail -34
+rm -rf $out/pmc_sq
