@@ -213,8 +213,7 @@ taco_model* taco_train_model(taco_train* t);
 int taco_train_set_deterministic(taco_train* t, int on);
 /* Weight gradients: on = 0 (default) computes dW = X^T . dY on the bf16 matrix cores with operands split three ways (24 bits) and
  * six products per tile, fp32 accumulation (k_wgrad_bf3: fp32-grade, ~2^-24 per product); on = 1 keeps them on the
- * exact-fp32 MFMA (k_wgrad, round 1); on = 2: the split-bf16 kernel with one 64 x 64 tile per wave everywhere (round 4), where the default
- * lets a workgroup of four waves own a 128 x 128 tile and convert every operand block once (k_wgrad_bf3s, round 5).  A/B and test hook. */
+ * exact-fp32 MFMA (k_wgrad, round 1).  Process-wide A/B and test hook. */
 int taco_train_set_exact_wgrad(taco_train* t, int on);
 /* Feed-forward GEMMs of the training step (both CBHGs' conv banks / projections / highways / GRU input projections, encoder prenet,
  * linear head) and their data gradients.  k_gemm = exact-fp32 MFMA; k_gemm_bf3 = the inference kernels: bf16 matrix cores, both

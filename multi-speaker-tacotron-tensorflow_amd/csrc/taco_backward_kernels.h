@@ -562,145 +562,6 @@ __global__ __launch_bounds__(64) void k_wgrad_bf3_group(const WgGroup G) {
   wgrad_bf3_body<1>(g, local % gx, (local / gx) % gy, local / (gx * gy));
 }
 
-// ---- the same product with the operand blocks converted ONCE per workgroup (round 5) ----
-// SQ counters of the training step (profiles/r05_v2_train_pmc_sq.txt): the one-wave kernel above spends 47 % of a launch issuing VALU instructions
-// -- every operand element is converted to its three bf16 planes by every wave whose tile uses it -- against 17 % for the matrix pipe, and a wave
-// pulls its fp32 operands at the rate a CU gets from L2 whatever it does.  Here a workgroup of 4 waves owns a 128 x 128 tile: per
-// 16-row block the 256 threads load and convert the 16 x 128 block of x and the 16 x 128 block of dy once (16 elements per thread instead of 32
-// per lane), park the planes in LDS as [plane][row half][column][8 rows] -- a lane's MFMA fragment (one column, eight consecutive rows) is one
-// ds_read_b128 and the 32 lanes of a row half read 512 consecutive bytes (no bank conflicts) --, and every wave reads the fragments of its 64 x 64 sub-tile from there: half the conversions and half the L2 bytes per
-// product.  Two LDS buffers (48 KB), one barrier per block; the next block's global loads are in flight across the MFMAs.  Same products, same
-// order inside a tile, same outputs (atomics / per-slice partial tiles) as wgrad_bf3_body.
-#define WGS_T 128
-#define WGS_LDS (2 * 2 * 3 * WGS_T * 16)          // unsigned shorts: [buffer][x | dy][plane][row half][column][8 rows]
-__device__ __forceinline__ void wgrad_bf3s_body(const WgArgs& g, int bx, int by, int bz, unsigned short* sm) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i = lane & 31, h = lane >> 5;
-  const int kb = bx * WGS_T, nb = by * WGS_T;
-  const int nsplit = (g.M + g.rpb - 1) / g.rpb;
-  const int tap = bz / nsplit, sp = bz - tap * nsplit;
-  const int shift = tap - g.padl;
-  const int m0 = sp * g.rpb, m1 = min(g.M, m0 + g.rpb);
-  // loader: column lc of the tile (x: k, dy: n), rows 8 lh .. 8 lh + 7 of the block
-  const int lc = tid & (WGS_T - 1), lh = tid >> 7;
-  const bool kok = kb + lc < g.K, nok = nb + lc < g.N;
-  const bool full = (kb + WGS_T <= g.K) && (nb + WGS_T <= g.N) && !g.gather && !g.ygather;     // workgroup-uniform: no column masks, plain row indices
-  float av[8], bv[8];
-  auto fetch = [&](int mb) {
-    const int tb = (g.T > 0) ? (mb % g.T) : 0;     // (see wgrad_bf3_body: the block must lie in one batch row before AND after the tap shift)
-    const bool inner = full && (mb + 16 <= m1) && (g.T <= 0 || (tb + 15 < g.T && tb + shift >= 0 && tb + 15 + shift < g.T));
-    if (inner) {
-      const unsigned xo = (unsigned)(mb + 8 * lh + shift) * (unsigned)g.ldx + (unsigned)(kb + lc);
-      const unsigned yo = (unsigned)(mb + 8 * lh) * (unsigned)g.ldy + (unsigned)(nb + lc);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { av[e] = g.x[xo + (unsigned)e * (unsigned)g.ldx]; bv[e] = g.dy[yo + (unsigned)e * (unsigned)g.ldy]; }
-      return;
-    }
-    const int mr = mb + 8 * lh;
-    int tt = (g.T > 0) ? (mr % g.T) : 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int m = mr + e;
-      bool rok = m < m1;
-      if (g.T > 0) { const int ts = tt + shift; rok = rok && ts >= 0 && ts < g.T; if (++tt == g.T) tt = 0; }
-      const bool mok = m < m1;
-      size_t xr = 0, yr = 0;
-      if (mok) { xr = g.gather ? (size_t)g.gather[m] : (size_t)(m + shift); yr = g.ygather ? (size_t)g.ygather[m] : (size_t)m; }
-      av[e] = (rok && kok) ? g.x[xr * g.ldx + kb + lc] : 0.f;
-      bv[e] = (mok && nok) ? g.dy[yr * g.ldy + nb + lc] : 0.f;
-    }
-  };
-  auto plane = [&](int buf, int op, int p, int half) { return sm + (size_t)((((buf * 2 + op) * 3 + p) * 2 + half) * WGS_T) * 8; };
-  auto stash = [&](int buf) {
-    bf16x8 hi, mid, lo;
-    wgb_split3(av, hi, mid, lo);
-    *reinterpret_cast<bf16x8*>(plane(buf, 0, 0, lh) + lc * 8) = hi;
-    *reinterpret_cast<bf16x8*>(plane(buf, 0, 1, lh) + lc * 8) = mid;
-    *reinterpret_cast<bf16x8*>(plane(buf, 0, 2, lh) + lc * 8) = lo;
-    wgb_split3(bv, hi, mid, lo);
-    *reinterpret_cast<bf16x8*>(plane(buf, 1, 0, lh) + lc * 8) = hi;
-    *reinterpret_cast<bf16x8*>(plane(buf, 1, 1, lh) + lc * 8) = mid;
-    *reinterpret_cast<bf16x8*>(plane(buf, 1, 2, lh) + lc * 8) = lo;
-  };
-  // this wave's 64 x 64 sub-tile
-  const int kw0 = kb + 64 * (wave >> 1), nw0 = nb + 64 * (wave & 1);
-  const bool work = kw0 < g.K && nw0 < g.N;                        // (a wave without columns still loads, converts and meets the barriers)
-  const bool k2 = kw0 + 32 < g.K, n2 = nw0 + 32 < g.N;
-  wg_f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  fetch(m0);
-  stash(0);
-  __syncthreads();
-  int buf = 0;
-  for (int mb = m0; mb < m1; mb += 16) {
-    const bool more = mb + 16 < m1;
-    if (more) fetch(mb + 16);                                       // in flight across the MFMAs below
-    if (work) {
-      bf16x8 ah[2], am[2], al[2], bh[2], bm[2], bl[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const int ca = (64 * (wave >> 1) + 32 * a + i) * 8, cb = (64 * (wave & 1) + 32 * a + i) * 8;
-        ah[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 0, 0, h) + ca); am[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 0, 1, h) + ca); al[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 0, 2, h) + ca);
-        bh[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 1, 0, h) + cb); bm[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 1, 1, h) + cb); bl[a] = *reinterpret_cast<const bf16x8*>(plane(buf, 1, 2, h) + cb);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        if (a == 1 && !k2) break;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          if (b == 1 && !n2) break;
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);      // small terms first
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bm[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[a], bh[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bm[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-        }
-      }
-    }
-    if (more) stash(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
-  }
-  if (!work) return;
-  float* out = g.part ? g.part + ((size_t)sp * g.kw + tap) * g.K * g.N : g.dw + (size_t)tap * g.K * g.lddw;
-  const int ldo = g.part ? g.N : g.lddw;
-  const bool nokc[2] = {nw0 + i < g.N, nw0 + 32 + i < g.N};
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      if ((a == 1 && !k2) || (b == 1 && !n2) || !nokc[b]) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = kw0 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (kr < g.K) {
-          float* p = out + (size_t)kr * ldo + nw0 + 32 * b + i;
-          if (g.part) *p = acc[a][b][r]; else atomicAdd(p, acc[a][b][r]);
-        }
-      }
-    }
-}
-__global__ __launch_bounds__(256) void k_wgrad_bf3s(const WgArgs g) {
-  __shared__ __attribute__((aligned(16))) unsigned short sm[WGS_LDS];
-  wgrad_bf3s_body(g, blockIdx.x, blockIdx.y, blockIdx.z, sm);
-}
-// (group launch: as k_wgrad_bf3_group, for the problems that take the workgroup tile)
-__global__ __launch_bounds__(256) void k_wgrad_bf3s_group(const WgGroup G) {
-  __shared__ __attribute__((aligned(16))) unsigned short sm[WGS_LDS];
-  const int b = blockIdx.x;
-  int p = 0;
-  while (p + 1 < G.n && G.start[p + 1] <= b) ++p;
-  p = __builtin_amdgcn_readfirstlane(p);
-  const WgArgs g = G.p[p];
-  const int local = b - G.start[p], gx = (g.K + WGS_T - 1) / WGS_T, gy = (g.N + WGS_T - 1) / WGS_T;
-  wgrad_bf3s_body(g, local % gx, (local / gx) % gy, local / (gx * gy), sm);
-}
-
 // dw[tap][k][n] += sum over the M-slices, slice 0 first (fixed order: run-to-run reproducible)
 __global__ void k_wgrad_reduce(const float* part, int nsplit, int kw, int K, int N, float* dw, int lddw) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = (size_t)kw * K * N;

@@ -200,22 +200,21 @@ static thread_local DetScratch g_det;
 // Deterministic mode: the collected problems write per-slice partials into consecutive regions of the deterministic scratch (det_used: the
 // cursor; a problem that does not fit flushes the region first) and two more group launches add the slices up in a fixed order.  (Problems
 // launched on their own in between use the scratch from its start: everything is stream ordered, the group's kernels run at the flush.)
-struct WgBatch { WgGroup g; WgGroup gs; ColGroup c; WgRedGroup r; ColRedGroup cr; size_t det_used = 0; bool active = false; hipStream_t st = nullptr; };      // gs: problems on the 128 x 128 workgroup tile (k_wgrad_bf3s_group)
+struct WgBatch { WgGroup g; ColGroup c; WgRedGroup r; ColRedGroup cr; size_t det_used = 0; bool active = false; hipStream_t st = nullptr; };
 static thread_local WgBatch g_wgb;
 static int wg_flush() {      // (column sums of the region ride along: same hazards, same flush points)
   WgGroup& G = g_wgb.g; ColGroup& Cg = g_wgb.c;
   if (Cg.n > 0) hipLaunchKernelGGL(k_colsum_group, dim3(Cg.start[Cg.n]), dim3(256), 0, g_wgb.st, Cg);
   if (G.n > 0) hipLaunchKernelGGL(k_wgrad_bf3_group, dim3(G.start[G.n]), dim3(64), 0, g_wgb.st, G);
-  if (g_wgb.gs.n > 0) hipLaunchKernelGGL(k_wgrad_bf3s_group, dim3(g_wgb.gs.start[g_wgb.gs.n]), dim3(256), 0, g_wgb.st, g_wgb.gs);
   if (g_wgb.cr.n > 0) hipLaunchKernelGGL(k_colsum_reduce_group, dim3(g_wgb.cr.start[g_wgb.cr.n]), dim3(256), 0, g_wgb.st, g_wgb.cr);
   if (g_wgb.r.n > 0) hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(g_wgb.r.start[g_wgb.r.n]), dim3(256), 0, g_wgb.st, g_wgb.r);
-  if (Cg.n > 0 || G.n > 0 || g_wgb.gs.n > 0) HIPCHK(hipGetLastError());
-  G.n = 0; G.start[0] = 0; Cg.n = 0; Cg.start[0] = 0; g_wgb.gs.n = 0; g_wgb.gs.start[0] = 0;
+  if (Cg.n > 0 || G.n > 0) HIPCHK(hipGetLastError());
+  G.n = 0; G.start[0] = 0; Cg.n = 0; Cg.start[0] = 0;
   g_wgb.r.n = 0; g_wgb.r.start[0] = 0; g_wgb.cr.n = 0; g_wgb.cr.start[0] = 0; g_wgb.det_used = 0;
   return 0;
 }
 static void wg_begin(hipStream_t st) {
-  g_wgb.active = true; g_wgb.st = st; g_wgb.g.n = 0; g_wgb.g.start[0] = 0; g_wgb.gs.n = 0; g_wgb.gs.start[0] = 0; g_wgb.c.n = 0; g_wgb.c.start[0] = 0;
+  g_wgb.active = true; g_wgb.st = st; g_wgb.g.n = 0; g_wgb.g.start[0] = 0; g_wgb.c.n = 0; g_wgb.c.start[0] = 0;
   g_wgb.r.n = 0; g_wgb.r.start[0] = 0; g_wgb.cr.n = 0; g_wgb.cr.start[0] = 0; g_wgb.det_used = 0;
 }
 static int wg_end() { const int rc = wg_flush(); g_wgb.active = false; return rc; }
@@ -266,15 +265,12 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
   WgArgs g; g.ygather = ygather; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
   g.kw = kw; g.padl = padl;
   const bool bf3 = g_wgrad_bf3 != 0;
-  // 128 x 128 workgroup tile with the operand blocks converted once into LDS (k_wgrad_bf3s): wherever both K and N reach past one 64-wide tile
-  // (g_wgrad_bf3 == 2 keeps round 4's per-wave tiles everywhere: A/B)
-  const bool shared = g_wgrad_bf3 == 1 && K > 64 && N > 64;
   // split-bf16 kernel: 128 x 128 tiles (4 waves) when those alone give a few hundred workgroups, else 64 x 64 tiles (1 wave): every
   // M-slice a workgroup takes ends in one atomic per output element, so slices are kept LONG (>= 256 rows where the grid allows)
   const long t128 = (long)cdiv(K, 128) * cdiv(N, 128) * kw, t64 = (long)cdiv(K, 64) * cdiv(N, 64) * kw;
-  const bool big = bf3 && !shared && t128 >= 64;
-  { const long tiles = (big || shared) ? t128 : t64; int rpb = 1024;
-    const long want = bf3 ? (shared ? 640 : big ? 768 : 1024) : 2048;      // workgroups (one-wave workgroups: four times as many fit a CU).  (Ordered sums: halving or doubling the
+  const bool big = bf3 && t128 >= 64;
+  { const long tiles = big ? t128 : t64; int rpb = 1024;
+    const long want = bf3 ? (big ? 768 : 1024) : 2048;      // workgroups (one-wave workgroups: four times as many fit a CU).  (Ordered sums: halving or doubling the
                                                              // slices of the small problems changes nothing, 15.87 / 15.88 ms; a quarter of them: 16.14 -- the partials' traffic is not what the mode costs)
     while (rpb > (bf3 ? 128 : 64) && tiles * cdiv(M, rpb) < want) rpb >>= 1;
     g.rpb = rpb; }
@@ -286,7 +282,7 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
     g.part = g_det.p;
   }
   const int nsplit = cdiv(M, g.rpb);
-  if (g_wgb.active && bf3 && !big) {       // inside a batching region: joins the group launch of its tile kind
+  if (g_wgb.active && bf3 && !big) {       // small problem inside a batching region: joins the group launch
     if (g.part) {                          // deterministic: its own region of the scratch, summed by the group's reduce launch
       const size_t need = (size_t)nsplit * kw * K * N;
       bool clash = false;                  // (same rule as for the column sums: one writer per output per reduce launch)
@@ -297,16 +293,10 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
       R.p[R.n].part = g.part; R.p[R.n].dw = dw; R.p[R.n].nsplit = nsplit; R.p[R.n].kw = kw; R.p[R.n].K = K; R.p[R.n].N = N; R.p[R.n].lddw = lddw;
       R.start[R.n + 1] = R.start[R.n] + cdiv(kw * K * N, 256); ++R.n;
     }
-    WgGroup& G = shared ? g_wgb.gs : g_wgb.g;
+    WgGroup& G = g_wgb.g;
     G.p[G.n] = g;
-    G.start[G.n + 1] = G.start[G.n] + (shared ? cdiv(K, WGS_T) * cdiv(N, WGS_T) : cdiv(K, 64) * cdiv(N, 64)) * kw * nsplit;
+    G.start[G.n + 1] = G.start[G.n] + cdiv(K, 64) * cdiv(N, 64) * kw * nsplit;
     if (++G.n == WG_MAXP) return wg_flush();
-    return 0;
-  }
-  if (shared) {
-    hipLaunchKernelGGL(k_wgrad_bf3s, dim3(cdiv(K, WGS_T), cdiv(N, WGS_T), kw * nsplit), dim3(256), 0, st, g);
-    if (g.part) hipLaunchKernelGGL(k_wgrad_reduce, EWGRID((size_t)kw * K * N), 0, st, (const float*)g.part, nsplit, kw, K, N, dw, lddw);
-    HIPCHK(hipGetLastError());
     return 0;
   }
   if (bf3 && big) hipLaunchKernelGGL((k_wgrad_bf3<4>), dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit), dim3(256), 0, st, g);

@@ -129,7 +129,7 @@ class Trainer(object):
     def set_exact_wgrad(self, on=True):
         """Weight gradients on the exact-fp32 MFMA (round 1's k_wgrad) instead of the default split-bf16 matrix-core kernel
         (k_wgrad_bf3: operands split three ways, six products, fp32-grade).  Process-wide A/B and test hook."""
-        _lib.check(self._lib.taco_train_set_exact_wgrad(self._h, int(on)))      # True / 1: exact; 2: split-bf16 on per-wave tiles only (round 4's kernels, A/B)
+        _lib.check(self._lib.taco_train_set_exact_wgrad(self._h, 1 if on else 0))
         if getattr(self, "_graph", None) is not None:
             self._graph = None
 

@@ -27,7 +27,7 @@ def measure(args):
     if args.exact_gemm != 4:
         tr.set_exact_gemm(args.exact_gemm)
     if args.exact_wgrad:
-        tr.set_exact_wgrad(args.exact_wgrad)
+        tr.set_exact_wgrad(True)
     tr.set_deterministic(bool(args.deterministic))
     rs = np.random.RandomState(77 + rank)
     B, T_in, T_out = args.batch, args.t_in, args.t_out
@@ -86,7 +86,7 @@ def measure(args):
                        "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact", 4: "forward bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients bf16 MFMA with operands split in two (3 products)"}[args.exact_gemm],
                        "backward_scans": ("post-net: k_bigru_oct_bwd (one row per cluster of 8 CUs) from 9 to 32 rows, else k_bigru_duo_bwd; encoder: k_bigru_resb (recurrent kernels in registers)"
                                           if args.engine and engine["protocol"] and args.bptt else "k_bigru_rows_bwd (round 1's kernel: A/B engine)"),
-                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad == 1 else "bf16 MFMA, operands split three ways (fp32-grade)" + (", per-wave 64 x 64 tiles only" if args.exact_wgrad == 2 else "; 128 x 128 workgroup tiles with operand blocks converted once"),
+                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
             "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9})
@@ -100,8 +100,8 @@ def measure(args):
         step_s = wall / args.steps
         total = 3 * fwd * world
         fgemm = {3: "exact-fp32 MFMA", 1: "exact-fp32 MFMA", 0: "bf16 MFMA x3", 2: "bf16 MFMA x3", 4: "bf16 MFMA x6 (fp32-grade)"}[args.exact_gemm]
-        bf16_issued = ((3 if args.exact_gemm in (0, 2) else 6 if args.exact_gemm == 4 else 0) + (3 if args.exact_gemm in (0, 3, 4) else 0) + (0 if args.exact_wgrad == 1 else 6)) * ff
-        f32_mfma = ((0 if args.exact_gemm in (0, 2, 4) else 1) + (1 if args.exact_gemm in (1, 2) else 0) + (1 if args.exact_wgrad == 1 else 0)) * ff
+        bf16_issued = ((3 if args.exact_gemm in (0, 2) else 6 if args.exact_gemm == 4 else 0) + (3 if args.exact_gemm in (0, 3, 4) else 0) + (0 if args.exact_wgrad else 6)) * ff
+        f32_mfma = ((0 if args.exact_gemm in (0, 2, 4) else 1) + (1 if args.exact_gemm in (1, 2) else 0) + (1 if args.exact_wgrad else 0)) * ff
         report["roofline"] = {
             "bound": "mfma", "achieved": total / step_s / 1e12, "peak": bench.MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
             "frac": total / step_s / 1e12 / bench.MFMA_F32_PEAK_TF, "traffic": None,
