@@ -12,6 +12,11 @@
 //   * between layers: barrier, the lanes write their outputs into the planes, barrier;
 //   * the last link (N = 6H columns) loops over column groups of W and stores straight to the projection buffer, the backward
 //     direction's columns time-reversed per row (tf.reverse_sequence, A.7) exactly as k_gemm_bf3's epilogue does.
+//
+// Round 5: the same kernel also runs the ENCODER PRENET (taco_lib.hip: run_prenet_chain) -- the embedding rows gathered straight into the planes
+// (ChainArgs.gather), a 256-wide ReLU layer, and the second layer as the chain's last link with a ReLU on its way out (ChainLayer.act) --, and the
+// workgroups of that launch that own no tile clear the words the forward's persistent kernels poll (ChainArgs.ntiles, zp, znw).  The workgroups of
+// an XCD walk every layer's K loop from different starting steps (CH_ROT).
 #pragma once
 #include "taco_kernels.h"
 

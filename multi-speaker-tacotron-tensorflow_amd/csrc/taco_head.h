@@ -5,11 +5,14 @@
 // rows again (eight 64-channel rounds, two barriers each, nothing in flight while the tile is converted) and 1280 workgroups take
 // five turns on the chip: 91 us at C2, 27 % of the bf16 pipe.  Here a workgroup owns 64 rows for ALL columns:
 //   * the rows are staged ONCE -- fp32 -> (hi, lo) bf16 planes [64][K + 8] in LDS, one barrier in the whole kernel;
-//   * wave w sweeps the column-tile pairs w, w + 8, ... (64 x 64 outputs per pass, K / 16 steps of 12 MFMAs); its weight fragments
-//     come straight from the layer's pack in L2 through a ring of HD_PF register sets that runs on across the passes, so the stream
-//     never restarts; the stores of a pass drain behind the products of the next one;
+//   * wave w sweeps the column-tile pairs w, w + 8, ... ONE 32-column tile at a time (round 5; 64 x 32 outputs, K / 16 steps of 6
+//     MFMAs; round 4: the pair at once); its weight fragments come straight from the layer's pack in L2 through a ring of HD_PF
+//     register sets that runs on across the tiles, so the stream never restarts; the stores of a tile ride inside the product loop
+//     of the next one -- a quarter of a wave's stores is left after its last products;
+//   * the workgroups of an XCD start their sweep at different passes (HD_ROT): they do not all ask the L2 for the same tiles at once;
 //   * the columns past the last full tile (ONE at N = 1025) are dot products on the vector ALU from the same planes (hi + lo as fp32,
-//     fp32 weights): a 33rd MFMA tile would hand one wave a third pass while seven idle.
+//     fp32 weights): a 33rd MFMA tile would hand one wave a third pass while seven idle.  They come FIRST, right behind the staging
+//     barrier: behind the sweep their weight loads queued up behind the last tile's stores.
 #pragma once
 #include "taco_kernels.h"
 

@@ -2020,7 +2020,7 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   const int CH = m->overlap > 16 ? m->overlap : 16;   // decoder steps per post-net chunk
   if (!m->overlap || (size_t)(n / CH + 4) > m->events.size()) {
     // every word a persistent kernel polls and the stop flags, cleared by ONE launch in front of the forward; the stop rule and the
-    // error latch are ONE launch behind it (16 graph nodes at C2; 20 in round 3)
+    // error latch are ONE launch behind it (11 graph nodes at C2 with the clears riding in the prenet launch; 13 in round 4, 20 in round 3)
     ZeroRegions z; memset(&z, 0, sizeof z);
     z.p[0] = (uint32_t*)w.dec.xbuf; z.nw[0] = ((size_t)((char*)w.dec.dxctl - (char*)w.dec.xbuf) + 256) / 4;
     z.p[1] = (uint32_t*)w.dec.nz; z.nw[1] = (size_t)n * B;

@@ -5,6 +5,22 @@ tag=${1:-vXX}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ "$2" = "core" ]; then
+  # the hash-tied part only (after a change to the kernel sources that moves no number, e.g. comments):  bash tools/collect_profiles.sh rNN_vM core
+  # order: the counter passes FIRST, so that the bench line finds its traffic profile only if this script is followed by adopt + a second bench run;
+  # here the line is printed last and patched by tools/adopt_profiles.sh's caller as before
+  B="python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 3 --warmup 0 --lanes 1"
+  timeout 400 rocprofv3 --pmc FETCH_SIZE -d $out/pmc_f -o f --output-format csv -- $B > $out/pmc_f.log 2>&1
+  timeout 400 rocprofv3 --pmc WRITE_SIZE -d $out/pmc_w -o w --output-format csv -- $B > $out/pmc_w.log 2>&1
+  python tools/pmc_traffic.py $out/pmc_f $out/pmc_w $out/pmc_hbm_traffic > $out/pmc_traffic.log 2>&1
+  cp $out/pmc_hbm_traffic.json profiles/${tag%%_*}_${tag##*_}_pmc_hbm_traffic.json      # (on the box only: lets the bench line below find its profile by the source hash)
+  timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
+  cp $out/ks/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+  timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
+  rm -rf $out/ks/*kernel_trace.csv $out/pmc_f $out/pmc_w
+  tail -c 400 $out/bench_C2.json
+  exit 0
+fi
 [ -x tools/time_stages_native ] && timeout 60 ./tools/time_stages_native > $out/time_stages_native.txt 2>&1     # C ABI only, no Python: seconds
 timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
 timeout 300 python bench.py --workload C1 --steps 12 --warmup 3 > $out/bench_C1.json 2>> $out/bench_C2.err      # (with its CPU baseline: one utterance is cheap)
