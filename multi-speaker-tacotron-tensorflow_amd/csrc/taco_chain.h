@@ -216,7 +216,22 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
         f[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         src[u] = (i < (CH_BM + 2) * nq && row >= 0 && row < a.M) ? gpart + (size_t)row * E.N1 + c : nullptr;
       }
-      for (int q = 0; q < E.P; ++q) {            // parts in a fixed order; the NSTG loads of a part are in flight together
+      // parts in a fixed order (part q before part q + 1: bit-reproducible); the loads of TWO parts are in flight together -- a part's 9 loads per
+      // thread alone left a full memory round trip exposed per part (2 at the post-net, 8 at the encoder)
+      int q = 0;
+      for (; q + 1 < E.P; q += 2) {
+        float4 g[NSTG], g2[NSTG];
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) {
+          g[u] = src[u] ? *reinterpret_cast<const float4*>(src[u] + (size_t)q * E.MN) : make_float4(0.f, 0.f, 0.f, 0.f);
+          g2[u] = src[u] ? *reinterpret_cast<const float4*>(src[u] + (size_t)(q + 1) * E.MN) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) { f[u].x += g[u].x; f[u].y += g[u].y; f[u].z += g[u].z; f[u].w += g[u].w; }
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) { f[u].x += g2[u].x; f[u].y += g2[u].y; f[u].z += g2[u].z; f[u].w += g2[u].w; }
+      }
+      if (q < E.P) {
         float4 g[NSTG];
 #pragma unroll
         for (int u = 0; u < NSTG; ++u) g[u] = src[u] ? *reinterpret_cast<const float4*>(src[u] + (size_t)q * E.MN) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -401,19 +416,21 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
     if (L.type == CH_XPROJ) {
       // ---- last link: N = 6H columns in groups of W, stored straight to the projection buffer ----
       const int ngroups = (L.N + W - 1) / W;
-      const int bb0 = m0 / a.T;                // a tile of 64 rows spans at most two batch rows when T >= 64
+      const int bb0 = m0 / a.T;                // a tile of 64 rows spans at most two batch rows when T >= 64: their lengths once, not once per stored element
+      const int nbrow = (a.M - 1) / a.T;
+      const int Lb0 = a.rev_len ? a.rev_len[min(bb0, nbrow)] : a.T, Lb1 = a.rev_len ? a.rev_len[min(bb0 + 1, nbrow)] : a.T;
       auto store_group = [&](int ng, const f32x16 (&acc)[TM]) {
         const int ocol = ng * W + col;
         if (ocol >= L.N) return;
         const float bia = L.bias ? L.bias[ocol] : 0.f;
         const bool rev = a.rev_col0 >= 0 && ocol >= a.rev_col0;
-        const float floor_ = L.act == ACT_RELU ? 0.f : -INFINITY;      // (a chain that ends in a ReLU layer: the encoder prenet)
+        const bool relu_out = L.act == ACT_RELU;                       // (a chain that ends in a ReLU layer: the encoder prenet; otherwise the value passes as it is, a NaN included)
         if (full && !rev) {
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm) {
             float* po = a.out + (size_t)(m0 + rloc(tm, 0)) * a.ldo + ocol;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = fmaxf(acc[tm][r] + bia, floor_);
+            for (int r = 0; r < 16; ++r) { const float v = acc[tm][r] + bia; po[(size_t)((r & 3) + 8 * (r >> 2)) * a.ldo] = relu_out ? fmaxf(v, 0.f) : v; }
           }
         } else {                               // the backward direction's columns go to the time-reversed row of the batch row
           int lhs = lh;                        // (opaque per call: the 32 reversed row indices are formed here, not kept -- and spilled -- across the column groups)
@@ -426,10 +443,10 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
               int orow = row;
               if (rev) {
                 const int bb = a.T >= CH_BM ? bb0 + (row >= (bb0 + 1) * a.T ? 1 : 0) : row / a.T;
-                const int tt = row - bb * a.T, Lb = a.rev_len ? a.rev_len[min(bb, (a.M - 1) / a.T)] : a.T;
+                const int tt = row - bb * a.T, Lb = a.T >= CH_BM ? (bb == bb0 ? Lb0 : Lb1) : (a.rev_len ? a.rev_len[min(bb, (a.M - 1) / a.T)] : a.T);
                 orow = tt < Lb ? bb * a.T + (Lb - 1 - tt) : row;
               }
-              if (row < a.M) a.out[(size_t)orow * a.ldo + ocol] = fmaxf(acc[tm][r] + bia, floor_);
+              if (row < a.M) { const float v = acc[tm][r] + bia; a.out[(size_t)orow * a.ldo + ocol] = relu_out ? fmaxf(v, 0.f) : v; }
             }
         }
       };
