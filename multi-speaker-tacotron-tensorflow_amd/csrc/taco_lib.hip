@@ -1616,8 +1616,8 @@ static bool prenet_chain_fits(const taco_model* m) {
   return a.bh && b.bh && a.kw == 1 && b.kw == 1 && a.N == 256 && a.cin == hp.embedding_size && a.cin_pad16 <= 256 && (hp.embedding_size & 3) == 0 &&
          b.cin == 256 && b.N == hp.enc_prenet[1] && a.var_index >= 0 && b.var_index >= 0;
 }
-static thread_local const ZeroRegions* g_zero_rider = nullptr;      // forward_enqueue -> run_prenet_chain: the forward's up-front clears ride in the prenet launch
-static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids, int M, float* out) {
+// riders (nullable): regions the launch's spare workgroups clear -- the words the persistent kernels of the same forward poll (forward_enqueue)
+static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids, int M, float* out, const ZeroRegions* riders) {
   const taco_hparams& hp = m->hp;
   ChainArgs a; memset(&a, 0, sizeof a);
   a.x = AP(m, m->emb); a.ldx = hp.embedding_size; a.Cin = hp.embedding_size; a.gather = ids;
@@ -1630,24 +1630,24 @@ static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids,
     l.type = types[i]; l.K16 = v.K16; l.NT = v.NT; l.N = v.N; l.act = ACT_RELU;
   }
   int nwg = cdiv(M, CH_BM);
-  if (g_zero_rider) {
+  if (riders) {
     a.ntiles = nwg;
-    for (int i = 0; i < 4; ++i) { a.zp[i] = g_zero_rider->p[i]; a.znw[i] = g_zero_rider->nw[i]; }
+    for (int i = 0; i < 4; ++i) { a.zp[i] = riders->p[i]; a.znw[i] = riders->nw[i]; }
     nwg += std::min(192, std::max(16, 256 - nwg));
-    g_zero_rider = nullptr;
   }
   hipLaunchKernelGGL((k_pointwise_chain<256>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
   HIPCHK(hipGetLastError());
   return 0;
 }
+// riders: see run_prenet_chain; only passed where prenet_chain_fits(m) (the caller clears the regions itself otherwise)
 static int encoder_forward(const taco_model* m, hipStream_t st, const int* ids, const int* lengths, const int* speaker_id,
-                           int B, int T, float* enc_out, const EncWs& w, bool spk_done) {
+                           int B, int T, float* enc_out, const EncWs& w, bool spk_done, const ZeroRegions* riders = nullptr) {
   const taco_hparams& hp = m->hp;
   const int M = B * T;
   if (is_deepvoice(m) && !spk_done) TRY(spk_forward(m, st, speaker_id, B, w.spk));
   const float* cur = AP(m, m->emb); int curd = hp.embedding_size;
   if (prenet_chain_fits(m)) {
-    TRY(run_prenet_chain(m, st, ids, M, w.pre[1]));
+    TRY(run_prenet_chain(m, st, ids, M, w.pre[1], riders));
     return cbhg_forward(m, st, m->enc, w.pre[1], B, T, lengths, is_deepvoice(m) ? w.spk.vec[0] : nullptr,
                         is_deepvoice(m) ? w.spk.vec[1] : nullptr, enc_out, w.cb);
   }
@@ -2027,9 +2027,8 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
     z.p[2] = (uint32_t*)w.post.cb.gxbuf; z.nw[2] = ((size_t)((char*)w.post.cb.gxctl - (char*)w.post.cb.gxbuf) + 256) / 4;
     z.p[3] = (uint32_t*)w.enc.cb.gxbuf; z.nw[3] = ((size_t)((char*)w.enc.cb.gxctl - (char*)w.enc.cb.gxbuf) + 256) / 4;     // (an encoder of width 256 scans on k_bigru_duo too)
     // (they ride in the encoder prenet's launch where that is the chain kernel -- the first launch of the forward, with CUs to spare)
-    struct Rider { ~Rider() { g_zero_rider = nullptr; } } rider;
-    if (prenet_chain_fits(m)) g_zero_rider = &z;
-    else {
+    const bool ride = prenet_chain_fits(m);
+    if (!ride) {
       hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
       HIPCHK(hipGetLastError());
     }
@@ -2037,7 +2036,7 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
       explicit Guard(const ZeroRegions& z) { g_cleared.cnt = 0; for (int i = 0; i < 4; ++i) if (z.p[i]) { g_cleared.p[g_cleared.cnt] = z.p[i]; g_cleared.n[g_cleared.cnt++] = z.nw[i] * 4; } }
       ~Guard() { g_cleared.cnt = 0; }
     } guard(z);
-    TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false));
+    TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false, ride ? &z : nullptr));
     TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, nullptr, nullptr, w.dec, true, &w.enc.spk));
     TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
     if (stop) {
