@@ -29,3 +29,15 @@ def test_profile_files_named_in_the_documents_exist():
             if not glob.glob(p) and not glob.glob(p + "*"):      # (a name may be a prefix or carry a wildcard)
                 missing.append((doc, c))
     assert not missing, missing
+
+
+def test_tests_named_in_the_documents_exist():
+    """`tests/test_x.py::test_name` (or a prefix of a name, where the prose cuts it with an ellipsis) refers to a test that is there."""
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md"):
+        s = open(os.path.join(ROOT, doc)).read()
+        for f, name in set(re.findall(r"(tests/test_[a-z_0-9]+\.py)::(test_[A-Za-z0-9_]+)", s)):
+            p = os.path.join(ROOT, f)
+            if not os.path.exists(p) or ("def " + name) not in open(p).read():
+                missing.append((doc, f, name))
+    assert not missing, missing
