@@ -41,3 +41,15 @@ def test_tests_named_in_the_documents_exist():
             if not os.path.exists(p) or ("def " + name) not in open(p).read():
                 missing.append((doc, f, name))
     assert not missing, missing
+
+
+def test_tools_named_in_the_documents_exist():
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md", "profiles/README.md", "tools/scratch/README.md"):
+        s = open(os.path.join(ROOT, doc)).read()
+        for t in set(re.findall(r"tools/[A-Za-z0-9_/]+\.(?:py|sh|hip|cpp|h|patch)", s)):
+            if t.startswith("tools/rejected/"):      # named as history: removed from the tree in round 3
+                continue
+            if not os.path.exists(os.path.join(ROOT, t)):
+                missing.append((doc, t))
+    assert not missing, missing
