@@ -37,7 +37,9 @@ def floor_constants():
 
     def newest(pat):
         fs = glob.glob(os.path.join(prof, pat))
-        key = lambda f: (int((re.findall(r"^r(\d+)_", os.path.basename(f)) or ["0"])[0]), os.path.getmtime(f))
+        # round, then the collection's version (rNN_vM_... / ..._vM.ext), then age, then name: the same choice on a fresh checkout, where every file has the same mtime
+        key = lambda f: (int((re.findall(r"^r(\d+)_", os.path.basename(f)) or ["0"])[0]), int((re.findall(r"_v(\d+)[_.]", os.path.basename(f)) or ["0"])[-1]),
+                         os.path.getmtime(f), os.path.basename(f))
         return sorted(fs, key=key)[-1] if fs else None
     c = {"sources": {}, "hop_us": None, "dec_step_us": None, "dec_chain_us": None, "dec_hops": 10, "scan_phases_us": None,
          "scan_sync_us": None, "scan_kernel": None, "enc_scan_ns": None}
