@@ -42,14 +42,21 @@ def floor_constants():
                          os.path.getmtime(f), os.path.basename(f))
         return sorted(fs, key=key)[-1] if fs else None
     c = {"sources": {}, "hop_us": None, "dec_step_us": None, "dec_chain_us": None, "dec_hops": 10, "scan_phases_us": None,
-         "scan_sync_us": None, "scan_kernel": None, "enc_scan_ns": None}
+         "scan_sync_us": None, "scan_kernel": None, "enc_scan_ns": None, "iso_poll_us": None, "iso_exchange_us": None}
+    here = source_hash()
+
+    def src(f, h):
+        """a source of the floor: the file and whether it was taken from THIS build of the kernels (None: the file carries no hash -- profiles of
+        rounds 1-5 -- so the term may describe older kernel sources)"""
+        return {"file": os.path.basename(f), "kernel_source_hash": h, "matches_this_build": (h == here) if h else None}
     f = newest("r*decoder_timeline.json")
     try:
-        rec = json.load(open(f))["C2"]["persistent"]
+        doc = json.load(open(f))
+        rec = doc["C2"]["persistent"]
         tl, sp = rec["timeline_us"], rec["gates_stage_split_us"]
         c["dec_step_us"], c["hop_us"] = float(sum(tl.values())), float(sp["gather(poll)"])
         c["dec_chain_us"] = c["dec_step_us"] - c["dec_hops"] * c["hop_us"]
-        c["sources"]["decoder"] = os.path.basename(f)
+        c["sources"]["decoder"] = src(f, doc.get("kernel_source_hash"))
     except Exception:
         pass
     f = newest("r*scan_timeline.json")
@@ -59,7 +66,7 @@ def floor_constants():
         c["scan_phases_us"] = sum(v for k, v in ph.items() if "collect" not in k) / rec["clocks_per_us"]
         c["scan_sync_us"] = sum(v for k, v in ph.items() if "collect" in k) / rec["clocks_per_us"]
         c["scan_kernel"] = rec["kernel"]
-        c["sources"]["scan"] = os.path.basename(f)
+        c["sources"]["scan"] = src(f, rec.get("kernel_source_hash"))
     except Exception:
         pass
     f = newest("r*c2_kernel_stats*.csv")
@@ -67,7 +74,22 @@ def floor_constants():
         import csv
         q = [r for r in csv.DictReader(open(f)) if "k_bigru_quad" in r["Name"]][0]
         c["enc_scan_ns"] = float(q["AverageNs"])
-        c["sources"]["encoder_scan"] = os.path.basename(f)
+        hf = f[:-len(".csv")] + ".hash"
+        c["sources"]["encoder_scan"] = src(f, open(hf).read().strip() if os.path.exists(hf) else None)
+    except Exception:
+        pass
+    # the decoder's exchange IN ISOLATION (tools/ubench_mfma_stage, the stage without any arithmetic: publish, poll until every granule of the
+    # gathered vector carries the tag + LDS write, barrier) -- the hardware part of a hop; what the traced gather of the real kernel shows
+    # beyond it is the arrival spread of the member's slower waves, a property of this build
+    f = newest("r*ubench_mfma_stage*.txt")
+    try:
+        ln = [l for l in open(f) if l.startswith("no compute")][0]
+        us_step, clk_stage = float(re.search(r"([\d.]+) us per step", ln).group(1)), float(re.search(r"([\d.]+) clocks per stage", ln).group(1))
+        poll = float(re.search(r"poll \+ LDS write\s+([\d.]+)", ln).group(1))
+        clk_per_us = clk_stage * 10.0 / us_step
+        c["iso_poll_us"], c["iso_exchange_us"] = poll / clk_per_us, clk_stage / clk_per_us
+        c["sources"]["decoder_exchange_in_isolation"] = src(f, None)
+        c["sources"]["decoder_exchange_in_isolation"]["matches_this_build"] = "n/a: the micro-benchmark uses the kernel's publish / gather primitives, not its step"
     except Exception:
         pass
     return c
@@ -613,6 +635,15 @@ def main():
                                                "engine_info": model.decoder_engine_info()}
         p4.close()
         model.check_device_errors()
+        # (iii-b) more rows than one pass holds: four requests = 128 rows through ONE call of the C ABI, which runs them as two passes of 64
+        # (synthesizer.py:120-131 / eval.py --batch_size put no cap on the batch)
+        if 4 * B > 64:
+            p5 = model.plan_pool(B, T_in, n, lanes=1, coalesce=4)
+            fill(p5, 4)
+            companions["four_requests_per_call"] = {"mel_frames_per_s": 4 * B * n * r / timed_pool(p5, 1, max(4, ksteps // 2)), "rows_per_call": 4 * B,
+                                                    "plan": model.engine_plan(4 * B, T_in, n * r).split(";")[0]}
+            p5.close()
+            model.check_device_errors()
         # (iv) the launch-per-stage engine of round 1 (decoder and scans as chains of small launches that leave most CUs idle), with
         # four forwards in flight to fill them: higher throughput than it has latency to show for
         if args.decoder_engine != 0:
@@ -666,27 +697,34 @@ def main():
         have = lambda *ks: all(fc.get(k) is not None for k in ks)
         terms = {"feed_forward_at_measured_mfma_ceiling": 3 * ff_flops / (MFMA_BF16_MEASURED_TF * 1e12) * 1e3}
         if have("hop_us", "dec_chain_us"):
-            terms["decoder_hops"] = n * fc["dec_hops"] * fc["hop_us"] * 1e-3
+            iso = min(fc["iso_poll_us"], fc["hop_us"]) if have("iso_poll_us") else fc["hop_us"]
+            terms["decoder_handoffs_in_isolation"] = n * fc["dec_hops"] * iso * 1e-3
+            if have("iso_poll_us"):
+                terms["decoder_arrival_spread"] = n * fc["dec_hops"] * (fc["hop_us"] - iso) * 1e-3
             terms["decoder_chains"] = n * fc["dec_chain_us"] * 1e-3
         if have("scan_phases_us", "scan_sync_us"):
             terms["postnet_scan_phases"] = T_mel * fc["scan_phases_us"] * 1e-3
             terms["postnet_scan_collects_and_barriers"] = T_mel * fc["scan_sync_us"] * 1e-3
         if have("enc_scan_ns"):
             terms["encoder_scan"] = fc["enc_scan_ns"] * 1e-6
-        hw = {k: terms[k] for k in ("decoder_hops", "feed_forward_at_measured_mfma_ceiling") if k in terms}
+        hw = {k: terms[k] for k in ("decoder_handoffs_in_isolation", "feed_forward_at_measured_mfma_ceiling") if k in terms}
         design = {k: v for k, v in terms.items() if k not in hw}
         missing = [k for k in ("decoder", "scan", "encoder_scan") if k not in fc["sources"]]
         floor = {"hardware_terms": hw, "hardware_total": sum(hw.values()),
                  "design_terms": design, "design_total": sum(design.values()),
                  "total": sum(terms.values()), "measured_forward_ms": fwd_s * 1e3,
                  "sources": fc["sources"], "terms_without_a_profile": missing,
+                 "decoder_with_no_arithmetic_ms": (n * fc["dec_hops"] * fc["iso_exchange_us"] * 1e-3) if have("iso_exchange_us") else None,
                  "note": "one forward in flight; C2 geometry.  hardware_terms are bounds no rewrite of THIS decomposition avoids: the decoder's ten dependent "
-                         "exchanges per step at the measured L2 hand-off time (the gather of a gates stage in the decoder timeline%s; MI355X_MICROARCH.md "
-                         "gives 0.8 us idle) and the feed-forward products at the measured matrix-pipe ceiling.  design_terms are this build's own "
-                         "dependent-instruction time (decoder chains between exchanges, the scan's phases, collects and barriers, the encoder scan) -- MEASURED "
-                         "time of these kernels, read from the profile files named in `sources` (newest round first), a description and a work-list, "
-                         "not a floor.  0.30 of the HBM streaming roofline would need %.2f ms per forward"
-                         % ((": %.2f us" % fc["hop_us"]) if have("hop_us") else "", abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
+                         "exchanges per step at the hand-off time measured IN ISOLATION (tools/ubench_mfma_stage: publish -> every granule of the gathered vector "
+                         "seen%s) and the feed-forward products at the measured matrix-pipe ceiling.  design_terms are this build's own time: what the traced "
+                         "gather of the real kernel%s shows beyond the isolated hand-off (the arrival spread of a member's slower waves), the dependent-instruction "
+                         "chains between exchanges, the scan's phases, collects and barriers, the encoder scan -- MEASURED time of these kernels, read from the "
+                         "profile files named in `sources` (each with the kernel-source hash it was taken from and whether that is this build), a description "
+                         "and a work-list, not a floor.  decoder_with_no_arithmetic_ms: ten exchanges per step with publish, LDS write and barrier but no "
+                         "arithmetic at all (the same micro-benchmark).  0.30 of the HBM streaming roofline would need %.2f ms per forward"
+                         % ((": %.2f us" % fc["iso_poll_us"]) if have("iso_poll_us") else "", (" (%.2f us)" % fc["hop_us"]) if have("hop_us") else "",
+                            abytes / (0.30 * HBM_PEAK_GBS * 1e9) * 1e3)}
         out = {
             "metric": "mel-frames/sec (batched decode)", "value": frames / wall, "unit": "mel-frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,

@@ -278,6 +278,13 @@ int taco_model_device_errors(taco_model* m, int* out);
  * compute units of the device, debug switches).  Nothing is launched.  `out` receives a NUL-terminated line (out_len >= 64; truncated
  * if shorter than the text).  The run-time facts (exchange protocol the census chose) are in taco_debug_decoder_info afterwards. */
 int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual, char* out, int out_len);
+/* Batch-position bit-invariance for serving setups that need it (a request's outputs must not depend on which rows it was batched or
+ * sharded with).  on = 1: every row tile of the fused point-wise kernel walks a layer's contraction from step 0, so a row's fp32
+ * accumulation order is the same wherever the row lands: outputs are bitwise equal under batch permutation / re-sharding at any
+ * size.  on = 0 (default): the workgroups of an XCD start their K loops at different steps (faster weight stream out of the L2);
+ * results are reproducible run to run and equal under permutation to fp32 rounding (bitwise only while a layer has fewer than 8
+ * row tiles of 64 rows).  Takes effect for calls and plans made afterwards. */
+int taco_model_set_batch_invariant(taco_model* m, int on);
 
 #ifdef __cplusplus
 }

@@ -153,6 +153,7 @@ PROTOTYPES = {
     "taco_debug_set_decoder_persist": (_I, [_P, _I, _I]),
     "taco_debug_decoder_info": (_I, [_P, C.POINTER(_I)]),
     "taco_model_engine_plan": (_I, [_P, _I, _I, _I, _I, C.c_char_p, _I]),
+    "taco_model_set_batch_invariant": (_I, [_P, _I]),
     "taco_debug_decoder_trace": (_I, [_P, _I, C.POINTER(C.c_longlong)]),
 }
 

@@ -64,6 +64,7 @@ struct ChainArgs {
   float* y; int ldy;               // optional: the last highway output [M, W] (null: not stored)
   const int* rev_len; int rev_col0;
   int M, T, nlayers;
+  int krot;                        // 1: workgroups start their K loops at different steps (CH_ROT, the default); 0: every tile walks K from step 0
   // riders: with ntiles > 0 the workgroups ntiles .. gridDim.x - 1 own no tile; they clear up to four regions of 32-bit words (the words the
   // persistent kernels of the same forward poll: a launch of its own otherwise -- the encoder prenet's chain leaves three quarters of the CUs free)
   int ntiles; unsigned* zp[4]; unsigned long long znw[4];
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
     return;
   }
   const int m0 = blockIdx.x * CH_BM;
+  // first k16 step of this workgroup's K loops, in 32nds of a layer's K (CH_ROT; ChainArgs::krot = 0 switches it off at run time: every row's fp32
+  // accumulation order is then the same whichever tile the row lands in -- bit-invariance under batch permutation / sharding at any size)
+  const int krot = (CH_ROT && a_in.krot) ? ((int)(blockIdx.x >> 3) & 31) : 0;
 #ifdef TACO_TRACE
   const bool trc = (blockIdx.x == (a_in.ntiles > 0 ? a_in.ntiles : gridDim.x) / 2) && threadIdx.x == 0;
   int trci = 5;
@@ -460,8 +464,8 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           for (int r = 0; r < 16; ++r) { acc[tm][r] = 0.f; acc2[tm][r] = 0.f; }
-        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
-        else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);     // the odd group: one matrix
+        if (ng + 1 < ngroups) ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt2, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, krot * L.K16 >> 5);
+        else ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, nt, L.bh, L.bl, nt, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, krot * L.K16 >> 5);     // the odd group: one matrix
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
       const float bia = L.bias ? L.bias[col] : 0.f;
       if (dual) {
         const float bia2 = L.bias2 ? L.bias2[col] : 0.f;
-        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
+        ch_mma_loop<TM, LDSW, true, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh2, L.bl2, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, krot * L.K16 >> 5);
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif
@@ -503,7 +507,7 @@ __global__ __launch_bounds__(512) void k_pointwise_chain(const ChainArgs a_in) {
             xreg[tm][r] = Hh * Tg + xreg[tm][r] * (1.f - Tg);
           }
       } else {
-        ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, CH_ROT ? ((int)(blockIdx.x >> 3) & 31) * L.K16 >> 5 : 0);
+        ch_mma_loop<TM, LDSW, false, PF>(L.K16, L.NT, L.bh, L.bl, wn, L.bh, L.bl, wn, xhi, xlo, wm * TM * 32, l31, lh, acc, acc2, krot * L.K16 >> 5);
 #ifdef TACO_TRACE
         CTRC(trci); ++trci;
 #endif

@@ -76,6 +76,10 @@ __global__ void k_zero_fill_many(const ZeroMany z) {
 // bytes -- is registered, so a stage whose region changes (or a new stage) clears itself instead of trusting a list kept elsewhere.
 struct ClearedSet { const void* p[8]; size_t n[8]; int cnt; };
 static thread_local ClearedSet g_cleared = {};
+static void register_cleared(const ZeroRegions& z) {      // called by whoever has JUST enqueued the launch that clears z's regions
+  for (int i = 0; i < 4; ++i)
+    if (z.p[i] && g_cleared.cnt < 8) { g_cleared.p[g_cleared.cnt] = z.p[i]; g_cleared.n[g_cleared.cnt++] = z.nw[i] * 4; }
+}
 static hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
 static hipError_t clear_polled(void* p, size_t bytes, hipStream_t st) {
   for (int i = 0; i < g_cleared.cnt; ++i)
@@ -208,6 +212,7 @@ struct taco_model {
   int force_cfg = -1;
   unsigned* d_err = nullptr;   // set by a persistent kernel whose bounded spin expired
   int persist = 1;             // use the persistent BiGRU kernel when it fits
+  int ff_rot = 1;              // k_pointwise_chain: workgroups of an XCD start their K loops at different steps (0: taco_model_set_batch_invariant)
   int bf3 = 1;                 // feed-forward GEMMs (both CBHGs, linear head) on the bf16 matrix cores with 3-term split operands
   int bf3x6 = 0;               // training shadow model: feed-forward GEMMs on the six-product (fp32-grade) split-bf16 instantiation
   int bf3_tn = 0;              // debug: force the bf3 tile width (1: 128x64, 2: 128x128)
@@ -1364,7 +1369,7 @@ static int run_chain(const taco_model* m, hipStream_t st, const Cbhg& c, const f
   ChainArgs a; memset(&a, 0, sizeof a);
   if (entry) a.e = *entry;
   a.x = x; a.ldx = in_dim; a.Cin = in_dim; a.out = w.xproj; a.ldo = 6 * c.rnn; a.rev_len = lengths; a.rev_col0 = 3 * c.rnn;
-  a.M = M; a.T = T;
+  a.M = M; a.T = T; a.krot = m->ff_rot;
   if (ff_out) { a.y = w.hi0; a.ldy = c.rnn; *ff_out = w.hi0; }
   auto add = [&](const ConvL& L, int type) {
     const GemmVar& v = m->hvars[L.var_index];
@@ -1621,7 +1626,7 @@ static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids,
   const taco_hparams& hp = m->hp;
   ChainArgs a; memset(&a, 0, sizeof a);
   a.x = AP(m, m->emb); a.ldx = hp.embedding_size; a.Cin = hp.embedding_size; a.gather = ids;
-  a.out = out; a.ldo = hp.enc_prenet[1]; a.rev_len = nullptr; a.rev_col0 = -1; a.M = M; a.T = M;
+  a.out = out; a.ldo = hp.enc_prenet[1]; a.rev_len = nullptr; a.rev_col0 = -1; a.M = M; a.T = M; a.krot = m->ff_rot;
   const int types[2] = {CH_DENSE, CH_XPROJ};
   for (int i = 0; i < 2; ++i) {
     const GemmVar& v = m->hvars[m->enc_prenet[i].var_index];
@@ -1637,6 +1642,7 @@ static int run_prenet_chain(const taco_model* m, hipStream_t st, const int* ids,
   }
   hipLaunchKernelGGL((k_pointwise_chain<256>), dim3(nwg), dim3(512), (size_t)2 * CH_BM * (256 + 8) * sizeof(unsigned short), st, a);
   HIPCHK(hipGetLastError());
+  if (riders) register_cleared(*riders);      // the riders are in the stream now: the persistent kernels behind this launch need no fill of their own
   return 0;
 }
 // riders: see run_prenet_chain; only passed where prenet_chain_fits(m) (the caller clears the regions itself otherwise)
@@ -2005,9 +2011,10 @@ static int latch_errors(const taco_model* m, hipStream_t st, int32_t* stop) {
   return 0;
 }
 
-static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
-                           int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
-                           int32_t* stop, void* ws, size_t ws_bytes) {
+// One pass of at most 64 batch rows (what the persistent kernels place on one chip: 8 groups x 8 rows).
+static int forward_pass(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
+                        int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
+                        int32_t* stop, void* ws, size_t ws_bytes) {
   TRY(check_common(m, B, T_in));
   if (n <= 0) return fail(TACO_ERR_ARG, "n_steps must be positive");
   if (!ids || !lengths || !mel || !linear || !align || !ws) return fail(TACO_ERR_ARG, "null buffer");
@@ -2027,15 +2034,15 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
     z.p[2] = (uint32_t*)w.post.cb.gxbuf; z.nw[2] = ((size_t)((char*)w.post.cb.gxctl - (char*)w.post.cb.gxbuf) + 256) / 4;
     z.p[3] = (uint32_t*)w.enc.cb.gxbuf; z.nw[3] = ((size_t)((char*)w.enc.cb.gxctl - (char*)w.enc.cb.gxbuf) + 256) / 4;     // (an encoder of width 256 scans on k_bigru_duo too)
     // (they ride in the encoder prenet's launch where that is the chain kernel -- the first launch of the forward, with CUs to spare)
+    // The regions count as cleared (zero_async then skips its own fill) only from the point where the launch that clears them HAS been
+    // enqueued: here for the fill kernel, inside run_prenet_chain for the riders -- never on the strength of a predicate evaluated twice.
+    struct Guard { Guard() { g_cleared.cnt = 0; } ~Guard() { g_cleared.cnt = 0; } } guard;
     const bool ride = prenet_chain_fits(m);
     if (!ride) {
       hipLaunchKernelGGL(k_zero_fill_multi, dim3(256, 4), dim3(256), 0, st, z);
       HIPCHK(hipGetLastError());
+      register_cleared(z);
     }
-    struct Guard {
-      explicit Guard(const ZeroRegions& z) { g_cleared.cnt = 0; for (int i = 0; i < 4; ++i) if (z.p[i]) { g_cleared.p[g_cleared.cnt] = z.p[i]; g_cleared.n[g_cleared.cnt++] = z.nw[i] * 4; } }
-      ~Guard() { g_cleared.cnt = 0; }
-    } guard(z);
     TRY(encoder_forward(m, st, ids, lengths, spk, B, T_in, w.enc_out, w.enc, false, ride ? &z : nullptr));
     TRY(decoder_forward(m, st, w.enc_out, spk, B, T_in, n, manual, nullptr, mel, align, nullptr, nullptr, w.dec, true, &w.enc.spk));
     TRY(postnet_forward(m, st, mel, spk, B, T_mel, linear, nullptr, w.post));
@@ -2068,6 +2075,59 @@ static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, co
   HIPCHK(hipStreamWaitEvent(st, m->events[ev], 0));
   TRY(postnet_tail(m, st, spk, B, T_mel, linear, nullptr, w.post));
   return latch_errors(m, st, stop);
+}
+
+// Any batch size (synthesizer.py:120-131 and eval.py:86-119 put no cap on it): more than 64 rows run as ceil(B / 64) passes of equal
+// size over the SAME workspace, back to back on the caller's stream (batch rows are independent at inference: BatchNorm uses the
+// moving statistics, modules.py:131).  The stop step of the batch (helpers.py:29 with dynamic_decode's all-rows-finished loop condition)
+// is the maximum over the passes' stop steps -- a row's `finished` is sticky, so the loop would have ended when the LAST pass's rows
+// were all done; a negative pass word (a persistent kernel gave up) wins.
+struct PassPlan { int passes, rows; };
+static PassPlan pass_plan(int B) { PassPlan p; p.passes = (B + 63) / 64; p.rows = p.passes ? (B + p.passes - 1) / p.passes : 0; return p; }
+__global__ void k_stop_combine(const int* pstop, int np, int* stop) {
+  if (threadIdx.x == 0) {
+    int worst = 0, err = 0;
+    for (int i = 0; i < np; ++i) { const int v = pstop[i]; if (v < 0 && !err) err = v; worst = max(worst, v); }
+    *stop = err ? err : worst;
+  }
+}
+static size_t forward_workspace(const taco_model* m, int B, int T_in, int n, FullWs* w_out, int32_t** pstop, void* ws, size_t ws_bytes, bool* ok) {
+  const PassPlan pp = pass_plan(B);
+  Carver cv(ws, ws_bytes);
+  FullWs w;
+  carve_full(cv, m, pp.rows, T_in, n, w);
+  const size_t pass_bytes = cv.off;
+  int32_t* ps = pp.passes > 1 ? (int32_t*)cv.i((size_t)pp.passes) : nullptr;
+  if (w_out) *w_out = w;
+  if (pstop) *pstop = ps;
+  if (ok) *ok = cv.ok();
+  (void)pass_bytes;
+  return cv.off;
+}
+static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
+                           int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
+                           int32_t* stop, void* ws, size_t ws_bytes) {
+  if (B <= 64) return forward_pass(m, st, ids, lengths, spk, B, T_in, n, manual, mel, linear, align, stop, ws, ws_bytes);
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  if (T_in <= 0 || n <= 0) return fail(TACO_ERR_ARG, "bad time %d / steps %d", T_in, n);
+  if (!ids || !lengths || !mel || !linear || !align || !ws) return fail(TACO_ERR_ARG, "null buffer");
+  const PassPlan pp = pass_plan(B);
+  int32_t* pstop = nullptr; bool ok = false;
+  const size_t need = forward_workspace(m, B, T_in, n, nullptr, &pstop, ws, ws_bytes, &ok);
+  if (!ok) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", need, ws_bytes);
+  const size_t rM = (size_t)m->hp.reduction_factor * m->hp.num_mels, T_mel = (size_t)n * m->hp.reduction_factor;
+  for (int p = 0; p < pp.passes; ++p) {
+    const int b0 = p * pp.rows, rows = std::min(pp.rows, B - b0);
+    if (rows <= 0) break;
+    TRY(forward_pass(m, st, ids + (size_t)b0 * T_in, lengths + b0, spk ? spk + b0 : nullptr, rows, T_in, n,
+                     manual ? manual + (size_t)b0 * n * T_in : nullptr, mel + (size_t)b0 * n * rM, linear + (size_t)b0 * T_mel * m->hp.num_freq,
+                     align + (size_t)b0 * T_in * n, stop ? pstop + p : nullptr, ws, ws_bytes));
+  }
+  if (stop) {
+    hipLaunchKernelGGL(k_stop_combine, dim3(1), dim3(64), 0, st, (const int*)pstop, pp.passes, stop);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2458,6 +2518,15 @@ int taco_stop_steps(void* hip_stream, const float* d_mel, int B, int n_steps, in
   return 0;
 }
 
+// on: every tile of k_pointwise_chain walks a layer's K from step 0, so a row's fp32 accumulation order does not depend on the tile -- i.e. on
+// the batch position or the shard -- it lands in: outputs are bit-invariant under batch permutation at any size.  off (default): the
+// workgroups of an XCD start at different steps (they do not all ask the L2 for the same weight slices at once): results
+// stay reproducible run to run, and equal under permutation to fp32 rounding, bitwise only while the launch has fewer than 8 tiles.
+int taco_model_set_batch_invariant(taco_model* m, int on) {
+  if (!m) return fail(TACO_ERR_ARG, "null model");
+  m->ff_rot = on ? 0 : 1;
+  return 0;
+}
 int taco_debug_set_att_split(taco_model* m, int slices) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->att_split = slices;
@@ -2513,6 +2582,11 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
 int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual, char* out, int out_len) {
   if (!m || !m->finalized || !out || out_len < 64) return fail(TACO_ERR_ARG, "bad argument");
   std::string s;
+  if (B > 64 && !m->tp) {      // taco_forward_infer / taco_plan_create serve any batch as passes of at most 64 rows; the plan below is a pass's
+    const PassPlan pp = pass_plan(B);
+    s = std::to_string(B) + " rows = " + std::to_string(pp.passes) + " passes of " + std::to_string(pp.rows) + " (the last one " + std::to_string(B - (pp.passes - 1) * pp.rows) + "); per pass: ";
+    B = pp.rows;
+  }
   auto why_common = [&](int rows) -> std::string {
     if (!m->dx_mode) return "switched off (taco_debug_set_decoder_persist 0)";
     if (m->cu_count < DX_NGROUP * DX_GROUP) return "the device exposes " + std::to_string(m->cu_count) + " compute units (a partition of an MI355X, or another part): the whole-chip kernels need 256";
@@ -2588,21 +2662,19 @@ int taco_debug_force_gemm_config(taco_model* m, int cfg) {
 }
 
 size_t taco_workspace_bytes(const taco_model* m, int B, int T_in, int n_steps) {
-  if (!m) return 0;
-  Carver cv(nullptr, 0);
-  FullWs w;
-  carve_full(cv, m, B, T_in, n_steps, w);
-  return cv.off;
+  if (!m || B <= 0) return 0;
+  return forward_workspace(m, B, T_in, n_steps, nullptr, nullptr, nullptr, 0, nullptr);      // (more than 64 rows: the workspace of ONE pass + the passes' stop words)
 }
 
 size_t taco_stage_workspace_bytes(const taco_model* m, int B, int T) {
   if (!m) return 0;
   // large enough for any single stage at (B, T): encoder at T_in=T, decoder with T_in=T and n_steps=T, post-net at T_mel=T
   Carver a(nullptr, 0), b(nullptr, 0), c(nullptr, 0);
-  EncWs e; carve_enc(a, m, B, T, e);
-  DecWs d; carve_dec(b, m, B, T, T, d);
-  PostWs p; carve_post(c, m, B, T, p);
-  return std::max(a.off, std::max(b.off, c.off));
+  const int R = B > 64 ? pass_plan(B).rows : B;      // more than 64 rows: passes over one pass's workspace (+ the passes' stop words)
+  EncWs e; carve_enc(a, m, R, T, e);
+  DecWs d; carve_dec(b, m, R, T, T, d);
+  PostWs p; carve_post(c, m, R, T, p);
+  return std::max(a.off, std::max(b.off, c.off)) + (B > 64 ? 256 : 0);
 }
 
 int taco_forward_infer(taco_model* m, void* hip_stream, const int32_t* d_inputs, const int32_t* d_input_lengths,
@@ -2662,6 +2734,13 @@ void taco_plan_destroy(taco_plan* p) {
 int taco_encoder_forward(taco_model* m, void* hip_stream, const int32_t* d_inputs, const int32_t* d_input_lengths,
                          const int32_t* d_speaker_id, int B, int T_in, float* d_encoder_out, void* d_workspace,
                          size_t workspace_bytes) {
+  if (m && m->finalized && B > 64 && T_in > 0 && d_inputs && d_input_lengths && d_encoder_out) {      // passes of at most 64 rows (forward_enqueue)
+    const PassPlan pp = pass_plan(B);
+    for (int b0 = 0; b0 < B; b0 += pp.rows)
+      TRY(taco_encoder_forward(m, hip_stream, d_inputs + (size_t)b0 * T_in, d_input_lengths + b0, d_speaker_id ? d_speaker_id + b0 : nullptr, std::min(pp.rows, B - b0),
+                               T_in, d_encoder_out + (size_t)b0 * T_in * 2 * m->hp.enc_rnn_size, d_workspace, workspace_bytes));
+    return 0;
+  }
   TRY(check_common(m, B, T_in));
   if (!d_inputs || !d_input_lengths || !d_encoder_out || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
   if (m->hp.num_speakers > 1 && !d_speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
@@ -2676,6 +2755,25 @@ int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder
                          int T_in, int n_steps, const float* d_manual_alignments, const float* d_teacher_frames,
                          float* d_mel, float* d_alignments, int32_t* d_stop_step, float* d_dbg_states, void* d_workspace,
                          size_t workspace_bytes) {
+  if (m && m->finalized && B > 64 && T_in > 0 && n_steps > 0 && d_encoder_out && d_mel && d_alignments && d_workspace) {      // passes of at most 64 rows
+    if (d_dbg_states) return fail(TACO_ERR_UNSUPPORTED, "the per-step state dump is laid out [step][row]: at most 64 rows per call");
+    const PassPlan pp = pass_plan(B);
+    const size_t rM = (size_t)m->hp.reduction_factor * m->hp.num_mels, D = (size_t)2 * m->hp.enc_rnn_size;
+    if (workspace_bytes < 256) return fail(TACO_ERR_STATE, "workspace too small");
+    int32_t* pstop = (int32_t*)((char*)d_workspace + ((workspace_bytes - (size_t)pp.passes * sizeof(int32_t)) & ~(size_t)255));      // the tail of the caller's buffer
+    const size_t pass_bytes = (size_t)((char*)pstop - (char*)d_workspace);
+    int p = 0;
+    for (int b0 = 0; b0 < B; b0 += pp.rows, ++p)
+      TRY(taco_decoder_forward(m, hip_stream, d_encoder_out + (size_t)b0 * T_in * D, d_speaker_id ? d_speaker_id + b0 : nullptr, std::min(pp.rows, B - b0), T_in, n_steps,
+                               d_manual_alignments ? d_manual_alignments + (size_t)b0 * n_steps * T_in : nullptr,
+                               d_teacher_frames ? d_teacher_frames + (size_t)b0 * n_steps * m->hp.num_mels : nullptr, d_mel + (size_t)b0 * n_steps * rM,
+                               d_alignments + (size_t)b0 * T_in * n_steps, d_stop_step ? pstop + p : nullptr, nullptr, d_workspace, pass_bytes));
+    if (d_stop_step) {
+      hipLaunchKernelGGL(k_stop_combine, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, (const int*)pstop, pp.passes, d_stop_step);
+      HIPCHK(hipGetLastError());
+    }
+    return 0;
+  }
   TRY(check_common(m, B, T_in));
   if (n_steps <= 0 || !d_encoder_out || !d_mel || !d_alignments || !d_workspace) return fail(TACO_ERR_ARG, "bad argument");
   if (m->hp.num_speakers > 1 && !d_speaker_id) return fail(TACO_ERR_ARG, "speaker_id required for a multi-speaker model");
@@ -2689,6 +2787,14 @@ int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder
 
 int taco_postnet_forward(taco_model* m, void* hip_stream, const float* d_mel, const int32_t* d_speaker_id, int B, int T_mel,
                          float* d_linear, float* d_post_out, void* d_workspace, size_t workspace_bytes) {
+  if (m && m->finalized && B > 64 && T_mel > 0 && d_mel && d_linear) {      // passes of at most 64 rows
+    const PassPlan pp = pass_plan(B);
+    for (int b0 = 0; b0 < B; b0 += pp.rows)
+      TRY(taco_postnet_forward(m, hip_stream, d_mel + (size_t)b0 * T_mel * m->hp.num_mels, d_speaker_id ? d_speaker_id + b0 : nullptr, std::min(pp.rows, B - b0), T_mel,
+                               d_linear + (size_t)b0 * T_mel * m->hp.num_freq, d_post_out ? d_post_out + (size_t)b0 * T_mel * 2 * m->hp.post_rnn_size : nullptr,
+                               d_workspace, workspace_bytes));
+    return 0;
+  }
   TRY(check_common(m, B, T_mel));
   if (!d_mel || !d_linear || !d_workspace) return fail(TACO_ERR_ARG, "null buffer");
   HIPCHK(hipSetDevice(m->device));

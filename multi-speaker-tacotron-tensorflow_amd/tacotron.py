@@ -563,6 +563,13 @@ class Tacotron(object):
                                                   _ptr(ws), n))
         return (lin, post) if return_post else lin
 
+    def set_batch_invariant(self, on=True):
+        """taco_model_set_batch_invariant: outputs bitwise independent of the batch position / shard a row lands in, at any batch size (the fused
+        point-wise kernel then starts every tile's contraction at step 0; default off: equal under permutation to fp32 rounding only).
+        Cached plans are dropped: a plan keeps the setting it was captured with."""
+        _lib.check(self._lib.taco_model_set_batch_invariant(self._handle, 1 if on else 0))
+        self._plans.clear()
+
     def set_decoder_engine(self, mode=1, rows_per_group=0):
         """Decoder loop engine: 1 = one persistent weight-stationary launch when the configuration fits (default), 0 = one launch per
         stage, 2 = persistent with write-through exchanges.  Cached plans are dropped (they captured the previous engine)."""

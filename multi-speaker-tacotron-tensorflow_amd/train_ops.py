@@ -9,6 +9,9 @@
 
 PyTorch provides device memory, the stream and torch.distributed; the arithmetic is in libtaco_hip.so."""
 import ctypes as C
+import glob
+import os
+import re
 
 import torch
 
@@ -48,7 +51,8 @@ class FlatAdam(object):
         self.params = flat_params
         self.m = torch.zeros_like(flat_params)
         self.v = torch.zeros_like(flat_params)
-        self.global_step = 0
+        self.global_step = 0          # what the learning-rate schedule reads (tacotron.py:312-325); train.py:196-197 resets it to 0 for --initialize_path
+        self.adam_t = 0               # Adam updates applied so far = the exponent of TF's beta1_power / beta2_power accumulators, which a restore keeps
         self.hyper = (initial_learning_rate, beta1, beta2, epsilon, decay_learning_rate_mode, is_randomly_initialized, clip_norm)
         self._ws = torch.empty(1 << 14, dtype=torch.uint8, device=flat_params.device)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=flat_params.device)
@@ -63,9 +67,48 @@ class FlatAdam(object):
         lr0, b1, b2, eps, mode, rnd, clip = self.hyper
         assert flat_grads.shape == self.params.shape and flat_grads.dtype == torch.float32
         _lib.check(self._lib.taco_adam_step_f32(_st(), _p(self.params), _p(flat_grads.contiguous()), _p(self.m), _p(self.v),
-                                                self.params.numel(), self.global_step, self.learning_rate, b1, b2, eps, clip,
+                                                self.params.numel(), self.adam_t, self.learning_rate, b1, b2, eps, clip,
                                                 _p(self.gnorm), _p(self._ws), self._ws.numel()))
         self.global_step += 1
+        self.adam_t += 1
+
+
+# ---- train-state checkpoints: what tf.train.Saver writes and restores for the training run (train.py:175,189-203,242-244) ----
+def train_state_paths(log_dir, step):
+    """(weights file, optimizer file) of a checkpoint: `model.ckpt-<step>.safetensors` (the parameters incl. the BatchNorm moving statistics:
+    what Synthesizer.load reads) and `model.ckpt-<step>.optim.safetensors` (Adam m / v, global_step, the number of Adam updates)."""
+    base = os.path.join(log_dir, "model.ckpt-%d" % int(step))
+    return base + ".safetensors", base + ".optim.safetensors"
+
+
+def list_train_checkpoints(log_dir):
+    """[(step, weights file)] in ascending step order (a weights file without its optimizer file is a weight pack, not a resumable state)."""
+    out = []
+    for p in glob.glob(os.path.join(log_dir, "model.ckpt-*.safetensors")):
+        m = re.match(r"model\.ckpt-(\d+)\.safetensors$", os.path.basename(p))
+        if m and os.path.exists(p[:-len(".safetensors")] + ".optim.safetensors"):
+            out.append((int(m.group(1)), p))
+    return sorted(out)
+
+
+def prune_train_checkpoints(log_dir, max_to_keep=5, keep_every_n_hours=2.0):
+    """tf.train.Saver(max_to_keep=5, keep_checkpoint_every_n_hours=2) (train.py:175): the newest `max_to_keep` stay; of the older ones, one per
+    `keep_every_n_hours` of file time stays for good.  Returns the paths removed."""
+    ck = list_train_checkpoints(log_dir)
+    removed = []
+    if max_to_keep is None or len(ck) <= max_to_keep:
+        return removed
+    last_kept = None
+    for step, path in ck[:-max_to_keep]:
+        t = os.path.getmtime(path)
+        if keep_every_n_hours and (last_kept is None or t - last_kept >= keep_every_n_hours * 3600.0):
+            last_kept = t
+            continue
+        for q in (path, path[:-len(".safetensors")] + ".optim.safetensors"):
+            if os.path.exists(q):
+                os.remove(q)
+                removed.append(q)
+    return removed
 
 
 def allreduce_gradients(flat_grads):

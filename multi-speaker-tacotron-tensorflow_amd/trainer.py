@@ -9,12 +9,14 @@ backward) -> all-reduce of `grads` / world size -> clip_by_global_norm + Adam (t
 taco_train_refresh (weight packs regenerated from the flat parameters).  PyTorch is device memory, streams and
 torch.distributed only."""
 import ctypes as C
+import hashlib
+import os
 
 import numpy as np
 import torch
 
 from . import _lib
-from .train_ops import FlatAdam, allreduce_gradients
+from .train_ops import FlatAdam, allreduce_gradients, train_state_paths, list_train_checkpoints, prune_train_checkpoints
 
 
 def _p(t):
@@ -210,6 +212,58 @@ class Trainer(object):
     def refresh(self):
         with torch.cuda.device(self.device):
             _lib.check(self._lib.taco_train_refresh(self._h, _st(), _p(self.params)))
+
+    # ---- train-state checkpoints (train.py:175 `tf.train.Saver`, :189-203 restore, :242-244 save) ----
+    def _layout_id(self):
+        h = hashlib.sha256()
+        for name, shape in self.spec:
+            h.update(("%s:%s:%d;" % (name, "x".join(map(str, shape)), self.offsets[name][0])).encode())
+        return np.frombuffer(h.digest()[:8], np.uint8).copy()
+
+    def save_checkpoint(self, log_dir, max_to_keep=5, keep_every_n_hours=2.0):
+        """`saver.save(sess, checkpoint_path, global_step=step)` (train.py:242-244): everything a resumed run needs, i.e. every variable
+        the reference's Saver holds -- the parameters INCLUDING the BatchNorm moving statistics (they live in the flat parameter
+        buffer), Adam's m and v, the step counters.  Two safetensors files (train_ops.train_state_paths); the weights file is a weight
+        pack Synthesizer.load reads as it stands.  Older checkpoints are pruned like Saver(max_to_keep=5,
+        keep_checkpoint_every_n_hours=2).  Returns the weights file."""
+        from safetensors.numpy import save_file
+        from .weights import save_weights
+        torch.cuda.synchronize(self.device)
+        wpath, opath = train_state_paths(log_dir, self.adam.global_step)
+        save_weights(wpath, self.get_weights())
+        save_file({"adam_m": self.adam.m.detach().cpu().numpy(), "adam_v": self.adam.v.detach().cpu().numpy(),
+                   "global_step": np.asarray([self.adam.global_step], np.int64), "adam_t": np.asarray([self.adam.adam_t], np.int64),
+                   "layout": self._layout_id()}, opath)
+        prune_train_checkpoints(log_dir, max_to_keep, keep_every_n_hours)
+        return wpath
+
+    def restore_checkpoint(self, path_or_dir, reset_global_step=False):
+        """`saver.restore(sess, get_most_recent_checkpoint(dir))` (train.py:189-193): parameters, BatchNorm moving statistics, Adam
+        slots and counters come back, and the next train_step continues the run to the bit.  reset_global_step: the
+        `--initialize_path` branch (train.py:194-203) -- every variable restored, then `global_step` assigned 0: the learning-rate
+        schedule starts over while the Adam moments and the beta-power accumulators carry on.  Returns the global step."""
+        from safetensors.numpy import load_file
+        from .weights import load_weights
+        if os.path.isdir(path_or_dir):
+            ck = list_train_checkpoints(path_or_dir)
+            if not ck:
+                raise Exception(" [!] No checkpoint found in {}".format(path_or_dir))
+            wpath = ck[-1][1]
+        else:
+            wpath = path_or_dir
+        opath = wpath[:-len(".safetensors")] + ".optim.safetensors"
+        if not os.path.exists(opath):
+            raise _lib.TacoError(_lib.TACO_ERR_STATE, "%s has no optimizer state beside it (%s): a weight pack, not a train-state checkpoint"
+                                 % (wpath, os.path.basename(opath)))
+        st = load_file(opath)
+        if st["adam_m"].shape != (self.num_params,) or not np.array_equal(st["layout"], self._layout_id()):
+            raise _lib.TacoError(_lib.TACO_ERR_SHAPE, "the optimizer state of %s was written for another parameter layout (other hyper-parameters)" % wpath)
+        self.set_weights(load_weights(wpath))
+        self.adam.m.copy_(torch.from_numpy(st["adam_m"]))
+        self.adam.v.copy_(torch.from_numpy(st["adam_v"]))
+        self.adam.adam_t = int(st["adam_t"][0])
+        self.adam.global_step = 0 if reset_global_step else int(st["global_step"][0])
+        return self.adam.global_step
 
     # ---- one forward (+ backward) ----
     def forward_backward(self, inputs, input_lengths, mel_targets, linear_targets, loss_coeff=None, backward=True, keep_outputs=False,

@@ -445,7 +445,7 @@ def test_engine_plan_says_which_engine_a_call_gets_and_why_not():
     assert "decoder loop: persistent k_decoder_xcd<4>" in plan and "post-net scan: persistent k_bigru_oct<4>" in plan and "split-bf16" in plan, plan
     assert "encoder prenet: one k_pointwise_chain launch" in plan, plan            # round 5: gather + both layers + the forward's zero fills in one launch
     assert "k_decoder_xcd<1>" in m.engine_plan(2, 512)
-    assert "rows > 64" in m.engine_plan(65, 64)
+    assert "65 rows = 2 passes of 33" in m.engine_plan(65, 64) and "k_decoder_xcd<8>" in m.engine_plan(65, 64), m.engine_plan(65, 64)
     assert "does not fit a member's LDS" in m.engine_plan(64, 2000), m.engine_plan(64, 2000)
     ids, L = O.synthetic_inputs(3, 12, 402)
     m.run(ids, L)

@@ -147,6 +147,31 @@ def test_batch_permutation_and_row_independence():
     assert maxabs(mel1[0], mel[2]) < 1e-5
 
 
+def test_batch_permutation_at_production_size_with_and_without_batch_invariance():
+    """the fused point-wise kernel starts a workgroup's K loops at a step derived from its tile index (CH_ROT), so with 8 or
+    more row tiles a row's fp32 accumulation order depends on where in the batch it sits.  Reference widths, 32 rows x 64 inputs (32 tiles
+    in the encoder, 16 in the post-net): by default a permuted batch gives the permuted outputs to fp32 rounding; with
+    taco_model_set_batch_invariant (Tacotron.set_batch_invariant) to the bit."""
+    ohp = O.OracleHParams(max_iters=8)
+    w = O.init_weights(ohp, 1, 125)
+    ids, L = O.synthetic_inputs(32, 64, 135, ragged=True)
+    perm = np.random.RandomState(3).permutation(32)
+    m = build_model(ohp, w)
+    mel, lin, al = _run(m, ids, L, honor_stop=False)
+    mel2, lin2, al2 = _run(m, ids[perm], L[perm], honor_stop=False)
+    d = max(maxabs(mel[perm], mel2), maxabs(lin[perm], lin2), maxabs(al[perm], al2))
+    print("permuted batch, default (rotated K loops): max difference %.2e, bitwise equal: %s" % (d, d == 0.0))
+    assert d < 2e-5
+    m.set_batch_invariant(True)
+    mel, lin, al = _run(m, ids, L, honor_stop=False)
+    mel2, lin2, al2 = _run(m, ids[perm], L[perm], honor_stop=False)
+    assert np.array_equal(mel[perm], mel2) and np.array_equal(lin[perm], lin2) and np.array_equal(al[perm], al2)
+    # ... and a shard of the batch reproduces its rows to the bit (what data-parallel serving relies on)
+    mel3, lin3, al3 = _run(m, ids[8:16], L[8:16], honor_stop=False)
+    print("an 8-row shard vs its rows inside the 32-row batch: max difference %.2e" % max(maxabs(mel3, mel[8:16]), maxabs(lin3, lin[8:16])))
+    assert maxabs(mel3, mel[8:16]) < 2e-5 and maxabs(lin3, lin[8:16]) < 2e-5       # (other rows per decoder group: another instantiation, same arithmetic to rounding)
+
+
 def test_pad_ids_beyond_length_do_not_matter_for_other_rows():
     ohp = tiny_hp()
     w = O.init_weights(ohp, 1, 26)
@@ -529,14 +554,68 @@ def test_batch_limits(B):
     _check(_run(m, ids, L, honor_stop=False), O.forward(w, ohp, ids, L, honor_stop=False))
 
 
-def test_batch_above_the_limit_and_bad_shapes_are_errors():
+@pytest.mark.parametrize("B", [65, 96, 130])
+def test_more_than_64_rows_run_as_passes_of_equal_size(B):
+    """The reference puts no cap on the batch (synthesizer.py:120-131: whatever `texts` holds; eval.py:86-119 --batch_size): the C ABI
+    serves B > 64 as ceil(B / 64) passes over one workspace (taco_forward_infer and taco_plan_create alike).  Against the oracle on
+    the whole batch, ragged lengths, and against the same rows served alone (rows never interact at inference)."""
+    ohp = tiny_hp(max_iters=3)
+    w = O.init_weights(ohp, 1, 55)
+    ids, L = O.synthetic_inputs(B, 7, 56, ragged=True)
+    m = build_model(ohp, w)
+    hip = _run(m, ids, L, honor_stop=False)                 # Tacotron.run replays a captured plan: taco_plan_create
+    _check(hip, O.forward(w, ohp, ids, L, honor_stop=False))
+    rows = (B + (B + 63) // 64 - 1) // ((B + 63) // 64)     # rows per pass
+    alone = _run(m, ids[rows:2 * rows], L[rows:2 * rows], honor_stop=False)
+    for a, b in zip(hip, alone):
+        assert np.array_equal(a[rows:2 * rows], b)          # the second pass == its rows as a batch of their own, to the bit
+
+
+def test_more_than_64_rows_on_the_persistent_engine_and_the_eager_entry_point():
+    """Reference widths (the persistent decoder and scans), 96 rows = two passes of 48: eager taco_forward_infer == the captured plan ==
+    each pass's rows served alone, to the bit; the stop word is the maximum over the passes."""
+    import torch
     import taco_amd
+    from util import dev, ptr, stream
+    ohp = O.OracleHParams(max_iters=3)
+    w = O.init_weights(ohp, 1, 57)
+    B, T_in, n, r = 96, 16, 3, ohp.reduction_factor
+    ids, L = O.synthetic_inputs(B, T_in, 58, ragged=True)
+    m = build_model(ohp, w)
+    assert "96 rows = 2 passes of 48" in m.engine_plan(B, T_in), m.engine_plan(B, T_in)
+    mel_g, lin_g, al_g = _run(m, ids, L, honor_stop=False)
+    assert m.stop_step == n
+    for lo in (0, 48):
+        mel_a, lin_a, al_a = _run(m, ids[lo:lo + 48], L[lo:lo + 48], honor_stop=False)
+        assert np.array_equal(mel_g[lo:lo + 48], mel_a) and np.array_equal(lin_g[lo:lo + 48], lin_a) and np.array_equal(al_g[lo:lo + 48], al_a)
+    ref = O.forward(w, ohp, ids[44:52], L[44:52], honor_stop=False)      # eight rows across the seam between the passes
+    assert maxabs(mel_g[44:52], ref["mel"]) < 1e-3 and maxabs(lin_g[44:52], ref["linear"]) < 1e-3 and maxabs(al_g[44:52], ref["alignments"]) < 1e-3
+    mel = torch.empty((B, n * r, ohp.num_mels), device="cuda")
+    lin = torch.empty((B, n * r, ohp.num_freq), device="cuda")
+    al = torch.empty((B, T_in, n), device="cuda")
+    stop = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    nb = int(m._lib.taco_workspace_bytes(m._handle, B, T_in, n))
+    assert nb < 1.2 * int(m._lib.taco_workspace_bytes(m._handle, 48, T_in, n)) + 4096          # the workspace of ONE pass
+    ws = torch.empty((nb,), dtype=torch.uint8, device="cuda")
+    idd, Ld = dev(ids), dev(L)
+    taco_amd._lib.check(m._lib.taco_forward_infer(m._handle, stream(), ptr(idd), ptr(Ld), ptr(None), B, T_in, n,
+                                                  ptr(None), ptr(mel), ptr(lin), ptr(al), ptr(stop), ptr(ws), nb))
+    torch.cuda.synchronize()
+    assert np.array_equal(mel.cpu().numpy(), mel_g) and np.array_equal(lin.cpu().numpy(), lin_g) and np.array_equal(al.cpu().numpy(), al_g)
+    assert int(stop.item()) == n
+    # every row finished at step 1 in both passes (helpers.py:29): the combined stop step is 1
+    w2 = {k: v.copy() for k, v in w.items()}
+    w2["decoder/frame_projection/kernel"][:] = 0
+    w2["decoder/frame_projection/bias"][:] = 0
+    m2 = build_model(ohp, w2)
+    _run(m2, ids, L)
+    assert m2.stop_step == 1
+
+
+def test_bad_shapes_are_errors():
     ohp = tiny_hp(max_iters=2)
     m = build_model(ohp, O.init_weights(ohp, 1, 55))
-    ids, L = O.synthetic_inputs(65, 5, 56)
-    with pytest.raises(Exception) as e:
-        m.run(inputs=ids, input_lengths=L)
-    assert "64" in str(e.value)
+    ids, L = O.synthetic_inputs(3, 5, 56)
     with pytest.raises(Exception):
         m.run(inputs=ids[0], input_lengths=L[:1])          # rank-1 inputs
 
@@ -691,3 +770,53 @@ def test_alignment_argmax_is_compared_on_every_step_of_a_full_horizon(atype, bia
           % (atype, bias, B, T_in, n, 100.0 * d["masked_by_floor"] / d["steps"], d["steps"], moved))
     assert d["masked_by_floor"] < 0.05 * d["steps"], d
     _check(hip, ref, tol=1e-3)
+
+
+# ---- full size x full horizon against oracle outputs committed as fixtures (tests/golden/make_full_size_golden.py) ----
+def _golden(name):
+    p = os.path.join(os.path.dirname(__file__), "golden", name)
+    if not os.path.exists(p):
+        pytest.skip("%s not generated (python tests/golden/make_full_size_golden.py)" % name)
+    return np.load(p)
+
+
+def test_C3_all_32_rows_all_128_steps_against_the_committed_oracle_outputs():
+    """BASELINE.json configs[2] at full size AND full horizon: 32 rows x 128 decoder steps, deepvoice, 4 speakers (round 5 ran 16 steps, or 8 of
+    the rows).  The oracle's float64 outputs are a fixture (40 s of CPU when made); weights and inputs are re-created from its seed."""
+    import make_full_size_golden as G
+    g = _golden("full_C3.npz")
+    hp, ns, seed, ids, L, spk = G.c3_case()
+    assert int(g["seed"]) == seed and np.array_equal(g["inputs"], ids) and np.array_equal(g["input_lengths"], L) and np.array_equal(g["speaker_id"], spk)
+    m = build_model(hp, O.init_weights(hp, ns, seed), num_speakers=ns)
+    assert "k_decoder_xcd<4>" in m.engine_plan(32, 128)
+    mel, lin, al = _run(m, ids, L, spk, honor_stop=False)
+    st = int(g["linear_stride"])
+    errs = {"mel": maxabs(mel, g["mel"]), "linear": maxabs(lin[:, ::st], g["linear"]), "alignments": maxabs(al, g["alignments"])}
+    print("C3 full size x full horizon vs the oracle fixture:", errs)
+    assert max(errs.values()) < 1e-3, errs
+    n, bad = argmax_match(al, g["alignments"].astype(np.float64))
+    assert bad == 0 and n > 0.45 * 32 * 128, (n, bad)
+
+
+def test_C5_all_8_rows_all_1000_steps_against_the_committed_oracle_outputs():
+    """BASELINE.json configs[4] at full size and full horizon: 8 rows x T_in 512 x 1000 decoder steps (round 5 compared 2 of the 8 rows).  The fixture
+    holds every 4th decoder step's frames, the linear output on a frame stride, the alignment arg-max / peak / runner-up of EVERY step and every
+    8th step's alignments."""
+    import make_full_size_golden as G
+    g = _golden("full_C5.npz")
+    hp, seed, ids, L = G.c5_case()
+    assert int(g["seed"]) == seed and np.array_equal(g["inputs"], ids) and np.array_equal(g["input_lengths"], L)
+    m = build_model(hp, O.init_weights(hp, 1, seed))
+    mel, lin, al = _run(m, ids, L, honor_stop=False)
+    B, n, r, M = 8, hp.max_iters, hp.reduction_factor, hp.num_mels
+    ss, ls, as_ = int(g["step_stride"]), int(g["linear_stride"]), int(g["align_stride"])
+    errs = {"mel": maxabs(mel.reshape(B, n, r * M)[:, ::ss], g["mel_steps"]), "linear": maxabs(lin[:, ::ls], g["linear"]),
+            "alignments": maxabs(al[:, :, ::as_], g["alignments"])}
+    print("C5 full size x full horizon vs the oracle fixture:", errs)
+    assert max(errs.values()) < 1e-3, errs
+    # arg-max of every step whose oracle peak is above the floor and is not tied with the runner-up at fp32 resolution
+    peak, second = g["align_peak"], g["align_second"]
+    sel = (peak > 1e-6) & ((peak - second) > 4e-6 * peak)
+    got = al.argmax(axis=1)
+    print("C5 arg-max: %d of %d steps compared (the monotonic mass of random weights leaks past the last encoder step)" % (int(sel.sum()), sel.size))
+    assert sel.sum() > 500 and np.array_equal(got[sel], g["align_argmax"][sel].astype(got.dtype))

@@ -830,3 +830,119 @@ def test_a_device_fault_poisons_the_step_and_adam_skips_the_update():
     assert np.isfinite(float(lwc)) and not torch.equal(tr.params[o:o + c], before[o:o + c])
     tr.check_device_errors()
     tr.close()
+
+
+def test_a_restored_checkpoint_continues_the_run_to_the_bit(tmp_path):
+    """train.py:175 (tf.train.Saver), :189-193 (saver.restore of the most recent checkpoint), :242-244 (saver.save every checkpoint_interval):
+    parameters, BatchNorm moving statistics, Adam's m / v and the step counters are persisted -- a run that is stopped after three steps,
+    restored into a NEW trainer and stepped twice more ends with the same bits as the run that never stopped (deterministic reductions are
+    the default).  The weights file of a checkpoint is a weight pack the inference model loads; `--initialize_path` (train.py:194-203)
+    restores everything and resets global_step only."""
+    import torch
+    import taco_amd
+    hp, w, ids, L, mt, lt, co = _setup("bah_mon", seed=31)
+    a = _trainer(hp, w)
+    for _ in range(3):
+        a.train_step(ids, L, mt, lt, co)
+    ck = a.save_checkpoint(str(tmp_path))
+    assert ck.endswith("model.ckpt-3.safetensors") and taco_amd.train_ops.list_train_checkpoints(str(tmp_path)) == [(3, ck)]
+    for _ in range(2):
+        step_a, loss_a = a.train_step(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    b = _trainer(hp, O.init_weights(hp, 1, 99))              # different initial values: everything must come from the checkpoint
+    assert b.restore_checkpoint(str(tmp_path)) == 3 and b.global_step == 3 and b.adam.adam_t == 3
+    for _ in range(2):
+        step_b, loss_b = b.train_step(ids, L, mt, lt, co)
+    torch.cuda.synchronize()
+    assert step_a == step_b == 5 and float(loss_a) == float(loss_b)
+    assert torch.equal(a.params, b.params) and torch.equal(a.adam.m, b.adam.m) and torch.equal(a.adam.v, b.adam.v)
+    moving = [k for k, _ in a.spec if k.endswith(("moving_mean", "moving_variance"))]
+    w0, wa = w, a.get_weights()
+    assert moving and any(maxabs(w0[k], wa[k]) > 1e-6 for k in moving)          # the moving statistics did move, and were part of the state
+    # --initialize_path: the schedule restarts, Adam's bias-correction powers do not
+    c = _trainer(hp, O.init_weights(hp, 1, 98))
+    assert c.restore_checkpoint(ck, reset_global_step=True) == 0 and c.adam.adam_t == 3 and c.global_step == 0
+    assert abs(c.learning_rate - O.learning_rate(0, 0.002, 0, True)) < 1e-12
+    # the weights file alone serves inference (synthesizer.py:66-67 restores the same variables)
+    m = taco_amd.create_model(to_product_hp(hp))
+    m.load_weights(taco_amd.weights.load_weights(ck))
+    m.initialize(None, None, 1, None)
+    lin, al = m.run(inputs=ids, input_lengths=L)
+    assert np.isfinite(lin.cpu().numpy()).all()
+    # a weight pack without optimizer state is refused, so is a state written for other hyper-parameters
+    taco_amd.weights.save_weights(str(tmp_path / "model.ckpt-9.safetensors"), w)
+    with pytest.raises(taco_amd._lib.TacoError):
+        b.restore_checkpoint(str(tmp_path / "model.ckpt-9.safetensors"))
+    hp2, w2 = tiny_hp(attention_type="bah_mon", enc_bank_size=3), None
+    d = _trainer(hp2, O.init_weights(hp2, 1, 5))
+    with pytest.raises(taco_amd._lib.TacoError):
+        d.restore_checkpoint(ck)
+    for t in (a, b, c, d):
+        t.close()
+
+
+@pytest.mark.parametrize("persist,bptt,B", [(1, 1, 12), (1, 1, 32), (10, 1, 12), (11, 1, 12), (1, 1, 40), (1, 1, 4), (1, 0, 12)])
+def test_a_poisoned_workspace_does_not_reach_the_gradients(persist, bptt, B):
+    """the zero fills of the post-net scan's gate tape (forward) and of its gate-gradient / r*h buffers (backward) are skipped when
+    the scan has no lengths, on the contract that every scan kernel variant writes every element (k_bigru_oct<.., true> / k_bigru_duo<.., true> /
+    k_bigru_res, k_bigru_oct_bwd / k_bigru_duo_bwd / k_bigru_rows_bwd).  Enforced here: the whole step workspace is filled with NaN bit
+    patterns between two identical steps -- per kernel choice (taco_debug_set_persistent 1 / 10 / 11, rows that select the one-row clusters
+    or the 32-CU groups, the per-stage BPTT engine) -- and the second step's losses and gradients must be finite and equal to the first's to
+    the bit (ordered reductions are the default)."""
+    import ctypes as C
+    import torch
+    hp = O.OracleHParams(max_iters=4)
+    w = O.init_weights(hp, 1, 141)
+    T_in, T_out = 10, 16
+    ids, L = O.synthetic_inputs(B, T_in, 142, ragged=True)
+    rs = np.random.RandomState(143)
+    mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+    tr = _trainer(hp, w)
+    mh = C.c_void_p(tr._lib.taco_train_model(tr._h))
+    assert tr._lib.taco_debug_set_persistent(mh, persist) == 0
+    tr.set_bptt_engine(bool(bptt))
+    l1 = tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True).clone()
+    torch.cuda.synchronize()
+    g1 = tr.grads.clone()
+    assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(l1).all())
+    tr._ws.fill_(0xFF)                                        # every fp32 word of the workspace a NaN
+    tr.grads.fill_(float("nan"))
+    l2 = tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True)
+    torch.cuda.synchronize()
+    tr.check_device_errors()
+    assert bool(torch.isfinite(tr.grads).all()) and bool(torch.isfinite(l2).all())
+    assert torch.equal(tr.grads, g1) and torch.equal(l2, l1)
+    tr.close()
+
+
+def test_C4_shard_gradients_at_32_rows_against_the_committed_autograd_fixture():
+    """BASELINE.json configs[3], one data-parallel shard at its real size: B = 32, T_in = 128, T_out = 512 at the reference widths -- every
+    gradient tensor's norm and a fixed sample of 2000 of its elements against float64 reverse-mode autograd of the independent torch
+    formulation (tests/golden/full_C4_grads.npz, made by tests/golden/make_full_size_golden.py; round 5 compared a 2-row slice)."""
+    import os
+    import torch
+    import make_full_size_golden as G
+    p = os.path.join(os.path.dirname(__file__), "golden", "full_C4_grads.npz")
+    if not os.path.exists(p):
+        pytest.skip("full_C4_grads.npz not generated (python tests/golden/make_full_size_golden.py C4)")
+    g = np.load(p)
+    hp, seed, ids, L, mt, lt = G.c4_case()
+    assert int(g["seed"]) == seed
+    tr = _trainer(hp, O.init_weights(hp, 1, seed))
+    losses = tr.forward_backward(ids, L, mt, lt)
+    torch.cuda.synchronize()
+    tr.check_device_errors()
+    assert abs(float(losses[0]) - float(g["loss"])) < 1e-4
+    got = tr.grad_dict()
+    gnorm = float(np.sqrt(sum(float(g["norm:" + k]) ** 2 for k in g["names"])))
+    worst = []
+    for k in (str(x) for x in g["names"]):
+        v = np.asarray(got[k], np.float64).reshape(-1)
+        idx = G.grad_sample_index(k, v.size)
+        ref, nrm = g["sample:" + k], float(g["norm:" + k])
+        scale = max(float(g["max:" + k]), 1e-3 * gnorm)
+        worst.append((float(np.abs(v[idx] - ref).max()) / scale, abs(float(np.sqrt((v * v).sum())) - nrm) / max(nrm, 1e-3 * gnorm), k))
+    worst.sort(reverse=True)
+    print("C4 shard, B = 32: worst sampled element error / tensor scale, norm error:", worst[:4])
+    assert worst[0][0] < 2e-3 and max(w[1] for w in worst) < 2e-3, worst[:5]
+    tr.close()

@@ -269,3 +269,23 @@ def test_ctypes_prototypes_agree_with_the_header_argument_by_argument():
             assert klass_py(a) == b, (name, i, params[i], a)
         assert klass_py(restype) == klass_c(ret), (name, ret, restype)
     assert seen == set(_lib.PROTOTYPES), sorted(seen ^ set(_lib.PROTOTYPES))
+
+
+def test_checkpoint_pruning_follows_the_reference_saver(tmp_path):
+    """tf.train.Saver(max_to_keep=5, keep_checkpoint_every_n_hours=2) (train.py:175): the five newest train-state checkpoints stay; of the
+    older ones, one per two hours of file time survives.  Pure host logic (files only)."""
+    import os
+    from taco_amd.train_ops import train_state_paths, list_train_checkpoints, prune_train_checkpoints
+    d = str(tmp_path)
+    t0 = 1_700_000_000
+    for i, step in enumerate(range(1000, 11000, 1000)):          # ten checkpoints, 45 minutes apart
+        for p in train_state_paths(d, step):
+            open(p, "wb").close()
+            os.utime(p, (t0 + i * 2700, t0 + i * 2700))
+    open(os.path.join(d, "model.ckpt-500.safetensors"), "wb").close()      # a weight pack without optimizer state: not a train-state checkpoint
+    assert [s for s, _ in list_train_checkpoints(d)] == list(range(1000, 11000, 1000))
+    removed = prune_train_checkpoints(d, max_to_keep=5, keep_every_n_hours=2.0)
+    left = [s for s, _ in list_train_checkpoints(d)]
+    assert left == [1000, 4000, 6000, 7000, 8000, 9000, 10000], left          # 1000 (first), 4000 (2 h 15 min later) kept for good; 6000.. = the newest five
+    assert len(removed) == 6 and os.path.exists(os.path.join(d, "model.ckpt-500.safetensors"))
+    assert prune_train_checkpoints(d, max_to_keep=None) == []

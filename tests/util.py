@@ -47,10 +47,12 @@ def maxabs(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0
 
 
+import os
+ARGMAX_FLOOR = float(os.environ.get("TACO_ARGMAX_FLOOR", "1e-6"))      # (experiments: TACO_ARGMAX_FLOOR=1e-30 python -m pytest ...)
 ARGMAX_STATS = {"calls": 0, "steps": 0, "masked_by_floor": 0, "excused_as_ties": 0, "mismatches": 0}     # summed over a session
 
 
-def argmax_detail(a_hip, a_ref, floor=1e-6, tie=4e-6):
+def argmax_detail(a_hip, a_ref, floor=None, tie=4e-6):
     """alignment argmax over the encoder axis, HIP vs oracle, step by step.  Returns a dict:
     steps            decoder steps x rows in the arrays
     masked_by_floor  steps not compared because the reference's peak is <= `floor` (the monotonic mass has leaked past the last
@@ -61,6 +63,7 @@ def argmax_detail(a_hip, a_ref, floor=1e-6, tie=4e-6):
                      less than `tie` of the peak: a tie at fp32 resolution (2^-23 per operation, a few operations deep)
     mismatch         strict_mismatch - excused_as_ties: what the tests hold at zero"""
     a_hip, a_ref = np.asarray(a_hip), np.asarray(a_ref)
+    floor = ARGMAX_FLOOR if floor is None else floor
     peak = a_ref.max(axis=1)
     sel = peak > floor
     picked = np.take_along_axis(a_ref, a_hip.argmax(axis=1)[:, None, :], axis=1)[:, 0, :]     # the oracle's value where HIP peaks
@@ -71,7 +74,7 @@ def argmax_detail(a_hip, a_ref, floor=1e-6, tie=4e-6):
     return d
 
 
-def argmax_match(a_hip, a_ref, floor=1e-6, tie=4e-6):
+def argmax_match(a_hip, a_ref, floor=None, tie=4e-6):
     """(n_compared, n_mismatch) of argmax_detail; every call prints what it masked and excused and adds to ARGMAX_STATS (the
     session totals are printed by tests/conftest.py at the end of a run).  At C2 with tools/parity_margins.py's seed one of 2784
     steps has its top two positions 1.3e-6 apart, and the exact-fp32 path computes them EQUAL

@@ -7,6 +7,8 @@ cp $o/bench_C2.json profiles/${rnd}_bench_${ver}.json
 for w in C1 C3 C5; do cp $o/bench_$w.json profiles/${rnd}_bench_${ver}_$w.json; done
 cp $o/bench_C2_coalesce2.json profiles/${rnd}_bench_${ver}_coalesce2.json
 cp $o/kernel_stats.csv profiles/${rnd}_c2_kernel_stats_${ver}.csv
+[ -f $o/kernel_stats.hash ] && cp $o/kernel_stats.hash profiles/${rnd}_c2_kernel_stats_${ver}.hash
+[ -f $o/ubench_mfma_stage.txt ] && cp $o/ubench_mfma_stage.txt profiles/${rnd}_${ver}_ubench_mfma_stage.txt
 cp $o/pmc_hbm_traffic.json profiles/${rnd}_${ver}_pmc_hbm_traffic.json
 cp $o/pmc_hbm_traffic.txt profiles/${rnd}_${ver}_pmc_hbm_traffic.txt
 cp $o/pmc_sq.txt profiles/${rnd}_${ver}_pmc_sq.txt

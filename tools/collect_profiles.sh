@@ -16,6 +16,7 @@ if [ "$2" = "core" ]; then
   cp $out/pmc_hbm_traffic.json profiles/${tag%%_*}_${tag##*_}_pmc_hbm_traffic.json      # (on the box only: lets the bench line below find its profile by the source hash)
   timeout 400 rocprofv3 --kernel-trace --stats -d $out/ks -o ks --output-format csv -- python bench.py --no-cpu-baseline --no-companions --no-stage-timing --steps 5 --warmup 2 --lanes 1 > $out/ks.log 2>&1
   cp $out/ks/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+  python -c "import bench; print(bench.source_hash())" > $out/kernel_stats.hash
   timeout 600 python bench.py --steps 20 --warmup 4 > $out/bench_C2.json 2> $out/bench_C2.err
   rm -rf $out/ks/*kernel_trace.csv $out/pmc_f $out/pmc_w
   tail -c 400 $out/bench_C2.json
@@ -58,6 +59,8 @@ timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 python tools/pmc_traffic.py $out/pmc_f $out/pmc_w $out/pmc_hbm_traffic > $out/pmc_traffic.log 2>&1
 python tools/pmc_sq.py $out/pmc_sq $out/pmc_sq.txt > /dev/null 2>&1
 cp $out/ks/*kernel_stats.csv $out/kernel_stats.csv 2>/dev/null
+python -c "import bench; print(bench.source_hash())" > $out/kernel_stats.hash      # the build the statistics were taken from (bench.py floor_constants)
+[ -x tools/ubench_mfma_stage ] && timeout 120 ./tools/ubench_mfma_stage > $out/ubench_mfma_stage.txt 2>&1      # the decoder's exchange in isolation (latency_floor_ms.hardware_terms)
 rm -rf $out/ks/*kernel_trace.csv $out/pmc_f $out/pmc_w $out/pmc_sq     # raw traces are large; the reductions above are what is kept
 ls -la $out
 tail -c 600 $out/bench_C2.json

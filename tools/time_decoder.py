@@ -86,6 +86,8 @@ def main():
         res[name] = rec
         model.close()
     if jpath:
+        import bench
+        res["kernel_source_hash"] = bench.source_hash()      # ties the timeline to the build it was taken from (bench.py floor_constants)
         json.dump(res, open(jpath, "w"), indent=1)
 
 

@@ -60,6 +60,7 @@ med = np.median(d[1:], axis=0)
 print("  " + "  ".join("%s %.0f" % (n, c) for n, c in zip(names, med)) + "   (clocks)")
 if jpath:
     recs = json.load(open(jpath)) if os.path.exists(jpath) else []
-    recs.append({"B": B, "T": T, "persist": PERSIST, "kernel": kernel, "total_us": us, "input_projection_us": us_gemm, "scan_us": scan_us,
+    import bench
+    recs.append({"kernel_source_hash": bench.source_hash(), "B": B, "T": T, "persist": PERSIST, "kernel": kernel, "total_us": us, "input_projection_us": us_gemm, "scan_us": scan_us,
                  "step_clocks": step, "clocks_per_us": cpu, "phases_clocks": {n: float(c) for n, c in zip(names, med)}})
     json.dump(recs, open(jpath, "w"), indent=1)
