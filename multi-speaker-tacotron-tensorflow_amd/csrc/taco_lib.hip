@@ -1719,8 +1719,8 @@ static bool dx_usable(const taco_model* m, int B, int T_in, const float* manual,
   // training shadow model's pack has them (taco_model_finalize)
   if (!m->dx_mode || !m->dx_pack || B > 8 * DX_NGROUP || m->cu_count < DX_NGROUP * DX_GROUP) return false;
   // teacher forcing: the TAPE instantiation -- the training shadow model (pack in teacher form), or an inference model at the reference widths
-  // (raw frame rows of prenet layer 1 kept beside the composite pack); not together with manual alignments
-  if (teacher && !(m->tp || (m->dx_p1o_raw && !manual && m->hp.num_mels <= DX_P2))) return false;
+  // (raw frame rows of prenet layer 1 kept beside the composite pack), with or without manual alignments
+  if (teacher && !(m->tp || (m->dx_p1o_raw && m->hp.num_mels <= DX_P2))) return false;
   const int RG = dx_rows_per_group(m, B);
   if (m->hp.attention_size == 512 && RG > 4) return false;        // 128 score channels per member: no instantiation (query registers, the q / v slots)
   return dx_lds_floats(RG, T_in, m->tp != nullptr || teacher != nullptr, m->hp.attention_size) * sizeof(float) <= 160 * 1024;
@@ -1732,9 +1732,9 @@ static int dx_launch_rg(hipStream_t st, const DxArgs& a_in, size_t lds) {
     if (a.trace && !a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, false, AW, PD, true>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
   }
   a.trace = nullptr;
-  if constexpr (!TAPE) {
-    if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, false, true, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
-  }
+  // manual alignments: their own instantiation (the score phases are compiled out); with teacher frames as well (round 6: teacher-forced decoding under
+  // manual alignments on an inference model -- taco_decoder_forward with both -- used to fall to the launch-per-stage loop)
+  if (a.manual) { hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE, true, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a); HIPCHK(hipGetLastError()); return 0; }
   hipLaunchKernelGGL((k_decoder_xcd<RG, TAPE, false, AW, PD>), dim3(DX_NGROUP * DX_GROUP), dim3(DX_NT), lds, st, a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -2083,7 +2083,14 @@ static int forward_pass(taco_model* m, hipStream_t st, const int32_t* ids, const
 // is the maximum over the passes' stop steps -- a row's `finished` is sticky, so the loop would have ended when the LAST pass's rows
 // were all done; a negative pass word (a persistent kernel gave up) wins.
 struct PassPlan { int passes, rows; };
-static PassPlan pass_plan(int B) { PassPlan p; p.passes = (B + 63) / 64; p.rows = p.passes ? (B + p.passes - 1) / p.passes : 0; return p; }
+static PassPlan pass_plan(int B, int cap = 64) { PassPlan p; p.passes = (B + cap - 1) / cap; p.rows = p.passes ? (B + p.passes - 1) / p.passes : 0; return p; }
+// Rows one pass of the decoder loop may hold: 64 (8 groups x 8 rows) -- but an inference model with attention_size 512 (hparams.py:71-82, the first
+// "Deep Voice 2" block) has no persistent instantiation at 8 rows per group (128 score channels per member do not fit the query registers), so its
+// passes hold at most 32 rows: two passes on the persistent decoder instead of one on the launch-per-stage loop, which is four times slower per step.
+static int pass_cap(const taco_model* m) {
+  if (m && !m->tp && m->hp.attention_size == 512 && m->dx_mode && m->dx_pack && m->cu_count >= DX_NGROUP * DX_GROUP) return 32;
+  return 64;
+}
 __global__ void k_stop_combine(const int* pstop, int np, int* stop) {
   if (threadIdx.x == 0) {
     int worst = 0, err = 0;
@@ -2092,7 +2099,7 @@ __global__ void k_stop_combine(const int* pstop, int np, int* stop) {
   }
 }
 static size_t forward_workspace(const taco_model* m, int B, int T_in, int n, FullWs* w_out, int32_t** pstop, void* ws, size_t ws_bytes, bool* ok) {
-  const PassPlan pp = pass_plan(B);
+  const PassPlan pp = pass_plan(B, pass_cap(m));
   Carver cv(ws, ws_bytes);
   FullWs w;
   carve_full(cv, m, pp.rows, T_in, n, w);
@@ -2107,11 +2114,12 @@ static size_t forward_workspace(const taco_model* m, int B, int T_in, int n, Ful
 static int forward_enqueue(taco_model* m, hipStream_t st, const int32_t* ids, const int32_t* lengths, const int32_t* spk,
                            int B, int T_in, int n, const float* manual, float* mel, float* linear, float* align,
                            int32_t* stop, void* ws, size_t ws_bytes) {
-  if (B <= 64) return forward_pass(m, st, ids, lengths, spk, B, T_in, n, manual, mel, linear, align, stop, ws, ws_bytes);
   if (!m) return fail(TACO_ERR_ARG, "null model");
+  const int cap = pass_cap(m);
+  if (B <= cap) return forward_pass(m, st, ids, lengths, spk, B, T_in, n, manual, mel, linear, align, stop, ws, ws_bytes);
   if (T_in <= 0 || n <= 0) return fail(TACO_ERR_ARG, "bad time %d / steps %d", T_in, n);
   if (!ids || !lengths || !mel || !linear || !align || !ws) return fail(TACO_ERR_ARG, "null buffer");
-  const PassPlan pp = pass_plan(B);
+  const PassPlan pp = pass_plan(B, cap);
   int32_t* pstop = nullptr; bool ok = false;
   const size_t need = forward_workspace(m, B, T_in, n, nullptr, &pstop, ws, ws_bytes, &ok);
   if (!ok) return fail(TACO_ERR_STATE, "workspace too small: need %zu bytes, have %zu", need, ws_bytes);
@@ -2435,6 +2443,11 @@ int taco_model_finalize(taco_model* m) {
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<8, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define DX_ATTR_T(RG) \
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<RG, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  DX_ATTR_T(1) DX_ATTR_T(2) DX_ATTR_T(4) DX_ATTR_T(8)      // teacher frames (with and without manual alignments)
+#undef DX_ATTR_T
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<1, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));      // the stamped instantiations
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<2, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decoder_xcd<4, false, false, DX_W, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2582,8 +2595,8 @@ int taco_debug_decoder_info(taco_model* m, int* out16) {
 int taco_model_engine_plan(taco_model* m, int B, int T_in, int T_mel, int manual, char* out, int out_len) {
   if (!m || !m->finalized || !out || out_len < 64) return fail(TACO_ERR_ARG, "bad argument");
   std::string s;
-  if (B > 64 && !m->tp) {      // taco_forward_infer / taco_plan_create serve any batch as passes of at most 64 rows; the plan below is a pass's
-    const PassPlan pp = pass_plan(B);
+  if (B > pass_cap(m) && !m->tp) {      // taco_forward_infer / taco_plan_create serve any batch as passes of at most 64 rows (32: attention_size 512); the plan below is a pass's
+    const PassPlan pp = pass_plan(B, pass_cap(m));
     s = std::to_string(B) + " rows = " + std::to_string(pp.passes) + " passes of " + std::to_string(pp.rows) + " (the last one " + std::to_string(B - (pp.passes - 1) * pp.rows) + "); per pass: ";
     B = pp.rows;
   }
@@ -2671,10 +2684,11 @@ size_t taco_stage_workspace_bytes(const taco_model* m, int B, int T) {
   // large enough for any single stage at (B, T): encoder at T_in=T, decoder with T_in=T and n_steps=T, post-net at T_mel=T
   Carver a(nullptr, 0), b(nullptr, 0), c(nullptr, 0);
   const int R = B > 64 ? pass_plan(B).rows : B;      // more than 64 rows: passes over one pass's workspace (+ the passes' stop words)
+  const int Rd = B > pass_cap(m) ? pass_plan(B, pass_cap(m)).rows : B;
   EncWs e; carve_enc(a, m, R, T, e);
-  DecWs d; carve_dec(b, m, R, T, T, d);
+  DecWs d; carve_dec(b, m, Rd, T, T, d);
   PostWs p; carve_post(c, m, R, T, p);
-  return std::max(a.off, std::max(b.off, c.off)) + (B > 64 ? 256 : 0);
+  return std::max(a.off, std::max(b.off, c.off)) + (B > pass_cap(m) ? 256 : 0);
 }
 
 int taco_forward_infer(taco_model* m, void* hip_stream, const int32_t* d_inputs, const int32_t* d_input_lengths,
@@ -2755,9 +2769,9 @@ int taco_decoder_forward(taco_model* m, void* hip_stream, const float* d_encoder
                          int T_in, int n_steps, const float* d_manual_alignments, const float* d_teacher_frames,
                          float* d_mel, float* d_alignments, int32_t* d_stop_step, float* d_dbg_states, void* d_workspace,
                          size_t workspace_bytes) {
-  if (m && m->finalized && B > 64 && T_in > 0 && n_steps > 0 && d_encoder_out && d_mel && d_alignments && d_workspace) {      // passes of at most 64 rows
+  if (m && m->finalized && B > pass_cap(m) && !(d_dbg_states && B <= 64) && T_in > 0 && n_steps > 0 && d_encoder_out && d_mel && d_alignments && d_workspace) {      // passes of at most 64 (32) rows
     if (d_dbg_states) return fail(TACO_ERR_UNSUPPORTED, "the per-step state dump is laid out [step][row]: at most 64 rows per call");
-    const PassPlan pp = pass_plan(B);
+    const PassPlan pp = pass_plan(B, pass_cap(m));
     const size_t rM = (size_t)m->hp.reduction_factor * m->hp.num_mels, D = (size_t)2 * m->hp.enc_rnn_size;
     if (workspace_bytes < 256) return fail(TACO_ERR_STATE, "workspace too small");
     int32_t* pstop = (int32_t*)((char*)d_workspace + ((workspace_bytes - (size_t)pp.passes * sizeof(int32_t)) & ~(size_t)255));      // the tail of the caller's buffer

@@ -184,7 +184,21 @@ def test_other_presets_on_the_persistent_decoder(preset, atype, B):
     m, info, _, _ = _decoder_vs_oracle(ohp, w, ids, L, n)
     plan = m.engine_plan(B, 37)
     if ohp.attention_size == 512 and B > 32:
-        assert info["protocol"] == 0 and "one launch per stage" in plan and "attention_size 512" in plan, (info, plan)
+        # no instantiation at 8 rows per group (query registers): round 6 serves such a batch as TWO passes of at most 32 rows on the persistent
+        # decoder (the per-step state dump of _decoder_vs_oracle is laid out [step][row] and keeps the whole batch in one launch-per-stage call)
+        import torch
+        assert info["protocol"] == 0 and "40 rows = 2 passes of 20" in plan and "persistent k_decoder_xcd<4, attention 512" in plan, (info, plan)
+        taps = {}
+        ref = O.forward(w, ohp, ids, L, n_steps=n, taps=taps, honor_stop=False)
+        mel, al, stop, _ = m.decoder(taps["encoder"], n)
+        torch.cuda.synchronize()
+        assert m.decoder_engine_info()["protocol"] in (1, 2) and int(stop.item()) == n
+        assert maxabs(mel.cpu().numpy(), ref["mel"]) < 2e-4 and maxabs(al.cpu().numpy(), ref["alignments"]) < 2e-4
+        lin, al2 = m.run(inputs=ids, input_lengths=L, honor_stop=False)
+        torch.cuda.synchronize()
+        assert m.decoder_engine_info()["protocol"] in (1, 2)
+        assert maxabs(m.mel_outputs.cpu().numpy(), ref["mel"]) < 2e-4 and maxabs(lin.cpu().numpy(), ref["linear"]) < 2e-4
+        m.check_device_errors()
     else:
         assert info["has_pack"] and info["protocol"] in (1, 2), (info, plan)
         assert "persistent k_decoder_xcd<%d, attention %d, %d prenet layers>" % (4 if B <= 32 else 8, ohp.attention_size, len(ohp.dec_prenet_sizes)) in plan, plan
@@ -247,8 +261,17 @@ def test_teacher_forced_decoding_on_the_persistent_decoder(model_type, B, atype)
     mel0, al0, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk, teacher_frames=frames)
     torch.cuda.synchronize()
     assert maxabs(mel0.cpu().numpy(), mel.cpu().numpy()) < 2e-5 and maxabs(al0.cpu().numpy(), al.cpu().numpy()) < 2e-5
-    # the same model without teacher frames afterwards: the composite registers are back
+    # teacher frames TOGETHER with manual alignments (rnn_wrappers.py:313-317 under helpers.py:35-67): the <TAPE, MAN> instantiation (round 6; the
+    # launch-per-stage loop until then)
     m.set_decoder_engine(1)
+    man = np.random.RandomState(6).dirichlet(np.ones(16), (B, n))
+    refm = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, teacher_frames=frames, manual_alignments=man, honor_stop=False)
+    melm, alm, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk, teacher_frames=frames, manual_alignments=man)
+    torch.cuda.synchronize()
+    m.check_device_errors()
+    assert m.decoder_engine_info()["protocol"] in (1, 2)
+    assert maxabs(melm.cpu().numpy(), refm["mel"]) < 2e-4 and maxabs(alm.cpu().numpy(), np.transpose(man, (0, 2, 1))) < 1e-6
+    # the same model without teacher frames afterwards: the composite registers are back
     free = O.forward(w, ohp, ids, L, speaker_id=spk, num_speakers=ns, n_steps=n, honor_stop=False)
     mel1, _, _, _ = m.decoder(taps["encoder"], n, speaker_id=spk)
     torch.cuda.synchronize()

@@ -795,7 +795,7 @@ def test_C3_all_32_rows_all_128_steps_against_the_committed_oracle_outputs():
     print("C3 full size x full horizon vs the oracle fixture:", errs)
     assert max(errs.values()) < 1e-3, errs
     n, bad = argmax_match(al, g["alignments"].astype(np.float64))
-    assert bad == 0 and n > 0.45 * 32 * 128, (n, bad)
+    assert bad == 0 and n > 0.9 * 32 * 128, (n, bad)           # (95 % of the steps have a peak above the floor of tests/util.py)
 
 
 def test_C5_all_8_rows_all_1000_steps_against_the_committed_oracle_outputs():
@@ -816,7 +816,7 @@ def test_C5_all_8_rows_all_1000_steps_against_the_committed_oracle_outputs():
     assert max(errs.values()) < 1e-3, errs
     # arg-max of every step whose oracle peak is above the floor and is not tied with the runner-up at fp32 resolution
     peak, second = g["align_peak"], g["align_second"]
-    sel = (peak > 1e-6) & ((peak - second) > 4e-6 * peak)
+    sel = (peak > 1e-20) & ((peak - second) > 2e-5 * peak)           # (tests/util.py: the floor and the tie criterion of argmax_match)
     got = al.argmax(axis=1)
     print("C5 arg-max: %d of %d steps compared (the monotonic mass of random weights leaks past the last encoder step)" % (int(sel.sum()), sel.size))
-    assert sel.sum() > 500 and np.array_equal(got[sel], g["align_argmax"][sel].astype(got.dtype))
+    assert sel.sum() > 1200 and np.array_equal(got[sel], g["align_argmax"][sel].astype(got.dtype))

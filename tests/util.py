@@ -48,22 +48,32 @@ def maxabs(a, b):
 
 
 import os
-ARGMAX_FLOOR = float(os.environ.get("TACO_ARGMAX_FLOOR", "1e-6"))      # (experiments: TACO_ARGMAX_FLOOR=1e-30 python -m pytest ...)
+# Steps are compared wherever the oracle's peak is above 1e-20 (rounds 1-5: 1e-6, which masked 17 % of the session's steps).  With
+# Glorot-random weights the monotonic mass leaks past the last encoder position and the peak decays geometrically -- to 1e-228 in float64
+# at C5.  What the fp32 path resolves down there was measured (tools/scratch/argmax_probe.py on the full-size fixtures): at C3 (T_in 128,
+# 128 steps) the HIP value at the oracle's peak position stays within 4.7e-5 RELATIVE of the oracle down to 1e-30 and the arg-max agrees on
+# 4095 of 4096 steps (the one flip: two positions 6.4e-6 apart); at C5 (T_in 512, 1000 steps) the relative error grows as the peak decays --
+# 2e-3 for peaks in (1e-12, 1e-6], 1.5e-2 in (1e-20, 1e-12], 1.5e-1 below -- and the only four flips of 1696 steps sit at peaks of 1e-27,
+# between positions 6e-5 .. 2e-3 apart.  Above 1e-20 no flip was seen outside fp32 ties; below, the comparison would test the error growth
+# of a geometric decay, not the attended position.  A differing arg-max is excused as a tie only where the oracle's own values at the two
+# positions differ by less than `tie` = 2e-5 of the peak (below the relative error measured even for the large peaks).
+ARGMAX_FLOOR = float(os.environ.get("TACO_ARGMAX_FLOOR", "1e-20"))
+ARGMAX_TIE = float(os.environ.get("TACO_ARGMAX_TIE", "2e-5"))
 ARGMAX_STATS = {"calls": 0, "steps": 0, "masked_by_floor": 0, "excused_as_ties": 0, "mismatches": 0}     # summed over a session
 
 
-def argmax_detail(a_hip, a_ref, floor=None, tie=4e-6):
+def argmax_detail(a_hip, a_ref, floor=None, tie=None):
     """alignment argmax over the encoder axis, HIP vs oracle, step by step.  Returns a dict:
     steps            decoder steps x rows in the arrays
-    masked_by_floor  steps not compared because the reference's peak is <= `floor` (the monotonic mass has leaked past the last
-                     encoder step there and fp32 / fp64 underflow differently)
+    masked_by_floor  steps not compared because the reference's peak is <= `floor` (see above)
     compared         steps - masked_by_floor
     strict_mismatch  compared steps whose argmax differs
     excused_as_ties  of those, steps where the oracle's peak and the oracle's value at the position the HIP path picked differ by
-                     less than `tie` of the peak: a tie at fp32 resolution (2^-23 per operation, a few operations deep)
+                     less than `tie` of the peak: a tie at fp32 resolution
     mismatch         strict_mismatch - excused_as_ties: what the tests hold at zero"""
     a_hip, a_ref = np.asarray(a_hip), np.asarray(a_ref)
     floor = ARGMAX_FLOOR if floor is None else floor
+    tie = ARGMAX_TIE if tie is None else tie
     peak = a_ref.max(axis=1)
     sel = peak > floor
     picked = np.take_along_axis(a_ref, a_hip.argmax(axis=1)[:, None, :], axis=1)[:, 0, :]     # the oracle's value where HIP peaks
@@ -74,7 +84,7 @@ def argmax_detail(a_hip, a_ref, floor=None, tie=4e-6):
     return d
 
 
-def argmax_match(a_hip, a_ref, floor=None, tie=4e-6):
+def argmax_match(a_hip, a_ref, floor=None, tie=None):
     """(n_compared, n_mismatch) of argmax_detail; every call prints what it masked and excused and adds to ARGMAX_STATS (the
     session totals are printed by tests/conftest.py at the end of a run).  At C2 with tools/parity_margins.py's seed one of 2784
     steps has its top two positions 1.3e-6 apart, and the exact-fp32 path computes them EQUAL
