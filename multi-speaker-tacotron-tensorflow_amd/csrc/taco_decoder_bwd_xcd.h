@@ -24,6 +24,12 @@
 #include "taco_decoder_xcd.h"
 #include "taco_backward_kernels.h"
 
+// s_sleep units (64 clocks) in front of the first poll of every gather of the backward loop: as in the forward kernel (DX_FIRST_POLL_DELAY), a poll that
+// reaches the L2 ahead of the group's stores costs a second round trip
+#ifndef DB_POLL_DELAY
+#define DB_POLL_DELAY 0
+#endif
+
 // register map (per thread; host mirror: dbx_build_pack in taco_lib.hip).  A 256-input row = 4 registers (inputs 4l..4l+3), a 512-input
 // row = 8 (two halves), a 128-input row = 2.  (The frame projection's data gradient d o2 = dmel . Wf^T does not depend on the
 // recurrence: the host computes it for all steps with one GEMM, and the kernel reads its own column of it with the tape values.)
@@ -369,7 +375,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcp2, 256, q, en, dcp); DB_OUT(a.g_dgp2, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(1);
     // a cell's parts 'b' and 'c' as two stages; CX/CH/GX/GH: register bases, VC/VG: LDS vectors, XG: gate-gradient exchange
@@ -392,7 +398,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
     float dhp[RL];
     // ================= GRU 2 'b' =================
     DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, (z2 ? 0.f : OWN(OW_H2P, q)), OWN(OW_R2, q), OWN(OW_U2, q), dhp, a.g_dgp2)
-    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(2);
     // ================= GRU 2 'c' -> residual -> GRU 1 'a' =================
@@ -414,12 +420,12 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcp1, 256, q, en, dcp); DB_OUT(a.g_dgp1, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(3);
     // ================= GRU 1 'b' =================
     DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, (z1 ? 0.f : OWN(OW_H1P, q)), OWN(OW_R1, q), OWN(OW_U1, q), dhp, a.g_dgp1)
-    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(4);
     // ================= GRU 1 'c' -> d o0 =================
@@ -437,7 +443,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_do0, 256, q, en, do0);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(5);
     // ================= concat projection^T: d h_att (kept), d ctx -> exchange =================
@@ -456,7 +462,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dctx, 256, q, en, dc);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(6);
     // ================= attention backward of the member's row =================
@@ -480,7 +486,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         float s = 0.f;
         if (j < T && (Pr >= 4 || part < Pr)) {
           float v[NPQ];
-          dx_poll<NPQ>(X + xl.da + (size_t)(arow * Pr + (Pr >= 4 ? part * NPQ : part)) * T + j, (size_t)T, tag, v, rt);
+          dx_poll<NPQ, DB_POLL_DELAY>(X + xl.da + (size_t)(arow * Pr + (Pr >= 4 ? part * NPQ : part)) * T + j, (size_t)T, tag, v, rt);
 #pragma unroll
           for (int u = 0; u < NPQ; ++u) s += v[u];
         }
@@ -582,7 +588,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         if (i < RG * 256) {
           const int r = i / 256, c = i % 256;
           float v[Pp];
-          dx_poll<Pp>(X + xl.dq + (size_t)(r * Pp) * 256 + c, (size_t)256, tag, v, rt);
+          dx_poll<Pp, DB_POLL_DELAY>(X + xl.dq + (size_t)(r * Pp) * 256 + c, (size_t)256, tag, v, rt);
           float s = 0.f;
 #pragma unroll
           for (int k = 0; k < Pp; ++k) s += v[k];
@@ -609,12 +615,12 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcpA, 256, q, en, dcp); DB_OUT(a.g_dgpA, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(10);
     // ================= attention GRU 'b' (the x part has 128 inputs: rows 4m + w of waves 0-3) =================
     DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, (zA ? 0.f : OWN(OW_HAP, q)), OWN(OW_RA, q), OWN(OW_UA, q), dhp, a.g_dgpA)
-    dx_gather<RG, 512, false, DBS_LD>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(11);
     // ================= attention GRU 'c' -> d p2 (ReLU mask) =================
@@ -634,7 +640,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         }
       }
     }
-    dx_gather<RG, 128, false, DBS_LD>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
+    dx_gather<RG, 128, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(12);
     // ================= prenet layer 2^T, ReLU mask of layer 1 =================
@@ -654,7 +660,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dz1, 256, q, en, dz1);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(13);
     // ================= prenet layer 1 (context rows)^T: the gradient of context(t - 1) =================

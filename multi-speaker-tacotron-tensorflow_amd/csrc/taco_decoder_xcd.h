@@ -58,6 +58,17 @@ typedef __attribute__((address_space(1))) unsigned dx_gu32;
 #ifndef DX_POLL_SLEEP
 #define DX_POLL_SLEEP 0          // s_sleep units (64 clocks) between two polls of a stale granule
 #endif
+// s_sleep units (64 clocks) in front of the FIRST poll of a decoder gather (round 6).  A poll that reaches the L2 ahead of the stores it waits
+// for comes back stale and costs a second round trip (~500 clocks); where nothing runs between a wave's publish and its gather (DX_FIRST_POLL_DELAY:
+// r*h of the three cells, h_att, context, the next step's prenet) a short sleep lets the group's stores land first.  Gathers that follow a
+// run-ahead pass (DX_POLL_DELAY_B: p2, the partial scores, h1, h2) start later, and gain as much.  Measured at C2 on two boxes, decoder alone
+// (profiles/r06_ab_poll_delay.txt): 0 / 0 1.336 ms, 4 / 4 1.322, 5 / 5 1.298, 6 / 6 1.299, 7 / 7 1.328, 8 / 8 1.350 -- a flat optimum around 320 clocks.
+#ifndef DX_FIRST_POLL_DELAY
+#define DX_FIRST_POLL_DELAY 5
+#endif
+#ifndef DX_POLL_DELAY_B
+#define DX_POLL_DELAY_B 5
+#endif
 #define DX_TRACE_STEPS 8
 #define DX_TRACE_SLOTS 16
 
@@ -528,12 +539,13 @@ __device__ __forceinline__ void dx_publish_n(dx_gu64* p, int stride, const float
 #define DX_PIN(x) asm("" : "+v"(x))
 // Poll N granules (p0 + u*stride) until every one carries `tag` (L1-bypassing loads).  All N are re-requested together on every
 // round, so a late producer costs one L2 round trip after its store lands, not one per granule.  Bounded.
-template <int N>
+template <int N, int DLY = 0>
 __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsigned tag, float (&v)[N], DxRt& rt) {
   // (keeping a second round of requests in flight behind the one being examined was measured: 11.8 -> 14.2 us per decoder step at
   // C2 -- the extra L2 requests of 16 K pollers delay the very stores they are waiting for)
   unsigned long long g[N];
   unsigned spins = 0;
+  if (DLY) __builtin_amdgcn_s_sleep(DLY);
   for (;;) {
     bool ok = true;
 #pragma unroll
@@ -559,10 +571,11 @@ __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsign
 // per group; the 512-wide gate-gradient vectors of the BPTT kernel): measured on the exchange stage in isolation
 // (tools/ubench_rowsets, variant T) 13.96 -> 12.63 us per step at eight rows, and nothing at two granules per thread (C2's decoder).
 typedef unsigned long long dx_u64x2 __attribute__((ext_vector_type(2)));
-template <int NP>
+template <int NP, int DLY = 0>
 __device__ __forceinline__ void dx_poll_pairs(const dx_gu64* p0, size_t stride, unsigned tag, float (&v)[2 * NP], DxRt& rt) {
   dx_u64x2 g[NP];
   unsigned spins = 0;
+  if (DLY) __builtin_amdgcn_s_sleep(DLY);
   for (;;) {
     bool ok = true;
 #pragma unroll
@@ -584,13 +597,13 @@ __device__ __forceinline__ void dx_poll_pairs(const dx_gu64* p0, size_t stride, 
 #pragma unroll
   for (int u = 0; u < NP; ++u) { v[2 * u] = __uint_as_float((unsigned)g[u][0]); v[2 * u + 1] = __uint_as_float((unsigned)g[u][1]); }
 }
-template <int RG, int N, bool RES, int LD = DXS_LD, int NT = DX_NT>
+template <int RG, int N, bool RES, int LD = DXS_LD, int NT = DX_NT, int DLY = 0>
 __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float* st, int off, int off_res, int off2, int tid, DxRt& rt) {
   constexpr int NI = (RG * N + NT - 1) / NT;
   if constexpr (NI >= 4 && NI % 2 == 0 && (RG * N) % (2 * NT) == 0 && N % 2 == 0) {
     constexpr int NP = NI / 2;
     float v[NI];
-    dx_poll_pairs<NP>(X + 2 * tid, (size_t)2 * NT, tag, v, rt);
+    dx_poll_pairs<NP, DLY>(X + 2 * tid, (size_t)2 * NT, tag, v, rt);
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int i = 2 * (u * NT + tid), r = i / N, n = i % N;
@@ -605,7 +618,7 @@ __device__ __forceinline__ void dx_gather(const dx_gu64* X, unsigned tag, float*
   const bool act = (RG * N >= NT) || tid < RG * N;
   if (act) {
     float v[NI];
-    dx_poll<NI>(X + tid, NT, tag, v, rt);
+    dx_poll<NI, DLY>(X + tid, NT, tag, v, rt);
 #pragma unroll
     for (int u = 0; u < NI; ++u) {
       const int i = u * NT + tid;
@@ -968,7 +981,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     dxq_zero<RG>(ag01);
     dx_zero<1, RG>(ag2);
     dxw_pair<DXR_AGH, RG>(WP, st + DXS_HATT, lane, ag01);
-    dx_gather<RG, DX_P2, false>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
+    dx_gather<RG, DX_P2, false, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
     __syncthreads();
     if constexpr (PD == 3) {
       // ================= prenet layer 3 (64 columns, two per member); its output takes the OUT2 slot, dead until the end of the step =================
@@ -983,7 +996,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
             dx_publish<WTC>(X + xl.p3 + erow[q] * DX_P3 + member * 2 + wave, fmaxf(s[0][q] + bl[DXB_P3 * DX_NW + wave], 0.f), tag, rt);
         }
       }
-      dx_gather<RG, DX_P3, false>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
+      dx_gather<RG, DX_P3, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
       __syncthreads();
     }
     DX_STAMP(1);
@@ -1005,7 +1018,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         DX_TAPE(DXT_RA, q, rg); DX_TAPE(DXT_UA, q, g_u[q]); DX_TAPE(DXT_RHA, q, rg * g_h[q]);
       }
     }
-    dx_gather<RG, DX_W, false>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(2);
     {
@@ -1023,7 +1036,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     }
 #pragma unroll
     for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H1 + en];
-    dx_gather<RG, DX_W, false>(X + xl.ha, tag, st, DXS_HATT, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.ha, tag, st, DXS_HATT, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(3);
     // ================= attention (rnn_wrappers.py:304-341) =================
@@ -1097,7 +1110,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
           float s = 0.f;
           if (j < T) {
             float v[NP];
-            dx_poll<NP>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
+            dx_poll<NP, DX_POLL_DELAY_B>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
 #pragma unroll
             for (int u = 0; u < NP; ++u) s += v[u];
           }
@@ -1148,7 +1161,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       dx_publish<WTC>(X + xl.ctx + arow * DX_W + asl * DC + tid, s, tag, rt);
       if (TAPE && a.tp_ctx && brow < a.B) a.tp_ctx[((size_t)brow * a.n + t) * a.ld_ctx + asl * DC + tid] = s;
     }
-    dx_gather<RG, DX_W, false>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(6);
     // ================= concat projection folded into residual GRU 1 (rnn_wrappers.py:405-415; tacotron.py:166-172) =================
@@ -1176,7 +1189,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       }
       DX_STAMP(13);
     }
-    dx_gather<RG, DX_W, false>(X + xl.rh1, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rh1, tag, st, DXS_T, 0, 0, tid, rt);
     DX_STAMP(14);
     __syncthreads();
     DX_STAMP(7);
@@ -1204,8 +1217,8 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     dxq_zero<RG>(g2p);
     dx_zero<1, RG>(g2c);
     if (G1_AHEAD) dxw_pair<DXR_G2H, RG>(WP, st + DXS_H2, lane, g2p);
-    dx_gather<RG, DX_W, false>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
-    dx_gather<RG, DX_W, false>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, 0>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(8);
     // ================= residual GRU 2 =================
@@ -1226,7 +1239,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         DX_TAPE(DXT_R2, q, rg); DX_TAPE(DXT_U2, q, g_u[q]); DX_TAPE(DXT_RH2, q, rg * g_h[q]);
       }
     }
-    dx_gather<RG, DX_W, false>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(9);
     {
@@ -1246,7 +1259,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     float p1a[1][RG];
     dx_zero<1, RG>(p1a);
     if (G1_AHEAD) dxw_single<DXR_P1C, RG>(WP, st + DXS_CTX, lane, p1a);
-    dx_gather<RG, DX_W, true>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
+    dx_gather<RG, DX_W, true, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
     __syncthreads();
     DX_STAMP(10);
     // ================= prenet layer 1 of step t+1 (composite: frame projection folded in, helpers.py:31) and the frame
@@ -1341,7 +1354,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         if (b < a.B) a.dbg[((size_t)t * a.B + b) * a.dbgw + q * DX_W + nn] = st[r * DXS_LD + off + nn];
       }
     }
-    if (t + 1 < a.n) dx_gather<RG, DX_W, false>(X + xl.p1, tag, st, DXS_T, 0, 0, tid, rt);
+    if (t + 1 < a.n) dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.p1, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(11);
   }
