@@ -27,7 +27,7 @@
 // s_sleep units (64 clocks) in front of the first poll of every gather of the backward loop: as in the forward kernel (DX_FIRST_POLL_DELAY), a poll that
 // reaches the L2 ahead of the group's stores costs a second round trip
 #ifndef DB_POLL_DELAY
-#define DB_POLL_DELAY 0
+#define DB_POLL_DELAY 5      // measured on the C4-shard step: 0 -> 12.36 ms, 3 -> 12.32, 5 -> 12.29, 7 -> 12.32 (profiles/r06_ab_poll_delay.txt)
 #endif
 
 // register map (per thread; host mirror: dbx_build_pack in taco_lib.hip).  A 256-input row = 4 registers (inputs 4l..4l+3), a 512-input
