@@ -401,6 +401,7 @@ def main():
     ap.add_argument("--no-stage-timing", action="store_true",
                     help="skip the per-stage timings (roofline.stages): counter passes must see nothing but whole forwards, or their per-forward figures count the extra stage runs")
     ap.add_argument("--decoder-engine", type=int, default=1, help="1 persistent XCD-local decoder (default), 0 launch per stage, 2 persistent write-through")
+    ap.add_argument("--chip-turns", type=int, default=1, help="debug A/B: 0 switches off the per-device ordering of whole-chip kernels across streams (taco_debug_set_chip_turns)")
     ap.add_argument("--cpu-arm", type=int, default=0, help=argparse.SUPPRESS)          # internal: one arm of cpu_baseline() in its own process
     ap.add_argument("--cpu-seed", type=int, default=1234, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=20.0, help=argparse.SUPPRESS)
@@ -467,6 +468,8 @@ def main():
         model._lib.taco_debug_set_overlap(model._handle, args.overlap)
     if args.decoder_engine != 1:
         model.set_decoder_engine(args.decoder_engine)
+    if args.chip_turns != 1:
+        model._lib.taco_debug_set_chip_turns(args.chip_turns)
     rs = np.random.RandomState(seed + 100 * rank)
     ids = rs.randint(2, 80, size=(B, T_in)).astype(np.int32)                   # (strong scaling: every rank draws its own B/N rows)
     ids[:, T_in - 1] = 1                                                       # fixed-length batches

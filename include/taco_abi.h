@@ -99,6 +99,12 @@ int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_in
                      taco_plan** out);
 int taco_plan_launch(taco_plan* p, void* hip_stream);
 int taco_plan_num_nodes(const taco_plan* p);
+/* 1 if the plan contains a whole-chip persistent kernel (the decoder loop or a post-net scan on the persistent engine).  Such kernels need
+ * every compute unit of the device at once; the library puts them -- eager launches and plan replays alike, from any stream or thread of
+ * the process -- in a total order per device (a launch that follows one on another stream waits for an event recorded on that stream), so that
+ * two of them never wait for each other's compute units.
+ * Everything else of a forward still overlaps across streams.  Other processes on the same device are outside its reach. */
+int taco_plan_whole_chip(const taco_plan* p);
 void taco_plan_destroy(taco_plan* p);
 
 /* ---- stage-level entry points (parity tests, profiling) ---- */

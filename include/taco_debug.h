@@ -69,6 +69,10 @@ int taco_debug_decoder_trace(taco_model* m, int enable, long long* out);
  * (their outputs are then meaningless), so that the feed-forward part of a stage can be timed alone (bench.py roofline.stages) */
 int taco_debug_set_skip_scans(taco_model* m, int on);
 
+/* A/B hook: on = 0 switches off the per-device ordering of whole-chip kernels across the streams of this process (taco_plan_whole_chip in
+ * taco_abi.h); two persistent forwards on different streams then starve each other until their bounded spins report a device fault */
+int taco_debug_set_chip_turns(int on);
+
 /* test hook: force the k_gemm tile configuration (0: 128x64, 1: 64x64, 2: 32x64 split-K, 3: 128x128; -1 auto) */
 int taco_debug_force_gemm_config(taco_model* m, int cfg);
 

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "taco_plan_create": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _S, C.POINTER(_P)]),
     "taco_plan_launch": (_I, [_P, _P]),
     "taco_plan_num_nodes": (_I, [_P]),
+    "taco_plan_whole_chip": (_I, [_P]),
     "taco_plan_destroy": (None, [_P]),
     "taco_encoder_forward": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _S]),
     "taco_decoder_forward": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _S]),
@@ -140,6 +141,7 @@ PROTOTYPES = {
     "taco_train_forward_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _S]),
     "taco_debug_force_gemm_config": (_I, [_P, _I]),
     "taco_debug_set_skip_scans": (_I, [_P, _I]),
+    "taco_debug_set_chip_turns": (_I, [_I]),
     "taco_debug_set_front": (_I, [_P, _I, _I]),
     "taco_debug_set_persistent": (_I, [_P, _I]),
     "taco_debug_set_overlap": (_I, [_P, _I]),

@@ -38,6 +38,47 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+// ------------------------------------------------------------------------------------------------
+// one whole-chip kernel at a time per device and process
+// ------------------------------------------------------------------------------------------------
+// The persistent kernels (k_decoder_xcd, k_bigru_oct / duo / xcd and their backward twins) need all 256 workgroups resident at once.  Two of them
+// dispatched to one device together -- two models or plans of ONE process on different streams or threads -- can each end up waiting for compute
+// units the other one holds until their bounded spins expire.  A ChipTurn in the scope of every such launch (and of every replay of a plan that
+// contains one) puts them in a total order: under a per-device mutex, a launch on ANOTHER stream than the previous whole-chip launch first records
+// an event on that previous stream (behind everything enqueued there so far) and makes its own stream wait for it.  Launches that follow each other
+// on one stream -- the serving loop, bench.py -- cost a mutex and a pointer compare, no event (an event record behind every replay was measured:
+// +0.01 ms per C2 forward).  Everything else of a forward still overlaps across streams.  Inside a stream capture nothing is waited for or
+// recorded; the capture is only marked (g_captured_whole_chip), and taco_plan_launch takes the turn for the whole graph.  Other PROCESSES on the
+// device are outside its reach: one process per GPU stays the deployment rule.
+#include <mutex>
+struct ChipTurnState { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool armed = false; };
+static ChipTurnState g_turn[32];
+static int g_chip_turns = 1;                                   // taco_debug_set_chip_turns: 0 switches the ordering off (A/B)
+static thread_local bool g_captured_whole_chip = false;        // a whole-chip launch was captured on this thread since the flag was last cleared
+struct ChipTurn {
+  ChipTurnState* t = nullptr; hipStream_t st;
+  ChipTurn(int device, hipStream_t stream) : st(stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { g_captured_whole_chip = true; return; }
+    (void)hipGetLastError();
+    if (!g_chip_turns || device < 0 || device >= 32) return;
+    t = &g_turn[device];
+    t->mu.lock();
+    if (t->armed && t->last != st) {
+      bool ordered = false;
+      if (t->ev || hipEventCreateWithFlags(&t->ev, hipEventDisableTiming) == hipSuccess)
+        ordered = hipEventRecord(t->ev, t->last) == hipSuccess && hipStreamWaitEvent(st, t->ev, 0) == hipSuccess;
+      if (!ordered) { (void)hipGetLastError(); (void)hipDeviceSynchronize(); }      // the previous stream is gone (destroyed by its owner): its work may still run
+    }
+  }
+  ~ChipTurn() {
+    if (!t) return;
+    t->armed = true; t->last = st;
+    t->mu.unlock();
+  }
+  ChipTurn(const ChipTurn&) = delete; ChipTurn& operator=(const ChipTurn&) = delete;
+};
+
 // Stream-ordered zero fill as a kernel launch.  hipMemsetAsync nodes of a captured graph were seen to fill with a stale 16-byte
 // pattern after another plan of the process had been destroyed (round 2: the census words and the exchange tags of a decoder plan,
 // the BatchNorm sums of a captured train step); a kernel node has no such state.  p 4-byte aligned, bytes a multiple of 4.
@@ -1157,6 +1198,7 @@ static bool duo_usable(const taco_model* m, const Cbhg& c, int B, int T) {
 // both directions of RG rows on one group of 32 CUs, software-pipelined against each other; gsave != null: the TAPE instantiation
 static int duo_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* xproj, const int* lengths, const float* init_state,
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
+  ChipTurn turn(m->device, st);
   GdArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.gd_pack); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
   a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
@@ -1204,6 +1246,7 @@ static int oct_upw(const taco_model* m, const Cbhg& c, int B, int T) {
 static bool oct_bwd_usable(const taco_model* m, const Cbhg& c, int B, int T) { return c.gob_pack && oct_upw(m, c, B, T) != 0; }
 static int oct_bwd_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* dout, const float* out, const float* gsave,
                           const float* h0, const int* lengths, float* dg, float* rh, float* dh0, unsigned long long* gxbuf, unsigned* gxctl) {
+  ChipTurn turn(m->device, st);
   GbArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.gob_pack); a.dout = dout; a.out = out; a.gsave = gsave; a.h0 = h0; a.lengths = lengths; a.dg = dg; a.rh = rh; a.dh0 = dh0;
   a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
@@ -1214,6 +1257,7 @@ static int oct_bwd_launch(const taco_model* m, hipStream_t st, const Cbhg& c, in
 }
 static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UPW, int B, int T, const float* xproj, const int* lengths, const float* init_state,
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
+  ChipTurn turn(m->device, st);
   GdArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.go_pack[UPW == 4 ? 2 : UPW == 2 ? 1 : 0]); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
   a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace && !gsave) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
@@ -1258,6 +1302,7 @@ static int bigru_scan(const taco_model* m, hipStream_t st, const Cbhg& c, int B,
     // waves, one per CU.  persist 9: 512 workgroups of 4 waves, two per CU from independent chains -- measured slower (6088 vs 5224
     // clocks per step at C2): the phases of a step are chains of dependent instructions, a wave alone on its SIMD is no faster
     const int NWV = m->persist == 9 ? 4 : 8, rowgroups = gx_ngroups(NWV) / 2;     // persist 8: round 2's default geometry
+    ChipTurn turn(m->device, st);
     GxArgs a; memset(&a, 0, sizeof a);
     const size_t* pk = NWV == 8 ? c.gx_pack : c.gx_pack4;
     a.wpack0 = AP(m, pk[0]); a.wpack1 = AP(m, pk[1]); a.xproj = w.xproj; a.h0 = init_state; a.lengths = lengths; a.out = out;
@@ -1744,6 +1789,7 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
                      const float* manual, float* mel, float* align_out, float* dbg, int dbgw, const float* keys, int* nz,
                      unsigned long long* xbuf, unsigned* dxctl, float* rowbias, const float* h_att0, const float* h10, const float* h20,
                      const DxArgs* tape = nullptr) {
+  ChipTurn turn(m->device, st);
   const int RG = dx_rows_per_group(m, B);
   DxArgs a; memset(&a, 0, sizeof a);
   if (tape) a = *tape;
@@ -1806,6 +1852,7 @@ static bool dbx_usable(const taco_model* m, int B, int T_in) {
   return db_lds_floats(dx_rows_per_group(m, B), T_in) * sizeof(float) <= 160 * 1024;
 }
 static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int T_in, int n, unsigned long long* xbuf, unsigned* dxctl) {
+  ChipTurn turn(m->device, st);
   const int RG = dx_rows_per_group(m, B);
   a.wpack = AP(m, m->dbx_pack);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
@@ -2662,6 +2709,7 @@ int taco_debug_set_front(taco_model* m, int delay_clocks, int prio) {
   m->front_delay = delay_clocks; m->front_prio = prio;     // k_cbhg_front: start delay and s_setprio level of the second K half (tools/time_front.py)
   return 0;
 }
+int taco_debug_set_chip_turns(int on) { g_chip_turns = on ? 1 : 0; return 0; }
 int taco_debug_set_skip_scans(taco_model* m, int on) {
   if (!m) return fail(TACO_ERR_ARG, "null model");
   m->skip_scans = on ? 1 : 0;
@@ -2705,6 +2753,7 @@ struct taco_plan {
   hipGraphExec_t exec = nullptr;
   size_t nodes = 0;
   int device = 0;
+  bool whole_chip = false;      // the graph contains a whole-chip persistent kernel: a replay takes the device's turn (ChipTurn)
 };
 
 int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_input_lengths, const int32_t* d_speaker_id,
@@ -2716,15 +2765,17 @@ int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_in
   HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
   hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) { (void)hipStreamDestroy(cs); return fail(TACO_ERR_HIP, "hipStreamBeginCapture: %s", hipGetErrorString(e)); }
+  g_captured_whole_chip = false;
   int rc = forward_enqueue(m, cs, d_inputs, d_input_lengths, d_speaker_id, B, T_in, n_steps, d_manual_alignments, d_mel,
                            d_linear, d_alignments, d_stop_step, d_workspace, workspace_bytes);
+  const bool whole_chip = g_captured_whole_chip;
   hipGraph_t g = nullptr;
   e = hipStreamEndCapture(cs, &g);
   (void)hipStreamDestroy(cs);
   if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
   if (e != hipSuccess) return fail(TACO_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
   taco_plan* p = new taco_plan();
-  p->graph = g; p->device = m->device;
+  p->graph = g; p->device = m->device; p->whole_chip = whole_chip;
   e = hipGraphInstantiate(&p->exec, g, nullptr, nullptr, 0);
   if (e != hipSuccess) { (void)hipGraphDestroy(g); delete p; return fail(TACO_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
   (void)hipGraphGetNodes(g, nullptr, &p->nodes);
@@ -2734,10 +2785,16 @@ int taco_plan_create(taco_model* m, const int32_t* d_inputs, const int32_t* d_in
 
 int taco_plan_launch(taco_plan* p, void* hip_stream) {
   if (!p || !p->exec) return fail(TACO_ERR_ARG, "null plan");
+  if (p->whole_chip) {
+    ChipTurn turn(p->device, (hipStream_t)hip_stream);
+    HIPCHK(hipGraphLaunch(p->exec, (hipStream_t)hip_stream));
+    return 0;
+  }
   HIPCHK(hipGraphLaunch(p->exec, (hipStream_t)hip_stream));
   return 0;
 }
 int taco_plan_num_nodes(const taco_plan* p) { return p ? (int)p->nodes : 0; }
+int taco_plan_whole_chip(const taco_plan* p) { return (p && p->whole_chip) ? 1 : 0; }
 void taco_plan_destroy(taco_plan* p) {
   if (!p) return;
   if (p->exec) (void)hipGraphExecDestroy(p->exec);

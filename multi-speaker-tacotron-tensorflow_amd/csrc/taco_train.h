@@ -635,6 +635,7 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     TRY(oct_bwd_launch(m, st, c, B, T, dout, w.out, w.gsave, h0, lengths, w.dg, w.rh, dh0, w.gxbuf, w.gxctl));
   } else if (duo_bwd) {
     // both directions of RG rows per group of 32 CUs, the directions software-pipelined against each other (k_bigru_duo_bwd)
+    ChipTurn turn(m->device, st);
     GbArgs a; memset(&a, 0, sizeof a);
     a.wpack = AP(m, c.gb_pack); a.dout = dout; a.out = w.out; a.gsave = w.gsave; a.h0 = h0; a.lengths = lengths; a.dg = w.dg; a.rh = w.rh; a.dh0 = dh0;
     a.xbuf = w.gxbuf; a.ctl = w.gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;

@@ -110,11 +110,12 @@ class PlanPool(object):
     """`lanes` independent forwards of one shape in flight, each with its own hipGraph plan, buffers and
     HIP stream.
 
-    Two engines, two ways to use the chip (DESIGN.md 3.3).  The persistent engine (one whole-chip launch for the decoder loop, one
-    for the post-net scan) finishes a C2 forward in 3.6 ms but owns every CU while it runs: forwards of different lanes cannot
-    overlap, and two whole-chip kernels dispatched together can starve each other (the placement census then times out into the
-    slow protocol or raises a device error).  The launch-per-stage engine leaves most CUs idle per forward (8.6 ms alone) and is
-    the one several lanes can fill (4 lanes: 3.1 ms per forward).  `engine="auto"` therefore captures the plans of a one-lane pool
+    Two engines, two ways to use the chip (DESIGN.md 3.6).  The persistent engine (one whole-chip launch for the decoder loop, one
+    for the post-net scan) finishes a C2 forward in 2.7 ms but owns every CU while those two kernels run: the library keeps the
+    whole-chip kernels of a process in a total order per device (`taco_plan_whole_chip`, an event wait in front of a replay and an
+    event record behind it), so forwards of different lanes on this engine take turns -- correct from any number of streams and
+    threads, but with nothing gained over one lane.  The launch-per-stage engine leaves most CUs idle per forward (8.6 ms alone) and
+    is the one several lanes can fill (4 lanes: 2.9 ms per forward).  `engine="auto"` therefore captures the plans of a one-lane pool
     with the model's current engine and the plans of a multi-lane pool with the launch-per-stage engine; "persistent" / "launch"
     force one.  The model object is read-only during a forward, so lanes share it.
 
