@@ -561,6 +561,9 @@ __device__ __forceinline__ void go_reduce(const float (&v)[UPW * NG], float (&ou
 #ifndef GO_REQ2
 #define GO_REQ2 1          // A/B (tools/scratch): 0 = no second, mid-phase request
 #endif
+// (Round 6, measured at C2 on top of the two requests, post-net alone 1.155 ms: without the second request 1.203; a sleep of 2 / 4 units in front of the fallback
+// poll 1.171-1.191 / 1.219-1.225 -- so about one collect in four does fall through to the poll; a THIRD request behind the phase's reduction, checked
+// only by the lanes whose first two answers were stale, 1.243-1.263: the load in front of the publish store delays the store.  Left as it is.)
 #ifndef GO_DYN
 #define GO_DYN 0           // A/B: 1 = the protocol test of every publish and the tracer test of every stamp at run time, as in k_bigru_duo / k_decoder_xcd
 #endif
