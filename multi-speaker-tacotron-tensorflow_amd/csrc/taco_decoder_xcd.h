@@ -513,11 +513,22 @@ struct DxRt {     // run-time state of a thread
 };
 // WTC: the protocol as a compile-time constant (0: XCD-local, 1: write-through) where the kernel body is instantiated per protocol -- the
 // run-time test (-1) costs a branch per publish, ~30 clocks each on the chain (round 5: 11 % of a post-net scan step, measured)
+// DX_PUB_MODE (A/B, tools/ubench_mfma_stage): how an XCD-local granule leaves the lane.  0 (default): global_store_dwordx2 sc0; 1: a workgroup-scope
+// atomic swap whose result is dropped (executed at the L2); 2: a non-temporal store; 3: a plain store
+#ifndef DX_PUB_MODE
+#define DX_PUB_MODE 0
+#endif
+__device__ __forceinline__ void dx_store_local(dx_gu64* p, unsigned long long g) {
+  if (DX_PUB_MODE == 1) (void)__hip_atomic_exchange(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else if (DX_PUB_MODE == 2) __builtin_nontemporal_store(g, p);
+  else if (DX_PUB_MODE == 3) *p = g;
+  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // sc0: stays in this XCD's L2
+}
 template <int WTC = -1>
 __device__ __forceinline__ void dx_publish(dx_gu64* p, float v, unsigned tag, const DxRt& rt) {
   const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
   if (WTC == 1 || (WTC < 0 && rt.wt)) __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // sc1: write-through, any placement
-  else __hip_atomic_store(p, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);           // sc0: stays in this XCD's L2
+  else dx_store_local(p, g);
 }
 // N granules of one lane at once (p + u*stride): ONE uniform branch on the protocol around all stores, so that the epilogue that
 // produced the values stays a single basic block (a branch per value kept the compiler from interleaving the exp/rcp chains of
@@ -532,7 +543,7 @@ __device__ __forceinline__ void dx_publish_n(dx_gu64* p, int stride, const float
     for (int u = 0; u < N; ++u) __hip_atomic_store(p + u * stride, g[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
 #pragma unroll
-    for (int u = 0; u < N; ++u) __hip_atomic_store(p + u * stride, g[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int u = 0; u < N; ++u) dx_store_local(p + u * stride, g[u]);
   }
 }
 // keeps a value's computation where it is written (LLVM otherwise sinks an expensive operand of a select into a branch)
