@@ -221,6 +221,13 @@ int taco_train_set_deterministic(taco_train* t, int on);
  * six products per tile, fp32 accumulation (k_wgrad_bf3: fp32-grade, ~2^-24 per product); on = 1 keeps them on the
  * exact-fp32 MFMA (k_wgrad, round 1).  Process-wide A/B and test hook. */
 int taco_train_set_exact_wgrad(taco_train* t, int on);
+/* Split-bf16 weight gradients from PRE-SPLIT operands (csrc/taco_wgrad_planes.h): mode 1 (default) converts the operands of the large
+ * problems -- a whole conv bank, proj_1, the linear head -- once into bf16 planes and multiplies them with a kernel that converts
+ * nothing; mode 2 sends every eligible problem that way (test hook); mode 0 keeps all of them on k_wgrad_bf3.  Same six products, same
+ * fixed summation order per slice.  Changing 0 <-> non-zero changes taco_train_workspace_bytes. */
+int taco_train_set_wgrad_planes(taco_train* t, int mode);
+/* How many weight gradients of the last taco_train_forward_backward were computed from pre-split planes (a conv bank counts once). */
+int taco_train_planes_problems(const taco_train* t);
 /* Feed-forward GEMMs of the training step (both CBHGs' conv banks / projections / highways / GRU input projections, encoder prenet,
  * linear head) and their data gradients.  k_gemm = exact-fp32 MFMA; k_gemm_bf3 = the inference kernels: bf16 matrix cores, both
  * operands split in two, three products per tile (~2^-17 per product, fp32 accumulation), weight planes re-split on the device from

@@ -134,6 +134,8 @@ PROTOTYPES = {
     "taco_train_set_sync_bn": (_I, [_P, _P, _P, _I]),
     "taco_train_set_deterministic": (_I, [_P, _I]),
     "taco_train_set_exact_wgrad": (_I, [_P, _I]),
+    "taco_train_set_wgrad_planes": (_I, [_P, _I]),
+    "taco_train_planes_problems": (_I, [_P]),
     "taco_train_set_bptt_engine": (_I, [_P, _I]),
     "taco_train_set_exact_gemm": (_I, [_P, _I]),
     "taco_train_debug_bigru": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _S]),

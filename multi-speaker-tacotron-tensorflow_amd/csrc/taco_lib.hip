@@ -10,6 +10,7 @@
 #include "taco_head.h"
 #include "taco_train_kernels.h"
 #include "taco_backward_kernels.h"
+#include "taco_wgrad_planes.h"
 #include "taco_decoder_bwd_xcd.h"
 #include "../../include/taco_abi.h"
 #include "../../include/taco_debug.h"

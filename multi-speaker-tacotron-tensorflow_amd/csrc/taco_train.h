@@ -50,8 +50,11 @@ struct taco_train {
   int sync_world = 1;
   int resident_bwd_scan = 1;           // the encoder's backward scan with the recurrent kernels in registers (k_bigru_resb); 0 (with taco_train_set_bptt_engine(t, 0)): k_bigru_rows_bwd
   int bptt_persistent = 1;             // taco_train_set_bptt_engine: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd) where it fits
+  mutable int planes_problems = 0;     // weight gradients of the last backward pass that were computed from pre-split planes (a conv bank counts once)
+  int wgrad_planes = 1;                // taco_train_set_wgrad_planes: 1 = large weight gradients from pre-split bf16 planes (taco_wgrad_planes.h), 2 = every eligible one (tests), 0 = off
   int deterministic = 1;               // taco_train_set_deterministic: ordered two-stage sums (default since round 4) or fp32 atomics; the former needs DET_SCRATCH_FLOATS of workspace
 };
+#define WP_SCRATCH_COLS 2048           // plane scratch: room for (widest conv bank + WP_SCRATCH_COLS) columns of the longest row set, three bf16 planes each
 #define DET_SCRATCH_FLOATS ((size_t)48 << 20)      // 192 MB: e.g. 30 M-slices of the largest weight gradient (post-net proj_1, 3 x 2048 x 256)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -257,6 +260,102 @@ static int run_colsum(hipStream_t st, const float* a, int lda, const float* b, i
   HIPCHK(hipGetLastError());
   return 0;
 }
+// ---- weight gradients from pre-split planes (taco_wgrad_planes.h) ----
+// The operands of a LARGE weight gradient are converted once into bf16 planes (k_wp_split: fragment-major, the tap shifts and their
+// batch-row masks applied to copies of the narrower operand) and multiplied by a kernel that converts nothing (k_wp_gemm).  Measured per
+// problem against k_wgrad_bf3 (tools/ubench_wgrad_planes.hip, profiles/r06_ubench_wgrad_planes.txt): the conversion pass is bound by
+// its 10 bytes per element, so it pays where an element meets many products -- post-net proj_1 (542 -> 382 us), the linear head
+// (365 -> 208), a whole conv bank as ONE product launch over one conversion of its dz (post-net: ~1240 -> ~330) -- and loses on
+// 256 x 256-sized problems (highway, GRU kernels, the decoder's hoisted gradients), which stay on k_wgrad_bf3.
+static thread_local int g_wgrad_planes = 1;            // installed from the trainer for the duration of a step (EngineGuard)
+struct WpScratch { uint4* p = nullptr; size_t cap = 0; };
+static thread_local WpScratch g_wps;
+static thread_local int g_wp_count = 0;               // problems of the step in flight that took this path
+#define WP_MIN_MACS 3.0e9                               // mode 1: problems below this many multiply-adds stay on k_wgrad_bf3
+constexpr int WP_SM = 1, WP_NB = 3;                    // 16-row stages, ring of three: 72 KB of LDS, two workgroups per CU
+static int wp_gemm_launch(hipStream_t st, const WpGemmArgs& g, dim3 grid) {
+  constexpr size_t lds = (size_t)WP_NB * 24 * WP_SM * 1024;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)k_wp_gemm<WP_SM, WP_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  HIPCHK(attr);
+  hipLaunchKernelGGL((k_wp_gemm<WP_SM, WP_NB>), grid, dim3(256), lds, st, g);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+static int wp_rows_per_slice(int Mp, long tiles, size_t per) {      // ~768 workgroups; in deterministic mode the slices' partial tiles must fit the scratch
+  int rpb = Mp;
+  while (rpb > 256 && tiles * cdiv(Mp, rpb) < 768) rpb >>= 1;
+  rpb = cdiv(rpb, 16 * WP_SM) * 16 * WP_SM;
+  if (g_det.p) while ((size_t)cdiv(Mp, rpb) * per > g_det.cap && rpb < Mp) rpb *= 2;
+  return rpb;
+}
+static void wp_split_launch(hipStream_t st, const float* src, const int* gather, int ld, int M, int T, int C, int Mp, int ncopy, int sigma0, int dsigma, uint4* out) {
+  WpSplitArgs a; a.src = src; a.gather = gather; a.out = out; a.ld = ld; a.M = M; a.T = T; a.C = C; a.Mp = Mp; a.ncopy = ncopy; a.sigma0 = sigma0; a.dsigma = dsigma;
+  hipLaunchKernelGGL(k_wp_split, dim3(cdiv(cdiv(C, 32), 4), Mp / 64, ncopy), dim3(256), 0, st, a);
+}
+// one weight gradient (the arguments of run_wgrad); handled = false: not eligible, nothing was launched
+static int run_wgrad_planes(hipStream_t st, const float* x, const int* gather, int ldx, const float* dy, int ldy, float* dw, int lddw,
+                            int M, int T, int K, int N, int kw, int padl, bool& handled) {
+  handled = false;
+  if (!g_wgrad_planes || !g_wps.p) return 0;
+  if (g_wgrad_planes == 1 && (double)M * K * N * kw < WP_MIN_MACS) return 0;
+  const bool shifted = kw > 1 || padl != 0;
+  if (shifted && (gather || T <= 0)) return 0;
+  const int Mp = cdiv(M, 64) * 64;
+  const bool a_per_tap = K <= N;            // the narrower operand carries the tap copies
+  const size_t na = wp_plane_uint4(K, Mp, a_per_tap ? kw : 1), nb = wp_plane_uint4(N, Mp, a_per_tap ? 1 : kw);
+  const size_t per = (size_t)kw * K * N;
+  if (na + nb > g_wps.cap || (g_det.p && per > g_det.cap)) return 0;
+  uint4* pa = g_wps.p; uint4* pb = g_wps.p + na;
+  // dW[tap] = sum_m X[m + s] dY[m], s = tap - padl: either X carries the shift s, or dY carries -s (m' = m + s)
+  wp_split_launch(st, x, gather, ldx, M, T, K, Mp, a_per_tap ? kw : 1, (shifted && a_per_tap) ? -padl : 0, a_per_tap ? 1 : 0, pa);
+  wp_split_launch(st, dy, nullptr, ldy, M, T, N, Mp, a_per_tap ? 1 : kw, (shifted && !a_per_tap) ? padl : 0, a_per_tap ? 0 : -1, pb);
+  WpGemmArgs g; memset(&g, 0, sizeof g);
+  g.a = pa; g.b = pb; g.K = K; g.N = N; g.Mp = Mp; g.kw = kw; g.a_per_tap = a_per_tap ? 1 : 0; g.dw = dw; g.lddw = lddw; g.nw = 0;
+  const long tiles = (long)cdiv(K, 128) * cdiv(N, 128) * kw;
+  g.rpb = wp_rows_per_slice(Mp, tiles, per);
+  g.part = g_det.p;
+  const int nsplit = cdiv(Mp, g.rpb);
+  TRY(wp_gemm_launch(st, g, dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit)));
+  if (g.part) hipLaunchKernelGGL(k_wgrad_reduce, EWGRID(per), 0, st, (const float*)g.part, nsplit, kw, K, N, dw, lddw);
+  HIPCHK(hipGetLastError());
+  handled = true; ++g_wp_count;
+  return 0;
+}
+// ALL widths 1 .. nw of a conv bank (dz of every width complete in dY [M, nw * Cw]): one conversion of dz, nw shifted copies of the
+// bank's input, one product launch, one ordered sum per width (a group launch).  dwk[k - 1] = the kernel gradient of width k [k][K][Cw].
+static int run_wgrad_bank_planes(hipStream_t st, const float* x, int ldx, const float* dY, int ldy, float* const* dwk, int M, int T, int K, int Cw, int nw, bool& handled) {
+  handled = false;
+  if (!g_wgrad_planes || !g_wps.p || nw < 2 || nw > WP_MAXW || (Cw & 31) || T <= 0) return 0;
+  const int ntap = nw * (nw + 1) / 2;
+  if (g_wgrad_planes == 1 && (double)M * K * Cw * ntap < WP_MIN_MACS) return 0;
+  const int Mp = cdiv(M, 64) * 64;
+  const size_t na = wp_plane_uint4(K, Mp, nw), nb = wp_plane_uint4(nw * Cw, Mp, 1);
+  const size_t per = (size_t)ntap * K * Cw;
+  if (na + nb > g_wps.cap || (g_det.p && per > g_det.cap) || nw > WG_MAXP) return 0;
+  uint4* pa = g_wps.p; uint4* pb = g_wps.p + na;
+  wp_split_launch(st, x, nullptr, ldx, M, T, K, Mp, nw, -((nw - 1) / 2), 1, pa);       // copy j: shift j - (nw - 1) / 2; width k, tap: shift tap - (k - 1) / 2
+  wp_split_launch(st, dY, nullptr, ldy, M, T, nw * Cw, Mp, 1, 0, 0, pb);
+  WpGemmArgs g; memset(&g, 0, sizeof g);
+  g.a = pa; g.b = pb; g.K = K; g.N = Cw; g.Mp = Mp; g.kw = 1; g.a_per_tap = 1; g.lddw = Cw; g.nw = nw;
+  const long tiles = (long)cdiv(K, 128) * cdiv(Cw, 128) * ntap;
+  g.rpb = wp_rows_per_slice(Mp, tiles, per);
+  g.part = g_det.p;
+  const int nsplit = cdiv(Mp, g.rpb);
+  size_t off = 0;
+  for (int k = 1; k <= nw; ++k) { g.dwk[k - 1] = dwk[k - 1]; g.part_off[k - 1] = (unsigned)off; off += (size_t)nsplit * k * K * Cw; }
+  TRY(wp_gemm_launch(st, g, dim3(cdiv(K, 128), cdiv(Cw, 128), ntap * nsplit)));
+  if (g.part) {
+    WgRedGroup R; R.n = 0; R.start[0] = 0;
+    for (int k = 1; k <= nw; ++k) {
+      R.p[R.n].part = g.part + g.part_off[k - 1]; R.p[R.n].dw = dwk[k - 1]; R.p[R.n].nsplit = nsplit; R.p[R.n].kw = k; R.p[R.n].K = K; R.p[R.n].N = Cw; R.p[R.n].lddw = Cw;
+      R.start[R.n + 1] = R.start[R.n] + cdiv(k * K * Cw, 256); ++R.n;
+    }
+    hipLaunchKernelGGL(k_wgrad_reduce_group, dim3(R.start[R.n]), dim3(256), 0, st, R);
+  }
+  HIPCHK(hipGetLastError());
+  handled = true; ++g_wp_count;
+  return 0;
+}
 // 1 (default): weight gradients on the bf16 matrix cores with operands split three ways and six products per tile (k_wgrad_bf3:
 // fp32-grade); 0: exact-fp32 MFMA (k_wgrad).  taco_train_set_exact_wgrad.
 static thread_local int g_wgrad_bf3 = 1;     // installed from the trainer for the duration of a step (EngineGuard)
@@ -265,6 +364,11 @@ static int run_wgrad(hipStream_t st, const float* x, const int* gather, int ldx,
   WgArgs g; g.ygather = ygather; g.x = x; g.gather = gather; g.dy = dy; g.dw = dw; g.ldx = ldx; g.ldy = ldy; g.lddw = lddw; g.M = M; g.T = T; g.K = K; g.N = N;
   g.kw = kw; g.padl = padl;
   const bool bf3 = g_wgrad_bf3 != 0;
+  if (bf3 && !ygather) {                     // large problems: from pre-split planes
+    bool handled = false;
+    TRY(run_wgrad_planes(st, x, gather, ldx, dy, ldy, dw, lddw, M, T, K, N, kw, padl, handled));
+    if (handled) return 0;
+  }
   // split-bf16 kernel: 128 x 128 tiles (4 waves) when those alone give a few hundred workgroups, else 64 x 64 tiles (1 wave): every
   // M-slice a workgroup takes ends in one atomic per output element, so slices are kept LONG (>= 256 rows where the grid allows)
   const long t128 = (long)cdiv(K, 128) * cdiv(N, 128) * kw, t64 = (long)cdiv(K, 64) * cdiv(N, 64) * kw;
@@ -412,6 +516,7 @@ struct TrainWs {
   SpkWs spk; float* dvec[8]; float* dspk_emb; float* dzs; int* rowidx;   // deepvoice: speaker vectors, their gradients, scratch
   float *linrv, *dlin_sum;                                               // simple: speaker term of the linear head [B, F], time-summed dlin
   float* detscr;                                                         // deterministic reductions: per-slice partial sums
+  uint4* wpscr; size_t wps_uint4;                                        // bf16 planes of the weight gradients' operands (taco_wgrad_planes.h)
 };
 static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n, TrainWs& w) {
   const taco_model* m = t->sm;
@@ -435,6 +540,10 @@ static void carve_train(Carver& cv, const taco_train* t, int B, int T_in, int n,
   const size_t nrv = is_simple(m) ? (size_t)B * hp.num_freq : 1;
   w.linrv = cv.f(nrv); w.dlin_sum = cv.f(nrv);
   w.detscr = cv.f(t->deterministic ? DET_SCRATCH_FLOATS : 1);
+  { const size_t rows = (size_t)cdiv((int)std::max(Me, Mp), 64) * 64;
+    const size_t cols = (size_t)std::max(hp.enc_bank_size * hp.enc_bank_channels, hp.post_bank_size * hp.post_bank_channels) + WP_SCRATCH_COLS;
+    w.wps_uint4 = t->wgrad_planes ? rows / 16 * (cols / 32) * 3 * 64 : 1;
+    w.wpscr = (uint4*)cv.raw(w.wps_uint4 * sizeof(uint4)); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -765,11 +874,17 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
       bank_dz = true;
     }
   }
+  bool bank_wg = false;                 // every width's kernel gradient from ONE conversion of dz and one product launch (taco_wgrad_planes.h)
+  if (bank_dz && g_wgrad_bf3 && !in_gather && (int)c.bank.size() <= WP_MAXW) {
+    float* dwk[WP_MAXW];
+    for (size_t bi = 0; bi < c.bank.size(); ++bi) dwk[c.bank[bi].kw - 1] = x.g(sc + "/conv_bank/conv1d_" + std::to_string(c.bank[bi].kw) + "/kernel");
+    TRY(run_wgrad_bank_planes(st, in, c.in_dim, w.dbig0, KC, dwk, M, T, c.in_dim, c.C, c.K, bank_wg));
+  }
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
     const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k);
     TRY(conv_bn_backward_apply(x, n, w.bank_a + c0, KC, w.dbig1 + c0, KC, w.bank_mu + c0, w.bank_rs + c0, true, w.dbig0 + c0, KC, M, c.C, w.stat, c0, KC, bank_dz));
-    TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
+    if (!bank_wg) TRY(run_wgrad(st, in, in_gather, c.in_dim, w.dbig0 + c0, KC, x.g(n + "/kernel"), c.C, M, T, c.in_dim, c.C, k, (k - 1) / 2));
     TRY(run_dgrad(m, st, ct.bank_d[bi], w.dbig0 + c0, KC, M, T, din, c.in_dim, din, c.in_dim));   // accumulates onto the residual path
   }
   return 0;
@@ -1084,9 +1199,9 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
   if (n > hp.max_iters) return fail(TACO_ERR_SHAPE, "T_out/r = %d exceeds max_iters %d", n, hp.max_iters);
   TRY(check_common(m, B, T_in));
   struct EngineGuard {  // the GEMM helpers see this trainer's engine switches for the duration of this step only
-    int w, d, e;
-    EngineGuard(const taco_train* t) : w(g_wgrad_bf3), d(g_dgrad_bf3), e(g_dgrad_exact) { g_wgrad_bf3 = t->wgrad_bf3; g_dgrad_bf3 = t->dgrad_bf3; g_dgrad_exact = t->dgrad_exact; }
-    ~EngineGuard() { g_wgrad_bf3 = w; g_dgrad_bf3 = d; g_dgrad_exact = e; }
+    int w, d, e, p;
+    EngineGuard(const taco_train* t) : w(g_wgrad_bf3), d(g_dgrad_bf3), e(g_dgrad_exact), p(g_wgrad_planes) { g_wgrad_bf3 = t->wgrad_bf3; g_dgrad_bf3 = t->dgrad_bf3; g_dgrad_exact = t->dgrad_exact; g_wgrad_planes = t->wgrad_planes; }
+    ~EngineGuard() { g_wgrad_bf3 = w; g_dgrad_bf3 = d; g_dgrad_exact = e; g_wgrad_planes = p; }
   } engine_guard(t);
   if ((m->bf3 || m->bf3x6 || g_dgrad_bf3) && !t->bf3_current) return fail(TACO_ERR_STATE, "taco_train_set_exact_gemm(0) needs a taco_train_refresh before the next step (the split-bf16 weight planes are stale)");
   Carver cv(ws, ws_bytes);
@@ -1097,6 +1212,11 @@ static int train_forward_backward(taco_train* t, hipStream_t st, float* P, float
     DetGuard(float* p, size_t cap) { g_det.p = p; g_det.cap = cap; }
     ~DetGuard() { g_det.p = nullptr; g_det.cap = 0; }
   } det_guard(t->deterministic ? w.detscr : nullptr, t->deterministic ? DET_SCRATCH_FLOATS : 0);
+  struct WpGuard {      // the plane scratch of the weight gradients, for the duration of this step only
+    const taco_train* t;
+    WpGuard(const taco_train* t_, uint4* p, size_t cap) : t(t_) { g_wps.p = p; g_wps.cap = cap; g_wp_count = 0; }
+    ~WpGuard() { g_wps.p = nullptr; g_wps.cap = 0; t->planes_problems = g_wp_count; }
+  } wp_guard(t, t->wgrad_planes ? w.wpscr : nullptr, t->wgrad_planes ? w.wps_uint4 : 0);
   const int Me = B * T_in, Mp = B * T_out;
   // ---- forward ----
   const float* cur = x.p("embedding"); int curd = hp.embedding_size;

@@ -135,6 +135,19 @@ class Trainer(object):
         if getattr(self, "_graph", None) is not None:
             self._graph = None
 
+    def set_wgrad_planes(self, mode=1):
+        """Split-bf16 weight gradients from pre-split operands (csrc/taco_wgrad_planes.h): 1 (default) = the large problems (a whole conv
+        bank, proj_1, the linear head) convert their operands once into bf16 planes and multiply them with a kernel that converts nothing;
+        2 = every eligible problem (test hook); 0 = all on k_wgrad_bf3 (the step before round 6's second half)."""
+        _lib.check(self._lib.taco_train_set_wgrad_planes(self._h, int(mode)))
+        self._ws = self._ws_eager = None       # the workspace size changes
+        if getattr(self, "_graph", None) is not None:
+            self._graph = None
+
+    def planes_problems(self):
+        """Weight gradients of the last backward pass that were computed from pre-split planes (a conv bank counts once)."""
+        return int(self._lib.taco_train_planes_problems(self._h))
+
     # ---- engines ----
     def set_decoder_engine(self, mode=1):
         """1 (default): at the reference widths the teacher-forced decoder loop and the post-net scan of the forward run as the

@@ -946,3 +946,48 @@ def test_C4_shard_gradients_at_32_rows_against_the_committed_autograd_fixture():
     print("C4 shard, B = 32: worst sampled element error / tensor scale, norm error:", worst[:4])
     assert worst[0][0] < 2e-3 and max(w[1] for w in worst) < 2e-3, worst[:5]
     tr.close()
+
+
+@pytest.mark.parametrize("wide,B,T_in,T_out,atype", [(True, 4, 16, 32, "bah_mon"), (True, 3, 21, 100, "bah"), (True, 5, 37, 44, "bah_mon"),
+                                                     (False, 3, 9, 12, "bah_mon"), (False, 5, 13, 23, "bah_norm")])
+def test_weight_gradients_from_pre_split_planes_equal_the_in_kernel_split(wide, B, T_in, T_out, atype):
+    """csrc/taco_wgrad_planes.h (round 6): the operands of a weight gradient converted ONCE into bf16 planes (fragment-major, the conv
+    taps' shifts and batch-row masks applied to copies of the narrower operand; a whole conv bank as one product launch) give the
+    gradients of k_wgrad_bf3, which converts inside the product loop -- same three-way split, same six products, fp32 sums in another
+    slice order.  Mode 2 sends EVERY eligible problem through the planes (mode 1, the default, only the large ones: at these test sizes
+    none), so every shape class is covered: odd widths (1025 bins, 80 mels, the scaled model's 8 / 36), row counts that are not
+    multiples of 64, taps across batch-row boundaries at lengths that are not multiples of 16, +-1-step shifts of the recurrent kernels.
+    Both engines are also held to the float64 autograd."""
+    import torch
+    if wide:
+        hp = O.OracleHParams(max_iters=max(16, T_out // 4), attention_type=atype)
+        w = O.init_weights(hp, 1, 41)
+        ids, L = O.synthetic_inputs(B, T_in, 42, ragged=True)
+        rs = np.random.RandomState(43)
+        mt, lt = rs.rand(B, T_out, hp.num_mels), rs.rand(B, T_out, hp.num_freq)
+        co = rs.uniform(0.5, 1.5, size=B)
+    else:
+        hp, w, ids, L, mt, lt, co = _setup(atype, B=B, T_in=T_in, T_out=T_out)
+    tr = _trainer(hp, w)
+    got, count = {}, {}
+    for mode in (0, 2, 1):
+        tr.set_wgrad_planes(mode)
+        tr.forward_backward(ids, L, mt, lt, co)
+        torch.cuda.synchronize()
+        got[mode] = tr.grad_dict()
+        count[mode] = tr.planes_problems()
+    print("weight gradients from pre-split planes: mode 0 -> %d, mode 2 -> %d, mode 1 -> %d problems" % (count[0], count[2], count[1]))
+    assert count[0] == 0 and count[1] == 0 and count[2] >= 40       # (both conv banks, proj_1 / proj_2, highways, GRU kernels, head, decoder)
+    gn = max(float(np.abs(v).max()) for v in got[0].values())
+    worst = sorted(((maxabs(got[2][k], got[0][k]) / max(float(np.abs(got[0][k]).max()), 1e-3 * gn), k) for k in got[0]), reverse=True)
+    print("planes (every eligible problem) vs in-kernel split, relative per tensor, worst three:", worst[:3])
+    assert worst[0][0] < 2e-5, worst[:5]
+    moved = [k for k in got[0] if not np.array_equal(got[2][k], got[0][k])]      # (one slice on both paths = the same order of the same products)
+    print("%d of %d gradient tensors took another summation order" % (len(moved), len(got[0])))
+    for k in got[0]:       # the default mode at these sizes: nothing is large enough, bit-identical to mode 0
+        assert np.array_equal(got[1][k], got[0][k]), k
+    loss, g, _ = TF.train_grads(w, hp, ids, L, mt, lt, co)
+    rep, _ = _grad_report(got[2], g)
+    tol = 3e-3 if B * T_out <= 200 else 5e-2       # (the L1 sign flips of test_gradients_at_full_reference_widths)
+    assert rep[0][0] < tol, rep[:5]
+    tr.close()

@@ -28,6 +28,8 @@ def measure(args):
         tr.set_exact_gemm(args.exact_gemm)
     if args.exact_wgrad:
         tr.set_exact_wgrad(True)
+    if args.wgrad_planes != 1:
+        tr.set_wgrad_planes(args.wgrad_planes)
     tr.set_deterministic(bool(args.deterministic))
     rs = np.random.RandomState(77 + rank)
     B, T_in, T_out = args.batch, args.t_in, args.t_out
@@ -86,7 +88,7 @@ def measure(args):
                        "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact", 4: "forward bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients bf16 MFMA with operands split in two (3 products)"}[args.exact_gemm],
                        "backward_scans": ("post-net: k_bigru_oct_bwd (one row per cluster of 8 CUs) from 9 to 32 rows, else k_bigru_duo_bwd; encoder: k_bigru_resb (recurrent kernels in registers)"
                                           if args.engine and engine["protocol"] and args.bptt else "k_bigru_rows_bwd (round 1's kernel: A/B engine)"),
-                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)",
+                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)" + ("; conv banks, proj_1 and the linear head from pre-split planes" if args.wgrad_planes == 1 else "; every eligible problem from pre-split planes" if args.wgrad_planes == 2 else ""),
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
             "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9})
@@ -134,6 +136,7 @@ def main():
     ap.add_argument("--engine", type=int, default=1, help="1: persistent whole-chip kernels for the teacher-forced decoder loop and the post-net scans (default); 0: one launch per stage (rounds 1-2)")
     ap.add_argument("--bptt", type=int, default=1, help="1: the decoder's BPTT as one persistent launch (k_decoder_bwd_xcd; default); 0: the chain of per-stage launches")
     ap.add_argument("--exact-gemm", type=int, default=4, help="4 (default): forward on the six-product split (fp32-grade), data gradients split-bf16; 3: forward GEMMs on the exact-fp32 MFMA (k_gemm), data gradients on the split-bf16 kernels (k_gemm_bf3); 1: everything exact; 0: everything split-bf16; 4: forward on the six-product split (fp32-grade), data gradients split-bf16")
+    ap.add_argument("--wgrad-planes", type=int, default=1, help="split-bf16 weight gradients from pre-split operands: 1 the large problems (default), 2 every eligible one, 0 none (k_wgrad_bf3 only)")
     ap.add_argument("--exact-wgrad", type=int, default=0, help="1: weight gradients on the exact-fp32 MFMA (k_wgrad) instead of the split-bf16 kernel")
     ap.add_argument("--deterministic", type=int, default=1, help="1 (the library's default): ordered two-stage sums, bit-reproducible steps; 0: fp32 atomics")
     ap.add_argument("--sync-bn", type=int, default=0, help="1: BatchNorm statistics over the global batch (12 small all-reduces per step: one per BatchNorm layer forward, one per layer or conv bank backward); "
