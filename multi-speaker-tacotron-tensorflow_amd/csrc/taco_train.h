@@ -272,14 +272,21 @@ struct WpScratch { uint4* p = nullptr; size_t cap = 0; };
 static thread_local WpScratch g_wps;
 static thread_local int g_wp_count = 0;               // problems of the step in flight that took this path
 #define WP_MIN_MACS 3.0e9                               // mode 1: problems below this many multiply-adds stay on k_wgrad_bf3
-constexpr int WP_SM = 1, WP_NB = 3;                    // 16-row stages, ring of three: 72 KB of LDS, two workgroups per CU
-static int wp_gemm_launch(hipStream_t st, const WpGemmArgs& g, dim3 grid) {
-  constexpr size_t lds = (size_t)WP_NB * 24 * WP_SM * 1024;
-  static const hipError_t attr = hipFuncSetAttribute((const void*)k_wp_gemm<WP_SM, WP_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+constexpr int WP_SM = 1, WP_NB = 3;                    // 16-row stages, ring of three
+template <int WK, int WN>
+static int wp_gemm_launch_t(hipStream_t st, const WpGemmArgs& g, int z) {
+  constexpr size_t lds = (size_t)WP_NB * 3 * 2 * (WK + WN) * WP_SM * 1024;
+  static const hipError_t attr = hipFuncSetAttribute((const void*)k_wp_gemm<WK, WN, WP_SM, WP_NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   HIPCHK(attr);
-  hipLaunchKernelGGL((k_wp_gemm<WP_SM, WP_NB>), grid, dim3(256), lds, st, g);
+  hipLaunchKernelGGL((k_wp_gemm<WK, WN, WP_SM, WP_NB>), dim3(cdiv(g.K, 64 * WK), cdiv(g.N, 64 * WN), z), dim3(64 * WK * WN), lds, st, g);
   HIPCHK(hipGetLastError());
   return 0;
+}
+// workgroup tile (k x n): 128 x 128 (four waves, 72 KB of LDS, two workgroups per CU)
+static void wp_tile(int K, int N, int& tk, int& tn) { (void)K; (void)N; tk = 128; tn = 128; }
+static int wp_gemm_launch(hipStream_t st, const WpGemmArgs& g, int tk, int tn, int z) {
+  if (tk == 128 && tn == 128) return wp_gemm_launch_t<2, 2>(st, g, z);
+  return fail(TACO_ERR_STATE, "no k_wp_gemm instantiation for a %d x %d tile", tk, tn);
 }
 static int wp_rows_per_slice(int Mp, long tiles, size_t per) {      // ~768 workgroups; in deterministic mode the slices' partial tiles must fit the scratch
   int rpb = Mp;
@@ -311,11 +318,12 @@ static int run_wgrad_planes(hipStream_t st, const float* x, const int* gather, i
   wp_split_launch(st, dy, nullptr, ldy, M, T, N, Mp, a_per_tap ? 1 : kw, (shifted && !a_per_tap) ? padl : 0, a_per_tap ? 0 : -1, pb);
   WpGemmArgs g; memset(&g, 0, sizeof g);
   g.a = pa; g.b = pb; g.K = K; g.N = N; g.Mp = Mp; g.kw = kw; g.a_per_tap = a_per_tap ? 1 : 0; g.dw = dw; g.lddw = lddw; g.nw = 0;
-  const long tiles = (long)cdiv(K, 128) * cdiv(N, 128) * kw;
+  int tk, tn; wp_tile(K, N, tk, tn);
+  const long tiles = (long)cdiv(K, tk) * cdiv(N, tn) * kw;
   g.rpb = wp_rows_per_slice(Mp, tiles, per);
   g.part = g_det.p;
   const int nsplit = cdiv(Mp, g.rpb);
-  TRY(wp_gemm_launch(st, g, dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit)));
+  TRY(wp_gemm_launch(st, g, tk, tn, kw * nsplit));
   if (g.part) hipLaunchKernelGGL(k_wgrad_reduce, EWGRID(per), 0, st, (const float*)g.part, nsplit, kw, K, N, dw, lddw);
   HIPCHK(hipGetLastError());
   handled = true; ++g_wp_count;
@@ -337,13 +345,14 @@ static int run_wgrad_bank_planes(hipStream_t st, const float* x, int ldx, const 
   wp_split_launch(st, dY, nullptr, ldy, M, T, nw * Cw, Mp, 1, 0, 0, pb);
   WpGemmArgs g; memset(&g, 0, sizeof g);
   g.a = pa; g.b = pb; g.K = K; g.N = Cw; g.Mp = Mp; g.kw = 1; g.a_per_tap = 1; g.lddw = Cw; g.nw = nw;
-  const long tiles = (long)cdiv(K, 128) * cdiv(Cw, 128) * ntap;
+  int tk, tn; wp_tile(K, Cw, tk, tn);
+  const long tiles = (long)cdiv(K, tk) * cdiv(Cw, tn) * ntap;
   g.rpb = wp_rows_per_slice(Mp, tiles, per);
   g.part = g_det.p;
   const int nsplit = cdiv(Mp, g.rpb);
   size_t off = 0;
   for (int k = 1; k <= nw; ++k) { g.dwk[k - 1] = dwk[k - 1]; g.part_off[k - 1] = (unsigned)off; off += (size_t)nsplit * k * K * Cw; }
-  TRY(wp_gemm_launch(st, g, dim3(cdiv(K, 128), cdiv(Cw, 128), ntap * nsplit)));
+  TRY(wp_gemm_launch(st, g, tk, tn, ntap * nsplit));
   if (g.part) {
     WgRedGroup R; R.n = 0; R.start[0] = 0;
     for (int k = 1; k <= nw; ++k) {

@@ -9,7 +9,7 @@
 //                is 1 KB = 64 lanes x 16 bytes, lane (i = c % 32, h = (m % 16) / 8) holding rows ms * 16 + 8 h .. + 7 of column c --
 //                exactly the A / B operand of v_mfma_f32_32x32x16_bf16 when the contraction runs over rows.  Blocks of one (plane, ct)
 //                are consecutive in ms: a product workgroup streams 1 KB blocks.
-//   k_wp_gemm    dW[tap][k][n] = sum over m of X[m + tap - padl][k] dY[m][n]: a 128 x 128 (k x n) tile per workgroup of four waves
+//   k_wp_gemm    dW[tap][k][n] = sum over m of X[m + tap - padl][k] dY[m][n]: a (64 WK) x (64 WN) (k x n) tile per workgroup of WK x WN waves
 //                (64 x 64 per wave: 2 x 2 MFMA tiles, six products per tile pair as in k_wgrad_bf3 -- lo*hi, hi*lo, mid*mid, mid*hi,
 //                hi*mid, hi*hi), over an M-slice.  Blocks go from global memory STRAIGHT INTO LDS (global_load_lds_dwordx4: the
 //                block order in memory is the lane order of the load) through a ring of stages; a lane's fragment is one
@@ -72,18 +72,23 @@ struct WpGemmArgs {
 };
 typedef __attribute__((address_space(3))) unsigned char wp_lds_byte;
 
-// SM = row chunks (of 16) per stage, NB = stages in the ring.  LDS per stage: 2 operands x 3 planes x 4 column tiles x SM KB.
-template <int SM, int NB>
-__global__ __launch_bounds__(256) void k_wp_gemm(const WpGemmArgs g) {
+// WK x WN waves, each a 64 x 64 block of the (64 WK) x (64 WN) workgroup tile; SM = row chunks (of 16) per stage, NB = stages in the
+// ring.  LDS per stage: 3 planes x 2 (WK + WN) column tiles x SM KB, as 1 KB blocks [operand][plane][column tile][chunk]; block j of a
+// stage is fetched by wave j mod (WK WN).
+template <int WK, int WN, int SM, int NB>
+__global__ __launch_bounds__(64 * WK * WN) void k_wp_gemm(const WpGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char wp_smem[];
-  constexpr int CH = 24 * SM;               // 1 KB blocks per stage: [operand 2][plane 3][ct 4][ms SM]
-  constexpr int LPW = CH / 4;               // LDS-direct loads per wave and stage
+  static_assert(NB >= 2 && NB <= 4, "the counted waits below know one or two later stages in flight");
+  constexpr int NWV = WK * WN, TA = 2 * WK, TB = 2 * WN;
+  constexpr int CHA = 3 * TA * SM, CH = 3 * (TA + TB) * SM;      // 1 KB blocks of a stage: X part, whole stage
+  constexpr int LPW = (CH + NWV - 1) / NWV;                    // LDS-direct loads per wave and stage: LPW, or LPW - 1 for waves >= CH % NWV
+  constexpr int NFULL = CH % NWV == 0 ? NWV : CH % NWV;        // waves that issue LPW loads
   constexpr unsigned STAGE = CH * 1024u;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wk = wave >> 1, wn = wave & 1;
+  const int wk = wave / WN, wn = wave - wk * WN;
   const int i = lane & 31, h = lane >> 5;
   const int nsplit = (g.Mp + g.rpb - 1) / g.rpb;
-  int tap, sp, kwid = 0, CTB = (g.N + 31) / 32, ctb0 = blockIdx.y * 4, ctb_end;
+  int tap, sp, kwid = 0, CTB = (g.N + 31) / 32, ctb0 = blockIdx.y * TB, ctb_end;
   size_t acopy, bcopy;
   if (g.nw > 0) {                           // bank mode (wave-uniform: everything below comes from blockIdx and the arguments)
     const int ntap = g.nw * (g.nw + 1) / 2;
@@ -100,23 +105,28 @@ __global__ __launch_bounds__(256) void k_wp_gemm(const WpGemmArgs g) {
     ctb_end = CTB;
   }
   const int CTA = (g.K + 31) / 32, MS = g.Mp / 16;
-  const int cta0 = blockIdx.x * 4;
+  const int cta0 = blockIdx.x * TA;
   const int ms0 = sp * (g.rpb / 16), ms1 = min(MS, ms0 + g.rpb / 16);
   const int nst = (ms1 - ms0 + SM - 1) / SM;
   const uint4* abase = g.a + acopy * 3 * CTA * MS * 64 + lane;
   const uint4* bbase = g.b + bcopy * 3 * CTB * MS * 64 + lane;
   const unsigned lds0 = (unsigned)(size_t)(wp_lds_byte*)wp_smem;
+  const bool fullw = wave < NFULL;          // (wave-uniform)
 
-  auto issue = [&](int s, int buf) {        // this wave's LPW blocks of stage s into ring slot buf
+  auto issue = [&](int s, int buf) {        // this wave's blocks of stage s into ring slot buf
 #pragma unroll
     for (int u = 0; u < LPW; ++u) {
-      const int j = wave * LPW + u;                       // block of the stage (wave-uniform)
-      const int op = j / (12 * SM), r = j - op * 12 * SM;
-      const int p = r / (4 * SM), r2 = r - p * 4 * SM, ctl = r2 / SM, q = r2 - ctl * SM;
-      const int msq = min(ms0 + s * SM + q, MS - 1);      // (a chunk past the slice's end is re-read and never used)
+      const int j = wave + u * NWV;                       // block of the stage (wave-uniform)
+      if (u == LPW - 1 && !fullw) break;
+      const int msq0 = ms0 + s * SM;
       const uint4* src;
-      if (op == 0) src = abase + ((size_t)(p * CTA + min(cta0 + ctl, CTA - 1)) * MS + msq) * 64;
-      else src = bbase + ((size_t)(p * CTB + min(ctb0 + ctl, ctb_end - 1)) * MS + msq) * 64;
+      if (j < CHA) {
+        const int p = j / (TA * SM), r2 = j - p * TA * SM, ctl = r2 / SM, q = r2 - ctl * SM;
+        src = abase + ((size_t)(p * CTA + min(cta0 + ctl, CTA - 1)) * MS + min(msq0 + q, MS - 1)) * 64;      // (a chunk past the slice's end is re-read and never used)
+      } else {
+        const int r = j - CHA, p = r / (TB * SM), r2 = r - p * TB * SM, ctl = r2 / SM, q = r2 - ctl * SM;
+        src = bbase + ((size_t)(p * CTB + min(ctb0 + ctl, ctb_end - 1)) * MS + min(msq0 + q, MS - 1)) * 64;
+      }
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * STAGE + (unsigned)j * 1024u);
       gx_load_lds16(reinterpret_cast<const float*>(src), dst);
     }
@@ -135,8 +145,8 @@ __global__ __launch_bounds__(256) void k_wp_gemm(const WpGemmArgs g) {
   for (int s = 0; s < nst; ++s) {
     // stage s has landed for this wave when at most the loads of the later stages in flight remain
     const int later = min(nst - 1 - s, NB - 2);
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory");
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory");
+    if (later >= 2) { if (fullw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (LPW - 1)) : "memory"); }
+    else if (later == 1) { if (fullw) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPW - 1) : "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();          // every wave's blocks of stage s are in LDS; every wave is done with stage s - 1
     if (s + NB - 1 < nst) issue(s + NB - 1, (s + NB - 1) % NB);
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(256) void k_wp_gemm(const WpGemmArgs g) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-          af[t][p] = *reinterpret_cast<const bf16x8*>(st + ((size_t)((0 * 3 + p) * 4 + 2 * wk + t) * SM + q) * 1024 + lane * 16);
-          bf[t][p] = *reinterpret_cast<const bf16x8*>(st + ((size_t)((1 * 3 + p) * 4 + 2 * wn + t) * SM + q) * 1024 + lane * 16);
+          af[t][p] = *reinterpret_cast<const bf16x8*>(st + ((size_t)(p * TA + 2 * wk + t) * SM + q) * 1024 + lane * 16);
+          bf[t][p] = *reinterpret_cast<const bf16x8*>(st + (size_t)CHA * 1024 + ((size_t)(p * TB + 2 * wn + t) * SM + q) * 1024 + lane * 16);
         }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void k_wp_gemm(const WpGemmArgs g) {
         }
     }
   }
-  const int kb = blockIdx.x * 128 + wk * 64, nb = blockIdx.y * 128 + wn * 64;
+  const int kb = blockIdx.x * 64 * WK + wk * 64, nb = blockIdx.y * 64 * WN + wn * 64;
   float* out;
   if (g.nw > 0) out = g.part ? g.part + g.part_off[kwid - 1] + ((size_t)sp * kwid + tap) * g.K * g.N : g.dwk[kwid - 1] + (size_t)tap * g.K * g.lddw;
   else out = g.part ? g.part + ((size_t)sp * g.kw + tap) * g.K * g.N : g.dw + (size_t)tap * g.K * g.lddw;

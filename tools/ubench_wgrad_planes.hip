@@ -10,30 +10,34 @@
 #include <cmath>
 #include <vector>
 #include <random>
+#include <cstring>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 struct Shape { const char* name; int M, T, K, N, kw, padl; };
 
-template <int SM, int NB>
-static int launch_gemm(const WpGemmArgs& g, dim3 grid, hipStream_t st) {
-  const size_t lds = (size_t)NB * 24 * SM * 1024;
+template <int WK, int WN, int SM, int NB>
+static int launch_gemm(const WpGemmArgs& g, int kw_nsplit, hipStream_t st) {
+  const size_t lds = (size_t)NB * 3 * 2 * (WK + WN) * SM * 1024;
   static bool set = false;
-  if (!set) { CK(hipFuncSetAttribute((const void*)k_wp_gemm<SM, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
-  hipLaunchKernelGGL((k_wp_gemm<SM, NB>), grid, dim3(256), lds, st, g);
+  if (!set) { CK(hipFuncSetAttribute((const void*)k_wp_gemm<WK, WN, SM, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; }
+  hipLaunchKernelGGL((k_wp_gemm<WK, WN, SM, NB>), dim3(cdiv(g.K, 64 * WK), cdiv(g.N, 64 * WN), kw_nsplit), dim3(64 * WK * WN), lds, st, g);
   return 0;
 }
-static int launch_cfg(int cfg, const WpGemmArgs& g, dim3 grid, hipStream_t st) {
+struct Cfg { const char* name; int tk, tn, sm; };
+static const Cfg cfgs[] = {{"128 x 128, 16 rows x 3 (72 KB)", 128, 128, 1}, {"256 x 128, 16 rows x 3 (108 KB)", 256, 128, 1}, {"128 x 256, 16 rows x 3 (108 KB)", 128, 256, 1},
+                           {"256 x 256, 16 rows x 3 (144 KB)", 256, 256, 1}, {"256 x 128, 32 rows x 2 (144 KB)", 256, 128, 2}, {"256 x 256, 16 rows x 2 (96 KB)", 256, 256, 1}};
+static int launch_cfg(int cfg, const WpGemmArgs& g, int z, hipStream_t st) {
   switch (cfg) {
-    case 0: return launch_gemm<1, 2>(g, grid, st);
-    case 1: return launch_gemm<1, 3>(g, grid, st);
-    case 2: return launch_gemm<1, 4>(g, grid, st);
-    case 3: return launch_gemm<2, 2>(g, grid, st);
-    case 4: return launch_gemm<2, 3>(g, grid, st);
+    case 0: return launch_gemm<2, 2, 1, 3>(g, z, st);
+    case 1: return launch_gemm<4, 2, 1, 3>(g, z, st);
+    case 2: return launch_gemm<2, 4, 1, 3>(g, z, st);
+    case 3: return launch_gemm<4, 4, 1, 3>(g, z, st);
+    case 4: return launch_gemm<4, 2, 2, 2>(g, z, st);
+    case 5: return launch_gemm<4, 4, 1, 2>(g, z, st);
   }
   return 1;
 }
-static const char* cfg_name[] = {"16 rows x 2 (48 KB)", "16 rows x 3 (72 KB)", "16 rows x 4 (96 KB)", "32 rows x 2 (96 KB)", "32 rows x 3 (144 KB)"};
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
@@ -97,8 +101,7 @@ int main(int argc, char** argv) {
     sa.ncopy = na; sa.sigma0 = (shifted && a_per_tap) ? -s.padl : 0; sa.dsigma = a_per_tap ? 1 : 0;
     WpSplitArgs sb; sb.src = dyv; sb.gather = nullptr; sb.out = pb; sb.ld = N; sb.M = M; sb.T = s.T; sb.C = N; sb.Mp = Mp;
     sb.ncopy = nbc; sb.sigma0 = (shifted && !a_per_tap) ? s.padl : 0; sb.dsigma = a_per_tap ? 0 : -1;
-    WpGemmArgs gg; gg.a = pa; gg.b = pb; gg.K = K; gg.N = N; gg.Mp = Mp; gg.kw = kw; gg.a_per_tap = a_per_tap ? 1 : 0; gg.part = part; gg.dw = dw_new; gg.lddw = N;
-    const long tiles = (long)cdiv(K, 128) * cdiv(N, 128) * kw;
+    WpGemmArgs gg; memset(&gg, 0, sizeof gg); gg.a = pa; gg.b = pb; gg.K = K; gg.N = N; gg.Mp = Mp; gg.kw = kw; gg.a_per_tap = a_per_tap ? 1 : 0; gg.part = part; gg.dw = dw_new; gg.lddw = N;
     printf("%-38s M %5d  today %8.1f us (%s, %d slices)\n", s.name, M, ms_old * 1e3, big ? "128-tile" : "64-tile", nsplit_old);
     // double-precision sample
     std::vector<int> si(512); std::vector<double> ref(512);
@@ -116,9 +119,10 @@ int main(int argc, char** argv) {
     double eo = 0, scale = 0;
     for (int q = 0; q < 512; ++q) { eo = fmax(eo, fabs(ho[si[q]] - ref[q])); scale = fmax(scale, fabs(ref[q])); }
     printf("    today: max |err| %.2e (sample max |dW| %.2e)\n", eo, scale);
-    for (int cfg = 0; cfg < 5; ++cfg) {
-      const int sm = (cfg >= 3) ? 2 : 1;
-      for (int want : {256, 512, 1024}) {
+    for (int cfg = 0; cfg < 6; ++cfg) {
+      const int sm = cfgs[cfg].sm;
+      const long tiles = (long)cdiv(K, cfgs[cfg].tk) * cdiv(N, cfgs[cfg].tn) * kw;
+      for (int want : {384, 768}) {
         int rpb = Mp;
         while (rpb > 256 && tiles * cdiv(Mp, rpb) < want) rpb >>= 1;
         rpb = cdiv(rpb, 16 * sm) * 16 * sm;
@@ -131,7 +135,7 @@ int main(int argc, char** argv) {
             hipLaunchKernelGGL(k_wp_split, dim3(cdiv(cdiv(K, 32), 4), Mp / 64, na), dim3(256), 0, st, sa);
             hipLaunchKernelGGL(k_wp_split, dim3(cdiv(cdiv(N, 32), 4), Mp / 64, nbc), dim3(256), 0, st, sb);
           }
-          launch_cfg(cfg, gg, dim3(cdiv(K, 128), cdiv(N, 128), kw * nsplit), st);
+          launch_cfg(cfg, gg, kw * nsplit, st);
           hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, (const float*)gg.part, nsplit, kw, K, N, dw_new, N);
         };
         run_new(true); CK(hipStreamSynchronize(st)); CK(hipGetLastError());
@@ -145,8 +149,8 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0, st)); for (int r = 0; r < reps; ++r) run_new(false); CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
         CK(hipEventElapsedTime(&ms_gemm, e0, e1)); ms_gemm /= reps;
         const double tf = 12.0 * M * (double)K * N * kw / (ms_gemm * 1e-3) * 1e-12;
-        printf("    planes, stage %-22s %4d slices: split + product + sum %8.1f us, product + sum %8.1f us (%6.1f TF/s bf16)  max |err| %.2e  max |new - today| %.2e\n",
-               cfg_name[cfg], nsplit, ms_all * 1e3, ms_gemm * 1e3, tf, en, dmax);
+        printf("    planes, %-32s %4d slices: split + product + sum %8.1f us, product + sum %8.1f us (%6.1f TF/s bf16)  max |err| %.2e  max |new - today| %.2e\n",
+               cfgs[cfg].name, nsplit, ms_all * 1e3, ms_gemm * 1e3, tf, en, dmax);
       }
     }
     hipFree(dx); hipFree(dyv); hipFree(dw_old); hipFree(dw_new); hipFree(pa); hipFree(pb);
