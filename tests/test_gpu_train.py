@@ -949,7 +949,7 @@ def test_C4_shard_gradients_at_32_rows_against_the_committed_autograd_fixture():
 
 
 @pytest.mark.parametrize("wide,B,T_in,T_out,atype", [(True, 4, 16, 32, "bah_mon"), (True, 3, 21, 100, "bah"), (True, 5, 37, 44, "bah_mon"),
-                                                     (False, 3, 9, 12, "bah_mon"), (False, 5, 13, 23, "bah_norm")])
+                                                     (False, 3, 9, 12, "bah_mon"), (False, 5, 13, 21, "bah_norm")])
 def test_weight_gradients_from_pre_split_planes_equal_the_in_kernel_split(wide, B, T_in, T_out, atype):
     """csrc/taco_wgrad_planes.h (round 6): the operands of a weight gradient converted ONCE into bf16 planes (fragment-major, the conv
     taps' shifts and batch-row masks applied to copies of the narrower operand; a whole conv bank as one product launch) give the
