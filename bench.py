@@ -310,7 +310,7 @@ def train_step_report(steps, warmup, **switches):
     B=32, T_in=128, T_out=512 per GPU, timed by tools/bench_train.py's measure() (ms per step, phase split, engine flags, FLOP roofline)."""
     import argparse as _ap
     ns = _ap.Namespace(steps=steps, warmup=warmup, batch=32, t_in=128, t_out=512, graph=0, engine=1, bptt=1, exact_gemm=4, exact_wgrad=0,
-                       deterministic=1, sync_bn=0)
+                       wgrad_planes=1, deterministic=1, sync_bn=0)
     for k, v in switches.items():
         setattr(ns, k, v)
     return _bench_train_module().measure(ns)

@@ -51,3 +51,20 @@ def test_source_hash_covers_every_kernel_source_and_nothing_else():
     h = bench.source_hash()
     assert len(h) == 16 and int(h, 16) >= 0
     assert bench.source_hash() == h                                          # stable
+
+
+def test_the_train_step_companion_hands_measure_every_switch_it_reads(monkeypatch):
+    """bench.py's `train_step_c4_shard` companion builds the argument namespace of tools/bench_train.py's measure() by hand: a switch
+    added to the tool (round 6: --wgrad-planes) and not to the namespace turned the companion into an error string inside an otherwise
+    healthy bench line.  Every `args.<name>` that measure() reads must be in the namespace."""
+    import os, re, types
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "tools", "bench_train.py")).read()
+    body = src[src.index("def measure(args):"):src.index("\ndef ", src.index("def measure(args):") + 10)]
+    read = set(re.findall(r"\bargs\.([a-z_]+)", body))
+    assert {"steps", "warmup", "batch", "wgrad_planes", "deterministic"} <= read
+    seen = {}
+    monkeypatch.setattr(bench, "_bench_train_module", lambda: types.SimpleNamespace(measure=lambda ns: seen.update(vars(ns)) or {}))
+    bench.train_step_report(2, 1)
+    assert read <= set(seen), sorted(read - set(seen))

@@ -28,7 +28,7 @@ def measure(args):
         tr.set_exact_gemm(args.exact_gemm)
     if args.exact_wgrad:
         tr.set_exact_wgrad(True)
-    if args.wgrad_planes != 1:
+    if getattr(args, "wgrad_planes", 1) != 1:
         tr.set_wgrad_planes(args.wgrad_planes)
     tr.set_deterministic(bool(args.deterministic))
     rs = np.random.RandomState(77 + rank)
@@ -88,7 +88,7 @@ def measure(args):
                        "feed_forward_and_data_gradient_gemms": {3: "forward exact-fp32 MFMA, data gradients bf16 MFMA with operands split in two (3 products)", 1: "exact-fp32 MFMA", 0: "bf16 MFMA, operands split in two (3 products, the inference kernels)", 2: "forward split-bf16, data gradients exact", 4: "forward bf16 MFMA with operands split in three (6 products, fp32-grade), data gradients bf16 MFMA with operands split in two (3 products)"}[args.exact_gemm],
                        "backward_scans": ("post-net: k_bigru_oct_bwd (one row per cluster of 8 CUs) from 9 to 32 rows, else k_bigru_duo_bwd; encoder: k_bigru_resb (recurrent kernels in registers)"
                                           if args.engine and engine["protocol"] and args.bptt else "k_bigru_rows_bwd (round 1's kernel: A/B engine)"),
-                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)" + ("; conv banks, proj_1 and the linear head from pre-split planes" if args.wgrad_planes == 1 else "; every eligible problem from pre-split planes" if args.wgrad_planes == 2 else ""),
+                       "weight_gradients": "exact-fp32 MFMA" if args.exact_wgrad else "bf16 MFMA, operands split three ways (fp32-grade)" + ("; conv banks, proj_1 and the linear head from pre-split planes" if getattr(args, "wgrad_planes", 1) == 1 else "; every eligible problem from pre-split planes" if args.wgrad_planes == 2 else ""),
                        "reductions": "ordered two-stage sums (deterministic)" if args.deterministic else "fp32 atomics"},
             "world_size_seen": world, "sync_bn": bool(sync_bn),
             "loss_without_coeff_first_last": [first, float(l)], "workspace_GB": tr._ws.numel() / 1e9})
