@@ -317,12 +317,27 @@ __global__ __launch_bounds__(256) void k_bn_bwd_v4(const float* a, int lda, cons
 #define BNB_MAXK 16
 struct BnBank { const float* gamma[BNB_MAXK]; const float* beta[BNB_MAXK]; const float* sdy[BNB_MAXK]; const float* sdyxh[BNB_MAXK];
                 float* mov_mean[BNB_MAXK]; float* mov_var[BNB_MAXK]; int Cw; };
-__global__ __launch_bounds__(256) void k_bn_apply_bank_v4(const float* a, int lda, const float* mu, const float* rstd, const BnBank nb, float* y, int ldy, int M, int C) {
+// BatchNorm output of ONE element, in one fixed instruction sequence: the fused forward pool below and the pool's backward pass both
+// recompute it from the bank's activation tape and must pick the same maximum of a window (the BatchNorm output itself is not stored).
+__device__ __forceinline__ float bn_out1(float a, float m, float r, float g, float b) { return __fmaf_rn(__fmul_rn(__fsub_rn(a, m), r), g, b); }
+__device__ __forceinline__ float4 bn_out4(const float4 a, const float4 m, const float4 r, const float4 g, const float4 b) {
+  return make_float4(bn_out1(a.x, m.x, r.x, g.x, b.x), bn_out1(a.y, m.y, r.y, g.y, b.y), bn_out1(a.z, m.z, r.z, g.z, b.z), bn_out1(a.w, m.w, r.w, g.w, b.w));
+}
+// BatchNorm of all widths + max_pooling1d(width w, stride 1, 'same') in one pass over the bank's activations (modules.py:35-47): the pooled
+// tensor is the only output -- the BatchNorm output [B T, K C] is neither written nor read back (round 6: 134 MB less tape at the C4 shard).
+__global__ __launch_bounds__(256) void k_bn_pool_bank_v4(const float* a, int lda, const float* mu, const float* rstd, const BnBank nb, float* pool, int ldp, int M, int T, int C, int w) {
   V4_INDEX(M, C);
   const unsigned k = c / (unsigned)nb.Cw, cl = c - k * nb.Cw;
-  const float4 av = ld4(a + (size_t)m * lda + c), mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(nb.gamma[k] + cl), bv = ldp4(nb.beta[k] + cl);
-  st4(y + (size_t)m * ldy + c, make_float4((av.x - mv.x) * rv.x * gv.x + bv.x, (av.y - mv.y) * rv.y * gv.y + bv.y,
-                                           (av.z - mv.z) * rv.z * gv.z + bv.z, (av.w - mv.w) * rv.w * gv.w + bv.w));
+  const float4 mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(nb.gamma[k] + cl), bv = ldp4(nb.beta[k] + cl);
+  const int t = (int)(m % (unsigned)T), pl = (w - 1) >> 1;
+  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int j = 0; j < w; ++j) {
+    const int tt = t - pl + j;
+    if (tt < 0 || tt >= T) continue;
+    const float4 v = bn_out4(ld4(a + (size_t)((int)m - pl + j) * lda + c), mv, rv, gv, bv);
+    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
+  }
+  st4(pool + (size_t)m * ldp + c, best);
 }
 __global__ __launch_bounds__(256) void k_bn_bwd_bank_v4(const float* a, int lda, const float* dy, int ldy, const float* mu, const float* rstd, const BnBank nb,
                                                        int relu, float* dz, int ldz, int M, int C, float invM) {
@@ -620,20 +635,11 @@ __global__ void k_maxpool_bwd(const float* x, const float* dp, float* dx, int M,
   }
   dx[i] = acc;
 }
-__global__ __launch_bounds__(256) void k_maxpool_fwd_v4(const float* x, float* y, int M, int T, int C, int w) {
+// max_pooling1d's backward pass, four columns per thread, with the pooled tensor's input recomputed from the bank's activations (k_bn_pool_bank_v4 stores no BatchNorm output)
+__global__ __launch_bounds__(256) void k_maxpool_bwd_bn_v4(const float* a, int lda, const float* mu, const float* rstd, const BnBank nb, const float* dp, float* dx, int M, int T, int C, int w) {
   V4_INDEX(M, C);
-  const int t = (int)(m % (unsigned)T), pl = (w - 1) >> 1;
-  float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-  for (int j = 0; j < w; ++j) {
-    const int tt = t - pl + j;
-    if (tt < 0 || tt >= T) continue;
-    const float4 v = ld4(x + (size_t)((int)m - pl + j) * C + c);
-    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
-  }
-  st4(y + (size_t)m * C + c, best);
-}
-__global__ __launch_bounds__(256) void k_maxpool_bwd_v4(const float* x, const float* dp, float* dx, int M, int T, int C, int w) {
-  V4_INDEX(M, C);
+  const unsigned kk = c / (unsigned)nb.Cw, cl = c - kk * nb.Cw;
+  const float4 mv = ldp4(mu + c), rv = ldp4(rstd + c), gv = ldp4(nb.gamma[kk] + cl), bv = ldp4(nb.beta[kk] + cl);
   const int t = (int)(m % (unsigned)T), pl = (w - 1) >> 1;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int tp = t - (w - 1 - pl); tp <= t + pl; ++tp) {      // output positions whose window contains t
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(256) void k_maxpool_bwd_v4(const float* x, const fl
     for (int j = 0; j < w; ++j) {
       const int tt = tp - pl + j;
       if (tt < 0 || tt >= T) continue;
-      const float4 v = ld4(x + (size_t)((int)m + tt - t) * C + c);
+      const float4 v = bn_out4(ld4(a + (size_t)((int)m + tt - t) * lda + c), mv, rv, gv, bv);
       if (v.x > best.x) { best.x = v.x; ax = tt; }
       if (v.y > best.y) { best.y = v.y; ay = tt; }
       if (v.z > best.z) { best.z = v.z; az = tt; }

@@ -437,6 +437,8 @@ static int run_dgrad(const taco_model* m, hipStream_t st, const ConvL& Ld, const
 // ---------------------------------------------------------------------------------------------------------------
 // tape layout
 // ---------------------------------------------------------------------------------------------------------------
+// BatchNorm + max-pool of a conv bank as one pass (k_bn_pool_bank_v4): the widths fit the pointer table and the columns go four at a time
+static inline bool bank_pool_fused(const Cbhg& c) { return c.K <= BNB_MAXK && (c.C & 3) == 0; }
 struct CbhgTape {
   float *bank_a, *bank_y, *pool, *bank_mu, *bank_rs;
   float *pa[4], *py[4], *pmu[4], *prs[4];
@@ -447,7 +449,7 @@ struct CbhgTape {
 };
 static void carve_cbhg_tape(Carver& cv, const Cbhg& c, int B, int T, CbhgTape& w) {
   const size_t M = (size_t)B * T, KC = (size_t)c.K * c.C;
-  w.bank_a = cv.f(M * KC); w.bank_y = cv.f(M * KC); w.pool = cv.f(M * KC); w.bank_mu = cv.f(KC); w.bank_rs = cv.f(KC);
+  w.bank_a = cv.f(M * KC); w.bank_y = cv.f(bank_pool_fused(c) ? 1 : M * KC); w.pool = cv.f(M * KC); w.bank_mu = cv.f(KC); w.bank_rs = cv.f(KC);
   size_t wide = std::max<size_t>(c.in_dim, c.rnn);
   for (int i = 0; i < c.nproj; ++i) {
     w.pa[i] = cv.f(M * c.proj_dim[i]); w.py[i] = cv.f(M * c.proj_dim[i]); w.pmu[i] = cv.f(c.proj_dim[i]); w.prs[i] = cv.f(c.proj_dim[i]);
@@ -621,18 +623,18 @@ static int cbhg_forward_train(const TrainCtx& x, const Cbhg& c, const CbhgT& ct,
     // column block k-1 of the concatenation belongs to conv1d_k (modules.py:35-44)
     for (int k = 1; k <= c.K; ++k) { names.push_back(sc + "/conv_bank/conv1d_" + std::to_string(k)); cols.push_back(c.C); }
     TRY(bn_stats(x, w.bank_a, KC, M, KC, w.bank_mu, w.bank_rs, w.stat, names.data(), cols.data(), c.K));
-    if (c.K <= BNB_MAXK && (c.C & 3) == 0 && al16h(w.bank_a) && al16h(w.bank_y)) {      // all widths in one launch, four columns per thread
+    if (bank_pool_fused(c) && al16h(w.bank_a) && al16h(w.pool)) {      // BatchNorm of all widths + the max-pool in ONE pass: the BatchNorm output is never stored (k_bn_pool_bank_v4)
       BnBank nb; memset(&nb, 0, sizeof nb); nb.Cw = c.C;
       for (int k = 1; k <= c.K; ++k) { nb.gamma[k - 1] = x.p(names[k - 1] + "/gamma"); nb.beta[k - 1] = x.p(names[k - 1] + "/beta"); }
-      hipLaunchKernelGGL(k_bn_apply_bank_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_a, KC, (const float*)w.bank_mu, (const float*)w.bank_rs, nb, w.bank_y, KC, M, KC);
-    } else
+      hipLaunchKernelGGL(k_bn_pool_bank_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_a, KC, (const float*)w.bank_mu, (const float*)w.bank_rs, nb, w.pool, KC, M, T, KC, c.maxpool);
+    } else {
     for (int k = 1; k <= c.K; ++k) {
       const int c0 = (k - 1) * c.C;
       hipLaunchKernelGGL(k_bn_apply, EWGRID((size_t)M * c.C), 0, st, w.bank_a + c0, KC, w.bank_mu + c0, w.bank_rs + c0,
                          x.p(names[k - 1] + "/gamma"), x.p(names[k - 1] + "/beta"), w.bank_y + c0, KC, M, c.C);
+    }
+    hipLaunchKernelGGL(k_maxpool_fwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.pool, M, T, KC, c.maxpool);
     } }
-  if ((KC & 3) == 0 && al16h(w.bank_y) && al16h(w.pool)) hipLaunchKernelGGL(k_maxpool_fwd_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_y, w.pool, M, T, KC, c.maxpool);
-  else hipLaunchKernelGGL(k_maxpool_fwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.pool, M, T, KC, c.maxpool);
   HIPCHK(hipGetLastError());
   const float* cur = w.pool; int curd = KC;
   for (int i = 0; i < c.nproj; ++i) {
@@ -851,8 +853,11 @@ static int cbhg_backward(const TrainCtx& x, const Cbhg& c, const CbhgT& ct, cons
     if (i > 0) { /* dnext == dcur already holds the gradient of py[i-1] */ }
   }
   // ---- maxpool + conv bank ----
-  if ((KC & 3) == 0 && al16h(w.bank_y) && al16h(w.dbig0) && al16h(w.dbig1)) hipLaunchKernelGGL(k_maxpool_bwd_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_y, (const float*)w.dbig0, w.dbig1, M, T, KC, c.maxpool);
-  else hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
+  if (bank_pool_fused(c) && al16h(w.bank_a) && al16h(w.pool)) {      // (the forward's test: the pool's input is recomputed from the bank's activations)
+    BnBank nb; memset(&nb, 0, sizeof nb); nb.Cw = c.C;
+    for (int k = 1; k <= c.K; ++k) { const std::string n = sc + "/conv_bank/conv1d_" + std::to_string(k); nb.gamma[k - 1] = x.p(n + "/gamma"); nb.beta[k - 1] = x.p(n + "/beta"); }
+    hipLaunchKernelGGL(k_maxpool_bwd_bn_v4, EWGRID((size_t)M * KC / 4), 0, st, (const float*)w.bank_a, KC, (const float*)w.bank_mu, (const float*)w.bank_rs, nb, (const float*)w.dbig0, w.dbig1, M, T, KC, c.maxpool);
+  } else hipLaunchKernelGGL(k_maxpool_bwd, EWGRID((size_t)M * KC), 0, st, w.bank_y, w.dbig0, w.dbig1, M, T, KC, c.maxpool);
   HIPCHK(hipGetLastError());
   for (size_t bi = 0; bi < c.bank.size(); ++bi) {     // the bank's BatchNorm sums of all widths, then one exchange for all of them
     const int k = c.bank[bi].kw, c0 = (k - 1) * c.C;
