@@ -633,6 +633,7 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
   // a producer that published late; it is back by the time the phase's reduction and epilogue are done).  256 threads x 8 bytes each: nothing.
   unsigned long long pre = 0ull, pre2 = 0ull;
 
+  // (Round 6, measured: s_setprio 1 for waves 4-7 costs 38 us per C2 scan, for waves 0-3 it changes nothing; profiles/r06_ab_priority.txt.)
   const int tid_outer = tid, lane_outer = lane;
   for (int s = 0; s < T; ++s) {
     const unsigned tag = (unsigned)s + 1u;

@@ -66,6 +66,9 @@ typedef __attribute__((address_space(1))) unsigned dx_gu32;
 #ifndef DX_FIRST_POLL_DELAY
 #define DX_FIRST_POLL_DELAY 5
 #endif
+#ifndef DX_PRIO_OLD
+#define DX_PRIO_OLD 1       // s_setprio level of waves 0-3 (the first wave of every SIMD) for the whole loop; 0: none.  See dx_body.
+#endif
 #ifndef DX_POLL_DELAY_B
 #define DX_POLL_DELAY_B 5
 #endif
@@ -949,6 +952,11 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
   }
   // (accumulators of the passes that run ahead of their stage live across exactly one gather)
 
+  // Static priority for the FIRST wave of every SIMD (waves 0-3; their SIMD partners are waves 4-7): the older wave wins the issue arbitration
+  // by age anyway, with s_setprio 1 it also wins every tie -- the stage's first four columns are published earlier and the vector is complete
+  // sooner.  A/B of variant builds on one box (profiles/r06_ab_priority.txt): decoder alone 1.305 -> 1.289-1.295 ms at levels 1, 2, 3 alike;
+  // priority for the YOUNGER half instead 1.303 (no gain; in the post-net scan it costs 38 us, and the older half gains nothing there).
+  if (DX_PRIO_OLD && wave < 4) __builtin_amdgcn_s_setprio(DX_PRIO_OLD);
   const int tid_outer = tid, lane_outer = lane;
   for (int t = 0; t < a.n; ++t) {
     const unsigned tag = (unsigned)t + 1u;
