@@ -881,14 +881,16 @@ def test_a_restored_checkpoint_continues_the_run_to_the_bit(tmp_path):
         t.close()
 
 
-@pytest.mark.parametrize("persist,bptt,B", [(1, 1, 12), (1, 1, 32), (10, 1, 12), (11, 1, 12), (1, 1, 40), (1, 1, 4), (1, 0, 12)])
-def test_a_poisoned_workspace_does_not_reach_the_gradients(persist, bptt, B):
+@pytest.mark.parametrize("persist,bptt,B,planes", [(1, 1, 12, 1), (1, 1, 32, 1), (10, 1, 12, 1), (11, 1, 12, 1), (1, 1, 40, 1), (1, 1, 4, 1), (1, 0, 12, 1),
+                                                   (1, 1, 12, 2), (1, 1, 37, 2)])
+def test_a_poisoned_workspace_does_not_reach_the_gradients(persist, bptt, B, planes):
     """the zero fills of the post-net scan's gate tape (forward) and of its gate-gradient / r*h buffers (backward) are skipped when
     the scan has no lengths, on the contract that every scan kernel variant writes every element (k_bigru_oct<.., true> / k_bigru_duo<.., true> /
     k_bigru_res, k_bigru_oct_bwd / k_bigru_duo_bwd / k_bigru_rows_bwd).  Enforced here: the whole step workspace is filled with NaN bit
     patterns between two identical steps -- per kernel choice (taco_debug_set_persistent 1 / 10 / 11, rows that select the one-row clusters
     or the 32-CU groups, the per-stage BPTT engine) -- and the second step's losses and gradients must be finite and equal to the first's to
-    the bit (ordered reductions are the default)."""
+    the bit (ordered reductions are the default).  planes = 2 (round 6): every eligible weight gradient from pre-split planes -- the plane
+    scratch (rows padded to 64, columns to 32) is part of the poisoned workspace, and the conv banks' BatchNorm output is no longer stored."""
     import ctypes as C
     import torch
     hp = O.OracleHParams(max_iters=4)
@@ -901,7 +903,10 @@ def test_a_poisoned_workspace_does_not_reach_the_gradients(persist, bptt, B):
     mh = C.c_void_p(tr._lib.taco_train_model(tr._h))
     assert tr._lib.taco_debug_set_persistent(mh, persist) == 0
     tr.set_bptt_engine(bool(bptt))
+    if planes != 1:
+        tr.set_wgrad_planes(planes)
     l1 = tr.forward_backward(ids, L, mt, lt, freeze_moving_averages=True).clone()
+    assert planes != 2 or tr.planes_problems() >= 40
     torch.cuda.synchronize()
     g1 = tr.grads.clone()
     assert bool(torch.isfinite(g1).all()) and bool(torch.isfinite(l1).all())
