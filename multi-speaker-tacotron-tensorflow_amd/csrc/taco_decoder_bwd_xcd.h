@@ -29,6 +29,24 @@
 #ifndef DB_POLL_DELAY
 #define DB_POLL_DELAY 5      // measured on the C4-shard step: 0 -> 12.36 ms, 3 -> 12.32, 5 -> 12.29, 7 -> 12.32 (profiles/r06_ab_poll_delay.txt)
 #endif
+// per-site sleeps as in the forward kernel (DX_DLY): the A/B build -DDX_DLY_RT reads the twelve of this kernel from a second constant table (TACO_DB_DLY).
+// tools/sweep_db_delays.py (profiles/r06_sweep_db_delays.txt; the measure is the traced step length): 30 388 clocks per step with every site at 5,
+// 29 600-29 700 with the three sites whose curves are clear -- the d q partials (falls monotonically to 0), the d alpha partials, d z2 -- moved; the
+// other nine are flat within the noise around 4-6 and keep 5.  DB_DLY_TUNED = 0 restores DB_POLL_DELAY everywhere.
+#ifndef DB_DLY_TUNED
+#define DB_DLY_TUNED 1
+#endif
+__host__ __device__ constexpr int db_site_delay(int site) {
+  //                      dcp2 dgp2 dcp1 dgp1 do0 dctx da dq dcpa dgpa dz2 dz1
+  constexpr int tuned[12] = {5, 5, 5, 5, 5, 5, 1, 0, 5, 5, 2, 5};
+  return DB_DLY_TUNED ? tuned[site] : DB_POLL_DELAY;
+}
+#ifdef DX_DLY_RT
+__constant__ int g_db_dly[16];
+#define DB_DLY(site) (100 + (site))
+#else
+#define DB_DLY(site) db_site_delay(site)
+#endif
 
 // register map (per thread; host mirror: dbx_build_pack in taco_lib.hip).  A 256-input row = 4 registers (inputs 4l..4l+3), a 512-input
 // row = 8 (two halves), a 128-input row = 2.  (The frame projection's data gradient d o2 = dmel . Wf^T does not depend on the
@@ -376,7 +394,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcp2, 256, q, en, dcp); DB_OUT(a.g_dgp2, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(0)>(X + xl.dcp2, tag, st, DBS_DCP2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(1);
     // a cell's parts 'b' and 'c' as two stages; CX/CH/GX/GH: register bases, VC/VG: LDS vectors, XG: gate-gradient exchange
@@ -399,7 +417,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
     float dhp[RL];
     // ================= GRU 2 'b' =================
     DB_CELL_B(DBR_C2X, DBR_C2H, DBS_DCP2, xl.dgp2, (z2 ? 0.f : OWN(OW_H2P, q)), OWN(OW_R2, q), OWN(OW_U2, q), dhp, a.g_dgp2)
-    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_DLY(1)>(X + xl.dgp2, tag, st, DBS_DGP2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(2);
     // ================= GRU 2 'c' -> residual -> GRU 1 'a' =================
@@ -421,12 +439,12 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcp1, 256, q, en, dcp); DB_OUT(a.g_dgp1, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(2)>(X + xl.dcp1, tag, st, DBS_DCP1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(3);
     // ================= GRU 1 'b' =================
     DB_CELL_B(DBR_C1X, DBR_C1H, DBS_DCP1, xl.dgp1, (z1 ? 0.f : OWN(OW_H1P, q)), OWN(OW_R1, q), OWN(OW_U1, q), dhp, a.g_dgp1)
-    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_DLY(3)>(X + xl.dgp1, tag, st, DBS_DGP1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(4);
     // ================= GRU 1 'c' -> d o0 =================
@@ -444,7 +462,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_do0, 256, q, en, do0);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(4)>(X + xl.do0, tag, st, DBS_DO0, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(5);
     // ================= concat projection^T: d h_att (kept), d ctx -> exchange =================
@@ -463,7 +481,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dctx, 256, q, en, dc);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(5)>(X + xl.dctx, tag, st, DBS_DCTX, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(6);
     // ================= attention backward of the member's row =================
@@ -487,7 +505,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         float s = 0.f;
         if (j < T && (Pr >= 4 || part < Pr)) {
           float v[NPQ];
-          dx_poll<NPQ, DB_POLL_DELAY>(X + xl.da + (size_t)(arow * Pr + (Pr >= 4 ? part * NPQ : part)) * T + j, (size_t)T, tag, v, rt);
+          dx_poll<NPQ, DB_DLY(6)>(X + xl.da + (size_t)(arow * Pr + (Pr >= 4 ? part * NPQ : part)) * T + j, (size_t)T, tag, v, rt);
 #pragma unroll
           for (int u = 0; u < NPQ; ++u) s += v[u];
         }
@@ -589,7 +607,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         if (i < RG * 256) {
           const int r = i / 256, c = i % 256;
           float v[Pp];
-          dx_poll<Pp, DB_POLL_DELAY>(X + xl.dq + (size_t)(r * Pp) * 256 + c, (size_t)256, tag, v, rt);
+          dx_poll<Pp, DB_DLY(7)>(X + xl.dq + (size_t)(r * Pp) * 256 + c, (size_t)256, tag, v, rt);
           float s = 0.f;
 #pragma unroll
           for (int k = 0; k < Pp; ++k) s += v[k];
@@ -616,12 +634,12 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dcpA, 256, q, en, dcp); DB_OUT(a.g_dgpA, 512, q, 256 + en, dgu[q]);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(8)>(X + xl.dcpa, tag, st, DBS_DCPA, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(10);
     // ================= attention GRU 'b' (the x part has 128 inputs: rows 4m + w of waves 0-3) =================
     DB_CELL_B(DBR_CAX, DBR_CAH, DBS_DCPA, xl.dgpa, (zA ? 0.f : OWN(OW_HAP, q)), OWN(OW_RA, q), OWN(OW_UA, q), dhp, a.g_dgpA)
-    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
+    dx_gather<RG, 512, false, DBS_LD, DX_NT, DB_DLY(9)>(X + xl.dgpa, tag, st, DBS_DGPA, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(11);
     // ================= attention GRU 'c' -> d p2 (ReLU mask) =================
@@ -641,7 +659,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         }
       }
     }
-    dx_gather<RG, 128, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
+    dx_gather<RG, 128, false, DBS_LD, DX_NT, DB_DLY(10)>(X + xl.dz2, tag, st, DBS_DZ2, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(12);
     // ================= prenet layer 2^T, ReLU mask of layer 1 =================
@@ -661,7 +679,7 @@ __device__ __forceinline__ void db_body(const DbArgs& a, float* dx_smem, int gro
         DB_OUT(a.g_dz1, 256, q, en, dz1);
       }
     }
-    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_POLL_DELAY>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
+    dx_gather<RG, 256, false, DBS_LD, DX_NT, DB_DLY(11)>(X + xl.dz1, tag, st, DBS_DZ1, 0, 0, tid, rt);
     __syncthreads();
     DB_STAMP(13);
     // ================= prenet layer 1 (context rows)^T: the gradient of context(t - 1) =================
@@ -705,6 +723,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_bwd_xcd(const DbArgs a_in) {
   const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
   const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
   DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+#ifdef DX_DLY_RT
+  for (int i = 0; i < 12; ++i) rt.dly[i] = g_db_dly[i];
+#endif
   if (__builtin_amdgcn_readfirstlane((int)rt.wt)) db_body<RG, true, TRACE>(a, dx_smem, group, member, rt);
   else db_body<RG, false, TRACE>(a, dx_smem, group, member, rt);
 }

@@ -511,9 +511,41 @@ __device__ __forceinline__ void dxs_reduce(const float (&a)[NC][RG], float (&out
   }
 }
 
+// A/B build -DDX_DLY_RT (tools/sweep_dx_delays.py): the sleep in front of every gather's first poll comes from a constant table that the host
+// fills from TACO_DX_DLY before each launch, so that one build sweeps all ten gathers; the production build has the per-site immediates.
+// Round 6, last: ONE build with the eleven sleeps in a constant table (-DDX_DLY_RT) and a coordinate descent over them on the decoder stage alone
+// (tools/sweep_dx_delays.py, profiles/r06_sweep_dx_delays.txt: three passes, every site at 0..9 units, 3 x 20 launches per point) moved the
+// stage from 1330 us (all sites at 5) to 1275 us per call: the gathers behind a SHORT producer phase want no sleep at all (the partial scores,
+// the context, r*h of GRU 2, the next step's prenet 1: their curves fall monotonically to 0), the others stay at 4-6.  DX_DLY_TUNED = 0
+// restores the two classes above for every site.
+#ifndef DX_DLY_TUNED
+#define DX_DLY_TUNED 1
+#endif
+__host__ __device__ constexpr int dx_site_delay(int site, int dflt) {
+  //                      p2 p3 rha ha sc ctx rh1 h1 rh2 h2 p1
+  constexpr int tuned[11] = {4, 5, 6, 5, 0, 0, 5, 5, 0, 4, 0};
+  return DX_DLY_TUNED ? tuned[site] : dflt;
+}
+#ifdef DX_DLY_RT
+__constant__ int g_dx_dly[16];
+#define DX_DLY(site, dflt) (100 + (site))
+#else
+#define DX_DLY(site, dflt) dx_site_delay(site, dflt)
+#endif
 struct DxRt {     // run-time state of a thread
   dx_gu32* err; bool wt; bool dead;
+#ifdef DX_DLY_RT
+  int dly[12];
+#endif
 };
+template <int DLY>
+__device__ __forceinline__ void dx_first_poll_sleep(const DxRt& rt) {
+#ifdef DX_DLY_RT
+  if constexpr (DLY >= 100) { const int n = __builtin_amdgcn_readfirstlane(rt.dly[DLY - 100]); for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); return; }
+#endif
+  if constexpr (DLY > 0 && DLY < 100) __builtin_amdgcn_s_sleep(DLY);
+  (void)rt;
+}
 // WTC: the protocol as a compile-time constant (0: XCD-local, 1: write-through) where the kernel body is instantiated per protocol -- the
 // run-time test (-1) costs a branch per publish, ~30 clocks each on the chain (round 5: 11 % of a post-net scan step, measured)
 // DX_PUB_MODE (A/B, tools/ubench_mfma_stage): how an XCD-local granule leaves the lane.  0 (default): global_store_dwordx2 sc0; 1: a workgroup-scope
@@ -559,7 +591,7 @@ __device__ __forceinline__ void dx_poll(const dx_gu64* p0, size_t stride, unsign
   // C2 -- the extra L2 requests of 16 K pollers delay the very stores they are waiting for)
   unsigned long long g[N];
   unsigned spins = 0;
-  if (DLY) __builtin_amdgcn_s_sleep(DLY);
+  dx_first_poll_sleep<DLY>(rt);
   for (;;) {
     bool ok = true;
 #pragma unroll
@@ -589,7 +621,7 @@ template <int NP, int DLY = 0>
 __device__ __forceinline__ void dx_poll_pairs(const dx_gu64* p0, size_t stride, unsigned tag, float (&v)[2 * NP], DxRt& rt) {
   dx_u64x2 g[NP];
   unsigned spins = 0;
-  if (DLY) __builtin_amdgcn_s_sleep(DLY);
+  dx_first_poll_sleep<DLY>(rt);
   for (;;) {
     bool ok = true;
 #pragma unroll
@@ -1000,7 +1032,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     dxq_zero<RG>(ag01);
     dx_zero<1, RG>(ag2);
     dxw_pair<DXR_AGH, RG>(WP, st + DXS_HATT, lane, ag01);
-    dx_gather<RG, DX_P2, false, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
+    dx_gather<RG, DX_P2, false, DXS_LD, DX_NT, DX_DLY(0, DX_POLL_DELAY_B)>(X + xl.p2, tag, st, DXS_P2, 0, 0, tid, rt);
     __syncthreads();
     if constexpr (PD == 3) {
       // ================= prenet layer 3 (64 columns, two per member); its output takes the OUT2 slot, dead until the end of the step =================
@@ -1015,7 +1047,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
             dx_publish<WTC>(X + xl.p3 + erow[q] * DX_P3 + member * 2 + wave, fmaxf(s[0][q] + bl[DXB_P3 * DX_NW + wave], 0.f), tag, rt);
         }
       }
-      dx_gather<RG, DX_P3, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
+      dx_gather<RG, DX_P3, false, DXS_LD, DX_NT, DX_DLY(1, DX_FIRST_POLL_DELAY)>(X + xl.p3, tag, st, DXS_OUT2, 0, 0, tid, rt);
       __syncthreads();
     }
     DX_STAMP(1);
@@ -1037,7 +1069,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         DX_TAPE(DXT_RA, q, rg); DX_TAPE(DXT_UA, q, g_u[q]); DX_TAPE(DXT_RHA, q, rg * g_h[q]);
       }
     }
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(2, DX_FIRST_POLL_DELAY)>(X + xl.rha, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(2);
     {
@@ -1055,7 +1087,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     }
 #pragma unroll
     for (int q = 0; q < RL; ++q) g_h[q] = st[erow[q] * DXS_LD + DXS_H1 + en];
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.ha, tag, st, DXS_HATT, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(3, DX_FIRST_POLL_DELAY)>(X + xl.ha, tag, st, DXS_HATT, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(3);
     // ================= attention (rnn_wrappers.py:304-341) =================
@@ -1129,7 +1161,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
           float s = 0.f;
           if (j < T) {
             float v[NP];
-            dx_poll<NP, DX_POLL_DELAY_B>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
+            dx_poll<NP, DX_DLY(4, DX_POLL_DELAY_B)>(X + xl.sc + (size_t)(arow * Pc + part * NP) * T + j, (size_t)T, tag, v, rt);
 #pragma unroll
             for (int u = 0; u < NP; ++u) s += v[u];
           }
@@ -1180,7 +1212,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       dx_publish<WTC>(X + xl.ctx + arow * DX_W + asl * DC + tid, s, tag, rt);
       if (TAPE && a.tp_ctx && brow < a.B) a.tp_ctx[((size_t)brow * a.n + t) * a.ld_ctx + asl * DC + tid] = s;
     }
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(5, DX_FIRST_POLL_DELAY)>(X + xl.ctx, tag, st, DXS_CTX, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(6);
     // ================= concat projection folded into residual GRU 1 (rnn_wrappers.py:405-415; tacotron.py:166-172) =================
@@ -1208,7 +1240,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
       }
       DX_STAMP(13);
     }
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rh1, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(6, DX_FIRST_POLL_DELAY)>(X + xl.rh1, tag, st, DXS_T, 0, 0, tid, rt);
     DX_STAMP(14);
     __syncthreads();
     DX_STAMP(7);
@@ -1236,7 +1268,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     dxq_zero<RG>(g2p);
     dx_zero<1, RG>(g2c);
     if (G1_AHEAD) dxw_pair<DXR_G2H, RG>(WP, st + DXS_H2, lane, g2p);
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(7, DX_POLL_DELAY_B)>(X + xl.h1, tag, st, DXS_H1, 0, 0, tid, rt);
     dx_gather<RG, DX_W, false, DXS_LD, DX_NT, 0>(X + xl.o1, tag, st, DXS_OUT1, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(8);
@@ -1258,7 +1290,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         DX_TAPE(DXT_R2, q, rg); DX_TAPE(DXT_U2, q, g_u[q]); DX_TAPE(DXT_RH2, q, rg * g_h[q]);
       }
     }
-    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
+    dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(8, DX_FIRST_POLL_DELAY)>(X + xl.rh2, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(9);
     {
@@ -1278,7 +1310,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
     float p1a[1][RG];
     dx_zero<1, RG>(p1a);
     if (G1_AHEAD) dxw_single<DXR_P1C, RG>(WP, st + DXS_CTX, lane, p1a);
-    dx_gather<RG, DX_W, true, DXS_LD, DX_NT, DX_POLL_DELAY_B>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
+    dx_gather<RG, DX_W, true, DXS_LD, DX_NT, DX_DLY(9, DX_POLL_DELAY_B)>(X + xl.h2, tag, st, DXS_H2, DXS_OUT1, DXS_OUT2, tid, rt);
     __syncthreads();
     DX_STAMP(10);
     // ================= prenet layer 1 of step t+1 (composite: frame projection folded in, helpers.py:31) and the frame
@@ -1373,7 +1405,7 @@ __device__ __forceinline__ void dx_body(const DxArgs& a, float* dx_smem, int gro
         if (b < a.B) a.dbg[((size_t)t * a.B + b) * a.dbgw + q * DX_W + nn] = st[r * DXS_LD + off + nn];
       }
     }
-    if (t + 1 < a.n) dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_FIRST_POLL_DELAY>(X + xl.p1, tag, st, DXS_T, 0, 0, tid, rt);
+    if (t + 1 < a.n) dx_gather<RG, DX_W, false, DXS_LD, DX_NT, DX_DLY(10, DX_FIRST_POLL_DELAY)>(X + xl.p1, tag, st, DXS_T, 0, 0, tid, rt);
     __syncthreads();
     DX_STAMP(11);
   }
@@ -1390,6 +1422,9 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const int group = __builtin_amdgcn_readfirstlane(ictl[0]);
   const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
   DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
+#ifdef DX_DLY_RT
+  for (int i = 0; i < 12; ++i) rt.dly[i] = g_dx_dly[i];
+#endif
   if (__builtin_amdgcn_readfirstlane((int)rt.wt)) dx_body<RG, TAPE, MAN, AW, PD, true, TRACE>(a, dx_smem, group, member, rt);
   else dx_body<RG, TAPE, MAN, AW, PD, false, TRACE>(a, dx_smem, group, member, rt);
 }

@@ -1791,6 +1791,15 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
                      unsigned long long* xbuf, unsigned* dxctl, float* rowbias, const float* h_att0, const float* h10, const float* h20,
                      const DxArgs* tape = nullptr) {
   ChipTurn turn(m->device, st);
+#ifdef DX_DLY_RT
+  {   // A/B build: the eleven first-poll sleeps (units of 64 clocks) from TACO_DX_DLY = "a,b,c,..." (sites 0..10 of taco_decoder_xcd.h); eager launches only
+    int d[16]; const int dflt[11] = {DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY,
+                                     DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY};
+    for (int i = 0; i < 16; ++i) d[i] = i < 11 ? dx_site_delay(i, dflt[i]) : 0;
+    if (const char* e = getenv("TACO_DX_DLY")) { int i = 0; const char* p = e; while (*p && i < 11) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dx_dly), d, sizeof d));
+  }
+#endif
   const int RG = dx_rows_per_group(m, B);
   DxArgs a; memset(&a, 0, sizeof a);
   if (tape) a = *tape;
@@ -1854,6 +1863,14 @@ static bool dbx_usable(const taco_model* m, int B, int T_in) {
 }
 static int dbx_launch(const taco_model* m, hipStream_t st, DbArgs a, int B, int T_in, int n, unsigned long long* xbuf, unsigned* dxctl) {
   ChipTurn turn(m->device, st);
+#ifdef DX_DLY_RT
+  {   // A/B build: the twelve first-poll sleeps of the backward loop from TACO_DB_DLY (sites 0..11 of taco_decoder_bwd_xcd.h)
+    int d[16];
+    for (int i = 0; i < 16; ++i) d[i] = i < 12 ? db_site_delay(i) : 0;
+    if (const char* e = getenv("TACO_DB_DLY")) { int i = 0; const char* p = e; while (*p && i < 12) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_db_dly), d, sizeof d));
+  }
+#endif
   const int RG = dx_rows_per_group(m, B);
   a.wpack = AP(m, m->dbx_pack);
   a.att_v = AP(m, m->att_v); a.att_b = AP(m, m->att_b); a.score_bias = AP(m, m->att_sb);
