@@ -521,16 +521,17 @@ __device__ __forceinline__ void dxs_reduce(const float (&a)[NC][RG], float (&out
 #ifndef DX_DLY_TUNED
 #define DX_DLY_TUNED 1
 #endif
-__host__ __device__ constexpr int dx_site_delay(int site, int dflt) {
-  //                      p2 p3 rha ha sc ctx rh1 h1 rh2 h2 p1
-  constexpr int tuned[11] = {4, 5, 6, 5, 0, 0, 5, 5, 0, 4, 0};
-  return DX_DLY_TUNED ? tuned[site] : dflt;
+__host__ __device__ constexpr int dx_site_delay(int site, int dflt, int RG = 4) {
+  //                          p2 p3 rha ha sc ctx rh1 h1 rh2 h2 p1
+  constexpr int tuned4[11] = {4, 5, 6, 5, 0, 0, 5, 5, 0, 4, 0};      // swept at C2 (four rows per group); also serves one and two rows (C1 / C5 got faster with it)
+  constexpr int tuned8[11] = {7, 5, 3, 5, 0, 6, 5, 6, 4, 6, 2};      // swept on a 64-row pass (eight rows per group: longer producer phases): 1972 (all 5) / 1980 (the table above) -> 1940 us per call
+  return DX_DLY_TUNED ? (RG == 8 ? tuned8[site] : tuned4[site]) : dflt;
 }
 #ifdef DX_DLY_RT
 __constant__ int g_dx_dly[16];
 #define DX_DLY(site, dflt) (100 + (site))
 #else
-#define DX_DLY(site, dflt) dx_site_delay(site, dflt)
+#define DX_DLY(site, dflt) dx_site_delay(site, dflt, RG)
 #endif
 struct DxRt {     // run-time state of a thread
   dx_gu32* err; bool wt; bool dead;

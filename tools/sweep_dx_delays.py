@@ -22,6 +22,7 @@ def main():
     passes = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     torch.cuda.set_device(0)
     B, T_in, r, n, ns, mt = WORKLOADS["C2"]
+    B = int(os.environ.get("SWEEP_ROWS", B))          # 64: the eight-rows-per-group instantiation of a 64-row pass
     hp = taco_amd.hparams.copy(max_iters=n, reduction_factor=r, model_type=mt)
     model = taco_amd.create_model(hp)
     model.load_weights(taco_amd.weights.random_weights(hp, ns, seed=1234))
