@@ -528,7 +528,7 @@ __host__ __device__ constexpr int dx_site_delay(int site, int dflt, int RG = 4) 
   return DX_DLY_TUNED ? (RG == 8 ? tuned8[site] : tuned4[site]) : dflt;
 }
 #ifdef DX_DLY_RT
-__constant__ int g_dx_dly[16];
+__constant__ int g_dx_dly[32];      // [0..10]: waves 0-3, [16..26]: waves 4-7 (sweep of a per-half table)
 #define DX_DLY(site, dflt) (100 + (site))
 #else
 #define DX_DLY(site, dflt) dx_site_delay(site, dflt, RG)
@@ -536,7 +536,7 @@ __constant__ int g_dx_dly[16];
 struct DxRt {     // run-time state of a thread
   dx_gu32* err; bool wt; bool dead;
 #ifdef DX_DLY_RT
-  int dly[12];
+  int dly[12];       // this wave's table (waves 0-3 / 4-7 may differ in the A/B build)
 #endif
 };
 template <int DLY>
@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(DX_NT) void k_decoder_xcd(const DxArgs a_in) {
   const int member = __builtin_amdgcn_readfirstlane(ictl[1]);
   DxRt rt; rt.err = errw; rt.wt = ictl[2] != 0; rt.dead = ictl[3] != 0;
 #ifdef DX_DLY_RT
-  for (int i = 0; i < 12; ++i) rt.dly[i] = g_dx_dly[i];
+  { const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) * 16; for (int i = 0; i < 12; ++i) rt.dly[i] = g_dx_dly[half + i]; }
 #endif
   if (__builtin_amdgcn_readfirstlane((int)rt.wt)) dx_body<RG, TAPE, MAN, AW, PD, true, TRACE>(a, dx_smem, group, member, rt);
   else dx_body<RG, TAPE, MAN, AW, PD, false, TRACE>(a, dx_smem, group, member, rt);

@@ -1793,10 +1793,12 @@ static int dx_launch(const taco_model* m, hipStream_t st, const float* enc_out, 
   ChipTurn turn(m->device, st);
 #ifdef DX_DLY_RT
   {   // A/B build: the eleven first-poll sleeps (units of 64 clocks) from TACO_DX_DLY = "a,b,c,..." (sites 0..10 of taco_decoder_xcd.h); eager launches only
-    int d[16]; const int dflt[11] = {DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY,
+    int d[32]; const int dflt[11] = {DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY,
                                      DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY, DX_POLL_DELAY_B, DX_FIRST_POLL_DELAY};
-    for (int i = 0; i < 16; ++i) d[i] = i < 11 ? dx_site_delay(i, dflt[i]) : 0;
-    if (const char* e = getenv("TACO_DX_DLY")) { int i = 0; const char* p = e; while (*p && i < 11) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    const int RGs = dx_rows_per_group(m, B);
+    for (int i = 0; i < 32; ++i) d[i] = (i & 15) < 11 ? dx_site_delay(i & 15, dflt[i & 15], RGs) : 0;
+    if (const char* e = getenv("TACO_DX_DLY")) { int i = 0; const char* p = e; while (*p && i < 11) { d[i] = d[16 + i] = atoi(p); ++i; while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    if (const char* e = getenv("TACO_DX_DLY_B")) { int i = 0; const char* p = e; while (*p && i < 11) { d[16 + i] = atoi(p); ++i; while (*p && *p != ',') ++p; if (*p == ',') ++p; } }      // waves 4-7
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dx_dly), d, sizeof d));
   }
 #endif

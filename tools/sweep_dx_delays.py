@@ -15,6 +15,8 @@ import torch
 import taco_amd
 from bench import WORKLOADS
 
+START = [int(x) for x in os.environ.get("SWEEP_START", "5,5,5,5,5,5,5,5,5,5,5").split(",")]
+HALF_B = os.environ.get("SWEEP_HALF_B", "0") == "1"      # sweep the sleeps of waves 4-7 (the second wave of every SIMD) on their own
 SITES = ["p2", "p3 (3-layer prenet only)", "r*h att", "h att", "partial scores", "context", "r*h 1", "h1", "r*h 2", "h2", "prenet 1 of the next step"]
 
 
@@ -35,7 +37,11 @@ def main():
     model.set_decoder_engine(1, 0)
 
     def measure(d, reps=20, rounds=3):
-        os.environ["TACO_DX_DLY"] = ",".join(str(x) for x in d)
+        if HALF_B:      # the table of waves 4-7 alone moves; waves 0-3 keep SWEEP_START
+            os.environ["TACO_DX_DLY"] = ",".join(str(x) for x in START)
+            os.environ["TACO_DX_DLY_B"] = ",".join(str(x) for x in d)
+        else:
+            os.environ["TACO_DX_DLY"] = ",".join(str(x) for x in d)
         model.decoder(enc, n, None)
         torch.cuda.synchronize()
         ts = []
@@ -49,7 +55,7 @@ def main():
             ts.append(e0.elapsed_time(e1) / reps * 1e3)
         return float(np.median(ts))
 
-    cur = [int(x) for x in os.environ.get("SWEEP_START", "5,5,5,5,5,5,5,5,5,5,5").split(",")]
+    cur = list(START)
     best = measure(cur)
     print("start %s: %.1f us per decoder call (%.3f us per step)" % (cur, best, best / n))
     for v in (0, 3, 4, 6, 7):
