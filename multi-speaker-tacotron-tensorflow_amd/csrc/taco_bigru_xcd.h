@@ -567,6 +567,24 @@ __device__ __forceinline__ void go_reduce(const float (&v)[UPW * NG], float (&ou
 #ifndef GO_DYN
 #define GO_DYN 0           // A/B: 1 = the protocol test of every publish and the tracer test of every stamp at run time, as in k_bigru_duo / k_decoder_xcd
 #endif
+// A/B build -DGO_KNOB_RT (tools/sweep_go_knobs.py): per phase (gates F, gates B, cand F, cand B) the place of the second request (0: behind the
+// products -- the production code --, 1: behind the reduction, 2: none), a sleep in front of the first request, a sleep in front of the
+// fallback poll of the collect behind the phase; from a constant table the host fills from TACO_GO_KNOB before each launch.
+// tools/sweep_go_knobs.py on that build (profiles/r06_sweep_go_knobs.txt, op-level call at the C2 post-net shape): every sleep loses (64 clocks in
+// front of a request cost 8-16 us per call), the second request belongs behind the products where it is -- except in the gates B phase, where
+// NONE is better (937 -> 929 us per call, both passes): the r*h(F) vector it asks for was published a whole phase + barrier earlier and the
+// first request already has it.  GO_KNOB_TUNED = 0: the second request in all four phases, as rounds 5-6.
+#ifndef GO_KNOB_TUNED
+#define GO_KNOB_TUNED 1
+#endif
+__host__ __device__ constexpr int go_knob_default(int i) { return (GO_KNOB_TUNED && i == 1) ? 2 : 0; }
+#ifdef GO_KNOB_RT
+__constant__ int g_go_knob[16];
+#define GO_KNOB(i) kn[i]
+#else
+#define GO_KNOB(i) go_knob_default(i)
+#endif
+__device__ __forceinline__ void go_knob_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }
 template <bool WT>
 __device__ __forceinline__ void go_publish(dx_gu64* p, float v, unsigned tag) {
   const unsigned long long g = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
@@ -586,6 +604,10 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
   const int row = place * UPW + (slot % UPW), member = slot / UPW;
   if (row >= a.B || member >= MB) return;
   const int T = a.T;
+#ifdef GO_KNOB_RT
+  int kn[12];
+  for (int q = 0; q < 12; ++q) kn[q] = __builtin_amdgcn_readfirstlane(g_go_knob[q]);
+#endif
   const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
   const bool tracer = (TRACE || GO_DYN) && a.trace && row == 0 && member == 0 && tid == 0;
 
@@ -652,12 +674,13 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
     auto request2 = [&](const dx_gu64* Xv, int D) {
       if ((wave >> 2) == D) pre2 = __hip_atomic_load(Xv + (tid & 255), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
+    int csite = 0;
     auto collect = [&](const dx_gu64* Xv, unsigned tg, float* dst, int D) {
       if ((wave >> 2) == D) {
         float v[1];
         if ((unsigned)(pre2 >> 32) == tg) v[0] = __uint_as_float((unsigned)pre2);
         else if ((unsigned)(pre >> 32) == tg) v[0] = __uint_as_float((unsigned)pre);
-        else dx_poll<1>(Xv + (tid & 255), 0, tg, v, rt);       // a producer was late: the ordinary bounded poll
+        else { go_knob_sleep(GO_KNOB(8 + csite)); dx_poll<1>(Xv + (tid & 255), 0, tg, v, rt); }       // a producer was late: the ordinary bounded poll
         dst[tid & 255] = v[0];
       }
     };
@@ -678,11 +701,12 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
       for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
 #pragma unroll
       for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
-      if (GO_REQ2 && Xn) request2(Xn, Dn);
+      if (GO_REQ2 && Xn && GO_KNOB(D) == 0) request2(Xn, Dn);
       float v[2 * UPW], sm[2];
 #pragma unroll
       for (int i = 0; i < UPW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
       go_reduce<UPW, 2>(v, sm);
+      if (GO_REQ2 && Xn && GO_KNOB(D) == 1) request2(Xn, Dn);
       const float rr = dx_sigmoid_fast(sm[0] + x0[D][0]);
       gv[D] = dx_sigmoid_fast(sm[1] + x0[D][1]);
       float rh = rr * hv[D];
@@ -715,8 +739,9 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
         acc = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.w}, (taco_f32x2){W[R0 + 2], W[R0 + 3]}, acc);
         v[0] = acc.x + acc.y;
       }
-      if (GO_REQ2 && Xn) request2(Xn, Dn);
+      if (GO_REQ2 && Xn && GO_KNOB(2 + D) == 0) request2(Xn, Dn);
       go_reduce<UPW, 1>(v, sm);
+      if (GO_REQ2 && Xn && GO_KNOB(2 + D) == 1) request2(Xn, Dn);
       const float cc = taco_tanh_fast(sm[0] + x0[D][2]);
       float blend = gv[D] * hv[D] + (1.f - gv[D]) * cc;
       DX_PIN(blend);
@@ -737,28 +762,36 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
     // (the load for h'(B) of the previous step was requested at the end of that step)
     gates(F{}, s > 0 ? X_hB : nullptr, 1);
     GO_STAMP(1);
+    csite = 0;
     if (s > 0) collect(X_hB, tag - 1u, hs + H, 1);
     __syncthreads();
     GO_STAMP(2);
+    go_knob_sleep(GO_KNOB(4 + 1));
     request(X_rhF, 0);
     gates(Bk{}, X_rhF, 0);
     GO_STAMP(3);
+    csite = 1;
     collect(X_rhF, tag, xs, 0);
     __syncthreads();
     GO_STAMP(4);
+    go_knob_sleep(GO_KNOB(4 + 2));
     request(X_rhB, 1);
     cand(F{}, X_rhB, 1);
     GO_STAMP(5);
+    csite = 2;
     collect(X_rhB, tag, xs + H, 1);
     __syncthreads();
     GO_STAMP(6);
+    go_knob_sleep(GO_KNOB(4 + 3));
     request(X_hF, 0);
     cand(Bk{}, X_hF, 0);
     GO_STAMP(7);
+    csite = 3;
     collect(X_hF, tag, hs, 0);
     if (sb == GX_BLK - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's part of the next ring slot has landed
     __syncthreads();
     GO_STAMP(8);
+    go_knob_sleep(GO_KNOB(4 + 0));
     request(X_hB, 1);
   }
 }

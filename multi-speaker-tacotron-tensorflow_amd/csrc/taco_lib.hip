@@ -1259,6 +1259,13 @@ static int oct_bwd_launch(const taco_model* m, hipStream_t st, const Cbhg& c, in
 static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UPW, int B, int T, const float* xproj, const int* lengths, const float* init_state,
                       float* out, float* gsave, unsigned long long* gxbuf, unsigned* gxctl) {
   ChipTurn turn(m->device, st);
+#ifdef GO_KNOB_RT
+  {   // A/B build: the twelve knobs of k_bigru_oct from TACO_GO_KNOB (taco_bigru_xcd.h); eager launches only
+    int d[16]; for (int i = 0; i < 16; ++i) d[i] = i < 12 ? go_knob_default(i) : 0;
+    if (const char* e = getenv("TACO_GO_KNOB")) { int i = 0; const char* p = e; while (*p && i < 12) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_go_knob), d, sizeof d));
+  }
+#endif
   GdArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.go_pack[UPW == 4 ? 2 : UPW == 2 ? 1 : 0]); a.xproj = xproj; a.h0 = init_state; a.lengths = lengths; a.out = out; a.gsave = gsave;
   a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.trace = (m->trace_on && m->d_trace && !gsave) ? m->d_trace + DX_TRACE_STEPS * DX_TRACE_SLOTS : nullptr;
