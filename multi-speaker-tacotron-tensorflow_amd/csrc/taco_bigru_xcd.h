@@ -584,6 +584,15 @@ __constant__ int g_go_knob[16];
 #else
 #define GO_KNOB(i) go_knob_default(i)
 #endif
+// the backward scan's four second requests (phase_ca F / B, phase_b F / B): entries 12..15 of the same table (1 = none).  All sixteen settings,
+// interleaved, on the whole C4-shard forward + backward (tools/sweep_train_knobs.py, profiles/r06_sweep_train_knobs.txt): none in phase_ca F and
+// phase_b B is 14 us better than all four (11 412 -> 11 398 us per pass), none in phase_b F costs 20 us.
+__host__ __device__ constexpr int gob_knob_default(int i) { return (GO_KNOB_TUNED && (i == 0 || i == 3)) ? 1 : 0; }
+#ifdef GO_KNOB_RT
+#define GOB_KNOB(i) kb[i]
+#else
+#define GOB_KNOB(i) gob_knob_default(i)
+#endif
 __device__ __forceinline__ void go_knob_sleep(int n) { for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1); }
 template <bool WT>
 __device__ __forceinline__ void go_publish(dx_gu64* p, float v, unsigned tag) {
@@ -1114,6 +1123,10 @@ __device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int pl
   const int row = place * UPW + (slot % UPW), member = slot / UPW;
   if (row >= a.B || member >= MB) return;
   const int T = a.T;
+#ifdef GO_KNOB_RT
+  int kb[4];
+  for (int q = 0; q < 4; ++q) kb[q] = __builtin_amdgcn_readfirstlane(g_go_knob[12 + q]);
+#endif
   const int L = __builtin_amdgcn_readfirstlane(a.lengths ? a.lengths[row] : T);
 
   float W[NREG];
@@ -1202,7 +1215,7 @@ __device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int pl
         for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.z, gu.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
 #pragma unroll
         for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.w, gu.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
-        if (Xn) request2(Xn, nn, Dn);
+        if (Xn && GOB_KNOB(D) == 0) request2(Xn, nn, Dn);
         float v[UPW], sm[1];
 #pragma unroll
         for (int i = 0; i < UPW; ++i) v[i] = acc[i].x + acc[i].y;
@@ -1255,7 +1268,7 @@ __device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int pl
       for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.z, hx.z}, (taco_f32x2){W[R0 + 8 * i + 2], W[R0 + 8 * i + 6]}, acc[i]);
 #pragma unroll
       for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
-      if (Xn) request2(Xn, nn, Dn);
+      if (Xn && GOB_KNOB(2 + D) == 0) request2(Xn, nn, Dn);
       float v[UPW], sm[1];
 #pragma unroll
       for (int i = 0; i < UPW / 2; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }

@@ -1248,6 +1248,13 @@ static bool oct_bwd_usable(const taco_model* m, const Cbhg& c, int B, int T) { r
 static int oct_bwd_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int B, int T, const float* dout, const float* out, const float* gsave,
                           const float* h0, const int* lengths, float* dg, float* rh, float* dh0, unsigned long long* gxbuf, unsigned* gxctl) {
   ChipTurn turn(m->device, st);
+#ifdef GO_KNOB_RT
+  {   // A/B build: entries 12..15 of TACO_GO_KNOB are the backward scan's four second requests
+    int d[16]; for (int i = 0; i < 16; ++i) d[i] = i < 12 ? go_knob_default(i) : gob_knob_default(i - 12);
+    if (const char* e = getenv("TACO_GO_KNOB")) { int i = 0; const char* p = e; while (*p && i < 16) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_go_knob), d, sizeof d));
+  }
+#endif
   GbArgs a; memset(&a, 0, sizeof a);
   a.wpack = AP(m, c.gob_pack); a.dout = dout; a.out = out; a.gsave = gsave; a.h0 = h0; a.lengths = lengths; a.dg = dg; a.rh = rh; a.dh0 = dh0;
   a.xbuf = gxbuf; a.ctl = gxctl; a.err = m->d_err; a.B = B; a.T = T; a.force_wt = m->dx_mode == 2 ? 1 : 0;
@@ -1261,8 +1268,8 @@ static int oct_launch(const taco_model* m, hipStream_t st, const Cbhg& c, int UP
   ChipTurn turn(m->device, st);
 #ifdef GO_KNOB_RT
   {   // A/B build: the twelve knobs of k_bigru_oct from TACO_GO_KNOB (taco_bigru_xcd.h); eager launches only
-    int d[16]; for (int i = 0; i < 16; ++i) d[i] = i < 12 ? go_knob_default(i) : 0;
-    if (const char* e = getenv("TACO_GO_KNOB")) { int i = 0; const char* p = e; while (*p && i < 12) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
+    int d[16]; for (int i = 0; i < 16; ++i) d[i] = i < 12 ? go_knob_default(i) : gob_knob_default(i - 12);
+    if (const char* e = getenv("TACO_GO_KNOB")) { int i = 0; const char* p = e; while (*p && i < 16) { d[i++] = atoi(p); while (*p && *p != ',') ++p; if (*p == ',') ++p; } }
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_go_knob), d, sizeof d));
   }
 #endif
