@@ -585,9 +585,11 @@ __constant__ int g_go_knob[16];
 #define GO_KNOB(i) go_knob_default(i)
 #endif
 // the backward scan's four second requests (phase_ca F / B, phase_b F / B): entries 12..15 of the same table (1 = none).  All sixteen settings,
-// interleaved, on the whole C4-shard forward + backward (tools/sweep_train_knobs.py, profiles/r06_sweep_train_knobs.txt): none in phase_ca F and
-// phase_b B is 14 us better than all four (11 412 -> 11 398 us per pass), none in phase_b F costs 20 us.
-__host__ __device__ constexpr int gob_knob_default(int i) { return (GO_KNOB_TUNED && (i == 0 || i == 3)) ? 1 : 0; }
+// interleaved, on the whole C4-shard forward + backward with the gradients checked to the bit (tools/sweep_train_knobs.py,
+// profiles/r06_sweep_train_knobs.txt): keeping all four is best (dropping any costs 10-30 us per pass).  (A first sweep had shown a gain of
+// 14 us for two of them: with a request dropped, the previous phase's answer -- SAME step tag -- passed for the gather's own and the fallback
+// poll never ran; the GPU suite caught it, a dropped request now clears the stale answer, and the tool compares gradients.)
+__host__ __device__ constexpr int gob_knob_default(int i) { (void)i; return 0; }
 #ifdef GO_KNOB_RT
 #define GOB_KNOB(i) kb[i]
 #else
@@ -711,6 +713,7 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
 #pragma unroll
       for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
       if (GO_REQ2 && Xn && GO_KNOB(D) == 0) request2(Xn, Dn);
+      else if (GO_KNOB(D) == 2) pre2 = 0ull;      // no second request in this phase: the previous phase's answer must not pass for this one (its tag can be the same)
       float v[2 * UPW], sm[2];
 #pragma unroll
       for (int i = 0; i < UPW; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }
@@ -749,6 +752,7 @@ __device__ __forceinline__ void go_body(const GdArgs& a, float* gx_smem, int pla
         v[0] = acc.x + acc.y;
       }
       if (GO_REQ2 && Xn && GO_KNOB(2 + D) == 0) request2(Xn, Dn);
+      else if (GO_KNOB(2 + D) == 2) pre2 = 0ull;
       go_reduce<UPW, 1>(v, sm);
       if (GO_REQ2 && Xn && GO_KNOB(2 + D) == 1) request2(Xn, Dn);
       const float cc = taco_tanh_fast(sm[0] + x0[D][2]);
@@ -1216,6 +1220,7 @@ __device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int pl
 #pragma unroll
         for (int i = 0; i < UPW; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){gr.w, gu.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
         if (Xn && GOB_KNOB(D) == 0) request2(Xn, nn, Dn);
+        else pre2 = 0ull;      // no second request: a stale answer of the previous phase (the same step tag) must not pass for this gather
         float v[UPW], sm[1];
 #pragma unroll
         for (int i = 0; i < UPW; ++i) v[i] = acc[i].x + acc[i].y;
@@ -1269,6 +1274,7 @@ __device__ __forceinline__ void gob_body(const GbArgs& a, float* gx_smem, int pl
 #pragma unroll
       for (int i = 0; i < UPW / 2; ++i) acc[i] = __builtin_elementwise_fma((taco_f32x2){hx.w, hx.w}, (taco_f32x2){W[R0 + 8 * i + 3], W[R0 + 8 * i + 7]}, acc[i]);
       if (Xn && GOB_KNOB(2 + D) == 0) request2(Xn, nn, Dn);
+      else pre2 = 0ull;
       float v[UPW], sm[1];
 #pragma unroll
       for (int i = 0; i < UPW / 2; ++i) { v[2 * i] = acc[i].x; v[2 * i + 1] = acc[i].y; }

@@ -32,6 +32,15 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
+    # every setting must give the SAME gradients (ordered reductions: to the bit) -- a second request that is dropped must not let a stale answer pass
+    os.environ["TACO_GO_KNOB"] = fwd + ",0,0,0,0"
+    tr.forward_backward(ids, L, mt, lt, None); torch.cuda.synchronize()
+    ref = tr.grads.clone()
+    for k in settings:
+        os.environ["TACO_GO_KNOB"] = fwd + "," + ",".join(str(v) for v in k)
+        tr.forward_backward(ids, L, mt, lt, None); torch.cuda.synchronize()
+        assert torch.equal(tr.grads, ref), ("gradients differ with knobs", k)
+    print("all %d settings give bit-identical gradients" % len(settings))
     for r in range(ROUNDS):
         for k in (settings if r % 2 == 0 else settings[::-1]):
             times[k].append(run(k))
